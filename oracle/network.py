@@ -1,0 +1,116 @@
+"""CPU oracle: network-level composition (CodepsNet "train" forward and the adaptation step).
+TEST INFRASTRUCTURE.  Follows codeps/online_adap.py:76-139 ("train"), :291-436 ("adapt") with the
+dead work removed (encoder features of frames t-1/t+1 are never consumed when
+flow_head is None, algos/depth.py:389-393).  Pinned by tests/golden/network_{train,adapt}.npz.
+
+``sds`` = dict of per-module state dicts keyed like CodepsNet.get_state_dict
+(codeps/online_adap.py:438-455); encoder dicts carry torchvision keys without the ``encoder.`` prefix.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import heads, losses, panoptic, resnet
+
+THINGS = [9, 10, 11, 12, 13]                   # datasets/dataset.py:212-229 (label mode "codeps")
+
+
+def _strip(sd):
+    return {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
+
+
+def encode(sd, x, num_layers, training=False):
+    return resnet.features(_strip(sd), x, num_layers, training)
+
+
+def depth_forward(sds, cfg, rgb, training_pose=False):
+    """algos/depth.py:374-423 (_forward) without flow head.  rgb = {0,-1,1: [B,3,H,W]}."""
+    feats = encode(sds["backbone_po_depth"], rgb[0], cfg["nof_layers"], cfg.get("train_encoder", False))
+    depth, disp = heads.depth_head(sds["depth_head"], feats)
+    pf = encode(sds["backbone_pose_sflow"], torch.cat([rgb[-1], rgb[0]], 1), cfg.get("pose_layers", 18),
+                training_pose)
+    t0 = heads.pose_head(sds["pose_head"], pf, invert_pose=True)
+    pf = encode(sds["backbone_pose_sflow"], torch.cat([rgb[0], rgb[1]], 1), cfg.get("pose_layers", 18),
+                training_pose)
+    t1 = heads.pose_head(sds["pose_head"], pf)
+    return feats, depth, disp, (t0, t1)
+
+
+def train_forward(sds, cfg, sample, noise=None, do_panoptic=True):
+    """-> (losses, result) like CodepsNet.forward(mode="train") (codeps/online_adap.py:76-139,216-268)."""
+    rgb = sample["rgb"]
+    feats, depth, disp, poses = depth_forward(sds, cfg, rgb)
+    out, res = OrderedDict(), OrderedDict()
+    out["depth_recon"] = losses.reconstruction_loss(sample["camera_model"], (rgb[0], rgb[-1], rgb[1]),
+                                                    depth, poses, cfg.get("num_scales", 5), noise)
+    out["depth_smth"] = losses.smoothness_loss(rgb[0], disp)
+    probs = heads.semantic_head(sds["semantic_head"], feats, cfg.get("use_guda_fusion", True))
+    out["semantic"] = losses.semantic_loss(probs, sample["semantic"], sample["semantic_weights"],
+                                           cfg.get("class_weights"), cfg.get("top_k", 0.2))
+    sem_pred = probs.argmax(1).to(torch.uint8)
+    center, offset, thing = heads.instance_head(sds["instance_head"], feats, cfg.get("use_thing_mask", False),
+                                                cfg.get("train_instance_bn", False))
+    out["center"] = losses.center_loss(center, sample["center"])
+    out["offset"] = losses.offset_loss(offset, sample["offset"])
+    if thing is not None:
+        out["thing_mask"] = losses.binary_mask_loss(thing, sample["thing_mask"].squeeze(1))
+        res["thing_mask"] = thing.argmax(1).to(torch.uint8)
+    res.update(depth=depth, semantic=sem_pred, center=center, offset=offset)
+    if do_panoptic:
+        pan, inst, _ = panoptic.panoptic_fusion(sem_pred.numpy(), center.detach().numpy(),
+                                                offset.detach().numpy(), THINGS)
+        res["panoptic"], res["instance"] = torch.from_numpy(pan), torch.from_numpy(inst)
+    return out, res
+
+
+def adapt_forward(sds, cfg, data, noise=None):
+    """Adaptation-step losses (codeps/online_adap.py:291-436 with algos/depth.py:507-577,
+    algos/semantic_seg.py:200-249).  data: {"target","target_replay","source": sample dicts,
+    "<x>mixup": pre-mixed sample dicts}.  Depth losses are the image-count weighted mean over
+    source/target/target_replay; the rolling "car not moving" rule (depth.py:537-558) is host state
+    and not part of this function.  ``noise``: {key: [per-scale tensors]} or None."""
+    out, res = OrderedDict(), OrderedDict()
+    recon, smth, n = {}, {}, {}
+    feats = {}
+    for key in ("source", "target", "target_replay"):
+        if key not in data:
+            continue
+        rgb = data[key]["rgb"]
+        feats[key], depth, disp, poses = depth_forward(sds, cfg, rgb, cfg.get("train_pose_bn", False))
+        recon[key] = losses.reconstruction_loss(data[key]["camera_model"], (rgb[0], rgb[-1], rgb[1]), depth,
+                                                poses, cfg.get("num_scales", 5),
+                                                None if noise is None else noise[key])
+        smth[key] = losses.smoothness_loss(rgb[0], disp)
+        n[key] = rgb[0].shape[0]
+        if key == "target":
+            res["depth"], res["T"] = depth, poses
+    tot = sum(n.values())
+    out["depth_recon"] = sum(recon[k] * n[k] for k in recon) / tot
+    out["depth_smth"] = sum(smth[k] * n[k] for k in smth) / tot
+    sem = lambda f: heads.semantic_head(sds["semantic_head"], f, cfg.get("use_guda_fusion", True))  # noqa: E731
+    res["semantic"] = sem(feats["target"]).argmax(1)
+    for key, item in data.items():
+        if key.endswith("mixup"):
+            f = encode(sds["backbone_po_depth"], item["rgb"][0], cfg["nof_layers"])
+            out["semantic_" + key] = losses.semantic_loss(sem(f), item["semantic"],
+                                                          torch.ones_like(item["semantic"]),
+                                                          cfg.get("class_weights"), cfg.get("top_k", 0.2))
+    if "source" in data:
+        out["semantic_source"] = losses.semantic_loss(sem(feats["source"]), data["source"]["semantic"],
+                                                      data["source"]["semantic_weights"],
+                                                      cfg.get("class_weights"), cfg.get("top_k", 0.2))
+    return out, res
+
+
+def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults used by misc/train_utils.py:194-201 (no weight decay, no amsgrad)."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    p.addcdiv_(m, (v.sqrt() / np.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+
+def ema_update(p_ema, p, alpha):
+    """codeps/online_adap.py:279-289."""
+    p_ema.copy_(alpha * p_ema + (1 - alpha) * p)

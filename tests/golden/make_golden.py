@@ -1,0 +1,372 @@
+"""Generate golden vectors by running the REAL CoDEPS reference on CPU (development container only).
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+The reference is imported from /root/reference through tests/golden/_ref_import.py (placeholders for
+its missing third-party deps).  Inputs come from tests/golden/inputs.py (seeded numpy), so the
+fixtures hold only seeds/shapes + the reference's outputs.  Nothing of the reference's source is
+stored.  The GPU box never runs this file.
+"""
+import json
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import _ref_import  # noqa: E402
+
+_ref_import.install()
+import inputs as gi  # noqa: E402
+
+torch.set_num_threads(1)
+
+from algos import (BinaryMaskLoss, CenterLoss, DepthAlgo, EdgeAwareSmoothnessLoss,  # noqa: E402
+                   InstanceSegAlgo, OffsetLoss, ReconstructionLoss, SemanticLoss, SemanticSegAlgo,
+                   SSIMLoss)
+from codeps.online_adap import CodepsNet  # noqa: E402
+from eval import DepthEvaluator, PanopticEvaluator, SemanticEvaluator  # noqa: E402
+from misc import CameraModel, ImageWarper  # noqa: E402
+from misc.image_warper import CoordinateWarper  # noqa: E402
+from models import DepthHead, InstanceHead, PoseHead, SemanticHead  # noqa: E402
+
+CPU = torch.device("cpu")
+R18 = np.array([64, 64, 128, 256, 512])
+R50 = np.array([64, 256, 512, 1024, 2048])
+THINGS = [9, 10, 11, 12, 13]
+STUFF = list(range(9))
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def grad_stats(module):
+    """[n_params, 2] float64 (sum, l2) of every parameter gradient, in named_parameters order."""
+    rows = []
+    for _n, p in module.named_parameters():
+        g = p.grad
+        rows.append([0.0, 0.0] if g is None else [g.double().sum().item(), g.double().norm().item()])
+    return np.array(rows)
+
+
+def cams(intr, w, h):
+    return [CameraModel.from_tensor(w, h, intr[i]) for i in range(intr.shape[0])]
+
+
+# ------------------------------------------------------------------------------------------ heads
+def golden_heads(tag, num_ch_enc, b, h, w, seed, full=True):
+    feats = gi.feature_pyramid(num_ch_enc, b, h, w, seed)
+    res = {"meta": json.dumps({"num_ch_enc": [int(c) for c in num_ch_enc], "b": b, "h": h, "w": w,
+                               "seed": seed})}
+
+    def run(name, module, fwd, pseed, train=False):
+        sd = gi.fill_state_dict(gi.shapes_of(module.state_dict()), pseed)
+        module.load_state_dict(sd)
+        module.train(train)
+        res[name + "_keys"] = json.dumps([[k, list(v)] for k, v in gi.shapes_of(module.state_dict()).items()])
+        fs = [f.clone().requires_grad_(True) for f in feats]
+        outs = fwd(module, fs)
+        loss = 0
+        for i, o in enumerate(outs):
+            res[f"{name}_out{i}"] = o
+            loss = loss + (o * gi.normal(tuple(o.shape), pseed * 7 + i)).sum()
+        loss.backward()
+        res[name + "_pgrad_stats"] = grad_stats(module)
+        for i, f in enumerate(fs):
+            if f.grad is not None:
+                res[f"{name}_dfeat{i}"] = f.grad
+        if train:   # BN running stats after one train-mode forward
+            res[name + "_bn_stats"] = np.concatenate(
+                [v.numpy().ravel() for k, v in module.state_dict().items()
+                 if k.endswith("running_mean") or k.endswith("running_var")])
+        return module
+
+    m = run("depth", DepthHead(num_ch_enc, True), lambda m_, f: m_(f, return_disparity=True), seed + 1)
+    res["depth_dw_disp"] = m.dispconvs["0"][1].weight.grad
+    res["depth_dw_up10"] = m.upconvs_1["0"][0].weight.grad
+    res["depth_db_up04"] = m.upconvs_0["4"][0].bias.grad
+    m = run("sem", SemanticHead(num_ch_enc, 14, True, True), lambda m_, f: [m_(f)], seed + 2)
+    res["sem_dw_guda"] = m.semconv_guda.weight.grad
+    if not full:
+        save(f"heads_{tag}", **res)
+        return
+    run("semng", SemanticHead(num_ch_enc, 14, True, False), lambda m_, f: [m_(f)], seed + 3)
+    run("inst", InstanceHead(num_ch_enc, True), lambda m_, f: list(m_(f)), seed + 4)
+    run("insttrain", InstanceHead(num_ch_enc, True), lambda m_, f: list(m_(f)), seed + 4, train=True)
+    run("instnomask", InstanceHead(num_ch_enc, False), lambda m_, f: list(m_(f))[:2], seed + 5)
+    run("pose", PoseHead(R18, 1, 2), lambda m_, f: [m_(f, False)], seed + 6)
+    run("poseinv", PoseHead(R18, 1, 2), lambda m_, f: [m_(f, True)], seed + 6)
+    save(f"heads_{tag}", **res)
+
+
+# ------------------------------------------------------------------------------------------ geometry
+def golden_geometry(seed=11):
+    b, h, w = 2, 24, 40
+    intr = gi.intrinsics(b, h, w, seed)
+    cm = cams(intr, w, h)
+    res = {"meta": json.dumps({"b": b, "h": h, "w": w, "seed": seed})}
+    # camera model round trips (misc/camera_model.py)
+    sc = cm[0].get_scaled_model_image_size(w // 2, h // 2)
+    res["scaled_intr"] = np.array(list(sc.intrinsics.values()), np.float64)
+    u = torch.arange(w).float().expand(h, w).contiguous()
+    v = torch.arange(h).float().view(h, 1).expand(h, w).contiguous()
+    rx, ry, rz = cm[1].get_viewing_ray(u.clone(), v.clone())
+    res["ray"] = torch.stack([rx, ry, rz])
+    pu, pv = cm[1].get_image_point(rx * 5, ry * 5, rz * 5)
+    res["reproj"] = torch.stack([pu, pv])
+    # warp
+    depth = gi.depth_map(b, h, w, seed)
+    T = gi.pose(b, seed)
+    src = gi.smooth_image(b, h, w, seed + 1)
+    res["grid"] = CoordinateWarper(w, h, CPU)(cm, depth, T)
+    res["warped"] = ImageWarper(w, h, CPU)(cm, src, depth, T)
+    res["warped_identity"] = ImageWarper(w, h, CPU)(cm, src, depth, torch.eye(4).repeat(b, 1, 1))
+    # SSIM map
+    a, c = gi.smooth_image(b, h, w, seed + 2), gi.smooth_image(b, h, w, seed + 3)
+    res["ssim"] = SSIMLoss()(a, c)
+    res["ssim_self"] = SSIMLoss()(a, a)
+    save("geometry", **res)
+
+
+# ------------------------------------------------------------------------------------------ losses
+def golden_recon(tag, b, h, w, seed, num_scales=5):
+    intr = gi.intrinsics(b, h, w, seed)
+    imgs = gi.triplet(b, h, w, seed)
+    depth = gi.depth_map(b, h, w, seed).requires_grad_(True)
+    poses = [gi.pose(b, seed + 1).requires_grad_(True), gi.pose(b, seed + 2).requires_grad_(True)]
+    rec = ReconstructionLoss(w, h, SSIMLoss(), num_scales, CPU)
+    torch.manual_seed(1000 + seed)
+    loss = rec(cams(intr, w, h), imgs, depth, poses)
+    loss.backward()
+    # the noise the reference drew (same generator state, same order)
+    torch.manual_seed(1000 + seed)
+    noise = {f"noise{s}": torch.randn(b, 2, h // 2 ** s, w // 2 ** s) * .00001 for s in range(num_scales)}
+    disp = gi.uniform((b, 1, h, w), seed + 4, 0.01, 1.0).requires_grad_(True)
+    sm = EdgeAwareSmoothnessLoss()(imgs[0], disp)
+    sm.backward()
+    save(f"recon_{tag}", meta=json.dumps({"b": b, "h": h, "w": w, "seed": seed, "num_scales": num_scales}),
+         loss=loss, ddepth=depth.grad, dT0=poses[0].grad, dT1=poses[1].grad,
+         smooth=sm, ddisp=disp.grad, **noise)
+
+
+def golden_sem_inst_losses(seed=31):
+    b, h, w, c = 2, 24, 40, 14
+    logits = gi.normal((b, c, h, w), seed, 2.0)
+    probs = torch.softmax(logits, 1).requires_grad_(True)
+    target = gi.semantic_labels(b, h, w, seed, c)
+    pw = gi.pixel_weights(b, h, w, seed)
+    res = {"meta": json.dumps({"b": b, "h": h, "w": w, "c": c, "seed": seed})}
+    for name, topk in (("topk", 0.2), ("full", 1.0)):
+        sl = SemanticLoss(device=CPU, class_weights=[1.0] * c, top_k_percent_pixels=topk, ignore_labels=[])
+        loss = sl(probs, target.clone(), pw)
+        probs.grad = None
+        loss.backward()
+        res[f"sem_{name}"] = loss
+        res[f"sem_{name}_dprobs"] = probs.grad.clone()
+    cw = [0.5 + 0.1 * i for i in range(c)]
+    sl = SemanticLoss(device=CPU, class_weights=cw, top_k_percent_pixels=0.2, ignore_labels=[])
+    probs.grad = None
+    loss = sl(probs, target.clone(), pw)
+    loss.backward()
+    res["sem_cw"] = loss
+    res["sem_cw_dprobs"] = probs.grad.clone()
+    res["class_weights"] = np.array(cw, np.float32)
+    # instance losses
+    cp = gi.normal((b, 1, h, w), seed + 1).requires_grad_(True)
+    ct = gi.center_heatmap(b, h, w, seed)
+    op = gi.normal((b, 2, h, w), seed + 2, 10.0).requires_grad_(True)
+    ot = gi.offsets(b, h, w, seed)
+    tp = torch.softmax(gi.normal((b, 2, h, w), seed + 3), 1).requires_grad_(True)
+    tm = (gi.semantic_labels(b, h, w, seed + 4, 2)).clone()
+    lc, lo, lm = CenterLoss()(cp, ct, None), OffsetLoss()(op, ot, None), BinaryMaskLoss()(tp, tm)
+    (lc + lo + lm).backward()
+    res.update(center=lc, offset=lo, mask=lm, dcenter=cp.grad, doffset=op.grad, dmask=tp.grad)
+    save("sem_inst_losses", **res)
+
+
+# ------------------------------------------------------------------------------------------ panoptic
+def golden_panoptic():
+    algo = InstanceSegAlgo(CenterLoss(), OffsetLoss(),
+                           PanopticEvaluator(stuff_list=STUFF, thing_list=THINGS, label_divisor=1000,
+                                             void_label=-1), BinaryMaskLoss())
+    res = {}
+    cases = []
+    h, w = 48, 96
+    # (a) random smooth case, uint8 semantics
+    sem = gi.semantic_labels(2, h, w, 41, 14, block=8)
+    cases.append(("rand", sem, gi.center_heatmap(2, h, w, 41, 12, 3.0), gi.offsets(2, h, w, 41, 20.0)))
+    # (b) empty: no centre above threshold
+    cases.append(("empty", sem, torch.full((2, 1, h, w), 0.05), gi.offsets(2, h, w, 42, 5.0)))
+    # (c) plateau ties: equal-valued neighbouring maxima (NMS keeps all equal maxima)
+    ctr = torch.zeros(1, 1, h, w)
+    ctr[0, 0, 10, 10] = 0.9
+    ctr[0, 0, 10, 11] = 0.9
+    ctr[0, 0, 30, 50] = 0.5
+    ctr[0, 0, 33, 52] = 0.5
+    ctr[0, 0, 0, 0] = 0.3
+    ctr[0, 0, h - 1, w - 1] = 0.3
+    cases.append(("ties", sem[:1], ctr, torch.zeros(1, 2, h, w)))
+    # (d) more than 200 centres: isolated peaks on a stride-8 lattice (12x24=288 > 200) with many
+    #     equal scores so that the strict '>' rule on the 200-th score matters
+    ctr = torch.zeros(1, 1, 96, 192)
+    g = np.random.default_rng(43)
+    vals = g.choice(np.array([0.2, 0.4, 0.6, 0.8], np.float32), (12, 24))
+    ctr[0, 0, 4::8, 4::8] = torch.from_numpy(vals)
+    sem_big = gi.semantic_labels(1, 96, 192, 44, 14, block=16, void_frac=0.1)
+    cases.append(("many", sem_big, ctr, gi.offsets(1, 96, 192, 45, 6.0)))
+    # (e) int64 semantics (adapt path passes argmax int64, algos/semantic_seg.py:213)
+    cases.append(("int64", sem.long(), gi.center_heatmap(2, h, w, 46, 6, 4.0), gi.offsets(2, h, w, 46, 30.0)))
+    # (f) all-thing image with a single centre and all-stuff image
+    sem_t = torch.full((2, h, w), 11, dtype=torch.uint8)
+    sem_t[1] = 3
+    cases.append(("uniform", sem_t, gi.center_heatmap(2, h, w, 47, 2, 5.0), gi.offsets(2, h, w, 47, 3.0)))
+    names = []
+    for name, s, c, o in cases:
+        pan, inst, pts = algo.panoptic_fusion(s.clone(), c.clone(), o.clone(), return_center=True)
+        names.append(name)
+        res[f"{name}_sem"], res[f"{name}_ctr"], res[f"{name}_off"] = s, c, o
+        res[f"{name}_pan"], res[f"{name}_inst"] = pan, inst
+        for i, p in enumerate(pts):
+            res[f"{name}_pts{i}"] = p.reshape(-1, 2) if p.numel() else np.zeros((0, 2), np.int64)
+    res["meta"] = json.dumps({"cases": names, "thing_list": THINGS})
+    save("panoptic", **res)
+
+
+# ------------------------------------------------------------------------------------------ network-level
+class _StandInEncoder(torch.nn.Module):
+    """R18-shaped trunk built from the oracle's torchvision restatement -- a stand-in, since
+    torchvision is absent; network-level goldens pin everything *around* the trunk."""
+
+    def __init__(self, in_ch, seed):
+        super().__init__()
+        from oracle import resnet
+        self._resnet = resnet
+        sd = gi.fill_state_dict(gi.shapes_of(resnet.make_state_dict(18, in_ch, 0, with_fc=False)), seed)
+        self.sd = {k: (torch.nn.Parameter(v) if v.is_floating_point() and "running" not in k else v)
+                   for k, v in sd.items()}
+        for k, v in self.sd.items():
+            if isinstance(v, torch.nn.Parameter):
+                self.register_parameter(k.replace(".", "_"), v)
+        self.num_ch_enc = R18
+
+    def forward(self, x):
+        return self._resnet.features(self.sd, x, 18, training=False)
+
+
+def _build_net(seed, use_thing_mask, w, h, adaptation=False, src_wh=None):
+    enc = _StandInEncoder(3, seed + 1)
+    penc = _StandInEncoder(6, seed + 2)
+    heads = OrderedDict(depth_head=DepthHead(R18, True), pose_head=PoseHead(R18, 1, 2),
+                        semantic_head=SemanticHead(R18, 14, True, True),
+                        instance_head=InstanceHead(R18, use_thing_mask))
+    for i, m in enumerate(heads.values()):
+        m.load_state_dict(gi.fill_state_dict(gi.shapes_of(m.state_dict()), seed + 10 + i))
+    ssim = SSIMLoss()
+    rec = ReconstructionLoss(w, h, ssim, 5, CPU)
+    rec_src = ReconstructionLoss(src_wh[0], src_wh[1], ssim, 5, CPU) if adaptation else None
+    dalgo = DepthAlgo(rec, EdgeAwareSmoothnessLoss(), DepthEvaluator(True, None), None, None, rec_src, None)
+    salgo = SemanticSegAlgo(SemanticLoss(device=CPU, class_weights=[1.0] * 14, top_k_percent_pixels=0.2,
+                                         ignore_labels=[]), SemanticEvaluator(num_classes=14, ignore_classes=[]))
+    ialgo = InstanceSegAlgo(CenterLoss(), OffsetLoss(),
+                            PanopticEvaluator(stuff_list=STUFF, thing_list=THINGS, label_divisor=1000,
+                                              void_label=-1), BinaryMaskLoss())
+    net = CodepsNet(None, enc, penc, heads["depth_head"], heads["pose_head"], None,
+                    heads["semantic_head"], heads["instance_head"], dalgo, salgo, ialgo)
+    net.eval()
+    return net
+
+
+def _sample(b, h, w, seed, labels=True):
+    f0, fm, fp = gi.triplet(b, h, w, seed)
+    d = {"rgb": {0: f0, -1: fm, 1: fp}, "camera_model": gi.intrinsics(b, h, w, seed)}
+    if labels:
+        d.update(semantic=gi.semantic_labels(b, h, w, seed), semantic_weights=gi.pixel_weights(b, h, w, seed),
+                 center=gi.center_heatmap(b, h, w, seed), offset=gi.offsets(b, h, w, seed),
+                 center_weights=torch.ones(b, 1, h, w, dtype=torch.uint8),
+                 offset_weights=torch.ones(b, 1, h, w, dtype=torch.uint8),
+                 thing_mask=(gi.semantic_labels(b, h, w, seed + 1, 2, void_frac=0.02)).unsqueeze(1))
+    return d
+
+
+def golden_network(seed=51):
+    b, h, w = 2, 64, 128
+    net = _build_net(seed, True, w, h)
+    sample = _sample(b, h, w, seed)
+    torch.manual_seed(2000 + seed)
+    losses, result, _stats = net(sample, "train", [0, -1, 1], do_panoptic_fusion=True)
+    wts = dict(depth_recon=10.0, depth_smth=0.001, semantic=1.0, center=20.0, offset=0.1, thing_mask=0.5)
+    total = sum(wts[k] * v for k, v in losses.items() if v is not None and k in wts)
+    total.backward()
+    res = {"meta": json.dumps({"b": b, "h": h, "w": w, "seed": seed, "weights": wts,
+                               "noise_seed": 2000 + seed})}
+    for k, v in losses.items():
+        if v is not None:
+            res["loss_" + k] = v
+    res["total"] = total
+    for k in ("depth", "semantic", "center", "offset", "panoptic", "instance", "thing_mask"):
+        res["res_" + k] = result[k]
+    for name in ("depth_head", "pose_head", "semantic_head", "instance_head", "backbone_po_depth",
+                 "backbone_pose_sflow"):
+        res["pgrad_" + name] = grad_stats(getattr(net, name))
+    save("network_train", **res)
+
+
+def golden_adapt(seed=61):
+    """DepthAlgo.adaptation weighted mean over keys with two resolutions + semantic adaptation losses
+    (algos/depth.py:507-595, algos/semantic_seg.py:200-249), mixup items given pre-mixed."""
+    ht, wt, hs, ws = 64, 160, 64, 128
+    net = _build_net(seed, False, wt, ht, adaptation=True, src_wh=(ws, hs))
+    data = {"target": _sample(1, ht, wt, seed, labels=False),
+            "target_replay": _sample(2, ht, wt, seed + 1, labels=False),
+            "source": _sample(2, hs, ws, seed + 2)}
+    mix = _sample(2, hs, ws, seed + 3)
+    torch.manual_seed(3000 + seed)
+    # the reference's adapt() runs Mixup.do_mixup (datasets/mixup.py, out of scope §8f-2) on '*mixup'
+    # keys; we pin the rest by calling the three algos exactly as CodepsNet.adapt does.
+    images = {k: [v["rgb"][o] for o in (0, -1, 1)] for k, v in data.items()}
+    feats = {k: [net.backbone_po_depth(v["rgb"][o]) for o in (0, -1, 1)] for k, v in data.items()}
+    feats["cut_mixup"] = [net.backbone_po_depth(mix["rgb"][0])]
+    cm = {k: cams(v["camera_model"], v["rgb"][0].shape[3], v["rgb"][0].shape[2]) for k, v in data.items()}
+    sem_gt = {"target": None, "target_replay": None, "source": data["source"]["semantic"],
+              "cut_mixup": mix["semantic"]}
+    sem_w = {"source": data["source"]["semantic_weights"]}
+    sem_losses, _cm, sem_pred = net.semantic_algo.adaptation(feats, net.semantic_head, sem_gt, sem_w)
+    dl, _fl, depth_pred, transf, _om, _ = net.depth_algo.adaptation(
+        images, feats, cm, net.depth_head, net.backbone_pose_sflow, net.pose_head, None)
+    wts = dict(depth_recon=10.0, depth_smth=0.001, semantic_source=1.0, semantic_cut_mixup=1.0)
+    total = 10.0 * dl["recon"] + 0.001 * dl["smth"] + sem_losses["source"] + sem_losses["cut_mixup"]
+    total.backward()
+    res = {"meta": json.dumps({"ht": ht, "wt": wt, "hs": hs, "ws": ws, "seed": seed, "weights": wts,
+                               "noise_seed": 3000 + seed}),
+           "loss_depth_recon": dl["recon"], "loss_depth_smth": dl["smth"],
+           "loss_semantic_source": sem_losses["source"], "loss_semantic_cut_mixup": sem_losses["cut_mixup"],
+           "total": total, "res_depth": depth_pred, "res_semantic": sem_pred,
+           "res_T0": transf[0], "res_T1": transf[1]}
+    for name in ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"):
+        res["pgrad_" + name] = grad_stats(getattr(net, name))
+    save("network_adapt", **res)
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    golden_geometry()
+    golden_heads("r18", R18, 2, 32, 64, 3)
+    golden_heads("r50", R50, 1, 32, 64, 5, full=False)
+    golden_recon("small", 2, 48, 80, 21)
+    golden_recon("odd", 1, 40, 72, 22, num_scales=3)
+    golden_sem_inst_losses()
+    golden_panoptic()
+    golden_network()
+    golden_adapt()
