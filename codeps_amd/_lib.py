@@ -1,0 +1,94 @@
+"""ctypes binding of libcodeps_hip.so (the C ABI declared in include/codeps_hip.h).
+
+`import torch` happens first on purpose: the library NEEDs libamdhip64.so.7 and must bind to the copy
+PyTorch-ROCm already mapped (one HIP runtime per process).  There is no fallback path: if the
+library is missing `lib()` raises, and every op in codeps_amd goes through `lib()`.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint64, c_void_p
+
+import torch  # noqa: F401  (must precede loading the .so, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcodeps_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+ABI_VERSION = 1
+
+_lib = None
+
+
+class CodepsHipError(RuntimeError):
+    pass
+
+
+class PhotometricDesc(Structure):
+    _fields_ = [("batch", c_int32), ("height", c_int32), ("width", c_int32), ("num_scales", c_int32),
+                ("alpha", c_float), ("noise_seed", c_uint64)]
+
+
+def build(jobs=8, verbose=False):
+    """Compile every HIP source for gfx950 into the in-tree shared library (hipcc cross-compiles
+    without a GPU)."""
+    out = subprocess.run(["make", "-C", CSRC, f"-j{jobs}"], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout[-4000:], out.stderr[-8000:])
+    if out.returncode != 0:
+        raise CodepsHipError("building libcodeps_hip.so failed")
+    return LIB_PATH
+
+
+def _sig(fn, res, *args):
+    fn.restype = res
+    fn.argtypes = list(args)
+
+
+# name -> (restype, argtypes); this table IS the Python view of include/codeps_hip.h and is checked
+# against the header by tests/test_abi.py
+P = c_void_p
+SIGNATURES = {
+    "codeps_version": (c_int, []),
+    "codeps_last_error": (c_char_p, []),
+    "codeps_photometric_workspace_bytes": (c_size_t, [POINTER(PhotometricDesc)]),
+    "codeps_photometric_fwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "codeps_photometric_bwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+}
+
+
+def lib():
+    """The loaded library (cached).  Raises CodepsHipError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CodepsHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C codeps_amd/csrc`).  codeps_amd has no CPU / eager fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            _sig(getattr(handle, name), res, *args)
+        if handle.codeps_version() != ABI_VERSION:
+            raise CodepsHipError(f"libcodeps_hip.so ABI {handle.codeps_version()} != binding {ABI_VERSION}; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CodepsHipError(f"{what} failed ({rc}): {lib().codeps_last_error().decode()}")
+
+
+def stream_ptr():
+    """Current PyTorch HIP stream as the void* the C ABI expects."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CodepsHipError("codeps_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
