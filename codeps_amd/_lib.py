@@ -28,6 +28,11 @@ class PhotometricDesc(Structure):
                 ("alpha", c_float), ("noise_seed", c_uint64)]
 
 
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("batch", "in_h", "in_w", "c0", "c1", "up0", "out_c", "out_h", "out_w", "kh", "kw",
+                                       "stride", "pad", "pad_mode", "act")]
+
+
 def build(jobs=8, verbose=False):
     """Compile every HIP source for gfx950 into the in-tree shared library (hipcc cross-compiles
     without a GPU)."""
@@ -47,12 +52,37 @@ def _sig(fn, res, *args):
 # name -> (restype, argtypes); this table IS the Python view of include/codeps_hip.h and is checked
 # against the header by tests/test_abi.py
 P = c_void_p
+I = c_int
+LL = ctypes.c_longlong
 SIGNATURES = {
     "codeps_version": (c_int, []),
     "codeps_last_error": (c_char_p, []),
     "codeps_photometric_workspace_bytes": (c_size_t, [POINTER(PhotometricDesc)]),
     "codeps_photometric_fwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_photometric_bwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "codeps_conv2d_pack_weights": (c_int, [I, I, I, I, I, I, P, P, P, P]),
+    "codeps_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
+    "codeps_conv2d_dgrad": (c_int, [POINTER(ConvDesc), I, P, P, P, P]),
+    "codeps_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "codeps_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, I, I, I, P, c_size_t, P]),
+    "codeps_nchw_to_nhwc": (c_int, [P, I, I, I, I, P, I, I, I, P]),
+    "codeps_nhwc_to_nchw": (c_int, [P, I, I, I, I, I, P, P]),
+    "codeps_colsum_workspace_bytes": (c_size_t, [LL, I, I]),
+    "codeps_act_bwd": (c_int, [P, P, P, I, LL, I, P, P, I, I, P, c_size_t, P]),
+    "codeps_bn_stats": (c_int, [P, LL, I, P, P, c_size_t, P]),
+    "codeps_bn_apply": (c_int, [P, P, P, P, P, P, I, LL, I, P, P]),
+    "codeps_bn_bwd_reduce": (c_int, [P, P, P, P, P, I, LL, I, P, P, c_size_t, P]),
+    "codeps_bn_bwd_apply": (c_int, [P, P, P, P, P, P, P, c_float, I, LL, I, P, P, P]),
+    "codeps_maxpool3x3s2_fwd": (c_int, [P, I, I, I, I, P, P, P]),
+    "codeps_maxpool3x3s2_bwd": (c_int, [P, P, I, I, I, I, P, P]),
+    "codeps_dwconv5x5": (c_int, [P, P, P, P, I, I, I, I, I, I, P, P]),
+    "codeps_dwconv5x5_wgrad": (c_int, [P, P, I, I, I, I, P, P, c_size_t, P]),
+    "codeps_bilinear_fwd": (c_int, [P, I, I, I, I, I, I, I, P, I, I, P]),
+    "codeps_bilinear_bwd": (c_int, [P, I, I, I, I, I, I, I, I, I, P, P]),
+    "codeps_softmax_fwd": (c_int, [P, LL, I, I, P, P]),
+    "codeps_softmax_bwd": (c_int, [P, P, LL, I, I, P, P]),
+    "codeps_disp_depth_fwd": (c_int, [P, LL, I, c_float, c_float, P, P, P]),
+    "codeps_disp_depth_bwd": (c_int, [P, P, P, LL, I, c_float, c_float, P, P]),
 }
 
 

@@ -1,0 +1,591 @@
+// NHWC fp32 implicit-GEMM convolution engine on the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32):
+// forward (+fused nearest-x2 upsample of source 0, concat-by-pointer of two sources, zero / reflect
+// padding, per-channel affine (folded eval BatchNorm or bias), residual add, ReLU / ELU), data gradient
+// and weight gradient.  Exact f32 arithmetic (MFMA f32 == k-ordered fmaf chain), no reduced precision.
+//
+// Replaces the ATen/cuDNN convolutions behind: torchvision ResNet (models/resnet_encoder.py:115-126),
+// DepthHead / SemanticHead decoders (models/depth_head.py:60-71, models/semantic_head.py:50-72),
+// InstanceHead 1x1 convs (models/instance_head.py:24-57,99-111), PoseHead (models/pose_head.py:36-44).
+//
+// GEMM view:  forward  Y[m][n] = sum_{tap,c} X(m,tap,c) * Wf[n][tap][c]      m = output pixel, n = out channel
+//             dgrad    dX[m][n] = sum_{tap,c} dZ(m,tap,c) * Wd[n][tap][c]    m = input pixel,  n = in channel
+//             wgrad    dW[m][n](tap) = sum_p dZ[p][m] * X(p,tap,n)           m = out channel,  n = in channel
+// Block tile (32*WM*TM) x (32*WN*TN), 256 threads = 4 waves (WM x WN), wave tile TM x TN MFMA tiles of
+// 32x32; K-step BK channels of one tap, register-staged global->LDS double buffering (one barrier per
+// K-step); LDS rows padded to BK+4 floats => conflict-free ds_read_b128 fragment reads
+// (row stride 36 or 20 dwords walks all 16 four-bank slots).  blockIdx is remapped so that the
+// N-tiles of one M-tile run on the same XCD (they share the A tile through that XCD's L2).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct ConvP {
+    // geometry (see codeps_conv_desc)
+    int B, H, W;          // logical input size (after the optional x2 upsample of source 0)
+    int C0, C1, Ct;       // channels of source 0 / 1, Ct = C0 + C1
+    int up0;
+    int Co, Ho, Wo;
+    int KH, KW, stride, pad, pad_mode;
+    int act;
+    int M, N;             // GEMM rows / cols of this launch
+    int n_mt, n_nt;       // tile counts
+    int src;              // dgrad: which source's gradient (0/1)
+    int Cs;               // dgrad: channels of that source;  c_off = its channel offset in the packed weights
+    int c_off;
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    return v;
+}
+
+// XCD-aware bijective block remap (guide T1): blocks with equal blockIdx % 8 share an XCD.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, i = bid / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// One implicit-GEMM kernel for forward and dgrad.
+//   A rows: pixels.  B rows: GEMM columns n (weights packed [n][tap][c], c contiguous).
+template <int MODE, int WM, int WN, int TM, int TN, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* __restrict__ a0,
+                                                         const float* __restrict__ a1, const float* __restrict__ wq,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ residual, float* __restrict__ out) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int LDK = BK + 4;                       // padded LDS row (floats)
+    constexpr int CPR = BK / 4;                       // 16-B chunks per row
+    constexpr int RPP = 256 / CPR;                    // rows covered per pass of the 256 threads
+    constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                 // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;                  // [2][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
+    const int nt = logical % p.n_nt, mt = logical / p.n_nt;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-thread A-row bookkeeping (rows r = tid / CPR + RPP * i)
+    const int chunk = tid % CPR, rbase = tid / CPR;
+    int rb[APASS], ry[APASS], rx[APASS];              // batch index (-1 = row out of range), pixel y, x
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m0 + rbase + RPP * i;
+        if (m < p.M && rbase + RPP * i < BM) {
+            const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : ((p.up0 && p.src == 0) ? (p.H / 2) * (p.W / 2) : p.H * p.W);
+            const int Wm = (MODE == MODE_FWD) ? p.Wo : ((p.up0 && p.src == 0) ? p.W / 2 : p.W);
+            rb[i] = m / HWm;
+            const int rem = m % HWm;
+            ry[i] = rem / Wm; rx[i] = rem % Wm;
+        } else { rb[i] = -1; ry[i] = 0; rx[i] = 0; }
+    }
+    // B rows (weights): row n = n0 + rbase + RPP*i, K-contiguous
+    const float* brow[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int n = n0 + rbase + RPP * i;
+        brow[i] = (n < p.N && rbase + RPP * i < BN) ? wq + (size_t)n * ((MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct
+                                                                   : (size_t)p.KH * p.KW * p.Co) + chunk * 4
+                            : nullptr;
+    }
+
+    // ---- K-step enumeration: (tap, source segment, channel chunk)
+    const int ntap = (MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW;
+    const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;          // channels per tap in the packed weights
+    const int steps_per_tap = Kc / BK;
+    const int nsteps = ntap * steps_per_tap;
+
+    f32x4 areg[APASS], breg[BPASS];
+
+    auto load_step = [&](int step) {
+        const int tap = step / steps_per_tap;
+        const int cstep = (step % steps_per_tap) * BK;       // channel offset within the tap
+        int ky, kx, qy = 0, qx = 0;
+        if (MODE == MODE_DGRAD && p.up0 && p.src == 0) {
+            const int q = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
+            qy = q >> 1; qx = q & 1; ky = t2 / p.KW; kx = t2 % p.KW;
+        } else { ky = tap / p.KW; kx = tap % p.KW; }
+        // ---- A operand
+        if (MODE == MODE_FWD) {
+            const bool s1 = cstep >= p.C0;                    // which source this chunk belongs to
+            const float* src = s1 ? a1 : a0;
+            const int cs = s1 ? p.C1 : p.C0, c = (s1 ? cstep - p.C0 : cstep) + chunk * 4;
+            const bool up = p.up0 && !s1;
+            const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rb[i] >= 0) {
+                    int iy = ry[i] * p.stride - p.pad + ky, ix = rx[i] * p.stride - p.pad + kx;
+                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                        if (up) { iy >>= 1; ix >>= 1; }
+                        v = *reinterpret_cast<const f32x4*>(src + (((size_t)rb[i] * Hs + iy) * Ws + ix) * cs + c);
+                    }
+                }
+                areg[i] = v;
+            }
+        } else {
+            // dgrad: A = dZ at the output pixels that read this input pixel through tap (ky,kx)
+            const int c = cstep + chunk * 4;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rb[i] >= 0) {
+                    int iy = ry[i], ix = rx[i];
+                    if (p.up0 && p.src == 0) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
+                    int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
+                    bool ok = ty >= 0 && tx >= 0;
+                    if (p.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
+                    if (ok && ty < p.Ho && tx < p.Wo)
+                        v = *reinterpret_cast<const f32x4*>(a0 + (((size_t)rb[i] * p.Ho + ty) * p.Wo + tx) * p.Co + c);
+                }
+                areg[i] = v;
+            }
+        }
+        // ---- B operand (packed weights, K contiguous)
+        int koff;
+        if (MODE == MODE_DGRAD && p.up0 && p.src == 0) koff = ((tap % (p.KH * p.KW)) * Kc) + cstep;
+        else koff = tap * Kc + cstep;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (brow[i]) v = *reinterpret_cast<const f32x4*>(brow[i] + koff);
+            breg[i] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+        float* Ab = As + buf * BM * LDK;
+        float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i)
+            if (rbase + RPP * i < BM) *reinterpret_cast<f32x4*>(Ab + (rbase + RPP * i) * LDK + chunk * 4) = areg[i];
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+            if (rbase + RPP * i < BN) *reinterpret_cast<f32x4*>(Bb + (rbase + RPP * i) * LDK + chunk * 4) = breg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) load_step(step + 1);           // global loads in flight during the MFMAs
+        const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK + lhalf * 4;
+        const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK + lhalf * 4;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + g * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (step + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column n = lane&31 of each 32x32 tile, rows (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + lrow;
+        if (n >= p.N) continue;
+        float sc = 1.f, sh = 0.f;
+        if (MODE == MODE_FWD) {
+            if (scale) sc = scale[n];
+            if (shift) sh = shift[n];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (MODE == MODE_FWD) {
+                    v = v * sc + sh;
+                    if (residual) v += residual[(size_t)m * p.N + n];
+                    v = apply_act(v, p.act);
+                }
+                out[(size_t)m * p.N + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- wgrad
+// dW[co][tap][ci] partial over a pixel range.  A = dZ^T (LDS [k=pixel][m=co]), B = X(tap) (LDS [k][n=ci]).
+struct WgradP {
+    int B, H, W, C0, C1, Ct, up0, Co, Ho, Wo, KH, KW, stride, pad, pad_mode;
+    int n_mt, n_nt, splits, pix_per_split, P;     // P = B*Ho*Wo output pixels
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* __restrict__ x0,
+                                                         const float* __restrict__ x1, const float* __restrict__ dz,
+                                                         float* __restrict__ part) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, BKP = 16;        // 16 pixels per K-step
+    constexpr int LDM = BM + 4, LDN = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                        // [2][BKP][LDM]
+    float* Bs = smem + 2 * BKP * LDM;        // [2][BKP][LDN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const bool active = wave < WM * WN;          // small tiles use fewer than 4 MFMA waves; all 4 still load
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int nt = bid % p.n_nt; bid /= p.n_nt;
+    const int mt = bid % p.n_mt;
+    const int tap = bid / p.n_mt;
+    const int ky = tap / p.KW, kx = tap % p.KW;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int pbeg = split * p.pix_per_split, pend = min(pbeg + p.pix_per_split, p.P);
+
+    // loader mapping: A: BKP x BM floats, 16-B chunks along m;  B: BKP x BN along n
+    constexpr int ACH = BM / 4, BCH = BN / 4;                 // chunks per pixel row
+    constexpr int AIT = (BKP * ACH + 255) / 256, BIT = (BKP * BCH + 255) / 256;
+    f32x4 areg[AIT], breg[BIT];
+
+    auto load_step = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int idx = tid + 256 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < BKP * ACH) {
+                const int kr = idx / ACH, ch = idx % ACH;
+                const int pix = p0 + kr, m = m0 + ch * 4;
+                if (pix < pend && m < p.Co) v = *reinterpret_cast<const f32x4*>(dz + (size_t)pix * p.Co + m);
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int idx = tid + 256 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < BKP * BCH) {
+                const int kr = idx / BCH, ch = idx % BCH;
+                const int pix = p0 + kr, n = n0 + ch * 4;
+                if (pix < pend && n < p.Ct) {
+                    const int b = pix / (p.Ho * p.Wo), rem = pix % (p.Ho * p.Wo);
+                    int iy = (rem / p.Wo) * p.stride - p.pad + ky, ix = (rem % p.Wo) * p.stride - p.pad + kx;
+                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                        const bool s1 = n >= p.C0;
+                        const bool up = p.up0 && !s1;
+                        const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+                        if (up) { iy >>= 1; ix >>= 1; }
+                        const float* src = s1 ? x1 : x0;
+                        const int cs = s1 ? p.C1 : p.C0, c = s1 ? n - p.C0 : n;
+                        v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c);
+                    }
+                }
+            }
+            breg[i] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BKP * ACH) *reinterpret_cast<f32x4*>(As + buf * BKP * LDM + (idx / ACH) * LDM + (idx % ACH) * 4) = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BKP * BCH) *reinterpret_cast<f32x4*>(Bs + buf * BKP * LDN + (idx / BCH) * LDN + (idx % BCH) * 4) = breg[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nsteps = (pend - pbeg + BKP - 1) / BKP;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    if (nsteps > 0) {
+        load_step(pbeg);
+        store_step(0);
+        __syncthreads();
+        for (int step = 0; step < nsteps; ++step) {
+            const int buf = step & 1;
+            if (step + 1 < nsteps) load_step(pbeg + (step + 1) * BKP);
+            const float* Ab = As + buf * BKP * LDM + wm * TM * 32 + lrow;
+            const float* Bb = Bs + buf * BKP * LDN + wn * TN * 32 + lrow;
+            if (active)
+#pragma unroll
+            for (int g = 0; g < BKP / 8; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kr = g * 8 + lhalf * 4 + e;
+                    float af[TM], bf[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = Ab[kr * LDM + i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = Bb[kr * LDN + j * 32];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (step + 1 < nsteps) store_step(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial slab [split][co][tap][ci]
+    float* dst = part + (size_t)split * p.Co * p.KH * p.KW * p.Ct;
+    if (active)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + lrow;
+        if (n >= p.Ct) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                if (m < p.Co) dst[((size_t)m * p.KH * p.KW + tap) * p.Ct + n] = acc[i][j][r];
+            }
+    }
+}
+
+// sum the split slabs and scatter into the OIHW gradient: dw[co][ci][ky][kx] (+= if accumulate)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int Co, int Ct,
+                                                           int taps, int co_real, int ci_real, float* __restrict__ dw,
+                                                           int accumulate) {
+    const long long total = (long long)Co * Ct * taps;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        // i enumerates the packed (channel-padded) layout [co][tap][ci] (coalesced reads)
+        const int ci = (int)(i % Ct);
+        const int tap = (int)((i / Ct) % taps);
+        const int co = (int)(i / ((long long)Ct * taps));
+        if (co >= co_real || ci >= ci_real) continue;
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += part[(size_t)s * total + i];
+        const size_t o = ((size_t)co * ci_real + ci) * taps + tap;
+        dw[o] = accumulate ? dw[o] + a : a;
+    }
+}
+
+// OIHW -> forward pack [co][tap][ci] and dgrad pack [ci][tap][co]
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int co_real, int ci_real, int taps,
+                                                           int Co, int Ci, float* __restrict__ wf, float* __restrict__ wd) {
+    // enumerate the channel-padded index space; padding rows/columns are zero
+    const long long total = (long long)Co * Ci * taps;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int tap = (int)(i % taps);
+        const int ci = (int)((i / taps) % Ci);
+        const int co = (int)(i / ((long long)taps * Ci));
+        const float v = (co < co_real && ci < ci_real) ? w[((size_t)co * ci_real + ci) * taps + tap] : 0.f;
+        if (wf) wf[((size_t)co * taps + tap) * Ci + ci] = v;
+        if (wd) wd[((size_t)ci * taps + tap) * Co + co] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------- host side
+static int check_conv(const codeps_conv_desc* d, const char* who) {
+    CODEPS_REQUIRE(d != nullptr, CODEPS_ERR_ARG, "%s: null descriptor", who);
+    CODEPS_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->c0 > 0 && d->c1 >= 0 && d->out_c > 0, CODEPS_ERR_ARG,
+                   "%s: bad shape", who);
+    CODEPS_REQUIRE(d->stride == 1 || d->stride == 2, CODEPS_ERR_ARG, "%s: stride %d unsupported", who, d->stride);
+    CODEPS_REQUIRE((d->c0 % 16) == 0 && (d->c1 % 16) == 0, CODEPS_ERR_ARG,
+                   "%s: channel counts (%d,%d) must be multiples of 16 (pad the stem input)", who, d->c0, d->c1);
+    CODEPS_REQUIRE(!d->up0 || ((d->in_h % 2) == 0 && (d->in_w % 2) == 0 && d->stride == 1), CODEPS_ERR_ARG,
+                   "%s: fused x2 upsample needs even size and stride 1", who);
+    const int ho = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1, wo = (d->in_w + 2 * d->pad - d->kw) / d->stride + 1;
+    CODEPS_REQUIRE(ho == d->out_h && wo == d->out_w, CODEPS_ERR_ARG, "%s: output size %dx%d != expected %dx%d", who, d->out_h,
+                   d->out_w, ho, wo);
+    CODEPS_REQUIRE(d->pad_mode == 0 || (d->pad < d->in_h && d->pad < d->in_w), CODEPS_ERR_ARG, "%s: reflect pad too large", who);
+    return CODEPS_OK;
+}
+
+static ConvP make_convp(const codeps_conv_desc* d) {
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.B = d->batch; p.H = d->in_h; p.W = d->in_w; p.C0 = d->c0; p.C1 = d->c1; p.Ct = d->c0 + d->c1; p.up0 = d->up0;
+    p.Co = d->out_c; p.Ho = d->out_h; p.Wo = d->out_w; p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.pad_mode = d->pad_mode; p.act = d->act;
+    return p;
+}
+
+template <int MODE, int WM, int WN, int TM, int TN, int BK>
+static void launch_igemm(ConvP p, const float* a0, const float* a1, const float* wq, const float* scale, const float* shift,
+                         const float* residual, float* out, hipStream_t st) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    p.n_mt = cdiv(p.M, BM); p.n_nt = cdiv(p.N, BN);
+    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK>;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3(p.n_mt * p.n_nt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
+}
+
+template <int MODE>
+static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a1, const float* wq, const float* scale,
+                           const float* shift, const float* residual, float* out, hipStream_t st) {
+    const bool bk32 = (kc_gran % 32) == 0;
+    // pick the N tile from the channel count, then the biggest M tile
+    if (p.N > 64) {
+        if (bk32) launch_igemm<MODE, 2, 2, 2, 2, 32>(p, a0, a1, wq, scale, shift, residual, out, st);
+        else      launch_igemm<MODE, 2, 2, 2, 2, 16>(p, a0, a1, wq, scale, shift, residual, out, st);
+    } else if (p.N > 32) {
+        if (bk32) launch_igemm<MODE, 2, 2, 2, 1, 32>(p, a0, a1, wq, scale, shift, residual, out, st);
+        else      launch_igemm<MODE, 2, 2, 2, 1, 16>(p, a0, a1, wq, scale, shift, residual, out, st);
+    } else {
+        if (bk32) launch_igemm<MODE, 4, 1, 2, 1, 32>(p, a0, a1, wq, scale, shift, residual, out, st);
+        else      launch_igemm<MODE, 4, 1, 2, 1, 16>(p, a0, a1, wq, scale, shift, residual, out, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
+                                          const float* w_oihw, float* w_fwd, float* w_dgrad, codeps_stream_t stream) {
+    CODEPS_REQUIRE(out_c > 0 && in_c > 0 && kh > 0 && kw > 0 && out_c_pad >= out_c && in_c_pad >= in_c && w_oihw &&
+                       (w_fwd || w_dgrad),
+                   CODEPS_ERR_ARG, "conv2d_pack_weights: bad arguments");
+    const long long total = (long long)out_c_pad * in_c_pad * kh * kw;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, out_c, in_c, kh * kw,
+                       out_c_pad, in_c_pad, w_fwd, w_dgrad);
+    CODEPS_CHECK_LAUNCH("pack_weights_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, const float* x1, const float* w_fwd,
+                                 const float* scale, const float* shift, const float* residual, float* y,
+                                 codeps_stream_t stream) {
+    int rc = check_conv(d, "conv2d_fwd");
+    if (rc != CODEPS_OK) return rc;
+    CODEPS_REQUIRE(x0 && w_fwd && y && (d->c1 == 0 || x1), CODEPS_ERR_ARG, "conv2d_fwd: null pointer");
+    ConvP p = make_convp(d);
+    p.M = d->batch * d->out_h * d->out_w; p.N = d->out_c;
+    const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
+    dispatch_igemm<MODE_FWD>(p, gran, x0, x1, w_fwd, scale, shift, residual, y, (hipStream_t)stream);
+    CODEPS_CHECK_LAUNCH("conv_igemm_kernel<fwd>");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, float* dx,
+                                   codeps_stream_t stream) {
+    int rc = check_conv(d, "conv2d_dgrad");
+    if (rc != CODEPS_OK) return rc;
+    CODEPS_REQUIRE(dz && w_dgrad && dx && (source == 0 || (source == 1 && d->c1 > 0)), CODEPS_ERR_ARG, "conv2d_dgrad: bad arguments");
+    CODEPS_REQUIRE(d->pad_mode == 0, CODEPS_ERR_ARG, "conv2d_dgrad: reflect padding has no dgrad path here");
+    CODEPS_REQUIRE((d->out_c % 16) == 0, CODEPS_ERR_ARG, "conv2d_dgrad: out_c %d must be a multiple of 16", d->out_c);
+    ConvP p = make_convp(d);
+    p.src = source;
+    p.Cs = source ? d->c1 : d->c0;
+    p.c_off = source ? d->c0 : 0;
+    const bool up = d->up0 && source == 0;
+    p.M = d->batch * (up ? (d->in_h / 2) * (d->in_w / 2) : d->in_h * d->in_w);
+    p.N = p.Cs;
+    // weights of this source: rows [c_off, c_off + Cs) of the [ci][tap][co] pack
+    const float* wsrc = w_dgrad + (size_t)p.c_off * d->kh * d->kw * d->out_c;
+    dispatch_igemm<MODE_DGRAD>(p, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, nullptr, dx, (hipStream_t)stream);
+    CODEPS_CHECK_LAUNCH("conv_igemm_kernel<dgrad>");
+    return CODEPS_OK;
+}
+
+static void wgrad_plan(const codeps_conv_desc* d, int& bm, int& bn, int& n_mt, int& n_nt, int& splits, int& pps) {
+    const int Ct = d->c0 + d->c1;
+    bm = d->out_c > 64 ? 128 : (d->out_c > 32 ? 64 : 32);
+    bn = Ct > 64 ? 128 : (Ct > 32 ? 64 : 32);
+    n_mt = cdiv(d->out_c, bm); n_nt = cdiv(Ct, bn);
+    const long long tiles = (long long)n_mt * n_nt * d->kh * d->kw;
+    const int P = d->batch * d->out_h * d->out_w;
+    long long s = std::max<long long>(1, (256 * 6) / tiles);
+    s = std::min<long long>(s, std::max(1, P / 256));
+    s = std::min<long long>(s, 512);
+    pps = (int)align_up((size_t)cdiv(P, (int)s), 16);
+    splits = cdiv(P, pps);
+}
+
+extern "C" size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d) {
+    if (check_conv(d, "conv2d_wgrad_workspace_bytes") != CODEPS_OK) return 0;
+    int bm, bn, n_mt, n_nt, splits, pps;
+    wgrad_plan(d, bm, bn, n_mt, n_nt, splits, pps);
+    return (size_t)splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
+}
+
+extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float* x1, const float* dz, float* dw_oihw,
+                                   int out_c_real, int in_c_real, int accumulate, void* workspace, size_t workspace_bytes,
+                                   codeps_stream_t stream) {
+    int rc = check_conv(d, "conv2d_wgrad");
+    if (rc != CODEPS_OK) return rc;
+    CODEPS_REQUIRE(x0 && dz && dw_oihw && workspace && (d->c1 == 0 || x1), CODEPS_ERR_ARG, "conv2d_wgrad: null pointer");
+    CODEPS_REQUIRE(out_c_real > 0 && out_c_real <= d->out_c && in_c_real > 0 && in_c_real <= d->c0 + d->c1, CODEPS_ERR_ARG,
+                   "conv2d_wgrad: real channel counts exceed the padded ones");
+    CODEPS_REQUIRE((d->out_c % 4) == 0, CODEPS_ERR_ARG, "conv2d_wgrad: out_c %d must be a multiple of 4", d->out_c);
+    int bm, bn, n_mt, n_nt, splits, pps;
+    wgrad_plan(d, bm, bn, n_mt, n_nt, splits, pps);
+    const size_t need = (size_t)splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
+    CODEPS_REQUIRE(workspace_bytes >= need, CODEPS_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    WgradP p;
+    memset(&p, 0, sizeof(p));
+    p.B = d->batch; p.H = d->in_h; p.W = d->in_w; p.C0 = d->c0; p.C1 = d->c1; p.Ct = d->c0 + d->c1; p.up0 = d->up0;
+    p.Co = d->out_c; p.Ho = d->out_h; p.Wo = d->out_w; p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.pad_mode = d->pad_mode; p.n_mt = n_mt; p.n_nt = n_nt; p.splits = splits; p.pix_per_split = pps;
+    p.P = d->batch * d->out_h * d->out_w;
+    const int grid = n_mt * n_nt * d->kh * d->kw * splits;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+#define WG_LAUNCH(WM, WN, TM, TN)                                                                              \
+    do {                                                                                                       \
+        constexpr int BM_ = 32 * WM * TM, BN_ = 32 * WN * TN;                                                  \
+        const size_t lds = (size_t)2 * 16 * (BM_ + 4 + BN_ + 4) * sizeof(float);                               \
+        hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), lds, st, p, x0, x1, dz, part); \
+    } while (0)
+    if (bm == 128 && bn == 128) WG_LAUNCH(2, 2, 2, 2);
+    else if (bm == 128 && bn == 64) WG_LAUNCH(2, 2, 2, 1);
+    else if (bm == 128 && bn == 32) WG_LAUNCH(4, 1, 1, 1);
+    else if (bm == 64 && bn == 128) WG_LAUNCH(2, 2, 1, 2);
+    else if (bm == 64 && bn == 64) WG_LAUNCH(2, 2, 1, 1);
+    else if (bm == 64 && bn == 32) WG_LAUNCH(2, 1, 1, 1);   // 2 waves idle-padded below
+    else if (bm == 32 && bn == 128) WG_LAUNCH(1, 4, 1, 1);
+    else if (bm == 32 && bn == 64) WG_LAUNCH(1, 2, 1, 1);
+    else WG_LAUNCH(1, 1, 1, 1);
+#undef WG_LAUNCH
+    CODEPS_CHECK_LAUNCH("conv_wgrad_kernel");
+    const long long total = (long long)d->out_c * (d->c0 + d->c1) * d->kh * d->kw;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, part, splits,
+                       d->out_c, d->c0 + d->c1, d->kh * d->kw, out_c_real, in_c_real, dw_oihw, accumulate);
+    CODEPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return CODEPS_OK;
+}

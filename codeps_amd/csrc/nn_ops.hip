@@ -1,0 +1,732 @@
+// HBM-bound NHWC building blocks around the conv engine (all fp32, 16-byte vector accesses, no atomics):
+// layout conversion, activation backward + bias gradient, BatchNorm (train-mode statistics as
+// exchangeable sums for SyncBN, apply, backward), 3x3/2 max-pool, 5x5 depthwise conv, bilinear resize
+// (both align_corners conventions) writing into channel slices (concat-by-pointer), channel softmax,
+// sigmoid + disparity->depth.
+//
+// Reference ops replaced: nn.BatchNorm2d / SyncBatchNorm (misc/train_utils.py:50-51, torchvision ResNet,
+// models/instance_head.py:26-49), nn.MaxPool2d(3,2,1) (models/resnet_encoder.py:31), depthwise 5x5
+// (models/instance_head.py:38-46,90-98), F.interpolate bilinear (models/semantic_head.py:66-69,
+// models/instance_head.py:65-68,116-118), nn.Softmax(dim=1) (semantic_head.py:74, instance_head.py:146),
+// sigmoid + disp_to_depth (models/depth_head.py:48-54,71-74), ELU/ReLU backward.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GRID_CAP = 256 * 8;          // memory-bound grids: <= 8 blocks per CU, grid-stride the rest
+
+static inline int grid_for(long long work_items) {
+    return (int)std::max<long long>(1, std::min<long long>((work_items + 255) / 256, GRID_CAP));
+}
+
+// ---------------------------------------------------------------------------------- layout
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, int H, int W,
+                                                           float* __restrict__ y, int Cp, int c_off, int zero_rest) {
+    // one thread per (pixel, 4-channel group) of the destination
+    const int groups = zero_rest ? Cp / 4 : (C + 3) / 4;
+    const long long total = (long long)B * H * W * groups;
+    const long long HW = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % groups);
+        const long long pix = i / groups;
+        const int b = (int)(pix / HW);
+        const long long hw = pix % HW;
+        if (zero_rest) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = g * 4 + e - c_off;
+                v[e] = (c >= 0 && c < C) ? x[((size_t)b * C + c) * HW + hw] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(y + (size_t)pix * Cp + g * 4) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = g * 4 + e;
+                if (c < C) y[(size_t)pix * Cp + c_off + c] = x[((size_t)b * C + c) * HW + hw];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int B, int C, int H, int W, int Cp,
+                                                           float* __restrict__ y) {
+    const long long HW = (long long)H * W, total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long hw = i % HW;
+        const int c = (int)((i / HW) % C);
+        const int b = (int)(i / (HW * C));
+        y[i] = x[((size_t)b * HW + hw) * Cp + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------- column sums (per-channel)
+// Generic two-stage deterministic per-channel reduction over M rows of an [M][C] matrix.
+// stage 1: block (rows chunk) -> partial[blk][K][C];  stage 2: sum over blocks in order.
+constexpr int CS_ROWS = 64;               // rows per thread-row group iteration
+
+__device__ __forceinline__ float act_grad(float y, int act) {
+    if (act == 1) return y > 0.f ? 1.f : 0.f;
+    if (act == 2) return y > 0.f ? 1.f : y + 1.f;
+    return 1.f;
+}
+
+// dz = dy * act'(y) * scale;  col partial of dy*act'(y)  (bias / shift gradient)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ scale, int act, long long M, int C,
+                                                      float* __restrict__ dz, float* __restrict__ part, int rows_per_blk) {
+    // thread = (row lane r = tid / (C/4 clipped), channel group); C/4 groups must divide 256 or be <= 256
+    const int Gall = C / 4, G = Gall < 256 ? Gall : 256;          // blockIdx.y tiles the channel groups
+    const int tl = threadIdx.x % G, tr = threadIdx.x / G, TR = 256 / G;
+    const int tg = blockIdx.y * G + tl;
+    const bool cok = tg < Gall && tr < TR;
+    const long long r0 = (long long)blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+    if (scale && cok) sc = *reinterpret_cast<const f32x4*>(scale + tg * 4);
+    if (cok)
+        for (long long r = r0 + tr; r < r1; r += TR) {
+            const size_t o = (size_t)r * C + tg * 4;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+            f32x4 d = g;
+            if (act) {
+                const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = g[e] * act_grad(yy[e], act);
+            }
+            acc += d;
+            if (dz) *reinterpret_cast<f32x4*>(dz + o) = d * sc;
+        }
+    if (!part) return;
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < G && blockIdx.y * G + threadIdx.x < Gall) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < TR; ++k) t += red[k * G + threadIdx.x];
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + (blockIdx.y * G + threadIdx.x) * 4) = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblk, int K, int C,
+                                                            float* __restrict__ out, int c_real, int accumulate) {
+    // part: [nblk][K][C] -> out [K][c_real]
+    const int total = K * C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c = i % C, k = i / C;
+        if (c >= c_real) continue;
+        float a = 0.f;
+        for (int b = 0; b < nblk; ++b) a += part[(size_t)b * total + i];
+        float* o = out + (size_t)k * c_real + c;
+        *o = accumulate ? *o + a : a;
+    }
+}
+
+// ---------------------------------------------------------------------------------- BatchNorm (train)
+// forward statistics: partial (sum x, sum x^2) per channel
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C,
+                                                       float* __restrict__ part, int rows_per_blk) {
+    const int Gall = C / 4, G = Gall < 256 ? Gall : 256;          // blockIdx.y tiles the channel groups
+    const int tl = threadIdx.x % G, tr = threadIdx.x / G, TR = 256 / G;
+    const int tg = blockIdx.y * G + tl;
+    const bool cok = tg < Gall && tr < TR;
+    const long long r0 = (long long)blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (cok)
+        for (long long r = r0 + tr; r < r1; r += TR) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + tg * 4);
+            s += v; q += v * v;
+        }
+    __shared__ f32x4 red[2][256];
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < G && blockIdx.y * G + threadIdx.x < Gall) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < TR; ++k) { a += red[0][k * G + threadIdx.x]; b += red[1][k * G + threadIdx.x]; }
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + (blockIdx.y * G + threadIdx.x) * 4) = a;
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + (blockIdx.y * G + threadIdx.x) * 4) = b;
+    }
+}
+
+// y = act((x - mean) * invstd * gamma + beta + residual)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ residual,
+                                                       int act, long long M, int C, float* __restrict__ y) {
+    const int G = C / 4;
+    const long long total = M * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        const size_t o = (size_t)(i / G) * C + g * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + o);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * 4), is = *reinterpret_cast<const f32x4*>(invstd + g * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4), be = *reinterpret_cast<const f32x4*>(beta + g * 4);
+        f32x4 r = (v - mu) * is * ga + be;
+        if (residual) r += *reinterpret_cast<const f32x4*>(residual + o);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + o) = r;
+    }
+}
+
+// backward reduce: g = dy * act'(y); partial (sum g, sum g * xhat); optionally writes g (masked grad) to dres
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int act, long long M, int C,
+                                                            float* __restrict__ part, int rows_per_blk) {
+    const int Gall = C / 4, G = Gall < 256 ? Gall : 256;          // blockIdx.y tiles the channel groups
+    const int tl = threadIdx.x % G, tr = threadIdx.x / G, TR = 256 / G;
+    const int tg = blockIdx.y * G + tl;
+    const bool cok = tg < Gall && tr < TR;
+    const long long r0 = (long long)blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + tg * 4), is = *reinterpret_cast<const f32x4*>(invstd + tg * 4);
+        for (long long r = r0 + tr; r < r1; r += TR) {
+            const size_t o = (size_t)r * C + tg * 4;
+            f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+            if (act == 1) {
+                const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+            }
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+            s += g; q += g * xh;
+        }
+    }
+    __shared__ f32x4 red[2][256];
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < G && blockIdx.y * G + threadIdx.x < Gall) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < TR; ++k) { a += red[0][k * G + threadIdx.x]; b += red[1][k * G + threadIdx.x]; }
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + (blockIdx.y * G + threadIdx.x) * 4) = a;
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + (blockIdx.y * G + threadIdx.x) * 4) = b;
+    }
+}
+
+// dx = gamma*invstd * (g - sum_g/N - xhat * sum_gx/N);  dres = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, float inv_count, int act,
+                                                           long long M, int C, float* __restrict__ dx,
+                                                           float* __restrict__ dres) {
+    const int G = C / 4;
+    const long long total = M * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g4 = (int)(i % G);
+        const size_t o = (size_t)(i / G) * C + g4 * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        if (act == 1) {
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+        }
+        if (dres) *reinterpret_cast<f32x4*>(dres + o) = g;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + g4 * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g4 * 4);
+        const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + g4 * 4), sgx = *reinterpret_cast<const f32x4*>(sums + C + g4 * 4);
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+        *reinterpret_cast<f32x4*>(dx + o) = ga * is * (g - sg * inv_count - xh * sgx * inv_count);
+    }
+}
+
+// ---------------------------------------------------------------------------------- max-pool 3x3 / stride 2 / pad 1
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho, int Wo,
+                                                          float* __restrict__ y, uint8_t* __restrict__ arg) {
+    const int G = C / 4;
+    const long long total = (long long)B * Ho * Wo * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        long long pix = i / G;
+        const int ox = (int)(pix % Wo); pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + g * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e] || (v[e] != v[e])) { best[e] = v[e]; bi[e] = ky * 3 + kx; }
+            }
+        const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * C + g * 4;
+        *reinterpret_cast<f32x4*>(y + o) = best;
+        if (arg) *reinterpret_cast<uint32_t*>(arg + o) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg, int B,
+                                                          int H, int W, int C, int Ho, int Wo, float* __restrict__ dx) {
+    const int G = C / 4;
+    const long long total = (long long)B * H * W * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        long long pix = i / G;
+        const int ix = (int)(pix % W); pix /= W;
+        const int iy = (int)(pix % H);
+        const int b = (int)(pix / H);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        // outputs whose window [2o-1, 2o+1] contains this pixel
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy >= Ho) continue;
+            const int ky = iy - (oy * 2 - 1);
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= Wo) continue;
+                const int kx = ix - (ox * 2 - 1);
+                const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * C + g * 4;
+                const uint32_t pk = *reinterpret_cast<const uint32_t*>(arg + o);
+                const f32x4 gd = *reinterpret_cast<const f32x4*>(dy + o);
+                const uint32_t me = (uint32_t)(ky * 3 + kx);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((pk >> (8 * e)) & 0xFF) == me) a[e] += gd[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + iy) * W + ix) * C + g * 4) = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------- depthwise 5x5, stride 1, pad 2
+// weights repacked [25][C].  mode 0: forward (optionally affine + ReLU), mode 1: data gradient (flipped taps)
+__global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w25c,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                      int B, int H, int W, int C, int flip, float* __restrict__ y) {
+    const int G = C / 4;
+    const long long total = (long long)B * H * W * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        long long pix = i / G;
+        const int ox = (int)(pix % W); pix /= W;
+        const int oy = (int)(pix % H);
+        const int b = (int)(pix / H);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const int iy = oy - 2 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int ix = ox - 2 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const int tap = flip ? (4 - ky) * 5 + (4 - kx) : ky * 5 + kx;
+                a += *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + g * 4) *
+                     *reinterpret_cast<const f32x4*>(w25c + (size_t)tap * C + g * 4);
+            }
+        }
+        if (scale) a = a * *reinterpret_cast<const f32x4*>(scale + g * 4);
+        if (shift) a += *reinterpret_cast<const f32x4*>(shift + g * 4);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + (((size_t)b * H + oy) * W + ox) * C + g * 4) = a;
+    }
+}
+
+// depthwise weight gradient partials: part[blk][25][C]
+__global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, int B, int H,
+                                                            int W, int C, float* __restrict__ part, int rows_per_blk) {
+    const int Gall = C / 4, G = Gall < 256 ? Gall : 256;          // blockIdx.y tiles the channel groups
+    const int tl = threadIdx.x % G, tr = threadIdx.x / G, TR = 256 / G;
+    const int tg = blockIdx.y * G + tl;
+    const bool cok = tg < Gall && tr < TR;
+    const long long M = (long long)B * H * W;
+    const long long r0 = (long long)blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    __shared__ f32x4 red[256];
+    for (int tap = 0; tap < 25; ++tap) {
+        const int ky = tap / 5, kx = tap % 5;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (cok)
+            for (long long r = r0 + tr; r < r1; r += TR) {
+                const int ox = (int)(r % W), oy = (int)((r / W) % H), b = (int)(r / ((long long)W * H));
+                const int iy = oy - 2 + ky, ix = ox - 2 + kx;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                a += *reinterpret_cast<const f32x4*>(dz + (size_t)r * C + tg * 4) *
+                     *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + tg * 4);
+            }
+        __syncthreads();
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < G && blockIdx.y * G + threadIdx.x < Gall) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < TR; ++k) t += red[k * G + threadIdx.x];
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 25 + tap) * C + (blockIdx.y * G + threadIdx.x) * 4) = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- bilinear resize (NHWC)
+__device__ __forceinline__ void bil_src(int align, float ratio, int dst, int in_size, int out_size, int& i0, int& i1, float& l0,
+                                        float& l1) {
+    float r;
+    if (align) r = ratio * (float)dst;                          // ratio = (in-1)/(out-1)
+    else {
+        if (in_size == out_size) { i0 = i1 = dst; l0 = 1.f; l1 = 0.f; return; }
+        r = ratio * ((float)dst + 0.5f) - 0.5f;                 // ratio = in/out
+        r = r < 0.f ? 0.f : r;
+    }
+    i0 = min((int)floorf(r), in_size - 1);
+    l1 = fminf(fmaxf(r - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho, int Wo,
+                                                           int align, float rh, float rw, float* __restrict__ y, int Cy, int c_off) {
+    const int G = C / 4;
+    const long long total = (long long)B * Ho * Wo * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        long long pix = i / G;
+        const int ox = (int)(pix % Wo); pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        bil_src(align, rh, oy, H, Ho, y0, y1, ly0, ly1);
+        bil_src(align, rw, ox, W, Wo, x0, x1, lx0, lx1);
+        const float* base = x + (size_t)b * H * W * C + g * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * C);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * C);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * C);
+        const f32x4 r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        *reinterpret_cast<f32x4*>(y + (((size_t)b * Ho + oy) * Wo + ox) * Cy + c_off + g * 4) = r;
+    }
+}
+
+// transposed resize as a gather over INPUT pixels (deterministic): dx[i] = sum_o w(o,i) dy[o]
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, int Ho, int Wo,
+                                                           int align, float rh, float rw, int Cy, int c_off,
+                                                           float* __restrict__ dx) {
+    const int G = C / 4;
+    const long long total = (long long)B * H * W * G;
+    const float inv_rh = rh > 0.f ? 1.f / rh : (float)Ho, inv_rw = rw > 0.f ? 1.f / rw : (float)Wo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        long long pix = i / G;
+        const int ix = (int)(pix % W); pix /= W;
+        const int iy = (int)(pix % H);
+        const int b = (int)(pix / H);
+        // output rows that can touch input row iy: src(o) in (iy-1, iy+1)  =>  o in ((iy-1.5)/r, (iy+1.5)/r) (+-1 slack)
+        const int oy_lo = max(0, (int)floorf(((float)iy - 1.5f) * inv_rh) - 1), oy_hi = min(Ho - 1, (int)ceilf(((float)iy + 1.5f) * inv_rh) + 1);
+        const int ox_lo = max(0, (int)floorf(((float)ix - 1.5f) * inv_rw) - 1), ox_hi = min(Wo - 1, (int)ceilf(((float)ix + 1.5f) * inv_rw) + 1);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly0, ly1;
+            bil_src(align, rh, oy, H, Ho, y0, y1, ly0, ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx0, lx1;
+                bil_src(align, rw, ox, W, Wo, x0, x1, lx0, lx1);
+                const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                a += (wy * wx) * *reinterpret_cast<const f32x4*>(dy + (((size_t)b * Ho + oy) * Wo + ox) * Cy + c_off + g * 4);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + iy) * W + ix) * C + g * 4) = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------- channel softmax / sigmoid-depth
+// x, y: [M][Cp] with C real channels (padding channels of y are written as 0)
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, long long M, int C, int Cp,
+                                                          float* __restrict__ y) {
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+        const float* px = x + (size_t)r * Cp;
+        float v[32];
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) { v[c] = px[c]; mx = fmaxf(mx, v[c]); }
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); s += v[c]; }
+        float* py = y + (size_t)r * Cp;
+        for (int c = 0; c < C; ++c) py[c] = v[c] / s;
+        for (int c = C; c < Cp; ++c) py[c] = 0.f;
+    }
+}
+
+// dx = y * (dy - sum_c dy*y)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long M,
+                                                          int C, int Cp, float* __restrict__ dx) {
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+        const float* pd = dy + (size_t)r * Cp;
+        const float* py = y + (size_t)r * Cp;
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot += pd[c] * py[c];
+        float* po = dx + (size_t)r * Cp;
+        for (int c = 0; c < C; ++c) po[c] = py[c] * (pd[c] - dot);
+        for (int c = C; c < Cp; ++c) po[c] = 0.f;
+    }
+}
+
+// logits [M][Cp] channel 0 -> disp = sigmoid, depth = 1 / (min_disp + (max_disp - min_disp) * disp)   (planar outputs [M])
+__global__ __launch_bounds__(256) void disp_depth_fwd_kernel(const float* __restrict__ x, long long M, int Cp, float min_disp,
+                                                             float max_disp, float* __restrict__ disp, float* __restrict__ depth) {
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+        const float s = 1.f / (1.f + expf(-x[(size_t)r * Cp]));
+        disp[r] = s;
+        depth[r] = 1.f / (min_disp + (max_disp - min_disp) * s);
+    }
+}
+
+// dlogit (written into channel 0 of a zeroed [M][Cp] row) = (ddisp + ddepth * d depth/d disp) * s(1-s)
+__global__ __launch_bounds__(256) void disp_depth_bwd_kernel(const float* __restrict__ ddisp, const float* __restrict__ ddepth,
+                                                             const float* __restrict__ disp, long long M, int Cp, float min_disp,
+                                                             float max_disp, float* __restrict__ dx) {
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+        const float s = disp[r];
+        const float sd = min_disp + (max_disp - min_disp) * s;
+        float g = 0.f;
+        if (ddisp) g += ddisp[r];
+        if (ddepth) g += ddepth[r] * (-(max_disp - min_disp) / (sd * sd));
+        float* po = dx + (size_t)r * Cp;
+        po[0] = g * s * (1.f - s);
+        for (int c = 1; c < Cp; ++c) po[c] = 0.f;
+    }
+}
+
+static int rows_per_block(long long M, int& nblk) {
+    // aim for <= 1024 partial blocks, >= 256 rows each
+    long long rpb = std::max<long long>(256, (M + 1023) / 1024);
+    nblk = (int)((M + rpb - 1) / rpb);
+    return (int)rpb;
+}
+
+static int check_colsum_c(int C, const char* who) {
+    CODEPS_REQUIRE(C >= 4 && (C % 4) == 0, CODEPS_ERR_ARG, "%s: channel count %d must be a positive multiple of 4", who, C);
+    return CODEPS_OK;
+}
+static inline int col_tiles(int C) { return cdiv(C / 4, 256); }
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" int codeps_nchw_to_nhwc(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off, int zero_rest,
+                                   codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0 && (c_pad % 4) == 0 && c_off >= 0 && c_off + c <= c_pad,
+                   CODEPS_ERR_ARG, "nchw_to_nhwc: bad arguments");
+    const long long items = (long long)batch * h * w * (zero_rest ? c_pad / 4 : (c + 3) / 4);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, x, batch, c, h, w, y, c_pad,
+                       c_off, zero_rest);
+    CODEPS_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_nhwc_to_nchw(const float* x, int batch, int c, int h, int w, int c_pad, float* y, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && y && batch > 0 && c > 0 && c <= c_pad && h > 0 && w > 0, CODEPS_ERR_ARG, "nhwc_to_nchw: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)batch * c * h * w)), dim3(256), 0, (hipStream_t)stream, x, batch,
+                       c, h, w, c_pad, y);
+    CODEPS_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" size_t codeps_colsum_workspace_bytes(long long rows, int c, int k) {
+    int nblk;
+    rows_per_block(rows, nblk);
+    return (size_t)nblk * k * c * sizeof(float);
+}
+
+extern "C" int codeps_act_bwd(const float* dy, const float* y, const float* scale, int act, long long rows, int c, float* dz,
+                              float* dbias, int c_real, int accumulate, void* workspace, size_t workspace_bytes,
+                              codeps_stream_t stream) {
+    CODEPS_REQUIRE(dy && rows > 0 && (dz || dbias) && (act == 0 || y), CODEPS_ERR_ARG, "act_bwd: bad arguments");
+    int rc = check_colsum_c(c, "act_bwd");
+    if (rc) return rc;
+    int nblk;
+    const int rpb = rows_per_block(rows, nblk);
+    float* part = nullptr;
+    if (dbias) {
+        CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * c * 4, CODEPS_ERR_WORKSPACE, "act_bwd: workspace too small");
+        part = (float*)workspace;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, dy, y, scale, act, rows, c, dz, part, rpb);
+    CODEPS_CHECK_LAUNCH("act_bwd_kernel");
+    if (dbias) {
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, part, nblk, 1, c, dbias, c_real, accumulate);
+        CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
+    }
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_stats(const float* x, long long rows, int c, float* sums /*[2][c]*/, void* workspace, size_t workspace_bytes,
+                               codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && sums && rows > 0, CODEPS_ERR_ARG, "bn_stats: bad arguments");
+    int rc = check_colsum_c(c, "bn_stats");
+    if (rc) return rc;
+    int nblk;
+    const int rpb = rows_per_block(rows, nblk);
+    CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * 2 * c * 4, CODEPS_ERR_WORKSPACE, "bn_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, rows, c, (float*)workspace, rpb);
+    CODEPS_CHECK_LAUNCH("bn_stats_kernel");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
+    CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               const float* residual, int act, long long rows, int c, float* y, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && mean && invstd && gamma && beta && y && rows > 0 && (c % 4) == 0 && act >= 0 && act <= 1, CODEPS_ERR_ARG,
+                   "bn_apply: bad arguments");
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
+                       residual, act, rows, c, y);
+    CODEPS_CHECK_LAUNCH("bn_apply_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd, int act,
+                                    long long rows, int c, float* sums /*[2][c]*/, void* workspace, size_t workspace_bytes,
+                                    codeps_stream_t stream) {
+    CODEPS_REQUIRE(dy && x && mean && invstd && sums && rows > 0 && (act == 0 || y), CODEPS_ERR_ARG, "bn_bwd_reduce: bad arguments");
+    int rc = check_colsum_c(c, "bn_bwd_reduce");
+    if (rc) return rc;
+    int nblk;
+    const int rpb = rows_per_block(rows, nblk);
+    CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * 2 * c * 4, CODEPS_ERR_WORKSPACE, "bn_bwd_reduce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, dy, y, x, mean, invstd, act, rows, c, (float*)workspace, rpb);
+    CODEPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
+    CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                   const float* gamma, const float* sums, float inv_count, int act, long long rows, int c, float* dx,
+                                   float* dres, codeps_stream_t stream) {
+    CODEPS_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && rows > 0 && (c % 4) == 0 && (act == 0 || y), CODEPS_ERR_ARG,
+                   "bn_bwd_apply: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, invstd,
+                       gamma, sums, inv_count, act, rows, c, dx, dres);
+    CODEPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_maxpool3x3s2_fwd(const float* x, int batch, int h, int w, int c, float* y, uint8_t* argmax, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && y && batch > 0 && h > 0 && w > 0 && (c % 4) == 0, CODEPS_ERR_ARG, "maxpool_fwd: bad arguments");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)batch * ho * wo * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, batch,
+                       h, w, c, ho, wo, y, argmax);
+    CODEPS_CHECK_LAUNCH("maxpool_fwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, int batch, int h, int w, int c, float* dx,
+                                       codeps_stream_t stream) {
+    CODEPS_REQUIRE(dy && argmax && dx && batch > 0 && (c % 4) == 0, CODEPS_ERR_ARG, "maxpool_bwd: bad arguments");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)batch * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, dy, argmax,
+                       batch, h, w, c, ho, wo, dx);
+    CODEPS_CHECK_LAUNCH("maxpool_bwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_dwconv5x5(const float* x, const float* w25c, const float* scale, const float* shift, int act, int batch, int h,
+                                int w, int c, int flip, float* y, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && w25c && y && batch > 0 && h > 0 && w > 0 && (c % 4) == 0, CODEPS_ERR_ARG, "dwconv5x5: bad arguments");
+    hipLaunchKernelGGL(dwconv5_kernel, dim3(grid_for((long long)batch * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, w25c, scale,
+                       shift, act, batch, h, w, c, flip, y);
+    CODEPS_CHECK_LAUNCH("dwconv5_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_dwconv5x5_wgrad(const float* x, const float* dz, int batch, int h, int w, int c, float* dw25c, void* workspace,
+                                      size_t workspace_bytes, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && dz && dw25c && batch > 0, CODEPS_ERR_ARG, "dwconv5x5_wgrad: bad arguments");
+    int rc = check_colsum_c(c, "dwconv5x5_wgrad");
+    if (rc) return rc;
+    int nblk;
+    const int rpb = rows_per_block((long long)batch * h * w, nblk);
+    CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * 25 * c * 4, CODEPS_ERR_WORKSPACE, "dwconv5x5_wgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, dz, batch, h, w, c, (float*)workspace, rpb);
+    CODEPS_CHECK_LAUNCH("dwconv5_wgrad_kernel");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(25 * c, 256)), dim3(256), 0, st, (const float*)workspace, nblk, 25, c, dw25c, c, 0);
+    CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
+    return CODEPS_OK;
+}
+
+static void resize_ratios(int align, int h, int w, int ho, int wo, float& rh, float& rw) {
+    if (align) {
+        rh = ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f;
+        rw = wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+    } else {
+        rh = (float)h / (float)ho;
+        rw = (float)w / (float)wo;
+    }
+}
+
+extern "C" int codeps_bilinear_fwd(const float* x, int batch, int h, int w, int c, int out_h, int out_w, int align_corners, float* y,
+                                   int y_c, int y_c_off, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && y && batch > 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0 && (c % 4) == 0 && (y_c % 4) == 0 &&
+                       (y_c_off % 4) == 0 && y_c_off + c <= y_c,
+                   CODEPS_ERR_ARG, "bilinear_fwd: bad arguments");
+    float rh, rw;
+    resize_ratios(align_corners, h, w, out_h, out_w, rh, rw);
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for((long long)batch * out_h * out_w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                       batch, h, w, c, out_h, out_w, align_corners, rh, rw, y, y_c, y_c_off);
+    CODEPS_CHECK_LAUNCH("bilinear_fwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bilinear_bwd(const float* dy, int batch, int h, int w, int c, int out_h, int out_w, int align_corners, int y_c,
+                                   int y_c_off, float* dx, codeps_stream_t stream) {
+    CODEPS_REQUIRE(dy && dx && batch > 0 && h > 0 && w > 0 && out_h >= h && out_w >= w && (c % 4) == 0 && (y_c % 4) == 0 &&
+                       (y_c_off % 4) == 0 && y_c_off + c <= y_c,
+                   CODEPS_ERR_ARG, "bilinear_bwd: bad arguments (only up-sampling is differentiated)");
+    float rh, rw;
+    resize_ratios(align_corners, h, w, out_h, out_w, rh, rw);
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long long)batch * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, dy, batch, h,
+                       w, c, out_h, out_w, align_corners, rh, rw, y_c, y_c_off, dx);
+    CODEPS_CHECK_LAUNCH("bilinear_bwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_softmax_fwd(const float* x, long long rows, int c, int c_pad, float* y, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && y && rows > 0 && c > 0 && c <= 32 && c <= c_pad, CODEPS_ERR_ARG, "softmax_fwd: bad arguments (c <= 32)");
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, c, c_pad, y);
+    CODEPS_CHECK_LAUNCH("softmax_fwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_softmax_bwd(const float* dy, const float* y, long long rows, int c, int c_pad, float* dx, codeps_stream_t stream) {
+    CODEPS_REQUIRE(dy && y && dx && rows > 0 && c > 0 && c <= c_pad, CODEPS_ERR_ARG, "softmax_bwd: bad arguments");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, dy, y, rows, c, c_pad, dx);
+    CODEPS_CHECK_LAUNCH("softmax_bwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_disp_depth_fwd(const float* logits, long long rows, int c_pad, float min_depth, float max_depth, float* disp,
+                                     float* depth, codeps_stream_t stream) {
+    CODEPS_REQUIRE(logits && disp && depth && rows > 0 && c_pad > 0 && min_depth > 0 && max_depth > min_depth, CODEPS_ERR_ARG,
+                   "disp_depth_fwd: bad arguments");
+    hipLaunchKernelGGL(disp_depth_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, logits, rows, c_pad,
+                       (float)(1.0 / (double)max_depth), (float)(1.0 / (double)min_depth), disp, depth);
+    CODEPS_CHECK_LAUNCH("disp_depth_fwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_disp_depth_bwd(const float* ddisp, const float* ddepth, const float* disp, long long rows, int c_pad,
+                                     float min_depth, float max_depth, float* dlogits, codeps_stream_t stream) {
+    CODEPS_REQUIRE(disp && dlogits && (ddisp || ddepth) && rows > 0, CODEPS_ERR_ARG, "disp_depth_bwd: bad arguments");
+    hipLaunchKernelGGL(disp_depth_bwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, ddisp, ddepth, disp, rows, c_pad,
+                       (float)(1.0 / (double)max_depth), (float)(1.0 / (double)min_depth), dlogits);
+    CODEPS_CHECK_LAUNCH("disp_depth_bwd_kernel");
+    return CODEPS_OK;
+}

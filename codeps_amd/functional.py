@@ -70,3 +70,488 @@ def photometric_loss(images, depth, poses, intrinsics, num_scales=5, alpha=0.85,
     return _PhotometricLoss.apply(images[0], images[1], images[2], depth, poses[0].reshape(-1, 16),
                                   poses[1].reshape(-1, 16), intrinsics, noise, int(num_scales), float(alpha),
                                   int(seed))
+
+
+# =============================================================================================
+# NHWC activations.  Inside codeps_amd every feature map is a contiguous fp32 tensor [B, H, W, Cp]
+# with Cp = channel count padded to a multiple of 16 (padding channels hold zeros).  The reference's
+# NCHW interface is kept at module boundaries through zero-copy views (see `to_nchw` / `from_nchw`).
+# =============================================================================================
+def pad16(c):
+    return (int(c) + 15) // 16 * 16
+
+
+def from_nchw(x, c_pad=None):
+    """NCHW tensor (any strides) -> NHWC [B,H,W,Cp].  Zero-copy when `x` is a view handed out by
+    `to_nchw` (or any channels-last view of the right width); otherwise one layout-conversion kernel."""
+    require_cuda(x)
+    b, c, h, w = x.shape
+    cp = pad16(c) if c_pad is None else c_pad
+    base = getattr(x, "_codeps_nhwc", None)        # padded NHWC parent of a to_nchw() view
+    if base is not None and tuple(base.shape) == (b, h, w, cp):
+        return base
+    if x.dtype == torch.float32 and c == cp and x.stride(1) == 1 and x.permute(0, 2, 3, 1).is_contiguous():
+        return x.permute(0, 2, 3, 1)
+    return _NchwToNhwc.apply(x, cp)
+
+
+class _NchwToNhwc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cp):
+        x = _f32c(x)
+        b, c, h, w = x.shape
+        ctx.c = c
+        y = torch.empty(b, h, w, cp, dtype=torch.float32, device=x.device)
+        check(lib().codeps_nchw_to_nhwc(ptr(x), b, c, h, w, ptr(y), cp, 0, 1, stream_ptr()), "codeps_nchw_to_nhwc")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy)
+        b, h, w, cp = dy.shape
+        dx = torch.empty(b, ctx.c, h, w, dtype=torch.float32, device=dy.device)
+        check(lib().codeps_nhwc_to_nchw(ptr(dy), b, ctx.c, h, w, cp, ptr(dx), stream_ptr()), "codeps_nhwc_to_nchw")
+        return dx, None
+
+
+def to_nchw(y, c):
+    """NHWC [B,H,W,Cp] -> NCHW-shaped zero-copy view [B,c,H,W] (channels-last strides)."""
+    v = y.permute(0, 3, 1, 2)[:, :c]
+    v._codeps_nhwc = y
+    return v
+
+
+def images_to_nhwc(images, c_pad=16):
+    """[B,3,H,W] NCHW image(s) -> one NHWC tensor with the images stacked along channels and zero
+    padding up to c_pad (stem input; two frames for the pose net)."""
+    imgs = [_f32c(i) for i in images]
+    require_cuda(*imgs)
+    b, c, h, w = imgs[0].shape
+    y = torch.empty(b, h, w, c_pad, dtype=torch.float32, device=imgs[0].device)
+    for k, im in enumerate(imgs):
+        check(lib().codeps_nchw_to_nhwc(ptr(im), b, c, h, w, ptr(y), c_pad, k * c, 1 if k == 0 else 0, stream_ptr()),
+              "codeps_nchw_to_nhwc")
+    return y
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    """Per-(device, tag) scratch buffer, grown on demand (stream-ordered reuse, like a cuDNN workspace)."""
+    key = (device.index, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+_pack_cache = {}
+
+
+def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
+    """OIHW parameter -> (w_fwd, w_dgrad) packs.  Packs of frozen parameters are cached on
+    (storage, version); trainable ones are repacked every call (they change every step)."""
+    key = None
+    if not weight.requires_grad:
+        key = (weight.data_ptr(), weight._version, out_c_pad, in_c_pad)
+        hit = _pack_cache.get(key)
+        if hit is not None and (hit[1] is not None or not need_dgrad):
+            return hit
+    co, ci, kh, kw = weight.shape
+    w = _f32c(weight.detach())
+    wf = torch.empty(out_c_pad * kh * kw * in_c_pad, dtype=torch.float32, device=w.device)
+    wd = torch.empty_like(wf) if need_dgrad else None
+    check(lib().codeps_conv2d_pack_weights(co, ci, kh, kw, out_c_pad, in_c_pad, ptr(w), ptr(wf), ptr(wd), stream_ptr()),
+          "codeps_conv2d_pack_weights")
+    if key is not None:
+        _pack_cache[key] = (wf, wd)
+    return wf, wd
+
+
+def _pad_vec(v, n):
+    if v is None:
+        return None
+    v = _f32c(v.detach())
+    if v.numel() == n:
+        return v
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v
+    return out
+
+
+def _conv_desc(x0, x1, out_c_pad, kh, kw, stride, pad, pad_mode, act, up0):
+    b = x0.shape[0]
+    c0 = x0.shape[3]
+    c1 = 0 if x1 is None else x1.shape[3]
+    if up0:
+        h, w = x0.shape[1] * 2, x0.shape[2] * 2
+    else:
+        h, w = x0.shape[1], x0.shape[2]
+    if x1 is not None and (x1.shape[1] != h or x1.shape[2] != w):
+        raise _lib.CodepsHipError(f"conv2d: skip tensor is {tuple(x1.shape[1:3])}, expected {(h, w)}")
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    return _lib.ConvDesc(b, h, w, c0, c1, int(up0), out_c_pad, ho, wo, kh, kw, stride, pad, pad_mode, act)
+
+
+ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = act(conv(cat(up(x0), x1), W) * scale + shift + residual) on NHWC tensors (C ABI conv2d)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, scale, shift, residual, stride, pad, pad_mode, act, up0):
+        require_cuda(x0, x1, weight)
+        co, ci, kh, kw = weight.shape
+        cop = pad16(co)
+        c_in = x0.shape[3] + (0 if x1 is None else x1.shape[3])
+        if x1 is not None and c_in != ci:
+            raise _lib.CodepsHipError("conv2d: concat sources must not carry channel padding")
+        need_dgrad = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
+        wf, wd = pack_weights(weight, cop, c_in, need_dgrad)
+        desc = _conv_desc(x0, x1, cop, kh, kw, stride, pad, pad_mode, act, up0)
+        sc = _pad_vec(scale, cop)
+        sh = _pad_vec(shift if shift is not None else bias, cop)
+        if residual is not None:
+            residual = residual.contiguous()
+        y = torch.empty(desc.batch, desc.out_h, desc.out_w, cop, dtype=torch.float32, device=x0.device)
+        check(lib().codeps_conv2d_fwd(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
+                                      stream_ptr()), "codeps_conv2d_fwd")
+        ctx.desc, ctx.co, ctx.ci, ctx.has_bias = desc, co, ci, bias is not None
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x0, x1, y if act else None, wd, sc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, y, wd, sc = ctx.saved_tensors
+        desc = ctx.desc
+        dy = dy.contiguous()
+        rows, cop = dy.numel() // dy.shape[-1], dy.shape[-1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        dbias = torch.empty(ctx.co, dtype=torch.float32, device=dy.device) if need_b else None
+        dres = None
+        if desc.act or sc is not None or need_b:
+            wsb = lib().codeps_colsum_workspace_bytes(rows, cop, 1)
+            ws = _workspace(wsb, dy.device, "colsum")
+            if ctx.has_res and ctx.needs_input_grad[6] and sc is not None:
+                dres = torch.empty_like(dy)
+                check(lib().codeps_act_bwd(ptr(dy), ptr(y), None, desc.act, rows, cop, ptr(dres), None, ctx.co, 0, ptr(ws),
+                                           ws.numel(), stream_ptr()), "codeps_act_bwd")
+            dz = torch.empty_like(dy) if (desc.act or sc is not None) else dy
+            check(lib().codeps_act_bwd(ptr(dy), ptr(y), ptr(sc), desc.act, rows, cop, ptr(dz) if dz is not dy else None,
+                                       ptr(dbias), ctx.co, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_act_bwd")
+        else:
+            dz = dy
+        if ctx.has_res and ctx.needs_input_grad[6] and dres is None:
+            dres = dz
+        dx0 = dx1 = dw = None
+        if ctx.needs_input_grad[0]:
+            dx0 = torch.empty_like(x0)
+            check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(dx0), stream_ptr()),
+                  "codeps_conv2d_dgrad")
+        if x1 is not None and ctx.needs_input_grad[1]:
+            dx1 = torch.empty_like(x1)
+            check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 1, ptr(dz), ptr(wd), ptr(dx1), stream_ptr()),
+                  "codeps_conv2d_dgrad")
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty(ctx.co, ctx.ci, desc.kh, desc.kw, dtype=torch.float32, device=dy.device)
+            wsb = lib().codeps_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
+            ws = _workspace(wsb, dy.device, "wgrad")
+            check(lib().codeps_conv2d_wgrad(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(dz), ptr(dw), ctx.co, ctx.ci, 0, ptr(ws),
+                                            ws.numel(), stream_ptr()), "codeps_conv2d_wgrad")
+        return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None
+
+
+def conv2d(x0, weight, bias=None, *, x1=None, scale=None, shift=None, residual=None, stride=1, pad=0, pad_mode="zeros",
+           act=None, up0=False):
+    """NHWC convolution.  x0 [B,H,W,C0p]; optional skip x1 concatenated along channels after an
+    optional nearest-x2 upsample of x0; weight OIHW; returns [B,Ho,Wo,pad16(Cout)]."""
+    return _Conv2d.apply(x0, x1, weight, bias, scale, shift, residual, int(stride), int(pad),
+                         1 if pad_mode == "reflect" else 0, ACT[act], bool(up0))
+
+
+# ---------------------------------------------------------------------------------------- BatchNorm
+def bn_fold(weight, bias, running_mean, running_var, eps):
+    """Eval-mode BatchNorm as a per-channel affine (scale, shift) for the conv epilogue."""
+    scale = weight.detach() * torch.rsqrt(running_var + eps)
+    return scale, bias.detach() - running_mean * scale
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """Train-mode BatchNorm (+ residual, + ReLU) on NHWC with batch statistics; the raw sums pass
+    through `reduce_fn` (an all-reduce over ranks for SyncBN, identity otherwise)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, reduce_fn):
+        require_cuda(x, gamma, beta)
+        x = x.contiguous()
+        cp = x.shape[-1]
+        rows = x.numel() // cp
+        c = gamma.numel()
+        sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
+        wsb = lib().codeps_colsum_workspace_bytes(rows, cp, 2)
+        ws = _workspace(wsb, x.device, "colsum")
+        check(lib().codeps_bn_stats(ptr(x), rows, cp, ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_stats")
+        count = float(rows)
+        if reduce_fn is not None:
+            sums, count = reduce_fn(sums, count)
+        mean = sums[0] / count
+        var = (sums[1] / count - mean * mean).clamp_(min=0)
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean[:c], alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var[:c] * (count / max(count - 1, 1)), alpha=momentum)
+        g, b_ = _pad_vec(gamma, cp), _pad_vec(beta, cp)
+        if residual is not None:
+            residual = residual.contiguous()
+        y = torch.empty_like(x)
+        check(lib().codeps_bn_apply(ptr(x), ptr(mean), ptr(invstd), ptr(g), ptr(b_), ptr(residual), act, rows, cp, ptr(y),
+                                    stream_ptr()), "codeps_bn_apply")
+        ctx.save_for_backward(x, y if act else None, mean, invstd, g)
+        ctx.act, ctx.c, ctx.count, ctx.reduce_fn, ctx.has_res = act, c, count, reduce_fn, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        cp = x.shape[-1]
+        rows = x.numel() // cp
+        sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
+        wsb = lib().codeps_colsum_workspace_bytes(rows, cp, 2)
+        ws = _workspace(wsb, x.device, "colsum")
+        check(lib().codeps_bn_bwd_reduce(ptr(dy), ptr(y), ptr(x), ptr(mean), ptr(invstd), ctx.act, rows, cp, ptr(sums), ptr(ws),
+                                         ws.numel(), stream_ptr()), "codeps_bn_bwd_reduce")
+        dgamma, dbeta = sums[1, :ctx.c].clone(), sums[0, :ctx.c].clone()      # local (DDP averages them later)
+        if ctx.reduce_fn is not None:
+            sums, _ = ctx.reduce_fn(sums, 0.0)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        check(lib().codeps_bn_bwd_apply(ptr(dy), ptr(y), ptr(x), ptr(mean), ptr(invstd), ptr(g), ptr(sums), 1.0 / ctx.count,
+                                        ctx.act, rows, cp, ptr(dx), ptr(dres), stream_ptr()), "codeps_bn_bwd_apply")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None, act=None,
+                     reduce_fn=None):
+    return _BatchNormTrain.apply(x, gamma, beta, residual, running_mean, running_var, float(momentum), float(eps), ACT[act],
+                                 reduce_fn)
+
+
+# ---------------------------------------------------------------------------------------- pooling / resize
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x)
+        x = x.contiguous()
+        b, h, w, c = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty(b, ho, wo, c, dtype=torch.float32, device=x.device)
+        arg = torch.empty(b, ho, wo, c, dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+        check(lib().codeps_maxpool3x3s2_fwd(ptr(x), b, h, w, c, ptr(y), ptr(arg), stream_ptr()), "codeps_maxpool3x3s2_fwd")
+        ctx.save_for_backward(arg)
+        ctx.shape = (b, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        b, h, w, c = ctx.shape
+        dx = torch.empty(b, h, w, c, dtype=torch.float32, device=dy.device)
+        check(lib().codeps_maxpool3x3s2_bwd(ptr(dy.contiguous()), ptr(arg), b, h, w, c, ptr(dx), stream_ptr()),
+              "codeps_maxpool3x3s2_bwd")
+        return dx
+
+
+def max_pool3x3s2(x):
+    return _MaxPool.apply(x)
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_h, out_w, align, out, c_off):
+        require_cuda(x)
+        x = x.contiguous()
+        b, h, w, c = x.shape
+        if out is None:
+            out, c_off = torch.empty(b, out_h, out_w, c, dtype=torch.float32, device=x.device), 0
+            ctx.mark = False
+        else:
+            ctx.mark_dirty(out)
+            ctx.mark = True
+        check(lib().codeps_bilinear_fwd(ptr(x), b, h, w, c, out_h, out_w, int(align), ptr(out), out.shape[-1], c_off,
+                                        stream_ptr()), "codeps_bilinear_fwd")
+        ctx.geom = (b, h, w, c, out_h, out_w, int(align), out.shape[-1], c_off)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, h, w, c, oh, ow, align, yc, c_off = ctx.geom
+        dx = torch.empty(b, h, w, c, dtype=torch.float32, device=dy.device)
+        check(lib().codeps_bilinear_bwd(ptr(dy.contiguous()), b, h, w, c, oh, ow, align, yc, c_off, ptr(dx), stream_ptr()),
+              "codeps_bilinear_bwd")
+        return dx, None, None, None, (dy if ctx.mark else None), None
+
+
+def bilinear_resize(x, out_h, out_w, align_corners):
+    return _Bilinear.apply(x, int(out_h), int(out_w), bool(align_corners), None, 0)
+
+
+class _BilinearConcat(torch.autograd.Function):
+    """cat([resize(x_i)], channel) materialised once: every source is resized straight into its channel
+    slice of the destination (GUDA fusion, models/semantic_head.py:64-70; instance decoder cat)."""
+
+    @staticmethod
+    def forward(ctx, out_h, out_w, align, *xs):
+        require_cuda(*xs)
+        xs = [x.contiguous() for x in xs]
+        b = xs[0].shape[0]
+        ctot = sum(x.shape[-1] for x in xs)
+        out = torch.empty(b, out_h, out_w, ctot, dtype=torch.float32, device=xs[0].device)
+        off, geoms = 0, []
+        for x in xs:
+            _, h, w, c = x.shape
+            if (h, w) == (out_h, out_w):
+                out[..., off:off + c] = x            # same size: plain strided copy
+            else:
+                check(lib().codeps_bilinear_fwd(ptr(x), b, h, w, c, out_h, out_w, int(align), ptr(out), ctot, off,
+                                                stream_ptr()), "codeps_bilinear_fwd")
+            geoms.append((h, w, c, off))
+            off += c
+        ctx.geoms, ctx.meta = geoms, (b, out_h, out_w, int(align), ctot)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, oh, ow, align, ctot = ctx.meta
+        dy = dy.contiguous()
+        grads = []
+        for i, (h, w, c, off) in enumerate(ctx.geoms):
+            if not ctx.needs_input_grad[3 + i]:
+                grads.append(None)
+                continue
+            if (h, w) == (oh, ow):
+                grads.append(dy[..., off:off + c].contiguous())
+                continue
+            dx = torch.empty(b, h, w, c, dtype=torch.float32, device=dy.device)
+            check(lib().codeps_bilinear_bwd(ptr(dy), b, h, w, c, oh, ow, align, ctot, off, ptr(dx), stream_ptr()),
+                  "codeps_bilinear_bwd")
+            grads.append(dx)
+        return (None, None, None, *grads)
+
+
+def bilinear_concat(xs, out_h, out_w, align_corners):
+    return _BilinearConcat.apply(int(out_h), int(out_w), bool(align_corners), *xs)
+
+
+# ---------------------------------------------------------------------------------------- depthwise 5x5
+class _DwConv5(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, act):
+        require_cuda(x, weight)
+        x = x.contiguous()
+        b, h, w, c = x.shape
+        creal = weight.shape[0]
+        w25 = torch.zeros(25, c, dtype=torch.float32, device=x.device)
+        w25[:, :creal] = weight.detach().reshape(creal, 25).t()
+        sc, sh = _pad_vec(scale, c), _pad_vec(shift, c)
+        y = torch.empty_like(x)
+        check(lib().codeps_dwconv5x5(ptr(x), ptr(w25), ptr(sc), ptr(sh), act, b, h, w, c, 0, ptr(y), stream_ptr()),
+              "codeps_dwconv5x5")
+        ctx.save_for_backward(x, w25, y if act else None, sc)
+        ctx.act, ctx.creal = act, creal
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w25, y, sc = ctx.saved_tensors
+        b, h, w, c = x.shape
+        dy = dy.contiguous()
+        rows = b * h * w
+        if ctx.act or sc is not None:
+            dz = torch.empty_like(dy)
+            check(lib().codeps_act_bwd(ptr(dy), ptr(y), ptr(sc), ctx.act, rows, c, ptr(dz), None, c, 0, None, 0, stream_ptr()),
+                  "codeps_act_bwd")
+        else:
+            dz = dy
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib().codeps_dwconv5x5(ptr(dz), ptr(w25), None, None, 0, b, h, w, c, 1, ptr(dx), stream_ptr()),
+                  "codeps_dwconv5x5")
+        if ctx.needs_input_grad[1]:
+            d25 = torch.empty(25, c, dtype=torch.float32, device=x.device)
+            wsb = lib().codeps_colsum_workspace_bytes(rows, c, 25)
+            ws = _workspace(wsb, x.device, "colsum")
+            check(lib().codeps_dwconv5x5_wgrad(ptr(x), ptr(dz), b, h, w, c, ptr(d25), ptr(ws), ws.numel(), stream_ptr()),
+                  "codeps_dwconv5x5_wgrad")
+            dw = d25[:, :ctx.creal].t().reshape(ctx.creal, 1, 5, 5).contiguous()
+        return dx, dw, None, None, None
+
+
+def dwconv5x5(x, weight, scale=None, shift=None, act=None):
+    return _DwConv5.apply(x, weight, scale, shift, ACT[act])
+
+
+# ---------------------------------------------------------------------------------------- output heads
+class _Softmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        require_cuda(x)
+        x = x.contiguous()
+        cp = x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib().codeps_softmax_fwd(ptr(x), x.numel() // cp, c, cp, ptr(y), stream_ptr()), "codeps_softmax_fwd")
+        ctx.save_for_backward(y)
+        ctx.c = c
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        cp = y.shape[-1]
+        dx = torch.empty_like(y)
+        check(lib().codeps_softmax_bwd(ptr(dy.contiguous()), ptr(y), y.numel() // cp, ctx.c, cp, ptr(dx), stream_ptr()),
+              "codeps_softmax_bwd")
+        return dx, None
+
+
+def channel_softmax(x, c):
+    """Softmax over the first c channels of NHWC logits (padding channels -> 0)."""
+    return _Softmax.apply(x, int(c))
+
+
+class _DispDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, min_depth, max_depth):
+        require_cuda(logits)
+        logits = logits.contiguous()
+        b, h, w, cp = logits.shape
+        disp = torch.empty(b, 1, h, w, dtype=torch.float32, device=logits.device)
+        depth = torch.empty_like(disp)
+        check(lib().codeps_disp_depth_fwd(ptr(logits), b * h * w, cp, min_depth, max_depth, ptr(disp), ptr(depth), stream_ptr()),
+              "codeps_disp_depth_fwd")
+        ctx.save_for_backward(disp)
+        ctx.meta = (cp, min_depth, max_depth)
+        return depth, disp
+
+    @staticmethod
+    def backward(ctx, ddepth, ddisp):
+        (disp,) = ctx.saved_tensors
+        cp, mn, mx = ctx.meta
+        b, _, h, w = disp.shape
+        dx = torch.empty(b, h, w, cp, dtype=torch.float32, device=disp.device)
+        ddepth = None if ddepth is None else ddepth.contiguous()
+        ddisp = None if ddisp is None else ddisp.contiguous()
+        check(lib().codeps_disp_depth_bwd(ptr(ddisp), ptr(ddepth), ptr(disp), b * h * w, cp, mn, mx, ptr(dx), stream_ptr()),
+              "codeps_disp_depth_bwd")
+        return dx, None, None
+
+
+def disp_depth(logits, min_depth=0.1, max_depth=100.0):
+    """sigmoid + disp_to_depth on channel 0 of NHWC logits -> (depth, disp), both [B,1,H,W]."""
+    return _DispDepth.apply(logits, float(min_depth), float(max_depth))

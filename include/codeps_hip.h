@@ -59,6 +59,107 @@ int codeps_photometric_bwd(const codeps_photometric_desc* d, const float* img_t,
                            float* grad_depth, float* grad_pose_m, float* grad_pose_p,
                            void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * conv2d: NHWC fp32 implicit-GEMM convolution on the f32 MFMA.  Replaces the ATen/cuDNN convs behind
+ * torchvision ResNet (models/resnet_encoder.py:115-126), the Depth/Semantic decoders
+ * (models/depth_head.py:60-71, models/semantic_head.py:50-72), InstanceHead 1x1 convs
+ * (models/instance_head.py:24-57,99-111) and PoseHead (models/pose_head.py:36-44).
+ * Activations are NHWC with channel counts padded to multiples of 16 (padding channels hold zeros);
+ * nn.Parameter weights stay OIHW and are repacked by codeps_conv2d_pack_weights.
+ *   input  = concat(source0 [B, in_h(/2), in_w(/2), c0] (nearest-upsampled x2 on load if up0),
+ *                   source1 [B, in_h, in_w, c1] (c1 may be 0))
+ *   y[B,out_h,out_w,out_c] = act( conv(input, W) * scale[n] + shift[n] + residual )
+ *   scale/shift/residual nullable (bias-only conv: scale NULL, shift = bias; folded eval BN: both).
+ */
+typedef struct {
+    int32_t batch, in_h, in_w;   /* logical input size (after the optional x2 upsample of source 0) */
+    int32_t c0, c1;              /* channels of source 0 / source 1 (multiples of 16) */
+    int32_t up0;                 /* 1: source 0 is stored at half resolution, nearest x2 on load */
+    int32_t out_c, out_h, out_w;
+    int32_t kh, kw, stride, pad; /* stride 1 or 2 */
+    int32_t pad_mode;            /* 0 zeros, 1 reflect (ReflectionPad2d) */
+    int32_t act;                 /* 0 none, 1 ReLU, 2 ELU(alpha=1) */
+} codeps_conv_desc;
+
+/* OIHW [out_c][in_c][kh][kw] -> w_fwd [out_c_pad][kh*kw][in_c_pad] and/or w_dgrad [in_c_pad][kh*kw][out_c_pad]. */
+int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
+                               const float* w_oihw, float* w_fwd, float* w_dgrad, codeps_stream_t stream);
+int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, const float* x1, const float* w_fwd,
+                      const float* scale, const float* shift, const float* residual, float* y,
+                      codeps_stream_t stream);
+/* dz = gradient w.r.t. the pre-activation conv output [B,out_h,out_w,out_c]; dx = gradient of `source`
+ * at ITS stored resolution (the x2-upsample transpose, a 2x2 sum, is fused for source 0 when up0). */
+int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad,
+                        float* dx, codeps_stream_t stream);
+size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d);
+/* dw_oihw [out_c_real][in_c_real][kh][kw] (= or += when accumulate); split-K slabs + fixed-order reduce. */
+int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float* x1, const float* dz,
+                        float* dw_oihw, int out_c_real, int in_c_real, int accumulate, void* workspace,
+                        size_t workspace_bytes, codeps_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * NHWC building blocks (HBM-bound; rows = B*H*W pixels, c = padded channel count, multiple of 4).
+ * Per-channel reductions are two-stage and fixed-order (deterministic); their scratch is
+ * codeps_colsum_workspace_bytes(rows, c, k) with k = number of simultaneously reduced quantities.
+ */
+/* NCHW planar -> NHWC with channels [c_off, c_off+c) of a c_pad-wide pixel; zero_rest=1 also zero-fills
+ * the other channels (image -> padded stem input; two calls build the 6-channel pose-net input). */
+int codeps_nchw_to_nhwc(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off,
+                        int zero_rest, codeps_stream_t stream);
+int codeps_nhwc_to_nchw(const float* x, int batch, int c, int h, int w, int c_pad, float* y,
+                        codeps_stream_t stream);
+size_t codeps_colsum_workspace_bytes(long long rows, int c, int k);
+/* dz = dy * act'(y) * scale[c];  dbias[c_real] (= / +=) sum_rows dy * act'(y).  act: 0 none 1 ReLU 2 ELU
+ * (derivative from the OUTPUT y).  dz or dbias may be NULL.  Replaces ELU/ReLU backward + bias grad. */
+int codeps_act_bwd(const float* dy, const float* y, const float* scale, int act, long long rows, int c,
+                   float* dz, float* dbias, int c_real, int accumulate, void* workspace,
+                   size_t workspace_bytes, codeps_stream_t stream);
+/* Train-mode BatchNorm (nn.BatchNorm2d / SyncBatchNorm, misc/train_utils.py:50-51): statistics leave
+ * the library as raw sums so the caller can all-reduce them over ranks before normalising.
+ *   bn_stats:       sums[0][c] = sum x, sums[1][c] = sum x^2
+ *   bn_apply:       y = act((x - mean) * invstd * gamma + beta + residual)        act 0/1
+ *   bn_bwd_reduce:  g = dy * act'(y);  sums[0] = sum g, sums[1] = sum g * xhat
+ *   bn_bwd_apply:   dx = gamma*invstd*(g - sums[0]*inv_count - xhat*sums[1]*inv_count); dres = g (nullable) */
+int codeps_bn_stats(const float* x, long long rows, int c, float* sums, void* workspace,
+                    size_t workspace_bytes, codeps_stream_t stream);
+int codeps_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, const float* residual, int act, long long rows, int c, float* y,
+                    codeps_stream_t stream);
+int codeps_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean,
+                         const float* invstd, int act, long long rows, int c, float* sums, void* workspace,
+                         size_t workspace_bytes, codeps_stream_t stream);
+int codeps_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean,
+                        const float* invstd, const float* gamma, const float* sums, float inv_count, int act,
+                        long long rows, int c, float* dx, float* dres, codeps_stream_t stream);
+/* nn.MaxPool2d(3, 2, 1) (models/resnet_encoder.py:31); argmax = window tap 0..8 per element (u8). */
+int codeps_maxpool3x3s2_fwd(const float* x, int batch, int h, int w, int c, float* y, uint8_t* argmax,
+                            codeps_stream_t stream);
+int codeps_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, int batch, int h, int w, int c, float* dx,
+                            codeps_stream_t stream);
+/* 5x5 depthwise conv, stride 1, zero pad 2 (models/instance_head.py:38-46,90-98); weights [25][c];
+ * y = act(conv * scale + shift); flip=1 gives the data gradient. */
+int codeps_dwconv5x5(const float* x, const float* w25c, const float* scale, const float* shift, int act,
+                     int batch, int h, int w, int c, int flip, float* y, codeps_stream_t stream);
+int codeps_dwconv5x5_wgrad(const float* x, const float* dz, int batch, int h, int w, int c, float* dw25c,
+                           void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* F.interpolate(mode="bilinear", align_corners=...) on NHWC, output written into channels
+ * [y_c_off, y_c_off+c) of a y_c-wide pixel (concat-by-pointer); _bwd is the deterministic transpose. */
+int codeps_bilinear_fwd(const float* x, int batch, int h, int w, int c, int out_h, int out_w,
+                        int align_corners, float* y, int y_c, int y_c_off, codeps_stream_t stream);
+int codeps_bilinear_bwd(const float* dy, int batch, int h, int w, int c, int out_h, int out_w,
+                        int align_corners, int y_c, int y_c_off, float* dx, codeps_stream_t stream);
+/* nn.Softmax(dim=1) over the first c of c_pad channels (padding written as 0) and its backward. */
+int codeps_softmax_fwd(const float* x, long long rows, int c, int c_pad, float* y, codeps_stream_t stream);
+int codeps_softmax_bwd(const float* dy, const float* y, long long rows, int c, int c_pad, float* dx,
+                       codeps_stream_t stream);
+/* sigmoid + DepthHead.disp_to_depth (models/depth_head.py:48-54,71-74): channel 0 of logits[rows][c_pad]
+ * -> planar disp[rows], depth[rows]; _bwd writes d logits (channel 0, rest zero). */
+int codeps_disp_depth_fwd(const float* logits, long long rows, int c_pad, float min_depth, float max_depth,
+                          float* disp, float* depth, codeps_stream_t stream);
+int codeps_disp_depth_bwd(const float* ddisp, const float* ddepth, const float* disp, long long rows,
+                          int c_pad, float min_depth, float max_depth, float* dlogits,
+                          codeps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
