@@ -7,7 +7,7 @@ library is missing `lib()` raises, and every op in codeps_amd goes through `lib(
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint64, c_void_p
 
 import torch  # noqa: F401  (must precede loading the .so, see module docstring)
 
@@ -83,6 +83,17 @@ SIGNATURES = {
     "codeps_softmax_bwd": (c_int, [P, P, LL, I, I, P, P]),
     "codeps_disp_depth_fwd": (c_int, [P, LL, I, c_float, c_float, P, P, P]),
     "codeps_disp_depth_bwd": (c_int, [P, P, P, LL, I, c_float, c_float, P, P]),
+    "codeps_loss_workspace_bytes": (c_size_t, [LL]),
+    "codeps_smoothness_fwd": (c_int, [P, P, I, I, I, P, P, P, c_size_t, P]),
+    "codeps_smoothness_bwd": (c_int, [P, P, P, P, I, I, I, P, P, c_size_t, P]),
+    "codeps_semantic_loss_fwd": (c_int, [P, I, I, P, P, P, I, LL, c_double, P, P, c_size_t, P]),
+    "codeps_semantic_loss_bwd": (c_int, [P, I, I, P, P, P, I, LL, c_double, P, P, P, c_size_t, P]),
+    "codeps_instance_loss_fwd": (c_int, [I, P, I, I, P, P, I, I, I, P, P, c_size_t, P]),
+    "codeps_instance_loss_bwd": (c_int, [I, P, I, I, P, P, I, I, I, P, P, P]),
+    "codeps_pose_fwd": (c_int, [P, I, I, I, I, P, P, P]),
+    "codeps_pose_bwd": (c_int, [P, P, I, I, I, I, P, P]),
+    "codeps_reflect_pad_fold": (c_int, [P, I, I, I, I, I, P, P]),
+    "codeps_adam_ema_step": (c_int, [P, P, P, P, P, LL, I, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 
 

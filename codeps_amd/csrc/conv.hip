@@ -452,7 +452,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK>;
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     hipLaunchKernelGGL(k, dim3(p.n_mt * p.n_nt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
 }
 

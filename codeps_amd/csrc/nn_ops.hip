@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 // ---------------------------------------------------------------------------------- column sums (per-channel)
 // Generic two-stage deterministic per-channel reduction over M rows of an [M][C] matrix.
 // stage 1: block (rows chunk) -> partial[blk][K][C];  stage 2: sum over blocks in order.
-constexpr int CS_ROWS = 64;               // rows per thread-row group iteration
 
 __device__ __forceinline__ float act_grad(float y, int act) {
     if (act == 1) return y > 0.f ? 1.f : 0.f;

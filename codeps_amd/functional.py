@@ -248,7 +248,18 @@ class _Conv2d(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[6] and dres is None:
             dres = dz
         dx0 = dx1 = dw = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and desc.pad_mode == 1:
+            # reflect padding: data gradient w.r.t. the (virtual) padded tensor, then fold the border back
+            p_ = desc.pad
+            dpad = _lib.ConvDesc(desc.batch, desc.in_h + 2 * p_, desc.in_w + 2 * p_, desc.c0, 0, 0, desc.out_c, desc.out_h,
+                                 desc.out_w, desc.kh, desc.kw, desc.stride, 0, 0, desc.act)
+            dxp = torch.empty(desc.batch, desc.in_h + 2 * p_, desc.in_w + 2 * p_, desc.c0, dtype=torch.float32, device=dy.device)
+            check(lib().codeps_conv2d_dgrad(ctypes.byref(dpad), 0, ptr(dz), ptr(wd), ptr(dxp), stream_ptr()),
+                  "codeps_conv2d_dgrad")
+            dx0 = torch.empty_like(x0)
+            check(lib().codeps_reflect_pad_fold(ptr(dxp), desc.batch, desc.in_h, desc.in_w, desc.c0, p_, ptr(dx0), stream_ptr()),
+                  "codeps_reflect_pad_fold")
+        elif ctx.needs_input_grad[0]:
             dx0 = torch.empty_like(x0)
             check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(dx0), stream_ptr()),
                   "codeps_conv2d_dgrad")
@@ -555,3 +566,155 @@ class _DispDepth(torch.autograd.Function):
 def disp_depth(logits, min_depth=0.1, max_depth=100.0):
     """sigmoid + disp_to_depth on channel 0 of NHWC logits -> (depth, disp), both [B,1,H,W]."""
     return _DispDepth.apply(logits, float(min_depth), float(max_depth))
+
+
+# ---------------------------------------------------------------------------------------- pose
+class _Pose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, invert):
+        require_cuda(feat)
+        feat = feat.contiguous()
+        b, h, w, cp = feat.shape
+        vec = torch.empty(b, 6, dtype=torch.float32, device=feat.device)
+        T = torch.empty(b, 4, 4, dtype=torch.float32, device=feat.device)
+        check(lib().codeps_pose_fwd(ptr(feat), b, h * w, cp, int(invert), ptr(vec), ptr(T), stream_ptr()), "codeps_pose_fwd")
+        ctx.save_for_backward(vec)
+        ctx.meta = (b, h, w, cp, int(invert))
+        return T
+
+    @staticmethod
+    def backward(ctx, dT):
+        (vec,) = ctx.saved_tensors
+        b, h, w, cp, inv = ctx.meta
+        df = torch.empty(b, h, w, cp, dtype=torch.float32, device=vec.device)
+        check(lib().codeps_pose_bwd(ptr(dT.contiguous()), ptr(vec), b, h * w, cp, inv, ptr(df), stream_ptr()), "codeps_pose_bwd")
+        return df, None
+
+
+def pose_matrix(feat, invert=False):
+    """NHWC pose features [B,h,w,Cp] -> [B,4,4] (spatial mean * 0.01, frame 0, Rodrigues; models/pose_head.py:46-54)."""
+    return _Pose.apply(feat, bool(invert))
+
+
+# ---------------------------------------------------------------------------------------- losses
+def _loss_ws(pixels, device):
+    return torch.empty(lib().codeps_loss_workspace_bytes(pixels), dtype=torch.uint8, device=device)
+
+
+class _Smoothness(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, disp):
+        require_cuda(img, disp)
+        img, disp = _f32c(img), _f32c(disp)
+        b, _, h, w = img.shape
+        ws = _loss_ws(b * h * w, img.device)
+        mean = torch.empty(b, dtype=torch.float32, device=img.device)
+        loss = torch.empty(1, dtype=torch.float32, device=img.device)
+        check(lib().codeps_smoothness_fwd(ptr(img), ptr(disp), b, h, w, ptr(mean), ptr(loss), ptr(ws), ws.numel(), stream_ptr()),
+              "codeps_smoothness_fwd")
+        ctx.save_for_backward(img, disp, mean, ws)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        img, disp, mean, ws = ctx.saved_tensors
+        b, _, h, w = img.shape
+        dd = torch.empty_like(disp)
+        check(lib().codeps_smoothness_bwd(ptr(img), ptr(disp), ptr(mean), ptr(_f32c(g).reshape(1)), b, h, w, ptr(dd), ptr(ws),
+                                          ws.numel(), stream_ptr()), "codeps_smoothness_bwd")
+        return None, dd
+
+
+def smoothness_loss(img, disp):
+    """Edge-aware smoothness (algos/depth.py:58-107); img [B,3,H,W], disp [B,1,H,W] NCHW."""
+    return _Smoothness.apply(img, disp)
+
+
+class _SemanticLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, c, target, pixel_weights, class_weights, top_k, ignore_index):
+        require_cuda(probs, target, pixel_weights, class_weights)
+        probs = probs.contiguous()
+        cp = probs.shape[-1]
+        n = probs.numel() // cp
+        target = target.contiguous()
+        if target.dtype != torch.uint8:
+            target = target.to(torch.uint8)
+        if pixel_weights is not None:
+            pixel_weights = pixel_weights.contiguous().to(torch.uint8)
+        cw = None if class_weights is None else _f32c(class_weights)
+        ws = _loss_ws(n, probs.device)
+        loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+        check(lib().codeps_semantic_loss_fwd(ptr(probs), c, cp, ptr(target), ptr(pixel_weights), ptr(cw), ignore_index, n, top_k,
+                                             ptr(loss), ptr(ws), ws.numel(), stream_ptr()), "codeps_semantic_loss_fwd")
+        ctx.save_for_backward(probs, target, pixel_weights, cw, ws)
+        ctx.meta = (c, cp, n, top_k, ignore_index)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, target, pw, cw, ws = ctx.saved_tensors
+        c, cp, n, top_k, ign = ctx.meta
+        dp = torch.empty_like(probs)
+        check(lib().codeps_semantic_loss_bwd(ptr(probs), c, cp, ptr(target), ptr(pw), ptr(cw), ign, n, top_k,
+                                             ptr(_f32c(g).reshape(1)), ptr(dp), ptr(ws), ws.numel(), stream_ptr()),
+              "codeps_semantic_loss_bwd")
+        return dp, None, None, None, None, None, None
+
+
+def semantic_loss(probs_nhwc, num_classes, target, pixel_weights=None, class_weights=None, top_k=0.2, ignore_index=255):
+    """Hard-pixel-mined CE on softmax probabilities (algos/semantic_seg.py:45-67); probs NHWC [B,H,W,Cp]."""
+    return _SemanticLoss.apply(probs_nhwc, int(num_classes), target, pixel_weights, class_weights, float(top_k), int(ignore_index))
+
+
+class _InstanceLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, c, target, kind, ignore_index):
+        require_cuda(pred, target)
+        pred = pred.contiguous()
+        b, h, w, cp = pred.shape
+        if kind == 2:
+            tf, tu = None, target.contiguous().to(torch.uint8)
+        else:
+            tf, tu = _f32c(target), None
+        ws = _workspace(4096, pred.device, "instloss")
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        check(lib().codeps_instance_loss_fwd(kind, ptr(pred), c, cp, ptr(tf), ptr(tu), ignore_index, b, h * w, ptr(loss), ptr(ws),
+                                             ws.numel(), stream_ptr()), "codeps_instance_loss_fwd")
+        ctx.save_for_backward(pred, tf, tu)
+        ctx.meta = (c, cp, kind, ignore_index, b, h * w)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tf, tu = ctx.saved_tensors
+        c, cp, kind, ign, b, hw = ctx.meta
+        dp = torch.empty_like(pred)
+        check(lib().codeps_instance_loss_bwd(kind, ptr(pred), c, cp, ptr(tf), ptr(tu), ign, b, hw, ptr(_f32c(g).reshape(1)), ptr(dp),
+                                             stream_ptr()), "codeps_instance_loss_bwd")
+        return dp, None, None, None, None
+
+
+def center_loss(pred_nhwc, target):
+    """mean((c - c_gt)^2) (algos/instance_seg.py:12-25); pred NHWC [B,H,W,Cp] (ch 0), target [B,1,H,W]."""
+    return _InstanceLoss.apply(pred_nhwc, 1, target, 0, 255)
+
+
+def offset_loss(pred_nhwc, target):
+    """mean(|o - o_gt|) (algos/instance_seg.py:28-41); pred NHWC (ch 0,1), target [B,2,H,W]."""
+    return _InstanceLoss.apply(pred_nhwc, 2, target, 1, 255)
+
+
+def binary_mask_loss(probs_nhwc, target, ignore_index=255):
+    """mean CE on thing probabilities (algos/instance_seg.py:44-51); target u8 [B,H,W]."""
+    return _InstanceLoss.apply(probs_nhwc, 2, target, 2, int(ignore_index))
+
+
+# ---------------------------------------------------------------------------------------- optimiser
+def adam_ema_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0,
+                  ema_params=None, ema_alpha=0.99):
+    """One fused Adam (+EMA) step on flat fp32 buffers (C ABI: codeps_adam_ema_step)."""
+    require_cuda(params, grads, exp_avg, exp_avg_sq, ema_params)
+    check(lib().codeps_adam_ema_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(ema_params), params.numel(),
+                                     int(step), lr, betas[0], betas[1], eps, grad_scale, ema_alpha, stream_ptr()),
+          "codeps_adam_ema_step")

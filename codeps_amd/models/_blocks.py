@@ -1,0 +1,49 @@
+"""Shared helpers: conv + BatchNorm (+ReLU, +residual) on NHWC through the C ABI."""
+import torch
+from torch import nn
+
+from .. import functional as F
+
+_fold_cache = {}
+
+
+def folded_bn(bn: nn.BatchNorm2d):
+    """(scale, shift) of an eval-mode BatchNorm, cached while its tensors are unchanged."""
+    key = id(bn)
+    ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr())
+    hit = _fold_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        scale, shift = F.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    _fold_cache[key] = (ver, scale, shift)
+    return scale, shift
+
+
+def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None):
+    """act(BN(conv(x)) + residual).  Eval-mode BN is folded into the conv epilogue (one kernel);
+    train-mode BN uses batch statistics (`sync` = cross-rank sum reducer for SyncBatchNorm)."""
+    stride, pad = conv.stride[0], conv.padding[0]
+    if bn.training:
+        y = F.conv2d(x, conv.weight, stride=stride, pad=pad)
+        out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                 residual=residual, act=act, reduce_fn=sync)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        return out
+    scale, shift = folded_bn(bn)
+    return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act)
+
+
+def dwconv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, sync=None):
+    """5x5 depthwise + BN + ReLU (models/instance_head.py:38-46)."""
+    if bn.training:
+        y = F.dwconv5x5(x, conv.weight)
+        out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act="relu",
+                                 reduce_fn=sync)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        return out
+    scale, shift = folded_bn(bn)
+    return F.dwconv5x5(x, conv.weight, scale, shift, "relu")

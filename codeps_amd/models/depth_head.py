@@ -1,0 +1,69 @@
+"""DepthHead: drop-in for models/depth_head.py:10-78 (Monodepth2-style decoder -> sigmoid disparity ->
+depth).  Each decoder stage is two fused kernels: conv3x3+bias+ELU, and
+[nearest x2 upsample + concat skip + conv3x3 + bias + ELU] with the upsample / concat done on load."""
+from typing import Tuple, Union
+
+import numpy as np
+from numpy.typing import ArrayLike
+from torch import Tensor, nn
+
+from .. import functional as F
+
+
+def _make_decoder(module, num_ch_enc, num_ch_dec, use_skips):
+    module.upconvs_0, module.upconvs_1 = nn.ModuleDict(), nn.ModuleDict()
+    for i in range(4, -1, -1):
+        cin = num_ch_enc[-1] if i == 4 else num_ch_dec[i + 1]
+        module.upconvs_0[str(i)] = nn.Sequential(nn.Conv2d(int(cin), int(num_ch_dec[i]), 3, stride=1, padding=1),
+                                                 nn.ELU(inplace=True))
+        cin = num_ch_dec[i]
+        if use_skips and i > 0:
+            cin = cin + num_ch_enc[i - 1]
+        module.upconvs_1[str(i)] = nn.Sequential(nn.Conv2d(int(cin), int(num_ch_dec[i]), 3, stride=1, padding=1),
+                                                 nn.ELU(inplace=True))
+
+
+def _run_decoder(module, in_feats, keep=()):
+    """-> NHWC decoder output at scale 0 (and the scales listed in `keep`)."""
+    x = F.from_nchw(in_feats[-1])
+    kept = {}
+    for i in range(4, -1, -1):
+        c0, c1 = module.upconvs_0[str(i)][0], module.upconvs_1[str(i)][0]
+        x = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu")
+        skip = F.from_nchw(in_feats[i - 1]) if (module.use_skips and i > 0) else None
+        x = F.conv2d(x, c1.weight, c1.bias, x1=skip, pad=1, act="elu", up0=True)
+        if i in keep:
+            kept[i] = x
+    return x, kept
+
+
+class DepthHead(nn.Module):
+
+    def __init__(self, num_ch_enc: ArrayLike, use_skips: bool):
+        super().__init__()
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.use_skips = use_skips
+        self.scales = range(4)
+        self.outputs = {}
+        _make_decoder(self, self.num_ch_enc, self.num_ch_dec, use_skips)
+        self.dispconvs = nn.ModuleDict()
+        for s in self.scales:       # scales 1..3 exist for state_dict compatibility; nothing reads them
+            self.dispconvs[str(s)] = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(int(self.num_ch_dec[s]), 1, 3))
+        self.sigmoid = nn.Sigmoid()
+
+    @staticmethod
+    def disp_to_depth(disp: Tensor, min_depth: float = 0.1, max_depth: float = 100) -> Tensor:
+        min_disp = 1 / max_depth
+        max_disp = 1 / min_depth
+        return 1 / (min_disp + (max_disp - min_disp) * disp)
+
+    def forward(self, in_feats, return_disparity: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        x, _ = _run_decoder(self, in_feats)
+        conv = self.dispconvs["0"][1]
+        logits = F.conv2d(x, conv.weight, conv.bias, pad=1, pad_mode="reflect")
+        depth_map, disp_map = F.disp_depth(logits)          # sigmoid + disp_to_depth, one kernel
+        self.outputs = {0: disp_map}
+        if return_disparity:
+            return depth_map, disp_map
+        return depth_map

@@ -1,0 +1,46 @@
+"""PoseHead: drop-in for models/pose_head.py:14-137."""
+from collections import OrderedDict
+from typing import List
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as F
+
+
+class PoseHead(nn.Module):
+
+    def __init__(self, num_ch_enc, num_input_features, num_frames_to_predict_for=None, stride=1):
+        super().__init__()
+        self.num_ch_enc = num_ch_enc
+        self.num_input_features = num_input_features
+        if num_frames_to_predict_for is None:
+            num_frames_to_predict_for = num_input_features - 1
+        self.num_frames_to_predict_for = num_frames_to_predict_for
+        self.stride = stride
+        self.convs = OrderedDict()
+        self.convs[("squeeze")] = nn.Conv2d(int(self.num_ch_enc[-1]), 256, 1)
+        self.convs[("pose", 0)] = nn.Conv2d(num_input_features * 256, 256, 3, stride, 1)
+        self.convs[("pose", 1)] = nn.Conv2d(256, 256, 3, stride, 1)
+        self.convs[("pose", 2)] = nn.Conv2d(256, 6 * num_frames_to_predict_for, 1)
+        self.relu = nn.ReLU()
+        self.net = nn.ModuleList(list(self.convs.values()))
+
+    def forward(self, input_features: List[Tensor], invert_pose: bool = False) -> Tensor:
+        x = F.from_nchw(input_features[-1])
+        sq, p0, p1, p2 = self.net
+        x = F.conv2d(x, sq.weight, sq.bias, act="relu")
+        x = F.conv2d(x, p0.weight, p0.bias, stride=self.stride, pad=1, act="relu")
+        x = F.conv2d(x, p1.weight, p1.bias, stride=self.stride, pad=1, act="relu")
+        x = F.conv2d(x, p2.weight, p2.bias)
+        # spatial mean, *0.01, frame 0 of num_frames_to_predict_for, Rodrigues, (inverse) composition: one kernel
+        return F.pose_matrix(x, invert_pose)
+
+    @staticmethod
+    def transformation_from_parameters(axisangle: Tensor, translation: Tensor, invert: bool = False) -> Tensor:
+        """[B,1,3] axis-angle + [B,1,3] translation -> [B,4,4] (models/pose_head.py:56-78).  Utility kept
+        for callers of the reference API; runs the same HIP kernel on a 1x1 'feature map'."""
+        vec = torch.cat([axisangle.reshape(-1, 3), translation.reshape(-1, 3)], 1) * 100.0     # kernel applies 0.01
+        feat = torch.zeros(vec.shape[0], 1, 1, 16, dtype=torch.float32, device=vec.device)
+        feat[:, 0, 0, :6] = vec
+        return F.pose_matrix(feat, invert)

@@ -1,0 +1,125 @@
+"""ResnetEncoder: drop-in for the reference's models/resnet_encoder.py:82-126.
+
+The reference wraps torchvision's ResNet (requirements.txt:2, not vendored); here the trunk is defined
+directly with torchvision's module / parameter names (conv1, bn1, layerL.B.conv{1,2,3}, bn{1,2,3},
+downsample.{0,1}, fc) so that reference checkpoints load unchanged, and its forward runs the NHWC
+f32-MFMA conv engine: every conv+BN(+ReLU)(+residual) is ONE kernel in eval mode.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import functional as F
+from ._blocks import conv_bn
+
+_LAYERS = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]),
+           101: ("bottleneck", [3, 4, 23, 3]), 152: ("bottleneck", [3, 8, 36, 3])}
+
+
+class _BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward_nhwc(self, x, sync):
+        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], sync=sync)
+        out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync)
+        return conv_bn(out, self.conv2, self.bn2, "relu", residual=identity, sync=sync)
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)          # v1.5: stride on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward_nhwc(self, x, sync):
+        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], sync=sync)
+        out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync)
+        out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync)
+        return conv_bn(out, self.conv3, self.bn3, "relu", residual=identity, sync=sync)
+
+
+class _ResNet(nn.Module):
+    """torchvision-named ResNet trunk (+ unused fc kept for state_dict compatibility)."""
+
+    def __init__(self, num_layers, in_channels=3):
+        super().__init__()
+        kind, counts = _LAYERS[num_layers]
+        block = _BasicBlock if kind == "basic" else _Bottleneck
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(block, 64, counts[0], 1)
+        self.layer2 = self._make_layer(block, 128, counts[1], 2)
+        self.layer3 = self._make_layer(block, 256, counts[2], 2)
+        self.layer4 = self._make_layer(block, 512, counts[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, 1000)
+        for m in self.modules():                       # models/resnet_encoder.py:38-43 (= torchvision's init)
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes, 1, None) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+class ResnetEncoder(nn.Module):
+    """Signature and outputs of the reference class (models/resnet_encoder.py:82-126):
+    forward(input_image [B, num_input_images*num_channels_input, H, W]) -> 5 NCHW feature maps at
+    strides 2..32 (zero-copy channels-last views of the internal NHWC tensors)."""
+
+    def __init__(self, num_layers, pretrained, num_input_images=1, num_channels_input=3):
+        super().__init__()
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        if num_layers not in _LAYERS:
+            raise ValueError(f"{num_layers} is not a valid number of resnet layers")
+        if num_input_images > 1:
+            assert num_channels_input >= 3, "Require at least RGB image (3 channels)"
+            assert num_layers in [18, 50], "Can only run with 18 or 50 layer resnet"
+        if pretrained:
+            raise RuntimeError("pretrained=True needs the ImageNet download the reference does through torchvision; "
+                               "this build has no network: construct with pretrained=False and load a checkpoint "
+                               "(state_dict keys are the reference's).")
+        self.encoder = _ResNet(num_layers, num_input_images * num_channels_input)
+        self.num_layers = num_layers
+        if num_layers > 34:
+            self.num_ch_enc[1:] *= 4
+        self.sync_bn = None            # set by codeps_amd.distributed for SyncBatchNorm semantics
+
+    def forward(self, input_image):
+        enc = self.encoder
+        x = F.from_nchw(input_image, 16)
+        x = conv_bn(x, enc.conv1, enc.bn1, "relu", sync=self.sync_bn)
+        feats = [x]
+        x = F.max_pool3x3s2(x)
+        for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
+            for block in layer:
+                x = block.forward_nhwc(x, self.sync_bn)
+            feats.append(x)
+        return [F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]

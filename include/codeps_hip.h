@@ -160,6 +160,58 @@ int codeps_disp_depth_bwd(const float* ddisp, const float* ddepth, const float* 
                           int c_pad, float min_depth, float max_depth, float* dlogits,
                           codeps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-pixel losses (K11-K13).  Scalars (loss, grad_loss) are 1-element DEVICE buffers (no host sync).
+ * Scratch for all of them: codeps_loss_workspace_bytes(pixels); the buffer written by a _fwd must be
+ * handed unchanged to the matching _bwd (it holds the per-pixel loss map and the top-k threshold).
+ */
+size_t codeps_loss_workspace_bytes(long long pixels);
+/* EdgeAwareSmoothnessLoss.__call__ (algos/depth.py:58-107): img [B,3,H,W], disp [B,1,H,W] planar;
+ * mean_disp [B] is an output of _fwd and an input of _bwd. */
+int codeps_smoothness_fwd(const float* img, const float* disp, int batch, int h, int w, float* mean_disp,
+                          float* loss, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+int codeps_smoothness_bwd(const float* img, const float* disp, const float* mean_disp,
+                          const float* grad_loss, int batch, int h, int w, float* grad_disp, void* workspace,
+                          size_t workspace_bytes, codeps_stream_t stream);
+/* SemanticLoss.__call__ (algos/semantic_seg.py:45-67): CE applied to softmax PROBABILITIES
+ * (probs NHWC [pixels][c_pad], first c real), target / pixel_weights u8 [pixels] (pixel_weights and
+ * class_weights nullable), ignore_index 255, hard-pixel mining over the whole flattened batch with
+ * k = int(top_k * pixels) via an integer radix select (top_k = 1.0: plain mean). */
+int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, const uint8_t* target,
+                             const uint8_t* pixel_weights, const float* class_weights, int ignore_index,
+                             long long pixels, double top_k, float* loss, void* workspace,
+                             size_t workspace_bytes, codeps_stream_t stream);
+int codeps_semantic_loss_bwd(const float* probs, int c, int c_pad, const uint8_t* target,
+                             const uint8_t* pixel_weights, const float* class_weights, int ignore_index,
+                             long long pixels, double top_k, const float* grad_loss, float* grad_probs,
+                             void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* CenterLoss (kind 0, MSE), OffsetLoss (kind 1, L1), BinaryMaskLoss (kind 2, CE on probabilities,
+ * ignore 255) -- algos/instance_seg.py:12-51.  pred NHWC [batch*hw][c_pad]; target planar NCHW fp32
+ * [batch][c][hw] (kinds 0/1) or u8 [batch*hw] (kind 2).  Plain mean; pixel weights are ignored like
+ * the reference does. */
+int codeps_instance_loss_fwd(int kind, const float* pred, int c, int c_pad, const float* target_f,
+                             const uint8_t* target_u8, int ignore_index, int batch, int hw, float* loss,
+                             void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+int codeps_instance_loss_bwd(int kind, const float* pred, int c, int c_pad, const float* target_f,
+                             const uint8_t* target_u8, int ignore_index, int batch, int hw,
+                             const float* grad_loss, float* grad_pred, codeps_stream_t stream);
+/* PoseHead tail (models/pose_head.py:46-137): feat NHWC [batch][hw][c_pad] -> vec6 = 0.01 * spatial mean
+ * of channels 0..5 (frame 0: axis-angle, translation) -> T [batch][16] = T*R, or R^T*T(-t) if invert. */
+int codeps_pose_fwd(const float* feat, int batch, int hw, int c_pad, int invert, float* vec6, float* T,
+                    codeps_stream_t stream);
+int codeps_pose_bwd(const float* grad_T, const float* vec6, int batch, int hw, int c_pad, int invert,
+                    float* grad_feat, codeps_stream_t stream);
+/* Transpose of nn.ReflectionPad2d(pad) on NHWC: grad_padded [B][h+2p][w+2p][c] -> grad_x [B][h][w][c]. */
+int codeps_reflect_pad_fold(const float* grad_padded, int batch, int h, int w, int c, int pad, float* grad_x,
+                            codeps_stream_t stream);
+/* One fused multi-tensor step on FLAT buffers: torch.optim.Adam (lr, betas, eps; no weight decay;
+ * misc/train_utils.py:194-201) with grads pre-scaled by grad_scale (1/world_size after a SUM
+ * all-reduce), optionally followed by the EMA teacher update ema = a*ema + (1-a)*p
+ * (codeps/online_adap.py:279-289) when ema_params != NULL. */
+int codeps_adam_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                         float* ema_params, long long n, int step, float lr, float beta1, float beta2,
+                         float eps, float grad_scale, float ema_alpha, codeps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,92 @@
+"""Product nn.Modules (HIP path) against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+from helpers import close, grad_stats, keys_of, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(z, name, module, fwd, pseed, feats, out_tol=(2e-5, 2e-5), train=False):
+    sd = gi.fill_state_dict(keys_of(z, name), pseed)
+    module.load_state_dict(sd)
+    module.to(DEV).train(train)
+    fs = [f.clone().to(DEV).requires_grad_(True) for f in feats]
+    outs = fwd(module, fs)
+    loss = 0
+    for i, o in enumerate(outs):
+        close(o, z[f"{name}_out{i}"], *out_tol, f"{name}_out{i}")
+        loss = loss + (o * gi.normal(tuple(o.shape), pseed * 7 + i).to(DEV)).sum()
+    loss.backward()
+    st = grad_stats([p.grad for _n, p in module.named_parameters()])
+    ref = z[name + "_pgrad_stats"]
+    err = np.abs(st - ref) / (np.abs(ref[:, 1:2]) + 1e-6)
+    assert err.max() < 2e-3, f"{name}: param-grad stats differ (max {err.max():.2e} at row {err.argmax() // 2})"
+    for i, f in enumerate(fs):
+        if f"{name}_dfeat{i}" in z.files:
+            close(f.grad, z[f"{name}_dfeat{i}"], 2e-4, 2e-4, f"{name}_dfeat{i}")
+    return module
+
+
+@pytest.mark.parametrize("tag", ["r18", "r50"])
+def test_heads_against_reference_golden(tag):
+    from codeps_amd.models import DepthHead, InstanceHead, PoseHead, SemanticHead
+    z, meta = load("heads_" + tag)
+    seed, ch = meta["seed"], np.array(meta["num_ch_enc"])
+    feats = gi.feature_pyramid(ch, meta["b"], meta["h"], meta["w"], seed)
+    m = _run(z, "depth", DepthHead(ch, True), lambda m_, f: m_(f, return_disparity=True), seed + 1, feats, (1e-3, 1e-5))
+    close(m.dispconvs["0"][1].weight.grad, z["depth_dw_disp"], 2e-4, 2e-4)
+    close(m.upconvs_1["0"][0].weight.grad, z["depth_dw_up10"], 2e-4, 2e-4)
+    close(m.upconvs_0["4"][0].bias.grad, z["depth_db_up04"], 2e-4, 2e-4)
+    m = _run(z, "sem", SemanticHead(ch, 14, True, True), lambda m_, f: [m_(f)], seed + 2, feats)
+    close(m.semconv_guda.weight.grad, z["sem_dw_guda"], 2e-4, 2e-4)
+    if tag == "r50":
+        return
+    _run(z, "semng", SemanticHead(ch, 14, True, False), lambda m_, f: [m_(f)], seed + 3, feats)
+    _run(z, "inst", InstanceHead(ch, True), lambda m_, f: list(m_(f)), seed + 4, feats, (1e-4, 1e-4))
+    m = _run(z, "insttrain", InstanceHead(ch, True), lambda m_, f: list(m_(f)), seed + 4, feats, (2e-4, 2e-4), train=True)
+    bn = np.concatenate([v.detach().cpu().numpy().ravel() for k, v in m.state_dict().items()
+                         if k.endswith("running_mean") or k.endswith("running_var")])
+    close(bn, z["insttrain_bn_stats"], 1e-5, 1e-4, "BN running stats")
+    _run(z, "instnomask", InstanceHead(ch, False), lambda m_, f: list(m_(f))[:2], seed + 5, feats, (1e-4, 1e-4))
+    _run(z, "pose", PoseHead(ch, 1, 2), lambda m_, f: [m_(f, False)], seed + 6, feats, (1e-6, 1e-5))
+    _run(z, "poseinv", PoseHead(ch, 1, 2), lambda m_, f: [m_(f, True)], seed + 6, feats, (1e-6, 1e-5))
+
+
+@pytest.mark.parametrize("layers,in_ch,train", [(18, 3, False), (18, 6, True), (50, 3, False), (50, 3, True), (34, 3, False)])
+def test_encoder_against_oracle(layers, in_ch, train):
+    """Trunk vs the oracle's torchvision restatement (fwd, BN running stats, grads)."""
+    from codeps_amd.models import ResnetEncoder
+    from oracle import resnet as oresnet
+    torch.set_num_threads(8)
+    sd = gi.fill_state_dict(gi.shapes_of(oresnet.make_state_dict(layers, in_ch, 0)), 77 + layers)
+    enc = ResnetEncoder(layers, False, in_ch // 3, 3)
+    enc.load_state_dict({"encoder." + k: v for k, v in sd.items()})
+    enc.to(DEV).train(train)
+    x = gi.smooth_image(2, 64, 96, 5, 3)
+    if in_ch == 6:
+        x = torch.cat([x, gi.smooth_image(2, 64, 96, 6, 3)], 1)
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    rf = oresnet.features(ref_sd, x, layers, training=train)
+    feats = enc(x.to(DEV))
+    gs = [gi.normal(tuple(f.shape), 900 + i) for i, f in enumerate(rf)]
+    sum((f * g).sum() for f, g in zip(rf, gs)).backward()
+    sum((f * g.to(DEV)).sum() for f, g in zip(feats, gs)).backward()
+    for i, (a, b) in enumerate(zip(feats, rf)):
+        assert a.shape == b.shape
+        close(a, b, 2e-4 * float(b.abs().max()), 0, f"feat{i}")
+    for k, p in enc.encoder.named_parameters():
+        if k.startswith("fc"):
+            assert p.grad is None
+            continue
+        rg = ref_sd[k].grad
+        scale = float(rg.abs().max()) + 1e-12
+        close(p.grad, rg, 2e-3 * scale, 0, "grad " + k)
+    if train:
+        for k, v in enc.encoder.state_dict().items():
+            if "running" in k:
+                close(v, ref_sd[k], 1e-5, 1e-4, k)
