@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------- BatchNorm (train)
-// forward statistics: partial (sum x, sum x^2) per channel
+// forward statistics: partial (sum (x - s), sum (x - s)^2) per channel with the shift s = x[row 0][c]
+// ("shifted data" variance: no catastrophic cancellation when |mean| >> std)
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C,
                                                        float* __restrict__ part, int rows_per_blk) {
     const int Gall = C / 4, G = Gall < 256 ? Gall : 256;          // blockIdx.y tiles the channel groups
@@ -135,11 +136,13 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     const long long r0 = (long long)blockIdx.x * rows_per_blk;
     const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-    if (cok)
+    if (cok) {
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(x + tg * 4);
         for (long long r = r0 + tr; r < r1; r += TR) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + tg * 4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + tg * 4) - sh;
             s += v; q += v * v;
         }
+    }
     __shared__ f32x4 red[2][256];
     red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
     __syncthreads();

@@ -307,10 +307,11 @@ class _BatchNormTrain(torch.autograd.Function):
         ws = _workspace(wsb, x.device, "colsum")
         check(lib().codeps_bn_stats(ptr(x), rows, cp, ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_stats")
         count = float(rows)
-        if reduce_fn is not None:
-            sums, count = reduce_fn(sums, count)
-        mean = sums[0] / count
-        var = (sums[1] / count - mean * mean).clamp_(min=0)
+        d = sums[0] / count
+        mean = x.reshape(rows, cp)[0] + d                       # shifted-data statistics (see codeps_bn_stats)
+        var = (sums[1] / count - d * d).clamp_(min=0)
+        if reduce_fn is not None:                               # SyncBN: combine (mean, var, count) over ranks
+            mean, var, count = reduce_fn(mean, var, count)
         invstd = torch.rsqrt(var + eps)
         if running_mean is not None:
             with torch.no_grad():
@@ -339,12 +340,58 @@ class _BatchNormTrain(torch.autograd.Function):
                                          ws.numel(), stream_ptr()), "codeps_bn_bwd_reduce")
         dgamma, dbeta = sums[1, :ctx.c].clone(), sums[0, :ctx.c].clone()      # local (DDP averages them later)
         if ctx.reduce_fn is not None:
-            sums, _ = ctx.reduce_fn(sums, 0.0)
+            sums = ctx.reduce_fn.sum(sums)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         check(lib().codeps_bn_bwd_apply(ptr(dy), ptr(y), ptr(x), ptr(mean), ptr(invstd), ptr(g), ptr(sums), 1.0 / ctx.count,
                                         ctx.act, rows, cp, ptr(dx), ptr(dres), stream_ptr()), "codeps_bn_bwd_apply")
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+class _BatchNormEval(torch.autograd.Function):
+    """Eval-mode BatchNorm (running statistics) as its own op, used only when the BN affine parameters
+    need gradients (otherwise eval BN is folded into the producing conv's epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, act):
+        require_cuda(x, gamma, beta)
+        x = x.contiguous()
+        cp = x.shape[-1]
+        rows = x.numel() // cp
+        c = gamma.numel()
+        mean = _pad_vec(running_mean, cp)
+        invstd = _pad_vec(torch.rsqrt(running_var.detach() + eps), cp)
+        g, b_ = _pad_vec(gamma, cp), _pad_vec(beta, cp)
+        if residual is not None:
+            residual = residual.contiguous()
+        y = torch.empty_like(x)
+        check(lib().codeps_bn_apply(ptr(x), ptr(mean), ptr(invstd), ptr(g), ptr(b_), ptr(residual), act, rows, cp, ptr(y),
+                                    stream_ptr()), "codeps_bn_apply")
+        ctx.save_for_backward(x, y if act else None, mean, invstd, g)
+        ctx.act, ctx.c, ctx.has_res = act, c, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        cp = x.shape[-1]
+        rows = x.numel() // cp
+        sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
+        ws = _workspace(lib().codeps_colsum_workspace_bytes(rows, cp, 2), x.device, "colsum")
+        check(lib().codeps_bn_bwd_reduce(ptr(dy), ptr(y), ptr(x), ptr(mean), ptr(invstd), ctx.act, rows, cp, ptr(sums), ptr(ws),
+                                         ws.numel(), stream_ptr()), "codeps_bn_bwd_reduce")
+        dgamma, dbeta = sums[1, :ctx.c].clone(), sums[0, :ctx.c].clone()
+        zero = torch.zeros_like(sums)                      # fixed statistics: no mean / variance terms in dx
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        check(lib().codeps_bn_bwd_apply(ptr(dy), ptr(y), ptr(x), ptr(mean), ptr(invstd), ptr(g), ptr(zero), 0.0, ctx.act, rows, cp,
+                                        ptr(dx), ptr(dres), stream_ptr()), "codeps_bn_bwd_apply")
+        return dx, dgamma, dbeta, dres, None, None, None, None
+
+
+def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, residual=None, act=None):
+    return _BatchNormEval.apply(x, gamma, beta, residual, running_mean, running_var, float(eps), ACT[act])
 
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None, act=None,

@@ -32,6 +32,10 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
         return out
+    if torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad):
+        # eval statistics but trainable affine parameters: keep BN as its own op so gamma/beta get gradients
+        y = F.conv2d(x, conv.weight, stride=stride, pad=pad)
+        return F.batch_norm_eval(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual=residual, act=act)
     scale, shift = folded_bn(bn)
     return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act)
 
@@ -45,5 +49,8 @@ def dwconv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, sync=None):
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
         return out
+    if torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad):
+        y = F.dwconv5x5(x, conv.weight)
+        return F.batch_norm_eval(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, act="relu")
     scale, shift = folded_bn(bn)
     return F.dwconv5x5(x, conv.weight, scale, shift, "relu")

@@ -116,7 +116,8 @@ int codeps_act_bwd(const float* dy, const float* y, const float* scale, int act,
                    size_t workspace_bytes, codeps_stream_t stream);
 /* Train-mode BatchNorm (nn.BatchNorm2d / SyncBatchNorm, misc/train_utils.py:50-51): statistics leave
  * the library as raw sums so the caller can all-reduce them over ranks before normalising.
- *   bn_stats:       sums[0][c] = sum x, sums[1][c] = sum x^2
+ *   bn_stats:       sums[0][c] = sum (x - s_c), sums[1][c] = sum (x - s_c)^2 with the shift s_c = x[0][c]
+ *                   (mean = s + sums[0]/n, var = sums[1]/n - (sums[0]/n)^2: no cancellation)
  *   bn_apply:       y = act((x - mean) * invstd * gamma + beta + residual)        act 0/1
  *   bn_bwd_reduce:  g = dy * act'(y);  sums[0] = sum g, sums[1] = sum g * xhat
  *   bn_bwd_apply:   dx = gamma*invstd*(g - sums[0]*inv_count - xhat*sums[1]*inv_count); dres = g (nullable) */

@@ -66,26 +66,39 @@ def test_encoder_against_oracle(layers, in_ch, train):
     enc = ResnetEncoder(layers, False, in_ch // 3, 3)
     enc.load_state_dict({"encoder." + k: v for k, v in sd.items()})
     enc.to(DEV).train(train)
-    x = gi.smooth_image(2, 64, 96, 5, 3)
+    h, w = (128, 192) if (train and layers >= 50) else (64, 96)     # deep train-mode BN needs enough samples per channel
+    x = gi.smooth_image(2, h, w, 5, 3)
     if in_ch == 6:
-        x = torch.cat([x, gi.smooth_image(2, 64, 96, 6, 3)], 1)
-    ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
-              for k, v in sd.items()}
-    rf = oresnet.features(ref_sd, x, layers, training=train)
+        x = torch.cat([x, gi.smooth_image(2, h, w, 6, 3)], 1)
+    def oracle_run(dt):
+        osd = {k: ((v.clone().to(dt).requires_grad_(True) if "running" not in k else v.clone().to(dt))
+                   if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        of = oresnet.features(osd, x.to(dt), layers, training=train)
+        sum((f * gi.normal(tuple(f.shape), 900 + i).to(dt)).sum() for i, f in enumerate(of)).backward()
+        return osd, of
+
+    # float64 oracle = the reference value; the float32 oracle run measures how ill-conditioned this case is
+    # (train-mode BN over a handful of samples amplifies rounding): relative-L2 tolerance = max(1e-3, 8 x fp32-oracle noise)
+    ref_sd, rf = oracle_run(torch.float64)
+    f32_sd, _ = oracle_run(torch.float32)
     feats = enc(x.to(DEV))
-    gs = [gi.normal(tuple(f.shape), 900 + i) for i, f in enumerate(rf)]
-    sum((f * g).sum() for f, g in zip(rf, gs)).backward()
-    sum((f * g.to(DEV)).sum() for f, g in zip(feats, gs)).backward()
+    sum((f * gi.normal(tuple(f.shape), 900 + i).to(DEV)).sum() for i, f in enumerate(feats)).backward()
     for i, (a, b) in enumerate(zip(feats, rf)):
         assert a.shape == b.shape
-        close(a, b, 2e-4 * float(b.abs().max()), 0, f"feat{i}")
+        close(a, b.detach(), 2e-4 * float(b.detach().abs().max()), 0, f"feat{i}")
     for k, p in enc.encoder.named_parameters():
         if k.startswith("fc"):
             assert p.grad is None
             continue
         rg = ref_sd[k].grad
-        scale = float(rg.abs().max()) + 1e-12
-        close(p.grad, rg, 2e-3 * scale, 0, "grad " + k)
+        nrm = float(rg.norm()) + 1e-30
+        noise = float((f32_sd[k].grad.double() - rg).norm()) / nrm          # fp32 CPU oracle vs fp64
+        err = float((p.grad.double().cpu() - rg).norm()) / nrm
+        # a single ReLU whose pre-activation is ~1e-7 can land on the other side of 0 under a different
+        # (MFMA k-ordered) summation order; one flipped mask moves every upstream gradient by ~2e-3 rel-L2
+        # (measured: scratch analysis in DESIGN.md "numerics"), hence 1e-2 here and exactness checks elsewhere
+        # (tests/test_ops_gpu.py pins every op to 1e-5 in isolation).
+        assert err < max(1e-2 if train else 1e-3, 8 * noise), f"grad {k}: rel-L2 err {err:.2e} (fp32 oracle noise {noise:.2e})"
     if train:
         for k, v in enc.encoder.state_dict().items():
             if "running" in k:
