@@ -93,6 +93,9 @@ SIGNATURES = {
     "codeps_pose_fwd": (c_int, [P, I, I, I, I, P, P, P]),
     "codeps_pose_bwd": (c_int, [P, P, I, I, I, I, P, P]),
     "codeps_reflect_pad_fold": (c_int, [P, I, I, I, I, I, P, P]),
+    "codeps_panoptic_workspace_bytes": (c_size_t, [I, I, I]),
+    "codeps_panoptic_fusion": (c_int, [P, P, P, I, I, I, ctypes.c_ulonglong, I, I, c_float, I, I, P, P, P, P, P, c_size_t, P]),
+    "codeps_image_warp": (c_int, [P, P, P, P, I, I, I, I, I, P, P, P]),
     "codeps_adam_ema_step": (c_int, [P, P, P, P, P, LL, I, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 

@@ -1,0 +1,248 @@
+// Panoptic fusion (K14) entirely on the device, bit-exact w.r.t. the reference's CPU path:
+// misc/post_processing_panoptic.py:31-300 as driven by algos/instance_seg.py:207-258
+// (threshold 0.1, 7x7 NMS, top_k 200 with the strict '>' rule, nearest-centre grouping with first-index
+// ties, per-instance majority vote with smallest-label ties, ids = class*1000 + per-class counter in
+// ascending instance order, stuff -> class*1000, void / unassigned thing -> -1).
+// No host synchronisation: the number of centres stays in device memory; nothing like the reference's
+// [K, H*W, 2] float tensor (0.8 GB at 512x1024) is ever materialised.  Integer atomics only.
+//
+//   nms_flag_kernel      thresholded 7x7 local maxima -> u8 flag per pixel
+//   block_count_kernel   candidates per 1024-pixel chunk
+//   select_kernel        (1 block / image) exclusive scan of chunk counts, 200-th largest score by an
+//                        LDS radix select when there are >= 200 candidates, ordered list of kept centres
+//   group_kernel         per thing pixel argmin_k sqrt(dy^2+dx^2) (IEEE ops, no FMA contraction),
+//                        LDS-privatised per-instance class histogram
+//   assign_kernel        (1 block / image) majority class + running per-class instance counters
+//   paste_kernel         panoptic int16 + instance u8 maps
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 256;        // centre capacity (reference keeps < top_k = 200)
+constexpr int NCLS = 32;         // class histogram stride (semantic ids < 32; 255 = void)
+constexpr int CHUNK = 1024;
+
+struct PanP {
+    int H, W, top_k, nms, label_divisor, void_label;
+    float threshold;
+    unsigned long long thing_mask;   // bit c set <=> class c is a thing
+};
+
+__device__ __forceinline__ float thr_val(float v, float thr) { return v > thr ? v : -1.f; }
+
+__global__ __launch_bounds__(256) void nms_flag_kernel(PanP p, const float* __restrict__ ctr, uint8_t* __restrict__ flag) {
+    const int HW = p.H * p.W, b = blockIdx.y, r = (p.nms - 1) / 2;
+    const float* c = ctr + (size_t)b * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const int y = i / p.W, x = i % p.W;
+        const float v = thr_val(c[i], p.threshold);
+        float m = -INFINITY;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= p.H) continue;
+            for (int dx = -r; dx <= r; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= p.W) continue;
+                m = fmaxf(m, thr_val(c[yy * p.W + xx], p.threshold));
+            }
+        }
+        flag[(size_t)b * HW + i] = (v == m && v > 0.f) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void block_count_kernel(int HW, int nchunk, const uint8_t* __restrict__ flag, int* __restrict__ counts) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const uint8_t* f = flag + (size_t)b * HW;
+    int a = 0;
+    for (int i = ch * CHUNK + threadIdx.x; i < min((ch + 1) * CHUNK, HW); i += 256) a += f[i];
+    const float t = block_sum<256>((float)a, red);        // <= 1024: exact in fp32
+    if (threadIdx.x == 0) counts[b * nchunk + ch] = (int)t;
+}
+
+// state per image: [0] K candidates, [1] Kc kept centres, [2] tau bits
+__global__ __launch_bounds__(1024) void select_kernel(PanP p, int nchunk, const float* __restrict__ ctr, const uint8_t* __restrict__ flag,
+                                                      int* __restrict__ counts, int* __restrict__ state, int* __restrict__ centers) {
+    __shared__ unsigned hist[256];
+    __shared__ int sh_k, sh_prefix, sh_rank, sh_cnt;
+    __shared__ int scan[1024];
+    const int b = blockIdx.x, HW = p.H * p.W, tid = threadIdx.x;
+    const float* c = ctr + (size_t)b * HW;
+    const uint8_t* f = flag + (size_t)b * HW;
+    int* cnt = counts + b * nchunk;
+    // total number of candidates
+    int a = 0;
+    for (int i = tid; i < nchunk; i += 1024) a += cnt[i];
+    scan[tid] = a;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) scan[tid] += scan[tid + s]; __syncthreads(); }
+    const int K = scan[0];
+    __syncthreads();
+    // 200-th largest candidate score (keys: float bits of positive scores, monotone as uint32)
+    float tau = -INFINITY;
+    if (K >= p.top_k) {
+        if (tid == 0) { sh_prefix = 0; sh_rank = p.top_k; }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = (unsigned)sh_prefix;
+            const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int i = tid; i < HW; i += 1024) {
+                if (!f[i]) continue;
+                const unsigned key = __float_as_uint(c[i]);
+                if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned k = (unsigned)sh_rank, above = 0;
+                int bin = 255;
+                for (; bin > 0; --bin) { if (above + hist[bin] >= k) break; above += hist[bin]; }
+                sh_prefix = (int)(prefix | ((unsigned)bin << shift));
+                sh_rank = (int)(k - above);
+            }
+            __syncthreads();
+        }
+        tau = __uint_as_float((unsigned)sh_prefix);
+    }
+    // ordered list of kept centres (row-major order), at most MAXC
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    for (int base = 0; base < HW; base += 1024) {
+        if (cnt[base / CHUNK] == 0) continue;               // block-uniform: most chunks hold no candidate
+        const int i = base + tid;
+        const int keep = (i < HW && f[i] && c[i] > tau) ? 1 : 0;
+        scan[tid] = keep;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {          // inclusive Hillis-Steele scan
+            const int v = tid >= off ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int pos = sh_cnt + scan[tid] - keep;
+        if (keep && pos < MAXC) { centers[(b * MAXC + pos) * 2] = i / p.W; centers[(b * MAXC + pos) * 2 + 1] = i % p.W; }
+        __syncthreads();
+        if (tid == 1023) sh_cnt += scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) { state[b * 4] = K; state[b * 4 + 1] = min(sh_cnt, MAXC); state[b * 4 + 2] = (int)__float_as_uint(tau); state[b * 4 + 3] = sh_cnt; }
+}
+
+__global__ __launch_bounds__(256) void group_kernel(PanP p, const uint8_t* __restrict__ sem, const float* __restrict__ offs,
+                                                    const int* __restrict__ state, const int* __restrict__ centers, uint8_t* __restrict__ ins,
+                                                    int* __restrict__ hist) {
+    __shared__ float cy[MAXC], cx[MAXC];
+    __shared__ int lh[MAXC * NCLS];
+    const int b = blockIdx.y, HW = p.H * p.W;
+    const int Kc = state[b * 4 + 1];
+    for (int i = threadIdx.x; i < MAXC; i += 256) {
+        cy[i] = i < Kc ? (float)centers[(b * MAXC + i) * 2] : 0.f;
+        cx[i] = i < Kc ? (float)centers[(b * MAXC + i) * 2 + 1] : 0.f;
+    }
+    for (int i = threadIdx.x; i < MAXC * NCLS; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint8_t* s = sem + (size_t)b * HW;
+    const float* oy = offs + (size_t)b * 2 * HW;
+    const float* ox = oy + HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const int cls = s[i];
+        int id = 0;
+        if (Kc > 0 && cls < 64 && ((p.thing_mask >> cls) & 1ull)) {
+            const float yy = __fadd_rn((float)(i / p.W), oy[i]), xx = __fadd_rn((float)(i % p.W), ox[i]);
+            float best = INFINITY;
+            int bi = 0;
+            for (int k = 0; k < Kc; ++k) {
+                const float dy = __fsub_rn(cy[k], yy), dx = __fsub_rn(cx[k], xx);
+                const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx)));
+                if (d < best) { best = d; bi = k; }
+            }
+            id = bi + 1;
+            if (cls < NCLS) atomicAdd(&lh[bi * NCLS + cls], 1);
+        }
+        ins[(size_t)b * HW + i] = (uint8_t)id;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MAXC * NCLS; i += 256)
+        if (lh[i]) atomicAdd(&hist[(size_t)b * MAXC * NCLS + i], lh[i]);
+}
+
+__global__ void assign_kernel(PanP p, const int* __restrict__ state, const int* __restrict__ hist, int* __restrict__ idmap) {
+    // one thread per image: serial over <= MAXC instances, ascending id (reference loop order)
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int Kc = state[b * 4 + 1];
+    int counter[NCLS];
+    for (int c = 0; c < NCLS; ++c) counter[c] = 0;
+    for (int k = 0; k < MAXC; ++k) {
+        int val = -1;
+        if (k < Kc) {
+            const int* h = hist + ((size_t)b * MAXC + k) * NCLS;
+            int bestc = -1, bestn = 0;
+            for (int c = 0; c < NCLS; ++c)
+                if (h[c] > bestn) { bestn = h[c]; bestc = c; }          // first max = smallest label (torch.mode)
+            if (bestc >= 0) { counter[bestc] += 1; val = bestc * p.label_divisor + counter[bestc]; }
+        }
+        idmap[b * MAXC + k] = val;
+    }
+}
+
+__global__ __launch_bounds__(256) void paste_kernel(PanP p, const uint8_t* __restrict__ sem, const uint8_t* __restrict__ ins,
+                                                    const int* __restrict__ idmap, int16_t* __restrict__ pan) {
+    const int b = blockIdx.y, HW = p.H * p.W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const size_t o = (size_t)b * HW + i;
+        const int id = ins[o], cls = sem[o];
+        int v;
+        if (id > 0) v = idmap[b * MAXC + id - 1];
+        else if (cls == p.void_label || (cls < 64 && ((p.thing_mask >> cls) & 1ull))) v = -1;
+        else v = cls * p.label_divisor;
+        pan[o] = (int16_t)v;
+    }
+}
+
+__global__ void zero_int_kernel(int* p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0;
+}
+
+}  // namespace
+
+extern "C" size_t codeps_panoptic_workspace_bytes(int batch, int h, int w) {
+    const size_t HW = (size_t)h * w, nchunk = (HW + CHUNK - 1) / CHUNK;
+    return align_up((size_t)batch * HW, 256)                      // flags
+           + align_up((size_t)batch * nchunk * 4, 256)            // chunk counts
+           + align_up((size_t)batch * MAXC * NCLS * 4, 256)       // histograms
+           + align_up((size_t)batch * MAXC * 4, 256);             // id map
+}
+
+extern "C" int codeps_panoptic_fusion(const uint8_t* semantic, const float* center, const float* offset, int batch, int h, int w,
+                                      unsigned long long thing_class_mask, int label_divisor, int void_label, float threshold,
+                                      int nms_kernel, int top_k, int16_t* panoptic, uint8_t* instance, int* centers, int* state,
+                                      void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    CODEPS_REQUIRE(semantic && center && offset && panoptic && instance && centers && state && workspace && batch > 0 && h > 0 && w > 0,
+                   CODEPS_ERR_ARG, "panoptic_fusion: null pointer / bad shape");
+    CODEPS_REQUIRE(top_k >= 1 && top_k <= MAXC && (nms_kernel % 2) == 1 && label_divisor > 0, CODEPS_ERR_ARG,
+                   "panoptic_fusion: top_k must be in [1,%d], nms_kernel odd", MAXC);
+    CODEPS_REQUIRE(workspace_bytes >= codeps_panoptic_workspace_bytes(batch, h, w), CODEPS_ERR_WORKSPACE, "panoptic_fusion: workspace too small");
+    PanP p;
+    p.H = h; p.W = w; p.top_k = top_k; p.nms = nms_kernel; p.label_divisor = label_divisor; p.void_label = void_label;
+    p.threshold = threshold; p.thing_mask = thing_class_mask;
+    const int HW = h * w, nchunk = cdiv(HW, CHUNK);
+    char* ws = (char*)workspace;
+    uint8_t* flag = (uint8_t*)ws; ws += align_up((size_t)batch * HW, 256);
+    int* counts = (int*)ws;       ws += align_up((size_t)batch * nchunk * 4, 256);
+    int* hist = (int*)ws;         ws += align_up((size_t)batch * MAXC * NCLS * 4, 256);
+    int* idmap = (int*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = std::min(cdiv(HW, 256), 1024);
+    hipLaunchKernelGGL(zero_int_kernel, dim3(64), dim3(256), 0, st, hist, (long long)batch * MAXC * NCLS);
+    hipLaunchKernelGGL(nms_flag_kernel, dim3(gx, batch), dim3(256), 0, st, p, center, flag);
+    hipLaunchKernelGGL(block_count_kernel, dim3(nchunk, batch), dim3(256), 0, st, HW, nchunk, (const uint8_t*)flag, counts);
+    hipLaunchKernelGGL(select_kernel, dim3(batch), dim3(1024), 0, st, p, nchunk, center, (const uint8_t*)flag, counts, state, centers);
+    hipLaunchKernelGGL(group_kernel, dim3(std::min(gx, 256), batch), dim3(256), 0, st, p, semantic, offset, (const int*)state, (const int*)centers,
+                       instance, hist);
+    hipLaunchKernelGGL(assign_kernel, dim3(batch), dim3(64), 0, st, p, (const int*)state, (const int*)hist, idmap);
+    hipLaunchKernelGGL(paste_kernel, dim3(gx, batch), dim3(256), 0, st, p, semantic, (const uint8_t*)instance, (const int*)idmap, panoptic);
+    CODEPS_CHECK_LAUNCH("panoptic kernels");
+    return CODEPS_OK;
+}

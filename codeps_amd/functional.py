@@ -765,3 +765,32 @@ def adam_ema_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-4, betas=(0.9,
     check(lib().codeps_adam_ema_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(ema_params), params.numel(),
                                      int(step), lr, betas[0], betas[1], eps, grad_scale, ema_alpha, stream_ptr()),
           "codeps_adam_ema_step")
+
+
+# ---------------------------------------------------------------------------------------- panoptic fusion
+def panoptic_fusion(semantic, center, offset, thing_list, label_divisor=1000, void_label=255, threshold=0.1, nms_kernel=7,
+                    top_k=200):
+    """Device-side panoptic fusion (algos/instance_seg.py:207-258).  semantic [B,H,W] uint8/int64, center
+    [B,1,H,W], offset [B,2,H,W] -> (panoptic int16 [B,H,W], instance [B,H,W] (semantic's dtype),
+    centers int32 [B,256,2], state int32 [B,4] = (#candidates, #centres, ., .)).  No host sync."""
+    require_cuda(semantic, center, offset)
+    b, h, w = semantic.shape
+    sem8 = semantic if semantic.dtype == torch.uint8 else semantic.to(torch.uint8)
+    sem8 = sem8.contiguous()
+    center, offset = _f32c(center.detach()), _f32c(offset.detach())
+    mask = 0
+    for c in thing_list:
+        mask |= 1 << int(c)
+    dev = semantic.device
+    pan = torch.empty(b, h, w, dtype=torch.int16, device=dev)
+    inst = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
+    centers = torch.zeros(b, 256, 2, dtype=torch.int32, device=dev)
+    state = torch.empty(b, 4, dtype=torch.int32, device=dev)
+    nbytes = lib().codeps_panoptic_workspace_bytes(b, h, w)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().codeps_panoptic_fusion(ptr(sem8), ptr(center), ptr(offset), b, h, w, mask, label_divisor, void_label, threshold,
+                                       nms_kernel, top_k, ptr(pan), ptr(inst), ptr(centers), ptr(state), ptr(ws), nbytes,
+                                       stream_ptr()), "codeps_panoptic_fusion")
+    if semantic.dtype != torch.uint8:
+        inst = inst.to(semantic.dtype)
+    return pan, inst, centers, state

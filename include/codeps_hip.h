@@ -213,6 +213,29 @@ int codeps_adam_ema_step(float* params, const float* grads, float* exp_avg, floa
                          float* ema_params, long long n, int step, float lr, float beta1, float beta2,
                          float eps, float grad_scale, float ema_alpha, codeps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Panoptic fusion (K14): InstanceSegAlgo.panoptic_fusion (algos/instance_seg.py:207-258) ->
+ * get_panoptic_segmentation (misc/post_processing_panoptic.py:223-300), bit-exact, no host sync.
+ *   semantic u8 [B,H,W] (255 = void), center fp32 [B,1,H,W], offset fp32 [B,2,H,W] (dy,dx) NCHW planar,
+ *   thing_class_mask: bit c set <=> class c is a thing (c < 64).
+ *   panoptic int16 [B,H,W] (class*label_divisor + id, stuff class*label_divisor, -1 unassigned),
+ *   instance u8 [B,H,W] (1-based nearest-centre id inside the thing region, 0 elsewhere),
+ *   centers int32 [B,256,2] (y,x; first state[b][1] rows valid), state int32 [B,4] =
+ *   {#NMS candidates, #kept centres, bits of the top-k threshold, #kept before capping}. */
+size_t codeps_panoptic_workspace_bytes(int batch, int h, int w);
+int codeps_panoptic_fusion(const uint8_t* semantic, const float* center, const float* offset, int batch, int h,
+                           int w, unsigned long long thing_class_mask, int label_divisor, int void_label,
+                           float threshold, int nms_kernel, int top_k, int16_t* panoptic, uint8_t* instance,
+                           int* centers, int* state, void* workspace, size_t workspace_bytes,
+                           codeps_stream_t stream);
+
+/* ImageWarper / CoordinateWarper forward (misc/image_warper.py:100-184) for the reference's public
+ * (non-training) API: src [B,c,H,W] NCHW, depth [B,1,H,W], pose [B,16], intr [B,4];
+ * out [B,c,H,W] (nullable) = grid_sample(border, align_corners=True; nearest=1 for interp_mode
+ * "nearest"); grid [B,H,W,2] (nullable) = normalised sampling coordinates. */
+int codeps_image_warp(const float* src, const float* depth, const float* pose, const float* intr, int batch,
+                      int c, int h, int w, int nearest, float* out, float* grid, codeps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
