@@ -1,0 +1,149 @@
+"""Depth losses and DepthAlgo: drop-in for algos/depth.py:58-595 (flow losses excluded: make_sflow is
+off in every shipped config)."""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import functional as F
+from ..misc.camera_model import CameraModel
+
+
+class EdgeAwareSmoothnessLoss:
+    """algos/depth.py:58-107 -- one fused kernel pair (fwd, bwd)."""
+
+    def __call__(self, target_image: Tensor, disparity_map: Tensor) -> Tensor:
+        return F.smoothness_loss(target_image, disparity_map)
+
+
+class SSIMLoss:
+    """Constructor-compatible stand-in for algos/depth.py:110-155.  The 3x3 reflect-padded SSIM itself is
+    computed inside the fused photometric kernel; only window_size=3 is coherent in the reference
+     and only that is supported."""
+
+    def __init__(self, window_size: int = 3):
+        if window_size != 3:
+            raise ValueError("SSIMLoss: the fused photometric kernel implements the 3x3 window only")
+        self.c1, self.c2 = .01 ** 2, .03 ** 2
+
+
+def _intrinsics(camera_models, device) -> Tensor:
+    if isinstance(camera_models, Tensor):
+        return camera_models.to(device=device, dtype=torch.float32)
+    return CameraModel.batch_tensor(camera_models, device)
+
+
+class ReconstructionLoss:
+    """algos/depth.py:176-326: multi-scale photometric loss with auto-masking -> ONE fused forward and ONE
+    fused backward launch set (see csrc/photometric.hip)."""
+
+    def __init__(self, ref_img_width, ref_img_height, ssim: SSIMLoss, num_scales: int, device: torch.device = None,
+                 alpha: float = .85):
+        self.ssim, self.device, self.num_scales, self.alpha = ssim, device, num_scales, alpha
+        self.ref_img_width, self.ref_img_height = ref_img_width, ref_img_height
+        self.scaled_width = {i: ref_img_width // 2 ** i for i in range(num_scales)}
+        self.scaled_height = {i: ref_img_height // 2 ** i for i in range(num_scales)}
+        # test hook: flat tie-break noise tensor (already x1e-5), or a list of such tensors consumed one per
+        # call; None = in-kernel counter-based RNG (the production path)
+        self.noise = None
+
+    def __call__(self, camera_models, images: Tuple[Tensor, Tensor, Tensor], depth_map: Tensor, poses: Tuple[Tensor, Tensor],
+                 object_motion_maps=None, semantic_mask=None) -> Tensor:
+        if object_motion_maps is not None or semantic_mask is not None:
+            raise NotImplementedError("object motion maps / semantic masks belong to code paths without callers "
+                                      "(flow head off; algos/depth.py:284-292 unused)")
+        b, _, h, w = images[0].shape
+        assert (w, h) == (self.ref_img_width, self.ref_img_height), "image size differs from the loss' reference size"
+        intr = _intrinsics(camera_models, images[0].device)
+        assert intr.shape[0] == b, "Batch size of camera model does not match"
+        noise = self.noise.pop(0) if isinstance(self.noise, list) else self.noise
+        return F.photometric_loss(images, depth_map, poses, intr, self.num_scales, self.alpha, noise)
+
+
+class DepthAlgo:
+    """algos/depth.py:332-595."""
+
+    def __init__(self, reconstruction_loss: ReconstructionLoss, smoothness_loss: EdgeAwareSmoothnessLoss, evaluator=None,
+                 flow_smoothness_loss=None, flow_sparsity_loss=None,
+                 reconstruction_loss_adapt_source: Optional[ReconstructionLoss] = None, label_mode: Optional[str] = None):
+        self.reconstruction_loss = reconstruction_loss
+        self.reconstruction_loss_adapt_source = reconstruction_loss_adapt_source
+        self.smoothness_loss = smoothness_loss
+        self.evaluator = evaluator
+        self.flow_smoothness_loss, self.flow_sparsity_loss = flow_smoothness_loss, flow_sparsity_loss
+        self.labels = None
+        self.adaptation_cache = {"target_dist": [], "is_car_moving": False}
+        self.skip_rule_length = 300
+
+    @staticmethod
+    def _forward(images, depth_feats_window, depth_head, body_pose_sflow, pose_head, flow_head=None):
+        if flow_head is not None:
+            raise NotImplementedError("flow head is out of scope (make_sflow is False in every shipped config)")
+        depth, disp = depth_head(depth_feats_window[0], return_disparity=True)
+        # [t -> t-1]: frames in temporal order, pose inverted; [t -> t+1] (algos/depth.py:405-417)
+        if getattr(body_pose_sflow, "accepts_frame_tuple", False):
+            pair = lambda a, b: (a, b)                      # noqa: E731  stacked on the fly by the layout kernel
+        else:
+            pair = lambda a, b: torch.cat([a, b], dim=1)    # noqa: E731
+        t_prev = pose_head(body_pose_sflow(pair(images[1], images[0])), invert_pose=True)
+        t_next = pose_head(body_pose_sflow(pair(images[0], images[2])))
+        return [depth], [disp], [t_prev, t_next], None
+
+    def training(self, images, depth_feats_window, camera_models, depth_head, body_pose_sflow, pose_head, flow_head=None,
+                 depth_gt: Optional[Tensor] = None, use_reconstruction_loss_adapt_source: bool = False,
+                 return_disparity: bool = False):
+        depth_maps, disparity_maps, transformations, object_motion_maps = self._forward(
+            images, depth_feats_window, depth_head, body_pose_sflow, pose_head, flow_head)
+        depth_stats = None
+        if depth_gt is not None and self.evaluator is not None:
+            depth_stats = self.evaluator.compute_depth_metrics(depth_gt, depth_maps[0])
+        rec = self.reconstruction_loss_adapt_source if use_reconstruction_loss_adapt_source else self.reconstruction_loss
+        depth_recon_loss = rec(camera_models, images, depth_maps[0], transformations, object_motion_maps)
+        depth_smth_loss = self.smoothness_loss(images[0], disparity_maps[0])
+        if return_disparity:
+            return depth_recon_loss, depth_smth_loss, None, None, depth_maps[0], disparity_maps[0], transformations, \
+                   object_motion_maps, depth_stats
+        return depth_recon_loss, depth_smth_loss, None, None, depth_maps[0], transformations, object_motion_maps, depth_stats
+
+    def inference(self, feats, depth_head) -> Tensor:
+        return depth_head(feats)
+
+    def evaluation(self, feats, depth_head, depth_gt: Tensor):
+        depth = self.inference(feats, depth_head)
+        return self.evaluator.compute_depth_metrics(depth_gt, depth), depth
+
+    def adaptation(self, images: Dict[str, Tuple[Tensor, Tensor, Tensor]], depth_feats_window, camera_models, depth_head,
+                   body_pose_sflow, pose_head, flow_head=None, check_car_moving: bool = True):
+        """Per-key losses (source uses its own ReconstructionLoss geometry), image-count weighted mean
+        (algos/depth.py:507-577).  The reference's rolling "car not moving" rule (depth.py:537-558) needs the
+        pose norm on the host every frame; it is evaluated only when `check_car_moving` (one small D2H copy)."""
+        keys = [k for k in ["source", "target", "target_replay"] if k in images]
+        recon, smth, depth_pred, transformations, num_images = {}, {}, {}, {}, {k: 0 for k in keys}
+        for key in keys:
+            recon[key], smth[key], _, _, depth_pred[key], _, transformations[key], _, _ = self.training(
+                images[key], depth_feats_window[key], camera_models[key], depth_head, body_pose_sflow, pose_head, flow_head,
+                None, key == "source", return_disparity=True)
+            skip = False
+            if key == "target" and check_car_moving:
+                t0, t1 = transformations[key]
+                dist = float(((torch.linalg.norm(t0[0, :3, 3]) + torch.linalg.norm(t1[0, :3, 3])) / 2).detach())
+                cache = self.adaptation_cache["target_dist"]
+                if len(cache) > self.skip_rule_length:
+                    cache.pop(0)
+                skip = len(cache) == self.skip_rule_length and sum(cache) / self.skip_rule_length > 10 * dist
+                if not skip:
+                    cache.append(dist)
+                self.adaptation_cache["is_car_moving"] = skip
+            if skip:
+                recon.pop(key)
+                smth.pop(key)
+            else:
+                num_images[key] = images[key][0].shape[0]
+        total = sum(num_images.values())
+        if total > 0:
+            depth_recon_loss = sum(recon[k] * num_images[k] for k in recon) / total
+            depth_smth_loss = sum(smth[k] * num_images[k] for k in smth) / total
+        else:
+            depth_recon_loss = depth_smth_loss = None
+        return {"recon": depth_recon_loss, "smth": depth_smth_loss}, {"smth": None, "sparsity": None}, \
+            depth_pred.get("target"), transformations.get("target"), None, None

@@ -1,0 +1,89 @@
+"""SemanticLoss / SemanticSegAlgo: drop-in for algos/semantic_seg.py:15-67,150-249
+(SemanticConsistencyLoss is dead code in the reference, SURVEY.md §2 #10, and is not mirrored)."""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import functional as F
+
+
+class SemanticLoss:
+    """Hard-pixel-mined CE applied to softmax probabilities (algos/semantic_seg.py:15-67)."""
+
+    def __init__(self, device=None, ignore_index: int = 255, ignore_labels: Optional[List] = None,
+                 top_k_percent_pixels: float = 1.0, class_weights: Optional[Tuple[float, ...]] = None):
+        if not 0. < top_k_percent_pixels <= 1.0:
+            raise ValueError('top_k_percent_pixels must be within (0, 1]')
+        self.device, self.ignore_labels = device, ignore_labels
+        self.top_k_percent_pixels, self.ignore_index = top_k_percent_pixels, ignore_index
+        self.class_weights = None
+        if class_weights is not None:
+            kept = [w for label, w in enumerate(class_weights) if not ignore_labels or label not in ignore_labels]
+            self.class_weights = torch.tensor(kept, dtype=torch.float32)
+        self._cw_dev = None
+
+    def __call__(self, prediction_softmax: Tensor, target: Tensor, pixel_weights: Optional[Tensor], return_per_pixel=False):
+        if return_per_pixel:
+            raise NotImplementedError("return_per_pixel is only used by the reference's dead SemanticConsistencyLoss")
+        if self.ignore_labels:
+            # the reference remaps ignore_labels to 255 IN PLACE on the caller's target and drops those channels
+            # (algos/semantic_seg.py:50-55); no shipped config sets ignore labels (datasets/dataset.py:236-238)
+            raise NotImplementedError("ignore_labels != [] is not supported by the HIP path")
+        probs = F.from_nchw(prediction_softmax)
+        c = prediction_softmax.shape[1]
+        cw = None
+        if self.class_weights is not None:
+            if self._cw_dev is None or self._cw_dev.device != probs.device:
+                self._cw_dev = self.class_weights.to(probs.device)
+            cw = self._cw_dev
+        return F.semantic_loss(probs, c, target, pixel_weights, cw, self.top_k_percent_pixels, self.ignore_index)
+
+
+class SemanticSegAlgo:
+    """algos/semantic_seg.py:150-249."""
+
+    def __init__(self, semantic_loss: SemanticLoss, evaluator=None, semantic_consistency_loss=None):
+        self.semantic_loss, self.evaluator = semantic_loss, evaluator
+        self.semantic_consistency_loss = semantic_consistency_loss
+
+    def _confusion(self, pred, gt):
+        if self.evaluator is None or gt is None:
+            return None
+        return self.evaluator.compute_confusion_matrix(pred, gt)
+
+    def training(self, feats, semantic_head, semantic_gt: Tensor, semantic_weights: Tensor, ignore_classes: Optional[List] = None,
+                 semantic_gt_eval: Optional[Tensor] = None):
+        semantic_logits = semantic_head(feats)
+        if ignore_classes:
+            masked = semantic_logits.detach().clone()
+            masked[:, ignore_classes] = -float('inf')
+            semantic_pred = torch.argmax(masked, dim=1).type(torch.uint8)
+        else:
+            semantic_pred = torch.argmax(semantic_logits.detach(), dim=1).type(torch.uint8)
+        confusion_matrix = self._confusion(semantic_pred, semantic_gt_eval if semantic_gt_eval is not None else semantic_gt)
+        semantic_loss = self.semantic_loss(semantic_logits, semantic_gt, semantic_weights)
+        return semantic_loss, confusion_matrix, semantic_pred
+
+    def inference(self, feats, semantic_head) -> Tuple[Tensor, Tensor]:
+        semantic_logits = semantic_head(feats)
+        return torch.argmax(semantic_logits, dim=1).type(torch.uint8), semantic_logits
+
+    def evaluation(self, feats, semantic_head, semantic_gt: Tensor):
+        semantic_pred, semantic_logits = self.inference(feats, semantic_head)
+        return self._confusion(semantic_pred, semantic_gt), semantic_pred, semantic_logits
+
+    def adaptation(self, feats: Dict[str, list], semantic_head, semantic_gt: Dict[str, Tensor],
+                   semantic_weights: Dict[str, Tensor]):
+        with torch.no_grad():           # target prediction only feeds argmax / panoptic fusion
+            target_probs = semantic_head(feats['target'][0])
+        semantic_pred = torch.argmax(target_probs, dim=1)
+        losses = {'source': None}
+        for key, feat_mixup in feats.items():
+            if key.endswith('mixup'):
+                losses[key] = self.semantic_loss(semantic_head(feat_mixup[0]), semantic_gt[key], None)   # weights = ones
+        if 'source' in feats:
+            losses['source'] = self.semantic_loss(semantic_head(feats['source'][0]), semantic_gt['source'],
+                                                  semantic_weights['source'])
+        confusion_matrix = self._confusion(semantic_pred, semantic_gt.get('target'))
+        return losses, confusion_matrix, semantic_pred

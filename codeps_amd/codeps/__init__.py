@@ -1,0 +1,6 @@
+"""Host-side mirror of the reference's `codeps` package: CodepsNet (codeps/online_adap.py) and
+gen_models (codeps/model_setup.py)."""
+from .model_setup import gen_models
+from .online_adap import CodepsNet
+
+__all__ = ["CodepsNet", "gen_models"]

@@ -112,9 +112,16 @@ class ResnetEncoder(nn.Module):
             self.num_ch_enc[1:] *= 4
         self.sync_bn = None            # set by codeps_amd.distributed for SyncBatchNorm semantics
 
+    accepts_frame_tuple = True
+
     def forward(self, input_image):
+        """input_image: NCHW tensor, or a tuple of NCHW frames to be stacked along channels (the pose net's
+        frame pair) -- the tuple form skips the reference's torch.cat (algos/depth.py:408-413)."""
         enc = self.encoder
-        x = F.from_nchw(input_image, 16)
+        if isinstance(input_image, (tuple, list)):
+            x = F.images_to_nhwc(list(input_image), 16)
+        else:
+            x = F.from_nchw(input_image, 16)
         x = conv_bn(x, enc.conv1, enc.bn1, "relu", sync=self.sync_bn)
         feats = [x]
         x = F.max_pool3x3s2(x)

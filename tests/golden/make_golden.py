@@ -53,11 +53,14 @@ def save(name, **arrs):
 
 
 def grad_stats(module):
-    """[n_params, 2] float64 (sum, l2) of every parameter gradient, in named_parameters order."""
+    """[n_params, 2] float64 (random projection, l2) of every parameter gradient, in named_parameters order.
+    The projection vector is seeded per row (tests/golden/inputs.py::normal(shape, 4242 + row)); unlike a plain
+    sum it is not hypersensitive to sign-coherent rounding noise."""
     rows = []
-    for _n, p in module.named_parameters():
+    for i, (_n, p) in enumerate(module.named_parameters()):
         g = p.grad
-        rows.append([0.0, 0.0] if g is None else [g.double().sum().item(), g.double().norm().item()])
+        rows.append([0.0, 0.0] if g is None else
+                    [(g.double() * gi.normal(tuple(g.shape), 4242 + i).double()).sum().item(), g.double().norm().item()])
     return np.array(rows)
 
 

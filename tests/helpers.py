@@ -33,9 +33,15 @@ def close(a, b, atol, rtol=0.0, what=""):
 
 
 def grad_stats(named_grads):
+    """(random projection, l2) per gradient tensor -- same definition as tests/golden/make_golden.py."""
+    import inputs as gi
     rows = []
-    for g in named_grads:
-        rows.append([0.0, 0.0] if g is None else [g.double().sum().item(), g.double().norm().item()])
+    for i, g in enumerate(named_grads):
+        if g is None:
+            rows.append([0.0, 0.0])
+            continue
+        g = g.detach().double().cpu()
+        rows.append([(g * gi.normal(tuple(g.shape), 4242 + i).double()).sum().item(), g.norm().item()])
     return np.array(rows)
 
 

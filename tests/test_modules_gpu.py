@@ -23,7 +23,7 @@ def _run(z, name, module, fwd, pseed, feats, out_tol=(2e-5, 2e-5), train=False):
     loss.backward()
     st = grad_stats([p.grad for _n, p in module.named_parameters()])
     ref = z[name + "_pgrad_stats"]
-    err = np.abs(st - ref) / (np.abs(ref[:, 1:2]) + 1e-6)
+    err = np.abs(st - ref) / (np.abs(ref[:, 1:2]) + 1e-6)      # (projection, l2) relative to l2
     assert err.max() < 2e-3, f"{name}: param-grad stats differ (max {err.max():.2e} at row {err.argmax() // 2})"
     for i, f in enumerate(fs):
         if f"{name}_dfeat{i}" in z.files:

@@ -52,7 +52,7 @@ CONV_CASES = [
 def test_conv2d_forward_backward(case):
     F = _F()
     b, h, w, c0, c1, up0, co, k, stride, pad, pad_mode, act, bias, affine, residual = case
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed(1000 + CONV_CASES.index(case))
     hs, ws_ = (h // 2, w // 2) if up0 else (h, w)
     if up0:
         h, w = hs * 2, ws_ * 2
