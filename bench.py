@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the CoDEPS hot path on MI355X: adapt-step images/sec (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one continual-adaptation step (scripts/adapt_codeps.py:260-299 in the reference): forward of
+CodepsNet.adapt (frozen ResNet-101 encoder + Depth/Semantic/Instance/Pose heads + photometric, smoothness,
+semantic losses + panoptic fusion of the target frame), backward, ONE all-reduce of the flat gradient
+buffer (N > 1), fused Adam + EMA -- on the per-GPU batch of BASELINE config 3: 8 centre images
+(1 target + 3 target_replay + 2 source + 2 cut_mixup) at 512x1024, synthetic data, random-init weights
+(seed 20).  Weak scaling: every rank processes its own 8 images.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def build(device, encoder_layers, h, w, mode):
+    from codeps_amd.codeps import gen_models
+    from codeps_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults(adapt=(mode == "adapt"))
+    cfg.model.po_depth_net.params.nof_layers = encoder_layers
+    cfg.dataset.feed_img_size = [h, w]
+    cfg.adapt.source_dataset.feed_img_size = [h, w]
+    if mode == "train":
+        cfg.model.instance_head.use_thing_mask = True
+    torch.manual_seed(20)                   # the scripts' default seed (scripts/train_codeps.py:51)
+    net = gen_models(cfg, device, list(range(9)), [9, 10, 11, 12, 13], [], adaptation_mode=(mode == "adapt"))
+    return net, cfg
+
+
+def make_data(mode, h, w, device, rank, per_gpu):
+    from codeps_amd import synthetic
+    if mode == "adapt":
+        scale = max(per_gpu // 8, 1)
+        return synthetic.adapt_batch(h, w, device, 1234 + rank, 1 * scale, 3 * scale, 2 * scale, 2 * scale)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    return synthetic.triplet_item(per_gpu, h, w, gen, device, labels=True), per_gpu
+
+
+def cpu_baseline(net, h, w, budget_items=2):
+    """The oracle (CPU restatement, kind "port") timed on this host: fwd + bwd + Adam of an adapt step on a
+    bounded sample (1 source + 1 target centre image at full resolution) -- a reported baseline only."""
+    from codeps_amd import synthetic
+    from oracle import network
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sds = {}
+    for name in ("backbone_po_depth", "backbone_pose_sflow", "depth_head", "pose_head", "semantic_head", "instance_head"):
+        sds[name] = {k: v.detach().cpu().clone() for k, v in getattr(net, name).state_dict().items()}
+    train = [n for n in ("backbone_pose_sflow", "depth_head", "pose_head", "semantic_head")]
+    params = []
+    for n in train:
+        for k, v in sds[n].items():
+            if v.is_floating_point() and "running" not in k and ".fc." not in k:
+                v.requires_grad_(True)
+                params.append(v)
+    gen = torch.Generator().manual_seed(99)
+    dev = torch.device("cpu")
+    data = {"target": synthetic.triplet_item(1, h, w, gen, dev), "source": synthetic.triplet_item(1, h, w, gen, dev, labels=True)}
+    cfg = dict(nof_layers=net.backbone_po_depth.num_layers, train_pose_bn=True)
+    wts = dict(depth_recon=10.0, depth_smth=0.001, semantic_source=1.0)
+    t0 = time.perf_counter()
+    out, _ = network.adapt_forward(sds, cfg, data)
+    total = sum(wts[k] * out[k] for k in wts)
+    total.backward()
+    ms, vs = [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params]
+    with torch.no_grad():
+        for p, m, v in zip(params, ms, vs):
+            if p.grad is not None:
+                network.adam_step(p, p.grad, m, v, 1)
+    dt = time.perf_counter() - t0
+    return {"value": round(budget_items / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle adapt step (fwd+bwd+Adam) on 1 source + 1 target centre image at {h}x{w}, "
+                      f"{dt:.1f} s wall, torch CPU threads={cores}"}
+
+
+def conv_roofline(runner, data, steps=2):
+    """Live measurement of the dominant kernel family (f32-MFMA implicit-GEMM conv: fwd + dgrad + wgrad) with HIP
+    events on the launch stream: algorithmic FLOPs of every launch / its event-timed duration."""
+    from codeps_amd import functional as F
+    F._profile["events"].clear()
+    F._profile["on"] = True
+    for _ in range(steps):
+        runner.step(data)
+    torch.cuda.synchronize()
+    F._profile["on"] = False
+    by = {}
+    for kind, flops, a, b in F._profile["events"]:
+        d = by.setdefault(kind, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += a.elapsed_time(b) * 1e-3
+        d[2] += 1
+    F._profile["events"].clear()
+    flops = sum(v[0] for v in by.values())
+    secs = sum(v[1] for v in by.values())
+    n = sum(v[2] for v in by.values())
+    detail = {k: {"launches_per_step": v[2] // steps, "tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3)}
+              for k, v in by.items()}
+    ach = flops / secs / 1e12
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel + conv_wgrad_kernel (f32 MFMA 32x32x2)", "achieved": round(ach, 2),
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n // steps, "avg_launch_us": round(secs / n * 1e6, 2),
+            "conv_ms_per_step": round(secs / steps * 1e3, 3), "algorithmic_gflop_per_step": round(flops / steps / 1e9, 1),
+            "by_kind": detail}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="adapt", choices=["adapt", "train"])
+    ap.add_argument("--encoder", type=int, default=None, help="ResNet depth of the shared encoder (adapt: 101, train: 50)")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--per-gpu-batch", type=int, default=None)
+    ap.add_argument("--graph", type=int, default=1, help="replay forward+backward from a captured HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from codeps_amd import _lib
+    from codeps_amd.distributed import init_from_env
+    from codeps_amd.step import StepRunner
+    rank, local, world = init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: codeps_amd has no CPU path")
+    _lib.lib()                                           # fail loudly if the HIP library is missing
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    enc = args.encoder or (101 if args.mode == "adapt" else 50)
+    per_gpu = args.per_gpu_batch or (8 if args.mode == "adapt" else 4)
+    net, cfg = build(device, enc, args.height, args.width, args.mode)
+    data, n_images = make_data(args.mode, args.height, args.width, device, rank, per_gpu)
+    runner = StepRunner(net, cfg, args.mode, world)
+    if world > 1:
+        from codeps_amd.distributed import SyncBatchNormReducer
+        red = SyncBatchNormReducer()
+        for enc_mod in (net.backbone_po_depth, net.backbone_pose_sflow):
+            enc_mod.sync_bn = red
+        if net.instance_head is not None:
+            net.instance_head.sync_bn = red
+
+    for _ in range(max(args.warmup, 1)):
+        runner.step(data)
+    torch.cuda.synchronize()
+
+    graph = None
+    if args.graph and world == 1:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                runner.forward_backward(data)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                runner.forward_backward(data)
+            graph.replay()
+            runner.optimizer_step()
+            torch.cuda.synchronize()
+        except Exception as e:                            # noqa: BLE001  (eager is always valid)
+            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def one_step():
+        if graph is not None:
+            graph.replay()
+            runner.optimizer_step()
+        else:
+            runner.step(data)
+
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof = conv_roofline(runner, data)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "adapt":
+        cpu = cpu_baseline(net, args.height, args.width)
+
+    if rank == 0:
+        total_images = n_images * world * args.steps
+        line = {
+            "metric": "adapt-step images/sec" if args.mode == "adapt" else "pretrain-step images/sec",
+            "value": round(total_images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[2]: online-adapt step cfg/adapt_cityscapes_kitti_360.yaml, per-GPU batch "
+                                    f"{n_images} = 1 target + 3 target_replay + 2 source + 2 cut_mixup @ {args.height}x{args.width}, "
+                                    f"ResNet-{enc} encoder frozen, trainable pose encoder + depth/pose/semantic heads, EMA semantic head")
+                       if args.mode == "adapt" else
+                       (f"BASELINE configs[1]: pretrain step ResNet-{enc} + 4 heads @ {args.height}x{args.width}, per-GPU batch {n_images}"),
+                       "global_batch": n_images * world, "parallelism": f"dp{world}", "launch": "hip-graph" if graph is not None else "eager",
+                       "grad_allreduce_mb": round(runner.grad_bytes / 1e6, 1)},
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

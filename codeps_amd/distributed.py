@@ -1,0 +1,67 @@
+"""Batch-sharded (data-parallel) execution: one process per GPU (torchrun), RCCL over xGMI through
+torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests).
+
+The path shards over the batch only: every rank runs the step on its slice of
+target / replay / source / mixup items; the only data-path exchange is ONE all-reduce (SUM) of the flat fp32
+gradient buffer after backward (123 MB for the adapt YAML), plus -- for exact DistributedDataParallel +
+SyncBatchNorm semantics (misc/train_utils.py:47-59) -- the per-layer batch-statistics exchange of the
+train-mode BatchNorm layers.  Never a line-by-line copy of DDP's bucketed hooks.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def allreduce_flat_gradients(flat_grad, group=None):
+    """The single gradient collective of a step (SUM; the optimizer kernel applies 1/world)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return flat_grad
+
+
+class SyncBatchNormReducer:
+    """Cross-rank combination of BatchNorm batch statistics (torch.nn.SyncBatchNorm semantics):
+    forward: all-gather (mean, biased var, count) per rank and merge them with the parallel-variance
+    formula; backward: all-reduce (SUM) of (sum g, sum g*xhat).  Installed as `encoder.sync_bn`."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __call__(self, mean, var, count):
+        world = dist.get_world_size(self.group)
+        c = mean.numel()
+        packed = torch.cat([mean, var, mean.new_tensor([count])])
+        gathered = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(gathered, packed, group=self.group)
+        g = torch.stack(gathered)                      # [world, 2c+1]
+        means, vars_, counts = g[:, :c], g[:, c:2 * c], g[:, 2 * c:]
+        total = counts.sum()
+        mean_all = (means * counts).sum(0) / total
+        var_all = ((vars_ + (means - mean_all) ** 2) * counts).sum(0) / total
+        return mean_all, var_all, float(total)
+
+    def sum(self, sums):
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        return sums
+
+
+def shard_items(n_items, rank, world):
+    """Contiguous slice [lo, hi) of n_items for this rank (equal counts: n_items % world == 0)."""
+    assert n_items % world == 0, "keep per-key item counts equal across ranks so the plain mean is exact"
+    per = n_items // world
+    return rank * per, (rank + 1) * per

@@ -197,6 +197,31 @@ def _conv_desc(x0, x1, out_c_pad, kh, kw, stride, pad, pad_mode, act, up0):
 
 ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
 
+# Flat-gradient sink: the step harness (codeps_amd/step.py) registers, for every trainable conv weight / bias,
+# a view into ONE flat fp32 gradient buffer.  The conv backward then accumulates straight into that view
+# (wgrad / bias-reduce epilogues with accumulate=1) and reports no gradient to autograd -> no per-parameter
+# accumulate kernels, and the buffer is ready for a single RCCL all-reduce.
+_grad_sink = {}
+
+# Optional conv-engine profiler: {"events": [(kind, flops, start_evt, end_evt)]} filled while enabled (bench.py).
+_profile = {"on": False, "events": []}
+
+
+def _prof_begin():
+    if not _profile["on"]:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(start, kind, flops):
+    if start is None:
+        return
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    _profile["events"].append((kind, flops, start, e))
+
 
 class _Conv2d(torch.autograd.Function):
     """y = act(conv(cat(up(x0), x1), W) * scale + shift + residual) on NHWC tensors (C ABI conv2d)."""
@@ -217,9 +242,16 @@ class _Conv2d(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         y = torch.empty(desc.batch, desc.out_h, desc.out_w, cop, dtype=torch.float32, device=x0.device)
+        flops = 2.0 * desc.batch * desc.out_h * desc.out_w * co * ci * kh * kw         # algorithmic (unpadded)
+        t0 = _prof_begin()
         check(lib().codeps_conv2d_fwd(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
                                       stream_ptr()), "codeps_conv2d_fwd")
+        _prof_end(t0, "conv_fwd", flops)
         ctx.desc, ctx.co, ctx.ci, ctx.has_bias = desc, co, ci, bias is not None
+        ctx.flops = flops
+        ctx.w_sink = _grad_sink.get(id(weight)) if weight.requires_grad else None
+        ctx.b_sink = _grad_sink.get(id(bias)) if (bias is not None and bias.requires_grad) else None
+        ctx.c0_real = min(ci, x0.shape[3])
         ctx.has_res = residual is not None
         ctx.save_for_backward(x0, x1, y if act else None, wd, sc)
         return y
@@ -231,7 +263,10 @@ class _Conv2d(torch.autograd.Function):
         dy = dy.contiguous()
         rows, cop = dy.numel() // dy.shape[-1], dy.shape[-1]
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
-        dbias = torch.empty(ctx.co, dtype=torch.float32, device=dy.device) if need_b else None
+        dbias = None
+        if need_b:
+            dbias = ctx.b_sink if ctx.b_sink is not None else torch.empty(ctx.co, dtype=torch.float32, device=dy.device)
+        b_acc = 1 if ctx.b_sink is not None else 0
         dres = None
         if desc.act or sc is not None or need_b:
             wsb = lib().codeps_colsum_workspace_bytes(rows, cop, 1)
@@ -242,7 +277,9 @@ class _Conv2d(torch.autograd.Function):
                                            ws.numel(), stream_ptr()), "codeps_act_bwd")
             dz = torch.empty_like(dy) if (desc.act or sc is not None) else dy
             check(lib().codeps_act_bwd(ptr(dy), ptr(y), ptr(sc), desc.act, rows, cop, ptr(dz) if dz is not dy else None,
-                                       ptr(dbias), ctx.co, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_act_bwd")
+                                       ptr(dbias), ctx.co, b_acc, ptr(ws), ws.numel(), stream_ptr()), "codeps_act_bwd")
+            if ctx.b_sink is not None:
+                dbias = None            # already accumulated into the flat gradient buffer
         else:
             dz = dy
         if ctx.has_res and ctx.needs_input_grad[6] and dres is None:
@@ -261,18 +298,27 @@ class _Conv2d(torch.autograd.Function):
                   "codeps_reflect_pad_fold")
         elif ctx.needs_input_grad[0]:
             dx0 = torch.empty_like(x0)
+            t0 = _prof_begin()
             check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(dx0), stream_ptr()),
                   "codeps_conv2d_dgrad")
+            _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci))
         if x1 is not None and ctx.needs_input_grad[1]:
             dx1 = torch.empty_like(x1)
+            t0 = _prof_begin()
             check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 1, ptr(dz), ptr(wd), ptr(dx1), stream_ptr()),
                   "codeps_conv2d_dgrad")
+            _prof_end(t0, "conv_dgrad", ctx.flops * (1 - ctx.c0_real / ctx.ci))
         if ctx.needs_input_grad[2]:
-            dw = torch.empty(ctx.co, ctx.ci, desc.kh, desc.kw, dtype=torch.float32, device=dy.device)
+            sink = ctx.w_sink
+            dw = sink if sink is not None else torch.empty(ctx.co, ctx.ci, desc.kh, desc.kw, dtype=torch.float32, device=dy.device)
             wsb = lib().codeps_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
             ws = _workspace(wsb, dy.device, "wgrad")
-            check(lib().codeps_conv2d_wgrad(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(dz), ptr(dw), ctx.co, ctx.ci, 0, ptr(ws),
-                                            ws.numel(), stream_ptr()), "codeps_conv2d_wgrad")
+            t0 = _prof_begin()
+            check(lib().codeps_conv2d_wgrad(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(dz), ptr(dw), ctx.co, ctx.ci,
+                                            1 if sink is not None else 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_conv2d_wgrad")
+            _prof_end(t0, "conv_wgrad", ctx.flops)
+            if sink is not None:
+                dw = None               # accumulated in place into the flat gradient buffer
         return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None
 
 
