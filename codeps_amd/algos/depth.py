@@ -112,17 +112,51 @@ class DepthAlgo:
         depth = self.inference(feats, depth_head)
         return self.evaluator.compute_depth_metrics(depth_gt, depth), depth
 
+    def _pose_pair(self, images, body_pose_sflow, pose_head):
+        if getattr(body_pose_sflow, "accepts_frame_tuple", False):
+            pair = lambda a, b: (a, b)                      # noqa: E731
+        else:
+            pair = lambda a, b: torch.cat([a, b], dim=1)    # noqa: E731
+        return [pose_head(body_pose_sflow(pair(images[1], images[0])), invert_pose=True),
+                pose_head(body_pose_sflow(pair(images[0], images[2])))]
+
     def adaptation(self, images: Dict[str, Tuple[Tensor, Tensor, Tensor]], depth_feats_window, camera_models, depth_head,
-                   body_pose_sflow, pose_head, flow_head=None, check_car_moving: bool = True):
+                   body_pose_sflow, pose_head, flow_head=None, check_car_moving: bool = True, batched=None):
         """Per-key losses (source uses its own ReconstructionLoss geometry), image-count weighted mean
         (algos/depth.py:507-577).  The reference's rolling "car not moving" rule (depth.py:537-558) needs the
-        pose norm on the host every frame; it is evaluated only when `check_car_moving` (one small D2H copy)."""
+        pose norm on the host every frame; it is evaluated only when `check_car_moving` (one small D2H copy).
+
+        `batched` (optional, from CodepsNet.adapt): [(feats_of_one_resolution, {key: (b0, b1)})].  The depth head has
+        no batch-dependent op, so it runs ONCE per resolution over all keys' items (8x larger GEMMs than the
+        reference's per-key calls) and its outputs are sliced per key; the pose encoder keeps the reference's
+        per-key calls because its train-mode BatchNorm statistics depend on the batch composition."""
         keys = [k for k in ["source", "target", "target_replay"] if k in images]
+        pre = {}
+        for feats_b, slices in (batched or []):
+            mine = sorted((slices[k] for k in keys if k in slices))
+            if not mine:
+                continue
+            lo, hi = mine[0][0], mine[-1][1]
+            if sum(b1 - b0 for b0, b1 in mine) != hi - lo:
+                continue                                    # not contiguous: fall back to per-key calls
+            depth_all, disp_all = depth_head([f[lo:hi] for f in feats_b], return_disparity=True)
+            for k in keys:
+                if k in slices:
+                    b0, b1 = slices[k]
+                    pre[k] = (depth_all[b0 - lo:b1 - lo], disp_all[b0 - lo:b1 - lo])
         recon, smth, depth_pred, transformations, num_images = {}, {}, {}, {}, {k: 0 for k in keys}
         for key in keys:
-            recon[key], smth[key], _, _, depth_pred[key], _, transformations[key], _, _ = self.training(
-                images[key], depth_feats_window[key], camera_models[key], depth_head, body_pose_sflow, pose_head, flow_head,
-                None, key == "source", return_disparity=True)
+            if key in pre:
+                depth, disp = pre[key]
+                transformations[key] = self._pose_pair(images[key], body_pose_sflow, pose_head)
+                rec = self.reconstruction_loss_adapt_source if key == "source" else self.reconstruction_loss
+                recon[key] = rec(camera_models[key], images[key], depth, transformations[key], None)
+                smth[key] = self.smoothness_loss(images[key][0], disp)
+                depth_pred[key] = depth
+            else:
+                recon[key], smth[key], _, _, depth_pred[key], _, transformations[key], _, _ = self.training(
+                    images[key], depth_feats_window[key], camera_models[key], depth_head, body_pose_sflow, pose_head, flow_head,
+                    None, key == "source", return_disparity=True)
             skip = False
             if key == "target" and check_car_moving:
                 t0, t1 = transformations[key]

@@ -74,16 +74,31 @@ class SemanticSegAlgo:
         return self._confusion(semantic_pred, semantic_gt), semantic_pred, semantic_logits
 
     def adaptation(self, feats: Dict[str, list], semantic_head, semantic_gt: Dict[str, Tensor],
-                   semantic_weights: Dict[str, Tensor]):
+                   semantic_weights: Dict[str, Tensor], batched=None):
+        """algos/semantic_seg.py:200-249.  `batched` (optional, from CodepsNet.adapt): the semantic head has no
+        batch-dependent op, so all supervised keys of one resolution (source + *mixup) run through it in ONE call;
+        the hard-pixel mining stays per key (separate top-k over each key's pixels, like the reference)."""
         with torch.no_grad():           # target prediction only feeds argmax / panoptic fusion
             target_probs = semantic_head(feats['target'][0])
         semantic_pred = torch.argmax(target_probs, dim=1)
         losses = {'source': None}
-        for key, feat_mixup in feats.items():
-            if key.endswith('mixup'):
-                losses[key] = self.semantic_loss(semantic_head(feat_mixup[0]), semantic_gt[key], None)   # weights = ones
-        if 'source' in feats:
-            losses['source'] = self.semantic_loss(semantic_head(feats['source'][0]), semantic_gt['source'],
-                                                  semantic_weights['source'])
+        sup = [k for k in feats if k.endswith('mixup') or k == 'source']
+        probs = {}
+        for feats_b, slices in (batched or []):
+            mine = sorted((slices[k], k) for k in sup if k in slices)
+            if len(mine) < 2 or not hasattr(semantic_head, "forward_nhwc"):
+                continue
+            lo, hi = mine[0][0][0], mine[-1][0][1]
+            if sum(b1 - b0 for (b0, b1), _ in mine) != hi - lo:
+                continue
+            base = semantic_head.forward_nhwc([f[lo:hi] for f in feats_b])
+            for (b0, b1), k in mine:
+                probs[k] = F.to_nchw(base[b0 - lo:b1 - lo], semantic_head.num_classes)
+        for key in sup:
+            p = probs[key] if key in probs else semantic_head(feats[key][0])
+            if key == 'source':
+                losses['source'] = self.semantic_loss(p, semantic_gt['source'], semantic_weights['source'])
+            else:
+                losses[key] = self.semantic_loss(p, semantic_gt[key], None)          # weights = ones
         confusion_matrix = self._confusion(semantic_pred, semantic_gt.get('target'))
         return losses, confusion_matrix, semantic_pred

@@ -151,12 +151,31 @@ class CodepsNet(nn.Module):
         items = {k: v for k, v in in_data.items() if isinstance(v, dict)}
         camera_models = {k: v["camera_model"] for k, v in items.items() if not k.endswith("mixup")}
         images_window = {k: [v["rgb"][o] for o in depth_offsets] for k, v in items.items() if not k.endswith("mixup")}
-        po_depth_feats = {k: self._encode_window(v["rgb"], depth_offsets) for k, v in items.items() if not k.endswith("mixup")}
         for key in list(items):
-            if key.endswith("mixup"):
-                if self.mixup_fn is not None:
-                    in_data[key] = items[key] = self.mixup_fn(key, items[key], self.instance_algo, self.cfg_mixup)
-                po_depth_feats[key] = [self.backbone_po_depth(items[key]["rgb"][0])]
+            if key.endswith("mixup") and self.mixup_fn is not None:
+                in_data[key] = items[key] = self.mixup_fn(key, items[key], self.instance_algo, self.cfg_mixup)
+        po_depth_feats, batched = {}, []
+        if not self.backbone_po_depth.training and hasattr(self.backbone_po_depth, "forward_batch"):
+            # frozen encoder (eval BatchNorm) is batch-independent: ONE forward per resolution over the centre frames of
+            # every key (order: target, target_replay, source, mixups -> depth keys and supervised-semantic keys are
+            # contiguous batch ranges), instead of one small-batch forward per key
+            order = [k for k in ("target", "target_replay", "source") if k in items] + [k for k in items if k.endswith("mixup")]
+            groups = OrderedDict()
+            for k in order:
+                groups.setdefault(tuple(items[k]["rgb"][0].shape[2:]), []).append(k)
+            for _res, ks in groups.items():
+                feats_b = self.backbone_po_depth.forward_batch([items[k]["rgb"][0] for k in ks])
+                slices, off = {}, 0
+                for k in ks:
+                    n = items[k]["rgb"][0].shape[0]
+                    slices[k] = (off, off + n)
+                    po_depth_feats[k] = [[f[off:off + n] for f in feats_b]] + ([None, None] if not k.endswith("mixup") else [])
+                    off += n
+                batched.append((feats_b, slices))
+        else:
+            for k, v in items.items():
+                po_depth_feats[k] = [self.backbone_po_depth(v["rgb"][0])] if k.endswith("mixup") else \
+                    self._encode_window(v["rgb"], depth_offsets)
 
         center_losses, offset_losses, center_pred, offset_pred, thing_mask_pred = {}, {}, None, None, None
         if self.instance_algo is not None:
@@ -172,7 +191,7 @@ class CodepsNet(nn.Module):
         if self.semantic_algo is not None:
             semantic_losses, confusion_matrix, semantic_pred = self.semantic_algo.adaptation(
                 po_depth_feats, self.semantic_head, {k: v.get("semantic") for k, v in items.items()},
-                {k: v.get("semantic_weights") for k, v in items.items()})
+                {k: v.get("semantic_weights") for k, v in items.items()}, batched=batched)
 
         panoptic_pred, instance_pred = None, None
         if do_panoptic_fusion:
@@ -182,7 +201,7 @@ class CodepsNet(nn.Module):
         if self.depth_algo is not None:
             depth_losses, _, depth_pred, _, _, _ = self.depth_algo.adaptation(
                 images_window, po_depth_feats, camera_models, self.depth_head, self.backbone_pose_sflow, self.pose_head, None,
-                check_car_moving=self.check_car_moving)
+                check_car_moving=self.check_car_moving, batched=batched)
 
         losses = OrderedDict()
         losses["depth_recon"] = depth_losses.get("recon")

@@ -456,21 +456,45 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     hipLaunchKernelGGL(k, dim3(p.n_mt * p.n_nt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
 }
 
+// Tile choice: estimated time ~ waves of blocks over the 256 CUs x tile area x a small-tile inefficiency factor.
+// Big tiles win when the grid is large; per-key / deep-layer GEMMs with few rows need smaller tiles to fill the chip.
+struct TileOpt { int bm, bn; float penalty; };
+
+static int pick_tile(const ConvP& p, const TileOpt* opts, int n) {
+    int best = 0;
+    double best_t = 1e300;
+    for (int i = 0; i < n; ++i) {
+        const long long blocks = (long long)cdiv(p.M, opts[i].bm) * cdiv(p.N, opts[i].bn);
+        const double t = (double)((blocks + 255) / 256) * opts[i].bm * opts[i].bn * opts[i].penalty;
+        if (t < best_t) { best_t = t; best = i; }
+    }
+    return best;
+}
+
 template <int MODE>
 static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a1, const float* wq, const float* scale,
                            const float* shift, const float* residual, float* out, hipStream_t st) {
     const bool bk32 = (kc_gran % 32) == 0;
-    // pick the N tile from the channel count, then the biggest M tile
+#define IG(WM, WN, TM, TN)                                                                          \
+    do {                                                                                            \
+        if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
+        else      launch_igemm<MODE, WM, WN, TM, TN, 16>(p, a0, a1, wq, scale, shift, residual, out, st); \
+    } while (0)
     if (p.N > 64) {
-        if (bk32) launch_igemm<MODE, 2, 2, 2, 2, 32>(p, a0, a1, wq, scale, shift, residual, out, st);
-        else      launch_igemm<MODE, 2, 2, 2, 2, 16>(p, a0, a1, wq, scale, shift, residual, out, st);
+        static const TileOpt o[3] = {{128, 128, 1.0f}, {128, 64, 1.1f}, {64, 64, 1.3f}};
+        switch (pick_tile(p, o, 3)) {
+            case 0: IG(2, 2, 2, 2); break;
+            case 1: IG(2, 2, 2, 1); break;
+            default: IG(2, 2, 1, 1); break;
+        }
     } else if (p.N > 32) {
-        if (bk32) launch_igemm<MODE, 2, 2, 2, 1, 32>(p, a0, a1, wq, scale, shift, residual, out, st);
-        else      launch_igemm<MODE, 2, 2, 2, 1, 16>(p, a0, a1, wq, scale, shift, residual, out, st);
+        static const TileOpt o[2] = {{128, 64, 1.0f}, {64, 64, 1.2f}};
+        if (pick_tile(p, o, 2) == 0) IG(2, 2, 2, 1); else IG(2, 2, 1, 1);
     } else {
-        if (bk32) launch_igemm<MODE, 4, 1, 2, 1, 32>(p, a0, a1, wq, scale, shift, residual, out, st);
-        else      launch_igemm<MODE, 4, 1, 2, 1, 16>(p, a0, a1, wq, scale, shift, residual, out, st);
+        static const TileOpt o[2] = {{256, 32, 1.0f}, {128, 32, 1.15f}};
+        if (pick_tile(p, o, 2) == 0) IG(4, 1, 2, 1); else IG(4, 1, 1, 1);
     }
+#undef IG
 }
 
 }  // namespace

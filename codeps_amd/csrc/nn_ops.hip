@@ -503,8 +503,8 @@ __global__ __launch_bounds__(256) void disp_depth_bwd_kernel(const float* __rest
 }
 
 static int rows_per_block(long long M, int& nblk) {
-    // aim for <= 1024 partial blocks, >= 256 rows each
-    long long rpb = std::max<long long>(256, (M + 1023) / 1024);
+    // <= 256 partial blocks (the serial fixed-order finish pass walks them), >= 256 rows each
+    long long rpb = std::max<long long>(256, (M + 255) / 256);
     nblk = (int)((M + rpb - 1) / rpb);
     return (int)rpb;
 }

@@ -134,6 +134,21 @@ def images_to_nhwc(images, c_pad=16):
     return y
 
 
+def image_batches_to_nhwc(images, c_pad=16):
+    """[B_i,C,H,W] NCHW batches (same C,H,W) -> one NHWC tensor [sum B_i, H, W, c_pad] (batch concat on the fly)."""
+    imgs = [_f32c(i) for i in images]
+    require_cuda(*imgs)
+    _, c, h, w = imgs[0].shape
+    total = sum(i.shape[0] for i in imgs)
+    y = torch.empty(total, h, w, c_pad, dtype=torch.float32, device=imgs[0].device)
+    off = 0
+    for im in imgs:
+        b = im.shape[0]
+        check(lib().codeps_nchw_to_nhwc(ptr(im), b, c, h, w, ptr(y[off:off + b]), c_pad, 0, 1, stream_ptr()), "codeps_nchw_to_nhwc")
+        off += b
+    return y
+
+
 _ws_cache = {}
 
 
@@ -147,26 +162,34 @@ def _workspace(nbytes, device, tag):
     return buf
 
 
-_pack_cache = {}
+_pack_cache = {}           # frozen parameters: valid while (storage, version) is unchanged
+_pack_cache_train = {}     # trainable parameters: valid until the next optimizer step
+_weights_epoch = [0]       # bumped by every in-place optimizer update done through this library
+
+
+def invalidate_weight_cache(everything=False):
+    """Call after modifying parameters in place by means torch cannot see (raw-pointer kernels)."""
+    _weights_epoch[0] += 1
+    _pack_cache_train.clear()
+    if everything:
+        _pack_cache.clear()
 
 
 def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
-    """OIHW parameter -> (w_fwd, w_dgrad) packs.  Packs of frozen parameters are cached on
-    (storage, version); trainable ones are repacked every call (they change every step)."""
-    key = None
-    if not weight.requires_grad:
-        key = (weight.data_ptr(), weight._version, out_c_pad, in_c_pad)
-        hit = _pack_cache.get(key)
-        if hit is not None and (hit[1] is not None or not need_dgrad):
-            return hit
+    """OIHW parameter -> (w_fwd, w_dgrad) packs, cached on (storage, tensor version, weights epoch): frozen
+    weights are packed once, trainable ones once per optimizer step (the pose encoder runs 6x per step)."""
+    cache = _pack_cache_train if weight.requires_grad else _pack_cache
+    key = (weight.data_ptr(), weight._version, out_c_pad, in_c_pad)
+    hit = cache.get(key)
+    if hit is not None and (hit[1] is not None or not need_dgrad):
+        return hit
     co, ci, kh, kw = weight.shape
     w = _f32c(weight.detach())
     wf = torch.empty(out_c_pad * kh * kw * in_c_pad, dtype=torch.float32, device=w.device)
     wd = torch.empty_like(wf) if need_dgrad else None
     check(lib().codeps_conv2d_pack_weights(co, ci, kh, kw, out_c_pad, in_c_pad, ptr(w), ptr(wf), ptr(wd), stream_ptr()),
           "codeps_conv2d_pack_weights")
-    if key is not None:
-        _pack_cache[key] = (wf, wd)
+    cache[key] = (wf, wd)
     return wf, wd
 
 
@@ -811,6 +834,7 @@ def adam_ema_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-4, betas=(0.9,
     check(lib().codeps_adam_ema_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(ema_params), params.numel(),
                                      int(step), lr, betas[0], betas[1], eps, grad_scale, ema_alpha, stream_ptr()),
           "codeps_adam_ema_step")
+    invalidate_weight_cache()
 
 
 # ---------------------------------------------------------------------------------------- panoptic fusion

@@ -118,7 +118,9 @@ class ResnetEncoder(nn.Module):
         """input_image: NCHW tensor, or a tuple of NCHW frames to be stacked along channels (the pose net's
         frame pair) -- the tuple form skips the reference's torch.cat (algos/depth.py:408-413)."""
         enc = self.encoder
-        if isinstance(input_image, (tuple, list)):
+        if isinstance(input_image, _BatchOf):
+            x = F.image_batches_to_nhwc(list(input_image), 16)
+        elif isinstance(input_image, (tuple, list)):
             x = F.images_to_nhwc(list(input_image), 16)
         else:
             x = F.from_nchw(input_image, 16)
@@ -130,3 +132,13 @@ class ResnetEncoder(nn.Module):
                 x = block.forward_nhwc(x, self.sync_bn)
             feats.append(x)
         return [F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]
+
+    def forward_batch(self, images):
+        """Several NCHW image batches of one resolution -> ONE forward over their concatenation along the batch
+        axis (built directly in the stem's NHWC input buffer, no torch.cat).  Result-neutral only when BatchNorm
+        uses running statistics (eval mode): the caller checks `not self.training`."""
+        return self.forward(_BatchOf(images))
+
+
+class _BatchOf(list):
+    """Marker: list of NCHW tensors to be concatenated along the batch axis."""
