@@ -52,9 +52,9 @@ def make_data(mode, h, w, device, rank, per_gpu):
 
 def cpu_baseline(net, full_h, full_w, budget_items=2):
     """The oracle (CPU restatement, kind "port") timed on this host: fwd + bwd + Adam of an adapt step on a
-    BOUNDED sample -- 1 source + 1 target centre image at 1/16 of the pixels (128x256 crop-sized frames; every
-    kernel on the path is linear in the pixel count), scaled back to full-resolution images/sec.  Reported
-    baseline only.  Threads: min(usable cores, 32) -- the oracle's oneDNN convs stop scaling beyond that."""
+    BOUNDED sample -- 1 source + 1 target centre image at full resolution (about 10-20 s with 32 threads).
+    Reported baseline only.  Threads: min(usable cores, 32): with all 256 hardware threads of the GPU box the
+    oracle's oneDNN convolutions ran ~100x slower (925 s for this sample), so more threads is not "more baseline"."""
     from codeps_amd import synthetic
     from oracle import network
     try:
@@ -63,8 +63,8 @@ def cpu_baseline(net, full_h, full_w, budget_items=2):
         usable = os.cpu_count() or 1
     cores = max(1, min(usable, 32))
     torch.set_num_threads(cores)
-    h, w = full_h // 4, full_w // 4
-    pix_scale = (h * w) / float(full_h * full_w)
+    h, w = full_h, full_w
+    pix_scale = 1.0
     sds = {}
     for name in ("backbone_po_depth", "backbone_pose_sflow", "depth_head", "pose_head", "semantic_head", "instance_head"):
         sds[name] = {k: v.detach().cpu().clone() for k, v in getattr(net, name).state_dict().items()}
@@ -92,8 +92,7 @@ def cpu_baseline(net, full_h, full_w, budget_items=2):
     dt = time.perf_counter() - t0
     return {"value": round(budget_items / dt * pix_scale, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle adapt step (fwd+bwd+Adam, ResNet-{net.backbone_po_depth.num_layers}) on 1 source + 1 target centre "
-                      f"image at {h}x{w} (1/16 of the pixels of {full_h}x{full_w}; rate scaled by 1/16), {dt:.1f} s wall, "
-                      f"{cores} torch CPU threads"}
+                      f"image at {h}x{w}, {dt:.1f} s wall, {cores} torch CPU threads"}
 
 
 def conv_roofline(runner, data, steps=2):

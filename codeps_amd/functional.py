@@ -4,6 +4,7 @@ PyTorch supplies device memory (caching allocator), the current HIP stream and t
 all arithmetic happens in libcodeps_hip.so.  Every function raises on CPU tensors -- no fallback.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -179,17 +180,18 @@ def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
     """OIHW parameter -> (w_fwd, w_dgrad) packs, cached on (storage, tensor version, weights epoch): frozen
     weights are packed once, trainable ones once per optimizer step (the pose encoder runs 6x per step)."""
     cache = _pack_cache_train if weight.requires_grad else _pack_cache
-    key = (weight.data_ptr(), weight._version, out_c_pad, in_c_pad)
-    hit = cache.get(key)
-    if hit is not None and (hit[1] is not None or not need_dgrad):
-        return hit
+    key = (id(weight), out_c_pad, in_c_pad)
+    ent = cache.get(key)          # (weakref to the parameter, storage, version, w_fwd, w_dgrad): ids / addresses get reused
+    if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version and \
+            (ent[4] is not None or not need_dgrad):
+        return ent[3], ent[4]
     co, ci, kh, kw = weight.shape
     w = _f32c(weight.detach())
     wf = torch.empty(out_c_pad * kh * kw * in_c_pad, dtype=torch.float32, device=w.device)
     wd = torch.empty_like(wf) if need_dgrad else None
     check(lib().codeps_conv2d_pack_weights(co, ci, kh, kw, out_c_pad, in_c_pad, ptr(w), ptr(wf), ptr(wd), stream_ptr()),
           "codeps_conv2d_pack_weights")
-    cache[key] = (wf, wd)
+    cache[key] = (weakref.ref(weight), weight.data_ptr(), weight._version, wf, wd)
     return wf, wd
 
 

@@ -1,4 +1,6 @@
 """Shared helpers: conv + BatchNorm (+ReLU, +residual) on NHWC through the C ABI."""
+import weakref
+
 import torch
 from torch import nn
 
@@ -13,11 +15,11 @@ def folded_bn(bn: nn.BatchNorm2d):
     ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
            bn.weight.data_ptr())
     hit = _fold_cache.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and hit[3]() is bn:
         return hit[1], hit[2]
     with torch.no_grad():
         scale, shift = F.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-    _fold_cache[key] = (ver, scale, shift)
+    _fold_cache[key] = (ver, scale, shift, weakref.ref(bn))
     return scale, shift
 
 
