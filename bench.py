@@ -106,7 +106,7 @@ def conv_roofline(runner, data, steps=2):
     torch.cuda.synchronize()
     F._profile["on"] = False
     by = {}
-    for kind, flops, a, b in F._profile["events"]:
+    for kind, flops, a, b, _tag in F._profile["events"]:
         d = by.setdefault(kind, [0.0, 0.0, 0])
         d[0] += flops
         d[1] += a.elapsed_time(b) * 1e-3

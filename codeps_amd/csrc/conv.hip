@@ -216,30 +216,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column n = lane&31 of each 32x32 tile, rows (r&3)+8*(r>>2)+4*(lane>>5)
+    // ---- epilogue: accumulators -> LDS tile [BM][BN+4] -> coalesced float4 rows (512 B per 32 lanes at BN = 128),
+    //      affine / residual / activation applied on the vectorised side.  (MFMA C layout: lane holds column
+    //      n = lane&31 of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*(lane>>5); stored directly that would be one
+    //      128-B segment per half-wave per row.)
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;                                  // reuses the staging buffers (all waves passed the last barrier)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + lrow;
-        if (n >= p.N) continue;
-        float sc = 1.f, sh = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+    __syncthreads();
+    constexpr int V4 = BN / 4;                         // float4 per tile row
+    constexpr int RPASS = 256 / V4;                    // rows per pass
+    const int c4 = tid % V4, r0 = tid / V4;
+    const int n = n0 + c4 * 4;
+    if (n < p.N) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (MODE == MODE_FWD) {
-            if (scale) sc = scale[n];
-            if (shift) sh = shift[n];
+            if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+            if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
         }
+#pragma unroll 4
+        for (int rr = r0; rr < BM; rr += RPASS) {
+            const int m = m0 + rr;
+            if (m >= p.M) break;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
+            if (MODE == MODE_FWD) {
+                v = v * sc + sh;
+                if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (MODE == MODE_FWD) {
-                    v = v * sc + sh;
-                    if (residual) v += residual[(size_t)m * p.N + n];
-                    v = apply_act(v, p.act);
-                }
-                out[(size_t)m * p.N + n] = v;
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
             }
+            *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
         }
     }
 }
@@ -449,7 +461,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                          const float* residual, float* out, hipStream_t st) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     p.n_mt = cdiv(p.M, BM); p.n_nt = cdiv(p.N, BN);
-    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    const size_t lds = std::max((size_t)2 * (BM + BN) * (BK + 4), (size_t)BM * (BN + 4)) * sizeof(float);
     auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }

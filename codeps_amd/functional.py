@@ -240,12 +240,16 @@ def _prof_begin():
     return e
 
 
-def _prof_end(start, kind, flops):
+def _prof_end(start, kind, flops, desc=None):
     if start is None:
         return
     e = torch.cuda.Event(enable_timing=True)
     e.record()
-    _profile["events"].append((kind, flops, start, e))
+    tag = None
+    if desc is not None:
+        tag = (f"B{desc.batch} {desc.in_h}x{desc.in_w} {desc.c0}+{desc.c1}->{desc.out_c} k{desc.kh} s{desc.stride}"
+               f"{' up' if desc.up0 else ''}")
+    _profile["events"].append((kind, flops, start, e, tag))
 
 
 class _Conv2d(torch.autograd.Function):
@@ -271,7 +275,7 @@ class _Conv2d(torch.autograd.Function):
         t0 = _prof_begin()
         check(lib().codeps_conv2d_fwd(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
                                       stream_ptr()), "codeps_conv2d_fwd")
-        _prof_end(t0, "conv_fwd", flops)
+        _prof_end(t0, "conv_fwd", flops, desc)
         ctx.desc, ctx.co, ctx.ci, ctx.has_bias = desc, co, ci, bias is not None
         ctx.flops = flops
         ctx.w_sink = _grad_sink.get(id(weight)) if weight.requires_grad else None
@@ -326,13 +330,13 @@ class _Conv2d(torch.autograd.Function):
             t0 = _prof_begin()
             check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(dx0), stream_ptr()),
                   "codeps_conv2d_dgrad")
-            _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci))
+            _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci), desc)
         if x1 is not None and ctx.needs_input_grad[1]:
             dx1 = torch.empty_like(x1)
             t0 = _prof_begin()
             check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 1, ptr(dz), ptr(wd), ptr(dx1), stream_ptr()),
                   "codeps_conv2d_dgrad")
-            _prof_end(t0, "conv_dgrad", ctx.flops * (1 - ctx.c0_real / ctx.ci))
+            _prof_end(t0, "conv_dgrad", ctx.flops * (1 - ctx.c0_real / ctx.ci), desc)
         if ctx.needs_input_grad[2]:
             sink = ctx.w_sink
             dw = sink if sink is not None else torch.empty(ctx.co, ctx.ci, desc.kh, desc.kw, dtype=torch.float32, device=dy.device)
@@ -341,7 +345,7 @@ class _Conv2d(torch.autograd.Function):
             t0 = _prof_begin()
             check(lib().codeps_conv2d_wgrad(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(dz), ptr(dw), ctx.co, ctx.ci,
                                             1 if sink is not None else 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_conv2d_wgrad")
-            _prof_end(t0, "conv_wgrad", ctx.flops)
+            _prof_end(t0, "conv_wgrad", ctx.flops, desc)
             if sink is not None:
                 dw = None               # accumulated in place into the flat gradient buffer
         return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None
