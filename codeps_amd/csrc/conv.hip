@@ -256,6 +256,286 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------- 16-column variant
+// N <= 16 (disparity / class / centre-offset outputs, the 16-channel full-resolution decoder tail and their data
+// gradients): v_mfma_f32_16x16x4_f32 tiles, so no MFMA work is spent on zero-padded output columns.
+// With a single 16-wide column tile every A element feeds exactly one MFMA, i.e. there is NO reuse to stage for:
+// both operands go global -> VGPR directly (lane (l&15, q=l>>4) loads 16 B = k 4q..4q+3 of its own pixel row / weight
+// row for each 16-deep k group; 4 lanes cover one 64-B run), software-pipelined one K-step ahead in registers.
+// No LDS and no barrier in the main loop; waves run independently (64 rows = 4 row tiles per wave).
+template <int MODE, int BK>
+__global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
+                                                           const float* __restrict__ wq, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ residual,
+                                                           float* __restrict__ out) {
+    constexpr int BM = 256, TM = 4, G = BK / 16;
+    __shared__ __attribute__((aligned(16))) float Cs[BM * 20];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    int rb[TM], ry[TM], rx[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wave * 64 + i * 16 + l16;
+        if (m < p.M) {
+            const bool upd = MODE == MODE_DGRAD && p.up0 && p.src == 0;
+            const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : (upd ? (p.H / 2) * (p.W / 2) : p.H * p.W);
+            const int Wm = (MODE == MODE_FWD) ? p.Wo : (upd ? p.W / 2 : p.W);
+            rb[i] = m / HWm;
+            const int rem = m % HWm;
+            ry[i] = rem / Wm; rx[i] = rem % Wm;
+        } else { rb[i] = -1; ry[i] = 0; rx[i] = 0; }
+    }
+    const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
+    const float* brow = (l16 < p.N) ? wq + (size_t)l16 * p.KH * p.KW * Kc + q * 4 : nullptr;
+    const int ntap = (MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW;
+    const int steps_per_tap = Kc / BK, nsteps = ntap * steps_per_tap;
+
+    auto load_step = [&](int step, f32x4 (&af)[TM][G], f32x4 (&bf)[G]) {
+        const int tap = step / steps_per_tap, cstep = (step % steps_per_tap) * BK;
+        int ky, kx, qy = 0, qx = 0;
+        if (MODE == MODE_DGRAD && p.up0 && p.src == 0) {
+            const int qq = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
+            qy = qq >> 1; qx = qq & 1; ky = t2 / p.KW; kx = t2 % p.KW;
+        } else { ky = tap / p.KW; kx = tap % p.KW; }
+        const float* base[TM];
+        if (MODE == MODE_FWD) {
+            const bool s1 = cstep >= p.C0;
+            const float* src = s1 ? a1 : a0;
+            const int cs = s1 ? p.C1 : p.C0, c = (s1 ? cstep - p.C0 : cstep) + q * 4;
+            const bool up = p.up0 && !s1;
+            const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                base[i] = nullptr;
+                if (rb[i] >= 0) {
+                    int iy = ry[i] * p.stride - p.pad + ky, ix = rx[i] * p.stride - p.pad + kx;
+                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                        if (up) { iy >>= 1; ix >>= 1; }
+                        base[i] = src + (((size_t)rb[i] * Hs + iy) * Ws + ix) * cs + c;
+                    }
+                }
+            }
+        } else {
+            const int c = cstep + q * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                base[i] = nullptr;
+                if (rb[i] >= 0) {
+                    int iy = ry[i], ix = rx[i];
+                    if (p.up0 && p.src == 0) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
+                    int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
+                    bool ok = ty >= 0 && tx >= 0;
+                    if (p.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
+                    if (ok && ty < p.Ho && tx < p.Wo) base[i] = a0 + (((size_t)rb[i] * p.Ho + ty) * p.Wo + tx) * p.Co + c;
+                }
+            }
+        }
+        const int koff = ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? (tap % (p.KH * p.KW)) : tap) * Kc + cstep;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i][g] = base[i] ? *reinterpret_cast<const f32x4*>(base[i] + g * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bf[g] = brow ? *reinterpret_cast<const f32x4*>(brow + koff + g * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    f32x4 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a_cur[TM][G], b_cur[G], a_nxt[TM][G], b_nxt[G];
+    load_step(0, a_cur, b_cur);
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) load_step(step + 1, a_nxt, b_nxt);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i][g][e], b_cur[g][e], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            b_cur[g] = b_nxt[g];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a_cur[i][g] = a_nxt[i][g];
+        }
+    }
+    // epilogue through LDS: C layout col = lane&15, row = (lane>>4)*4 + reg  ->  one float4 per (row, 4 columns)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(wave * 64 + i * 16 + q * 4 + r) * 20 + l16] = acc[i][r];
+    __syncthreads();
+    const int c4 = tid & 3, r0 = tid >> 2;                   // 4 float4 per row, 64 rows per pass
+    const int n = c4 * 4;
+    if (n < p.N) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == MODE_FWD) {
+            if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+            if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+        }
+#pragma unroll
+        for (int rr = r0; rr < BM; rr += 64) {
+            const int m = m0 + rr;
+            if (m >= p.M) break;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * 20 + n);
+            if (MODE == MODE_FWD) {
+                v = v * sc + sh;
+                if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+            }
+            *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+        }
+    }
+}
+
+// LDS-staged flavour of the 16-column kernel for deep K (e.g. the 240-channel GUDA conv): full 128-B row segments are
+// fetched once per K-step by 8 adjacent lanes and re-read from LDS as fragments, which keeps the texture path off the
+// critical path when K per tap is large; the register-direct flavour above wins for the K = 144 decoder tail.
+template <int MODE, int BK>
+__global__ __launch_bounds__(256) void conv_igemm16_lds_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
+                                                               const float* __restrict__ wq, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ residual,
+                                                               float* __restrict__ out) {
+    constexpr int BM = 256, BN = 16, TM = 4;
+    constexpr int LDK = BK + 4, CPR = BK / 4, RPP = 256 / CPR, APASS = BM / RPP;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM;
+    const int chunk = tid % CPR, rbase = tid / CPR;
+    int rb[APASS], ry[APASS], rx[APASS];
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m0 + rbase + RPP * i;
+        if (m < p.M) {
+            const bool upd = MODE == MODE_DGRAD && p.up0 && p.src == 0;
+            const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : (upd ? (p.H / 2) * (p.W / 2) : p.H * p.W);
+            const int Wm = (MODE == MODE_FWD) ? p.Wo : (upd ? p.W / 2 : p.W);
+            rb[i] = m / HWm;
+            const int rem = m % HWm;
+            ry[i] = rem / Wm; rx[i] = rem % Wm;
+        } else { rb[i] = -1; ry[i] = 0; rx[i] = 0; }
+    }
+    const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
+    const float* brow = nullptr;
+    if (tid < BN * CPR && tid / CPR < p.N) brow = wq + (size_t)(tid / CPR) * p.KH * p.KW * Kc + chunk * 4;
+    const int ntap = (MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW;
+    const int steps_per_tap = Kc / BK, nsteps = ntap * steps_per_tap;
+    f32x4 areg[APASS], breg;
+    auto load_step = [&](int step) {
+        const int tap = step / steps_per_tap, cstep = (step % steps_per_tap) * BK;
+        int ky, kx, qy = 0, qx = 0;
+        if (MODE == MODE_DGRAD && p.up0 && p.src == 0) {
+            const int qq = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
+            qy = qq >> 1; qx = qq & 1; ky = t2 / p.KW; kx = t2 % p.KW;
+        } else { ky = tap / p.KW; kx = tap % p.KW; }
+        if (MODE == MODE_FWD) {
+            const bool s1 = cstep >= p.C0;
+            const float* src = s1 ? a1 : a0;
+            const int cs = s1 ? p.C1 : p.C0, c = (s1 ? cstep - p.C0 : cstep) + chunk * 4;
+            const bool up = p.up0 && !s1;
+            const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rb[i] >= 0) {
+                    int iy = ry[i] * p.stride - p.pad + ky, ix = rx[i] * p.stride - p.pad + kx;
+                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                        if (up) { iy >>= 1; ix >>= 1; }
+                        v = *reinterpret_cast<const f32x4*>(src + (((size_t)rb[i] * Hs + iy) * Ws + ix) * cs + c);
+                    }
+                }
+                areg[i] = v;
+            }
+        } else {
+            const int c = cstep + chunk * 4;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rb[i] >= 0) {
+                    int iy = ry[i], ix = rx[i];
+                    if (p.up0 && p.src == 0) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
+                    int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
+                    bool ok = ty >= 0 && tx >= 0;
+                    if (p.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
+                    if (ok && ty < p.Ho && tx < p.Wo)
+                        v = *reinterpret_cast<const f32x4*>(a0 + (((size_t)rb[i] * p.Ho + ty) * p.Wo + tx) * p.Co + c);
+                }
+                areg[i] = v;
+            }
+        }
+        const int koff = ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? (tap % (p.KH * p.KW)) : tap) * Kc + cstep;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (brow) v = *reinterpret_cast<const f32x4*>(brow + koff);
+        breg = v;
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(&As[buf][(rbase + RPP * i) * LDK + chunk * 4]) = areg[i];
+        if (tid < BN * CPR) *reinterpret_cast<f32x4*>(&Bs[buf][(tid / CPR) * LDK + chunk * 4]) = breg;
+    };
+    f32x4 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    const int l16 = lane & 15, q = lane >> 4;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) load_step(step + 1);
+        const float* Ab = &As[buf][(wave * 64 + l16) * LDK + q * 4];
+        const float* Bb = &Bs[buf][l16 * LDK + q * 4];
+#pragma unroll
+        for (int g = 0; g < BK / 16; ++g) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(Bb + g * 16);
+            f32x4 af[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 16 * LDK + g * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[e], acc[i], 0, 0, 0);
+        }
+        if (step + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+    float* Cs = &As[0][0];                                   // [256][20]
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(wave * 64 + i * 16 + q * 4 + r) * 20 + l16] = acc[i][r];
+    __syncthreads();
+    const int c4 = tid & 3, r0 = tid >> 2;
+    const int n = c4 * 4;
+    if (n < p.N) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == MODE_FWD) {
+            if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+            if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+        }
+#pragma unroll
+        for (int rr = r0; rr < BM; rr += 64) {
+            const int m = m0 + rr;
+            if (m >= p.M) break;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * 20 + n);
+            if (MODE == MODE_FWD) {
+                v = v * sc + sh;
+                if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+            }
+            *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- wgrad
 // dW[co][tap][ci] partial over a pixel range.  A = dZ^T (LDS [k=pixel][m=co]), B = X(tap) (LDS [k][n=ci]).
 struct WgradP {
@@ -487,6 +767,18 @@ template <int MODE>
 static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a1, const float* wq, const float* scale,
                            const float* shift, const float* residual, float* out, hipStream_t st) {
     const bool bk32 = (kc_gran % 32) == 0;
+    if (p.N <= 16) {
+        p.n_mt = cdiv(p.M, 256); p.n_nt = 1;
+        const int kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
+        const bool single = (MODE != MODE_FWD) || p.C1 == 0;
+        (void)single;
+        if (kc >= 96) {                        // deep K per tap (GUDA 240 channels): LDS-staged flavour
+            if (bk32) hipLaunchKernelGGL((conv_igemm16_lds_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
+            else      hipLaunchKernelGGL((conv_igemm16_lds_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
+        } else if (bk32) hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
+        else      hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
+        return;
+    }
 #define IG(WM, WN, TM, TN)                                                                          \
     do {                                                                                            \
         if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
