@@ -677,6 +677,137 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------- wgrad, small channel counts
+// Weight gradient of stride-1 1x1 / 3x3 convs with <= 32 output channels (the full-resolution decoder tail, the
+// disparity / class convs, the 240-channel GUDA conv): K (= pixels) is huge and the output is tiny, so the generic
+// one-tap-per-block kernel above is latency bound.  Here a block walks over 8x32 pixel tiles; per tile the dZ tile
+// and ONE halo tile of X (a 32-channel chunk) are staged in LDS and every tap reads its shifted window from that halo
+// (X is fetched once instead of once per tap); each wave owns 64 of the 256 pixels and keeps all (m-tile, n-tile, tap)
+// accumulators of v_mfma_f32_16x16x4_f32 in registers across tiles; per-wave partial slabs, fixed-order reduce.
+template <int MT, int NT, int KS>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
+                                                          const float* __restrict__ x0, const float* __restrict__ x1,
+                                                          const float* __restrict__ dz, float* __restrict__ part) {
+    constexpr int TH = 8, TW = 32, XH = TH + KS - 1, XW = TW + KS - 1, TAPS = KS * KS;
+    constexpr int LDZ = MT * 16 + 4, LDX = NT * 16 + 4;
+    __shared__ __attribute__((aligned(16))) float lds_all[TH * TW * LDZ + XH * XW * LDX];
+    float* dZs = lds_all;
+    float* Xs = lds_all + TH * TW * LDZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
+    const int chunk = blockIdx.x % ci_chunks, blk = blockIdx.x / ci_chunks;
+    const int c_base = chunk * NT * 16;                         // first input channel of this block's chunk
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    // source of this channel chunk (chunks never straddle the two concat sources: C0 is a multiple of NT*16 or C1 == 0)
+    const bool s1 = c_base >= p.C0;
+    const float* src = s1 ? x1 : x0;
+    const int cs = s1 ? p.C1 : p.C0, c_src = s1 ? c_base - p.C0 : c_base;
+    const bool up = p.up0 && !s1;
+    const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+
+    f32x4 acc[MT][NT][TAPS];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        __syncthreads();                                        // previous tile's MFMAs are done with the LDS
+        for (int i = tid; i < TH * TW * MT * 4; i += 256) {     // dZ tile: [pixel][MT*16] as float4
+            const int pix = i / (MT * 4), c4 = i % (MT * 4);
+            const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy < p.Ho && gx < p.Wo && c4 * 4 < p.Co) v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.Co + c4 * 4);
+            *reinterpret_cast<f32x4*>(dZs + pix * LDZ + c4 * 4) = v;
+        }
+        for (int i = tid; i < XH * XW * NT * 4; i += 256) {     // X halo tile: [position][NT*16] as float4
+            const int pos = i / (NT * 4), c4 = i % (NT * 4);
+            int iy = ty0 + pos / XW - p.pad, ix = tx0 + pos % XW - p.pad;
+            if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
+                if (up) { iy >>= 1; ix >>= 1; }
+                v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c_src + c4 * 4);
+            }
+            *reinterpret_cast<f32x4*>(Xs + pos * LDX + c4 * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {                          // 16 MFMA k-steps of 4 pixels: this wave's 64 pixels
+            const int pix = wave * 64 + j * 4 + q;
+            const int py = pix / TW, px = pix % TW;
+            float af[MT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = dZs[pix * LDZ + a * 16 + l16];
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const float* xr = Xs + ((py + ky) * XW + px + kx) * LDX + l16;
+#pragma unroll
+                    for (int bb = 0; bb < NT; ++bb) {
+                        const float bv = xr[bb * 16];
+#pragma unroll
+                        for (int a = 0; a < MT; ++a)
+                            acc[a][bb][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bv, acc[a][bb][ky * KS + kx], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    // cross-wave sum through LDS, then ONE partial slab [co][tap][ci] per block.
+    // C layout: column (ci) = lane&15, row (co) = (lane>>4)*4 + reg
+    constexpr int SLAB = MT * 16 * TAPS * NT * 16;              // floats of one block slab
+    static_assert(SLAB <= TH * TW * LDZ + XH * XW * LDX, "reduction buffer must fit in the staging LDS");
+    float* red = lds_all;
+    for (int w = 0; w < 4; ++w) {                               // waves add their accumulators in turn (fixed order)
+        __syncthreads();
+        if (wave != w) continue;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = red + ((a * 16 + q * 4 + r) * TAPS + t) * (NT * 16) + bb * 16 + l16;
+                        *d = (w == 0 ? 0.f : *d) + acc[a][bb][t][r];
+                    }
+    }
+    __syncthreads();
+    float* dst = part + (size_t)blk * p.Co * TAPS * p.Ct;
+    for (int i = tid; i < SLAB; i += 256) {
+        const int cl = i % (NT * 16), t = (i / (NT * 16)) % TAPS, co = i / (NT * 16 * TAPS);
+        const int ci = c_base + cl;
+        if (co < p.Co && ci < p.Ct) dst[((size_t)co * TAPS + t) * p.Ct + ci] = red[i];
+    }
+}
+
+struct SmallPlan { bool ok; int mt, nt, ci_chunks, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
+
+static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
+    SmallPlan s;
+    memset(&s, 0, sizeof(s));
+    const int Ct = d->c0 + d->c1;
+    s.ok = d->stride == 1 && d->kh == d->kw && (d->kh == 1 || d->kh == 3) && d->out_c <= 32 && d->out_h == d->in_h && d->out_w == d->in_w;
+    if (!s.ok) return s;
+    s.mt = d->out_c > 16 ? 2 : 1;
+    s.nt = (Ct % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0)) ? 2 : 1;
+    if (s.nt == 1 && d->c1 > 0 && d->c0 % 16 != 0) { s.ok = false; return s; }
+    s.ci_chunks = cdiv(Ct, s.nt * 16);
+    s.tiles_x = cdiv(d->out_w, 32); s.tiles_y = cdiv(d->out_h, 8);
+    const int total = d->batch * s.tiles_x * s.tiles_y;
+    int want = std::max(1, 768 / s.ci_chunks);                // ~3 blocks per CU in total
+    s.tiles_per_block = std::max(4, cdiv(total, want));
+    s.nblk = cdiv(total, s.tiles_per_block);
+    s.splits = s.nblk;
+    return s;
+}
+
 // sum the split slabs and scatter into the OIHW gradient: dw[co][ci][ky][kx] (+= if accumulate)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int Co, int Ct,
                                                            int taps, int co_real, int ci_real, float* __restrict__ dw,
@@ -688,8 +819,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int tap = (int)((i / Ct) % taps);
         const int co = (int)(i / ((long long)Ct * taps));
         if (co >= co_real || ci >= ci_real) continue;
-        float a = 0.f;
-        for (int s = 0; s < splits; ++s) a += part[(size_t)s * total + i];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;            // 4 independent chains (fixed order -> deterministic)
+        int s = 0;
+        for (; s + 3 < splits; s += 4) {
+            a0 += part[(size_t)s * total + i];
+            a1 += part[(size_t)(s + 1) * total + i];
+            a2 += part[(size_t)(s + 2) * total + i];
+            a3 += part[(size_t)(s + 3) * total + i];
+        }
+        for (; s < splits; ++s) a0 += part[(size_t)s * total + i];
+        const float a = (a0 + a1) + (a2 + a3);
         const size_t o = ((size_t)co * ci_real + ci) * taps + tap;
         dw[o] = accumulate ? dw[o] + a : a;
     }
@@ -867,6 +1006,8 @@ static void wgrad_plan(const codeps_conv_desc* d, int& bm, int& bn, int& n_mt, i
 
 extern "C" size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d) {
     if (check_conv(d, "conv2d_wgrad_workspace_bytes") != CODEPS_OK) return 0;
+    const SmallPlan sp = wgrad_small_plan(d);
+    if (sp.ok) return (size_t)sp.splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
     int bm, bn, n_mt, n_nt, splits, pps;
     wgrad_plan(d, bm, bn, n_mt, n_nt, splits, pps);
     return (size_t)splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
@@ -883,6 +1024,8 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     CODEPS_REQUIRE((d->out_c % 4) == 0, CODEPS_ERR_ARG, "conv2d_wgrad: out_c %d must be a multiple of 4", d->out_c);
     int bm, bn, n_mt, n_nt, splits, pps;
     wgrad_plan(d, bm, bn, n_mt, n_nt, splits, pps);
+    const SmallPlan sp = wgrad_small_plan(d);
+    if (sp.ok) splits = sp.splits;
     const size_t need = (size_t)splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
     CODEPS_REQUIRE(workspace_bytes >= need, CODEPS_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
     WgradP p;
@@ -894,6 +1037,25 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     const int grid = n_mt * n_nt * d->kh * d->kw * splits;
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
+    if (sp.ok) {
+        const int g = sp.nblk * sp.ci_chunks;
+#define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \
+                                                 sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part)
+        if (d->kh == 3) {
+            if (sp.mt == 1 && sp.nt == 1) WS_LAUNCH(1, 1, 3); else if (sp.mt == 1) WS_LAUNCH(1, 2, 3);
+            else if (sp.nt == 1) WS_LAUNCH(2, 1, 3); else WS_LAUNCH(2, 2, 3);
+        } else {
+            if (sp.mt == 1 && sp.nt == 1) WS_LAUNCH(1, 1, 1); else if (sp.mt == 1) WS_LAUNCH(1, 2, 1);
+            else if (sp.nt == 1) WS_LAUNCH(2, 1, 1); else WS_LAUNCH(2, 2, 1);
+        }
+#undef WS_LAUNCH
+        CODEPS_CHECK_LAUNCH("wgrad_small_kernel");
+        const long long total = (long long)d->out_c * (d->c0 + d->c1) * d->kh * d->kw;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, part, splits,
+                           d->out_c, d->c0 + d->c1, d->kh * d->kw, out_c_real, in_c_real, dw_oihw, accumulate);
+        CODEPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+        return CODEPS_OK;
+    }
 #define WG_LAUNCH(WM, WN, TM, TN)                                                                              \
     do {                                                                                                       \
         constexpr int BM_ = 32 * WM * TM, BN_ = 32 * WN * TN;                                                  \
