@@ -1,5 +1,6 @@
 """Depth losses and DepthAlgo: drop-in for algos/depth.py:58-595 (flow losses excluded: make_sflow is
 off in every shipped config)."""
+from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -145,10 +146,32 @@ class DepthAlgo:
                     b0, b1 = slices[k]
                     pre[k] = (depth_all[b0 - lo:b1 - lo], disp_all[b0 - lo:b1 - lo])
         recon, smth, depth_pred, transformations, num_images = {}, {}, {}, {}, {k: 0 for k in keys}
+        # pose nets of all keys of one resolution in ONE batched forward with per-call BatchNorm groups (exactly the
+        # statistics of the reference's 2 x len(keys) separate calls, in the reference's call order)
+        pre_pose = {}
+        if hasattr(body_pose_sflow, "forward_pair_groups"):
+            by_res = OrderedDict()
+            for k in keys:
+                if k in pre:
+                    by_res.setdefault(tuple(images[k][0].shape[2:]), []).append(k)
+            for ks in by_res.values():
+                pairs, spans, off = [], [], 0
+                for k in ks:                                           # call order of the reference: prev pair, next pair
+                    for a, b, inv in ((images[k][1], images[k][0], True), (images[k][0], images[k][2], False)):
+                        pairs.append((a, b))
+                        spans.append((k, inv, off, off + a.shape[0]))
+                        off += a.shape[0]
+                feats = body_pose_sflow.forward_pair_groups(pairs)
+                if hasattr(pose_head, "forward_spans"):
+                    mats = pose_head.forward_spans(feats, [(b0, b1, inv) for _k, inv, b0, b1 in spans])
+                else:
+                    mats = [pose_head([feats[-1][b0:b1]], invert_pose=inv) for _k, inv, b0, b1 in spans]
+                for (k, _inv, _b0, _b1), m in zip(spans, mats):
+                    pre_pose.setdefault(k, []).append(m)
         for key in keys:
             if key in pre:
                 depth, disp = pre[key]
-                transformations[key] = self._pose_pair(images[key], body_pose_sflow, pose_head)
+                transformations[key] = pre_pose[key] if key in pre_pose else self._pose_pair(images[key], body_pose_sflow, pose_head)
                 rec = self.reconstruction_loss_adapt_source if key == "source" else self.reconstruction_loss
                 recon[key] = rec(camera_models[key], images[key], depth, transformations[key], None)
                 smth[key] = self.smoothness_loss(images[key][0], disp)

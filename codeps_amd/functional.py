@@ -135,6 +135,23 @@ def images_to_nhwc(images, c_pad=16):
     return y
 
 
+def frame_pairs_to_nhwc(pairs, c_pad=16):
+    """[(frame_a [B_i,3,H,W], frame_b [B_i,3,H,W]), ...] -> NHWC [sum B_i, H, W, c_pad] with the two frames stacked
+    along channels (the pose net's input, algos/depth.py:408-413) and the pairs concatenated along the batch."""
+    require_cuda(*[t for p in pairs for t in p])
+    _, c, h, w = pairs[0][0].shape
+    total = sum(p[0].shape[0] for p in pairs)
+    y = torch.empty(total, h, w, c_pad, dtype=torch.float32, device=pairs[0][0].device)
+    off = 0
+    for fa, fb in pairs:
+        b = fa.shape[0]
+        for k, im in enumerate((_f32c(fa), _f32c(fb))):
+            check(lib().codeps_nchw_to_nhwc(ptr(im), b, c, h, w, ptr(y[off:off + b]), c_pad, k * c, 1 if k == 0 else 0, stream_ptr()),
+                  "codeps_nchw_to_nhwc")
+        off += b
+    return y
+
+
 def image_batches_to_nhwc(images, c_pad=16):
     """[B_i,C,H,W] NCHW batches (same C,H,W) -> one NHWC tensor [sum B_i, H, W, c_pad] (batch concat on the fly)."""
     imgs = [_f32c(i) for i in images]
@@ -367,60 +384,82 @@ def bn_fold(weight, bias, running_mean, running_var, eps):
 
 
 class _BatchNormTrain(torch.autograd.Function):
-    """Train-mode BatchNorm (+ residual, + ReLU) on NHWC with batch statistics; the raw sums pass
-    through `reduce_fn` (an all-reduce over ranks for SyncBN, identity otherwise)."""
+    """Train-mode BatchNorm (+ residual, + ReLU) on NHWC with batch statistics; the statistics pass through
+    `reduce_fn` (cross-rank combination for SyncBN, identity otherwise).
+
+    `groups` = list of (b0, b1) batch ranges with INDEPENDENT statistics: several reference-style calls (each with
+    its own batch statistics and its own running-stat momentum update, applied in list order) share one set of
+    batched convolutions -- e.g. the six pose-net calls of an adaptation step run as one batch of 12 frame pairs."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, reduce_fn):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, reduce_fn, groups):
         require_cuda(x, gamma, beta)
         x = x.contiguous()
         cp = x.shape[-1]
-        rows = x.numel() // cp
         c = gamma.numel()
-        sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
-        wsb = lib().codeps_colsum_workspace_bytes(rows, cp, 2)
-        ws = _workspace(wsb, x.device, "colsum")
-        check(lib().codeps_bn_stats(ptr(x), rows, cp, ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_stats")
-        count = float(rows)
-        d = sums[0] / count
-        mean = x.reshape(rows, cp)[0] + d                       # shifted-data statistics (see codeps_bn_stats)
-        var = (sums[1] / count - d * d).clamp_(min=0)
-        if reduce_fn is not None:                               # SyncBN: combine (mean, var, count) over ranks
-            mean, var, count = reduce_fn(mean, var, count)
-        invstd = torch.rsqrt(var + eps)
-        if running_mean is not None:
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean[:c], alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var[:c] * (count / max(count - 1, 1)), alpha=momentum)
+        bsz = x.shape[0]
+        per_item = x.numel() // cp // bsz
+        groups = [(0, bsz)] if not groups else list(groups)
         g, b_ = _pad_vec(gamma, cp), _pad_vec(beta, cp)
         if residual is not None:
             residual = residual.contiguous()
         y = torch.empty_like(x)
-        check(lib().codeps_bn_apply(ptr(x), ptr(mean), ptr(invstd), ptr(g), ptr(b_), ptr(residual), act, rows, cp, ptr(y),
-                                    stream_ptr()), "codeps_bn_apply")
-        ctx.save_for_backward(x, y if act else None, mean, invstd, g)
-        ctx.act, ctx.c, ctx.count, ctx.reduce_fn, ctx.has_res = act, c, count, reduce_fn, residual is not None
+        means, invstds, counts = [], [], []
+        for (b0, b1) in groups:
+            xg = x[b0:b1]
+            rows = (b1 - b0) * per_item
+            sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
+            ws = _workspace(lib().codeps_colsum_workspace_bytes(rows, cp, 2), x.device, "colsum")
+            check(lib().codeps_bn_stats(ptr(xg), rows, cp, ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_stats")
+            count = float(rows)
+            d = sums[0] / count
+            mean = xg.reshape(rows, cp)[0] + d                      # shifted-data statistics (see codeps_bn_stats)
+            var = (sums[1] / count - d * d).clamp_(min=0)
+            if reduce_fn is not None:                               # SyncBN: combine (mean, var, count) over ranks
+                mean, var, count = reduce_fn(mean, var, count)
+            invstd = torch.rsqrt(var + eps)
+            if running_mean is not None:
+                with torch.no_grad():
+                    running_mean.mul_(1 - momentum).add_(mean[:c], alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(var[:c] * (count / max(count - 1, 1)), alpha=momentum)
+            rg = None if residual is None else residual[b0:b1]
+            check(lib().codeps_bn_apply(ptr(xg), ptr(mean), ptr(invstd), ptr(g), ptr(b_), ptr(rg), act, rows, cp, ptr(y[b0:b1]),
+                                        stream_ptr()), "codeps_bn_apply")
+            means.append(mean)
+            invstds.append(invstd)
+            counts.append(count)
+        ctx.save_for_backward(x, y if act else None, g, *means, *invstds)
+        ctx.act, ctx.c, ctx.counts, ctx.reduce_fn, ctx.has_res, ctx.groups = act, c, counts, reduce_fn, residual is not None, groups
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, invstd, g = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        x, y, g = saved[0], saved[1], saved[2]
+        ng = len(ctx.groups)
+        means, invstds = saved[3:3 + ng], saved[3 + ng:3 + 2 * ng]
         dy = dy.contiguous()
         cp = x.shape[-1]
-        rows = x.numel() // cp
-        sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
-        wsb = lib().codeps_colsum_workspace_bytes(rows, cp, 2)
-        ws = _workspace(wsb, x.device, "colsum")
-        check(lib().codeps_bn_bwd_reduce(ptr(dy), ptr(y), ptr(x), ptr(mean), ptr(invstd), ctx.act, rows, cp, ptr(sums), ptr(ws),
-                                         ws.numel(), stream_ptr()), "codeps_bn_bwd_reduce")
-        dgamma, dbeta = sums[1, :ctx.c].clone(), sums[0, :ctx.c].clone()      # local (DDP averages them later)
-        if ctx.reduce_fn is not None:
-            sums = ctx.reduce_fn.sum(sums)
+        per_item = x.numel() // cp // x.shape[0]
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        check(lib().codeps_bn_bwd_apply(ptr(dy), ptr(y), ptr(x), ptr(mean), ptr(invstd), ptr(g), ptr(sums), 1.0 / ctx.count,
-                                        ctx.act, rows, cp, ptr(dx), ptr(dres), stream_ptr()), "codeps_bn_bwd_apply")
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        dgamma = dbeta = None
+        for gi, (b0, b1) in enumerate(ctx.groups):
+            rows = (b1 - b0) * per_item
+            sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
+            ws = _workspace(lib().codeps_colsum_workspace_bytes(rows, cp, 2), x.device, "colsum")
+            yg = None if y is None else y[b0:b1]
+            check(lib().codeps_bn_bwd_reduce(ptr(dy[b0:b1]), ptr(yg), ptr(x[b0:b1]), ptr(means[gi]), ptr(invstds[gi]), ctx.act, rows, cp,
+                                             ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_bwd_reduce")
+            dgamma = sums[1, :ctx.c].clone() if dgamma is None else dgamma + sums[1, :ctx.c]   # local (DDP averages later)
+            dbeta = sums[0, :ctx.c].clone() if dbeta is None else dbeta + sums[0, :ctx.c]
+            if ctx.reduce_fn is not None:
+                sums = ctx.reduce_fn.sum(sums)
+            dr = None if dres is None else dres[b0:b1]
+            check(lib().codeps_bn_bwd_apply(ptr(dy[b0:b1]), ptr(yg), ptr(x[b0:b1]), ptr(means[gi]), ptr(invstds[gi]), ptr(g), ptr(sums),
+                                            1.0 / ctx.counts[gi], ctx.act, rows, cp, ptr(dx[b0:b1]), ptr(dr), stream_ptr()),
+                  "codeps_bn_bwd_apply")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 class _BatchNormEval(torch.autograd.Function):
@@ -470,9 +509,9 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, residua
 
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None, act=None,
-                     reduce_fn=None):
+                     reduce_fn=None, groups=None):
     return _BatchNormTrain.apply(x, gamma, beta, residual, running_mean, running_var, float(momentum), float(eps), ACT[act],
-                                 reduce_fn)
+                                 reduce_fn, groups)
 
 
 # ---------------------------------------------------------------------------------------- pooling / resize

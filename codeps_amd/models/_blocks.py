@@ -23,16 +23,16 @@ def folded_bn(bn: nn.BatchNorm2d):
     return scale, shift
 
 
-def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None):
+def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None, groups=None):
     """act(BN(conv(x)) + residual).  Eval-mode BN is folded into the conv epilogue (one kernel);
     train-mode BN uses batch statistics (`sync` = cross-rank sum reducer for SyncBatchNorm)."""
     stride, pad = conv.stride[0], conv.padding[0]
     if bn.training:
         y = F.conv2d(x, conv.weight, stride=stride, pad=pad)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                 residual=residual, act=act, reduce_fn=sync)
+                                 residual=residual, act=act, reduce_fn=sync, groups=groups)
         if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            bn.num_batches_tracked += len(groups) if groups else 1
         return out
     if torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad):
         # eval statistics but trainable affine parameters: keep BN as its own op so gamma/beta get gradients

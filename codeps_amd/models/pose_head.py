@@ -26,15 +26,23 @@ class PoseHead(nn.Module):
         self.relu = nn.ReLU()
         self.net = nn.ModuleList(list(self.convs.values()))
 
-    def forward(self, input_features: List[Tensor], invert_pose: bool = False) -> Tensor:
+    def _features(self, input_features):
         x = F.from_nchw(input_features[-1])
         sq, p0, p1, p2 = self.net
         x = F.conv2d(x, sq.weight, sq.bias, act="relu")
         x = F.conv2d(x, p0.weight, p0.bias, stride=self.stride, pad=1, act="relu")
         x = F.conv2d(x, p1.weight, p1.bias, stride=self.stride, pad=1, act="relu")
-        x = F.conv2d(x, p2.weight, p2.bias)
+        return F.conv2d(x, p2.weight, p2.bias)
+
+    def forward(self, input_features: List[Tensor], invert_pose: bool = False) -> Tensor:
         # spatial mean, *0.01, frame 0 of num_frames_to_predict_for, Rodrigues, (inverse) composition: one kernel
-        return F.pose_matrix(x, invert_pose)
+        return F.pose_matrix(self._features(input_features), invert_pose)
+
+    def forward_spans(self, input_features: List[Tensor], spans) -> List[Tensor]:
+        """One batched pass of the (batch-independent) convs, then one pose-matrix kernel per (b0, b1, invert) span:
+        equivalent to calling forward() on every slice."""
+        x = self._features(input_features)
+        return [F.pose_matrix(x[b0:b1], inv) for b0, b1, inv in spans]
 
     @staticmethod
     def transformation_from_parameters(axisangle: Tensor, translation: Tensor, invert: bool = False) -> Tensor:

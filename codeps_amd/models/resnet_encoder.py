@@ -27,10 +27,10 @@ class _BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
-    def forward_nhwc(self, x, sync):
-        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], sync=sync)
-        out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync)
-        return conv_bn(out, self.conv2, self.bn2, "relu", residual=identity, sync=sync)
+    def forward_nhwc(self, x, sync, groups=None):
+        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
+        out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups)
+        return conv_bn(out, self.conv2, self.bn2, "relu", residual=identity, sync=sync, groups=groups)
 
 
 class _Bottleneck(nn.Module):
@@ -46,11 +46,11 @@ class _Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.downsample = downsample
 
-    def forward_nhwc(self, x, sync):
-        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], sync=sync)
-        out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync)
-        out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync)
-        return conv_bn(out, self.conv3, self.bn3, "relu", residual=identity, sync=sync)
+    def forward_nhwc(self, x, sync, groups=None):
+        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
+        out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups)
+        out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync, groups=groups)
+        return conv_bn(out, self.conv3, self.bn3, "relu", residual=identity, sync=sync, groups=groups)
 
 
 class _ResNet(nn.Module):
@@ -118,20 +118,34 @@ class ResnetEncoder(nn.Module):
         """input_image: NCHW tensor, or a tuple of NCHW frames to be stacked along channels (the pose net's
         frame pair) -- the tuple form skips the reference's torch.cat (algos/depth.py:408-413)."""
         enc = self.encoder
-        if isinstance(input_image, _BatchOf):
+        groups = None
+        if isinstance(input_image, _PairGroups):
+            x = F.frame_pairs_to_nhwc(list(input_image), 16)
+            groups, off = [], 0
+            for fa, _fb in input_image:
+                groups.append((off, off + fa.shape[0]))
+                off += fa.shape[0]
+        elif isinstance(input_image, _BatchOf):
             x = F.image_batches_to_nhwc(list(input_image), 16)
         elif isinstance(input_image, (tuple, list)):
             x = F.images_to_nhwc(list(input_image), 16)
         else:
             x = F.from_nchw(input_image, 16)
-        x = conv_bn(x, enc.conv1, enc.bn1, "relu", sync=self.sync_bn)
+        x = conv_bn(x, enc.conv1, enc.bn1, "relu", sync=self.sync_bn, groups=groups)
         feats = [x]
         x = F.max_pool3x3s2(x)
         for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
             for block in layer:
-                x = block.forward_nhwc(x, self.sync_bn)
+                x = block.forward_nhwc(x, self.sync_bn, groups)
             feats.append(x)
         return [F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]
+
+    def forward_pair_groups(self, pairs):
+        """pairs = [(frame_a, frame_b), ...]: every pair is what the reference feeds to ONE call of this encoder
+        (`torch.cat([a, b], 1)`, algos/depth.py:408-413).  All pairs run through one set of batched convolutions while
+        every BatchNorm keeps per-pair batch statistics and applies the running-stat momentum updates pair by pair in
+        list order -- bit-for-bit the semantics of len(pairs) separate calls, at len(pairs) x larger GEMMs."""
+        return self.forward(_PairGroups(pairs))
 
     def forward_batch(self, images):
         """Several NCHW image batches of one resolution -> ONE forward over their concatenation along the batch
@@ -142,3 +156,7 @@ class ResnetEncoder(nn.Module):
 
 class _BatchOf(list):
     """Marker: list of NCHW tensors to be concatenated along the batch axis."""
+
+
+class _PairGroups(list):
+    """Marker: list of (frame_a, frame_b) pairs = independent BatchNorm groups of one batched forward."""
