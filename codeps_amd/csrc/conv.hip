@@ -547,14 +547,15 @@ template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* __restrict__ x0,
                                                          const float* __restrict__ x1, const float* __restrict__ dz,
                                                          float* __restrict__ part) {
-    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, BKP = 16;        // 16 pixels per K-step
+    constexpr int KS = 4 / (WM * WN);              // narrow tiles: the spare waves split K (pixel rows) inside the block
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, BKP = KS == 4 ? 32 : 16;   // pixels per K-step
     constexpr int LDM = BM + 4, LDN = BN + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                        // [2][BKP][LDM]
     float* Bs = smem + 2 * BKP * LDM;        // [2][BKP][LDN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const bool active = wave < WM * WN;          // small tiles use fewer than 4 MFMA waves; all 4 still load
+    const int wt = wave % (WM * WN), kw = wave / (WM * WN);      // tile position, K-split lane of this wave
+    const int wm = wt / WN, wn = wt % WN;
     int bid = blockIdx.x;
     const int split = bid % p.splits; bid /= p.splits;
     const int nt = bid % p.n_nt; bid /= p.n_nt;
@@ -638,9 +639,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
             if (step + 1 < nsteps) load_step(pbeg + (step + 1) * BKP);
             const float* Ab = As + buf * BKP * LDM + wm * TM * 32 + lrow;
             const float* Bb = Bs + buf * BKP * LDN + wn * TN * 32 + lrow;
-            if (active)
 #pragma unroll
             for (int g = 0; g < BKP / 8; ++g) {
+                if (KS > 1 && (g % KS) != kw) continue;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int kr = g * 8 + lhalf * 4 + e;
@@ -660,9 +661,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
             __syncthreads();
         }
     }
+    if (KS > 1) {                                  // fixed-order sum of the K-split waves through LDS
+        static_assert(KS == 1 || BM * BN <= 2 * BKP * (LDM + LDN), "reduction tile must fit in the staging LDS");
+        float* red = smem;
+        for (int w = 0; w < KS; ++w) {
+            __syncthreads();
+            if (kw != w) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* d = red + (((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * BN) + (wn * TN + j) * 32 + lrow;
+                        const float v = (w == 0 ? 0.f : *d) + acc[i][j][r];
+                        if (w == KS - 1) acc[i][j][r] = v; else *d = v;
+                    }
+        }
+        if (kw != KS - 1) return;                  // the last K-split wave holds the block's total
+    }
     // partial slab [split][co][tap][ci]
     float* dst = part + (size_t)split * p.Co * p.KH * p.KW * p.Ct;
-    if (active)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + lrow;
@@ -1058,8 +1077,8 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     }
 #define WG_LAUNCH(WM, WN, TM, TN)                                                                              \
     do {                                                                                                       \
-        constexpr int BM_ = 32 * WM * TM, BN_ = 32 * WN * TN;                                                  \
-        const size_t lds = (size_t)2 * 16 * (BM_ + 4 + BN_ + 4) * sizeof(float);                               \
+        constexpr int BM_ = 32 * WM * TM, BN_ = 32 * WN * TN, BKP_ = (4 / (WM * WN)) == 4 ? 32 : 16;           \
+        const size_t lds = (size_t)2 * BKP_ * (BM_ + 4 + BN_ + 4) * sizeof(float);                             \
         hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), lds, st, p, x0, x1, dz, part); \
     } while (0)
     if (bm == 128 && bn == 128) WG_LAUNCH(2, 2, 2, 2);
@@ -1067,7 +1086,7 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     else if (bm == 128 && bn == 32) WG_LAUNCH(4, 1, 1, 1);
     else if (bm == 64 && bn == 128) WG_LAUNCH(2, 2, 1, 2);
     else if (bm == 64 && bn == 64) WG_LAUNCH(2, 2, 1, 1);
-    else if (bm == 64 && bn == 32) WG_LAUNCH(2, 1, 1, 1);   // 2 waves idle-padded below
+    else if (bm == 64 && bn == 32) WG_LAUNCH(2, 1, 1, 1);
     else if (bm == 32 && bn == 128) WG_LAUNCH(1, 4, 1, 1);
     else if (bm == 32 && bn == 64) WG_LAUNCH(1, 2, 1, 1);
     else WG_LAUNCH(1, 1, 1, 1);

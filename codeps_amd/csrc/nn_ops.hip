@@ -241,6 +241,191 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------- BatchNorm, multi-group launches
+// Several independent statistic groups (contiguous row ranges of one [rows][C] tensor, e.g. the six pose-net calls of
+// an adaptation step batched into one forward) handled by ONE launch per phase: blockIdx.z = group.
+struct BnGroups { int n; long long row0[8]; long long rows[8]; float inv_count[8]; };
+
+// partial (sum (x - s_g), sum (x - s_g)^2) with s_g = first row of the group: part[g][blk][2][C]
+__global__ __launch_bounds__(256) void bn_stats_mg_kernel(const float* __restrict__ x, BnGroups gr, int C, int nblk,
+                                                          float* __restrict__ part) {
+    const int g = blockIdx.z;
+    const int Gall = C / 4, G = Gall < 256 ? Gall : 256;
+    const int tl = threadIdx.x % G, tr = threadIdx.x / G, TR = 256 / G;
+    const int tg = blockIdx.y * G + tl;
+    const bool cok = tg < Gall && tr < TR;
+    const long long M = gr.rows[g], rpb = (M + nblk - 1) / nblk;
+    const long long r0 = gr.row0[g] + (long long)blockIdx.x * rpb;
+    const long long r1 = min(r0 + rpb, gr.row0[g] + M);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(x + (size_t)gr.row0[g] * C + tg * 4);
+        for (long long r = r0 + tr; r < r1; r += TR) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + tg * 4) - sh;
+            s += v; q += v * v;
+        }
+    }
+    __shared__ f32x4 red[2][256];
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < G && blockIdx.y * G + threadIdx.x < Gall) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < TR; ++k) { a += red[0][k * G + threadIdx.x]; b += red[1][k * G + threadIdx.x]; }
+        float* dst = part + (((size_t)g * nblk + blockIdx.x) * 2) * C + (blockIdx.y * G + threadIdx.x) * 4;
+        *reinterpret_cast<f32x4*>(dst) = a;
+        *reinterpret_cast<f32x4*>(dst + C) = b;
+    }
+}
+
+// one thread per channel: finish the partial sums of every group (fixed order), mean / biased var / invstd per group,
+// and the running-stat momentum updates applied group after group (= the order of the reference's separate calls)
+__global__ __launch_bounds__(256) void bn_finalize_mg_kernel(const float* __restrict__ x, const float* __restrict__ part, BnGroups gr,
+                                                             int C, int c_real, int nblk, float eps, float momentum,
+                                                             float* __restrict__ mean, float* __restrict__ var,
+                                                             float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float rm = 0.f, rv = 0.f;
+    const bool upd = running_mean != nullptr && c < c_real;
+    if (upd) { rm = running_mean[c]; rv = running_var[c]; }
+    for (int g = 0; g < gr.n; ++g) {
+        float s1 = 0.f, s2 = 0.f;
+        const float* p = part + (size_t)g * nblk * 2 * C + c;
+        for (int b = 0; b < nblk; ++b) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
+        const float n = (float)gr.rows[g];
+        const float d = s1 / n;
+        const float m = x[(size_t)gr.row0[g] * C + c] + d;
+        const float v = fmaxf(s2 / n - d * d, 0.f);
+        mean[g * C + c] = m; var[g * C + c] = v; invstd[g * C + c] = rsqrtf(v + eps);
+        if (upd) {
+            rm = rm * (1.f - momentum) + momentum * m;
+            rv = rv * (1.f - momentum) + momentum * (v * (n / fmaxf(n - 1.f, 1.f)));
+        }
+    }
+    if (upd) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
+__device__ __forceinline__ int bn_group_of(const BnGroups& gr, long long row) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) g += (i < gr.n && row >= gr.row0[i]) ? 1 : 0;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_mg_kernel(const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ residual, int act,
+                                                          long long M, int C, float* __restrict__ y) {
+    const int G = C / 4;
+    const long long total = M * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g4 = (int)(i % G);
+        const long long row = i / G;
+        const int grp = bn_group_of(gr, row);
+        const size_t o = (size_t)row * C + g4 * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + o);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + grp * C + g4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + grp * C + g4 * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g4 * 4), be = *reinterpret_cast<const f32x4*>(beta + g4 * 4);
+        f32x4 r = (v - mu) * is * ga + be;
+        if (residual) r += *reinterpret_cast<const f32x4*>(residual + o);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + o) = r;
+    }
+}
+
+// backward partials per group: (sum g, sum g*xhat) with g = dy * relu'(y): part[g][blk][2][C]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, int act, int C, int nblk,
+                                                               float* __restrict__ part) {
+    const int g = blockIdx.z;
+    const int Gall = C / 4, G = Gall < 256 ? Gall : 256;
+    const int tl = threadIdx.x % G, tr = threadIdx.x / G, TR = 256 / G;
+    const int tg = blockIdx.y * G + tl;
+    const bool cok = tg < Gall && tr < TR;
+    const long long M = gr.rows[g], rpb = (M + nblk - 1) / nblk;
+    const long long r0 = gr.row0[g] + (long long)blockIdx.x * rpb;
+    const long long r1 = min(r0 + rpb, gr.row0[g] + M);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + tg * 4), is = *reinterpret_cast<const f32x4*>(invstd + g * C + tg * 4);
+        for (long long r = r0 + tr; r < r1; r += TR) {
+            const size_t o = (size_t)r * C + tg * 4;
+            f32x4 gg = *reinterpret_cast<const f32x4*>(dy + o);
+            if (act == 1) {
+                const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+            }
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+            s += gg; q += gg * xh;
+        }
+    }
+    __shared__ f32x4 red[2][256];
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < G && blockIdx.y * G + threadIdx.x < Gall) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < TR; ++k) { a += red[0][k * G + threadIdx.x]; b += red[1][k * G + threadIdx.x]; }
+        float* dst = part + (((size_t)g * nblk + blockIdx.x) * 2) * C + (blockIdx.y * G + threadIdx.x) * 4;
+        *reinterpret_cast<f32x4*>(dst) = a;
+        *reinterpret_cast<f32x4*>(dst + C) = b;
+    }
+}
+
+// finish backward partials: sums[g][2][C] per group, dgamma / dbeta (= / +=) summed over groups
+__global__ __launch_bounds__(256) void bn_bwd_finish_mg_kernel(const float* __restrict__ part, BnGroups gr, int C, int c_real, int nblk,
+                                                               float* __restrict__ sums, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float tg = 0.f, tb = 0.f;
+    for (int g = 0; g < gr.n; ++g) {
+        float s1 = 0.f, s2 = 0.f;
+        const float* p = part + (size_t)g * nblk * 2 * C + c;
+        for (int b = 0; b < nblk; ++b) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
+        sums[(size_t)g * 2 * C + c] = s1; sums[(size_t)g * 2 * C + C + c] = s2;
+        tb += s1; tg += s2;
+    }
+    if (c < c_real) {
+        dgamma[c] = accumulate ? dgamma[c] + tg : tg;
+        dbeta[c] = accumulate ? dbeta[c] + tb : tb;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_mg_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ sums, int act,
+                                                              long long M, int C, float* __restrict__ dx, float* __restrict__ dres) {
+    const int G = C / 4;
+    const long long total = M * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g4 = (int)(i % G);
+        const long long row = i / G;
+        const int grp = bn_group_of(gr, row);
+        const size_t o = (size_t)row * C + g4 * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        if (act == 1) {
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+        }
+        if (dres) *reinterpret_cast<f32x4*>(dres + o) = g;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + grp * C + g4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + grp * C + g4 * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g4 * 4);
+        const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + (size_t)grp * 2 * C + g4 * 4);
+        const f32x4 sgx = *reinterpret_cast<const f32x4*>(sums + (size_t)grp * 2 * C + C + g4 * 4);
+        const float ic = gr.inv_count[grp];
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+        *reinterpret_cast<f32x4*>(dx + o) = ga * is * (g - sg * ic - xh * sgx * ic);
+    }
+}
+
 // ---------------------------------------------------------------------------------- max-pool 3x3 / stride 2 / pad 1
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho, int Wo,
                                                           float* __restrict__ y, uint8_t* __restrict__ arg) {
@@ -617,6 +802,84 @@ extern "C" int codeps_bn_bwd_apply(const float* dy, const float* y, const float*
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, invstd,
                        gamma, sums, inv_count, act, rows, c, dx, dres);
     CODEPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return CODEPS_OK;
+}
+
+static int make_groups(int n_groups, const long long* row0, const long long* rows, BnGroups& gr, long long& total, const char* who) {
+    CODEPS_REQUIRE(n_groups >= 1 && n_groups <= 8 && row0 && rows, CODEPS_ERR_ARG, "%s: 1..8 groups supported", who);
+    gr.n = n_groups;
+    total = 0;
+    for (int i = 0; i < 8; ++i) { gr.row0[i] = 0; gr.rows[i] = 0; gr.inv_count[i] = 0.f; }
+    for (int i = 0; i < n_groups; ++i) {
+        CODEPS_REQUIRE(rows[i] > 0 && row0[i] == total, CODEPS_ERR_ARG, "%s: groups must be non-empty, contiguous and in order", who);
+        gr.row0[i] = row0[i]; gr.rows[i] = rows[i];
+        total += rows[i];
+    }
+    return CODEPS_OK;
+}
+
+static int mg_blocks(const BnGroups& gr) {
+    long long mx = 0;
+    for (int i = 0; i < gr.n; ++i) mx = std::max(mx, gr.rows[i]);
+    return (int)std::max<long long>(1, std::min<long long>(256 / std::max(gr.n / 2, 1), (mx + 255) / 256));
+}
+
+extern "C" size_t codeps_bn_mg_workspace_bytes(int n_groups, int c) { return (size_t)n_groups * 256 * 2 * c * sizeof(float); }
+
+extern "C" int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* row0, const long long* rows, int c, int c_real,
+                                const float* gamma, const float* beta, const float* residual, int act, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean, float* var, float* invstd, float* y,
+                                int stats_only, int apply_only, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    BnGroups gr;
+    long long M;
+    int rc = make_groups(n_groups, row0, rows, gr, M, "bn_fwd_mg");
+    if (rc) return rc;
+    CODEPS_REQUIRE(x && mean && var && invstd && (c % 4) == 0 && c_real <= c && act >= 0 && act <= 1, CODEPS_ERR_ARG, "bn_fwd_mg: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = mg_blocks(gr);
+    if (!apply_only) {
+        CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)n_groups * nblk * 2 * c * 4, CODEPS_ERR_WORKSPACE, "bn_fwd_mg: workspace too small");
+        hipLaunchKernelGGL(bn_stats_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, x, gr, c, nblk, (float*)workspace);
+        hipLaunchKernelGGL(bn_finalize_mg_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, x, (const float*)workspace, gr, c, c_real, nblk, eps,
+                           momentum, mean, var, invstd, running_mean, running_var);
+        CODEPS_CHECK_LAUNCH("bn_stats_mg_kernel");
+    }
+    if (!stats_only) {
+        CODEPS_REQUIRE(gamma && beta && y, CODEPS_ERR_ARG, "bn_fwd_mg: null affine / output");
+        hipLaunchKernelGGL(bn_apply_mg_kernel, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, x, gr, (const float*)mean, (const float*)invstd,
+                           gamma, beta, residual, act, M, c, y);
+        CODEPS_CHECK_LAUNCH("bn_apply_mg_kernel");
+    }
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x, int n_groups, const long long* row0, const long long* rows,
+                                int c, int c_real, const float* mean, const float* invstd, const float* gamma, const float* inv_count,
+                                int act, float* sums, float* dgamma, float* dbeta, int accumulate, float* dx, float* dres,
+                                int reduce_only, int apply_only, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    BnGroups gr;
+    long long M;
+    int rc = make_groups(n_groups, row0, rows, gr, M, "bn_bwd_mg");
+    if (rc) return rc;
+    CODEPS_REQUIRE(dy && x && mean && invstd && sums && (c % 4) == 0 && (act == 0 || y), CODEPS_ERR_ARG, "bn_bwd_mg: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = mg_blocks(gr);
+    if (!apply_only) {
+        CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)n_groups * nblk * 2 * c * 4 && dgamma && dbeta, CODEPS_ERR_WORKSPACE,
+                       "bn_bwd_mg: workspace too small / null grads");
+        hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, dy, y, x, gr, mean, invstd, act, c, nblk,
+                           (float*)workspace);
+        hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma,
+                           dbeta, accumulate);
+        CODEPS_CHECK_LAUNCH("bn_bwd_reduce_mg_kernel");
+    }
+    if (!reduce_only) {
+        CODEPS_REQUIRE(gamma && inv_count && dx, CODEPS_ERR_ARG, "bn_bwd_mg: null gamma / inv_count / dx");
+        for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = inv_count[i];
+        hipLaunchKernelGGL(bn_bwd_apply_mg_kernel, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, (const float*)sums,
+                           act, M, c, dx, dres);
+        CODEPS_CHECK_LAUNCH("bn_bwd_apply_mg_kernel");
+    }
     return CODEPS_OK;
 }
 

@@ -383,13 +383,20 @@ def bn_fold(weight, bias, running_mean, running_var, eps):
     return scale, bias.detach() - running_mean * scale
 
 
+def _group_arrays(groups, per_item):
+    n = len(groups)
+    arr = ctypes.c_longlong * n
+    return n, arr(*[g[0] * per_item for g in groups]), arr(*[(g[1] - g[0]) * per_item for g in groups])
+
+
 class _BatchNormTrain(torch.autograd.Function):
-    """Train-mode BatchNorm (+ residual, + ReLU) on NHWC with batch statistics; the statistics pass through
-    `reduce_fn` (cross-rank combination for SyncBN, identity otherwise).
+    """Train-mode BatchNorm (+ residual, + ReLU) on NHWC with batch statistics (C ABI: codeps_bn_{fwd,bwd}_mg);
+    statistics pass through `reduce_fn` (cross-rank combination for SyncBN; None = local).
 
     `groups` = list of (b0, b1) batch ranges with INDEPENDENT statistics: several reference-style calls (each with
     its own batch statistics and its own running-stat momentum update, applied in list order) share one set of
-    batched convolutions -- e.g. the six pose-net calls of an adaptation step run as one batch of 12 frame pairs."""
+    batched convolutions -- e.g. the six pose-net calls of an adaptation step run as one batch of 12 frame pairs.
+    All groups are handled by one launch per phase."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, reduce_fn, groups):
@@ -400,65 +407,66 @@ class _BatchNormTrain(torch.autograd.Function):
         bsz = x.shape[0]
         per_item = x.numel() // cp // bsz
         groups = [(0, bsz)] if not groups else list(groups)
+        ng, row0, rows = _group_arrays(groups, per_item)
         g, b_ = _pad_vec(gamma, cp), _pad_vec(beta, cp)
         if residual is not None:
             residual = residual.contiguous()
+        dev = x.device
         y = torch.empty_like(x)
-        means, invstds, counts = [], [], []
-        for (b0, b1) in groups:
-            xg = x[b0:b1]
-            rows = (b1 - b0) * per_item
-            sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
-            ws = _workspace(lib().codeps_colsum_workspace_bytes(rows, cp, 2), x.device, "colsum")
-            check(lib().codeps_bn_stats(ptr(xg), rows, cp, ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_stats")
-            count = float(rows)
-            d = sums[0] / count
-            mean = xg.reshape(rows, cp)[0] + d                      # shifted-data statistics (see codeps_bn_stats)
-            var = (sums[1] / count - d * d).clamp_(min=0)
-            if reduce_fn is not None:                               # SyncBN: combine (mean, var, count) over ranks
-                mean, var, count = reduce_fn(mean, var, count)
+        mean = torch.empty(ng, cp, dtype=torch.float32, device=dev)
+        var, invstd = torch.empty_like(mean), torch.empty_like(mean)
+        ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
+        counts = [float((b1 - b0) * per_item) for b0, b1 in groups]
+        rm = running_mean if (running_mean is not None and running_mean.numel() == c) else None
+        if reduce_fn is None:
+            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, ptr(rm),
+                                         ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 0,
+                                         ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+        else:       # SyncBN: local statistics -> cross-rank combination -> apply
+            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(mean),
+                                         ptr(var), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+            for gi in range(ng):
+                m, v, counts[gi] = reduce_fn(mean[gi], var[gi], counts[gi])
+                mean[gi], var[gi] = m, v
+                if rm is not None:
+                    with torch.no_grad():
+                        rm.mul_(1 - momentum).add_(m[:c], alpha=momentum)
+                        running_var.mul_(1 - momentum).add_(v[:c] * (counts[gi] / max(counts[gi] - 1, 1)), alpha=momentum)
             invstd = torch.rsqrt(var + eps)
-            if running_mean is not None:
-                with torch.no_grad():
-                    running_mean.mul_(1 - momentum).add_(mean[:c], alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(var[:c] * (count / max(count - 1, 1)), alpha=momentum)
-            rg = None if residual is None else residual[b0:b1]
-            check(lib().codeps_bn_apply(ptr(xg), ptr(mean), ptr(invstd), ptr(g), ptr(b_), ptr(rg), act, rows, cp, ptr(y[b0:b1]),
-                                        stream_ptr()), "codeps_bn_apply")
-            means.append(mean)
-            invstds.append(invstd)
-            counts.append(count)
-        ctx.save_for_backward(x, y if act else None, g, *means, *invstds)
-        ctx.act, ctx.c, ctx.counts, ctx.reduce_fn, ctx.has_res, ctx.groups = act, c, counts, reduce_fn, residual is not None, groups
+            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, None, None,
+                                         ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1, ptr(ws), ws.numel(), stream_ptr()),
+                  "codeps_bn_fwd_mg")
+        ctx.inv_count = [1.0 / n for n in counts]
+        ctx.save_for_backward(x, y if act else None, g, mean, invstd)
+        ctx.act, ctx.c, ctx.reduce_fn, ctx.has_res, ctx.groups, ctx.per_item = act, c, reduce_fn, residual is not None, groups, per_item
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        saved = ctx.saved_tensors
-        x, y, g = saved[0], saved[1], saved[2]
-        ng = len(ctx.groups)
-        means, invstds = saved[3:3 + ng], saved[3 + ng:3 + 2 * ng]
+        x, y, g, mean, invstd = ctx.saved_tensors
         dy = dy.contiguous()
         cp = x.shape[-1]
-        per_item = x.numel() // cp // x.shape[0]
+        ng, row0, rows = _group_arrays(ctx.groups, ctx.per_item)
+        inv_count = (ctypes.c_float * ng)(*ctx.inv_count)
+        dev = x.device
+        sums = torch.empty(ng, 2, cp, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(ctx.c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty_like(dgamma)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        dgamma = dbeta = None
-        for gi, (b0, b1) in enumerate(ctx.groups):
-            rows = (b1 - b0) * per_item
-            sums = torch.empty(2, cp, dtype=torch.float32, device=x.device)
-            ws = _workspace(lib().codeps_colsum_workspace_bytes(rows, cp, 2), x.device, "colsum")
-            yg = None if y is None else y[b0:b1]
-            check(lib().codeps_bn_bwd_reduce(ptr(dy[b0:b1]), ptr(yg), ptr(x[b0:b1]), ptr(means[gi]), ptr(invstds[gi]), ctx.act, rows, cp,
-                                             ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_bwd_reduce")
-            dgamma = sums[1, :ctx.c].clone() if dgamma is None else dgamma + sums[1, :ctx.c]   # local (DDP averages later)
-            dbeta = sums[0, :ctx.c].clone() if dbeta is None else dbeta + sums[0, :ctx.c]
-            if ctx.reduce_fn is not None:
-                sums = ctx.reduce_fn.sum(sums)
-            dr = None if dres is None else dres[b0:b1]
-            check(lib().codeps_bn_bwd_apply(ptr(dy[b0:b1]), ptr(yg), ptr(x[b0:b1]), ptr(means[gi]), ptr(invstds[gi]), ptr(g), ptr(sums),
-                                            1.0 / ctx.counts[gi], ctx.act, rows, cp, ptr(dx[b0:b1]), ptr(dr), stream_ptr()),
-                  "codeps_bn_bwd_apply")
+        ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
+        if ctx.reduce_fn is None:
+            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), inv_count,
+                                         ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(dres), 0, 0, ptr(ws), ws.numel(),
+                                         stream_ptr()), "codeps_bn_bwd_mg")
+        else:
+            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), None, None, ctx.act,
+                                         ptr(sums), ptr(dgamma), ptr(dbeta), 0, None, None, 1, 0, ptr(ws), ws.numel(), stream_ptr()),
+                  "codeps_bn_bwd_mg")
+            sums = ctx.reduce_fn.sum(sums)
+            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), inv_count,
+                                         ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(dres), 0, 1, ptr(ws), ws.numel(),
+                                         stream_ptr()), "codeps_bn_bwd_mg")
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 

@@ -132,6 +132,24 @@ int codeps_bn_bwd_reduce(const float* dy, const float* y, const float* x, const 
 int codeps_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean,
                         const float* invstd, const float* gamma, const float* sums, float inv_count, int act,
                         long long rows, int c, float* dx, float* dres, codeps_stream_t stream);
+/* Multi-group train-mode BatchNorm: n_groups (<= 8) contiguous row ranges [row0[g], row0[g]+rows[g]) of one
+ * [rows][c] tensor, each with its OWN batch statistics (several reference-style calls batched into one forward);
+ * host arrays row0 / rows.  _fwd: statistics (shifted sums), mean / biased var / invstd [n_groups][c], running-stat
+ * momentum updates applied group after group, then y = act((x-mean_g)*invstd_g*gamma+beta+residual).
+ * stats_only / apply_only split the call for SyncBN (cross-rank combination of mean/var in between).
+ * _bwd: sums [n_groups][2][c] = (sum g, sum g*xhat), dgamma/dbeta [c_real] (=, or += when accumulate) summed over
+ * groups, dx and dres; inv_count = HOST array [n_groups] (1 / global element count of each group). */
+size_t codeps_bn_mg_workspace_bytes(int n_groups, int c);
+int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* row0, const long long* rows, int c, int c_real,
+                     const float* gamma, const float* beta, const float* residual, int act, float eps,
+                     float momentum, float* running_mean, float* running_var, float* mean, float* var,
+                     float* invstd, float* y, int stats_only, int apply_only, void* workspace,
+                     size_t workspace_bytes, codeps_stream_t stream);
+int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x, int n_groups, const long long* row0,
+                     const long long* rows, int c, int c_real, const float* mean, const float* invstd,
+                     const float* gamma, const float* inv_count, int act, float* sums, float* dgamma,
+                     float* dbeta, int accumulate, float* dx, float* dres, int reduce_only, int apply_only,
+                     void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 /* nn.MaxPool2d(3, 2, 1) (models/resnet_encoder.py:31); argmax = window tap 0..8 per element (u8). */
 int codeps_maxpool3x3s2_fwd(const float* x, int batch, int h, int w, int c, float* y, uint8_t* argmax,
                             codeps_stream_t stream);
