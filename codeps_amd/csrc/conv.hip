@@ -735,24 +735,44 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
-        __syncthreads();                                        // previous tile's MFMAs are done with the LDS
-        for (int i = tid; i < TH * TW * MT * 4; i += 256) {     // dZ tile: [pixel][MT*16] as float4
+        // all global loads of the tile are issued into registers first, then written to LDS (one latency, not one per
+        // element: a load -> ds_write pair per loop iteration would wait for every load separately)
+        constexpr int NZ = TH * TW * MT * 4 / 256, NX = (XH * XW * NT * 4 + 255) / 256;
+        f32x4 zr[NZ], xr_[NX];
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {                          // dZ tile: [pixel][MT*16] as float4
+            const int i = tid + 256 * u;
             const int pix = i / (MT * 4), c4 = i % (MT * 4);
             const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gy < p.Ho && gx < p.Wo && c4 * 4 < p.Co) v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.Co + c4 * 4);
-            *reinterpret_cast<f32x4*>(dZs + pix * LDZ + c4 * 4) = v;
+            zr[u] = v;
         }
-        for (int i = tid; i < XH * XW * NT * 4; i += 256) {     // X halo tile: [position][NT*16] as float4
-            const int pos = i / (NT * 4), c4 = i % (NT * 4);
-            int iy = ty0 + pos / XW - p.pad, ix = tx0 + pos % XW - p.pad;
-            if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {                          // X halo tile: [position][NT*16] as float4
+            const int i = tid + 256 * u;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
-                if (up) { iy >>= 1; ix >>= 1; }
-                v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c_src + c4 * 4);
+            if (i < XH * XW * NT * 4) {
+                const int pos = i / (NT * 4), c4 = i % (NT * 4);
+                int iy = ty0 + pos / XW - p.pad, ix = tx0 + pos % XW - p.pad;
+                if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
+                    if (up) { iy >>= 1; ix >>= 1; }
+                    v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c_src + c4 * 4);
+                }
             }
-            *reinterpret_cast<f32x4*>(Xs + pos * LDX + c4 * 4) = v;
+            xr_[u] = v;
+        }
+        __syncthreads();                                        // previous tile's MFMAs are done with the LDS
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int i = tid + 256 * u;
+            *reinterpret_cast<f32x4*>(dZs + (i / (MT * 4)) * LDZ + (i % (MT * 4)) * 4) = zr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + 256 * u;
+            if (i < XH * XW * NT * 4) *reinterpret_cast<f32x4*>(Xs + (i / (NT * 4)) * LDX + (i % (NT * 4)) * 4) = xr_[u];
         }
         __syncthreads();
 #pragma unroll 4

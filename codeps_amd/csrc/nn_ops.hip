@@ -284,15 +284,21 @@ __global__ __launch_bounds__(256) void bn_finalize_mg_kernel(const float* __rest
                                                              float* __restrict__ mean, float* __restrict__ var,
                                                              float* __restrict__ invstd, float* __restrict__ running_mean,
                                                              float* __restrict__ running_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    // 8 lanes per channel walk the partial blocks (fixed assignment + fixed-order shuffle tree -> deterministic)
+    const int c = blockIdx.x * 32 + threadIdx.x / 8, sub = threadIdx.x % 8;
+    const bool cin = c < C;
     float rm = 0.f, rv = 0.f;
-    const bool upd = running_mean != nullptr && c < c_real;
+    const bool upd = running_mean != nullptr && cin && c < c_real;
     if (upd) { rm = running_mean[c]; rv = running_var[c]; }
     for (int g = 0; g < gr.n; ++g) {
         float s1 = 0.f, s2 = 0.f;
-        const float* p = part + (size_t)g * nblk * 2 * C + c;
-        for (int b = 0; b < nblk; ++b) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
+        if (cin) {
+            const float* p = part + (size_t)g * nblk * 2 * C + c;
+            for (int b = sub; b < nblk; b += 8) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (!cin || sub != 0) continue;
         const float n = (float)gr.rows[g];
         const float d = s1 / n;
         const float m = x[(size_t)gr.row0[g] * C + c] + d;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void bn_finalize_mg_kernel(const float* __rest
             rv = rv * (1.f - momentum) + momentum * (v * (n / fmaxf(n - 1.f, 1.f)));
         }
     }
-    if (upd) { running_mean[c] = rm; running_var[c] = rv; }
+    if (upd && sub == 0) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
 __device__ __forceinline__ int bn_group_of(const BnGroups& gr, long long row) {
@@ -381,17 +387,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __re
 __global__ __launch_bounds__(256) void bn_bwd_finish_mg_kernel(const float* __restrict__ part, BnGroups gr, int C, int c_real, int nblk,
                                                                float* __restrict__ sums, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x * 32 + threadIdx.x / 8, sub = threadIdx.x % 8;
+    const bool cin = c < C;
     float tg = 0.f, tb = 0.f;
     for (int g = 0; g < gr.n; ++g) {
         float s1 = 0.f, s2 = 0.f;
-        const float* p = part + (size_t)g * nblk * 2 * C + c;
-        for (int b = 0; b < nblk; ++b) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
+        if (cin) {
+            const float* p = part + (size_t)g * nblk * 2 * C + c;
+            for (int b = sub; b < nblk; b += 8) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (!cin || sub != 0) continue;
         sums[(size_t)g * 2 * C + c] = s1; sums[(size_t)g * 2 * C + C + c] = s2;
         tb += s1; tg += s2;
     }
-    if (c < c_real) {
+    if (cin && sub == 0 && c < c_real) {
         dgamma[c] = accumulate ? dgamma[c] + tg : tg;
         dbeta[c] = accumulate ? dbeta[c] + tb : tb;
     }
@@ -840,7 +851,7 @@ extern "C" int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* r
     if (!apply_only) {
         CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)n_groups * nblk * 2 * c * 4, CODEPS_ERR_WORKSPACE, "bn_fwd_mg: workspace too small");
         hipLaunchKernelGGL(bn_stats_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, x, gr, c, nblk, (float*)workspace);
-        hipLaunchKernelGGL(bn_finalize_mg_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, x, (const float*)workspace, gr, c, c_real, nblk, eps,
+        hipLaunchKernelGGL(bn_finalize_mg_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, x, (const float*)workspace, gr, c, c_real, nblk, eps,
                            momentum, mean, var, invstd, running_mean, running_var);
         CODEPS_CHECK_LAUNCH("bn_stats_mg_kernel");
     }
@@ -869,7 +880,7 @@ extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x,
                        "bn_bwd_mg: workspace too small / null grads");
         hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, dy, y, x, gr, mean, invstd, act, c, nblk,
                            (float*)workspace);
-        hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma,
+        hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma,
                            dbeta, accumulate);
         CODEPS_CHECK_LAUNCH("bn_bwd_reduce_mg_kernel");
     }
