@@ -15,6 +15,8 @@
 // K-step); LDS rows padded to BK+4 floats => conflict-free ds_read_b128 fragment reads
 // (row stride 36 or 20 dwords walks all 16 four-bank slots).  blockIdx is remapped so that the
 // N-tiles of one M-tile run on the same XCD (they share the A tile through that XCD's L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -222,36 +224,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     //      128-B segment per half-wave per row.)
     constexpr int LDC = BN + 4;
     float* Cs = smem;                                  // reuses the staging buffers (all waves passed the last barrier)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cs[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
-    __syncthreads();
     constexpr int V4 = BN / 4;                         // float4 per tile row
     constexpr int RPASS = 256 / V4;                    // rows per pass
     const int c4 = tid % V4, r0 = tid / V4;
     const int n = n0 + c4 * 4;
-    if (n < p.N) {
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (MODE == MODE_FWD) {
-            if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
-            if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
-        }
-#pragma unroll 4
-        for (int rr = r0; rr < BM; rr += RPASS) {
-            const int m = m0 + rr;
-            if (m >= p.M) break;
-            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
-            if (MODE == MODE_FWD) {
-                v = v * sc + sh;
-                if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_FWD && n < p.N) {
+        if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+        if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+    }
+    // one pass per row-tile index i: staging holds WM*32 rows (keeps the LDS footprint at <= 34 KB so that the
+    // K-loop buffers, not the epilogue, decide how many blocks fit on a CU)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    for (int i = 0; i < TM; ++i) {
+        if (i > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+        __syncthreads();
+        if (n < p.N) {
+#pragma unroll 4
+            for (int rr = r0; rr < WM * 32; rr += RPASS) {
+                const int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
+                if (m >= p.M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
+                if (MODE == MODE_FWD) {
+                    v = v * sc + sh;
+                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
             }
-            *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
         }
     }
 }
@@ -703,13 +709,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
 // and ONE halo tile of X (a 32-channel chunk) are staged in LDS and every tap reads its shifted window from that halo
 // (X is fetched once instead of once per tap); each wave owns 64 of the 256 pixels and keeps all (m-tile, n-tile, tap)
 // accumulators of v_mfma_f32_16x16x4_f32 in registers across tiles; per-wave partial slabs, fixed-order reduce.
-template <int MT, int NT, int KS>
+template <int MT, int NT, int KS, int STRIDE, int TH, int TW>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                           const float* __restrict__ x0, const float* __restrict__ x1,
                                                           const float* __restrict__ dz, float* __restrict__ part) {
-    constexpr int TH = 8, TW = 32, XH = TH + KS - 1, XW = TW + KS - 1, TAPS = KS * KS;
+    constexpr int XH = (TH - 1) * STRIDE + KS, XW = (TW - 1) * STRIDE + KS, TAPS = KS * KS, PIX = TH * TW;
+    static_assert(PIX % 64 == 0 && (PIX * MT * 4) % 256 == 0, "tile must give every wave whole MFMA k-steps");
+    const int co_base = blockIdx.y * MT * 16;                    // output-channel group of this block (stem: 4 groups of 16)
     constexpr int LDZ = MT * 16 + 4, LDX = NT * 16 + 4;
-    __shared__ __attribute__((aligned(16))) float lds_all[TH * TW * LDZ + XH * XW * LDX];
+    constexpr int SLAB = MT * 16 * TAPS * NT * 16;              // floats of one block slab (cross-wave reduction buffer)
+    constexpr int STAGE = TH * TW * LDZ + XH * XW * LDX;
+    __shared__ __attribute__((aligned(16))) float lds_all[STAGE > SLAB ? STAGE : SLAB];
     float* dZs = lds_all;
     float* Xs = lds_all + TH * TW * LDZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
@@ -737,7 +747,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
         // all global loads of the tile are issued into registers first, then written to LDS (one latency, not one per
         // element: a load -> ds_write pair per loop iteration would wait for every load separately)
-        constexpr int NZ = TH * TW * MT * 4 / 256, NX = (XH * XW * NT * 4 + 255) / 256;
+        constexpr int NZ = PIX * MT * 4 / 256, NX = (XH * XW * NT * 4 + 255) / 256;
         f32x4 zr[NZ], xr_[NX];
 #pragma unroll
         for (int u = 0; u < NZ; ++u) {                          // dZ tile: [pixel][MT*16] as float4
@@ -745,7 +755,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
             const int pix = i / (MT * 4), c4 = i % (MT * 4);
             const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy < p.Ho && gx < p.Wo && c4 * 4 < p.Co) v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.Co + c4 * 4);
+            if (gy < p.Ho && gx < p.Wo && co_base + c4 * 4 < p.Co)
+                v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.Co + co_base + c4 * 4);
             zr[u] = v;
         }
 #pragma unroll
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (i < XH * XW * NT * 4) {
                 const int pos = i / (NT * 4), c4 = i % (NT * 4);
-                int iy = ty0 + pos / XW - p.pad, ix = tx0 + pos % XW - p.pad;
+                int iy = ty0 * STRIDE + pos / XW - p.pad, ix = tx0 * STRIDE + pos % XW - p.pad;
                 if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
                     if (up) { iy >>= 1; ix >>= 1; }
@@ -776,8 +787,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
         }
         __syncthreads();
 #pragma unroll 4
-        for (int j = 0; j < 16; ++j) {                          // 16 MFMA k-steps of 4 pixels: this wave's 64 pixels
-            const int pix = wave * 64 + j * 4 + q;
+        for (int j = 0; j < PIX / 16; ++j) {                    // MFMA k-steps of 4 pixels over this wave's PIX/4 pixels
+            const int pix = wave * (PIX / 4) + j * 4 + q;
             const int py = pix / TW, px = pix % TW;
             float af[MT];
 #pragma unroll
@@ -786,7 +797,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
             for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    const float* xr = Xs + ((py + ky) * XW + px + kx) * LDX + l16;
+                    const float* xr = Xs + ((py * STRIDE + ky) * XW + px * STRIDE + kx) * LDX + l16;
 #pragma unroll
                     for (int bb = 0; bb < NT; ++bb) {
                         const float bv = xr[bb * 16];
@@ -799,8 +810,6 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
     }
     // cross-wave sum through LDS, then ONE partial slab [co][tap][ci] per block.
     // C layout: column (ci) = lane&15, row (co) = (lane>>4)*4 + reg
-    constexpr int SLAB = MT * 16 * TAPS * NT * 16;              // floats of one block slab
-    static_assert(SLAB <= TH * TW * LDZ + XH * XW * LDX, "reduction buffer must fit in the staging LDS");
     float* red = lds_all;
     for (int w = 0; w < 4; ++w) {                               // waves add their accumulators in turn (fixed order)
         __syncthreads();
@@ -822,16 +831,28 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
     for (int i = tid; i < SLAB; i += 256) {
         const int cl = i % (NT * 16), t = (i / (NT * 16)) % TAPS, co = i / (NT * 16 * TAPS);
         const int ci = c_base + cl;
-        if (co < p.Co && ci < p.Ct) dst[((size_t)co * TAPS + t) * p.Ct + ci] = red[i];
+        if (co_base + co < p.Co && ci < p.Ct) dst[((size_t)(co_base + co) * TAPS + t) * p.Ct + ci] = red[i];
     }
 }
 
-struct SmallPlan { bool ok; int mt, nt, ci_chunks, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
+struct SmallPlan { bool ok, stem; int mt, nt, ci_chunks, co_groups, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
 
 static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
     SmallPlan s;
     memset(&s, 0, sizeof(s));
     const int Ct = d->c0 + d->c1;
+    s.co_groups = 1;
+    if (d->kh == 7 && d->kw == 7 && d->stride == 2 && Ct == 16 && d->c1 == 0 && !d->up0 && (d->out_c % 16) == 0) {
+        // ResNet stem (7x7 / 2 on the 16-channel padded image): 4x16-pixel output tiles, one 16-channel output group per block
+        s.ok = s.stem = true;
+        s.mt = 1; s.nt = 1; s.ci_chunks = 1; s.co_groups = d->out_c / 16;
+        s.tiles_x = cdiv(d->out_w, 16); s.tiles_y = cdiv(d->out_h, 4);
+        const int total = d->batch * s.tiles_x * s.tiles_y;
+        s.tiles_per_block = std::max(8, cdiv(total, std::max(1, 768 / s.co_groups)));
+        s.nblk = cdiv(total, s.tiles_per_block);
+        s.splits = s.nblk;
+        return s;
+    }
     s.ok = d->stride == 1 && d->kh == d->kw && (d->kh == 1 || d->kh == 3) && d->out_c <= 32 && d->out_h == d->in_h && d->out_w == d->in_w;
     if (!s.ok) return s;
     s.mt = d->out_c > 16 ? 2 : 1;
@@ -919,7 +940,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                          const float* residual, float* out, hipStream_t st) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     p.n_mt = cdiv(p.M, BM); p.n_nt = cdiv(p.N, BN);
-    const size_t lds = std::max((size_t)2 * (BM + BN) * (BK + 4), (size_t)BM * (BN + 4)) * sizeof(float);
+    const size_t lds = std::max((size_t)2 * (BM + BN) * (BK + 4), (size_t)WM * 32 * (BN + 4)) * sizeof(float);
     auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -944,7 +965,8 @@ static int pick_tile(const ConvP& p, const TileOpt* opts, int n) {
 template <int MODE>
 static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a1, const float* wq, const float* scale,
                            const float* shift, const float* residual, float* out, hipStream_t st) {
-    const bool bk32 = (kc_gran % 32) == 0;
+    static const int force_bk = getenv("CODEPS_FORCE_BK") ? atoi(getenv("CODEPS_FORCE_BK")) : 0;   // tuning experiments only
+    const bool bk32 = (kc_gran % 32) == 0 && force_bk != 16;
     if (p.N <= 16) {
         p.n_mt = cdiv(p.M, 256); p.n_nt = 1;
         const int kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
@@ -1078,9 +1100,12 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     float* part = (float*)workspace;
     if (sp.ok) {
         const int g = sp.nblk * sp.ci_chunks;
-#define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \
+#define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS, 1, 8, 32>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \
                                                  sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part)
-        if (d->kh == 3) {
+        if (sp.stem) {
+            hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 2, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x,
+                               sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
+        } else if (d->kh == 3) {
             if (sp.mt == 1 && sp.nt == 1) WS_LAUNCH(1, 1, 3); else if (sp.mt == 1) WS_LAUNCH(1, 2, 3);
             else if (sp.nt == 1) WS_LAUNCH(2, 1, 3); else WS_LAUNCH(2, 2, 3);
         } else {
