@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--per-gpu-batch", type=int, default=None)
     ap.add_argument("--graph", type=int, default=1, help="replay forward+backward from a captured HIP graph")
+    ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' + "
+                    "CODEPS_ALL_RANKS_ON_GPU0=1 lets the N>1 code path be exercised on a single-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -143,7 +145,9 @@ def main():
     from codeps_amd import _lib
     from codeps_amd.distributed import init_from_env
     from codeps_amd.step import StepRunner
-    rank, local, world = init_from_env()
+    rank, local, world = init_from_env(args.dist_backend)
+    if os.environ.get("CODEPS_ALL_RANKS_ON_GPU0") == "1":
+        local = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: codeps_amd has no CPU path")

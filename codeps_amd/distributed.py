@@ -55,6 +55,23 @@ class SyncBatchNormReducer:
         var_all = ((vars_ + (means - mean_all) ** 2) * counts).sum(0) / total
         return mean_all, var_all, float(total)
 
+    def combine_groups(self, mean, var, counts):
+        """All statistic groups of one BatchNorm layer in ONE all-gather: mean / var [G, C], counts = G floats."""
+        world = dist.get_world_size(self.group)
+        g, c = mean.shape
+        packed = torch.cat([mean.reshape(-1), var.reshape(-1), mean.new_tensor(counts)])
+        gathered = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(gathered, packed, group=self.group)
+        allp = torch.stack(gathered)                                  # [world, 2*G*C + G]
+        means = allp[:, :g * c].view(world, g, c)
+        vars_ = allp[:, g * c:2 * g * c].view(world, g, c)
+        cnts = allp[:, 2 * g * c:].view(world, g, 1)
+        total = cnts.sum(0)                                           # [G, 1]
+        mean_all = (means * cnts).sum(0) / total
+        var_all = ((vars_ + (means - mean_all) ** 2) * cnts).sum(0) / total
+        # counts are equal on all ranks by construction (equal shards) -> no host sync needed to read them back
+        return mean_all, var_all, [float(n) * world for n in counts]
+
     def sum(self, sums):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
         return sums

@@ -425,13 +425,12 @@ class _BatchNormTrain(torch.autograd.Function):
         else:       # SyncBN: local statistics -> cross-rank combination -> apply
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(mean),
                                          ptr(var), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
-            for gi in range(ng):
-                m, v, counts[gi] = reduce_fn(mean[gi], var[gi], counts[gi])
-                mean[gi], var[gi] = m, v
-                if rm is not None:
-                    with torch.no_grad():
-                        rm.mul_(1 - momentum).add_(m[:c], alpha=momentum)
-                        running_var.mul_(1 - momentum).add_(v[:c] * (counts[gi] / max(counts[gi] - 1, 1)), alpha=momentum)
+            mean, var, counts = reduce_fn.combine_groups(mean, var, counts)        # ONE all-gather per layer
+            if rm is not None:
+                with torch.no_grad():
+                    for gi in range(ng):
+                        rm.mul_(1 - momentum).add_(mean[gi, :c], alpha=momentum)
+                        running_var.mul_(1 - momentum).add_(var[gi, :c] * (counts[gi] / max(counts[gi] - 1, 1)), alpha=momentum)
             invstd = torch.rsqrt(var + eps)
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, None, None,
                                          ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1, ptr(ws), ws.numel(), stream_ptr()),

@@ -30,6 +30,14 @@ def _worker(rank, world, port, out):
     full = x.reshape(-1, 3)
     ok_stats = torch.allclose(mean, full.mean(0), atol=1e-6) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-6) \
         and count == full.shape[0]
+    # ---- all groups of a layer in one collective
+    xa, xb = x[lo:hi, :2].reshape(-1, 3), x[lo:hi, 2:].reshape(-1, 3)       # two statistic groups (row blocks)
+    mg, vg, cg = red.combine_groups(torch.stack([xa.mean(0), xb.mean(0)]),
+                                    torch.stack([xa.var(0, unbiased=False), xb.var(0, unbiased=False)]),
+                                    [float(xa.shape[0]), float(xb.shape[0])])
+    fa, fb = x[:, :2].reshape(-1, 3), x[:, 2:].reshape(-1, 3)
+    ok_stats = ok_stats and torch.allclose(mg[0], fa.mean(0), atol=1e-6) and torch.allclose(vg[1], fb.var(0, unbiased=False), atol=1e-6) \
+        and cg == [float(fa.shape[0]), float(fb.shape[0])]
     # ---- SyncBN backward sums
     g = torch.arange(6.0).view(2, 3) * (rank + 1)
     tot = red.sum(g.clone())
