@@ -60,7 +60,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // One implicit-GEMM kernel for forward and dgrad.
 //   A rows: pixels.  B rows: GEMM columns n (weights packed [n][tap][c], c contiguous).
-template <int MODE, int WM, int WN, int TM, int TN, int BK>
+template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* __restrict__ a0,
                                                          const float* __restrict__ a1, const float* __restrict__ wq,
                                                          const float* __restrict__ scale,
@@ -72,8 +72,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     constexpr int RPP = 256 / CPR;                    // rows covered per pass of the 256 threads
     constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                 // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;                  // [2][BN][LDK]
+    // NBUF = 2: LDS double buffer, one barrier per K-step.  NBUF = 1: the next stage lives only in registers, two
+    // barriers per K-step, half the LDS -> twice the co-resident blocks per CU (4 waves per SIMD hide each other's
+    // load / store / barrier phases behind MFMAs).
+    float* As = smem;                                 // [NBUF][BM][LDK]
+    float* Bs = smem + NBUF * BM * LDK;               // [NBUF][BN][LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 
     const int lrow = lane & 31, lhalf = lane >> 5;
     for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
+        const int buf = NBUF == 2 ? (step & 1) : 0;
         if (step + 1 < nsteps) load_step(step + 1);           // global loads in flight during the MFMAs
         const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK + lhalf * 4;
         const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK + lhalf * 4;
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
-        if (step + 1 < nsteps) store_step(buf ^ 1);
+        if (NBUF == 1) __syncthreads();                       // every wave is done reading the single buffer
+        if (step + 1 < nsteps) store_step(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -935,13 +939,13 @@ static ConvP make_convp(const codeps_conv_desc* d) {
     return p;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int BK>
+template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF = 2>
 static void launch_igemm(ConvP p, const float* a0, const float* a1, const float* wq, const float* scale, const float* shift,
                          const float* residual, float* out, hipStream_t st) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     p.n_mt = cdiv(p.M, BM); p.n_nt = cdiv(p.N, BN);
-    const size_t lds = std::max((size_t)2 * (BM + BN) * (BK + 4), (size_t)WM * 32 * (BN + 4)) * sizeof(float);
-    auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK>;
+    const size_t lds = std::max((size_t)NBUF * (BM + BN) * (BK + 4), (size_t)WM * 32 * (BN + 4)) * sizeof(float);
+    auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     hipLaunchKernelGGL(k, dim3(p.n_mt * p.n_nt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
@@ -979,9 +983,14 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         else      hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
         return;
     }
+    static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;          // tuning experiments only
 #define IG(WM, WN, TM, TN)                                                                          \
     do {                                                                                            \
-        if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
+        /* single LDS buffer (4 blocks / CU) pays off once the grid holds >= 6 blocks per CU (measured) */ \
+        const long long blocks_ = (long long)cdiv(p.M, 32 * WM * TM) * cdiv(p.N, 32 * WN * TN);     \
+        const int nbuf = nbuf_env ? nbuf_env : (blocks_ >= 1536 ? 1 : 2);                            \
+        if (bk32 && nbuf == 1) launch_igemm<MODE, WM, WN, TM, TN, 32, 1>(p, a0, a1, wq, scale, shift, residual, out, st); \
+        else if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else      launch_igemm<MODE, WM, WN, TM, TN, 16>(p, a0, a1, wq, scale, shift, residual, out, st); \
     } while (0)
     if (p.N > 64) {
