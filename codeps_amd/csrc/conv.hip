@@ -39,6 +39,9 @@ struct ConvP {
     int src;              // dgrad: which source's gradient (0/1)
     int Cs;               // dgrad: channels of that source;  c_off = its channel offset in the packed weights
     int c_off;
+    // stride-2 dgrad by input-parity class: rows enumerate the pixels (2y'+py, 2x'+px) only and the K loop walks just the
+    // taps whose parity can reach them (3x3: 1, 2, 2 or 4 taps instead of 9 mostly-zero ones)
+    int par, py, px, ky0, kx0, nky, nkx, Hc, Wc;
 };
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
@@ -91,8 +94,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     for (int i = 0; i < APASS; ++i) {
         const int m = m0 + rbase + RPP * i;
         if (m < p.M && rbase + RPP * i < BM) {
-            const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : ((p.up0 && p.src == 0) ? (p.H / 2) * (p.W / 2) : p.H * p.W);
-            const int Wm = (MODE == MODE_FWD) ? p.Wo : ((p.up0 && p.src == 0) ? p.W / 2 : p.W);
+            const bool parc = MODE == MODE_DGRAD && p.par;
+            const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : (parc ? p.Hc * p.Wc : ((p.up0 && p.src == 0) ? (p.H / 2) * (p.W / 2) : p.H * p.W));
+            const int Wm = (MODE == MODE_FWD) ? p.Wo : (parc ? p.Wc : ((p.up0 && p.src == 0) ? p.W / 2 : p.W));
             rb[i] = m / HWm;
             const int rem = m % HWm;
             ry[i] = rem / Wm; rx[i] = rem % Wm;
@@ -109,7 +113,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     }
 
     // ---- K-step enumeration: (tap, source segment, channel chunk)
-    const int ntap = (MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW;
+    const int ntap = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx
+                   : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
     const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;          // channels per tap in the packed weights
     const int steps_per_tap = Kc / BK;
     const int nsteps = ntap * steps_per_tap;
@@ -120,7 +125,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         const int tap = step / steps_per_tap;
         const int cstep = (step % steps_per_tap) * BK;       // channel offset within the tap
         int ky, kx, qy = 0, qx = 0;
-        if (MODE == MODE_DGRAD && p.up0 && p.src == 0) {
+        if (MODE == MODE_DGRAD && p.par) {
+            ky = p.ky0 + 2 * (tap / p.nkx); kx = p.kx0 + 2 * (tap % p.nkx);
+        } else if (MODE == MODE_DGRAD && p.up0 && p.src == 0) {
             const int q = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
             qy = q >> 1; qx = q & 1; ky = t2 / p.KW; kx = t2 % p.KW;
         } else { ky = tap / p.KW; kx = tap % p.KW; }
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (rb[i] >= 0) {
                     int iy = ry[i], ix = rx[i];
+                    if (p.par) { iy = 2 * iy + p.py; ix = 2 * ix + p.px; }
                     if (p.up0 && p.src == 0) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
                     int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
                     bool ok = ty >= 0 && tx >= 0;
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         }
         // ---- B operand (packed weights, K contiguous)
         int koff;
-        if (MODE == MODE_DGRAD && p.up0 && p.src == 0) koff = ((tap % (p.KH * p.KW)) * Kc) + cstep;
+        if (MODE == MODE_DGRAD && p.par) koff = (ky * p.KW + kx) * Kc + cstep;
+        else if (MODE == MODE_DGRAD && p.up0 && p.src == 0) koff = ((tap % (p.KH * p.KW)) * Kc) + cstep;
         else koff = tap * Kc + cstep;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
@@ -251,8 +260,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         if (n < p.N) {
 #pragma unroll 4
             for (int rr = r0; rr < WM * 32; rr += RPASS) {
-                const int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
+                int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
                 if (m >= p.M) continue;
+                if (MODE == MODE_DGRAD && p.par) {            // class row -> pixel of the full-resolution gradient
+                    const int bb = m / (p.Hc * p.Wc), rem = m % (p.Hc * p.Wc);
+                    m = (bb * p.H + 2 * (rem / p.Wc) + p.py) * p.W + 2 * (rem % p.Wc) + p.px;
+                }
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
                 if (MODE == MODE_FWD) {
                     v = v * sc + sh;
@@ -1055,6 +1068,32 @@ extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const 
     p.N = p.Cs;
     // weights of this source: rows [c_off, c_off + Cs) of the [ci][tap][co] pack
     const float* wsrc = w_dgrad + (size_t)p.c_off * d->kh * d->kw * d->out_c;
+    if (d->stride == 2 && p.N > 16) {
+        // one launch per input-parity class with only the taps that can reach it; classes without taps are zero
+        bool need_zero = false;
+        for (int c = 0; c < 4; ++c) {
+            const int py = c >> 1, px = c & 1;
+            const int ky0 = (py + d->pad) & 1, kx0 = (px + d->pad) & 1;
+            if (ky0 >= d->kh || kx0 >= d->kw) need_zero = true;
+        }
+        if (need_zero) {
+            hipError_t e = hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream);
+            CODEPS_REQUIRE(e == hipSuccess, CODEPS_ERR_LAUNCH, "conv2d_dgrad: memset failed: %s", hipGetErrorString(e));
+        }
+        for (int c = 0; c < 4; ++c) {
+            ConvP q = p;
+            q.par = 1; q.py = c >> 1; q.px = c & 1;
+            q.ky0 = (q.py + d->pad) & 1; q.kx0 = (q.px + d->pad) & 1;
+            if (q.ky0 >= d->kh || q.kx0 >= d->kw) continue;
+            q.nky = (d->kh - q.ky0 + 1) / 2; q.nkx = (d->kw - q.kx0 + 1) / 2;
+            q.Hc = (d->in_h - q.py + 1) / 2; q.Wc = (d->in_w - q.px + 1) / 2;
+            if (q.Hc <= 0 || q.Wc <= 0) continue;
+            q.M = d->batch * q.Hc * q.Wc;
+            dispatch_igemm<MODE_DGRAD>(q, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, nullptr, dx, (hipStream_t)stream);
+        }
+        CODEPS_CHECK_LAUNCH("conv_igemm_kernel<dgrad, parity classes>");
+        return CODEPS_OK;
+    }
     dispatch_igemm<MODE_DGRAD>(p, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, nullptr, dx, (hipStream_t)stream);
     CODEPS_CHECK_LAUNCH("conv_igemm_kernel<dgrad>");
     return CODEPS_OK;
