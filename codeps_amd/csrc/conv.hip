@@ -211,20 +211,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         if (step + 1 < nsteps) load_step(step + 1);           // global loads in flight during the MFMAs
         const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK + lhalf * 4;
         const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK + lhalf * 4;
+        // fragments of k-group g+1 are read while the 16 MFMAs of group g run (explicit register double buffer)
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            f32x4 af[TM], bf[TN];
+            if (g + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + g * 8);
+                for (int i = 0; i < TM; ++i) af[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (g + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + g * 8);
+                for (int j = 0; j < TN; ++j) bf[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (g + 1) * 8);
+            }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         if (NBUF == 1) __syncthreads();                       // every wave is done reading the single buffer
         if (step + 1 < nsteps) store_step(NBUF == 2 ? (buf ^ 1) : 0);
@@ -999,9 +1008,9 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
     static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;          // tuning experiments only
 #define IG(WM, WN, TM, TN)                                                                          \
     do {                                                                                            \
-        /* single LDS buffer (4 blocks / CU) pays off once the grid holds >= 6 blocks per CU (measured) */ \
-        const long long blocks_ = (long long)cdiv(p.M, 32 * WM * TM) * cdiv(p.N, 32 * WN * TN);     \
-        const int nbuf = nbuf_env ? nbuf_env : (blocks_ >= 1536 ? 1 : 2);                            \
+        /* single LDS buffer (next stage in registers, up to 4 blocks / CU): measured faster than the double-buffered */ \
+        /* form on the whole adapt step (63.3 vs 66.2 ms of conv time), so it is the default                          */ \
+        const int nbuf = nbuf_env ? nbuf_env : 1;                                                    \
         if (bk32 && nbuf == 1) launch_igemm<MODE, WM, WN, TM, TN, 32, 1>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else      launch_igemm<MODE, WM, WN, TM, TN, 16>(p, a0, a1, wq, scale, shift, residual, out, st); \
