@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     f32x4 sc = {1.f, 1.f, 1.f, 1.f};
     if (scale && cok) sc = *reinterpret_cast<const f32x4*>(scale + tg * 4);
     if (cok)
+#pragma unroll 4
         for (long long r = r0 + tr; r < r1; r += TR) {
             const size_t o = (size_t)r * C + tg * 4;
             const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
@@ -112,16 +113,20 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblk, int K, int C,
                                                             float* __restrict__ out, int c_real, int accumulate) {
-    // part: [nblk][K][C] -> out [K][c_real]
+    // part: [nblk][K][C] -> out [K][c_real]; 16 lanes per output walk the blocks (fixed assignment + fixed shuffle tree)
     const int total = K * C;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int c = i % C, k = i / C;
-        if (c >= c_real) continue;
-        float a = 0.f;
-        for (int b = 0; b < nblk; ++b) a += part[(size_t)b * total + i];
-        float* o = out + (size_t)k * c_real + c;
-        *o = accumulate ? *o + a : a;
-    }
+    const int i = blockIdx.x * 16 + threadIdx.x / 16, sub = threadIdx.x % 16;
+    const bool in = i < total;
+    float a = 0.f;
+    if (in)
+        for (int b = sub; b < nblk; b += 16) a += part[(size_t)b * total + i];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (!in || sub != 0) return;
+    const int c = i % C, k = i / C;
+    if (c >= c_real) return;
+    float* o = out + (size_t)k * c_real + c;
+    *o = accumulate ? *o + a : a;
 }
 
 // ---------------------------------------------------------------------------------- BatchNorm (train)
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(256) void bn_stats_mg_kernel(const float* __restric
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (cok) {
         const f32x4 sh = *reinterpret_cast<const f32x4*>(x + (size_t)gr.row0[g] * C + tg * 4);
+#pragma unroll 4
         for (long long r = r0 + tr; r < r1; r += TR) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + tg * 4) - sh;
             s += v; q += v * v;
@@ -284,8 +290,8 @@ __global__ __launch_bounds__(256) void bn_finalize_mg_kernel(const float* __rest
                                                              float* __restrict__ mean, float* __restrict__ var,
                                                              float* __restrict__ invstd, float* __restrict__ running_mean,
                                                              float* __restrict__ running_var) {
-    // 8 lanes per channel walk the partial blocks (fixed assignment + fixed-order shuffle tree -> deterministic)
-    const int c = blockIdx.x * 32 + threadIdx.x / 8, sub = threadIdx.x % 8;
+    // one wave per channel walks the partial blocks (fixed assignment + fixed-order shuffle tree -> deterministic)
+    const int c = blockIdx.x * 4 + threadIdx.x / 64, sub = threadIdx.x % 64;
     const bool cin = c < C;
     float rm = 0.f, rv = 0.f;
     const bool upd = running_mean != nullptr && cin && c < c_real;
@@ -294,10 +300,10 @@ __global__ __launch_bounds__(256) void bn_finalize_mg_kernel(const float* __rest
         float s1 = 0.f, s2 = 0.f;
         if (cin) {
             const float* p = part + (size_t)g * nblk * 2 * C + c;
-            for (int b = sub; b < nblk; b += 8) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
+            for (int b = sub; b < nblk; b += 64) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
         }
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
         if (!cin || sub != 0) continue;
         const float n = (float)gr.rows[g];
         const float d = s1 / n;
@@ -359,6 +365,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __re
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (cok) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + tg * 4), is = *reinterpret_cast<const f32x4*>(invstd + g * C + tg * 4);
+#pragma unroll 4
         for (long long r = r0 + tr; r < r1; r += TR) {
             const size_t o = (size_t)r * C + tg * 4;
             f32x4 gg = *reinterpret_cast<const f32x4*>(dy + o);
@@ -387,17 +394,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __re
 __global__ __launch_bounds__(256) void bn_bwd_finish_mg_kernel(const float* __restrict__ part, BnGroups gr, int C, int c_real, int nblk,
                                                                float* __restrict__ sums, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * 32 + threadIdx.x / 8, sub = threadIdx.x % 8;
+    const int c = blockIdx.x * 4 + threadIdx.x / 64, sub = threadIdx.x % 64;
     const bool cin = c < C;
     float tg = 0.f, tb = 0.f;
     for (int g = 0; g < gr.n; ++g) {
         float s1 = 0.f, s2 = 0.f;
         if (cin) {
             const float* p = part + (size_t)g * nblk * 2 * C + c;
-            for (int b = sub; b < nblk; b += 8) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
+            for (int b = sub; b < nblk; b += 64) { s1 += p[(size_t)b * 2 * C]; s2 += p[(size_t)b * 2 * C + C]; }
         }
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
         if (!cin || sub != 0) continue;
         sums[(size_t)g * 2 * C + c] = s1; sums[(size_t)g * 2 * C + C + c] = s2;
         tb += s1; tg += s2;
@@ -641,6 +648,90 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------- GUDA fusion without the 240-channel concat
+// SemanticHead's GUDA block (models/semantic_head.py:64-72) is conv3x3(cat_k bilinear_up(d_k)).  Both operators are linear and
+// the up-sampling acts per channel, so   conv3x3(up(d_k))(p) = sum_t up(W_t . d_k)(p + delta_t):
+// the channel contraction (W_t . d_k, a 1x1 conv to 9 x 16 tap-channels) is done at the LOW resolution of each decoder
+// level (1/4 ... 1/64 of the pixels, on the MFMA conv engine) and only 16-channel tap planes are interpolated at full
+// resolution here.  Zero padding of the 3x3 conv = taps whose position p + delta_t leaves the image contribute nothing.
+struct GudaBranch { const float* y; int h, w; float rh, rw; };      // y: [B][h][w][144] = 9 taps x 16 channels
+struct GudaP { int B, H, W, nb; GudaBranch br[3]; };
+
+__global__ __launch_bounds__(256) void guda_gather_fwd_kernel(GudaP p, const float* __restrict__ base, float* __restrict__ out) {
+    // one thread per (pixel, 4-channel group): out = base + sum_branch sum_tap bilinear(y_branch[tap])(p + delta_tap)
+    const long long total = (long long)p.B * p.H * p.W * 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i & 3);
+        long long pix = i >> 2;
+        const int x = (int)(pix % p.W); pix /= p.W;
+        const int y = (int)(pix % p.H);
+        const int b = (int)(pix / p.H);
+        f32x4 a = *reinterpret_cast<const f32x4*>(base + ((((size_t)b * p.H + y) * p.W + x) << 4) + g * 4);
+        for (int k = 0; k < p.nb; ++k) {
+            const GudaBranch br = p.br[k];
+            const float* yb = br.y + (size_t)b * br.h * br.w * 144 + g * 4;
+            int x0[3], x1[3]; float lx0[3], lx1[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) bil_src(0, br.rw, min(max(x + kx - 1, 0), p.W - 1), br.w, p.W, x0[kx], x1[kx], lx0[kx], lx1[kx]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int qy = y + ky - 1;
+                if (qy < 0 || qy >= p.H) continue;
+                int y0, y1; float ly0, ly1;
+                bil_src(0, br.rh, qy, br.h, p.H, y0, y1, ly0, ly1);
+                const float* r0 = yb + (size_t)y0 * br.w * 144 + ky * 48;
+                const float* r1 = yb + (size_t)y1 * br.w * 144 + ky * 48;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int qx = x + kx - 1;
+                    if (qx < 0 || qx >= p.W) continue;
+                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + x0[kx] * 144 + kx * 16);
+                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + x1[kx] * 144 + kx * 16);
+                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + x0[kx] * 144 + kx * 16);
+                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + x1[kx] * 144 + kx * 16);
+                    a += ly0 * (lx0[kx] * v00 + lx1[kx] * v01) + ly1 * (lx0[kx] * v10 + lx1[kx] * v11);
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + ((((size_t)b * p.H + y) * p.W + x) << 4) + g * 4) = a;
+    }
+}
+
+// d y_branch[b][qy][qx][tap][c] = sum over full-res r with footprint on (qy,qx): w(r -> q) * dout[r - delta_tap][c]
+// one thread per (low-res pixel, tap, 4-channel group); deterministic gather.
+__global__ __launch_bounds__(256) void guda_gather_bwd_kernel(int B, int H, int W, int h, int w, float rh, float rw,
+                                                              const float* __restrict__ dout, float* __restrict__ dy) {
+    const long long total = (long long)B * h * w * 36;
+    const float inv_rh = 1.f / rh, inv_rw = 1.f / rw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i & 3);
+        long long r = i >> 2;
+        const int tap = (int)(r % 9); r /= 9;
+        const int qx = (int)(r % w); r /= w;
+        const int qy = (int)(r % h);
+        const int b = (int)(r / h);
+        const int ky = tap / 3 - 1, kx = tap % 3 - 1;             // delta of this tap
+        // full-res rows o whose (clamped) source coordinate r(o) = rh (o + 0.5) - 0.5 lies in (qy - 1, qy + 1); the
+        // interpolation weight of low-res row qy is max(0, 1 - |clamp(r, 0, h - 1) - qy|)  (same as bil_src's l0 / l1)
+        const int oy_lo = max(0, (int)ceilf(((float)qy - 0.5f) * inv_rh - 0.5f) - 1), oy_hi = min(H - 1, (int)floorf(((float)qy + 1.5f) * inv_rh - 0.5f) + 1);
+        const int ox_lo = max(0, (int)ceilf(((float)qx - 0.5f) * inv_rw - 0.5f) - 1), ox_hi = min(W - 1, (int)floorf(((float)qx + 1.5f) * inv_rw - 0.5f) + 1);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = max(oy_lo, ky); oy <= min(oy_hi, H - 1 + ky); ++oy) {       // py = oy - ky must be a valid output row
+            const float ry = fminf(fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f), (float)(h - 1));
+            const float wy = fmaxf(0.f, 1.f - fabsf(ry - (float)qy));
+            const float* drow = dout + ((((size_t)b * H + (oy - ky)) * W) << 4) + g * 4;
+            f32x4 arow = {0.f, 0.f, 0.f, 0.f};
+            for (int ox = max(ox_lo, kx); ox <= min(ox_hi, W - 1 + kx); ++ox) {
+                const float rx = fminf(fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f), (float)(w - 1));
+                const float wx = fmaxf(0.f, 1.f - fabsf(rx - (float)qx));
+                arow += wx * *reinterpret_cast<const f32x4*>(drow + ((size_t)(ox - kx) << 4));
+            }
+            a += wy * arow;
+        }
+        *reinterpret_cast<f32x4*>(dy + ((((size_t)b * h + qy) * w + qx) * 9 + tap) * 16 + g * 4) = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------- channel softmax / sigmoid-depth
 // x, y: [M][Cp] with C real channels (padding channels of y are written as 0)
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, long long M, int C, int Cp,
@@ -699,8 +790,9 @@ __global__ __launch_bounds__(256) void disp_depth_bwd_kernel(const float* __rest
 }
 
 static int rows_per_block(long long M, int& nblk) {
-    // <= 256 partial blocks (the serial fixed-order finish pass walks them), >= 256 rows each
-    long long rpb = std::max<long long>(256, (M + 255) / 256);
+    // <= 1024 partial blocks (enough loads in flight to cover HBM latency; the finish pass walks them with 8 lanes per
+    // output in a fixed order), >= 128 rows each
+    long long rpb = std::max<long long>(128, (M + 1023) / 1024);
     nblk = (int)((M + rpb - 1) / rpb);
     return (int)rpb;
 }
@@ -756,7 +848,7 @@ extern "C" int codeps_act_bwd(const float* dy, const float* y, const float* scal
     hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, dy, y, scale, act, rows, c, dz, part, rpb);
     CODEPS_CHECK_LAUNCH("act_bwd_kernel");
     if (dbias) {
-        hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, part, nblk, 1, c, dbias, c_real, accumulate);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(c, 16)), dim3(256), 0, st, part, nblk, 1, c, dbias, c_real, accumulate);
         CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     }
     return CODEPS_OK;
@@ -773,7 +865,7 @@ extern "C" int codeps_bn_stats(const float* x, long long rows, int c, float* sum
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, rows, c, (float*)workspace, rpb);
     CODEPS_CHECK_LAUNCH("bn_stats_kernel");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 16)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     return CODEPS_OK;
 }
@@ -800,7 +892,7 @@ extern "C" int codeps_bn_bwd_reduce(const float* dy, const float* y, const float
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, dy, y, x, mean, invstd, act, rows, c, (float*)workspace, rpb);
     CODEPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 16)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     return CODEPS_OK;
 }
@@ -832,7 +924,7 @@ static int make_groups(int n_groups, const long long* row0, const long long* row
 static int mg_blocks(const BnGroups& gr) {
     long long mx = 0;
     for (int i = 0; i < gr.n; ++i) mx = std::max(mx, gr.rows[i]);
-    return (int)std::max<long long>(1, std::min<long long>(256 / std::max(gr.n / 2, 1), (mx + 255) / 256));
+    return (int)std::max<long long>(1, std::min<long long>(256, (mx + 127) / 128));
 }
 
 extern "C" size_t codeps_bn_mg_workspace_bytes(int n_groups, int c) { return (size_t)n_groups * 256 * 2 * c * sizeof(float); }
@@ -851,7 +943,7 @@ extern "C" int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* r
     if (!apply_only) {
         CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)n_groups * nblk * 2 * c * 4, CODEPS_ERR_WORKSPACE, "bn_fwd_mg: workspace too small");
         hipLaunchKernelGGL(bn_stats_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, x, gr, c, nblk, (float*)workspace);
-        hipLaunchKernelGGL(bn_finalize_mg_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, x, (const float*)workspace, gr, c, c_real, nblk, eps,
+        hipLaunchKernelGGL(bn_finalize_mg_kernel, dim3(cdiv(c, 4)), dim3(256), 0, st, x, (const float*)workspace, gr, c, c_real, nblk, eps,
                            momentum, mean, var, invstd, running_mean, running_var);
         CODEPS_CHECK_LAUNCH("bn_stats_mg_kernel");
     }
@@ -880,7 +972,7 @@ extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x,
                        "bn_bwd_mg: workspace too small / null grads");
         hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, dy, y, x, gr, mean, invstd, act, c, nblk,
                            (float*)workspace);
-        hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma,
+        hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 4)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma,
                            dbeta, accumulate);
         CODEPS_CHECK_LAUNCH("bn_bwd_reduce_mg_kernel");
     }
@@ -933,7 +1025,7 @@ extern "C" int codeps_dwconv5x5_wgrad(const float* x, const float* dz, int batch
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, dz, batch, h, w, c, (float*)workspace, rpb);
     CODEPS_CHECK_LAUNCH("dwconv5_wgrad_kernel");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(25 * c, 256)), dim3(256), 0, st, (const float*)workspace, nblk, 25, c, dw25c, c, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(25 * c, 16)), dim3(256), 0, st, (const float*)workspace, nblk, 25, c, dw25c, c, 0);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     return CODEPS_OK;
 }
@@ -971,6 +1063,31 @@ extern "C" int codeps_bilinear_bwd(const float* dy, int batch, int h, int w, int
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long long)batch * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, dy, batch, h,
                        w, c, out_h, out_w, align_corners, rh, rw, y_c, y_c_off, dx);
     CODEPS_CHECK_LAUNCH("bilinear_bwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_guda_gather_fwd(const float* base, int batch, int h, int w, int n_branches, const float* const* y, const int* bh,
+                                      const int* bw, float* out, codeps_stream_t stream) {
+    CODEPS_REQUIRE(base && out && y && bh && bw && n_branches >= 1 && n_branches <= 3 && batch > 0 && h > 0 && w > 0, CODEPS_ERR_ARG,
+                   "guda_gather_fwd: bad arguments");
+    GudaP p;
+    p.B = batch; p.H = h; p.W = w; p.nb = n_branches;
+    for (int k = 0; k < 3; ++k) { p.br[k].y = nullptr; p.br[k].h = p.br[k].w = 1; p.br[k].rh = p.br[k].rw = 1.f; }
+    for (int k = 0; k < n_branches; ++k) {
+        CODEPS_REQUIRE(y[k] && bh[k] > 0 && bw[k] > 0 && bh[k] < h && bw[k] < w, CODEPS_ERR_ARG, "guda_gather_fwd: branch %d must be coarser than the output", k);
+        p.br[k].y = y[k]; p.br[k].h = bh[k]; p.br[k].w = bw[k];
+        p.br[k].rh = (float)bh[k] / (float)h; p.br[k].rw = (float)bw[k] / (float)w;
+    }
+    hipLaunchKernelGGL(guda_gather_fwd_kernel, dim3(grid_for((long long)batch * h * w * 4)), dim3(256), 0, (hipStream_t)stream, p, base, out);
+    CODEPS_CHECK_LAUNCH("guda_gather_fwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_guda_gather_bwd(const float* grad_out, int batch, int h, int w, int bh, int bw, float* grad_y, codeps_stream_t stream) {
+    CODEPS_REQUIRE(grad_out && grad_y && batch > 0 && bh > 0 && bw > 0 && bh < h && bw < w, CODEPS_ERR_ARG, "guda_gather_bwd: bad arguments");
+    hipLaunchKernelGGL(guda_gather_bwd_kernel, dim3(grid_for((long long)batch * bh * bw * 36)), dim3(256), 0, (hipStream_t)stream, batch, h, w, bh, bw,
+                       (float)bh / (float)h, (float)bw / (float)w, grad_out, grad_y);
+    CODEPS_CHECK_LAUNCH("guda_gather_bwd_kernel");
     return CODEPS_OK;
 }
 

@@ -627,6 +627,63 @@ def bilinear_concat(xs, out_h, out_w, align_corners):
     return _BilinearConcat.apply(int(out_h), int(out_w), bool(align_corners), *xs)
 
 
+class _GudaGather(torch.autograd.Function):
+    """out = base + sum_k sum_tap up(y_k[tap])(p + delta_tap)   (C ABI: codeps_guda_gather_{fwd,bwd})."""
+
+    @staticmethod
+    def forward(ctx, base, *ys):
+        require_cuda(base, *ys)
+        base = base.contiguous()
+        ys = [y.contiguous() for y in ys]
+        b, h, w, c = base.shape
+        if c != 16 or any(y.shape[-1] != 144 for y in ys) or not 1 <= len(ys) <= 3:
+            raise CodepsHipError("guda_gather: base must carry 16 channels and every branch 9 x 16 tap channels")
+        n = len(ys)
+        out = torch.empty_like(base)
+        yp = (ctypes.c_void_p * n)(*[y.data_ptr() for y in ys])
+        bh = (ctypes.c_int * n)(*[y.shape[1] for y in ys])
+        bw = (ctypes.c_int * n)(*[y.shape[2] for y in ys])
+        check(lib().codeps_guda_gather_fwd(ptr(base), b, h, w, n, yp, bh, bw, ptr(out), stream_ptr()), "codeps_guda_gather_fwd")
+        ctx.geoms = [(y.shape[1], y.shape[2]) for y in ys]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        b, h, w, _ = dout.shape
+        grads = []
+        for i, (bh, bw) in enumerate(ctx.geoms):
+            if not ctx.needs_input_grad[1 + i]:
+                grads.append(None)
+                continue
+            dy = torch.empty(b, bh, bw, 144, dtype=torch.float32, device=dout.device)
+            check(lib().codeps_guda_gather_bwd(ptr(dout), b, h, w, bh, bw, ptr(dy), stream_ptr()), "codeps_guda_gather_bwd")
+            grads.append(dy)
+        return (dout if ctx.needs_input_grad[0] else None, *grads)
+
+
+def guda_fusion(coarse, fine, weight, bias):
+    """conv3x3(cat([bilinear_up(c) for c in coarse] + [fine], channel), weight, bias, padding=1) without the
+    concatenated tensor (GUDA fusion, models/semantic_head.py:64-72).  Convolution and up-sampling are both linear and the
+    up-sampling is per channel, so the channel contraction of every 3x3 tap is done at the coarse resolution
+    (a 1x1 conv to 9 x 16 tap channels on the conv engine: 1/4 ... 1/64 of the multiply-adds) and only the tap planes
+    are interpolated at full resolution."""
+    n = weight.shape[0]
+    if n > 16 or weight.shape[-2:] != (3, 3):
+        raise CodepsHipError("guda_fusion: expects a 3x3 convolution to <= 16 classes")
+    c0, ys = 0, []
+    for t in coarse:
+        ck = t.shape[-1]
+        taps = weight[:, c0:c0 + ck].permute(2, 3, 0, 1).reshape(9, n, ck)
+        taps = torch.nn.functional.pad(taps, (0, 0, 0, 16 - n)).reshape(144, ck, 1, 1)
+        ys.append(conv2d(t, taps))
+        c0 += ck
+    if c0 + fine.shape[-1] != weight.shape[1]:
+        raise CodepsHipError("guda_fusion: channel counts of the branches do not add up to the weight's input channels")
+    base = conv2d(fine, weight[:, c0:].contiguous(), bias, pad=1)
+    return _GudaGather.apply(base, *ys)
+
+
 # ---------------------------------------------------------------------------------------- depthwise 5x5
 class _DwConv5(torch.autograd.Function):
     @staticmethod

@@ -30,8 +30,11 @@ class SemanticHead(nn.Module):
         x, kept = _run_decoder(self, in_feats, keep=(3, 2, 1, 0) if self.use_guda_fusion else ())
         if self.use_guda_fusion:
             _, h, w, _ = x.shape
-            cat = F.bilinear_concat([kept[3], kept[2], kept[1], kept[0]], h, w, False)   # 240 channels, one buffer
-            logits = F.conv2d(cat, self.semconv_guda.weight, self.semconv_guda.bias, pad=1)
+            if kept[0].shape[1:3] == (h, w) and self.num_classes <= 16:
+                logits = F.guda_fusion([kept[3], kept[2], kept[1]], kept[0], self.semconv_guda.weight, self.semconv_guda.bias)
+            else:
+                cat = F.bilinear_concat([kept[3], kept[2], kept[1], kept[0]], h, w, False)   # 240 channels, one buffer
+                logits = F.conv2d(cat, self.semconv_guda.weight, self.semconv_guda.bias, pad=1)
         else:
             conv = self.semconv[1]
             logits = F.conv2d(x, conv.weight, conv.bias, pad=1, pad_mode="reflect")

@@ -351,25 +351,26 @@ def golden_adapt(seed=61):
     wts = dict(depth_recon=10.0, depth_smth=0.001, semantic_source=1.0, semantic_cut_mixup=1.0)
     total = 10.0 * dl["recon"] + 0.001 * dl["smth"] + sem_losses["source"] + sem_losses["cut_mixup"]
     total.backward()
+    with torch.no_grad():           # top-1 / top-2 probability margin of the target prediction: argmax ties are fp32 noise
+        top2 = net.semantic_head(feats["target"][0]).topk(2, dim=1).values
     res = {"meta": json.dumps({"ht": ht, "wt": wt, "hs": hs, "ws": ws, "seed": seed, "weights": wts,
                                "noise_seed": 3000 + seed}),
            "loss_depth_recon": dl["recon"], "loss_depth_smth": dl["smth"],
            "loss_semantic_source": sem_losses["source"], "loss_semantic_cut_mixup": sem_losses["cut_mixup"],
            "total": total, "res_depth": depth_pred, "res_semantic": sem_pred,
-           "res_T0": transf[0], "res_T1": transf[1]}
+           "res_semantic_margin": top2[:, 0] - top2[:, 1], "res_T0": transf[0], "res_T1": transf[1]}
     for name in ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"):
         res["pgrad_" + name] = grad_stats(getattr(net, name))
     save("network_adapt", **res)
 
 
 if __name__ == "__main__":
-    only = sys.argv[1:]
-    golden_geometry()
-    golden_heads("r18", R18, 2, 32, 64, 3)
-    golden_heads("r50", R50, 1, 32, 64, 5, full=False)
-    golden_recon("small", 2, 48, 80, 21)
-    golden_recon("odd", 1, 40, 72, 22, num_scales=3)
-    golden_sem_inst_losses()
-    golden_panoptic()
-    golden_network()
-    golden_adapt()
+    jobs = {"geometry": golden_geometry,
+            "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
+            "heads_r50": lambda: golden_heads("r50", R50, 1, 32, 64, 5, full=False),
+            "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),
+            "recon_odd": lambda: golden_recon("odd", 1, 40, 72, 22, num_scales=3),
+            "sem_inst_losses": golden_sem_inst_losses, "panoptic": golden_panoptic,
+            "network_train": golden_network, "network_adapt": golden_adapt}
+    for name in (sys.argv[1:] or jobs):          # no arguments = regenerate everything
+        jobs[name]()

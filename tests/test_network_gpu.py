@@ -110,6 +110,8 @@ def test_adaptation_step_against_reference():
     # 1e-3 absolute holds in the train test above; here: 1e-3 + 1e-4 relative, and tight in disparity space.
     close(result["depth"], z["res_depth"], 1e-3, 1e-4, "depth")
     close(1.0 / result["depth"], 1.0 / z["res_depth"], 2e-4, 5e-5, "scaled disparity (range 0.01..10)")
-    assert (result["semantic"].cpu().numpy() == z["res_semantic"]).all()
+    # labels must agree except where the reference's own top-1 / top-2 probability margin is inside fp32 noise
+    bad = result["semantic"].cpu().numpy() != z["res_semantic"]
+    assert bad.mean() < 1e-3 and (z["res_semantic_margin"][bad] < 1e-4).all(), (int(bad.sum()), z["res_semantic_margin"][bad])
     assert result["panoptic"].shape == (1, ht, wt) and result["image_features"].shape[1] == 512
     _check_pgrads(net, z, ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"))

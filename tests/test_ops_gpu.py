@@ -189,6 +189,31 @@ def test_bilinear_concat_guda():
         assert rel_err(nchw(d.grad, x.shape[1]), r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("h,w,b", [(32, 48, 2), (24, 40, 1)])
+def test_guda_fusion_matches_concat_conv(h, w, b):
+    """conv3x3(cat(up(d_k))) evaluated as per-tap 1x1 convs at low resolution + tap gather (semantic_head.py:64-72)."""
+    F = _F()
+    g = torch.Generator().manual_seed(h)
+    xs = [torch.randn(b, c, h // s, w // s, generator=g) for c, s in ((128, 8), (64, 4), (32, 2), (16, 1))]
+    wt, bias = torch.randn(14, 240, 3, 3, generator=g) * 0.05, torch.randn(14, generator=g)
+    rxs = [x.double().requires_grad_(True) for x in xs]
+    rw, rb = wt.double().requires_grad_(True), bias.double().requires_grad_(True)
+    cat = torch.cat([TF.interpolate(r, (h, w), mode="bilinear", align_corners=False) for r in rxs[:3]] + [rxs[3]], 1)
+    y = TF.conv2d(cat, rw, rb, padding=1)
+    gy = torch.randn(y.shape, generator=g).double()
+    (y * gy).sum().backward()
+    dxs = [nhwc(x).requires_grad_(True) for x in xs]
+    dw, db = wt.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    out = F.guda_fusion(dxs[:3], dxs[3], dw, db)
+    assert rel_err(nchw(out, 14), y.detach()) < 1e-5
+    assert float(out[..., 14:].abs().max()) == 0.0
+    out.backward(nhwc(gy.float(), 16))
+    for d, r, x in zip(dxs, rxs, xs):
+        assert rel_err(nchw(d.grad, x.shape[1]), r.grad) < 1e-5
+    assert rel_err(dw.grad.cpu(), rw.grad) < 1e-5
+    assert rel_err(db.grad.cpu(), rb.grad) < 1e-5
+
+
 def test_dwconv5x5():
     F = _F()
     g = torch.Generator().manual_seed(9)
