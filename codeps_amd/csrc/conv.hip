@@ -26,6 +26,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
+// Tuning aid (never set in the shipped build): -DCODEPS_ABLATE=1 drops the global loads of the K loop, =2 also the
+// LDS stores and barriers, =3 also the LDS fragment reads -- results are garbage, timings bound each pipeline stage.
+#ifndef CODEPS_ABLATE
+#define CODEPS_ABLATE 0
+#endif
+
 struct ConvP {
     // geometry (see codeps_conv_desc)
     int B, H, W;          // logical input size (after the optional x2 upsample of source 0)
@@ -43,6 +49,25 @@ struct ConvP {
     // taps whose parity can reach them (3x3: 1, 2, 2 or 4 taps instead of 9 mostly-zero ones)
     int par, py, px, ky0, kx0, nky, nkx, Hc, Wc;
 };
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// 16 zero floats in global memory: what a gathered load reads when its tap falls into the zero padding
+__device__ __attribute__((aligned(64))) float zero_page[16];
+
+// Gather-table entry of a zero-padding tap: a byte offset past the end of every buffer resource, so the hardware
+// range check of buffer_load returns 0 for it (no compare / select / branch in the K loop).
+constexpr unsigned GATHER_OOB = 0xFFFF0000u;
+
+// Raw buffer resource (stride 0 -> num_records in bytes) over [base, base + bytes); bytes saturates below GATHER_OOB.
+// base and bytes must be wave-uniform (they are functions of blockIdx only); readfirstlane pins them to SGPRs so the
+// compiler never has to wrap the loads in a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned n = __builtin_amdgcn_readfirstlane((unsigned)(bytes < (size_t)GATHER_OOB ? bytes : (size_t)GATHER_OOB));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)n, 0x00020000);
+}
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
@@ -87,31 +112,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     const int nt = logical % p.n_nt, mt = logical / p.n_nt;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // ---- per-thread A-row bookkeeping (rows r = tid / CPR + RPP * i)
-    const int chunk = tid % CPR, rbase = tid / CPR;
-    int rb[APASS], ry[APASS], rx[APASS];              // batch index (-1 = row out of range), pixel y, x
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-        const int m = m0 + rbase + RPP * i;
-        if (m < p.M && rbase + RPP * i < BM) {
-            const bool parc = MODE == MODE_DGRAD && p.par;
-            const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : (parc ? p.Hc * p.Wc : ((p.up0 && p.src == 0) ? (p.H / 2) * (p.W / 2) : p.H * p.W));
-            const int Wm = (MODE == MODE_FWD) ? p.Wo : (parc ? p.Wc : ((p.up0 && p.src == 0) ? p.W / 2 : p.W));
-            rb[i] = m / HWm;
-            const int rem = m % HWm;
-            ry[i] = rem / Wm; rx[i] = rem % Wm;
-        } else { rb[i] = -1; ry[i] = 0; rx[i] = 0; }
-    }
-    // B rows (weights): row n = n0 + rbase + RPP*i, K-contiguous
-    const float* brow[BPASS];
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-        const int n = n0 + rbase + RPP * i;
-        brow[i] = (n < p.N && rbase + RPP * i < BN) ? wq + (size_t)n * ((MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct
-                                                                   : (size_t)p.KH * p.KW * p.Co) + chunk * 4
-                            : nullptr;
-    }
-
     // ---- K-step enumeration: (tap, source segment, channel chunk)
     const int ntap = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx
                    : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
@@ -119,78 +119,109 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     const int steps_per_tap = Kc / BK;
     const int nsteps = ntap * steps_per_tap;
 
+    // ---- gather table (built once per block): tab[source][tap][row] = BYTE offset of the pixel that row reads through
+    //      that tap, relative to the first image this block touches; GATHER_OOB = zero padding.  The K loop then costs
+    //      one broadcast LDS read + one add per 16-B buffer_load (whose range check supplies the zeros) instead of the
+    //      div / mod / bounds / reflect / upsample arithmetic and its branches (measured: with the address arithmetic in
+    //      the loop the MFMA pipe idled 20-45 % of the time behind VALU work).
+    unsigned* tab = reinterpret_cast<unsigned*>(smem + NBUF * (BM + BN) * LDK);
+    const bool two_src = MODE == MODE_FWD && p.C1 > 0;
+    const bool parc = MODE == MODE_DGRAD && p.par;
+    const bool upd = MODE == MODE_DGRAD && p.up0 && p.src == 0;
+    const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : (parc ? p.Hc * p.Wc : (upd ? (p.H / 2) * (p.W / 2) : p.H * p.W));
+    const int Wm = (MODE == MODE_FWD) ? p.Wo : (parc ? p.Wc : (upd ? p.W / 2 : p.W));
+    const int b_first = m0 / HWm;                                // block-uniform: offsets stay < 4 GB whatever the tensor size
+    // source geometry: fwd source 0 (maybe at half resolution), fwd source 1, or dZ for dgrad
+    const int H0 = (MODE == MODE_FWD) ? (p.up0 ? p.H / 2 : p.H) : p.Ho, W0 = (MODE == MODE_FWD) ? (p.up0 ? p.W / 2 : p.W) : p.Wo;
+    const int cs0 = (MODE == MODE_FWD) ? p.C0 : p.Co;
+    {
+        for (int e = tid; e < ntap * BM; e += 256) {
+            const int row = e % BM, tap = e / BM;
+            const int m = m0 + row;
+            unsigned v0 = GATHER_OOB, v1 = GATHER_OOB;
+            if (m < p.M) {
+                const int bb = m / HWm - b_first, rem = m % HWm;
+                const int y = rem / Wm, x = rem % Wm;
+                if (MODE == MODE_FWD) {
+                    const int ky = tap / p.KW, kx = tap % p.KW;
+                    int iy = y * p.stride - p.pad + ky, ix = x * p.stride - p.pad + kx;
+                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                        v1 = (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(p.C1 * 4);
+                        v0 = p.up0 ? (unsigned)((bb * H0 + (iy >> 1)) * W0 + (ix >> 1)) * (unsigned)(cs0 * 4)      // fused nearest x2 of source 0
+                                   : (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(cs0 * 4);
+                    }
+                } else {
+                    // dgrad: the output pixel (ty, tx) that read this input pixel through tap (ky, kx)
+                    int ky, kx, qy = 0, qx = 0;
+                    if (parc) { ky = p.ky0 + 2 * (tap / p.nkx); kx = p.kx0 + 2 * (tap % p.nkx); }
+                    else if (upd) {
+                        const int q = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
+                        qy = q >> 1; qx = q & 1; ky = t2 / p.KW; kx = t2 % p.KW;
+                    } else { ky = tap / p.KW; kx = tap % p.KW; }
+                    int iy = y, ix = x;
+                    if (parc) { iy = 2 * iy + p.py; ix = 2 * ix + p.px; }
+                    if (upd) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
+                    int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
+                    bool ok = ty >= 0 && tx >= 0;
+                    if (p.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
+                    if (ok && ty < p.Ho && tx < p.Wo) v0 = (unsigned)((bb * p.Ho + ty) * p.Wo + tx) * (unsigned)(cs0 * 4);
+                }
+            }
+            tab[e] = v0;
+            if (two_src) tab[ntap * BM + e] = v1;
+        }
+    }
+    __syncthreads();
+    const int Btot = p.M > 0 ? (p.M + HWm - 1) / HWm : 1;        // images addressed by the rows of this launch (= batch)
+    const size_t img0 = (size_t)H0 * W0 * cs0, img1 = (size_t)p.H * p.W * p.C1;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a0 + (size_t)b_first * img0, (size_t)(Btot - b_first) * img0 * 4);
+    const __amdgpu_buffer_rsrc_t rs1 = two_src ? make_rsrc(a1 + (size_t)b_first * img1, (size_t)(Btot - b_first) * img1 * 4) : rs0;
+
+    // ---- per-thread staging roles: 16-B chunk `chunk` of rows rbase + RPP * i
+    const int chunk = tid % CPR, rbase = tid / CPR;
+    constexpr bool AGUARD = (BM % RPP) != 0, BGUARD = (BN % RPP) != 0;
+    // B rows (weights): row n = n0 + rbase + RPP*i, K-contiguous; rows past N are clamped (their columns are never stored)
+    const float* brow[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int n = min(n0 + rbase + RPP * i, p.N - 1);
+        brow[i] = wq + (size_t)n * ((MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct : (size_t)p.KH * p.KW * p.Co) + chunk * 4;
+    }
+
     f32x4 areg[APASS], breg[BPASS];
 
     auto load_step = [&](int step) {
         const int tap = step / steps_per_tap;
-        const int cstep = (step % steps_per_tap) * BK;       // channel offset within the tap
-        int ky, kx, qy = 0, qx = 0;
-        if (MODE == MODE_DGRAD && p.par) {
-            ky = p.ky0 + 2 * (tap / p.nkx); kx = p.kx0 + 2 * (tap % p.nkx);
-        } else if (MODE == MODE_DGRAD && p.up0 && p.src == 0) {
-            const int q = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
-            qy = q >> 1; qx = q & 1; ky = t2 / p.KW; kx = t2 % p.KW;
-        } else { ky = tap / p.KW; kx = tap % p.KW; }
+        const int cstep = (step - tap * steps_per_tap) * BK;   // channel offset within the tap
         // ---- A operand
-        if (MODE == MODE_FWD) {
-            const bool s1 = cstep >= p.C0;                    // which source this chunk belongs to
-            const float* src = s1 ? a1 : a0;
-            const int cs = s1 ? p.C1 : p.C0, c = (s1 ? cstep - p.C0 : cstep) + chunk * 4;
-            const bool up = p.up0 && !s1;
-            const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+        const bool s1 = MODE == MODE_FWD && cstep >= p.C0;        // which source this chunk belongs to
+        const __amdgpu_buffer_rsrc_t rs = s1 ? rs1 : rs0;
+        const unsigned coff = (unsigned)((s1 ? cstep - p.C0 : cstep) + chunk * 4) * 4u;
+        const unsigned* t = tab + ((s1 ? ntap : 0) + tap) * BM + rbase;
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (rb[i] >= 0) {
-                    int iy = ry[i] * p.stride - p.pad + ky, ix = rx[i] * p.stride - p.pad + kx;
-                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
-                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                        if (up) { iy >>= 1; ix >>= 1; }
-                        v = *reinterpret_cast<const f32x4*>(src + (((size_t)rb[i] * Hs + iy) * Ws + ix) * cs + c);
-                    }
-                }
-                areg[i] = v;
-            }
-        } else {
-            // dgrad: A = dZ at the output pixels that read this input pixel through tap (ky,kx)
-            const int c = cstep + chunk * 4;
-#pragma unroll
-            for (int i = 0; i < APASS; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (rb[i] >= 0) {
-                    int iy = ry[i], ix = rx[i];
-                    if (p.par) { iy = 2 * iy + p.py; ix = 2 * ix + p.px; }
-                    if (p.up0 && p.src == 0) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
-                    int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
-                    bool ok = ty >= 0 && tx >= 0;
-                    if (p.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
-                    if (ok && ty < p.Ho && tx < p.Wo)
-                        v = *reinterpret_cast<const f32x4*>(a0 + (((size_t)rb[i] * p.Ho + ty) * p.Wo + tx) * p.Co + c);
-                }
-                areg[i] = v;
-            }
+        for (int i = 0; i < APASS; ++i) {
+            const unsigned off = t[(AGUARD && rbase + RPP * i >= BM) ? 0 : RPP * i];
+            areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + coff, 0, 0));
         }
         // ---- B operand (packed weights, K contiguous)
         int koff;
-        if (MODE == MODE_DGRAD && p.par) koff = (ky * p.KW + kx) * Kc + cstep;
+        if (MODE == MODE_DGRAD && p.par) koff = ((p.ky0 + 2 * (tap / p.nkx)) * p.KW + p.kx0 + 2 * (tap % p.nkx)) * Kc + cstep;
         else if (MODE == MODE_DGRAD && p.up0 && p.src == 0) koff = ((tap % (p.KH * p.KW)) * Kc) + cstep;
         else koff = tap * Kc + cstep;
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (brow[i]) v = *reinterpret_cast<const f32x4*>(brow[i] + koff);
-            breg[i] = v;
-        }
+        for (int i = 0; i < BPASS; ++i) breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + koff);
     };
     auto store_step = [&](int buf) {
         float* Ab = As + buf * BM * LDK;
         float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
         for (int i = 0; i < APASS; ++i)
-            if (rbase + RPP * i < BM) *reinterpret_cast<f32x4*>(Ab + (rbase + RPP * i) * LDK + chunk * 4) = areg[i];
+            if (!AGUARD || rbase + RPP * i < BM)
+                *reinterpret_cast<f32x4*>(Ab + (rbase + RPP * i) * LDK + chunk * 4) = areg[i];
 #pragma unroll
         for (int i = 0; i < BPASS; ++i)
-            if (rbase + RPP * i < BN) *reinterpret_cast<f32x4*>(Bb + (rbase + RPP * i) * LDK + chunk * 4) = breg[i];
+            if (!BGUARD || rbase + RPP * i < BN) *reinterpret_cast<f32x4*>(Bb + (rbase + RPP * i) * LDK + chunk * 4) = breg[i];
     };
 
     f32x16 acc[TM][TN];
@@ -208,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     const int lrow = lane & 31, lhalf = lane >> 5;
     for (int step = 0; step < nsteps; ++step) {
         const int buf = NBUF == 2 ? (step & 1) : 0;
-        if (step + 1 < nsteps) load_step(step + 1);           // global loads in flight during the MFMAs
+        if (step + 1 < nsteps && CODEPS_ABLATE < 1) load_step(step + 1);           // global loads in flight during the MFMAs
         const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK + lhalf * 4;
         const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK + lhalf * 4;
         // fragments of k-group g+1 are read while the 16 MFMAs of group g run (explicit register double buffer)
@@ -217,9 +248,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
+#if CODEPS_ABLATE >= 3
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[1][i] = af[0][i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[1][j] = bf[0][j];
+#endif
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            if (g + 1 < BK / 8) {
+            if (g + 1 < BK / 8 && CODEPS_ABLATE < 3) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (g + 1) * 8);
 #pragma unroll
@@ -235,6 +272,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
+#if CODEPS_ABLATE >= 2
+        continue;
+#endif
         if (NBUF == 1) __syncthreads();                       // every wave is done reading the single buffer
         if (step + 1 < nsteps) store_step(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
@@ -602,42 +642,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
     constexpr int AIT = (BKP * ACH + 255) / 256, BIT = (BKP * BCH + 255) / 256;
     f32x4 areg[AIT], breg[BIT];
 
-    auto load_step = [&](int p0) {
+    // No division, bounds branch or source decision inside the K loop (they used to cost more issue slots than the
+    // MFMAs): every thread keeps the pixel coordinates of its chunks and steps them by BKP pixels per K-step.
+    //   A (dZ, dense rows): buffer_load through a resource that ends at this split's last pixel -> the tail reads 0.
+    //   B (x gathered through this block's tap): global_load from the pixel address, or from zero_page when the tap
+    //     falls into the padding / past the split (select on the address, loads are unconditional).
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(dz + (size_t)pbeg * p.Co, (size_t)max(pend - pbeg, 0) * p.Co * 4);
+    unsigned a_off[AIT];
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        const int idx = tid + 256 * i, kr = idx / ACH, m = m0 + (idx % ACH) * 4;
+        a_off[i] = (idx < BKP * ACH && m < p.Co) ? (unsigned)(kr * p.Co + m) * 4u : GATHER_OOB;
+    }
+    const unsigned a_stride = (unsigned)(BKP * p.Co) * 4u;
+    const float* b_src[BIT];
+    int b_x[BIT], b_y[BIT], b_b[BIT];
+    bool b_s1[BIT], b_okn[BIT];
+    int pix0 = pbeg + tid / BCH;                               // pixel of chunk 0; chunk i sits 256 * i / BCH pixels further
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+        const int idx = tid + 256 * i, kr = idx / BCH, n = n0 + (idx % BCH) * 4;
+        b_okn[i] = idx < BKP * BCH && n < p.Ct;
+        b_s1[i] = n >= p.C0;
+        b_src[i] = b_s1[i] ? x1 + (n - p.C0) : x0 + n;
+        const int pix = pbeg + kr;
+        b_b[i] = pix / (p.Ho * p.Wo);
+        const int rem = pix % (p.Ho * p.Wo);
+        b_y[i] = rem / p.Wo; b_x[i] = rem % p.Wo;
+    }
+
+    auto load_step = [&](int step) {
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            const int idx = tid + 256 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < BKP * ACH) {
-                const int kr = idx / ACH, ch = idx % ACH;
-                const int pix = p0 + kr, m = m0 + ch * 4;
-                if (pix < pend && m < p.Co) v = *reinterpret_cast<const f32x4*>(dz + (size_t)pix * p.Co + m);
-            }
-            areg[i] = v;
+            const unsigned off = a_off[i] == GATHER_OOB ? GATHER_OOB : a_off[i] + (unsigned)step * a_stride;
+            areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
-            const int idx = tid + 256 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < BKP * BCH) {
-                const int kr = idx / BCH, ch = idx % BCH;
-                const int pix = p0 + kr, n = n0 + ch * 4;
-                if (pix < pend && n < p.Ct) {
-                    const int b = pix / (p.Ho * p.Wo), rem = pix % (p.Ho * p.Wo);
-                    int iy = (rem / p.Wo) * p.stride - p.pad + ky, ix = (rem % p.Wo) * p.stride - p.pad + kx;
-                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
-                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                        const bool s1 = n >= p.C0;
-                        const bool up = p.up0 && !s1;
-                        const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
-                        if (up) { iy >>= 1; ix >>= 1; }
-                        const float* src = s1 ? x1 : x0;
-                        const int cs = s1 ? p.C1 : p.C0, c = s1 ? n - p.C0 : n;
-                        v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c);
-                    }
-                }
+            int iy = b_y[i] * p.stride - p.pad + ky, ix = b_x[i] * p.stride - p.pad + kx;
+            if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+            const bool ok = b_okn[i] && pix0 + (256 * i) / BCH < pend && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const bool up = p.up0 && !b_s1[i];
+            const int sh = up ? 1 : 0;
+            const int Hs = p.H >> sh, Ws = p.W >> sh, cs = b_s1[i] ? p.C1 : p.C0;
+            const float* ptr = b_src[i] + (size_t)(unsigned)((b_b[i] * Hs + (iy >> sh)) * Ws + (ix >> sh)) * cs;
+            breg[i] = *reinterpret_cast<const f32x4*>(ok ? ptr : zero_page);
+            // advance this chunk's pixel by BKP (branch-free; rows narrower than BKP take the uniform slow path)
+            if (p.Wo >= BKP) {
+                b_x[i] += BKP;
+                const bool wx = b_x[i] >= p.Wo;
+                b_x[i] -= wx ? p.Wo : 0; b_y[i] += wx ? 1 : 0;
+                const bool wy = b_y[i] >= p.Ho;
+                b_y[i] -= wy ? p.Ho : 0; b_b[i] += wy ? 1 : 0;
+            } else {
+                const int pix = pix0 + (256 * i) / BCH + BKP;
+                b_b[i] = pix / (p.Ho * p.Wo);
+                const int rem = pix % (p.Ho * p.Wo);
+                b_y[i] = rem / p.Wo; b_x[i] = rem % p.Wo;
             }
-            breg[i] = v;
         }
+        pix0 += BKP;
     };
     auto store_step = [&](int buf) {
 #pragma unroll
@@ -663,12 +727,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
     const int nsteps = (pend - pbeg + BKP - 1) / BKP;
     const int lrow = lane & 31, lhalf = lane >> 5;
     if (nsteps > 0) {
-        load_step(pbeg);
+        load_step(0);
         store_step(0);
         __syncthreads();
         for (int step = 0; step < nsteps; ++step) {
             const int buf = step & 1;
-            if (step + 1 < nsteps) load_step(pbeg + (step + 1) * BKP);
+            if (step + 1 < nsteps) load_step(step + 1);
             const float* Ab = As + buf * BKP * LDM + wm * TM * 32 + lrow;
             const float* Bb = Bs + buf * BKP * LDN + wn * TN * 32 + lrow;
 #pragma unroll
@@ -966,10 +1030,14 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                          const float* residual, float* out, hipStream_t st) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     p.n_mt = cdiv(p.M, BM); p.n_nt = cdiv(p.N, BN);
-    const size_t lds = std::max((size_t)NBUF * (BM + BN) * (BK + 4), (size_t)WM * 32 * (BN + 4)) * sizeof(float);
+    // K-loop staging buffers + the gather table [sources][taps][BM] behind them; the epilogue tile reuses the front
+    const int ntap = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
+    const int nsrc = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
+    const size_t lds = std::max(((size_t)NBUF * (BM + BN) * (BK + 4) + (size_t)nsrc * ntap * BM) * sizeof(float),
+                                (size_t)WM * 32 * (BN + 4) * sizeof(float));
     auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF>;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k, dim3(p.n_mt * p.n_nt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
 }
 
