@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede loading the .so, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -30,7 +30,7 @@ class PhotometricDesc(Structure):
 
 class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("batch", "in_h", "in_w", "c0", "c1", "up0", "out_c", "out_h", "out_w", "kh", "kw",
-                                       "stride", "pad", "pad_mode", "act")]
+                                       "stride", "pad", "pad_mode", "act", "stride_w", "pad_w")]
 
 
 def build(jobs=8, verbose=False):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "codeps_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, I, I, I, P, c_size_t, P]),
     "codeps_nchw_to_nhwc": (c_int, [P, I, I, I, I, P, I, I, I, P]),
+    "codeps_nchw_to_nhwc_xpad": (c_int, [P, I, I, I, I, P, I, I, I, I, I, P]),
     "codeps_nhwc_to_nchw": (c_int, [P, I, I, I, I, I, P, P]),
     "codeps_colsum_workspace_bytes": (c_size_t, [LL, I, I]),
     "codeps_act_bwd": (c_int, [P, P, P, I, LL, I, P, P, I, I, P, c_size_t, P]),

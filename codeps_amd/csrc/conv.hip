@@ -38,7 +38,8 @@ struct ConvP {
     int C0, C1, Ct;       // channels of source 0 / 1, Ct = C0 + C1
     int up0;
     int Co, Ho, Wo;
-    int KH, KW, stride, pad, pad_mode;
+    int KH, KW, stride, pad, pad_mode;   // stride / pad: vertical;  stride_w / pad_w: horizontal
+    int stride_w, pad_w;
     int act;
     int M, N;             // GEMM rows / cols of this launch
     int n_mt, n_nt;       // tile counts
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                 const int y = rem / Wm, x = rem % Wm;
                 if (MODE == MODE_FWD) {
                     const int ky = tap / p.KW, kx = tap % p.KW;
-                    int iy = y * p.stride - p.pad + ky, ix = x * p.stride - p.pad + kx;
+                    int iy = y * p.stride - p.pad + ky, ix = x * p.stride_w - p.pad_w + kx;
                     if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
                     if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
                         v1 = (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(p.C1 * 4);
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(256) void conv_igemm16_lds_kernel(ConvP p, const fl
 // ---------------------------------------------------------------------------------- wgrad
 // dW[co][tap][ci] partial over a pixel range.  A = dZ^T (LDS [k=pixel][m=co]), B = X(tap) (LDS [k][n=ci]).
 struct WgradP {
-    int B, H, W, C0, C1, Ct, up0, Co, Ho, Wo, KH, KW, stride, pad, pad_mode;
+    int B, H, W, C0, C1, Ct, up0, Co, Ho, Wo, KH, KW, stride, pad, pad_mode, stride_w, pad_w;
     int n_mt, n_nt, splits, pix_per_split, P;     // P = B*Ho*Wo output pixels
 };
 
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
         }
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
-            int iy = b_y[i] * p.stride - p.pad + ky, ix = b_x[i] * p.stride - p.pad + kx;
+            int iy = b_y[i] * p.stride - p.pad + ky, ix = b_x[i] * p.stride_w - p.pad_w + kx;
             if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
             const bool ok = b_okn[i] && pix0 + (256 * i) / BCH < pend && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const bool up = p.up0 && !b_s1[i];
@@ -799,11 +800,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
 // and ONE halo tile of X (a 32-channel chunk) are staged in LDS and every tap reads its shifted window from that halo
 // (X is fetched once instead of once per tap); each wave owns 64 of the 256 pixels and keeps all (m-tile, n-tile, tap)
 // accumulators of v_mfma_f32_16x16x4_f32 in registers across tiles; per-wave partial slabs, fixed-order reduce.
-template <int MT, int NT, int KS, int STRIDE, int TH, int TW>
+template <int MT, int NT, int KH, int KW, int SH, int SW, int TH, int TW>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                           const float* __restrict__ x0, const float* __restrict__ x1,
                                                           const float* __restrict__ dz, float* __restrict__ part) {
-    constexpr int XH = (TH - 1) * STRIDE + KS, XW = (TW - 1) * STRIDE + KS, TAPS = KS * KS, PIX = TH * TW;
+    constexpr int XH = (TH - 1) * SH + KH, XW = (TW - 1) * SW + KW, TAPS = KH * KW, PIX = TH * TW;
     static_assert(PIX % 64 == 0 && (PIX * MT * 4) % 256 == 0, "tile must give every wave whole MFMA k-steps");
     const int co_base = blockIdx.y * MT * 16;                    // output-channel group of this block (stem: 4 groups of 16)
     constexpr int LDZ = MT * 16 + 4, LDX = NT * 16 + 4;
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (i < XH * XW * NT * 4) {
                 const int pos = i / (NT * 4), c4 = i % (NT * 4);
-                int iy = ty0 * STRIDE + pos / XW - p.pad, ix = tx0 * STRIDE + pos % XW - p.pad;
+                int iy = ty0 * SH + pos / XW - p.pad, ix = tx0 * SW + pos % XW - p.pad_w;
                 if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
                     if (up) { iy >>= 1; ix >>= 1; }
@@ -884,16 +885,16 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
 #pragma unroll
             for (int a = 0; a < MT; ++a) af[a] = dZs[pix * LDZ + a * 16 + l16];
 #pragma unroll
-            for (int ky = 0; ky < KS; ++ky)
+            for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    const float* xr = Xs + ((py * STRIDE + ky) * XW + px * STRIDE + kx) * LDX + l16;
+                for (int kx = 0; kx < KW; ++kx) {
+                    const float* xr = Xs + ((py * SH + ky) * XW + px * SW + kx) * LDX + l16;
 #pragma unroll
                     for (int bb = 0; bb < NT; ++bb) {
                         const float bv = xr[bb * 16];
 #pragma unroll
                         for (int a = 0; a < MT; ++a)
-                            acc[a][bb][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bv, acc[a][bb][ky * KS + kx], 0, 0, 0);
+                            acc[a][bb][ky * KW + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bv, acc[a][bb][ky * KW + kx], 0, 0, 0);
                     }
                 }
         }
@@ -932,8 +933,11 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
     memset(&s, 0, sizeof(s));
     const int Ct = d->c0 + d->c1;
     s.co_groups = 1;
-    if (d->kh == 7 && d->kw == 7 && d->stride == 2 && Ct == 16 && d->c1 == 0 && !d->up0 && (d->out_c % 16) == 0) {
-        // ResNet stem (7x7 / 2 on the 16-channel padded image): 4x16-pixel output tiles, one 16-channel output group per block
+    const bool stem77 = d->kh == 7 && d->kw == 7 && d->stride == 2 && d->stride_w == 2 && d->pad_w == d->pad;
+    const bool stem74 = d->kh == 7 && d->kw == 4 && d->stride == 2 && d->stride_w == 1;          // double-pixel layout (functional.stem_conv2d)
+    if ((stem77 || stem74) && Ct == 16 && d->c1 == 0 && !d->up0 && (d->out_c % 16) == 0 && d->pad_mode == 0) {
+        // ResNet stem (7x7 / 2 on the 16-channel padded image, or its 7x4 double-pixel form): 4x16-pixel output tiles, one
+        // 16-channel output group per block
         s.ok = s.stem = true;
         s.mt = 1; s.nt = 1; s.ci_chunks = 1; s.co_groups = d->out_c / 16;
         s.tiles_x = cdiv(d->out_w, 16); s.tiles_y = cdiv(d->out_h, 4);
@@ -943,7 +947,8 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
         s.splits = s.nblk;
         return s;
     }
-    s.ok = d->stride == 1 && d->kh == d->kw && (d->kh == 1 || d->kh == 3) && d->out_c <= 32 && d->out_h == d->in_h && d->out_w == d->in_w;
+    s.ok = d->stride == 1 && d->stride_w == 1 && d->pad_w == d->pad && d->kh == d->kw && (d->kh == 1 || d->kh == 3) && d->out_c <= 32 &&
+           d->out_h == d->in_h && d->out_w == d->in_w;
     if (!s.ok) return s;
     s.mt = d->out_c > 16 ? 2 : 1;
     s.nt = (Ct % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0)) ? 2 : 1;
@@ -1004,12 +1009,17 @@ static int check_conv(const codeps_conv_desc* d, const char* who) {
     CODEPS_REQUIRE(d != nullptr, CODEPS_ERR_ARG, "%s: null descriptor", who);
     CODEPS_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->c0 > 0 && d->c1 >= 0 && d->out_c > 0, CODEPS_ERR_ARG,
                    "%s: bad shape", who);
-    CODEPS_REQUIRE(d->stride == 1 || d->stride == 2, CODEPS_ERR_ARG, "%s: stride %d unsupported", who, d->stride);
+    CODEPS_REQUIRE((d->stride == 1 || d->stride == 2) && (d->stride_w == 1 || d->stride_w == 2), CODEPS_ERR_ARG, "%s: stride (%d,%d) unsupported",
+                   who, d->stride, d->stride_w);
+    CODEPS_REQUIRE(d->pad >= 0 && d->pad_w >= 0 && d->kh > 0 && d->kw > 0, CODEPS_ERR_ARG, "%s: bad kernel / padding", who);
+    const bool sym = d->stride_w == d->stride && d->pad_w == d->pad;
+    CODEPS_REQUIRE(sym || (!d->up0 && d->pad_mode == 0 && d->out_c > 16), CODEPS_ERR_ARG,
+                   "%s: per-dimension stride / padding needs zero padding, no fused upsample and out_c > 16", who);
     CODEPS_REQUIRE((d->c0 % 16) == 0 && (d->c1 % 16) == 0, CODEPS_ERR_ARG,
                    "%s: channel counts (%d,%d) must be multiples of 16 (pad the stem input)", who, d->c0, d->c1);
-    CODEPS_REQUIRE(!d->up0 || ((d->in_h % 2) == 0 && (d->in_w % 2) == 0 && d->stride == 1), CODEPS_ERR_ARG,
+    CODEPS_REQUIRE(!d->up0 || ((d->in_h % 2) == 0 && (d->in_w % 2) == 0 && d->stride == 1 && d->stride_w == 1), CODEPS_ERR_ARG,
                    "%s: fused x2 upsample needs even size and stride 1", who);
-    const int ho = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1, wo = (d->in_w + 2 * d->pad - d->kw) / d->stride + 1;
+    const int ho = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1, wo = (d->in_w + 2 * d->pad_w - d->kw) / d->stride_w + 1;
     CODEPS_REQUIRE(ho == d->out_h && wo == d->out_w, CODEPS_ERR_ARG, "%s: output size %dx%d != expected %dx%d", who, d->out_h,
                    d->out_w, ho, wo);
     CODEPS_REQUIRE(d->pad_mode == 0 || (d->pad < d->in_h && d->pad < d->in_w), CODEPS_ERR_ARG, "%s: reflect pad too large", who);
@@ -1021,6 +1031,7 @@ static ConvP make_convp(const codeps_conv_desc* d) {
     memset(&p, 0, sizeof(p));
     p.B = d->batch; p.H = d->in_h; p.W = d->in_w; p.C0 = d->c0; p.C1 = d->c1; p.Ct = d->c0 + d->c1; p.up0 = d->up0;
     p.Co = d->out_c; p.Ho = d->out_h; p.Wo = d->out_w; p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.stride_w = d->stride_w; p.pad_w = d->pad_w;
     p.pad_mode = d->pad_mode; p.act = d->act;
     return p;
 }
@@ -1135,6 +1146,7 @@ extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const 
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(dz && w_dgrad && dx && (source == 0 || (source == 1 && d->c1 > 0)), CODEPS_ERR_ARG, "conv2d_dgrad: bad arguments");
     CODEPS_REQUIRE(d->pad_mode == 0, CODEPS_ERR_ARG, "conv2d_dgrad: reflect padding has no dgrad path here");
+    CODEPS_REQUIRE(d->stride_w == d->stride && d->pad_w == d->pad, CODEPS_ERR_ARG, "conv2d_dgrad: per-dimension stride / padding has no dgrad path");
     CODEPS_REQUIRE((d->out_c % 16) == 0, CODEPS_ERR_ARG, "conv2d_dgrad: out_c %d must be a multiple of 16", d->out_c);
     ConvP p = make_convp(d);
     p.src = source;
@@ -1218,6 +1230,7 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     memset(&p, 0, sizeof(p));
     p.B = d->batch; p.H = d->in_h; p.W = d->in_w; p.C0 = d->c0; p.C1 = d->c1; p.Ct = d->c0 + d->c1; p.up0 = d->up0;
     p.Co = d->out_c; p.Ho = d->out_h; p.Wo = d->out_w; p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.stride_w = d->stride_w; p.pad_w = d->pad_w;
     p.pad_mode = d->pad_mode; p.n_mt = n_mt; p.n_nt = n_nt; p.splits = splits; p.pix_per_split = pps;
     p.P = d->batch * d->out_h * d->out_w;
     const int grid = n_mt * n_nt * d->kh * d->kw * splits;
@@ -1225,11 +1238,15 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     float* part = (float*)workspace;
     if (sp.ok) {
         const int g = sp.nblk * sp.ci_chunks;
-#define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS, 1, 8, 32>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \
+#define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS, KS, 1, 1, 8, 32>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \
                                                  sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part)
         if (sp.stem) {
-            hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 2, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x,
-                               sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
+            if (d->kw == 7)
+                hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 7, 2, 2, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks,
+                                   sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
+            else                                       // double-pixel stem: 7 x 4 taps of 16 (2 pixels x 8 channels), stride (2, 1)
+                hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 4, 2, 1, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks,
+                                   sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
         } else if (d->kh == 3) {
             if (sp.mt == 1 && sp.nt == 1) WS_LAUNCH(1, 1, 3); else if (sp.mt == 1) WS_LAUNCH(1, 2, 3);
             else if (sp.nt == 1) WS_LAUNCH(2, 1, 3); else WS_LAUNCH(2, 2, 3);

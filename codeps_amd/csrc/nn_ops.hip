@@ -23,29 +23,35 @@ static inline int grid_for(long long work_items) {
 
 // ---------------------------------------------------------------------------------- layout
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, int H, int W,
-                                                           float* __restrict__ y, int Cp, int c_off, int zero_rest) {
-    // one thread per (pixel, 4-channel group) of the destination
+                                                           float* __restrict__ y, int Cp, int c_off, int zero_rest, int pad_l, int Wp) {
+    // one thread per (destination pixel, 4-channel group); rows of the destination are Wp >= pad_l + W pixels wide, the
+    // border columns are zero (written when zero_rest)
     const int groups = zero_rest ? Cp / 4 : (C + 3) / 4;
-    const long long total = (long long)B * H * W * groups;
+    const int Wd = zero_rest ? Wp : W;                           // columns this launch walks
+    const long long total = (long long)B * H * Wd * groups;
     const long long HW = (long long)H * W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int g = (int)(i % groups);
-        const long long pix = i / groups;
-        const int b = (int)(pix / HW);
-        const long long hw = pix % HW;
+        long long r = i / groups;
+        const int xd = (int)(r % Wd); r /= Wd;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        const int xs = zero_rest ? xd - pad_l : xd;              // source column
+        float* dst = y + (((size_t)b * H + yy) * Wp + (zero_rest ? xd : xd + pad_l)) * Cp;
+        const long long hw = (long long)yy * W + xs;
         if (zero_rest) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = g * 4 + e - c_off;
-                v[e] = (c >= 0 && c < C) ? x[((size_t)b * C + c) * HW + hw] : 0.f;
+                v[e] = (c >= 0 && c < C && xs >= 0 && xs < W) ? x[((size_t)b * C + c) * HW + hw] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(y + (size_t)pix * Cp + g * 4) = v;
+            *reinterpret_cast<f32x4*>(dst + g * 4) = v;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = g * 4 + e;
-                if (c < C) y[(size_t)pix * Cp + c_off + c] = x[((size_t)b * C + c) * HW + hw];
+                if (c < C) dst[c_off + c] = x[((size_t)b * C + c) * HW + hw];
             }
         }
     }
@@ -806,15 +812,27 @@ static inline int col_tiles(int C) { return cdiv(C / 4, 256); }
 }  // namespace
 
 // =============================================================================================== C ABI
-extern "C" int codeps_nchw_to_nhwc(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off, int zero_rest,
-                                   codeps_stream_t stream) {
-    CODEPS_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0 && (c_pad % 4) == 0 && c_off >= 0 && c_off + c <= c_pad,
-                   CODEPS_ERR_ARG, "nchw_to_nhwc: bad arguments");
-    const long long items = (long long)batch * h * w * (zero_rest ? c_pad / 4 : (c + 3) / 4);
+static int nchw_to_nhwc_impl(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off, int zero_rest, int pad_l,
+                             int pad_r, codeps_stream_t stream, const char* who) {
+    CODEPS_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0 && (c_pad % 4) == 0 && c_off >= 0 && c_off + c <= c_pad && pad_l >= 0 &&
+                       pad_r >= 0,
+                   CODEPS_ERR_ARG, "%s: bad arguments", who);
+    const int wp = pad_l + w + pad_r;
+    const long long items = (long long)batch * h * (zero_rest ? wp : w) * (zero_rest ? c_pad / 4 : (c + 3) / 4);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, x, batch, c, h, w, y, c_pad,
-                       c_off, zero_rest);
+                       c_off, zero_rest, pad_l, wp);
     CODEPS_CHECK_LAUNCH("nchw_to_nhwc_kernel");
     return CODEPS_OK;
+}
+
+extern "C" int codeps_nchw_to_nhwc(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off, int zero_rest,
+                                   codeps_stream_t stream) {
+    return nchw_to_nhwc_impl(x, batch, c, h, w, y, c_pad, c_off, zero_rest, 0, 0, stream, "nchw_to_nhwc");
+}
+
+extern "C" int codeps_nchw_to_nhwc_xpad(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off, int zero_rest,
+                                        int pad_left, int pad_right, codeps_stream_t stream) {
+    return nchw_to_nhwc_impl(x, batch, c, h, w, y, c_pad, c_off, zero_rest, pad_left, pad_right, stream, "nchw_to_nhwc_xpad");
 }
 
 extern "C" int codeps_nhwc_to_nchw(const float* x, int batch, int c, int h, int w, int c_pad, float* y, codeps_stream_t stream) {

@@ -122,47 +122,54 @@ def to_nchw(y, c):
     return v
 
 
-def images_to_nhwc(images, c_pad=16):
+def _to_nhwc_into(im, y, c_pad, c_off, zero_rest, xpad):
+    b, c, h, w = im.shape
+    check(lib().codeps_nchw_to_nhwc_xpad(ptr(im), b, c, h, w, ptr(y), c_pad, c_off, zero_rest, xpad[0], xpad[1], stream_ptr()),
+          "codeps_nchw_to_nhwc_xpad")
+
+
+STEM_XPAD = (4, 2)      # zero columns left / right of every row in the double-pixel stem layout (see stem_conv2d)
+
+
+def images_to_nhwc(images, c_pad=16, xpad=(0, 0)):
     """[B,3,H,W] NCHW image(s) -> one NHWC tensor with the images stacked along channels and zero
-    padding up to c_pad (stem input; two frames for the pose net)."""
+    padding up to c_pad (stem input; two frames for the pose net); xpad = extra zero columns (left, right)."""
     imgs = [_f32c(i) for i in images]
     require_cuda(*imgs)
     b, c, h, w = imgs[0].shape
-    y = torch.empty(b, h, w, c_pad, dtype=torch.float32, device=imgs[0].device)
+    y = torch.empty(b, h, w + sum(xpad), c_pad, dtype=torch.float32, device=imgs[0].device)
     for k, im in enumerate(imgs):
-        check(lib().codeps_nchw_to_nhwc(ptr(im), b, c, h, w, ptr(y), c_pad, k * c, 1 if k == 0 else 0, stream_ptr()),
-              "codeps_nchw_to_nhwc")
+        _to_nhwc_into(im, y, c_pad, k * c, 1 if k == 0 else 0, xpad)
     return y
 
 
-def frame_pairs_to_nhwc(pairs, c_pad=16):
+def frame_pairs_to_nhwc(pairs, c_pad=16, xpad=(0, 0)):
     """[(frame_a [B_i,3,H,W], frame_b [B_i,3,H,W]), ...] -> NHWC [sum B_i, H, W, c_pad] with the two frames stacked
     along channels (the pose net's input, algos/depth.py:408-413) and the pairs concatenated along the batch."""
     require_cuda(*[t for p in pairs for t in p])
     _, c, h, w = pairs[0][0].shape
     total = sum(p[0].shape[0] for p in pairs)
-    y = torch.empty(total, h, w, c_pad, dtype=torch.float32, device=pairs[0][0].device)
+    y = torch.empty(total, h, w + sum(xpad), c_pad, dtype=torch.float32, device=pairs[0][0].device)
     off = 0
     for fa, fb in pairs:
         b = fa.shape[0]
         for k, im in enumerate((_f32c(fa), _f32c(fb))):
-            check(lib().codeps_nchw_to_nhwc(ptr(im), b, c, h, w, ptr(y[off:off + b]), c_pad, k * c, 1 if k == 0 else 0, stream_ptr()),
-                  "codeps_nchw_to_nhwc")
+            _to_nhwc_into(im, y[off:off + b], c_pad, k * c, 1 if k == 0 else 0, xpad)
         off += b
     return y
 
 
-def image_batches_to_nhwc(images, c_pad=16):
+def image_batches_to_nhwc(images, c_pad=16, xpad=(0, 0)):
     """[B_i,C,H,W] NCHW batches (same C,H,W) -> one NHWC tensor [sum B_i, H, W, c_pad] (batch concat on the fly)."""
     imgs = [_f32c(i) for i in images]
     require_cuda(*imgs)
     _, c, h, w = imgs[0].shape
     total = sum(i.shape[0] for i in imgs)
-    y = torch.empty(total, h, w, c_pad, dtype=torch.float32, device=imgs[0].device)
+    y = torch.empty(total, h, w + sum(xpad), c_pad, dtype=torch.float32, device=imgs[0].device)
     off = 0
     for im in imgs:
         b = im.shape[0]
-        check(lib().codeps_nchw_to_nhwc(ptr(im), b, c, h, w, ptr(y[off:off + b]), c_pad, 0, 1, stream_ptr()), "codeps_nchw_to_nhwc")
+        _to_nhwc_into(im, y[off:off + b], c_pad, 0, 1, xpad)
         off += b
     return y
 
@@ -233,8 +240,9 @@ def _conv_desc(x0, x1, out_c_pad, kh, kw, stride, pad, pad_mode, act, up0):
         h, w = x0.shape[1], x0.shape[2]
     if x1 is not None and (x1.shape[1] != h or x1.shape[2] != w):
         raise _lib.CodepsHipError(f"conv2d: skip tensor is {tuple(x1.shape[1:3])}, expected {(h, w)}")
-    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-    return _lib.ConvDesc(b, h, w, c0, c1, int(up0), out_c_pad, ho, wo, kh, kw, stride, pad, pad_mode, act)
+    (sh, sw), (ph, pw) = stride, pad
+    ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+    return _lib.ConvDesc(b, h, w, c0, c1, int(up0), out_c_pad, ho, wo, kh, kw, sh, ph, pad_mode, act, sw, pw)
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
@@ -273,7 +281,7 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv(cat(up(x0), x1), W) * scale + shift + residual) on NHWC tensors (C ABI conv2d)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, scale, shift, residual, stride, pad, pad_mode, act, up0):
+    def forward(ctx, x0, x1, weight, bias, scale, shift, residual, stride, pad, pad_mode, act, up0, macs_per_out):
         require_cuda(x0, x1, weight)
         co, ci, kh, kw = weight.shape
         cop = pad16(co)
@@ -288,7 +296,7 @@ class _Conv2d(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         y = torch.empty(desc.batch, desc.out_h, desc.out_w, cop, dtype=torch.float32, device=x0.device)
-        flops = 2.0 * desc.batch * desc.out_h * desc.out_w * co * ci * kh * kw         # algorithmic (unpadded)
+        flops = 2.0 * desc.batch * desc.out_h * desc.out_w * co * (macs_per_out or ci * kh * kw)         # algorithmic (unpadded)
         t0 = _prof_begin()
         check(lib().codeps_conv2d_fwd(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
                                       stream_ptr()), "codeps_conv2d_fwd")
@@ -335,7 +343,7 @@ class _Conv2d(torch.autograd.Function):
             # reflect padding: data gradient w.r.t. the (virtual) padded tensor, then fold the border back
             p_ = desc.pad
             dpad = _lib.ConvDesc(desc.batch, desc.in_h + 2 * p_, desc.in_w + 2 * p_, desc.c0, 0, 0, desc.out_c, desc.out_h,
-                                 desc.out_w, desc.kh, desc.kw, desc.stride, 0, 0, desc.act)
+                                 desc.out_w, desc.kh, desc.kw, desc.stride, 0, 0, desc.act, desc.stride, 0)
             dxp = torch.empty(desc.batch, desc.in_h + 2 * p_, desc.in_w + 2 * p_, desc.c0, dtype=torch.float32, device=dy.device)
             check(lib().codeps_conv2d_dgrad(ctypes.byref(dpad), 0, ptr(dz), ptr(wd), ptr(dxp), stream_ptr()),
                   "codeps_conv2d_dgrad")
@@ -365,15 +373,55 @@ class _Conv2d(torch.autograd.Function):
             _prof_end(t0, "conv_wgrad", ctx.flops, desc)
             if sink is not None:
                 dw = None               # accumulated in place into the flat gradient buffer
-        return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None, None
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 
 
 def conv2d(x0, weight, bias=None, *, x1=None, scale=None, shift=None, residual=None, stride=1, pad=0, pad_mode="zeros",
-           act=None, up0=False):
+           act=None, up0=False, macs_per_out=None):
     """NHWC convolution.  x0 [B,H,W,C0p]; optional skip x1 concatenated along channels after an
-    optional nearest-x2 upsample of x0; weight OIHW; returns [B,Ho,Wo,pad16(Cout)]."""
-    return _Conv2d.apply(x0, x1, weight, bias, scale, shift, residual, int(stride), int(pad),
-                         1 if pad_mode == "reflect" else 0, ACT[act], bool(up0))
+    optional nearest-x2 upsample of x0; weight OIHW; stride / pad: int or (vertical, horizontal);
+    returns [B,Ho,Wo,pad16(Cout)].  macs_per_out: algorithmic multiply-adds per output element for the profiler when
+    the weight tensor is a re-laid-out form of the reference's (stem_conv2d)."""
+    return _Conv2d.apply(x0, x1, weight, bias, scale, shift, residual, _pair(stride), _pair(pad),
+                         1 if pad_mode == "reflect" else 0, ACT[act], bool(up0), macs_per_out)
+
+
+_stem_cache = {}
+
+
+def stem_weight(weight):
+    """ResNet conv1 weight [co, ci <= 8, 7, 7] -> its double-pixel form [co, 16, 7, 4]:
+    W'[o][p * 8 + c][ky][j] = W[o][c][ky][2 j + p - 1]  (tap 2j + p - 1 = -1 and channels >= ci are zero).
+    Differentiable (pad / view / permute), cached for frozen weights."""
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (7, 7) or ci > 8:
+        raise _lib.CodepsHipError("stem_weight: expects a 7x7 kernel over <= 8 input channels")
+    frozen = not (weight.requires_grad and torch.is_grad_enabled())
+    if frozen:
+        hit = _stem_cache.get(id(weight))
+        if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
+            return hit[2]
+    w8 = torch.nn.functional.pad(weight if not frozen else weight.detach(), (1, 0, 0, 0, 0, 8 - ci))      # [co, 8, 7, 8]: kx' = kx + 1
+    wp = w8.view(co, 8, 7, 4, 2).permute(0, 4, 1, 2, 3).reshape(co, 16, 7, 4)
+    if frozen:
+        _stem_cache[id(weight)] = (weakref.ref(weight), (weight.data_ptr(), weight._version), wp)
+    return wp
+
+
+def stem_conv2d(x, weight, *, scale=None, shift=None, act=None):
+    """ResNet conv1 (7x7, stride 2, padding 3, <= 8 input channels; models/resnet_encoder.py:115) on the double-pixel
+    stem layout: x [B, H, W + 6, 8] = images with STEM_XPAD zero columns (images_to_nhwc(..., 8, STEM_XPAD)).
+    Two neighbouring pixels are one 16-channel pixel of a [B, H, (W + 6) / 2, 16] view and conv1 is a 7x4 convolution
+    of stride (2, 1), padding (3, 0) over it: the GEMM K dimension is 448 instead of 784 (16-channel padded 7x7)."""
+    b, h, wp, c = x.shape
+    if c != 8 or wp % 2:
+        raise _lib.CodepsHipError("stem_conv2d: expects [B, H, W + 6, 8] with even W")
+    return conv2d(x.view(b, h, wp // 2, 16), stem_weight(weight), scale=scale, shift=shift, stride=(2, 1), pad=(3, 0), act=act,
+                  macs_per_out=weight.shape[1] * 49)
 
 
 # ---------------------------------------------------------------------------------------- BatchNorm

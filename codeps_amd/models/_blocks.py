@@ -23,10 +23,23 @@ def folded_bn(bn: nn.BatchNorm2d):
     return scale, shift
 
 
-def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None, groups=None):
+def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None, groups=None, stem=False):
     """act(BN(conv(x)) + residual).  Eval-mode BN is folded into the conv epilogue (one kernel);
-    train-mode BN uses batch statistics (`sync` = cross-rank sum reducer for SyncBatchNorm)."""
+    train-mode BN uses batch statistics (`sync` = cross-rank sum reducer for SyncBatchNorm).
+    stem=True: x is in the double-pixel stem layout and conv is ResNet's conv1 (F.stem_conv2d)."""
     stride, pad = conv.stride[0], conv.padding[0]
+    if stem:
+        if bn.training or (torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad)):
+            y = F.stem_conv2d(x, conv.weight)
+            if bn.training:
+                out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                         residual=residual, act=act, reduce_fn=sync, groups=groups)
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += len(groups) if groups else 1
+                return out
+            return F.batch_norm_eval(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual=residual, act=act)
+        scale, shift = folded_bn(bn)
+        return F.stem_conv2d(x, conv.weight, scale=scale, shift=shift, act=act)
     if bn.training:
         y = F.conv2d(x, conv.weight, stride=stride, pad=pad)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,

@@ -119,19 +119,27 @@ class ResnetEncoder(nn.Module):
         frame pair) -- the tuple form skips the reference's torch.cat (algos/depth.py:408-413)."""
         enc = self.encoder
         groups = None
+        first = input_image[0][0] if isinstance(input_image, _PairGroups) else (
+            input_image[0] if isinstance(input_image, (tuple, list)) else input_image)
+        # conv1 on <= 8 input channels and an even width runs in the double-pixel stem layout (F.stem_conv2d: K = 448
+        # instead of 784 for the 16-channel padded form); anything else takes the generic 16-channel path
+        stem = enc.conv1.in_channels <= 8 and first.shape[-1] % 2 == 0
+        cp, xpad = (8, F.STEM_XPAD) if stem else (16, (0, 0))
         if isinstance(input_image, _PairGroups):
-            x = F.frame_pairs_to_nhwc(list(input_image), 16)
+            x = F.frame_pairs_to_nhwc(list(input_image), cp, xpad)
             groups, off = [], 0
             for fa, _fb in input_image:
                 groups.append((off, off + fa.shape[0]))
                 off += fa.shape[0]
         elif isinstance(input_image, _BatchOf):
-            x = F.image_batches_to_nhwc(list(input_image), 16)
+            x = F.image_batches_to_nhwc(list(input_image), cp, xpad)
         elif isinstance(input_image, (tuple, list)):
-            x = F.images_to_nhwc(list(input_image), 16)
+            x = F.images_to_nhwc(list(input_image), cp, xpad)
+        elif stem:
+            x = F.images_to_nhwc([input_image], cp, xpad)
         else:
             x = F.from_nchw(input_image, 16)
-        x = conv_bn(x, enc.conv1, enc.bn1, "relu", sync=self.sync_bn, groups=groups)
+        x = conv_bn(x, enc.conv1, enc.bn1, "relu", sync=self.sync_bn, groups=groups, stem=stem)
         feats = [x]
         x = F.max_pool3x3s2(x)
         for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* codeps_stream_t;
 
-int codeps_version(void);                 /* ABI version, bumped on any signature change */
+int codeps_version(void);                 /* ABI version (2), bumped on any signature change */
 const char* codeps_last_error(void);      /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------------------------------------
@@ -76,9 +76,11 @@ typedef struct {
     int32_t c0, c1;              /* channels of source 0 / source 1 (multiples of 16) */
     int32_t up0;                 /* 1: source 0 is stored at half resolution, nearest x2 on load */
     int32_t out_c, out_h, out_w;
-    int32_t kh, kw, stride, pad; /* stride 1 or 2 */
+    int32_t kh, kw, stride, pad; /* vertical stride (1 or 2) / padding */
     int32_t pad_mode;            /* 0 zeros, 1 reflect (ReflectionPad2d) */
     int32_t act;                 /* 0 none, 1 ReLU, 2 ELU(alpha=1) */
+    int32_t stride_w, pad_w;     /* horizontal stride / padding (= stride / pad for every nn.Conv2d of the reference; they
+                                  * differ only for the double-pixel stem form, see codeps_nchw_to_nhwc_xpad) */
 } codeps_conv_desc;
 
 /* OIHW [out_c][in_c][kh][kw] -> w_fwd [out_c_pad][kh*kw][in_c_pad] and/or w_dgrad [in_c_pad][kh*kw][out_c_pad]. */
@@ -106,6 +108,13 @@ int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float*
  * the other channels (image -> padded stem input; two calls build the 6-channel pose-net input). */
 int codeps_nchw_to_nhwc(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off,
                         int zero_rest, codeps_stream_t stream);
+/* Same, into rows that carry pad_left / pad_right extra zero pixels: y[batch, h, pad_left + w + pad_right, c_pad].
+ * Double-pixel stem form (ResNet conv1 = 7x7 / 2 / 3 on <= 8 input channels, models/resnet_encoder.py:115): with
+ * c_pad = 8, pad_left = 4, pad_right = 2 two neighbouring pixels form one 16-float "pixel" of a
+ * [batch, h, (w + 6) / 2, 16] tensor, and conv1 becomes a 7 x 4 convolution of stride (2, 1), padding (3, 0) over it
+ * whose K dimension is 7*4*16 = 448 instead of 7*7*16 = 784 (weights W'[o][p*8 + c][ky][j] = W[o][c][ky][2j + p - 1]). */
+int codeps_nchw_to_nhwc_xpad(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off,
+                             int zero_rest, int pad_left, int pad_right, codeps_stream_t stream);
 int codeps_nhwc_to_nchw(const float* x, int batch, int c, int h, int w, int c_pad, float* y,
                         codeps_stream_t stream);
 size_t codeps_colsum_workspace_bytes(long long rows, int c, int k);

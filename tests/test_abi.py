@@ -38,11 +38,11 @@ def test_version_and_error_string():
     d = _lib.PhotometricDesc(1, 16, 16, 5, 0.85, 0)          # coarsest scale 1x1 < 2x2
     assert handle.codeps_photometric_workspace_bytes(ctypes.byref(d)) == 0
     assert b"smaller than 2x2" in handle.codeps_last_error()
-    c = _lib.ConvDesc(1, 8, 8, 3, 0, 0, 16, 8, 8, 3, 3, 1, 1, 0, 0)
+    c = _lib.ConvDesc(1, 8, 8, 3, 0, 0, 16, 8, 8, 3, 3, 1, 1, 0, 0, 1, 1)
     assert handle.codeps_conv2d_wgrad_workspace_bytes(ctypes.byref(c)) == 0
     assert b"multiples of 16" in handle.codeps_last_error()
 
 
 def test_structs_match_c_layout():
     assert ctypes.sizeof(_lib.PhotometricDesc) == 32 and _lib.PhotometricDesc.noise_seed.offset == 24
-    assert ctypes.sizeof(_lib.ConvDesc) == 15 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 17 * 4 and _lib.ConvDesc.stride_w.offset == 15 * 4

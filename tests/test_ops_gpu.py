@@ -189,6 +189,28 @@ def test_bilinear_concat_guda():
         assert rel_err(nchw(d.grad, x.shape[1]), r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("ci,h,w,b", [(3, 32, 64, 2), (6, 38, 52, 3)])
+def test_stem_conv_double_pixel_layout(ci, h, w, b):
+    """ResNet conv1 (7x7 / 2 / 3) through the double-pixel stem layout (nchw_to_nhwc_xpad + 7x4 conv of stride (2,1))."""
+    F = _F()
+    g = torch.Generator().manual_seed(ci * 7 + h)
+    x = torch.randn(b, ci, h, w, generator=g)
+    wt = torch.randn(64, ci, 7, 7, generator=g) * 0.05
+    rw = wt.double().requires_grad_(True)
+    y = TF.conv2d(x.double(), rw, None, 2, 3)
+    gy = torch.randn(y.shape, generator=g).double()
+    (y * gy).sum().backward()
+    halves = [x[:, :3].to(DEV)] + ([x[:, 3:].to(DEV)] if ci == 6 else [])
+    xs = F.images_to_nhwc(halves, 8, F.STEM_XPAD)
+    assert xs.shape == (b, h, w + 6, 8)
+    assert float(xs[:, :, :4].abs().max()) == 0.0 and float(xs[:, :, -2:].abs().max()) == 0.0 and float(xs[..., ci:].abs().max()) == 0.0
+    dw = wt.to(DEV).requires_grad_(True)
+    out = F.stem_conv2d(xs, dw)
+    assert rel_err(nchw(out, 64), y) < 1e-5
+    out.backward(nhwc(gy.float()))
+    assert rel_err(dw.grad.cpu(), rw.grad) < 1e-5
+
+
 @pytest.mark.parametrize("h,w,b", [(32, 48, 2), (24, 40, 1)])
 def test_guda_fusion_matches_concat_conv(h, w, b):
     """conv3x3(cat(up(d_k))) evaluated as per-tap 1x1 convs at low resolution + tap gather (semantic_head.py:64-72)."""
