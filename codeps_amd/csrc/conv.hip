@@ -87,6 +87,65 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Gather table of one block of BM rows (see conv_igemm_kernel): tab[source][tap][row] = byte offset of the pixel that row
+// reads through that tap, relative to the first image the block touches (GATHER_OOB = zero padding / row past M), plus
+// the buffer resources of the source(s) rebased to that image.  Ends with a barrier.
+template <int MODE, int BM>
+__device__ __forceinline__ void build_gather(const ConvP& p, int m0, int ntap, unsigned* tab, const float* a0, const float* a1,
+                                             __amdgpu_buffer_rsrc_t& rs0, __amdgpu_buffer_rsrc_t& rs1) {
+    const int tid = threadIdx.x;
+    const bool two_src = MODE == MODE_FWD && p.C1 > 0;
+    const bool parc = MODE == MODE_DGRAD && p.par;
+    const bool upd = MODE == MODE_DGRAD && p.up0 && p.src == 0;
+    const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : (parc ? p.Hc * p.Wc : (upd ? (p.H / 2) * (p.W / 2) : p.H * p.W));
+    const int Wm = (MODE == MODE_FWD) ? p.Wo : (parc ? p.Wc : (upd ? p.W / 2 : p.W));
+    const int b_first = m0 / HWm;                                // block-uniform: offsets stay < 4 GB whatever the tensor size
+    // source geometry: fwd source 0 (maybe at half resolution), fwd source 1, or dZ for dgrad
+    const int H0 = (MODE == MODE_FWD) ? (p.up0 ? p.H / 2 : p.H) : p.Ho, W0 = (MODE == MODE_FWD) ? (p.up0 ? p.W / 2 : p.W) : p.Wo;
+    const int cs0 = (MODE == MODE_FWD) ? p.C0 : p.Co;
+    for (int e = tid; e < ntap * BM; e += 256) {
+        const int row = e % BM, tap = e / BM;
+        const int m = m0 + row;
+        unsigned v0 = GATHER_OOB, v1 = GATHER_OOB;
+        if (m < p.M) {
+            const int bb = m / HWm - b_first, rem = m % HWm;
+            const int y = rem / Wm, x = rem % Wm;
+            if (MODE == MODE_FWD) {
+                const int ky = tap / p.KW, kx = tap % p.KW;
+                int iy = y * p.stride - p.pad + ky, ix = x * p.stride_w - p.pad_w + kx;
+                if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    v1 = (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(p.C1 * 4);
+                    v0 = p.up0 ? (unsigned)((bb * H0 + (iy >> 1)) * W0 + (ix >> 1)) * (unsigned)(cs0 * 4)      // fused nearest x2 of source 0
+                               : (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(cs0 * 4);
+                }
+            } else {
+                // dgrad: the output pixel (ty, tx) that read this input pixel through tap (ky, kx)
+                int ky, kx, qy = 0, qx = 0;
+                if (parc) { ky = p.ky0 + 2 * (tap / p.nkx); kx = p.kx0 + 2 * (tap % p.nkx); }
+                else if (upd) {
+                    const int q = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
+                    qy = q >> 1; qx = q & 1; ky = t2 / p.KW; kx = t2 % p.KW;
+                } else { ky = tap / p.KW; kx = tap % p.KW; }
+                int iy = y, ix = x;
+                if (parc) { iy = 2 * iy + p.py; ix = 2 * ix + p.px; }
+                if (upd) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
+                int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
+                bool ok = ty >= 0 && tx >= 0;
+                if (p.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
+                if (ok && ty < p.Ho && tx < p.Wo) v0 = (unsigned)((bb * p.Ho + ty) * p.Wo + tx) * (unsigned)(cs0 * 4);
+            }
+        }
+        tab[e] = v0;
+        if (two_src) tab[ntap * BM + e] = v1;
+    }
+    __syncthreads();
+    const int Btot = p.M > 0 ? (p.M + HWm - 1) / HWm : 1;        // images addressed by the rows of this launch (= batch)
+    const size_t img0 = (size_t)H0 * W0 * cs0, img1 = (size_t)p.H * p.W * p.C1;
+    rs0 = make_rsrc(a0 + (size_t)b_first * img0, (size_t)(Btot - b_first) * img0 * 4);
+    rs1 = two_src ? make_rsrc(a1 + (size_t)b_first * img1, (size_t)(Btot - b_first) * img1 * 4) : rs0;
+}
+
 // One implicit-GEMM kernel for forward and dgrad.
 //   A rows: pixels.  B rows: GEMM columns n (weights packed [n][tap][c], c contiguous).
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF>
@@ -126,58 +185,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     //      div / mod / bounds / reflect / upsample arithmetic and its branches (measured: with the address arithmetic in
     //      the loop the MFMA pipe idled 20-45 % of the time behind VALU work).
     unsigned* tab = reinterpret_cast<unsigned*>(smem + NBUF * (BM + BN) * LDK);
-    const bool two_src = MODE == MODE_FWD && p.C1 > 0;
-    const bool parc = MODE == MODE_DGRAD && p.par;
-    const bool upd = MODE == MODE_DGRAD && p.up0 && p.src == 0;
-    const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : (parc ? p.Hc * p.Wc : (upd ? (p.H / 2) * (p.W / 2) : p.H * p.W));
-    const int Wm = (MODE == MODE_FWD) ? p.Wo : (parc ? p.Wc : (upd ? p.W / 2 : p.W));
-    const int b_first = m0 / HWm;                                // block-uniform: offsets stay < 4 GB whatever the tensor size
-    // source geometry: fwd source 0 (maybe at half resolution), fwd source 1, or dZ for dgrad
-    const int H0 = (MODE == MODE_FWD) ? (p.up0 ? p.H / 2 : p.H) : p.Ho, W0 = (MODE == MODE_FWD) ? (p.up0 ? p.W / 2 : p.W) : p.Wo;
-    const int cs0 = (MODE == MODE_FWD) ? p.C0 : p.Co;
-    {
-        for (int e = tid; e < ntap * BM; e += 256) {
-            const int row = e % BM, tap = e / BM;
-            const int m = m0 + row;
-            unsigned v0 = GATHER_OOB, v1 = GATHER_OOB;
-            if (m < p.M) {
-                const int bb = m / HWm - b_first, rem = m % HWm;
-                const int y = rem / Wm, x = rem % Wm;
-                if (MODE == MODE_FWD) {
-                    const int ky = tap / p.KW, kx = tap % p.KW;
-                    int iy = y * p.stride - p.pad + ky, ix = x * p.stride_w - p.pad_w + kx;
-                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
-                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                        v1 = (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(p.C1 * 4);
-                        v0 = p.up0 ? (unsigned)((bb * H0 + (iy >> 1)) * W0 + (ix >> 1)) * (unsigned)(cs0 * 4)      // fused nearest x2 of source 0
-                                   : (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(cs0 * 4);
-                    }
-                } else {
-                    // dgrad: the output pixel (ty, tx) that read this input pixel through tap (ky, kx)
-                    int ky, kx, qy = 0, qx = 0;
-                    if (parc) { ky = p.ky0 + 2 * (tap / p.nkx); kx = p.kx0 + 2 * (tap % p.nkx); }
-                    else if (upd) {
-                        const int q = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
-                        qy = q >> 1; qx = q & 1; ky = t2 / p.KW; kx = t2 % p.KW;
-                    } else { ky = tap / p.KW; kx = tap % p.KW; }
-                    int iy = y, ix = x;
-                    if (parc) { iy = 2 * iy + p.py; ix = 2 * ix + p.px; }
-                    if (upd) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
-                    int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
-                    bool ok = ty >= 0 && tx >= 0;
-                    if (p.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
-                    if (ok && ty < p.Ho && tx < p.Wo) v0 = (unsigned)((bb * p.Ho + ty) * p.Wo + tx) * (unsigned)(cs0 * 4);
-                }
-            }
-            tab[e] = v0;
-            if (two_src) tab[ntap * BM + e] = v1;
-        }
-    }
-    __syncthreads();
-    const int Btot = p.M > 0 ? (p.M + HWm - 1) / HWm : 1;        // images addressed by the rows of this launch (= batch)
-    const size_t img0 = (size_t)H0 * W0 * cs0, img1 = (size_t)p.H * p.W * p.C1;
-    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a0 + (size_t)b_first * img0, (size_t)(Btot - b_first) * img0 * 4);
-    const __amdgpu_buffer_rsrc_t rs1 = two_src ? make_rsrc(a1 + (size_t)b_first * img1, (size_t)(Btot - b_first) * img1 * 4) : rs0;
+    __amdgpu_buffer_rsrc_t rs0, rs1;
+    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1);
 
     // ---- per-thread staging roles: 16-B chunk `chunk` of rows rbase + RPP * i
     const int chunk = tid % CPR, rbase = tid / CPR;
@@ -343,76 +352,36 @@ __global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float*
                                                            float* __restrict__ out) {
     constexpr int BM = 256, TM = 4, G = BK / 16;
     __shared__ __attribute__((aligned(16))) float Cs[BM * 20];
+    extern __shared__ __attribute__((aligned(16))) float smem[];         // gather table [sources][taps][BM]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * BM;
-    int rb[TM], ry[TM], rx[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wave * 64 + i * 16 + l16;
-        if (m < p.M) {
-            const bool upd = MODE == MODE_DGRAD && p.up0 && p.src == 0;
-            const int HWm = (MODE == MODE_FWD) ? p.Ho * p.Wo : (upd ? (p.H / 2) * (p.W / 2) : p.H * p.W);
-            const int Wm = (MODE == MODE_FWD) ? p.Wo : (upd ? p.W / 2 : p.W);
-            rb[i] = m / HWm;
-            const int rem = m % HWm;
-            ry[i] = rem / Wm; rx[i] = rem % Wm;
-        } else { rb[i] = -1; ry[i] = 0; rx[i] = 0; }
-    }
     const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
-    const float* brow = (l16 < p.N) ? wq + (size_t)l16 * p.KH * p.KW * Kc + q * 4 : nullptr;
     const int ntap = (MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW;
     const int steps_per_tap = Kc / BK, nsteps = ntap * steps_per_tap;
+    unsigned* tab = reinterpret_cast<unsigned*>(smem);
+    __amdgpu_buffer_rsrc_t rs0, rs1;
+    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1);
+    // weight row of this lane's column; columns past N read row N - 1 (their results are never stored)
+    const float* brow = wq + (size_t)min(l16, p.N - 1) * p.KH * p.KW * Kc + q * 4;
+    const int rrow = wave * 64 + l16;                            // this lane's row in tile i: rrow + 16 * i
 
     auto load_step = [&](int step, f32x4 (&af)[TM][G], f32x4 (&bf)[G]) {
-        const int tap = step / steps_per_tap, cstep = (step % steps_per_tap) * BK;
-        int ky, kx, qy = 0, qx = 0;
-        if (MODE == MODE_DGRAD && p.up0 && p.src == 0) {
-            const int qq = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
-            qy = qq >> 1; qx = qq & 1; ky = t2 / p.KW; kx = t2 % p.KW;
-        } else { ky = tap / p.KW; kx = tap % p.KW; }
-        const float* base[TM];
-        if (MODE == MODE_FWD) {
-            const bool s1 = cstep >= p.C0;
-            const float* src = s1 ? a1 : a0;
-            const int cs = s1 ? p.C1 : p.C0, c = (s1 ? cstep - p.C0 : cstep) + q * 4;
-            const bool up = p.up0 && !s1;
-            const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                base[i] = nullptr;
-                if (rb[i] >= 0) {
-                    int iy = ry[i] * p.stride - p.pad + ky, ix = rx[i] * p.stride - p.pad + kx;
-                    if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
-                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                        if (up) { iy >>= 1; ix >>= 1; }
-                        base[i] = src + (((size_t)rb[i] * Hs + iy) * Ws + ix) * cs + c;
-                    }
-                }
-            }
-        } else {
-            const int c = cstep + q * 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                base[i] = nullptr;
-                if (rb[i] >= 0) {
-                    int iy = ry[i], ix = rx[i];
-                    if (p.up0 && p.src == 0) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
-                    int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
-                    bool ok = ty >= 0 && tx >= 0;
-                    if (p.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
-                    if (ok && ty < p.Ho && tx < p.Wo) base[i] = a0 + (((size_t)rb[i] * p.Ho + ty) * p.Wo + tx) * p.Co + c;
-                }
-            }
-        }
+        const int tap = step / steps_per_tap, cstep = (step - tap * steps_per_tap) * BK;
+        const bool s1 = MODE == MODE_FWD && cstep >= p.C0;
+        const __amdgpu_buffer_rsrc_t rs = s1 ? rs1 : rs0;
+        const unsigned coff = (unsigned)((s1 ? cstep - p.C0 : cstep) + q * 4) * 4u;
+        const unsigned* t = tab + ((s1 ? ntap : 0) + tap) * BM + rrow;
         const int koff = ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? (tap % (p.KH * p.KW)) : tap) * Kc + cstep;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int i = 0; i < TM; ++i) {
+            const unsigned off = t[16 * i] + coff;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i][g] = base[i] ? *reinterpret_cast<const f32x4*>(base[i] + g * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-            bf[g] = brow ? *reinterpret_cast<const f32x4*>(brow + koff + g * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < G; ++g)
+                af[i][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + g * 64, 0, 0));
         }
+#pragma unroll
+        for (int g = 0; g < G; ++g) bf[g] = *reinterpret_cast<const f32x4*>(brow + koff + g * 16);
     };
 
     f32x4 acc[TM];
@@ -1080,8 +1049,18 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         if (kc >= 96) {                        // deep K per tap (GUDA 240 channels): LDS-staged flavour
             if (bk32) hipLaunchKernelGGL((conv_igemm16_lds_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
             else      hipLaunchKernelGGL((conv_igemm16_lds_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
-        } else if (bk32) hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
-        else      hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
+        } else {
+            const int ntap = (MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW;
+            const size_t lds = (size_t)((MODE == MODE_FWD && p.C1 > 0) ? 2 : 1) * ntap * 256 * sizeof(unsigned);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)conv_igemm16_kernel<MODE, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                (void)hipFuncSetAttribute((const void*)conv_igemm16_kernel<MODE, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                attr_set = true;
+            }
+            if (bk32) hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
+            else      hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
+        }
         return;
     }
     static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;          // tuning experiments only

@@ -516,35 +516,53 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w25c,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                       int B, int H, int W, int C, int flip, float* __restrict__ y) {
-    const int G = C / 4;
-    const long long total = (long long)B * H * W * G;
+    // one thread per (column, 4-channel group) and strip of RS output rows: the RS + 4 input rows of a strip are loaded
+    // once per tap column and feed all RS outputs (13 loads per tap column for 4 outputs instead of 40)
+    constexpr int RS = 4;
+    const int G = C / 4, strips = (H + RS - 1) / RS;
+    const long long total = (long long)B * strips * W * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int g = (int)(i % G);
-        long long pix = i / G;
-        const int ox = (int)(pix % W); pix /= W;
-        const int oy = (int)(pix % H);
-        const int b = (int)(pix / H);
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        long long r = i / G;
+        const int ox = (int)(r % W); r /= W;
+        const int oy0 = (int)(r % strips) * RS;
+        const int b = (int)(r / strips);
+        f32x4 a[RS];
 #pragma unroll
-        for (int ky = 0; ky < 5; ++ky) {
-            const int iy = oy - 2 + ky;
-            if (iy < 0 || iy >= H) continue;
+        for (int o = 0; o < RS; ++o) a[o] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const int ix = ox - 2 + kx;
-                if (ix < 0 || ix >= W) continue;
-                const int tap = flip ? (4 - ky) * 5 + (4 - kx) : ky * 5 + kx;
-                a += *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + g * 4) *
-                     *reinterpret_cast<const f32x4*>(w25c + (size_t)tap * C + g * 4);
+        for (int kx = 0; kx < 5; ++kx) {
+            const int ix = ox - 2 + kx;
+            if (ix < 0 || ix >= W) continue;
+            f32x4 wk[5];
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky)
+                wk[ky] = *reinterpret_cast<const f32x4*>(w25c + (size_t)(flip ? (4 - ky) * 5 + (4 - kx) : ky * 5 + kx) * C + g * 4);
+#pragma unroll
+            for (int ry = 0; ry < RS + 4; ++ry) {
+                const int iy = oy0 - 2 + ry;
+                if (iy < 0 || iy >= H) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + g * 4);
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int o = ry - ky;                      // output row (oy0 + o) reads input row ry through tap ky
+                    if (o >= 0 && o < RS) a[o] += v * wk[ky];
+                }
             }
         }
-        if (scale) a = a * *reinterpret_cast<const f32x4*>(scale + g * 4);
-        if (shift) a += *reinterpret_cast<const f32x4*>(shift + g * 4);
-        if (act == 1) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (scale) sc = *reinterpret_cast<const f32x4*>(scale + g * 4);
+        if (shift) sh = *reinterpret_cast<const f32x4*>(shift + g * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+        for (int o = 0; o < RS; ++o) {
+            if (oy0 + o >= H) continue;
+            f32x4 v = a[o] * sc + sh;
+            if (act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(y + (((size_t)b * H + oy0 + o) * W + ox) * C + g * 4) = v;
         }
-        *reinterpret_cast<f32x4*>(y + (((size_t)b * H + oy) * W + ox) * C + g * 4) = a;
     }
 }
 
@@ -1026,7 +1044,7 @@ extern "C" int codeps_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, i
 extern "C" int codeps_dwconv5x5(const float* x, const float* w25c, const float* scale, const float* shift, int act, int batch, int h,
                                 int w, int c, int flip, float* y, codeps_stream_t stream) {
     CODEPS_REQUIRE(x && w25c && y && batch > 0 && h > 0 && w > 0 && (c % 4) == 0, CODEPS_ERR_ARG, "dwconv5x5: bad arguments");
-    hipLaunchKernelGGL(dwconv5_kernel, dim3(grid_for((long long)batch * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, w25c, scale,
+    hipLaunchKernelGGL(dwconv5_kernel, dim3(grid_for((long long)batch * ((h + 3) / 4) * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, w25c, scale,
                        shift, act, batch, h, w, c, flip, y);
     CODEPS_CHECK_LAUNCH("dwconv5_kernel");
     return CODEPS_OK;
