@@ -95,7 +95,19 @@ def cpu_baseline(net, full_h, full_w, budget_items=2):
                       f"image at {h}x{w}, {dt:.1f} s wall, {cores} torch CPU threads"}
 
 
-def conv_roofline(runner, data, steps=2):
+def pmc_traffic(default_workload):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE passes of this same
+    command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  Counters cannot be read from inside
+    the process, so the value is the one measured when profiles/ was last refreshed -- None for other workloads."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not default_workload or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    return round(d["conv"]["hbm_mb_per_launch"] * 1e6), "profiles/r01_pmc_traffic.json (avg HBM bytes per conv launch)"
+
+
+def conv_roofline(runner, data, steps=2, default_workload=False):
     """Live measurement of the dominant kernel family (f32-MFMA implicit-GEMM conv: fwd + dgrad + wgrad) with HIP
     events on the launch stream: algorithmic FLOPs of every launch / its event-timed duration."""
     from codeps_amd import functional as F
@@ -118,8 +130,9 @@ def conv_roofline(runner, data, steps=2):
     detail = {k: {"launches_per_step": v[2] // steps, "tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3)}
               for k, v in by.items()}
     ach = flops / secs / 1e12
+    traffic, traffic_src = pmc_traffic(default_workload)
     return {"bound": "mfma", "kernel": "conv_igemm_kernel + conv_wgrad_kernel (f32 MFMA 32x32x2)", "achieved": round(ach, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": n // steps, "avg_launch_us": round(secs / n * 1e6, 2),
             "conv_ms_per_step": round(secs / steps * 1e3, 3), "algorithmic_gflop_per_step": round(flops / steps / 1e9, 1),
             "by_kind": detail}
@@ -214,7 +227,9 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = conv_roofline(runner, data)
+        default_wl = (args.mode == "adapt" and (args.encoder in (None, 101)) and (args.height, args.width) == (512, 1024)
+                      and args.per_gpu_batch in (None, 8))
+        roof = conv_roofline(runner, data, default_workload=default_wl)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "adapt":
         cpu = cpu_baseline(net, args.height, args.width)

@@ -598,11 +598,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave % (WM * WN), kw = wave / (WM * WN);      // tile position, K-split lane of this wave
     const int wm = wt / WN, wn = wt % WN;
-    int bid = blockIdx.x;
-    const int split = bid % p.splits; bid /= p.splits;
-    const int nt = bid % p.n_nt; bid /= p.n_nt;
-    const int mt = bid % p.n_mt;
-    const int tap = bid / p.n_mt;
+    // block -> (tile group g = (split, nt, mt), tap): the KH*KW tap blocks of one group read the same dZ rows and the same
+    // (shifted) X rows, so they are given consecutive-by-8 block ids = the same XCD, close in dispatch order: the
+    // operands come from HBM once and from that XCD's L2 for the other taps (measured before: 9x the HBM reads)
+    const int ntap = p.KH * p.KW, Gt = p.splits * p.n_nt * p.n_mt, G8 = (Gt / 8) * 8;
+    int g, tap;
+    if ((int)blockIdx.x < G8 * ntap) {
+        const int chunk = blockIdx.x / (8 * ntap), r = blockIdx.x % (8 * ntap);
+        tap = r / 8; g = chunk * 8 + (r % 8);
+    } else {
+        const int r = blockIdx.x - G8 * ntap, rest = Gt - G8;
+        tap = r / rest; g = G8 + r % rest;
+    }
+    const int split = g % p.splits;
+    const int nt = (g / p.splits) % p.n_nt;
+    const int mt = g / (p.splits * p.n_nt);
     const int ky = tap / p.KW, kx = tap % p.KW;
     const int m0 = mt * BM, n0 = nt * BN;
     const int pbeg = split * p.pix_per_split, pend = min(pbeg + p.pix_per_split, p.P);
@@ -702,7 +712,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
         __syncthreads();
         for (int step = 0; step < nsteps; ++step) {
             const int buf = step & 1;
-            if (step + 1 < nsteps) load_step(step + 1);
+            if (step + 1 < nsteps && CODEPS_ABLATE < 1) load_step(step + 1);
             const float* Ab = As + buf * BKP * LDM + wm * TM * 32 + lrow;
             const float* Bb = Bs + buf * BKP * LDN + wn * TN * 32 + lrow;
 #pragma unroll
@@ -712,10 +722,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
                 for (int e = 0; e < 4; ++e) {
                     const int kr = g * 8 + lhalf * 4 + e;
                     float af[TM], bf[TN];
+#if CODEPS_ABLATE >= 3
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = (float)(kr + i + step);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = (float)(kr - j);
+#else
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[i] = Ab[kr * LDM + i * 32];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bf[j] = Bb[kr * LDN + j * 32];
+#endif
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -723,6 +740,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
                 }
             }
+#if CODEPS_ABLATE >= 2
+            continue;
+#endif
             if (step + 1 < nsteps) store_step(buf ^ 1);
             __syncthreads();
         }
