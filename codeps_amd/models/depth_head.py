@@ -63,7 +63,9 @@ class DepthHead(nn.Module):
         conv = self.dispconvs["0"][1]
         logits = F.conv2d(x, conv.weight, conv.bias, pad=1, pad_mode="reflect")
         depth_map, disp_map = F.disp_depth(logits)          # sigmoid + disp_to_depth, one kernel
-        self.outputs = {0: disp_map}
+        # detached: a module attribute that holds the autograd graph of the last call keeps its AccumulateGrad nodes (and
+        # their streams) alive across iterations, which breaks HIP-graph capture of the next step
+        self.outputs = {0: disp_map.detach()}
         if return_disparity:
             return depth_map, disp_map
         return depth_map
