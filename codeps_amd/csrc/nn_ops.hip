@@ -568,28 +568,53 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
 
 // depthwise weight gradient partials: part[blk][25][C]
 __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, int B, int H,
-                                                            int W, int C, float* __restrict__ part, int rows_per_blk) {
+                                                            int W, int C, float* __restrict__ part, int items_per_blk) {
+    // dW[tap][c] = sum_pixels dz[p][c] * x[p + delta_tap][c].  One pass over the data: a thread owns a 4-channel group and
+    // walks items = (image, strip of RS output rows, column); per item the RS dz values and, per tap column, the RS + 4
+    // x values are loaded once and feed all 25 tap accumulators held in registers.  Block partials part[blk][25][C].
+    constexpr int RS = 4;
     const int Gall = C / 4, G = Gall < 256 ? Gall : 256;          // blockIdx.y tiles the channel groups
     const int tl = threadIdx.x % G, tr = threadIdx.x / G, TR = 256 / G;
     const int tg = blockIdx.y * G + tl;
     const bool cok = tg < Gall && tr < TR;
-    const long long M = (long long)B * H * W;
-    const long long r0 = (long long)blockIdx.x * rows_per_blk;
-    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    const int strips = (H + RS - 1) / RS;
+    const long long items = (long long)B * strips * W;
+    const long long i0 = (long long)blockIdx.x * items_per_blk;
+    const long long i1 = i0 + items_per_blk < items ? i0 + items_per_blk : items;
+    f32x4 acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cok)
+        for (long long it = i0 + tr; it < i1; it += TR) {
+            const int ox = (int)(it % W);
+            const int oy0 = (int)((it / W) % strips) * RS;
+            const int b = (int)(it / ((long long)W * strips));
+            f32x4 g[RS];
+#pragma unroll
+            for (int o = 0; o < RS; ++o)
+                g[o] = (oy0 + o < H) ? *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + oy0 + o) * W + ox) * C + tg * 4)
+                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int ix = ox - 2 + kx;
+                if (ix < 0 || ix >= W) continue;
+#pragma unroll
+                for (int ry = 0; ry < RS + 4; ++ry) {
+                    const int iy = oy0 - 2 + ry;
+                    if (iy < 0 || iy >= H) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + tg * 4);
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky) {
+                        const int o = ry - ky;                  // output row oy0 + o reads input row ry through tap ky
+                        if (o >= 0 && o < RS) acc[ky * 5 + kx] += g[o] * v;
+                    }
+                }
+            }
+        }
     __shared__ f32x4 red[256];
     for (int tap = 0; tap < 25; ++tap) {
-        const int ky = tap / 5, kx = tap % 5;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (cok)
-            for (long long r = r0 + tr; r < r1; r += TR) {
-                const int ox = (int)(r % W), oy = (int)((r / W) % H), b = (int)(r / ((long long)W * H));
-                const int iy = oy - 2 + ky, ix = ox - 2 + kx;
-                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-                a += *reinterpret_cast<const f32x4*>(dz + (size_t)r * C + tg * 4) *
-                     *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + tg * 4);
-            }
         __syncthreads();
-        red[threadIdx.x] = a;
+        red[threadIdx.x] = acc[tap];
         __syncthreads();
         if (threadIdx.x < G && blockIdx.y * G + threadIdx.x < Gall) {
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -1056,10 +1081,12 @@ extern "C" int codeps_dwconv5x5_wgrad(const float* x, const float* dz, int batch
     int rc = check_colsum_c(c, "dwconv5x5_wgrad");
     if (rc) return rc;
     int nblk;
-    const int rpb = rows_per_block((long long)batch * h * w, nblk);
+    (void)rows_per_block((long long)batch * h * w, nblk);        // block count (= workspace slabs) as codeps_colsum_workspace_bytes sizes it
     CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * 25 * c * 4, CODEPS_ERR_WORKSPACE, "dwconv5x5_wgrad: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, dz, batch, h, w, c, (float*)workspace, rpb);
+    const long long items = (long long)batch * ((h + 3) / 4) * w;  // (image, 4-row strip, column)
+    const int ipb = (int)((items + nblk - 1) / nblk);
+    hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, dz, batch, h, w, c, (float*)workspace, ipb);
     CODEPS_CHECK_LAUNCH("dwconv5_wgrad_kernel");
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(25 * c, 16)), dim3(256), 0, st, (const float*)workspace, nblk, 25, c, dw25c, c, 0);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
