@@ -84,7 +84,8 @@ SIGNATURES = {
     "codeps_bilinear_fwd": (c_int, [P, I, I, I, I, I, I, I, P, I, I, P]),
     "codeps_bilinear_bwd": (c_int, [P, I, I, I, I, I, I, I, I, I, P, P]),
     "codeps_guda_gather_fwd": (c_int, [P, I, I, I, I, P, P, P, P, P]),
-    "codeps_guda_gather_bwd": (c_int, [P, I, I, I, I, I, P, P]),
+    "codeps_guda_gather_bwd_workspace_bytes": (c_size_t, [I, I, I]),
+    "codeps_guda_gather_bwd": (c_int, [P, I, I, I, I, I, P, P, c_size_t, P]),
     "codeps_softmax_fwd": (c_int, [P, LL, I, I, P, P]),
     "codeps_softmax_bwd": (c_int, [P, P, LL, I, I, P, P]),
     "codeps_disp_depth_fwd": (c_int, [P, LL, I, c_float, c_float, P, P, P]),

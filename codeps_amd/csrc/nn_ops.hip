@@ -746,12 +746,45 @@ __global__ __launch_bounds__(256) void guda_gather_fwd_kernel(GudaP p, const flo
     }
 }
 
-// d y_branch[b][qy][qx][tap][c] = sum over full-res r with footprint on (qy,qx): w(r -> q) * dout[r - delta_tap][c]
-// one thread per (low-res pixel, tap, 4-channel group); deterministic gather.
-__global__ __launch_bounds__(256) void guda_gather_bwd_kernel(int B, int H, int W, int h, int w, float rh, float rw,
-                                                              const float* __restrict__ dout, float* __restrict__ dy) {
+// d y_branch[b][qy][qx][tap][c] = sum_oy wy(oy; qy) sum_ox wx(ox; qx) dout[b][oy - dky][ox - dkx][c]   (dk = tap offset -1..1,
+// w = bilinear weight of low-res row / column q for full-res row / column o).  The weights are separable, so the transpose
+// runs as two 1-D passes (4x fewer loads than the 2-D footprint sum at x8):
+//   pass 1: tmp[b][py][qx][kx][c] = sum_ox wx(ox; qx) dout[b][py][ox - dkx][c]        (full-res rows, low-res columns)
+//   pass 2: dy[b][qy][qx][ky*3+kx][c] = sum_oy wy(oy; qy) tmp[b][oy - dky][qx][kx][c]
+// The interpolation weight of low-res index q for full-res index o is max(0, 1 - |clamp(r (o + 0.5) - 0.5, 0, n - 1) - q|)
+// (same as bil_src's l0 / l1).  Deterministic gathers.
+__device__ __forceinline__ void guda_range(int q, float inv_r, int n_full, int& lo, int& hi) {
+    lo = max(0, (int)ceilf(((float)q - 0.5f) * inv_r - 0.5f) - 1);
+    hi = min(n_full - 1, (int)floorf(((float)q + 1.5f) * inv_r - 0.5f) + 1);
+}
+__device__ __forceinline__ float guda_weight(int o, int q, float r, int n_low) {
+    const float s = fminf(fmaxf(r * ((float)o + 0.5f) - 0.5f, 0.f), (float)(n_low - 1));
+    return fmaxf(0.f, 1.f - fabsf(s - (float)q));
+}
+
+__global__ __launch_bounds__(256) void guda_gather_bwd_x_kernel(int B, int H, int W, int w, float rw, const float* __restrict__ dout,
+                                                                float* __restrict__ tmp) {
+    const long long total = (long long)B * H * w * 12;
+    const float inv_rw = 1.f / rw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i & 3);
+        long long r = i >> 2;
+        const int kx = (int)(r % 3); r /= 3;
+        const int qx = (int)(r % w); r /= w;                     // r = b * H + py
+        int lo, hi;
+        guda_range(qx, inv_rw, W, lo, hi);
+        const float* row = dout + (((size_t)r * W) << 4) + g * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int ox = max(lo, kx - 1); ox <= min(hi, W - 2 + kx); ++ox)          // px = ox - (kx - 1) in [0, W)
+            a += guda_weight(ox, qx, rw, w) * *reinterpret_cast<const f32x4*>(row + ((size_t)(ox - kx + 1) << 4));
+        *reinterpret_cast<f32x4*>(tmp + (i << 2)) = a;           // tmp[b][py][qx][kx][16] in the enumeration order
+    }
+}
+
+__global__ __launch_bounds__(256) void guda_gather_bwd_y_kernel(int B, int H, int h, int w, float rh, const float* __restrict__ tmp,
+                                                                float* __restrict__ dy) {
     const long long total = (long long)B * h * w * 36;
-    const float inv_rh = 1.f / rh, inv_rw = 1.f / rw;
+    const float inv_rh = 1.f / rh;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int g = (int)(i & 3);
         long long r = i >> 2;
@@ -759,24 +792,13 @@ __global__ __launch_bounds__(256) void guda_gather_bwd_kernel(int B, int H, int 
         const int qx = (int)(r % w); r /= w;
         const int qy = (int)(r % h);
         const int b = (int)(r / h);
-        const int ky = tap / 3 - 1, kx = tap % 3 - 1;             // delta of this tap
-        // full-res rows o whose (clamped) source coordinate r(o) = rh (o + 0.5) - 0.5 lies in (qy - 1, qy + 1); the
-        // interpolation weight of low-res row qy is max(0, 1 - |clamp(r, 0, h - 1) - qy|)  (same as bil_src's l0 / l1)
-        const int oy_lo = max(0, (int)ceilf(((float)qy - 0.5f) * inv_rh - 0.5f) - 1), oy_hi = min(H - 1, (int)floorf(((float)qy + 1.5f) * inv_rh - 0.5f) + 1);
-        const int ox_lo = max(0, (int)ceilf(((float)qx - 0.5f) * inv_rw - 0.5f) - 1), ox_hi = min(W - 1, (int)floorf(((float)qx + 1.5f) * inv_rw - 0.5f) + 1);
+        const int ky = tap / 3, kx = tap % 3;
+        int lo, hi;
+        guda_range(qy, inv_rh, H, lo, hi);
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int oy = max(oy_lo, ky); oy <= min(oy_hi, H - 1 + ky); ++oy) {       // py = oy - ky must be a valid output row
-            const float ry = fminf(fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f), (float)(h - 1));
-            const float wy = fmaxf(0.f, 1.f - fabsf(ry - (float)qy));
-            const float* drow = dout + ((((size_t)b * H + (oy - ky)) * W) << 4) + g * 4;
-            f32x4 arow = {0.f, 0.f, 0.f, 0.f};
-            for (int ox = max(ox_lo, kx); ox <= min(ox_hi, W - 1 + kx); ++ox) {
-                const float rx = fminf(fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f), (float)(w - 1));
-                const float wx = fmaxf(0.f, 1.f - fabsf(rx - (float)qx));
-                arow += wx * *reinterpret_cast<const f32x4*>(drow + ((size_t)(ox - kx) << 4));
-            }
-            a += wy * arow;
-        }
+        for (int oy = max(lo, ky - 1); oy <= min(hi, H - 2 + ky); ++oy)
+            a += guda_weight(oy, qy, rh, h) *
+                 *reinterpret_cast<const f32x4*>(tmp + (((((size_t)b * H + (oy - ky + 1)) * w + qx) * 3 + kx) << 4) + g * 4);
         *reinterpret_cast<f32x4*>(dy + ((((size_t)b * h + qy) * w + qx) * 9 + tap) * 16 + g * 4) = a;
     }
 }
@@ -1146,11 +1168,19 @@ extern "C" int codeps_guda_gather_fwd(const float* base, int batch, int h, int w
     return CODEPS_OK;
 }
 
-extern "C" int codeps_guda_gather_bwd(const float* grad_out, int batch, int h, int w, int bh, int bw, float* grad_y, codeps_stream_t stream) {
+extern "C" size_t codeps_guda_gather_bwd_workspace_bytes(int batch, int h, int bw) { return (size_t)batch * h * bw * 3 * 16 * sizeof(float); }
+
+extern "C" int codeps_guda_gather_bwd(const float* grad_out, int batch, int h, int w, int bh, int bw, float* grad_y, void* workspace,
+                                      size_t workspace_bytes, codeps_stream_t stream) {
     CODEPS_REQUIRE(grad_out && grad_y && batch > 0 && bh > 0 && bw > 0 && bh < h && bw < w, CODEPS_ERR_ARG, "guda_gather_bwd: bad arguments");
-    hipLaunchKernelGGL(guda_gather_bwd_kernel, dim3(grid_for((long long)batch * bh * bw * 36)), dim3(256), 0, (hipStream_t)stream, batch, h, w, bh, bw,
-                       (float)bh / (float)h, (float)bw / (float)w, grad_out, grad_y);
-    CODEPS_CHECK_LAUNCH("guda_gather_bwd_kernel");
+    CODEPS_REQUIRE(workspace && workspace_bytes >= codeps_guda_gather_bwd_workspace_bytes(batch, h, bw), CODEPS_ERR_WORKSPACE,
+                   "guda_gather_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(guda_gather_bwd_x_kernel, dim3(grid_for((long long)batch * h * bw * 12)), dim3(256), 0, st, batch, h, w, bw,
+                       (float)bw / (float)w, grad_out, (float*)workspace);
+    hipLaunchKernelGGL(guda_gather_bwd_y_kernel, dim3(grid_for((long long)batch * bh * bw * 36)), dim3(256), 0, st, batch, h, bh, bw,
+                       (float)bh / (float)h, (const float*)workspace, grad_y);
+    CODEPS_CHECK_LAUNCH("guda_gather_bwd kernels");
     return CODEPS_OK;
 }
 

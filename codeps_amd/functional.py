@@ -705,7 +705,9 @@ class _GudaGather(torch.autograd.Function):
                 grads.append(None)
                 continue
             dy = torch.empty(b, bh, bw, 144, dtype=torch.float32, device=dout.device)
-            check(lib().codeps_guda_gather_bwd(ptr(dout), b, h, w, bh, bw, ptr(dy), stream_ptr()), "codeps_guda_gather_bwd")
+            ws = _workspace(lib().codeps_guda_gather_bwd_workspace_bytes(b, h, bw), dout.device, "guda")
+            check(lib().codeps_guda_gather_bwd(ptr(dout), b, h, w, bh, bw, ptr(dy), ptr(ws), ws.numel(), stream_ptr()),
+                  "codeps_guda_gather_bwd")
             grads.append(dy)
         return (dout if ctx.needs_input_grad[0] else None, *grads)
 

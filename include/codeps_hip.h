@@ -181,11 +181,13 @@ int codeps_bilinear_bwd(const float* dy, int batch, int h, int w, int c, int out
  * resolution on the conv engine, this op interpolates the 9 x 16 tap planes at full resolution:
  *   out[B,h,w,16] = base[B,h,w,16] + sum_k sum_tap up(y_k[..., tap*16:(tap+1)*16])(p + delta_tap)   (zero outside the image)
  *   y = host array of n_branches (<= 3) device pointers, y_k = [B, bh[k], bw[k], 144] NHWC, align_corners=False.
- * _bwd: grad_y_k = transpose of the above for ONE branch (grad_out [B,h,w,16] -> grad_y [B,bh,bw,144]). */
+ * _bwd: grad_y_k = transpose of the above for ONE branch (grad_out [B,h,w,16] -> grad_y [B,bh,bw,144]), as two
+ * separable 1-D passes through a [B,h,bw,3,16] workspace. */
 int codeps_guda_gather_fwd(const float* base, int batch, int h, int w, int n_branches, const float* const* y,
                            const int* bh, const int* bw, float* out, codeps_stream_t stream);
+size_t codeps_guda_gather_bwd_workspace_bytes(int batch, int h, int bw);
 int codeps_guda_gather_bwd(const float* grad_out, int batch, int h, int w, int bh, int bw, float* grad_y,
-                           codeps_stream_t stream);
+                           void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 /* nn.Softmax(dim=1) over the first c of c_pad channels (padding written as 0) and its backward. */
 int codeps_softmax_fwd(const float* x, long long rows, int c, int c_pad, float* y, codeps_stream_t stream);
 int codeps_softmax_bwd(const float* dy, const float* y, long long rows, int c, int c_pad, float* dx,
