@@ -12,7 +12,8 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 import torch  # noqa: F401  (must precede loading the .so, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcodeps_hip.so")
+# CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
+LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 ABI_VERSION = 2
 

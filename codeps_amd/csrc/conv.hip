@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ residual, float* __restrict__ out) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-    constexpr int LDK = BK + 4;                       // padded LDS row (floats)
+    constexpr int LDK = BK + 4;                       // padded LDS row (floats): conflict-free b128 fragment reads (an XOR-swizzled
+                                                      // unpadded layout was measured 1 % slower on the whole step)
     constexpr int CPR = BK / 4;                       // 16-B chunks per row
     constexpr int RPP = 256 / CPR;                    // rows covered per pass of the 256 threads
     constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
@@ -192,12 +193,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     const int chunk = tid % CPR, rbase = tid / CPR;
     constexpr bool AGUARD = (BM % RPP) != 0, BGUARD = (BN % RPP) != 0;
     // B rows (weights): row n = n0 + rbase + RPP*i, K-contiguous; rows past N are clamped (their columns are never stored)
-    const float* brow[BPASS];
+    const size_t wrow = (MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct : (size_t)p.KH * p.KW * p.Co;     // floats per packed weight row
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(wq, (size_t)p.N * wrow * 4);
+    unsigned boff[BPASS];
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-        const int n = min(n0 + rbase + RPP * i, p.N - 1);
-        brow[i] = wq + (size_t)n * ((MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct : (size_t)p.KH * p.KW * p.Co) + chunk * 4;
-    }
+    for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)(((size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow + chunk * 4) * 4);
 
     f32x4 areg[APASS], breg[BPASS];
 
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         else if (MODE == MODE_DGRAD && p.up0 && p.src == 0) koff = ((tap % (p.KH * p.KW)) * Kc) + cstep;
         else koff = tap * Kc + cstep;
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + koff);
+        for (int i = 0; i < BPASS; ++i)
+            breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + (unsigned)koff * 4u, 0, 0));
     };
     auto store_step = [&](int buf) {
         float* Ab = As + buf * BM * LDK;
@@ -250,28 +251,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     for (int step = 0; step < nsteps; ++step) {
         const int buf = NBUF == 2 ? (step & 1) : 0;
         if (step + 1 < nsteps && CODEPS_ABLATE < 1) load_step(step + 1);           // global loads in flight during the MFMAs
-        const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK + lhalf * 4;
-        const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK + lhalf * 4;
-        // fragments of k-group g+1 are read while the 16 MFMAs of group g run (explicit register double buffer)
-        f32x4 af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
-#if CODEPS_ABLATE >= 3
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[1][i] = af[0][i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[1][j] = bf[0][j];
-#endif
+        const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK;
+        const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK;
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            if (g + 1 < BK / 8 && CODEPS_ABLATE < 3) {
+            f32x4 af[TM], bf[TN];
+            const int fo = (2 * g + lhalf) * 4;               // lanes < 32 / >= 32 take k and k + 4 of each 8-deep group
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (g + 1) * 8);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + fo);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (g + 1) * 8);
-            }
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + fo);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -279,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
 #if CODEPS_ABLATE >= 2
