@@ -486,6 +486,9 @@ class _BatchNormTrain(torch.autograd.Function):
         ctx.inv_count = [1.0 / n for n in counts]
         ctx.save_for_backward(x, y if act else None, g, mean, invstd)
         ctx.act, ctx.c, ctx.reduce_fn, ctx.has_res, ctx.groups, ctx.per_item = act, c, reduce_fn, residual is not None, groups, per_item
+        # flat-gradient sinks of the affine parameters (codeps_amd.step): the backward accumulates dgamma / dbeta in place
+        gs, bs = _grad_sink.get(id(gamma)), _grad_sink.get(id(beta))
+        ctx.sinks = (gs, bs) if (gs is not None and bs is not None and gamma.requires_grad and beta.requires_grad) else None
         return y
 
     @staticmethod
@@ -497,23 +500,28 @@ class _BatchNormTrain(torch.autograd.Function):
         inv_count = (ctypes.c_float * ng)(*ctx.inv_count)
         dev = x.device
         sums = torch.empty(ng, 2, cp, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(ctx.c, dtype=torch.float32, device=dev)
-        dbeta = torch.empty_like(dgamma)
+        if ctx.sinks is not None:
+            dgamma, dbeta, acc = ctx.sinks[0], ctx.sinks[1], 1
+        else:
+            dgamma = torch.empty(ctx.c, dtype=torch.float32, device=dev)
+            dbeta, acc = torch.empty_like(dgamma), 0
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
         if ctx.reduce_fn is None:
             check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), inv_count,
-                                         ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(dres), 0, 0, ptr(ws), ws.numel(),
+                                         ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), acc, ptr(dx), ptr(dres), 0, 0, ptr(ws), ws.numel(),
                                          stream_ptr()), "codeps_bn_bwd_mg")
         else:
             check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), None, None, ctx.act,
-                                         ptr(sums), ptr(dgamma), ptr(dbeta), 0, None, None, 1, 0, ptr(ws), ws.numel(), stream_ptr()),
+                                         ptr(sums), ptr(dgamma), ptr(dbeta), acc, None, None, 1, 0, ptr(ws), ws.numel(), stream_ptr()),
                   "codeps_bn_bwd_mg")
             sums = ctx.reduce_fn.sum(sums)
             check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), inv_count,
                                          ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(dres), 0, 1, ptr(ws), ws.numel(),
                                          stream_ptr()), "codeps_bn_bwd_mg")
+        if ctx.sinks is not None:
+            dgamma = dbeta = None           # already accumulated into the flat gradient buffer
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
@@ -735,6 +743,25 @@ def guda_fusion(coarse, fine, weight, bias):
 
 
 # ---------------------------------------------------------------------------------------- depthwise 5x5
+_dw_cache = {}
+
+
+def _dw_pack(weight, c):
+    """Depthwise weight [C,1,5,5] -> [25][Cp] tap-major pack; cached for frozen weights (identity + version checked)."""
+    frozen = not weight.requires_grad
+    key = (id(weight), c)
+    if frozen:
+        hit = _dw_cache.get(key)
+        if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
+            return hit[2]
+    creal = weight.shape[0]
+    w25 = torch.zeros(25, c, dtype=torch.float32, device=weight.device)
+    w25[:, :creal] = weight.detach().reshape(creal, 25).t()
+    if frozen:
+        _dw_cache[key] = (weakref.ref(weight), (weight.data_ptr(), weight._version), w25)
+    return w25
+
+
 class _DwConv5(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, scale, shift, act):
@@ -742,8 +769,7 @@ class _DwConv5(torch.autograd.Function):
         x = x.contiguous()
         b, h, w, c = x.shape
         creal = weight.shape[0]
-        w25 = torch.zeros(25, c, dtype=torch.float32, device=x.device)
-        w25[:, :creal] = weight.detach().reshape(creal, 25).t()
+        w25 = _dw_pack(weight, c)
         sc, sh = _pad_vec(scale, c), _pad_vec(shift, c)
         y = torch.empty_like(x)
         check(lib().codeps_dwconv5x5(ptr(x), ptr(w25), ptr(sc), ptr(sh), act, b, h, w, c, 0, ptr(y), stream_ptr()),

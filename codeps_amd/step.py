@@ -55,7 +55,8 @@ class FlatState:
             p.data = self.flat[off:off + k].view_as(p)
             g = self.grad[off:off + k].view_as(p)
             p.grad = g
-            if p.dim() == 4 and p.shape[1] != 1 or (p.dim() == 1 and getattr(p, "_codeps_conv_bias", False)):
+            if p.dim() == 4 and p.shape[1] != 1 or (p.dim() == 1 and (getattr(p, "_codeps_conv_bias", False) or
+                                                                     getattr(p, "_codeps_bn_affine", False))):
                 F._grad_sink[id(p)] = g
             off += k
         self.ema = self.flat.clone() if with_ema else None
@@ -63,9 +64,13 @@ class FlatState:
 
 
 def _mark_conv_biases(net):
+    """Tag the 1-D parameters whose backward kernels can accumulate straight into the flat gradient buffer."""
     for m in net.modules():
         if isinstance(m, torch.nn.Conv2d) and m.bias is not None:
             m.bias._codeps_conv_bias = True
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.affine:
+            m.weight._codeps_bn_affine = True
+            m.bias._codeps_bn_affine = True
 
 
 class StepRunner:
