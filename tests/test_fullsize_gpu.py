@@ -1,0 +1,99 @@
+"""Full-size (BASELINE.json configs[2]: 512x1024 inputs) checks of the conv engine through size-independent properties
+and independent code paths; the oracle only finishes in seconds at small sizes (tests/test_ops_gpu.py), so here:
+  * linearity of the convolution,
+  * agreement with the vendor library's fp32 convolution on the GPU (MIOpen behind torch.nn.functional.conv2d --
+    a second implementation, used as a checker only),
+  * agreement of the re-laid-out fast paths (double-pixel stem, GUDA fusion without the concat) with the plain
+    formulation run through the generic kernels."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _F():
+    from codeps_amd import functional as F
+    return F
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def to_nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw(y, c):
+    return y[..., :c].permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("b,h,w,ci,co,k,s", [(8, 128, 256, 64, 64, 3, 1), (8, 32, 64, 256, 1024, 1, 1), (12, 128, 256, 64, 128, 3, 2),
+                                             (6, 256, 512, 32, 32, 3, 1)])
+def test_conv_matches_vendor_library_and_is_linear(b, h, w, ci, co, k, s):
+    F = _F()
+    g = torch.Generator(device=DEV).manual_seed(b * 131 + ci)
+    x1 = torch.randn(b, ci, h, w, device=DEV, generator=g)
+    x2 = torch.randn(b, ci, h, w, device=DEV, generator=g)
+    wt = torch.randn(co, ci, k, k, device=DEV, generator=g) * (1.0 / (ci * k * k) ** 0.5)
+    gy = torch.randn(b, co, (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1, device=DEV, generator=g)
+    # vendor library (NCHW)
+    rx, rw = x1.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ry = TF.conv2d(rx, rw, None, s, k // 2)
+    ry.backward(gy)
+    # this library (NHWC through the C ABI)
+    dx, dw = to_nhwc(x1).requires_grad_(True), wt.clone().requires_grad_(True)
+    y = F.conv2d(dx, dw, stride=s, pad=k // 2)
+    y.backward(to_nhwc(gy))
+    assert rel(to_nchw(y, co), ry) < 2e-4
+    assert rel(to_nchw(dx.grad, ci), rx.grad) < 2e-4
+    assert rel(dw.grad, rw.grad) < 2e-4
+    # linearity (same kernel, exact property): conv(2 x1 - 3 x2) = 2 conv(x1) - 3 conv(x2)
+    with torch.no_grad():
+        ya = F.conv2d(to_nhwc(2.0 * x1 - 3.0 * x2), wt, stride=s, pad=k // 2)
+        yb = 2.0 * y - 3.0 * F.conv2d(to_nhwc(x2), wt, stride=s, pad=k // 2)
+    assert rel(ya, yb) < 1e-5
+
+
+def test_stem_double_pixel_equals_generic_path_full_size():
+    """conv1 of the pose net (6 channels, 7x7 / 2 / 3) at 512x1024: double-pixel layout vs the 16-channel padded form."""
+    F = _F()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    fa, fb = (torch.randn(4, 3, 512, 1024, device=DEV, generator=g) for _ in range(2))
+    wt = torch.randn(64, 6, 7, 7, device=DEV, generator=g) * 0.06
+    gy = torch.randn(4, 256, 512, 64, device=DEV, generator=g)
+    w1, w2 = wt.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    y1 = F.stem_conv2d(F.images_to_nhwc([fa, fb], 8, F.STEM_XPAD), w1)
+    y2 = F.conv2d(F.images_to_nhwc([fa, fb], 16), w2, stride=2, pad=3)
+    y1.backward(gy)
+    y2.backward(gy)
+    assert y1.shape == y2.shape == (4, 256, 512, 64)
+    assert rel(y1, y2) < 1e-5
+    assert rel(w1.grad, w2.grad) < 1e-5
+    ref = TF.conv2d(torch.cat([fa, fb], 1), wt, None, 2, 3)          # vendor library
+    assert rel(to_nchw(y1, 64), ref) < 2e-4
+
+
+def test_guda_fusion_equals_concat_conv_full_size():
+    F = _F()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    h, w = 512, 1024
+    feats = [torch.randn(1, h // s, w // s, c, device=DEV, generator=g) for c, s in ((128, 8), (64, 4), (32, 2), (16, 1))]
+    wt = torch.randn(14, 240, 3, 3, device=DEV, generator=g) * 0.03
+    bias = torch.randn(14, device=DEV, generator=g)
+    gy = torch.randn(1, h, w, 16, device=DEV, generator=g)
+    gy[..., 14:] = 0
+    a = [f.clone().requires_grad_(True) for f in feats]
+    b = [f.clone().requires_grad_(True) for f in feats]
+    wa, wb = wt.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ba, bb = bias.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ya = F.guda_fusion(a[:3], a[3], wa, ba)
+    yb = F.conv2d(F.bilinear_concat(b, h, w, False), wb, bb, pad=1)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert rel(ya, yb) < 1e-5
+    for p, q in zip(a, b):
+        assert rel(p.grad, q.grad) < 1e-5
+    assert rel(wa.grad, wb.grad) < 1e-5 and rel(ba.grad, bb.grad) < 1e-5
