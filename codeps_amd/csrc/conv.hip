@@ -49,7 +49,12 @@ struct ConvP {
     // stride-2 dgrad by input-parity class: rows enumerate the pixels (2y'+py, 2x'+px) only and the K loop walks just the
     // taps whose parity can reach them (3x3: 1, 2, 2 or 4 taps instead of 9 mostly-zero ones)
     int par, py, px, ky0, kx0, nky, nkx, Hc, Wc;
+    // split-K (small-M launches): gridDim.y slices of `ksteps` K-steps each write raw partial sums to part[slice][M][N]
+    int ksplit, ksteps;
+    float* part;
+    size_t part_bytes;
 };
+
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -243,14 +248,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_step(0);
+    const int s_begin = p.ksplit > 1 ? (int)blockIdx.y * p.ksteps : 0;
+    const int s_end = p.ksplit > 1 ? min(nsteps, s_begin + p.ksteps) : nsteps;
+    load_step(s_begin);
     store_step(0);
     __syncthreads();
 
     const int lrow = lane & 31, lhalf = lane >> 5;
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = NBUF == 2 ? (step & 1) : 0;
-        if (step + 1 < nsteps && CODEPS_ABLATE < 1) load_step(step + 1);           // global loads in flight during the MFMAs
+    for (int step = s_begin; step < s_end; ++step) {
+        const int buf = NBUF == 2 ? ((step - s_begin) & 1) : 0;
+        if (step + 1 < s_end && CODEPS_ABLATE < 1) load_step(step + 1);           // global loads in flight during the MFMAs
         const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK;
         const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK;
 #pragma unroll
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         continue;
 #endif
         if (NBUF == 1) __syncthreads();                       // every wave is done reading the single buffer
-        if (step + 1 < nsteps) store_step(NBUF == 2 ? (buf ^ 1) : 0);
+        if (step + 1 < s_end) store_step(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -315,6 +322,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     m = (bb * p.H + 2 * (rem / p.Wc) + p.py) * p.W + 2 * (rem % p.Wc) + p.px;
                 }
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
+                if (p.ksplit > 1) {                           // raw partial sum of this K slice; splitk_finish_kernel does the rest
+                    *reinterpret_cast<f32x4*>(p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
+                    continue;
+                }
                 if (MODE == MODE_FWD) {
                     v = v * sc + sh;
                     if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
@@ -1014,6 +1025,31 @@ static ConvP make_convp(const codeps_conv_desc* d) {
     return p;
 }
 
+// K slices a launch of `blocks` tiles with `nsteps` K-steps is cut into (1 = no split-K); shared by the cost model and the launcher
+static int splitk_slices(const ConvP& p, int blocks, int nsteps) {
+    if (!p.part || blocks >= 192 || nsteps < 16) return 1;
+    int ks = std::min(std::min(512 / blocks, nsteps / 8), 16);
+    while (ks >= 2 && (size_t)ks * p.M * p.N * sizeof(float) > p.part_bytes) --ks;
+    return std::max(ks, 1);
+}
+
+// split-K finish: out = act((sum_z part[z]) * scale + shift + residual), fixed summation order
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, long long MN, int N,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ residual, int act, float* __restrict__ out) {
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (long long)gridDim.x * 1024) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
+        for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + (size_t)z * MN + i);
+        const int n = (int)(i % N);
+        if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + n);
+        if (shift) v += *reinterpret_cast<const f32x4*>(shift + n);
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        *reinterpret_cast<f32x4*>(out + i) = v;
+    }
+}
+
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF = 2>
 static void launch_igemm(ConvP p, const float* a0, const float* a1, const float* wq, const float* scale, const float* shift,
                          const float* residual, float* out, hipStream_t st) {
@@ -1027,19 +1063,34 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3(p.n_mt * p.n_nt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
+    // split-K when the tile grid cannot fill the chip and K is deep (B = 1 target inference, 1/32-resolution decoder inputs)
+    const int blocks = p.n_mt * p.n_nt, Kc = (MODE == MODE_FWD) ? p.Ct : p.Co, nsteps = ntap * (Kc / BK);
+    p.ksplit = 1; p.ksteps = nsteps;
+    const int ks = splitk_slices(p, blocks, nsteps);
+    if (ks >= 2) {
+        p.ksteps = cdiv(nsteps, ks);
+        p.ksplit = cdiv(nsteps, p.ksteps);
+    }
+    hipLaunchKernelGGL(k, dim3(blocks, p.ksplit), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
+    if (p.ksplit > 1) {
+        const long long MN = (long long)p.M * p.N;
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
+                           p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, MODE == MODE_FWD ? residual : nullptr,
+                           MODE == MODE_FWD ? p.act : 0, out);
+    }
 }
 
 // Tile choice: estimated time ~ waves of blocks over the 256 CUs x tile area x a small-tile inefficiency factor.
 // Big tiles win when the grid is large; per-key / deep-layer GEMMs with few rows need smaller tiles to fill the chip.
 struct TileOpt { int bm, bn; float penalty; };
 
-static int pick_tile(const ConvP& p, const TileOpt* opts, int n) {
+static int pick_tile(const ConvP& p, const TileOpt* opts, int n, int nsteps) {
     int best = 0;
     double best_t = 1e300;
     for (int i = 0; i < n; ++i) {
         const long long blocks = (long long)cdiv(p.M, opts[i].bm) * cdiv(p.N, opts[i].bn);
-        const double t = (double)((blocks + 255) / 256) * opts[i].bm * opts[i].bn * opts[i].penalty;
+        const int ks = blocks < 192 ? splitk_slices(p, (int)blocks, nsteps) : 1;
+        const double t = (double)((blocks * ks + 255) / 256) * opts[i].bm * opts[i].bn / ks * opts[i].penalty * (ks > 1 ? 1.08 : 1.0);
         if (t < best_t) { best_t = t; best = i; }
     }
     return best;
@@ -1072,6 +1123,8 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         }
         return;
     }
+    const int nsteps32 = ((MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW)) *
+                         (((MODE == MODE_FWD) ? p.Ct : p.Co) / (bk32 ? 32 : 16));
     static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;          // tuning experiments only
 #define IG(WM, WN, TM, TN)                                                                          \
     do {                                                                                            \
@@ -1084,17 +1137,17 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
     } while (0)
     if (p.N > 64) {
         static const TileOpt o[3] = {{128, 128, 1.0f}, {128, 64, 1.1f}, {64, 64, 1.3f}};
-        switch (pick_tile(p, o, 3)) {
+        switch (pick_tile(p, o, 3, nsteps32)) {
             case 0: IG(2, 2, 2, 2); break;
             case 1: IG(2, 2, 2, 1); break;
             default: IG(2, 2, 1, 1); break;
         }
     } else if (p.N > 32) {
         static const TileOpt o[2] = {{128, 64, 1.0f}, {64, 64, 1.2f}};
-        if (pick_tile(p, o, 2) == 0) IG(2, 2, 2, 1); else IG(2, 2, 1, 1);
+        if (pick_tile(p, o, 2, nsteps32) == 0) IG(2, 2, 2, 1); else IG(2, 2, 1, 1);
     } else {
         static const TileOpt o[2] = {{256, 32, 1.0f}, {128, 32, 1.15f}};
-        if (pick_tile(p, o, 2) == 0) IG(4, 1, 2, 1); else IG(4, 1, 1, 1);
+        if (pick_tile(p, o, 2, nsteps32) == 0) IG(4, 1, 2, 1); else IG(4, 1, 1, 1);
     }
 #undef IG
 }
@@ -1114,14 +1167,25 @@ extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, i
     return CODEPS_OK;
 }
 
+// Split-K workspace: launches whose tile grid cannot fill the chip (M <= 12288 rows) with a deep K are cut into up to 16
+// K slices that write partial sums there; 0 = this shape never splits.
+extern "C" size_t codeps_conv2d_fwd_workspace_bytes(const codeps_conv_desc* d) {
+    if (check_conv(d, "conv2d_fwd_workspace_bytes") != CODEPS_OK) return 0;
+    const long long M = (long long)d->batch * d->out_h * d->out_w;
+    const long long K = (long long)d->kh * d->kw * (d->c0 + d->c1);
+    if (d->out_c <= 16 || M > 12288 || K < 512) return 0;
+    return (size_t)16 * M * d->out_c * sizeof(float);
+}
+
 extern "C" int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, const float* x1, const float* w_fwd,
-                                 const float* scale, const float* shift, const float* residual, float* y,
-                                 codeps_stream_t stream) {
+                                 const float* scale, const float* shift, const float* residual, float* y, void* workspace,
+                                 size_t workspace_bytes, codeps_stream_t stream) {
     int rc = check_conv(d, "conv2d_fwd");
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(x0 && w_fwd && y && (d->c1 == 0 || x1), CODEPS_ERR_ARG, "conv2d_fwd: null pointer");
     ConvP p = make_convp(d);
     p.M = d->batch * d->out_h * d->out_w; p.N = d->out_c;
+    if (workspace && codeps_conv2d_fwd_workspace_bytes(d) > 0) { p.part = (float*)workspace; p.part_bytes = workspace_bytes; }
     const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
     dispatch_igemm<MODE_FWD>(p, gran, x0, x1, w_fwd, scale, shift, residual, y, (hipStream_t)stream);
     CODEPS_CHECK_LAUNCH("conv_igemm_kernel<fwd>");

@@ -298,8 +298,10 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty(desc.batch, desc.out_h, desc.out_w, cop, dtype=torch.float32, device=x0.device)
         flops = 2.0 * desc.batch * desc.out_h * desc.out_w * co * (macs_per_out or ci * kh * kw)         # algorithmic (unpadded)
         t0 = _prof_begin()
+        wsb = lib().codeps_conv2d_fwd_workspace_bytes(ctypes.byref(desc))          # split-K scratch (small-M, deep-K shapes only)
+        ws = _workspace(wsb, x0.device, "splitk") if wsb else None
         check(lib().codeps_conv2d_fwd(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
-                                      stream_ptr()), "codeps_conv2d_fwd")
+                                      ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()), "codeps_conv2d_fwd")
         _prof_end(t0, "conv_fwd", flops, desc)
         ctx.desc, ctx.co, ctx.ci, ctx.has_bias = desc, co, ci, bias is not None
         ctx.flops = flops

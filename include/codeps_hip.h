@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* codeps_stream_t;
 
-int codeps_version(void);                 /* ABI version (2), bumped on any signature change */
+int codeps_version(void);                 /* ABI version (3), bumped on any signature change */
 const char* codeps_last_error(void);      /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------------------------------------
@@ -86,9 +86,13 @@ typedef struct {
 /* OIHW [out_c][in_c][kh][kw] -> w_fwd [out_c_pad][kh*kw][in_c_pad] and/or w_dgrad [in_c_pad][kh*kw][out_c_pad]. */
 int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
                                const float* w_oihw, float* w_fwd, float* w_dgrad, codeps_stream_t stream);
+/* workspace (optional, may be NULL): scratch for split-K partial sums; codeps_conv2d_fwd_workspace_bytes(d) is the size
+ * that enables it for this shape (0 = never splits).  Small-M / deep-K launches (B = 1 inference, 1/32-resolution
+ * layers) are cut into K slices + a fixed-order finish pass so that they still fill the 256 CUs. */
+size_t codeps_conv2d_fwd_workspace_bytes(const codeps_conv_desc* d);
 int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, const float* x1, const float* w_fwd,
                       const float* scale, const float* shift, const float* residual, float* y,
-                      codeps_stream_t stream);
+                      void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 /* dz = gradient w.r.t. the pre-activation conv output [B,out_h,out_w,out_c]; dx = gradient of `source`
  * at ITS stored resolution (the x2-upsample transpose, a 2x2 sum, is fused for source 0 when up0). */
 int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad,
