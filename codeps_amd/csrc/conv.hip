@@ -1136,7 +1136,8 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         else      launch_igemm<MODE, WM, WN, TM, TN, 16>(p, a0, a1, wq, scale, shift, residual, out, st); \
     } while (0)
     if (p.N > 64) {
-        static const TileOpt o[3] = {{128, 128, 1.0f}, {128, 64, 1.1f}, {64, 64, 1.3f}};
+        static const float pen1 = getenv("CODEPS_PEN1") ? atof(getenv("CODEPS_PEN1")) : 1.1f, pen2 = getenv("CODEPS_PEN2") ? atof(getenv("CODEPS_PEN2")) : 1.3f;   // tuning experiments only
+        static const TileOpt o[3] = {{128, 128, 1.0f}, {128, 64, pen1}, {64, 64, pen2}};
         switch (pick_tile(p, o, 3, nsteps32)) {
             case 0: IG(2, 2, 2, 2); break;
             case 1: IG(2, 2, 2, 1); break;

@@ -356,9 +356,12 @@ __global__ __launch_bounds__(256) void bn_apply_mg_kernel(const float* __restric
 }
 
 // backward partials per group: (sum g, sum g*xhat) with g = dy * relu'(y): part[g][blk][2][C]
+// y == nullptr with act == 1: the ReLU mask is recomputed as (x - mean) * invstd * gamma + beta > 0 (the forward expression;
+// only valid without a residual) instead of reading the saved output -- one tensor less per pass
 __global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, int act, int C, int nblk,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int act, int C, int nblk,
                                                                float* __restrict__ part) {
     const int g = blockIdx.z;
     const int Gall = C / 4, G = Gall < 256 ? Gall : 256;
@@ -371,16 +374,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __re
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (cok) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + tg * 4), is = *reinterpret_cast<const f32x4*>(invstd + g * C + tg * 4);
+        f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+        if (!y && act == 1) { ga = *reinterpret_cast<const f32x4*>(gamma + tg * 4); be = *reinterpret_cast<const f32x4*>(beta + tg * 4); }
 #pragma unroll 4
         for (long long r = r0 + tr; r < r1; r += TR) {
             const size_t o = (size_t)r * C + tg * 4;
             f32x4 gg = *reinterpret_cast<const f32x4*>(dy + o);
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
             if (act == 1) {
-                const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+                const f32x4 yy = y ? *reinterpret_cast<const f32x4*>(y + o) : xh * ga + be;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
             }
-            const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
             s += gg; q += gg * xh;
         }
     }
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_mg_kernel(const float* __re
 __global__ __launch_bounds__(256) void bn_bwd_apply_mg_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                              const float* __restrict__ sums, int act,
+                                                              const float* __restrict__ beta, const float* __restrict__ sums, int act,
                                                               long long M, int C, float* __restrict__ dx, float* __restrict__ dres) {
     const int G = C / 4;
     const long long total = M * G;
@@ -434,18 +439,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_mg_kernel(const float* __res
         const int grp = bn_group_of(gr, row);
         const size_t o = (size_t)row * C + g4 * 4;
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + grp * C + g4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + grp * C + g4 * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g4 * 4);
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
         if (act == 1) {
-            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+            const f32x4 yy = y ? *reinterpret_cast<const f32x4*>(y + o) : xh * ga + *reinterpret_cast<const f32x4*>(beta + g4 * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
         }
         if (dres) *reinterpret_cast<f32x4*>(dres + o) = g;
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + grp * C + g4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + grp * C + g4 * 4);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g4 * 4);
         const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + (size_t)grp * 2 * C + g4 * 4);
         const f32x4 sgx = *reinterpret_cast<const f32x4*>(sums + (size_t)grp * 2 * C + C + g4 * 4);
         const float ic = gr.inv_count[grp];
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
         *reinterpret_cast<f32x4*>(dx + o) = ga * is * (g - sg * ic - xh * sgx * ic);
     }
 }
@@ -1040,20 +1045,21 @@ extern "C" int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* r
 }
 
 extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x, int n_groups, const long long* row0, const long long* rows,
-                                int c, int c_real, const float* mean, const float* invstd, const float* gamma, const float* inv_count,
-                                int act, float* sums, float* dgamma, float* dbeta, int accumulate, float* dx, float* dres,
+                                int c, int c_real, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const float* inv_count, int act, float* sums, float* dgamma, float* dbeta, int accumulate, float* dx, float* dres,
                                 int reduce_only, int apply_only, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     BnGroups gr;
     long long M;
     int rc = make_groups(n_groups, row0, rows, gr, M, "bn_bwd_mg");
     if (rc) return rc;
-    CODEPS_REQUIRE(dy && x && mean && invstd && sums && (c % 4) == 0 && (act == 0 || y), CODEPS_ERR_ARG, "bn_bwd_mg: bad arguments");
+    CODEPS_REQUIRE(dy && x && mean && invstd && sums && (c % 4) == 0 && (act == 0 || y || (gamma && beta && !dres)), CODEPS_ERR_ARG,
+                   "bn_bwd_mg: bad arguments (the ReLU mask needs y, or gamma + beta and no residual)");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = mg_blocks(gr);
     if (!apply_only) {
         CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)n_groups * nblk * 2 * c * 4 && dgamma && dbeta, CODEPS_ERR_WORKSPACE,
                        "bn_bwd_mg: workspace too small / null grads");
-        hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, dy, y, x, gr, mean, invstd, act, c, nblk,
+        hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, beta, act, c, nblk,
                            (float*)workspace);
         hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 4)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma,
                            dbeta, accumulate);
@@ -1062,7 +1068,7 @@ extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x,
     if (!reduce_only) {
         CODEPS_REQUIRE(gamma && inv_count && dx, CODEPS_ERR_ARG, "bn_bwd_mg: null gamma / inv_count / dx");
         for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = inv_count[i];
-        hipLaunchKernelGGL(bn_bwd_apply_mg_kernel, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, (const float*)sums,
+        hipLaunchKernelGGL(bn_bwd_apply_mg_kernel, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, beta, (const float*)sums,
                            act, M, c, dx, dres);
         CODEPS_CHECK_LAUNCH("bn_bwd_apply_mg_kernel");
     }

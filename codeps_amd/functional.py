@@ -486,7 +486,8 @@ class _BatchNormTrain(torch.autograd.Function):
                                          ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1, ptr(ws), ws.numel(), stream_ptr()),
                   "codeps_bn_fwd_mg")
         ctx.inv_count = [1.0 / n for n in counts]
-        ctx.save_for_backward(x, y if act else None, g, mean, invstd)
+        # ReLU without a residual: the backward recomputes the mask from x (y is neither kept nor re-read)
+        ctx.save_for_backward(x, y if (act and residual is not None) else None, g, b_, mean, invstd)
         ctx.act, ctx.c, ctx.reduce_fn, ctx.has_res, ctx.groups, ctx.per_item = act, c, reduce_fn, residual is not None, groups, per_item
         # flat-gradient sinks of the affine parameters (codeps_amd.step): the backward accumulates dgamma / dbeta in place
         gs, bs = _grad_sink.get(id(gamma)), _grad_sink.get(id(beta))
@@ -495,7 +496,7 @@ class _BatchNormTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, g, mean, invstd = ctx.saved_tensors
+        x, y, g, b_, mean, invstd = ctx.saved_tensors
         dy = dy.contiguous()
         cp = x.shape[-1]
         ng, row0, rows = _group_arrays(ctx.groups, ctx.per_item)
@@ -511,15 +512,15 @@ class _BatchNormTrain(torch.autograd.Function):
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
         if ctx.reduce_fn is None:
-            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), inv_count,
+            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), ptr(b_), inv_count,
                                          ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), acc, ptr(dx), ptr(dres), 0, 0, ptr(ws), ws.numel(),
                                          stream_ptr()), "codeps_bn_bwd_mg")
         else:
-            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), None, None, ctx.act,
-                                         ptr(sums), ptr(dgamma), ptr(dbeta), acc, None, None, 1, 0, ptr(ws), ws.numel(), stream_ptr()),
+            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), ptr(b_), None,
+                                         ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), acc, None, None, 1, 0, ptr(ws), ws.numel(), stream_ptr()),
                   "codeps_bn_bwd_mg")
             sums = ctx.reduce_fn.sum(sums)
-            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), inv_count,
+            check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), ptr(b_), inv_count,
                                          ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(dres), 0, 1, ptr(ws), ws.numel(),
                                          stream_ptr()), "codeps_bn_bwd_mg")
         if ctx.sinks is not None:

@@ -160,9 +160,11 @@ int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* row0, const 
                      size_t workspace_bytes, codeps_stream_t stream);
 int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x, int n_groups, const long long* row0,
                      const long long* rows, int c, int c_real, const float* mean, const float* invstd,
-                     const float* gamma, const float* inv_count, int act, float* sums, float* dgamma,
-                     float* dbeta, int accumulate, float* dx, float* dres, int reduce_only, int apply_only,
-                     void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+                     const float* gamma, const float* beta, const float* inv_count, int act, float* sums,
+                     float* dgamma, float* dbeta, int accumulate, float* dx, float* dres, int reduce_only,
+                     int apply_only, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* codeps_bn_bwd_mg: y may be NULL when act == 1 and the forward had no residual: the ReLU mask is then recomputed from
+ * x, mean, invstd, gamma, beta (one tensor less to keep and to read per backward pass). */
 /* nn.MaxPool2d(3, 2, 1) (models/resnet_encoder.py:31); argmax = window tap 0..8 per element (u8). */
 int codeps_maxpool3x3s2_fwd(const float* x, int batch, int h, int w, int c, float* y, uint8_t* argmax,
                             codeps_stream_t stream);
