@@ -149,3 +149,37 @@ def test_adam_ema_step():
     dq, dmq, dvq = torch.ones(5, device=DEV), torch.zeros(5, device=DEV), torch.zeros(5, device=DEV)
     F.adam_ema_step(dq, torch.arange(5.0).to(DEV), dmq, dvq, 1)
     close(dq, q.detach(), 1e-7, 1e-6)
+
+
+def test_degenerate_inputs_match_oracle():
+    """Edge cases of the domain: no thing pixels, no centre above the threshold, every thing pixel but a single centre,
+    an all-ignored semantic target, batch 1 at the smallest legal size."""
+    from codeps_amd import functional as F
+    from oracle import losses, panoptic
+    things = [9, 10, 11, 12, 13]
+    b, h, w = 2, 24, 40
+    sem = gi.semantic_labels(b, h, w, 5, 14, block=8)
+    ctr = gi.center_heatmap(b, h, w, 5, 3, 4.0)
+    off = gi.offsets(b, h, w, 5, 16.0)
+    cases = {
+        "no_things": (torch.clamp(sem, max=8), ctr, off),
+        "no_centres": (sem, ctr * 0.0, off),
+        "all_things_one_centre": (torch.full_like(sem, 11), ctr, off * 0.0),
+    }
+    for name, (s_, c_, o_) in cases.items():
+        pan, inst, centers, state = F.panoptic_fusion(s_.to(DEV), c_.to(DEV), o_.to(DEV), things)
+        rp, ri, pts = panoptic.panoptic_fusion(s_.numpy(), c_.numpy(), o_.numpy(), things)
+        assert np.array_equal(pan.cpu().numpy(), rp), name
+        assert np.array_equal(inst.cpu().numpy(), ri), name
+        for i in range(b):
+            assert np.array_equal(centers[i, :int(state[i, 1])].cpu().numpy(), pts[i]), name
+    # semantic loss: every pixel ignored -> the reference's top-k mean over zero losses is 0 with zero gradient
+    c = 14
+    probs = torch.softmax(gi.normal((1, c, 8, 16), 3, 2.0), 1)
+    target = torch.full((1, 8, 16), 255, dtype=torch.uint8)
+    p = nhwc(probs).requires_grad_(True)
+    loss = F.semantic_loss(p, c, target.to(DEV), None, None, 0.2)
+    loss.backward()
+    ref = losses.semantic_loss(probs.double(), target.long(), torch.ones(1, 8, 16, dtype=torch.float64), None, 0.2)
+    close(loss, ref.float(), 1e-7, 1e-6, "all-ignored semantic loss")
+    assert float(p.grad.abs().max()) == 0.0
