@@ -915,7 +915,123 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
     }
 }
 
-struct SmallPlan { bool ok, stem; int mt, nt, ci_chunks, co_groups, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
+// ---------------------------------------------------------------------------------- halo-tile wgrad, 64 x 64 channel tiles
+// 3x3 / stride 1 weight gradient for layers with >= 48 channels on both sides.  A block owns a (64 output channels) x
+// (64 input channels) tile of dW for all 9 taps and walks 4x16-pixel output tiles: the dZ tile and the X tile WITH its
+// one-pixel halo are staged in LDS once and feed all 9 taps (the per-tap blocks of conv_wgrad_kernel load both operands 9
+// times and spend more issue slots on gather arithmetic than on MFMAs).  The 4 waves split the CHANNELS, not the pixels:
+// wave (wco, wci) accumulates its 32 x 32 quadrant x 9 taps in 144 accumulator registers over every pixel of the
+// block's tiles, so there is no cross-wave reduction.  v_mfma_f32_16x16x4_f32, k = 4 pixels per step.
+__global__ __launch_bounds__(256) void wgrad_halo64_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
+                                                           const float* __restrict__ x0, const float* __restrict__ x1,
+                                                           const float* __restrict__ dz, float* __restrict__ part) {
+    constexpr int TH = 4, TW = 16, XH = TH + 2, XW = TW + 2, PIX = TH * TW, LD = 64 + 4;
+    __shared__ __attribute__((aligned(16))) float dZs[PIX * LD];
+    __shared__ __attribute__((aligned(16))) float Xs[XH * XW * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
+    const int wco = wave & 1, wci = wave >> 1;
+    const int co_base = blockIdx.y * 64;
+    const int chunk = blockIdx.x % ci_chunks, blk = blockIdx.x / ci_chunks;
+    const int c_base = chunk * 64;
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    // source of this channel chunk (chunks never straddle the two concat sources: C0 % 64 == 0 or C1 == 0)
+    const bool s1 = c_base >= p.C0;
+    const float* src = s1 ? x1 : x0;
+    const int cs = s1 ? p.C1 : p.C0, c_src = s1 ? c_base - p.C0 : c_base;
+    const bool up = p.up0 && !s1;
+    const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+
+    f32x4 acc[2][2][9];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NZ = PIX * 16 / 256, NX = (XH * XW * 16 + 255) / 256;
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        f32x4 zr[NZ], xr_[NX];
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {                          // dZ tile: [pixel][64] as float4
+            const int i = tid + 256 * u, pix = i >> 4, c4 = i & 15;
+            const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy < p.Ho && gx < p.Wo && co_base + c4 * 4 < p.Co)
+                v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.Co + co_base + c4 * 4);
+            zr[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {                          // X halo tile: [position][64] as float4
+            const int i = tid + 256 * u;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < XH * XW * 16) {
+                const int pos = i >> 4, c4 = i & 15;
+                int iy = ty0 + pos / XW - 1, ix = tx0 + pos % XW - 1;
+                if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
+                    if (up) { iy >>= 1; ix >>= 1; }
+                    v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c_src + c4 * 4);
+                }
+            }
+            xr_[u] = v;
+        }
+        __syncthreads();                                        // previous tile's MFMAs are done with the LDS
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            const int i = tid + 256 * u;
+            *reinterpret_cast<f32x4*>(dZs + (i >> 4) * LD + (i & 15) * 4) = zr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + 256 * u;
+            if (i < XH * XW * 16) *reinterpret_cast<f32x4*>(Xs + (i >> 4) * LD + (i & 15) * 4) = xr_[u];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int j = 0; j < PIX / 4; ++j) {                     // k-steps of 4 pixels over the whole tile
+            const int pix = j * 4 + q;
+            const int py = pix / TW, px = pix % TW;
+            float af[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = dZs[pix * LD + (wco * 2 + a) * 16 + l16];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float* xr = Xs + ((py + ky) * XW + px + kx) * LD + wci * 32 + l16;
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const float bv = xr[bb * 16];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+                            acc[a][bb][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bv, acc[a][bb][ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + reg
+    float* dst = part + (size_t)blk * p.Co * 9 * p.Ct;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int ci = c_base + (wci * 2 + bb) * 16 + l16;
+            if (ci >= p.Ct) continue;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co_base + (wco * 2 + a) * 16 + q * 4 + r;
+                    if (co < p.Co) dst[((size_t)co * 9 + t) * p.Ct + ci] = acc[a][bb][t][r];
+                }
+        }
+}
+
+struct SmallPlan { bool ok, stem, halo64; int mt, nt, ci_chunks, co_groups, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
 
 static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
     SmallPlan s;
@@ -932,6 +1048,21 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
         s.tiles_x = cdiv(d->out_w, 16); s.tiles_y = cdiv(d->out_h, 4);
         const int total = d->batch * s.tiles_x * s.tiles_y;
         s.tiles_per_block = std::max(8, cdiv(total, std::max(1, 768 / s.co_groups)));
+        s.nblk = cdiv(total, s.tiles_per_block);
+        s.splits = s.nblk;
+        return s;
+    }
+    static const int halo_off = getenv("CODEPS_NO_HALO64") ? 1 : 0;                                    // tuning experiments only
+    if (!halo_off && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->stride_w == 1 && d->pad == 1 && d->pad_w == 1 && d->out_c >= 48 && Ct >= 48 &&
+        cdiv(Ct, 64) * cdiv(d->out_c, 64) >= 2 && (d->c1 == 0 || d->c0 % 64 == 0) && d->out_h == d->in_h && d->out_w == d->in_w) {
+        // 64 x 64 channel tiles over 4x16-pixel tiles with halo (wgrad_halo64_kernel); a single-tile 64 -> 64 layer would need
+        // ~768 pixel blocks = 768 partial slabs, where the per-tap kernel measures faster
+        s.ok = s.halo64 = true;
+        s.ci_chunks = cdiv(Ct, 64); s.co_groups = cdiv(d->out_c, 64);
+        s.tiles_x = cdiv(d->out_w, 16); s.tiles_y = cdiv(d->out_h, 4);
+        const int total = d->batch * s.tiles_x * s.tiles_y;
+        const int want = std::max(1, 768 / (s.ci_chunks * s.co_groups));           // ~3 blocks per CU in total
+        s.tiles_per_block = std::max(2, cdiv(total, want));
         s.nblk = cdiv(total, s.tiles_per_block);
         s.splits = s.nblk;
         return s;
@@ -1293,7 +1424,10 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
         const int g = sp.nblk * sp.ci_chunks;
 #define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS, KS, 1, 1, 8, 32>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \
                                                  sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part)
-        if (sp.stem) {
+        if (sp.halo64) {
+            hipLaunchKernelGGL(wgrad_halo64_kernel, dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
+                               sp.tiles_per_block, x0, x1, dz, part);
+        } else if (sp.stem) {
             if (d->kw == 7)
                 hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 7, 2, 2, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks,
                                    sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
