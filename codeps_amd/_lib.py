@@ -78,6 +78,7 @@ SIGNATURES = {
     "codeps_bn_bwd_apply": (c_int, [P, P, P, P, P, P, P, c_float, I, LL, I, P, P, P]),
     "codeps_bn_mg_workspace_bytes": (c_size_t, [I, I]),
     "codeps_bn_fwd_mg": (c_int, [P, I, P, P, I, I, P, P, P, I, c_float, c_float, P, P, P, P, P, P, I, I, P, c_size_t, P]),
+    "codeps_bn_sync_combine": (c_int, [P, I, I, P, I, I, c_float, c_float, P, P, P, P, P, P]),
     "codeps_bn_bwd_mg": (c_int, [P, P, P, I, P, P, I, I, P, P, P, P, P, I, P, P, P, I, P, P, I, I, P, c_size_t, P]),
     "codeps_maxpool3x3s2_fwd": (c_int, [P, I, I, I, I, P, P, P]),
     "codeps_maxpool3x3s2_bwd": (c_int, [P, P, I, I, I, I, P, P]),

@@ -324,6 +324,40 @@ __global__ __launch_bounds__(256) void bn_finalize_mg_kernel(const float* __rest
     if (upd && sub == 0) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
+// SyncBatchNorm: merge the per-rank (mean, biased var) of every statistic group after the all-gather -- equal element counts
+// on all ranks, so the parallel-variance formula reduces to plain averages -- and apply the running-stat momentum updates
+// group after group with the GLOBAL count (torch.nn.SyncBatchNorm semantics).  gathered: [world][2][G][C].
+// One thread per channel; replaces ~45 tiny tensor ops per layer.
+__global__ __launch_bounds__(256) void bn_sync_combine_kernel(const float* __restrict__ gathered, int world, BnGroups gr, int C, int c_real,
+                                                              float eps, float momentum, float* __restrict__ mean, float* __restrict__ var,
+                                                              float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const bool upd = running_mean != nullptr && c < c_real;
+    float rm = upd ? running_mean[c] : 0.f, rv = upd ? running_var[c] : 0.f;
+    const float inv_w = 1.f / (float)world;
+    const size_t rank_stride = (size_t)2 * gr.n * C;
+    for (int g = 0; g < gr.n; ++g) {
+        float m = 0.f;
+        for (int r = 0; r < world; ++r) m += gathered[r * rank_stride + (size_t)g * C + c];
+        m *= inv_w;
+        float v = 0.f;
+        for (int r = 0; r < world; ++r) {
+            const float mr = gathered[r * rank_stride + (size_t)g * C + c], vr = gathered[r * rank_stride + (size_t)(gr.n + g) * C + c];
+            v += vr + (mr - m) * (mr - m);
+        }
+        v *= inv_w;
+        mean[g * C + c] = m; var[g * C + c] = v; invstd[g * C + c] = rsqrtf(v + eps);
+        if (upd) {
+            const float n = gr.inv_count[g];                     // here: the GLOBAL element count of the group
+            rm = rm * (1.f - momentum) + momentum * m;
+            rv = rv * (1.f - momentum) + momentum * (v * (n / fmaxf(n - 1.f, 1.f)));
+        }
+    }
+    if (upd) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
 __device__ __forceinline__ int bn_group_of(const BnGroups& gr, long long row) {
     int g = 0;
 #pragma unroll
@@ -1041,6 +1075,21 @@ extern "C" int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* r
                            gamma, beta, residual, act, M, c, y);
         CODEPS_CHECK_LAUNCH("bn_apply_mg_kernel");
     }
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_sync_combine(const float* gathered, int world, int n_groups, const float* global_counts, int c, int c_real, float eps,
+                                      float momentum, float* running_mean, float* running_var, float* mean, float* var, float* invstd,
+                                      codeps_stream_t stream) {
+    CODEPS_REQUIRE(gathered && global_counts && mean && var && invstd && world >= 1 && n_groups >= 1 && n_groups <= 8 && c > 0 && c_real <= c,
+                   CODEPS_ERR_ARG, "bn_sync_combine: bad arguments");
+    BnGroups gr;
+    gr.n = n_groups;
+    for (int i = 0; i < 8; ++i) { gr.row0[i] = 0; gr.rows[i] = 0; gr.inv_count[i] = 0.f; }
+    for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = global_counts[i];
+    hipLaunchKernelGGL(bn_sync_combine_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world, gr, c, c_real, eps, momentum,
+                       mean, var, invstd, running_mean, running_var);
+    CODEPS_CHECK_LAUNCH("bn_sync_combine_kernel");
     return CODEPS_OK;
 }
 

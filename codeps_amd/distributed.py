@@ -41,11 +41,22 @@ class SyncBatchNormReducer:
 
     def __init__(self, group=None):
         self.group = group
+        self._counts = {}           # (device, counts) -> device tensor: the per-group element counts never change between steps
+
+    def _count_tensor(self, like, counts):
+        """Device copy of the local element counts, made once: a fresh host->device copy per BatchNorm layer would
+        synchronise the host with the stream 40 times per step and stop it from running ahead of the GPU."""
+        key = (like.device, tuple(float(n) for n in counts))
+        t = self._counts.get(key)
+        if t is None:
+            t = torch.tensor(key[1], dtype=like.dtype, device=like.device)
+            self._counts[key] = t
+        return t
 
     def __call__(self, mean, var, count):
         world = dist.get_world_size(self.group)
         c = mean.numel()
-        packed = torch.cat([mean, var, mean.new_tensor([count])])
+        packed = torch.cat([mean, var, self._count_tensor(mean, [count])])
         gathered = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(gathered, packed, group=self.group)
         g = torch.stack(gathered)                      # [world, 2c+1]
@@ -53,13 +64,14 @@ class SyncBatchNormReducer:
         total = counts.sum()
         mean_all = (means * counts).sum(0) / total
         var_all = ((vars_ + (means - mean_all) ** 2) * counts).sum(0) / total
-        return mean_all, var_all, float(total)
+        # counts are equal on all ranks by construction (equal shards) -> no device->host read-back
+        return mean_all, var_all, float(count) * world
 
     def combine_groups(self, mean, var, counts):
         """All statistic groups of one BatchNorm layer in ONE all-gather: mean / var [G, C], counts = G floats."""
         world = dist.get_world_size(self.group)
         g, c = mean.shape
-        packed = torch.cat([mean.reshape(-1), var.reshape(-1), mean.new_tensor(counts)])
+        packed = torch.cat([mean.reshape(-1), var.reshape(-1), self._count_tensor(mean, counts)])
         gathered = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(gathered, packed, group=self.group)
         allp = torch.stack(gathered)                                  # [world, 2*G*C + G]
@@ -71,6 +83,14 @@ class SyncBatchNormReducer:
         var_all = ((vars_ + (means - mean_all) ** 2) * cnts).sum(0) / total
         # counts are equal on all ranks by construction (equal shards) -> no host sync needed to read them back
         return mean_all, var_all, [float(n) * world for n in counts]
+
+    def gather(self, packet):
+        """All-gather of one contiguous statistics packet -> [world, *packet.shape] (ranks write into slices of one
+        buffer; the merge itself is the HIP kernel codeps_bn_sync_combine)."""
+        world = dist.get_world_size(self.group)
+        buf = torch.empty((world,) + tuple(packet.shape), dtype=packet.dtype, device=packet.device)
+        dist.all_gather(list(buf.unbind(0)), packet, group=self.group)
+        return buf
 
     def sum(self, sums):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)

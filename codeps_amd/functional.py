@@ -472,16 +472,17 @@ class _BatchNormTrain(torch.autograd.Function):
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, ptr(rm),
                                          ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 0,
                                          ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
-        else:       # SyncBN: local statistics -> cross-rank combination -> apply
-            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(mean),
-                                         ptr(var), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
-            mean, var, counts = reduce_fn.combine_groups(mean, var, counts)        # ONE all-gather per layer
-            if rm is not None:
-                with torch.no_grad():
-                    for gi in range(ng):
-                        rm.mul_(1 - momentum).add_(mean[gi, :c], alpha=momentum)
-                        running_var.mul_(1 - momentum).add_(var[gi, :c] * (counts[gi] / max(counts[gi] - 1, 1)), alpha=momentum)
-            invstd = torch.rsqrt(var + eps)
+        else:       # SyncBN: local statistics -> all-gather -> one combine kernel (merge + running stats + invstd) -> apply
+            pk = torch.empty(2, ng, cp, dtype=torch.float32, device=dev)        # [mean | var] = the all-gather packet, no packing pass
+            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(pk[0]),
+                                         ptr(pk[1]), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+            gathered = reduce_fn.gather(pk)                                     # [world, 2, ng, cp], ONE collective per layer
+            world = gathered.shape[0]
+            counts = [n * world for n in counts]                                # equal shards on every rank by construction
+            gc = (ctypes.c_float * ng)(*counts)
+            check(lib().codeps_bn_sync_combine(ptr(gathered), world, ng, gc, cp, c, eps, momentum, ptr(rm),
+                                               ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd),
+                                               stream_ptr()), "codeps_bn_sync_combine")
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, None, None,
                                          ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1, ptr(ws), ws.numel(), stream_ptr()),
                   "codeps_bn_fwd_mg")

@@ -158,6 +158,12 @@ int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* row0, const 
                      float momentum, float* running_mean, float* running_var, float* mean, float* var,
                      float* invstd, float* y, int stats_only, int apply_only, void* workspace,
                      size_t workspace_bytes, codeps_stream_t stream);
+/* SyncBatchNorm (misc/train_utils.py:50-51, torch.nn.SyncBatchNorm): after the all-gather of every rank's per-group
+ * (mean, biased var) -- gathered [world][2][n_groups][c], equal element counts on all ranks -- merge them, compute invstd
+ * and apply the running-stat momentum updates group by group with the global counts (host array [n_groups]). */
+int codeps_bn_sync_combine(const float* gathered, int world, int n_groups, const float* global_counts, int c,
+                           int c_real, float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* var, float* invstd, codeps_stream_t stream);
 int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x, int n_groups, const long long* row0,
                      const long long* rows, int c, int c_real, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, const float* inv_count, int act, float* sums,

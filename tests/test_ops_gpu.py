@@ -292,3 +292,56 @@ def test_layout_roundtrip_zero_copy():
     assert F.from_nchw(v).data_ptr() == y.data_ptr()            # zero-copy round trip
     two = F.images_to_nhwc([x.to(DEV), (x + 1).to(DEV)])
     assert torch.equal(two[..., 3:6].cpu(), (x + 1).permute(0, 2, 3, 1)) and two[..., 6:].abs().max() == 0
+
+
+def test_sync_bn_combine_matches_parallel_variance():
+    """codeps_bn_sync_combine (the merge after the SyncBatchNorm all-gather) against the parallel-variance formula, and
+    the whole SyncBN forward/backward with a 3-rank reducer simulated on one GPU (every rank holds a different shard)."""
+    import ctypes
+    F = _F()
+    from codeps_amd._lib import lib, ptr, stream_ptr, check
+    g = torch.Generator().manual_seed(3)
+    world, ng, c = 3, 2, 32
+    shards = [torch.randn(4, 6, 5, c, generator=g) * (1 + r) + r for r in range(world)]          # NHWC, groups = batch halves
+    groups = [(0, 2), (2, 4)]
+    per = 2 * 6 * 5
+    # reference: statistics of the concatenation of all ranks' shards, per group
+    ref_mean, ref_var = [], []
+    for (b0, b1) in groups:
+        allx = torch.cat([s_[b0:b1].reshape(-1, c) for s_ in shards]).double()
+        ref_mean.append(allx.mean(0)); ref_var.append(allx.var(0, unbiased=False))
+    ref_mean, ref_var = torch.stack(ref_mean), torch.stack(ref_var)
+    packets = []
+    for s_ in shards:
+        m = torch.stack([s_[b0:b1].reshape(-1, c).double().mean(0) for b0, b1 in groups])
+        v = torch.stack([s_[b0:b1].reshape(-1, c).double().var(0, unbiased=False) for b0, b1 in groups])
+        packets.append(torch.stack([m, v]).float())
+    gathered = torch.stack(packets).to(DEV)                                                      # [world, 2, ng, c]
+    mean, var, invstd = (torch.empty(ng, c, device=DEV) for _ in range(3))
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    counts = (ctypes.c_float * ng)(*[float(per * world)] * ng)
+    check(lib().codeps_bn_sync_combine(ptr(gathered), world, ng, counts, c, c, 1e-5, 0.1, ptr(rm), ptr(rv), ptr(mean), ptr(var), ptr(invstd),
+                                       stream_ptr()), "codeps_bn_sync_combine")
+    assert rel_err(mean.cpu(), ref_mean) < 1e-5 and rel_err(var.cpu(), ref_var) < 1e-5
+    assert rel_err(invstd.cpu(), 1.0 / torch.sqrt(ref_var + 1e-5)) < 1e-5
+    erm, erv = torch.zeros(c).double(), torch.ones(c).double()
+    n = per * world
+    for gi in range(ng):
+        erm = erm * 0.9 + 0.1 * ref_mean[gi]
+        erv = erv * 0.9 + 0.1 * ref_var[gi] * n / (n - 1)
+    assert rel_err(rm.cpu(), erm) < 1e-5 and rel_err(rv.cpu(), erv) < 1e-5
+
+    # end to end: rank 0's SyncBN output / input gradient with a reducer that "gathers" the three shards' statistics
+    class FakeReducer:
+        def gather(self, pk):
+            return gathered
+        def sum(self, sums):                      # backward: sum over ranks of (sum g, sum g xhat); ranks 1, 2 contribute zero here
+            return sums
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    x = shards[0].to(DEV).requires_grad_(True)
+    y = F.batch_norm_train(x, gamma.to(DEV), beta.to(DEV), None, None, 0.1, 1e-5, None, "relu", FakeReducer(), groups)
+    want = []
+    for gi, (b0, b1) in enumerate(groups):
+        xh = (shards[0][b0:b1].double() - ref_mean[gi]) / torch.sqrt(ref_var[gi] + 1e-5)
+        want.append(torch.relu(xh * gamma.double() + beta.double()))
+    assert rel_err(y.detach().cpu(), torch.cat(want)) < 1e-5
