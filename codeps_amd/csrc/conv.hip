@@ -1047,7 +1047,8 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
         s.mt = 1; s.nt = 1; s.ci_chunks = 1; s.co_groups = d->out_c / 16;
         s.tiles_x = cdiv(d->out_w, 16); s.tiles_y = cdiv(d->out_h, 4);
         const int total = d->batch * s.tiles_x * s.tiles_y;
-        s.tiles_per_block = std::max(8, cdiv(total, std::max(1, 768 / s.co_groups)));
+        static const int stem_blocks = getenv("CODEPS_STEM_BLOCKS") ? atoi(getenv("CODEPS_STEM_BLOCKS")) : 768;   // env: tuning experiments only
+        s.tiles_per_block = std::max(8, cdiv(total, std::max(1, stem_blocks / s.co_groups)));
         s.nblk = cdiv(total, s.tiles_per_block);
         s.splits = s.nblk;
         return s;
@@ -1061,7 +1062,9 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
         s.ci_chunks = cdiv(Ct, 64); s.co_groups = cdiv(d->out_c, 64);
         s.tiles_x = cdiv(d->out_w, 16); s.tiles_y = cdiv(d->out_h, 4);
         const int total = d->batch * s.tiles_x * s.tiles_y;
-        const int want = std::max(1, 768 / (s.ci_chunks * s.co_groups));           // ~3 blocks per CU in total
+        // 228 VGPRs -> 2 blocks per CU: exactly one balanced round of <= 512 blocks (measured: 512 -> 54.8 ms/step, 448 -> 55.7, 576 -> 56.8)
+        static const int halo_blocks = getenv("CODEPS_HALO_BLOCKS") ? atoi(getenv("CODEPS_HALO_BLOCKS")) : 512;   // env: tuning experiments only
+        const int want = std::max(1, halo_blocks / (s.ci_chunks * s.co_groups));
         s.tiles_per_block = std::max(2, cdiv(total, want));
         s.nblk = cdiv(total, s.tiles_per_block);
         s.splits = s.nblk;
@@ -1076,7 +1079,8 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
     s.ci_chunks = cdiv(Ct, s.nt * 16);
     s.tiles_x = cdiv(d->out_w, 32); s.tiles_y = cdiv(d->out_h, 8);
     const int total = d->batch * s.tiles_x * s.tiles_y;
-    int want = std::max(1, 768 / s.ci_chunks);                // ~3 blocks per CU in total
+    static const int small_blocks = getenv("CODEPS_SMALL_BLOCKS") ? atoi(getenv("CODEPS_SMALL_BLOCKS")) : 512;   // env: tuning experiments only
+    int want = std::max(1, small_blocks / s.ci_chunks);                // one balanced round of 2 blocks per CU
     s.tiles_per_block = std::max(4, cdiv(total, want));
     s.nblk = cdiv(total, s.tiles_per_block);
     s.splits = s.nblk;
@@ -1383,7 +1387,8 @@ static void wgrad_plan(const codeps_conv_desc* d, int& bm, int& bn, int& n_mt, i
     n_mt = cdiv(d->out_c, bm); n_nt = cdiv(Ct, bn);
     const long long tiles = (long long)n_mt * n_nt * d->kh * d->kw;
     const int P = d->batch * d->out_h * d->out_w;
-    long long s = std::max<long long>(1, (256 * 6) / tiles);
+    static const int wg_blocks = getenv("CODEPS_WG_BLOCKS") ? atoi(getenv("CODEPS_WG_BLOCKS")) : 256 * 6;   // tuning experiments only
+    long long s = std::max<long long>(1, wg_blocks / tiles);
     s = std::min<long long>(s, std::max(1, P / 256));
     s = std::min<long long>(s, 512);
     pps = (int)align_up((size_t)cdiv(P, (int)s), 16);
