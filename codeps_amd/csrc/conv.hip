@@ -1162,8 +1162,10 @@ static ConvP make_convp(const codeps_conv_desc* d) {
 
 // K slices a launch of `blocks` tiles with `nsteps` K-steps is cut into (1 = no split-K); shared by the cost model and the launcher
 static int splitk_slices(const ConvP& p, int blocks, int nsteps) {
-    if (!p.part || blocks >= 192 || nsteps < 16) return 1;
-    int ks = std::min(std::min(512 / blocks, nsteps / 8), 16);
+    static const int sk_blocks = getenv("CODEPS_SPLITK_BLOCKS") ? atoi(getenv("CODEPS_SPLITK_BLOCKS")) : 192;   // env: tuning experiments only
+    static const int sk_target = getenv("CODEPS_SPLITK_TARGET") ? atoi(getenv("CODEPS_SPLITK_TARGET")) : 512;
+    if (!p.part || blocks >= sk_blocks || nsteps < 16) return 1;
+    int ks = std::min(std::min(sk_target / blocks, nsteps / 8), 16);
     while (ks >= 2 && (size_t)ks * p.M * p.N * sizeof(float) > p.part_bytes) --ks;
     return std::max(ks, 1);
 }
@@ -1224,7 +1226,7 @@ static int pick_tile(const ConvP& p, const TileOpt* opts, int n, int nsteps) {
     double best_t = 1e300;
     for (int i = 0; i < n; ++i) {
         const long long blocks = (long long)cdiv(p.M, opts[i].bm) * cdiv(p.N, opts[i].bn);
-        const int ks = blocks < 192 ? splitk_slices(p, (int)blocks, nsteps) : 1;
+        const int ks = splitk_slices(p, (int)blocks, nsteps);
         const double t = (double)((blocks * ks + 255) / 256) * opts[i].bm * opts[i].bn / ks * opts[i].penalty * (ks > 1 ? 1.08 : 1.0);
         if (t < best_t) { best_t = t; best = i; }
     }
@@ -1313,7 +1315,8 @@ extern "C" size_t codeps_conv2d_fwd_workspace_bytes(const codeps_conv_desc* d) {
     if (check_conv(d, "conv2d_fwd_workspace_bytes") != CODEPS_OK) return 0;
     const long long M = (long long)d->batch * d->out_h * d->out_w;
     const long long K = (long long)d->kh * d->kw * (d->c0 + d->c1);
-    if (d->out_c <= 16 || M > 12288 || K < 512) return 0;
+    static const long long sk_m = getenv("CODEPS_SPLITK_M") ? atoll(getenv("CODEPS_SPLITK_M")) : 12288;   // env: tuning experiments only
+    if (d->out_c <= 16 || M > sk_m || K < 512) return 0;
     return (size_t)16 * M * d->out_c * sizeof(float);
 }
 
