@@ -536,23 +536,28 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* _
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void pose_reduce_kernel(Levels L, const float* __restrict__ part,
-                                                          float* __restrict__ gpm, float* __restrict__ gpp) {
-    // one block per batch item; thread (e = tid % 32) sums entry e over a strided set of blocks
-    __shared__ float acc[8][32];
-    const int b = blockIdx.x, e = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
-    float a = 0.f;
+__global__ __launch_bounds__(1024) void pose_reduce_kernel(Levels L, const float* __restrict__ part,
+                                                           float* __restrict__ gpm, float* __restrict__ gpp) {
+    // one block of 1024 threads per batch item; thread (e = tid % 32) sums entry e over a strided set of tiles with 4
+    // independent chains (fixed assignment and order -> deterministic)
+    __shared__ float acc[32][32];
+    const int b = blockIdx.x, e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int s = 0; s < L.num_scales; ++s) {
         const int tiles = L.btx[s] * L.bty[s];
-        const int beg = L.bblk[s] + b * tiles;
-        for (int i = lane8; i < tiles; i += 8) a += part[(size_t)(beg + i) * 32 + e];
+        const float* p0 = part + (size_t)(L.bblk[s] + b * tiles) * 32 + e;
+        int i = grp;
+        for (; i + 96 < tiles; i += 128) {
+            a0 += p0[(size_t)i * 32]; a1 += p0[(size_t)(i + 32) * 32]; a2 += p0[(size_t)(i + 64) * 32]; a3 += p0[(size_t)(i + 96) * 32];
+        }
+        for (; i < tiles; i += 32) a0 += p0[(size_t)i * 32];
     }
-    acc[lane8][e] = a;
+    acc[grp][e] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (threadIdx.x < 32) {
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v += acc[i][threadIdx.x];
+        for (int i = 0; i < 32; ++i) v += acc[i][threadIdx.x];
         if (threadIdx.x < 16) gpm[b * 16 + threadIdx.x] = v;
         else gpp[b * 16 + threadIdx.x - 16] = v;
     }
@@ -657,7 +662,7 @@ extern "C" int codeps_photometric_bwd(const codeps_photometric_desc* d, const fl
                        d->alpha, (float)(1.0 - (double)d->alpha), grad_loss, (const float*)(ws + W.pyr),
                        (const uint8_t*)(ws + W.sel), grad_depth, (float*)(ws + W.gds), (float*)(ws + W.pose_part));
     CODEPS_CHECK_LAUNCH("photo_bwd_kernel");
-    hipLaunchKernelGGL(pose_reduce_kernel, dim3(L.batch), dim3(256), 0, st, L, (const float*)(ws + W.pose_part), grad_pose_m,
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(L.batch), dim3(1024), 0, st, L, (const float*)(ws + W.pose_part), grad_pose_m,
                        grad_pose_p);
     CODEPS_CHECK_LAUNCH("pose_reduce_kernel");
     if (L.num_scales > 1) {
