@@ -873,6 +873,48 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     }
 }
 
+// Cp == 16 (every class head of the path): one thread per pixel row held in four float4 registers (64 contiguous bytes
+// per lane, whole cache lines per wave) instead of scalar loads through an indexed local array
+__global__ __launch_bounds__(256) void softmax16_fwd_kernel(const float* __restrict__ x, long long M, int C, float* __restrict__ y) {
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(x + (size_t)r * 16 + k * 4);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c < C) mx = fmaxf(mx, v[c >> 2][c & 3]);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float e = c < C ? expf(v[c >> 2][c & 3] - mx) : 0.f;
+            v[c >> 2][c & 3] = e; s += e;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c >> 2][c & 3] = v[c >> 2][c & 3] / s;      // same rounding as the generic kernel (v / s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(y + (size_t)r * 16 + k * 4) = v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax16_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long M, int C,
+                                                            float* __restrict__ dx) {
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+        f32x4 d[4], p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d[k] = *reinterpret_cast<const f32x4*>(dy + (size_t)r * 16 + k * 4);
+            p[k] = *reinterpret_cast<const f32x4*>(y + (size_t)r * 16 + k * 4);
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c < C) dot += d[c >> 2][c & 3] * p[c >> 2][c & 3];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) d[c >> 2][c & 3] = c < C ? p[c >> 2][c & 3] * (d[c >> 2][c & 3] - dot) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dx + (size_t)r * 16 + k * 4) = d[k];
+    }
+}
+
 // logits [M][Cp] channel 0 -> disp = sigmoid, depth = 1 / (min_disp + (max_disp - min_disp) * disp)   (planar outputs [M])
 __global__ __launch_bounds__(256) void disp_depth_fwd_kernel(const float* __restrict__ x, long long M, int Cp, float min_disp,
                                                              float max_disp, float* __restrict__ disp, float* __restrict__ depth) {
@@ -1241,14 +1283,16 @@ extern "C" int codeps_guda_gather_bwd(const float* grad_out, int batch, int h, i
 
 extern "C" int codeps_softmax_fwd(const float* x, long long rows, int c, int c_pad, float* y, codeps_stream_t stream) {
     CODEPS_REQUIRE(x && y && rows > 0 && c > 0 && c <= 32 && c <= c_pad, CODEPS_ERR_ARG, "softmax_fwd: bad arguments (c <= 32)");
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, c, c_pad, y);
+    if (c_pad == 16) hipLaunchKernelGGL(softmax16_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, c, y);
+    else hipLaunchKernelGGL(softmax_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, c, c_pad, y);
     CODEPS_CHECK_LAUNCH("softmax_fwd_kernel");
     return CODEPS_OK;
 }
 
 extern "C" int codeps_softmax_bwd(const float* dy, const float* y, long long rows, int c, int c_pad, float* dx, codeps_stream_t stream) {
     CODEPS_REQUIRE(dy && y && dx && rows > 0 && c > 0 && c <= c_pad, CODEPS_ERR_ARG, "softmax_bwd: bad arguments");
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, dy, y, rows, c, c_pad, dx);
+    if (c_pad == 16) hipLaunchKernelGGL(softmax16_bwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, dy, y, rows, c, dx);
+    else hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, dy, y, rows, c, c_pad, dx);
     CODEPS_CHECK_LAUNCH("softmax_bwd_kernel");
     return CODEPS_OK;
 }
