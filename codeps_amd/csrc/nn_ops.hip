@@ -571,21 +571,30 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
         for (int o = 0; o < RS; ++o) a[o] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
+            // branch-free: out-of-image taps load a clamped address and are zeroed afterwards, so the 5 weight and 8 input
+            // loads of a tap column are issued back to back (with the bounds tests as branches every load waited for the last)
             const int ix = ox - 2 + kx;
-            if (ix < 0 || ix >= W) continue;
+            const bool xok = (unsigned)ix < (unsigned)W;
+            const int ixc = min(max(ix, 0), W - 1);
             f32x4 wk[5];
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky)
                 wk[ky] = *reinterpret_cast<const f32x4*>(w25c + (size_t)(flip ? (4 - ky) * 5 + (4 - kx) : ky * 5 + kx) * C + g * 4);
+            f32x4 v[RS + 4];
 #pragma unroll
             for (int ry = 0; ry < RS + 4; ++ry) {
                 const int iy = oy0 - 2 + ry;
-                if (iy < 0 || iy >= H) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + g * 4);
+                v[ry] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + min(max(iy, 0), H - 1)) * W + ixc) * C + g * 4);
+            }
+#pragma unroll
+            for (int ry = 0; ry < RS + 4; ++ry) {
+                const int iy = oy0 - 2 + ry;
+                const bool ok = xok && (unsigned)iy < (unsigned)H;
+                const f32x4 vv = ok ? v[ry] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ky = 0; ky < 5; ++ky) {
                     const int o = ry - ky;                      // output row (oy0 + o) reads input row ry through tap ky
-                    if (o >= 0 && o < RS) a[o] += v * wk[ky];
+                    if (o >= 0 && o < RS) a[o] += vv * wk[ky];
                 }
             }
         }
@@ -630,22 +639,26 @@ __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restr
             const int b = (int)(it / ((long long)W * strips));
             f32x4 g[RS];
 #pragma unroll
-            for (int o = 0; o < RS; ++o)
-                g[o] = (oy0 + o < H) ? *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + oy0 + o) * W + ox) * C + tg * 4)
-                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int o = 0; o < RS; ++o) g[o] = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + min(oy0 + o, H - 1)) * W + ox) * C + tg * 4);
+#pragma unroll
+            for (int o = 0; o < RS; ++o) if (oy0 + o >= H) g[o] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx) {
                 const int ix = ox - 2 + kx;
-                if (ix < 0 || ix >= W) continue;
+                const bool xok = (unsigned)ix < (unsigned)W;
+                const int ixc = min(max(ix, 0), W - 1);
+                f32x4 v[RS + 4];
+#pragma unroll
+                for (int ry = 0; ry < RS + 4; ++ry)          // unconditional loads from clamped addresses, zeroed below
+                    v[ry] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + min(max(oy0 - 2 + ry, 0), H - 1)) * W + ixc) * C + tg * 4);
 #pragma unroll
                 for (int ry = 0; ry < RS + 4; ++ry) {
                     const int iy = oy0 - 2 + ry;
-                    if (iy < 0 || iy >= H) continue;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + tg * 4);
+                    const f32x4 vv = (xok && (unsigned)iy < (unsigned)H) ? v[ry] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ky = 0; ky < 5; ++ky) {
                         const int o = ry - ky;                  // output row oy0 + o reads input row ry through tap ky
-                        if (o >= 0 && o < RS) acc[ky * 5 + kx] += g[o] * v;
+                        if (o >= 0 && o < RS) acc[ky * 5 + kx] += g[o] * vv;
                     }
                 }
             }
