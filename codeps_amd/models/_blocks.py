@@ -8,6 +8,23 @@ from .. import functional as F
 
 _fold_cache = {}
 
+# num_batches_tracked increments of the train-mode BatchNorm layers of the module forward in flight: applied by ONE
+# multi-tensor kernel in flush_bn_counters() (called at the end of every public forward that contains BatchNorm layers)
+# instead of one tiny kernel per layer
+_nbt_pending = []
+
+
+def _count_batch(bn, n):
+    if bn.num_batches_tracked is not None:
+        _nbt_pending.append((bn.num_batches_tracked, n))
+
+
+def flush_bn_counters():
+    if _nbt_pending:
+        with torch.no_grad():
+            torch._foreach_add_([t for t, _ in _nbt_pending], [n for _, n in _nbt_pending])
+        _nbt_pending.clear()
+
 
 def folded_bn(bn: nn.BatchNorm2d):
     """(scale, shift) of an eval-mode BatchNorm, cached while its tensors are unchanged."""
@@ -34,8 +51,7 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
             if bn.training:
                 out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                          residual=residual, act=act, reduce_fn=sync, groups=groups)
-                if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += len(groups) if groups else 1
+                _count_batch(bn, len(groups) if groups else 1)
                 return out
             return F.batch_norm_eval(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual=residual, act=act)
         scale, shift = folded_bn(bn)
@@ -44,8 +60,7 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
         y = F.conv2d(x, conv.weight, stride=stride, pad=pad)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                  residual=residual, act=act, reduce_fn=sync, groups=groups)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += len(groups) if groups else 1
+        _count_batch(bn, len(groups) if groups else 1)
         return out
     if torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad):
         # eval statistics but trainable affine parameters: keep BN as its own op so gamma/beta get gradients
@@ -61,8 +76,7 @@ def dwconv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, sync=None):
         y = F.dwconv5x5(x, conv.weight)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act="relu",
                                  reduce_fn=sync)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        _count_batch(bn, 1)
         return out
     if torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad):
         y = F.dwconv5x5(x, conv.weight)

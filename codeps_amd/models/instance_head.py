@@ -7,7 +7,7 @@ from numpy.typing import ArrayLike
 from torch import Tensor, nn
 
 from .. import functional as F
-from ._blocks import conv_bn, dwconv_bn_relu
+from ._blocks import conv_bn, dwconv_bn_relu, flush_bn_counters
 
 
 def _dwsep(cin, cout):
@@ -50,7 +50,9 @@ class _InstanceDecoder(nn.Module):
         return feat
 
     def forward(self, in_feats) -> Tensor:
-        return F.to_nchw(self.forward_nhwc(in_feats), int(self.num_ch_dec[-1]))
+        out = F.to_nchw(self.forward_nhwc(in_feats), int(self.num_ch_dec[-1]))
+        flush_bn_counters()
+        return out
 
     def __repr__(self):
         return self.net.__repr__()
@@ -74,7 +76,9 @@ class _InstanceHead(nn.Module):
         return F.conv2d(feat, self.net["conv"].weight, self.net["conv"].bias)
 
     def forward(self, in_feats: Tensor) -> Tensor:
-        return F.to_nchw(self.forward_nhwc(F.from_nchw(in_feats)), int(self.num_ch_head[1]))
+        out = F.to_nchw(self.forward_nhwc(F.from_nchw(in_feats)), int(self.num_ch_head[1]))
+        flush_bn_counters()
+        return out
 
     def __repr__(self):
         return self.net.__repr__()
@@ -105,4 +109,5 @@ class InstanceHead(nn.Module):
 
     def forward(self, in_feats) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
         center, offset, thing = self.forward_nhwc(in_feats)
+        flush_bn_counters()
         return F.to_nchw(center, 1), F.to_nchw(offset, 2), (None if thing is None else F.to_nchw(thing, 2))

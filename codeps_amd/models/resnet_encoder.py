@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
-from ._blocks import conv_bn
+from ._blocks import conv_bn, flush_bn_counters
 
 _LAYERS = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]),
            101: ("bottleneck", [3, 4, 23, 3]), 152: ("bottleneck", [3, 8, 36, 3])}
@@ -146,6 +146,7 @@ class ResnetEncoder(nn.Module):
             for block in layer:
                 x = block.forward_nhwc(x, self.sync_bn, groups)
             feats.append(x)
+        flush_bn_counters()
         return [F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]
 
     def forward_pair_groups(self, pairs):
