@@ -1099,12 +1099,15 @@ static int make_groups(int n_groups, const long long* row0, const long long* row
 }
 
 static int mg_blocks(const BnGroups& gr) {
+    // partial blocks per group: ~2048 blocks in total (8 per CU: enough loads in flight for a streaming reduction even when a
+    // single group = plain BatchNorm owns the launch), >= 128 rows each, <= 1024 per group (= the workspace slabs)
     long long mx = 0;
     for (int i = 0; i < gr.n; ++i) mx = std::max(mx, gr.rows[i]);
-    return (int)std::max<long long>(1, std::min<long long>(256, (mx + 127) / 128));
+    const long long cap = std::min<long long>(1024, std::max<long long>(256, 2048 / std::max(gr.n, 1)));
+    return (int)std::max<long long>(1, std::min<long long>(cap, (mx + 127) / 128));
 }
 
-extern "C" size_t codeps_bn_mg_workspace_bytes(int n_groups, int c) { return (size_t)n_groups * 256 * 2 * c * sizeof(float); }
+extern "C" size_t codeps_bn_mg_workspace_bytes(int n_groups, int c) { return (size_t)n_groups * 1024 * 2 * c * sizeof(float); }
 
 extern "C" int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* row0, const long long* rows, int c, int c_real,
                                 const float* gamma, const float* beta, const float* residual, int act, float eps, float momentum,
