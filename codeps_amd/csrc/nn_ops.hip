@@ -555,62 +555,69 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w25c,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                       int B, int H, int W, int C, int flip, float* __restrict__ y) {
-    // one thread per (column, 4-channel group) and strip of RS output rows: the RS + 4 input rows of a strip are loaded
-    // once per tap column and feed all RS outputs (13 loads per tap column for 4 outputs instead of 40)
-    constexpr int RS = 4;
-    const int G = C / 4, strips = (H + RS - 1) / RS;
-    const long long total = (long long)B * strips * W * G;
+    // one thread per 4-channel group and RS x CS block of output pixels: the (RS + 4) x (CS + 4) input patch is loaded once
+    // (48 loads + 25 weights for 8 outputs); branch-free: out-of-image taps load a clamped address and are zeroed afterwards,
+    // so the loads of a patch column are issued back to back
+    constexpr int RS = 4, CS = 2;
+    const int G = C / 4, strips = (H + RS - 1) / RS, cols = (W + CS - 1) / CS;
+    const long long total = (long long)B * strips * cols * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int g = (int)(i % G);
         long long r = i / G;
-        const int ox = (int)(r % W); r /= W;
+        const int ox0 = (int)(r % cols) * CS; r /= cols;
         const int oy0 = (int)(r % strips) * RS;
         const int b = (int)(r / strips);
-        f32x4 a[RS];
+        f32x4 a[RS][CS];
 #pragma unroll
-        for (int o = 0; o < RS; ++o) a[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < RS; ++o)
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) {
-            // branch-free: out-of-image taps load a clamped address and are zeroed afterwards, so the 5 weight and 8 input
-            // loads of a tap column are issued back to back (with the bounds tests as branches every load waited for the last)
-            const int ix = ox - 2 + kx;
+            for (int q = 0; q < CS; ++q) a[o][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 wprev[5];                                         // weights of tap column jx - 1 (for the second output column)
+#pragma unroll
+        for (int jx = 0; jx < CS + 4; ++jx) {                   // input patch column ox0 - 2 + jx
+            const int ix = ox0 - 2 + jx;
             const bool xok = (unsigned)ix < (unsigned)W;
             const int ixc = min(max(ix, 0), W - 1);
             f32x4 wk[5];
+            if (jx < 5) {
 #pragma unroll
-            for (int ky = 0; ky < 5; ++ky)
-                wk[ky] = *reinterpret_cast<const f32x4*>(w25c + (size_t)(flip ? (4 - ky) * 5 + (4 - kx) : ky * 5 + kx) * C + g * 4);
+                for (int ky = 0; ky < 5; ++ky)
+                    wk[ky] = *reinterpret_cast<const f32x4*>(w25c + (size_t)(flip ? (4 - ky) * 5 + (4 - jx) : ky * 5 + jx) * C + g * 4);
+            }
             f32x4 v[RS + 4];
 #pragma unroll
-            for (int ry = 0; ry < RS + 4; ++ry) {
-                const int iy = oy0 - 2 + ry;
-                v[ry] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + min(max(iy, 0), H - 1)) * W + ixc) * C + g * 4);
-            }
+            for (int ry = 0; ry < RS + 4; ++ry)
+                v[ry] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + min(max(oy0 - 2 + ry, 0), H - 1)) * W + ixc) * C + g * 4);
 #pragma unroll
             for (int ry = 0; ry < RS + 4; ++ry) {
                 const int iy = oy0 - 2 + ry;
-                const bool ok = xok && (unsigned)iy < (unsigned)H;
-                const f32x4 vv = ok ? v[ry] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 vv = (xok && (unsigned)iy < (unsigned)H) ? v[ry] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ky = 0; ky < 5; ++ky) {
                     const int o = ry - ky;                      // output row (oy0 + o) reads input row ry through tap ky
-                    if (o >= 0 && o < RS) a[o] += vv * wk[ky];
+                    if (o < 0 || o >= RS) continue;
+                    if (jx < 5) a[o][0] += vv * wk[ky];         // output column ox0:     tap kx = jx
+                    if (jx >= 1) a[o][1] += vv * wprev[ky];     // output column ox0 + 1: tap kx = jx - 1
                 }
             }
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) wprev[ky] = wk[ky];
         }
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (scale) sc = *reinterpret_cast<const f32x4*>(scale + g * 4);
         if (shift) sh = *reinterpret_cast<const f32x4*>(shift + g * 4);
 #pragma unroll
-        for (int o = 0; o < RS; ++o) {
-            if (oy0 + o >= H) continue;
-            f32x4 v = a[o] * sc + sh;
-            if (act == 1) {
+        for (int o = 0; o < RS; ++o)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int q = 0; q < CS; ++q) {
+                if (oy0 + o >= H || ox0 + q >= W) continue;
+                f32x4 v = a[o][q] * sc + sh;
+                if (act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(y + (((size_t)b * H + oy0 + o) * W + ox0 + q) * C + g * 4) = v;
             }
-            *reinterpret_cast<f32x4*>(y + (((size_t)b * H + oy0 + o) * W + ox) * C + g * 4) = v;
-        }
     }
 }
 
@@ -1204,7 +1211,7 @@ extern "C" int codeps_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, i
 extern "C" int codeps_dwconv5x5(const float* x, const float* w25c, const float* scale, const float* shift, int act, int batch, int h,
                                 int w, int c, int flip, float* y, codeps_stream_t stream) {
     CODEPS_REQUIRE(x && w25c && y && batch > 0 && h > 0 && w > 0 && (c % 4) == 0, CODEPS_ERR_ARG, "dwconv5x5: bad arguments");
-    hipLaunchKernelGGL(dwconv5_kernel, dim3(grid_for((long long)batch * ((h + 3) / 4) * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, w25c, scale,
+    hipLaunchKernelGGL(dwconv5_kernel, dim3(grid_for((long long)batch * ((h + 3) / 4) * ((w + 1) / 2) * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, w25c, scale,
                        shift, act, batch, h, w, c, flip, y);
     CODEPS_CHECK_LAUNCH("dwconv5_kernel");
     return CODEPS_OK;
