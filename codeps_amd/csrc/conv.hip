@@ -11,10 +11,13 @@
 //             dgrad    dX[m][n] = sum_{tap,c} dZ(m,tap,c) * Wd[n][tap][c]    m = input pixel,  n = in channel
 //             wgrad    dW[m][n](tap) = sum_p dZ[p][m] * X(p,tap,n)           m = out channel,  n = in channel
 // Block tile (32*WM*TM) x (32*WN*TN), 256 threads = 4 waves (WM x WN), wave tile TM x TN MFMA tiles of
-// 32x32; K-step BK channels of one tap, register-staged global->LDS double buffering (one barrier per
-// K-step); LDS rows padded to BK+4 floats => conflict-free ds_read_b128 fragment reads
-// (row stride 36 or 20 dwords walks all 16 four-bank slots).  blockIdx is remapped so that the
-// N-tiles of one M-tile run on the same XCD (they share the A tile through that XCD's L2).
+// 32x32; K-step BK channels of one tap.  Per block a gather table (byte offset of every row x tap, out-of-range marker
+// for zero padding) is built once; the K loop is buffer_load (hardware zero fill) -> registers -> one LDS stage ->
+// ds_read_b128 fragments -> MFMA, the next stage's loads in flight during the MFMAs.  LDS rows padded to BK+4 floats =>
+// conflict-free ds_read_b128 fragment reads (row stride 36 or 20 dwords walks all 16 four-bank slots).  blockIdx is
+// remapped so that the N-tiles of one M-tile run on the same XCD (they share the A tile through that XCD's L2).
+// Variants: 16-column kernels (N <= 16, v_mfma_f32_16x16x4_f32, operands straight to registers), split-K for small-M
+// launches, per-tap / halo-tile / stem weight-gradient kernels.  DESIGN.md section 3 has the measurements behind each choice.
 #include <stdlib.h>
 
 #include "common.h"
