@@ -38,12 +38,14 @@ def triplet_item(b, h, w, gen, device, labels=False, num_classes=14):
     return d
 
 
-def adapt_batch(h, w, device, seed, n_target=1, n_replay=3, n_source=2, n_mixup=2):
+def adapt_batch(h, w, device, seed, n_target=1, n_replay=3, n_source=2, n_mixup=2, target_hw=None):
     """Per-GPU adaptation batch of BASELINE config 3: 1 target + 3 target_replay + 2 source + 2 cut_mixup
-    (pre-mixed) centre images, all at (h, w)."""
+    (pre-mixed) centre images at (h, w); target_hw = a different size for the target-domain keys (the YAML's
+    384x1408 KITTI-360 crops)."""
     gen = torch.Generator(device=device).manual_seed(seed)
-    data = {"target": triplet_item(n_target, h, w, gen, device),
-            "target_replay": triplet_item(n_replay, h, w, gen, device),
+    th, tw = target_hw if target_hw is not None else (h, w)
+    data = {"target": triplet_item(n_target, th, tw, gen, device),
+            "target_replay": triplet_item(n_replay, th, tw, gen, device),
             "source": triplet_item(n_source, h, w, gen, device, labels=True)}
     mix = triplet_item(n_mixup, h, w, gen, device, labels=True)
     data["cut_mixup"] = {"rgb": {0: mix["rgb"][0]}, "semantic": mix["semantic"]}
