@@ -145,7 +145,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="adapt", choices=["adapt", "train"])
+    ap.add_argument("--mode", default="adapt", choices=["adapt", "train", "frame"],
+                    help="adapt = the BASELINE metric (one adaptation step); train = pretrain step (configs[1]); frame = secondary "
+                         "row: the per-frame evaluation passes of scripts/adapt_codeps.py:164-199 (codeps.frame.pre_step, EMA "
+                         "teacher, shared encoder features) + the adaptation step")
     ap.add_argument("--encoder", type=int, default=None, help="ResNet depth of the shared encoder (adapt: 101, train: 50)")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
@@ -163,6 +166,9 @@ def main():
     from codeps_amd import _lib
     from codeps_amd.distributed import init_from_env
     from codeps_amd.step import StepRunner
+    frame_mode = args.mode == "frame"
+    if frame_mode:
+        args.mode = "adapt"
     rank, local, world = init_from_env(args.dist_backend)
     if os.environ.get("CODEPS_ALL_RANKS_ON_GPU0") == "1":
         local = 0
@@ -208,12 +214,24 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
+    ema = None
+    if frame_mode:
+        import copy
+        from codeps_amd.codeps import pre_step
+        ema = copy.deepcopy(net)                            # scripts/adapt_codeps.py:146 (CodepsNet.ema_model)
+
     def one_step():
+        if frame_mode:
+            sample = {k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items()}
+            pre_step(net, ema, ["semantic_head"], sample, [0, -1, 1], True)
         if graph is not None:
             graph.replay()
             runner.optimizer_step()
         else:
             runner.step(data)
+
+    if frame_mode:
+        one_step()
 
     if world > 1:
         torch.distributed.barrier()
@@ -242,7 +260,8 @@ def main():
     if rank == 0:
         total_images = n_images * world * args.steps
         line = {
-            "metric": "adapt-step images/sec" if args.mode == "adapt" else "pretrain-step images/sec",
+            "metric": ("adapt-frame images/sec (evaluation passes + step)" if frame_mode else "adapt-step images/sec")
+                      if args.mode == "adapt" else "pretrain-step images/sec",
             "value": round(total_images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -56,7 +56,9 @@ class CodepsNet(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, in_data: Dict[str, Any], mode: str = "infer", depth_offsets: Optional[List[int]] = None,
                 do_panoptic_fusion: bool = False, do_class_wise_depth_stats: bool = False,
-                sem_ignore_classes: Optional[List[int]] = None):
+                sem_ignore_classes: Optional[List[int]] = None, feats: Optional[List[Tensor]] = None):
+        """feats ("eval" / "infer" only, not in the reference): the shared encoder's features of the centre frame computed
+        by the caller, so that a teacher and a student with the same frozen encoder run it once (codeps.frame.pre_step)."""
         assert mode in ["train", "eval", "infer", "adapt"], f"Unsupported mode: {mode}"
         if mode == "adapt":
             return self.adapt(in_data, depth_offsets, do_panoptic_fusion)
@@ -96,7 +98,7 @@ class CodepsNet(nn.Module):
                                                 thing_mask=in_data.get("thing_mask"), instance_head=self.instance_head)
         else:       # eval / infer: predictions (and statistics) only
             key_rgb = "rgb" if "rgb" in in_data else "rgb_tgt"
-            feats0 = self.backbone_po_depth(in_data[key_rgb][0])
+            feats0 = feats if feats is not None else self.backbone_po_depth(in_data[key_rgb][0])
             if self.depth_algo is not None:
                 depth_gt = in_data.get("depth") if mode == "eval" else None
                 if depth_gt is None:

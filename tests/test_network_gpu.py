@@ -115,3 +115,37 @@ def test_adaptation_step_against_reference():
     assert bad.mean() < 1e-3 and (z["res_semantic_margin"][bad] < 1e-4).all(), (int(bad.sum()), z["res_semantic_margin"][bad])
     assert result["panoptic"].shape == (1, ht, wt) and result["image_features"].shape[1] == 512
     _check_pgrads(net, z, ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"))
+
+
+def test_pre_step_shares_encoder_features_without_changing_results():
+    """the per-frame evaluation passes (scripts/adapt_codeps.py:164-199) with the frozen encoder run once per
+    image for teacher and student == the reference's separate calls, bit for bit."""
+    import copy
+    import bench
+    from codeps_amd import synthetic
+    from codeps_amd.codeps import pre_step
+    dev = torch.device(DEV)
+    net, _cfg = bench.build(dev, 18, 64, 128, "adapt")
+    from codeps_amd.step import freeze_for_adaptation
+    freeze_for_adaptation(net, _cfg)
+    ema = copy.deepcopy(net)
+    with torch.no_grad():                                   # the EMA'd head differs from the student's
+        for p in ema.semantic_head.parameters():
+            p.mul_(0.9)
+    data, _ = synthetic.adapt_batch(64, 128, dev, 5, 1, 1, 1, 2)
+    def run(share):
+        sample = {k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items()}
+        res, stats = pre_step(net, ema, ["semantic_head"], sample, [0, -1, 1], True, share_encoder=share)
+        return res, sample["cut_mixup"]
+    r1, m1 = run(True)
+    r2, m2 = run(False)
+    for k in ("depth", "semantic", "center", "offset", "panoptic"):
+        assert torch.equal(r1[k], r2[k]), k
+    for k in ("semantic_pred_tgt_ema", "center_pred_tgt_ema", "offset_pred_tgt_ema"):
+        assert torch.equal(m1[k], m2[k]), k
+    # the reference's own call sequence
+    with torch.no_grad():
+        ema.eval()
+        want_sem = ema(data["cut_mixup"], "eval", [0, -1, 1], False, False)[1]["semantic"]
+        want_ctr = net(data["cut_mixup"], "eval", [0, -1, 1], False, False)[1]["center"]
+    assert torch.equal(m1["semantic_pred_tgt_ema"], want_sem) and torch.equal(m1["center_pred_tgt_ema"], want_ctr)
