@@ -249,7 +249,7 @@ def main():
         dt = float(tmax.item())
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:            # every rank runs the profiled steps (they contain the SyncBN / gradient collectives); rank 0 reports
         default_wl = (args.mode == "adapt" and (args.encoder in (None, 101)) and (args.height, args.width) == (512, 1024)
                       and args.per_gpu_batch in (None, 8) and not args.yaml_faithful)
         roof = conv_roofline(runner, data, default_workload=default_wl)
