@@ -280,7 +280,10 @@ def main():
             line["roofline"] = roof
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
