@@ -251,7 +251,25 @@ ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
 # a view into ONE flat fp32 gradient buffer.  The conv backward then accumulates straight into that view
 # (wgrad / bias-reduce epilogues with accumulate=1) and reports no gradient to autograd -> no per-parameter
 # accumulate kernels, and the buffer is ready for a single RCCL all-reduce.
-_grad_sink = {}
+_grad_sink = {}            # id(param) -> (weakref(param), view into the flat gradient buffer)
+
+
+def register_grad_sink(param, view):
+    _grad_sink[id(param)] = (weakref.ref(param), view)
+
+
+def grad_sink(param):
+    """Flat-gradient view registered for exactly this tensor object (ids are re-used once a tensor dies: the weak reference
+    guards against a stale entry answering for a new parameter), else None."""
+    if param is None:
+        return None
+    hit = _grad_sink.get(id(param))
+    if hit is None:
+        return None
+    if hit[0]() is param:
+        return hit[1]
+    del _grad_sink[id(param)]
+    return None
 
 # Optional conv-engine profiler: {"events": [(kind, flops, start_evt, end_evt)]} filled while enabled (bench.py).
 _profile = {"on": False, "events": []}
@@ -305,8 +323,8 @@ class _Conv2d(torch.autograd.Function):
         _prof_end(t0, "conv_fwd", flops, desc)
         ctx.desc, ctx.co, ctx.ci, ctx.has_bias = desc, co, ci, bias is not None
         ctx.flops = flops
-        ctx.w_sink = _grad_sink.get(id(weight)) if weight.requires_grad else None
-        ctx.b_sink = _grad_sink.get(id(bias)) if (bias is not None and bias.requires_grad) else None
+        ctx.w_sink = grad_sink(weight) if weight.requires_grad else None
+        ctx.b_sink = grad_sink(bias) if (bias is not None and bias.requires_grad) else None
         ctx.c0_real = min(ci, x0.shape[3])
         ctx.has_res = residual is not None
         ctx.save_for_backward(x0, x1, y if act else None, wd, sc)
@@ -491,7 +509,7 @@ class _BatchNormTrain(torch.autograd.Function):
         ctx.save_for_backward(x, y if (act and residual is not None) else None, g, b_, mean, invstd)
         ctx.act, ctx.c, ctx.reduce_fn, ctx.has_res, ctx.groups, ctx.per_item = act, c, reduce_fn, residual is not None, groups, per_item
         # flat-gradient sinks of the affine parameters (codeps_amd.step): the backward accumulates dgamma / dbeta in place
-        gs, bs = _grad_sink.get(id(gamma)), _grad_sink.get(id(beta))
+        gs, bs = grad_sink(gamma), grad_sink(beta)
         ctx.sinks = (gs, bs) if (gs is not None and bs is not None and gamma.requires_grad and beta.requires_grad) else None
         return y
 

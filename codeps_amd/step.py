@@ -6,7 +6,7 @@ one pre-training step (scripts/train_codeps.py:97-108).
 
 All trainable parameters live in ONE flat fp32 buffer (views handed back to the nn.Parameters), likewise
 their gradients, Adam moments and the EMA copy; conv weight / bias gradients are accumulated straight into
-the flat buffer by the wgrad / bias kernels (codeps_amd.functional._grad_sink).
+the flat buffer by the wgrad / bias kernels (codeps_amd.functional.register_grad_sink).
 """
 from collections import OrderedDict
 
@@ -57,7 +57,7 @@ class FlatState:
             p.grad = g
             if p.dim() == 4 and p.shape[1] != 1 or (p.dim() == 1 and (getattr(p, "_codeps_conv_bias", False) or
                                                                      getattr(p, "_codeps_bn_affine", False))):
-                F._grad_sink[id(p)] = g
+                F.register_grad_sink(p, g)
             off += k
         self.ema = self.flat.clone() if with_ema else None
         self.numel = n
