@@ -177,6 +177,11 @@ def image_batches_to_nhwc(images, c_pad=16, xpad=(0, 0)):
 _ws_cache = {}
 
 
+def _weak(obj, cache, key):
+    """Weak reference to `obj` that drops cache[key] when the object dies (the caches are keyed by id(), which is re-used)."""
+    return weakref.ref(obj, lambda _r, c=cache, k=key: c.pop(k, None))
+
+
 def _workspace(nbytes, device, tag):
     """Per-(device, tag) scratch buffer, grown on demand (stream-ordered reuse, like a cuDNN workspace)."""
     key = (device.index, tag)
@@ -215,7 +220,7 @@ def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
     wd = torch.empty_like(wf) if need_dgrad else None
     check(lib().codeps_conv2d_pack_weights(co, ci, kh, kw, out_c_pad, in_c_pad, ptr(w), ptr(wf), ptr(wd), stream_ptr()),
           "codeps_conv2d_pack_weights")
-    cache[key] = (weakref.ref(weight), weight.data_ptr(), weight._version, wf, wd)
+    cache[key] = (_weak(weight, cache, key), weight.data_ptr(), weight._version, wf, wd)
     return wf, wd
 
 
@@ -255,7 +260,7 @@ _grad_sink = {}            # id(param) -> (weakref(param), view into the flat gr
 
 
 def register_grad_sink(param, view):
-    _grad_sink[id(param)] = (weakref.ref(param), view)
+    _grad_sink[id(param)] = (_weak(param, _grad_sink, id(param)), view)
 
 
 def grad_sink(param):
@@ -428,7 +433,7 @@ def stem_weight(weight):
     w8 = torch.nn.functional.pad(weight if not frozen else weight.detach(), (1, 0, 0, 0, 0, 8 - ci))      # [co, 8, 7, 8]: kx' = kx + 1
     wp = w8.view(co, 8, 7, 4, 2).permute(0, 4, 1, 2, 3).reshape(co, 16, 7, 4)
     if frozen:
-        _stem_cache[id(weight)] = (weakref.ref(weight), (weight.data_ptr(), weight._version), wp)
+        _stem_cache[id(weight)] = (_weak(weight, _stem_cache, id(weight)), (weight.data_ptr(), weight._version), wp)
     return wp
 
 
@@ -780,7 +785,7 @@ def _dw_pack(weight, c):
     w25 = torch.zeros(25, c, dtype=torch.float32, device=weight.device)
     w25[:, :creal] = weight.detach().reshape(creal, 25).t()
     if frozen:
-        _dw_cache[key] = (weakref.ref(weight), (weight.data_ptr(), weight._version), w25)
+        _dw_cache[key] = (_weak(weight, _dw_cache, key), (weight.data_ptr(), weight._version), w25)
     return w25
 
 

@@ -36,7 +36,7 @@ def folded_bn(bn: nn.BatchNorm2d):
         return hit[1], hit[2]
     with torch.no_grad():
         scale, shift = F.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-    _fold_cache[key] = (ver, scale, shift, weakref.ref(bn))
+    _fold_cache[key] = (ver, scale, shift, weakref.ref(bn, lambda _r, k=key: _fold_cache.pop(k, None)))
     return scale, shift
 
 
