@@ -953,11 +953,12 @@ __global__ __launch_bounds__(256) void wgrad_halo64_kernel(WgradP p, int ci_chun
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Software pipeline over tiles (as in wgrad_small_kernel): tile t + 1 is loaded into registers during the MFMAs of tile t.
     constexpr int NZ = PIX * 16 / 256, NX = (XH * XW * 16 + 255) / 256;
-    for (int tile = t_beg; tile < t_end; ++tile) {
+    f32x4 zr[NZ], xr_[NX];
+    auto load_tile = [&](int tile) {
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
-        f32x4 zr[NZ], xr_[NX];
 #pragma unroll
         for (int u = 0; u < NZ; ++u) {                          // dZ tile: [pixel][64] as float4
             const int i = tid + 256 * u, pix = i >> 4, c4 = i & 15;
@@ -982,6 +983,9 @@ __global__ __launch_bounds__(256) void wgrad_halo64_kernel(WgradP p, int ci_chun
             }
             xr_[u] = v;
         }
+    };
+    if (t_beg < t_end) load_tile(t_beg);
+    for (int tile = t_beg; tile < t_end; ++tile) {
         __syncthreads();                                        // previous tile's MFMAs are done with the LDS
 #pragma unroll
         for (int u = 0; u < NZ; ++u) {
@@ -994,6 +998,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64_kernel(WgradP p, int ci_chun
             if (i < XH * XW * 16) *reinterpret_cast<f32x4*>(Xs + (i >> 4) * LD + (i & 15) * 4) = xr_[u];
         }
         __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);
 #pragma unroll 2
         for (int j = 0; j < PIX / 4; ++j) {                     // k-steps of 4 pixels over the whole tile
             const int pix = j * 4 + q;
