@@ -62,6 +62,7 @@ SIGNATURES = {
     "codeps_photometric_fwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_photometric_bwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_pack_weights": (c_int, [I, I, I, I, I, I, P, P, P, P]),
+    "codeps_conv2d_arith": (c_int, [POINTER(ConvDesc), I, I]),
     "codeps_conv2d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_dgrad": (c_int, [POINTER(ConvDesc), I, P, P, P, P]),

@@ -60,6 +60,24 @@ struct ConvP {
 
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+// Split-precision operands (CODEPS_SPLIT, default 3 pieces): x = p0 + p1 (+ p2) with bf16 pieces (round to nearest each time);
+// bf16 x bf16 products are exact in fp32, so NP = 3 with the six products of order <= 2 reproduces the fp32 product to
+// ~6e-9 relative, NP = 2 with three products to ~4e-6 (tools/split_precision_study.py).
+template <int NP>
+__device__ __forceinline__ void split_bf16(const f32x4 v, u16x4 (&pc)[NP]) {
+    f32x4 r = v;
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)r[e]);
+            pc[q][e] = h;
+            r[e] -= __builtin_bit_cast(float, (unsigned)h << 16);
+        }
+}
 
 // 16 zero floats in global memory: what a gathered load reads when its tap falls into the zero padding
 __device__ __attribute__((aligned(64))) float zero_page[16];
@@ -156,14 +174,15 @@ __device__ __forceinline__ void build_gather(const ConvP& p, int m0, int ntap, u
 
 // One implicit-GEMM kernel for forward and dgrad.
 //   A rows: pixels.  B rows: GEMM columns n (weights packed [n][tap][c], c contiguous).
-template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF>
+template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF, int NP = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* __restrict__ a0,
                                                          const float* __restrict__ a1, const float* __restrict__ wq,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ residual, float* __restrict__ out) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-    constexpr int LDK = BK + 4;                       // padded LDS row (floats): conflict-free b128 fragment reads (an XOR-swizzled
+    static_assert(NP == 0 || (BK == 32 && NBUF == 1), "split-precision variant: BK = 32, single LDS stage");
+    constexpr int LDK = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // padded LDS row (floats): conflict-free b128 fragment reads (an XOR-swizzled
                                                       // unpadded layout was measured 1 % slower on the whole step)
     constexpr int CPR = BK / 4;                       // 16-B chunks per row
     constexpr int RPP = 256 / CPR;                    // rows covered per pass of the 256 threads
@@ -236,11 +255,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
         for (int i = 0; i < APASS; ++i)
-            if (!AGUARD || rbase + RPP * i < BM)
-                *reinterpret_cast<f32x4*>(Ab + (rbase + RPP * i) * LDK + chunk * 4) = areg[i];
+            if (!AGUARD || rbase + RPP * i < BM) {
+                if constexpr (NP == 0) {
+                    *reinterpret_cast<f32x4*>(Ab + (rbase + RPP * i) * LDK + chunk * 4) = areg[i];
+                } else {                                     // row = [piece][32 bf16]; this thread's 4 k values of every piece
+                    u16x4 pc[NP > 0 ? NP : 1];
+                    split_bf16<(NP > 0 ? NP : 1)>(areg[i], pc);
+                    unsigned short* row = reinterpret_cast<unsigned short*>(Ab + (rbase + RPP * i) * LDK);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x4*>(row + q * BK + chunk * 4) = pc[q];
+                }
+            }
 #pragma unroll
         for (int i = 0; i < BPASS; ++i)
-            if (!BGUARD || rbase + RPP * i < BN) *reinterpret_cast<f32x4*>(Bb + (rbase + RPP * i) * LDK + chunk * 4) = breg[i];
+            if (!BGUARD || rbase + RPP * i < BN) {
+                if constexpr (NP == 0) {
+                    *reinterpret_cast<f32x4*>(Bb + (rbase + RPP * i) * LDK + chunk * 4) = breg[i];
+                } else {
+                    u16x4 pc[NP > 0 ? NP : 1];
+                    split_bf16<(NP > 0 ? NP : 1)>(breg[i], pc);
+                    unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + RPP * i) * LDK);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x4*>(row + q * BK + chunk * 4) = pc[q];
+                }
+            }
     };
 
     f32x16 acc[TM][TN];
@@ -263,23 +301,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         if (step + 1 < s_end && CODEPS_ABLATE < 1) load_step(step + 1);           // global loads in flight during the MFMAs
         const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK;
         const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK;
+        if constexpr (NP == 0) {
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            f32x4 af[TM], bf[TN];
-            const int fo = (2 * g + lhalf) * 4;               // lanes < 32 / >= 32 take k and k + 4 of each 8-deep group
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 af[TM], bf[TN];
+                const int fo = (2 * g + lhalf) * 4;               // lanes < 32 / >= 32 take k and k + 4 of each 8-deep group
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + fo);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + fo);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + fo);
-            __builtin_amdgcn_s_setprio(1);
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + fo);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else {
+            // v_mfma_f32_32x32x16_bf16: lane (row = lane % 32, half = lane / 32) holds the 8 consecutive k values 8 * half .. of a
+            // 16-deep chunk; per chunk the products p_a * p_b with a + b < NP, smallest terms first
+#pragma unroll
+            for (int kc = 0; kc < BK / 16; ++kc) {
+                bf16x8 af[TM][NP > 0 ? NP : 1], bf[TN][NP > 0 ? NP : 1];
+                const int ho = kc * 16 + lhalf * 8;               // halfword offset inside a piece
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                    for (int q = 0; q < NP; ++q)
+                        af[i][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Ab + i * 32 * LDK) + q * BK + ho);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        bf[j][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Bb + j * 32 * LDK) + q * BK + ho);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+                    for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
         }
 #if CODEPS_ABLATE >= 2
         continue;
@@ -1195,7 +1264,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF = 2>
+template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF = 2, int NP = 0>
 static void launch_igemm(ConvP p, const float* a0, const float* a1, const float* wq, const float* scale, const float* shift,
                          const float* residual, float* out, hipStream_t st) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -1203,9 +1272,10 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     // K-loop staging buffers + the gather table [sources][taps][BM] behind them; the epilogue tile reuses the front
     const int ntap = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
     const int nsrc = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
-    const size_t lds = std::max(((size_t)NBUF * (BM + BN) * (BK + 4) + (size_t)nsrc * ntap * BM) * sizeof(float),
+    constexpr int LDKf = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // LDS row in floats (split precision: NP pieces x BK bf16 + pad)
+    const size_t lds = std::max(((size_t)NBUF * (BM + BN) * LDKf + (size_t)nsrc * ntap * BM) * sizeof(float),
                                 (size_t)WM * 32 * (BN + 4) * sizeof(float));
-    auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF>;
+    auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, NP>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     // split-K when the tile grid cannot fill the chip and K is deep (B = 1 target inference, 1/32-resolution decoder inputs)
@@ -1270,13 +1340,21 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
     }
     const int nsteps32 = ((MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW)) *
                          (((MODE == MODE_FWD) ? p.Ct : p.Co) / (bk32 ? 32 : 16));
+    // Operand arithmetic of the main kernel.  3 (default): every fp32 operand is the exact sum of three bf16 pieces (8 + 8 + 8 =
+    // 24 significand bits); the six piece products of order <= 2 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
+    // product error ~6e-9 relative, below fp32 rounding (tools/split_precision_study.py), 192 instead of 512 MFMA cycles per
+    // 16-deep chunk.  0: v_mfma_f32_32x32x2_f32.  2: two pieces / three products, ~4e-6 relative: faster still but NOT inside this
+    // repo's parity bar (6 network / trunk tests fail) -- experiments only.
+    static const int split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
     static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;          // tuning experiments only
 #define IG(WM, WN, TM, TN)                                                                          \
     do {                                                                                            \
         /* single LDS buffer (next stage in registers, up to 4 blocks / CU): measured faster than the double-buffered */ \
         /* form on the whole adapt step (63.3 vs 66.2 ms of conv time), so it is the default                          */ \
         const int nbuf = nbuf_env ? nbuf_env : 1;                                                    \
-        if (bk32 && nbuf == 1) launch_igemm<MODE, WM, WN, TM, TN, 32, 1>(p, a0, a1, wq, scale, shift, residual, out, st); \
+        if (bk32 && nbuf == 1 && split_np == 3) launch_igemm<MODE, WM, WN, TM, TN, 32, 1, 3>(p, a0, a1, wq, scale, shift, residual, out, st); \
+        else if (bk32 && nbuf == 1 && split_np == 2) launch_igemm<MODE, WM, WN, TM, TN, 32, 1, 2>(p, a0, a1, wq, scale, shift, residual, out, st); \
+        else if (bk32 && nbuf == 1) launch_igemm<MODE, WM, WN, TM, TN, 32, 1>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else      launch_igemm<MODE, WM, WN, TM, TN, 16>(p, a0, a1, wq, scale, shift, residual, out, st); \
     } while (0)
@@ -1315,6 +1393,28 @@ extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, i
                        out_c_pad, in_c_pad, w_fwd, w_dgrad);
     CODEPS_CHECK_LAUNCH("pack_weights_kernel");
     return CODEPS_OK;
+}
+
+// Which arithmetic a launch of this shape uses: 3 / 2 = fp32 operands as 3 / 2 bf16 pieces on v_mfma_f32_32x32x16_bf16 (main
+// kernel, K chunks of 32 channels), 0 = f32 MFMA (16-column kernels, 16-channel K chunks, CODEPS_SPLIT=0).  mode 0 = forward,
+// 1 = data gradient w.r.t. `source`; weight gradients always run on the f32 MFMA.  Used by bench.py to price each launch
+// against the right peak.
+static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
+    static const int split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
+    static const int force_bk = getenv("CODEPS_FORCE_BK") ? atoi(getenv("CODEPS_FORCE_BK")) : 0;
+    static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;
+    if (split_np != 2 && split_np != 3) return 0;
+    if (force_bk == 16 || (nbuf_env && nbuf_env != 1)) return 0;
+    if (mode == 0) {
+        const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
+        return (d->out_c > 16 && gran % 32 == 0) ? split_np : 0;
+    }
+    const int n = source ? d->c1 : d->c0;
+    return (n > 16 && d->out_c % 32 == 0) ? split_np : 0;
+}
+extern "C" int codeps_conv2d_arith(const codeps_conv_desc* d, int mode, int source) {
+    if (check_conv(d, "conv2d_arith") != CODEPS_OK) return -1;
+    return conv_arith(d, mode, source);
 }
 
 // Split-K workspace: launches whose tile grid cannot fill the chip (M <= 12288 rows) with a deep K are cut into up to 16

@@ -288,7 +288,7 @@ def _prof_begin():
     return e
 
 
-def _prof_end(start, kind, flops, desc=None):
+def _prof_end(start, kind, flops, desc=None, source=0):
     if start is None:
         return
     e = torch.cuda.Event(enable_timing=True)
@@ -297,6 +297,11 @@ def _prof_end(start, kind, flops, desc=None):
     if desc is not None:
         tag = (f"B{desc.batch} {desc.in_h}x{desc.in_w} {desc.c0}+{desc.c1}->{desc.out_c} k{desc.kh} s{desc.stride}"
                f"{' up' if desc.up0 else ''}")
+        # arithmetic of the launch: bf16-split operands on the bf16 MFMA (fwd / dgrad main kernel) or the f32 MFMA
+        if kind == "conv_fwd" and lib().codeps_conv2d_arith(ctypes.byref(desc), 0, 0) > 0:
+            kind = "conv_fwd_split"
+        elif kind == "conv_dgrad" and lib().codeps_conv2d_arith(ctypes.byref(desc), 1, source) > 0:
+            kind = "conv_dgrad_split"
     _profile["events"].append((kind, flops, start, e, tag))
 
 
@@ -386,7 +391,7 @@ class _Conv2d(torch.autograd.Function):
             t0 = _prof_begin()
             check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 1, ptr(dz), ptr(wd), ptr(dx1), stream_ptr()),
                   "codeps_conv2d_dgrad")
-            _prof_end(t0, "conv_dgrad", ctx.flops * (1 - ctx.c0_real / ctx.ci), desc)
+            _prof_end(t0, "conv_dgrad", ctx.flops * (1 - ctx.c0_real / ctx.ci), desc, 1)
         if ctx.needs_input_grad[2]:
             sink = ctx.w_sink
             dw = sink if sink is not None else torch.empty(ctx.co, ctx.ci, desc.kh, desc.kw, dtype=torch.float32, device=dy.device)

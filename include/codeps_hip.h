@@ -86,6 +86,11 @@ typedef struct {
 /* OIHW [out_c][in_c][kh][kw] -> w_fwd [out_c_pad][kh*kw][in_c_pad] and/or w_dgrad [in_c_pad][kh*kw][out_c_pad]. */
 int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
                                const float* w_oihw, float* w_fwd, float* w_dgrad, codeps_stream_t stream);
+/* Arithmetic of a launch of this shape (mode 0 forward, 1 data gradient w.r.t. `source`): 3 = every fp32 operand as the exact
+ * sum of three bf16 pieces, six piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (product error ~6e-9
+ * relative, below fp32 rounding); 0 = v_mfma_f32_*_f32 (16-column kernels, 16-channel K chunks, all weight gradients).
+ * Reporting only (bench.py prices each launch against the matching peak). */
+int codeps_conv2d_arith(const codeps_conv_desc* d, int mode, int source);
 /* workspace (optional, may be NULL): scratch for split-K partial sums; codeps_conv2d_fwd_workspace_bytes(d) is the size
  * that enables it for this shape (0 = never splits).  Small-M / deep-K launches (B = 1 inference, 1/32-resolution
  * layers) are cut into K slices + a fixed-order finish pass so that they still fill the 256 CUs. */
