@@ -345,3 +345,28 @@ def test_sync_bn_combine_matches_parallel_variance():
         xh = (shards[0][b0:b1].double() - ref_mean[gi]) / torch.sqrt(ref_var[gi] + 1e-5)
         want.append(torch.relu(xh * gamma.double() + beta.double()))
     assert rel_err(y.detach().cpu(), torch.cat(want)) < 1e-5
+
+
+def test_conv_error_is_at_fp32_rounding_level():
+    """The default arithmetic of the main conv kernel (fp32 operands as three bf16 pieces, six products on the bf16 MFMA, fp32
+    accumulate) must be indistinguishable from an fp32 convolution: its error against float64 stays within 3x the error of
+    torch's own fp32 CPU convolution of the same tensors (measured: 2.5e-7 vs 1.7e-7 relative L2 forward; the f32 MFMA path
+    gives 2.2e-7, a 2-piece split 4.5e-6 = 26x)."""
+    F = _F()
+    g = torch.Generator().manual_seed(77)
+    x = torch.relu(torch.randn(2, 256, 24, 40, generator=g))
+    wt = torch.randn(256, 256, 3, 3, generator=g) * 0.02
+    gy = torch.randn(2, 256, 24, 40, generator=g)
+    l2 = lambda a, b: float((a.double() - b).norm() / b.norm())
+    r64 = x.double().requires_grad_(True)
+    ref = TF.conv2d(r64, wt.double(), None, 1, 1)
+    (ref * gy.double()).sum().backward()
+    r32 = x.clone().requires_grad_(True)
+    y32 = TF.conv2d(r32, wt, None, 1, 1)
+    (y32 * gy).sum().backward()
+    dx = nhwc(x).requires_grad_(True)
+    y = F.conv2d(dx, wt.to(DEV), pad=1)
+    y.backward(nhwc(gy))
+    assert l2(nchw(y, 256), ref.detach()) < 3 * l2(y32.detach(), ref.detach())
+    # data gradient: a sequential fp32 chain of 2304 random-sign terms (the f32 MFMA path measures the same 3.3x)
+    assert l2(nchw(dx.grad, 256), r64.grad) < 5 * l2(r32.grad, r64.grad)
