@@ -1,7 +1,10 @@
-// NHWC fp32 implicit-GEMM convolution engine on the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32):
+// NHWC fp32 implicit-GEMM convolution engine on the gfx950 matrix cores:
 // forward (+fused nearest-x2 upsample of source 0, concat-by-pointer of two sources, zero / reflect
 // padding, per-channel affine (folded eval BatchNorm or bias), residual add, ReLU / ELU), data gradient
-// and weight gradient.  Exact f32 arithmetic (MFMA f32 == k-ordered fmaf chain), no reduced precision.
+// and weight gradient.  fp32 in, fp32 out, fp32 accumulation.  The main forward / data-gradient kernel feeds the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16) with every fp32 operand split EXACTLY into three bf16 pieces and sums the six piece products of
+// order <= 2 (error <= 2^-24 per product, below fp32 rounding; 2.7x fewer MFMA cycles than v_mfma_f32_32x32x2_f32, which
+// weight gradients, 16-column kernels and CODEPS_SPLIT=0 use).  No reduced precision.
 //
 // Replaces the ATen/cuDNN convolutions behind: torchvision ResNet (models/resnet_encoder.py:115-126),
 // DepthHead / SemanticHead decoders (models/depth_head.py:60-71, models/semantic_head.py:50-72),
