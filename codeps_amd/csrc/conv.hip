@@ -65,10 +65,17 @@ struct ConvP {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 // Split-precision operands (CODEPS_SPLIT, default 3 pieces): x = p0 + p1 (+ p2) with bf16 pieces (round to nearest each time);
 // bf16 x bf16 products are exact in fp32, so NP = 3 with the six products of order <= 2 reproduces the fp32 product to
 // ~6e-9 relative, NP = 2 with three products to ~4e-6 (tools/split_precision_study.py).
+// eight bf16 values (k .. k + 7) as one 16-byte LDS store
+__device__ __forceinline__ i32x4 pack8(const u16x4 a, const u16x4 b) {
+    return i32x4{(int)((unsigned)a[0] | ((unsigned)a[1] << 16)), (int)((unsigned)a[2] | ((unsigned)a[3] << 16)),
+                 (int)((unsigned)b[0] | ((unsigned)b[1] << 16)), (int)((unsigned)b[2] | ((unsigned)b[3] << 16))};
+}
+
 template <int NP>
 __device__ __forceinline__ void split_bf16(const f32x4 v, u16x4 (&pc)[NP]) {
     f32x4 r = v;
@@ -187,7 +194,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     static_assert(NP == 0 || (BK == 32 && NBUF == 1), "split-precision variant: BK = 32, single LDS stage");
     constexpr int LDK = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // padded LDS row (floats): conflict-free b128 fragment reads (an XOR-swizzled
                                                       // unpadded layout was measured 1 % slower on the whole step)
-    constexpr int CPR = BK / 4;                       // 16-B chunks per row
+    constexpr int KPT = NP > 0 ? 8 : 4;               // consecutive k values staged per thread and row (split kernel: 8, so that each bf16
+                                                      // piece goes to LDS as one 16-B write)
+    constexpr int SUB = KPT / 4;                      // 16-B global loads per staged chunk
+    constexpr int CPR = BK / KPT;                     // chunks per row
     constexpr int RPP = 256 / CPR;                    // rows covered per pass of the 256 threads
     constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -227,9 +237,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(wq, (size_t)p.N * wrow * 4);
     unsigned boff[BPASS];
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)(((size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow + chunk * 4) * 4);
+    for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)(((size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow + chunk * KPT) * 4);
 
-    f32x4 areg[APASS], breg[BPASS];
+    f32x4 areg[APASS * SUB], breg[BPASS * SUB];
 
     auto load_step = [&](int step) {
         const int tap = step / steps_per_tap;
@@ -237,12 +247,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         // ---- A operand
         const bool s1 = MODE == MODE_FWD && cstep >= p.C0;        // which source this chunk belongs to
         const __amdgpu_buffer_rsrc_t rs = s1 ? rs1 : rs0;
-        const unsigned coff = (unsigned)((s1 ? cstep - p.C0 : cstep) + chunk * 4) * 4u;
+        const unsigned coff = (unsigned)((s1 ? cstep - p.C0 : cstep) + chunk * KPT) * 4u;
         const unsigned* t = tab + ((s1 ? ntap : 0) + tap) * BM + rbase;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const unsigned off = t[(AGUARD && rbase + RPP * i >= BM) ? 0 : RPP * i];
-            areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + coff, 0, 0));
+#pragma unroll
+            for (int u = 0; u < SUB; ++u)
+                areg[i * SUB + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + coff + 16 * u, 0, 0));
         }
         // ---- B operand (packed weights, K contiguous)
         int koff;
@@ -251,7 +263,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         else koff = tap * Kc + cstep;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i)
-            breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + (unsigned)koff * 4u, 0, 0));
+#pragma unroll
+            for (int u = 0; u < SUB; ++u)
+                breg[i * SUB + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + (unsigned)koff * 4u + 16 * u, 0, 0));
     };
     auto store_step = [&](int buf) {
         float* Ab = As + buf * BM * LDK;
@@ -261,12 +275,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
             if (!AGUARD || rbase + RPP * i < BM) {
                 if constexpr (NP == 0) {
                     *reinterpret_cast<f32x4*>(Ab + (rbase + RPP * i) * LDK + chunk * 4) = areg[i];
-                } else {                                     // row = [piece][32 bf16]; this thread's 4 k values of every piece
-                    u16x4 pc[NP > 0 ? NP : 1];
-                    split_bf16<(NP > 0 ? NP : 1)>(areg[i], pc);
+                } else {                                     // row = [piece][32 bf16]; this thread's 8 k values of every piece: one b128 each
+                    u16x4 lo[NP > 0 ? NP : 1], hi[NP > 0 ? NP : 1];
+                    split_bf16<(NP > 0 ? NP : 1)>(areg[i * SUB], lo);
+                    split_bf16<(NP > 0 ? NP : 1)>(areg[i * SUB + SUB - 1], hi);
                     unsigned short* row = reinterpret_cast<unsigned short*>(Ab + (rbase + RPP * i) * LDK);
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x4*>(row + q * BK + chunk * 4) = pc[q];
+                    for (int q = 0; q < NP; ++q)
+                        *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = pack8(lo[q], hi[q]);
                 }
             }
 #pragma unroll
@@ -275,11 +291,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                 if constexpr (NP == 0) {
                     *reinterpret_cast<f32x4*>(Bb + (rbase + RPP * i) * LDK + chunk * 4) = breg[i];
                 } else {
-                    u16x4 pc[NP > 0 ? NP : 1];
-                    split_bf16<(NP > 0 ? NP : 1)>(breg[i], pc);
+                    u16x4 lo[NP > 0 ? NP : 1], hi[NP > 0 ? NP : 1];
+                    split_bf16<(NP > 0 ? NP : 1)>(breg[i * SUB], lo);
+                    split_bf16<(NP > 0 ? NP : 1)>(breg[i * SUB + SUB - 1], hi);
                     unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + RPP * i) * LDK);
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x4*>(row + q * BK + chunk * 4) = pc[q];
+                    for (int q = 0; q < NP; ++q)
+                        *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = pack8(lo[q], hi[q]);
                 }
             }
     };
