@@ -107,6 +107,10 @@ SIGNATURES = {
     "codeps_panoptic_workspace_bytes": (c_size_t, [I, I, I]),
     "codeps_panoptic_fusion": (c_int, [P, P, P, I, I, I, ctypes.c_ulonglong, I, I, c_float, I, I, P, P, P, P, P, c_size_t, P]),
     "codeps_image_warp": (c_int, [P, P, P, P, I, I, I, I, I, P, P, P]),
+    "codeps_warp_c2c": (c_int, [P, I, P, P, I, I, I, I, I, I, I, I, ctypes.c_double, P, P]),
+    "codeps_cut_mixup": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, ctypes.c_double, P, P, P, P]),
+    "codeps_offset_center_workspace_bytes": (c_size_t, [I]),
+    "codeps_offset_center": (c_int, [P, I, I, I, ctypes.c_double, P, P, P, P, c_size_t, P]),
     "codeps_adam_ema_step": (c_int, [P, P, P, P, P, LL, I, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 

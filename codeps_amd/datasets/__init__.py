@@ -1,0 +1,2 @@
+"""Host-side mirrors of the reference's `datasets` package that sit on the adapt path."""
+from .mixup import Mixup  # noqa: F401

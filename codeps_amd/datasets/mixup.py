@@ -1,0 +1,123 @@
+"""Mixup: device-side mirror of datasets/mixup.py for the strategies the adaptation YAMLs select.
+
+`Mixup.do_mixup(strategy, mixup_data, instance_algo, cfg_mixup)` has the reference's signature, input dict and output dict
+(datasets/mixup.py:406-489) and is what CodepsNet.adapt calls for every `*mixup` key (codeps/online_adap.py:331-335;
+install it with `net.mixup_fn = Mixup.do_mixup`).  Differences in HOW, not WHAT:
+  * the three float64 `grid_sample` warps and the three boolean-mask scatters of `cut_mixup` run as ONE kernel that only
+    warps pixels inside the cut rectangles (codeps_cut_mixup);
+  * the centre / offset ground truth is regenerated on the device (codeps_offset_center) instead of the reference's
+    per-image D2H copy -> numpy loop -> H2D copy (mixup.py:243-257);
+  * nothing synchronises the host: the cell choice is the reference's own `np.random.choice` call sequence (host RNG,
+    mixup.py:108), everything else is enqueued on the current stream.
+`class_mixup` / `conf_instance_mixup` are not selected by either adaptation YAML (cfg/adapt_*.yaml:34) and raise.
+"""
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import functional as F
+from .._lib import CodepsHipError
+from ..misc.camera_model import CameraModel
+
+
+def _intr(models_or_tensor) -> Tensor:
+    if isinstance(models_or_tensor, Tensor):
+        return models_or_tensor
+    return CameraModel.batch_tensor(models_or_tensor)
+
+
+class Mixup:
+    _pending_status: List[Any] = []             # (pinned host copy of an offset_center status word, event), checked lazily
+
+    def __init__(self):
+        pass
+
+    # ------------------------------------------------------------------ building blocks (reference names)
+    @staticmethod
+    def warp_c2c(cam_model_src, cam_model_tgt, in_src: Tensor, in_tgt: Tensor, depth_val: Optional[float] = 1,
+                 interp_mode="bilinear", padding_mode="border") -> Tensor:
+        """mixup.py:211-229: `in_src` (seen by cam_model_src) resampled into cam_model_tgt's view, the size of `in_tgt`.
+        Camera models: lists of CameraModel like the reference, or a [B,4] intrinsics tensor.  Returns in_src's dtype
+        (the reference returns the float64 intermediate and casts afterwards; the rounding is the same single one)."""
+        dev = in_src.device
+        return F.warp_c2c(in_src, _intr(cam_model_src).to(dev), _intr(cam_model_tgt).to(dev), in_tgt.shape[-2:], interp_mode,
+                          padding_mode, depth_val)
+
+    @staticmethod
+    def get_off_cen(lbl_inst_mixup: Tensor):
+        """mixup.py:243-257 -> (center [B,1,H,W], offset [B,2,H,W]) fp32, sigma 8 (dataset.py:126)."""
+        center, offset, status = F.offset_center(lbl_inst_mixup, 8.0)
+        host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+        host.copy_(status, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        Mixup._pending_status.append((host, done))
+        return center, offset
+
+    @staticmethod
+    def check():
+        """Raise if an earlier get_off_cen met more distinct instance ids than the device table holds.  Called at the start
+        of every do_mixup: only status words whose copy to pinned host memory has already completed are looked at (at most
+        a handful stay queued), so the host never waits for the stream here."""
+        keep = []
+        for host, done in Mixup._pending_status:
+            if not done.query():
+                if len(Mixup._pending_status) > 16:
+                    done.synchronize()
+                else:
+                    keep.append((host, done))
+                    continue
+            if bool((host < 0).any()):
+                Mixup._pending_status = []
+                raise CodepsHipError("codeps_offset_center: more than 4096 distinct instance ids in one image")
+        Mixup._pending_status = keep
+
+    @staticmethod
+    def _cut_cells(batch: int, nof_vert_split: int, nof_hor_split: int, height: int, width: int, nof_segments: int) -> np.ndarray:
+        """The reference's cell draw (mixup.py:96-146; the rare-class branch is dead code there: `or True`, :106) ->
+        rectangles [B,nof_segments,4] = (y0, y1, x0, x1), end-exclusive with the reference's '-1' (mixup.py:138-144)."""
+        crop_h, crop_w = height // nof_vert_split, width // nof_hor_split
+        rects = np.empty((batch, nof_segments, 4), np.int32)
+        for b in range(batch):
+            split_ids = np.random.choice(nof_vert_split * nof_hor_split, nof_segments, replace=False)
+            for s, split_id in enumerate(split_ids):
+                mul_x, mul_y = int(split_id) % nof_hor_split, int(split_id) // nof_hor_split
+                rects[b, s] = (mul_y * crop_h, (mul_y + 1) * crop_h - 1, mul_x * crop_w, (mul_x + 1) * crop_w - 1)
+        return rects
+
+    # ------------------------------------------------------------------ entry point
+    @staticmethod
+    def do_mixup(mixup_strategy: str, mixup_data: Dict[str, Any], instance_algo, cfg_mixup) -> Dict[str, Any]:
+        Mixup.check()
+        if mixup_strategy != "cut_mixup":
+            raise NotImplementedError(f"mixup strategy {mixup_strategy!r}: only 'cut_mixup' (cfg/adapt_*.yaml:34) is built")
+        img_src = mixup_data["rgb_src"][0]
+        img_tgt = mixup_data["rgb_tgt"][0]
+        semantic_src, instance_src = mixup_data["semantic_src"], mixup_data["instance_src"]          # [B,1,H,W]
+        semantic_pred = mixup_data["semantic_pred_tgt_ema"].detach()
+        center_pred = mixup_data["center_pred_tgt_ema"].detach()
+        offset_pred = mixup_data["offset_pred_tgt_ema"].detach()
+        _, instance_pred = instance_algo.panoptic_fusion(semantic_pred, center_pred, offset_pred)
+        b, _, h, w = img_src.shape
+        geom = bool(cfg_mixup.general.geom_augment)
+        if not geom and img_tgt.shape != img_src.shape:
+            raise AssertionError("Not implemented")                                      # mixup.py:150
+        cm = cfg_mixup.cut_mix
+        rects = torch.from_numpy(Mixup._cut_cells(b, cm.nof_vert_splits, cm.nof_hor_splits, h, w, cm.nof_segments))
+        dev = img_src.device
+        rects = rects.to(dev, non_blocking=True)
+        intr_src = mixup_data["camera_model_src"].to(dev) if geom else None
+        intr_tgt = mixup_data["camera_model_tgt"].to(dev) if geom else None
+        rgb, sem, inst = F.cut_mixup(img_src, img_tgt, semantic_src.reshape(b, h, w), semantic_pred, instance_src.reshape(b, h, w),
+                                     instance_pred, rects, intr_src, intr_tgt)
+        center, offset = Mixup.get_off_cen(inst)
+        return {
+            "rgb": {0: rgb},
+            "camera_model": mixup_data["camera_model_src"],
+            "semantic": sem.to(semantic_src.dtype),
+            "center": center,
+            "offset": offset,
+            "instance": inst.to(instance_src.dtype),
+        }

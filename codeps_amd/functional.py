@@ -1081,3 +1081,73 @@ def panoptic_fusion(semantic, center, offset, thing_list, label_divisor=1000, vo
     if semantic.dtype != torch.uint8:
         inst = inst.to(semantic.dtype)
     return pan, inst, centers, state
+
+
+# ------------------------------------------------------------------------------------------------ mix-up
+_C2C_DTYPES = {torch.float32: 0, torch.uint8: 1, torch.int32: 2}
+
+
+def warp_c2c(in_maps, intr_in, intr_out, out_hw, interp_mode="bilinear", padding_mode="border", depth_val=1.0):
+    """Mixup.warp_c2c (datasets/mixup.py:211-229): in_maps [B,C,hs,ws] (or [B,hs,ws] -> C = 1) seen by cameras intr_in
+    [B,4] -> [B,C,ho,wo] as seen by cameras intr_out; float64 sampling arithmetic, stored in in_maps' dtype (fp32 for
+    images; uint8 / int32 / int64 label maps, nearest only)."""
+    require_cuda(in_maps, intr_in, intr_out)
+    if interp_mode not in ("bilinear", "nearest") or padding_mode not in ("zeros", "border"):
+        raise ValueError(f"warp_c2c: interp_mode {interp_mode!r} / padding_mode {padding_mode!r} not supported")
+    x = in_maps.unsqueeze(1) if in_maps.dim() == 3 else in_maps
+    orig = x.dtype
+    if orig == torch.int64 or orig == torch.int16:
+        x = x.to(torch.int32)
+    elif orig not in _C2C_DTYPES:
+        x = x.float()
+    if interp_mode == "bilinear" and x.dtype != torch.float32:
+        raise TypeError("warp_c2c: bilinear sampling of an integer map")
+    x = x.contiguous()
+    b, c, hs, ws = x.shape
+    ho, wo = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty(b, c, ho, wo, dtype=x.dtype, device=x.device)
+    check(lib().codeps_warp_c2c(ptr(x), _C2C_DTYPES[x.dtype], ptr(_f32c(intr_in)), ptr(_f32c(intr_out)), b, c, hs, ws, ho, wo,
+                                int(interp_mode == "nearest"), int(padding_mode == "border"), float(depth_val), ptr(out), stream_ptr()),
+          "codeps_warp_c2c")
+    return out if out.dtype == orig else out.to(orig)
+
+
+def cut_mixup(img_src, img_tgt, sem_src, sem_tgt, inst_src, inst_tgt, rects, intr_src=None, intr_tgt=None, depth_val=1.0):
+    """Mixup.cut_mixup (datasets/mixup.py:314-344) fused with do_mixup's camera-to-camera warps (mixup.py:431-441).
+    img_* [B,3,.,.] fp32, label maps [B,.,.] int32, rects [B,nseg,4] int32 (y0, y1, x0, x1; end-exclusive)
+    -> (rgb_mixup fp32 [B,3,H,W], semantic int32 [B,H,W], instance int32 [B,H,W])."""
+    require_cuda(img_src, img_tgt, sem_src, sem_tgt, inst_src, inst_tgt, rects)
+    b, _, h, w = img_src.shape
+    ht, wt = img_tgt.shape[-2:]
+    img_src, img_tgt = _f32c(img_src), _f32c(img_tgt)
+    labels = [t.contiguous() if t.dtype == torch.int32 else t.to(torch.int32).contiguous() for t in (sem_src, sem_tgt, inst_src, inst_tgt)]
+    rects = rects.to(torch.int32).contiguous()
+    dev = img_src.device
+    rgb = torch.empty(b, 3, h, w, dtype=torch.float32, device=dev)
+    sem = torch.empty(b, h, w, dtype=torch.int32, device=dev)
+    inst = torch.empty(b, h, w, dtype=torch.int32, device=dev)
+    geom = intr_src is not None and intr_tgt is not None
+    check(lib().codeps_cut_mixup(ptr(img_src), ptr(img_tgt), ptr(labels[0]), ptr(labels[1]), ptr(labels[2]), ptr(labels[3]),
+                                 ptr(_f32c(intr_src)) if geom else None, ptr(_f32c(intr_tgt)) if geom else None, ptr(rects),
+                                 rects.shape[1], b, h, w, ht, wt, float(depth_val), ptr(rgb), ptr(sem), ptr(inst), stream_ptr()),
+          "codeps_cut_mixup")
+    return rgb, sem, inst
+
+
+def offset_center(instance, sigma=8.0):
+    """Mixup.get_off_cen (datasets/mixup.py:243-257 -> datasets/dataset.py:126-177) on the device: instance [B,(1,)H,W]
+    integer ids -> (center fp32 [B,1,H,W], offset fp32 [B,2,H,W], status int32 [B] = #instances or -1 on overflow).
+    No host sync: read `status` when convenient (Mixup.check does)."""
+    require_cuda(instance)
+    inst = instance.reshape((instance.shape[0],) + tuple(instance.shape[-2:]))
+    inst = inst.contiguous() if inst.dtype == torch.int32 else inst.to(torch.int32).contiguous()
+    b, h, w = inst.shape
+    dev = inst.device
+    center = torch.empty(b, 1, h, w, dtype=torch.float32, device=dev)
+    offset = torch.empty(b, 2, h, w, dtype=torch.float32, device=dev)
+    status = torch.empty(b, dtype=torch.int32, device=dev)
+    nbytes = lib().codeps_offset_center_workspace_bytes(b)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().codeps_offset_center(ptr(inst), b, h, w, float(sigma), ptr(center), ptr(offset), ptr(status), ptr(ws), nbytes,
+                                     stream_ptr()), "codeps_offset_center")
+    return center, offset, status

@@ -292,6 +292,37 @@ int codeps_panoptic_fusion(const uint8_t* semantic, const float* center, const f
 int codeps_image_warp(const float* src, const float* depth, const float* pose, const float* intr, int batch,
                       int c, int h, int w, int nearest, float* out, float* grid, codeps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pseudo-label mix-up on the device (Mixup.do_mixup, datasets/mixup.py:406-489, called from
+ * CodepsNet.adapt, codeps/online_adap.py:331-335).  Camera intrinsics are [B,4] fp32 = (fx, fy, cx, cy)
+ * (CameraModel.to_tensor, misc/camera_model.py:22-23); images / label maps are NCHW planar like the reference's.
+ *
+ * K15  Mixup.warp_c2c (mixup.py:211-229): out [B,c,ho,wo] = grid_sample(in.double(), grid.double(),
+ *      align_corners=True) where the grid is the projection of the OUTPUT camera's viewing rays (intr_out, ho x wo,
+ *      depth depth_val) into the INPUT camera (intr_in, hs x ws).  float64 coordinates / weights in the reference's
+ *      operation order; the result is rounded once to the storage type.  dtype: 0 = fp32, 1 = uint8, 2 = int32;
+ *      nearest = 1 -> mode "nearest" (the only mode for integer maps); border = 1 -> padding_mode "border", else "zeros". */
+int codeps_warp_c2c(const void* in, int dtype, const float* intr_in, const float* intr_out, int batch, int c, int hs, int ws,
+                    int ho, int wo, int nearest, int border, double depth_val, void* out, codeps_stream_t stream);
+/* K16  Mixup.cut_mixup (mixup.py:314-344) fused with the three warp_c2c calls that precede it in do_mixup
+ *      (mixup.py:431-441: target image bilinear / zeros, teacher instance map nearest / zeros, teacher semantic map
+ *      nearest / border): inside the rectangles rects [B][nseg][4] = (y0, y1, x0, x1), end-exclusive exactly like the
+ *      reference's slices (mixup.py:138-144 -- note its "-1"), the outputs take the (warped) target values, elsewhere the
+ *      source's.  intr_src / intr_tgt NULL <=> cfg.general.geom_augment False (then ht x wt must equal h x w).
+ *      img_* [B,3,.,.] fp32, label maps [B,.,.] int32. */
+int codeps_cut_mixup(const float* img_src, const float* img_tgt, const int* sem_src, const int* sem_tgt, const int* inst_src,
+                     const int* inst_tgt, const float* intr_src, const float* intr_tgt, const int* rects, int nseg, int batch,
+                     int h, int w, int ht, int wt, double depth_val, float* rgb_mix, int* sem_mix, int* inst_mix,
+                     codeps_stream_t stream);
+/* K17  Mixup.get_off_cen (mixup.py:243-257) -> Dataset.get_offset_center (datasets/dataset.py:126-177) without the
+ *      device->host->device round trip: instance int32 [B,H,W] (0 = stuff / unlabeled) -> center fp32 [B,1,H,W]
+ *      (max of the per-instance Gaussians of width sigma around the rounded centre of mass), offset fp32 [B,2,H,W]
+ *      ((dy, dx) to the float64 centre of mass), status int32 [B] = number of instances, or -1 when an image holds
+ *      more than 4096 distinct ids (outputs then invalid; the host mirror raises). */
+size_t codeps_offset_center_workspace_bytes(int batch);
+int codeps_offset_center(const int* instance, int batch, int h, int w, double sigma, float* center, float* offset, int* status,
+                         void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,8 +63,13 @@ def smooth_image(batch, h, w, seed, channels=3):
     """Low-pass noise in [0,1], then ImageNet-style normalisation (SURVEY.md §8d synthetic rgb)."""
     g = _rng(seed)
     coarse = g.uniform(0, 1, (batch, channels, max(h // 8, 2), max(w // 8, 2))).astype(np.float32)
-    img = torch.nn.functional.interpolate(torch.from_numpy(coarse), (h, w), mode="bilinear",
-                                          align_corners=False)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)            # the interpolation kernel's rounding depends on how the work is split across threads
+    try:
+        img = torch.nn.functional.interpolate(torch.from_numpy(coarse), (h, w), mode="bilinear",
+                                              align_corners=False)
+    finally:
+        torch.set_num_threads(nthreads)
     img = img + torch.from_numpy(g.normal(0, 0.02, (batch, channels, h, w)).astype(np.float32))
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)[:, :channels]
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)[:, :channels]
@@ -140,3 +145,33 @@ def center_heatmap(batch, h, w, seed, n_max=20, sigma=8.0):
 
 def offsets(batch, h, w, seed, mag=64.0):
     return uniform((batch, 2, h, w), seed + 23, -mag, mag)
+
+
+def instance_labels(semantic, seed, things=(9, 10, 11, 12, 13), block=8, per_class=5):
+    """Instance-id map [B,1,H,W] int32 for a blocky semantic map [B,H,W]: thing blocks get class*1000 + k (several
+    disjoint blocks may share an id, like occluded objects), stuff / void pixels 0."""
+    g = _rng(seed + 29)
+    sem = semantic.numpy().astype(np.int64)
+    b, h, w = sem.shape
+    k = g.integers(1, per_class + 1, (b, -(-h // block), -(-w // block)))
+    k = np.repeat(np.repeat(k, block, 1), block, 2)[:, :h, :w]
+    inst = np.where(np.isin(sem, things), sem * 1000 + k, 0)
+    return torch.from_numpy(inst.astype(np.int32)).unsqueeze(1)
+
+
+def mixup_item(batch, hs, ws, ht, wt, seed, num_classes=14):
+    """The `mixup_data` dict Mixup.do_mixup receives (datasets/replay_buffer.py:281-305 + the teacher's predictions,
+    scripts/adapt_codeps.py:173-199): source image / labels at (hs, ws), target image / predictions at (ht, wt)."""
+    sem_src = semantic_labels(batch, hs, ws, seed, num_classes)
+    return {
+        "rgb_src": {0: smooth_image(batch, hs, ws, seed + 1)},
+        "rgb_tgt": {0: smooth_image(batch, ht, wt, seed + 2)},
+        "semantic_src": sem_src.unsqueeze(1).contiguous(),
+        "instance_src": instance_labels(sem_src, seed + 3),
+        "semantic_pred_tgt_ema": semantic_labels(batch, ht, wt, seed + 4, num_classes, void_frac=0.0),   # uint8 like SemanticSegAlgo.inference
+        "center_pred_tgt_ema": center_heatmap(batch, ht, wt, seed + 5, 10, 3.0),
+        "offset_pred_tgt_ema": offsets(batch, ht, wt, seed + 6, 16.0),
+        "camera_model_src": intrinsics(batch, hs, ws, seed + 7),
+        "camera_model_tgt": intrinsics(batch, ht, wt, seed + 8) * torch.tensor([0.8, 0.8, 1.0, 1.0]),
+        "tgt_is_replay": torch.tensor([i % 2 for i in range(batch)]),
+    }

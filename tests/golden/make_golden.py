@@ -364,6 +364,56 @@ def golden_adapt(seed=61):
     save("network_adapt", **res)
 
 
+# ------------------------------------------------------------------------------------------ mix-up
+def _cfg_mixup(geom):
+    from yacs.config import CfgNode as CN
+    return CN(general=CN(geom_augment=geom), cut_mix=CN(nof_vert_splits=2, nof_hor_splits=4, nof_segments=2),
+              class_mix=CN(conf_thresh=0.98), conf_instance_mix=CN(conf_thresh=0.98, min_inst_size=100))
+
+
+def golden_mixup():
+    from datasets.mixup import Mixup
+    algo = InstanceSegAlgo(CenterLoss(), OffsetLoss(),
+                           PanopticEvaluator(stuff_list=STUFF, thing_list=THINGS, label_divisor=1000,
+                                             void_label=-1), BinaryMaskLoss())
+    res, meta = {}, {"cases": {}, "thing_list": THINGS}
+    for name, (b, hs, ws, ht, wt, geom, seed) in {"geom": (2, 48, 96, 40, 112, True, 71), "plain": (2, 48, 96, 48, 96, False, 72),
+                                                  "geom_same": (1, 64, 128, 64, 128, True, 73)}.items():
+        item = gi.mixup_item(b, hs, ws, ht, wt, seed)
+        np.random.seed(seed)
+        out = Mixup.do_mixup("cut_mixup", {k: (dict(v) if isinstance(v, dict) else v) for k, v in item.items()}, algo,
+                             _cfg_mixup(geom))
+        meta["cases"][name] = dict(b=b, hs=hs, ws=ws, ht=ht, wt=wt, geom=geom, seed=seed)
+        res[f"{name}_rgb"], res[f"{name}_semantic"], res[f"{name}_instance"] = out["rgb"][0], out["semantic"], out["instance"]
+        res[f"{name}_center"], res[f"{name}_offset"] = out["center"], out["offset"]
+        if geom:                                   # the float64 warps on their own (Mixup.warp_c2c, three mode combinations)
+            cs = [CameraModel.from_tensor(ws, hs, t) for t in item["camera_model_src"]]
+            ct = [CameraModel.from_tensor(wt, ht, t) for t in item["camera_model_tgt"]]
+            _, inst_t = algo.panoptic_fusion(item["semantic_pred_tgt_ema"].clone(), item["center_pred_tgt_ema"].clone(),
+                                             item["offset_pred_tgt_ema"].clone())
+            res[f"{name}_inst_tgt"] = inst_t
+            res[f"{name}_warp_rgb"] = Mixup.warp_c2c(ct, cs, item["rgb_tgt"][0], item["rgb_src"][0], interp_mode="bilinear",
+                                                     padding_mode="zeros")
+            res[f"{name}_warp_rgb_border"] = Mixup.warp_c2c(ct, cs, item["rgb_tgt"][0], item["rgb_src"][0])
+            res[f"{name}_warp_inst"] = Mixup.warp_c2c(ct, cs, inst_t, item["instance_src"], interp_mode="nearest",
+                                                      padding_mode="zeros")
+            res[f"{name}_warp_sem"] = Mixup.warp_c2c(ct, cs, item["semantic_pred_tgt_ema"], item["semantic_src"],
+                                                     interp_mode="nearest", padding_mode="border")
+    # Mixup.get_off_cen on its own: ids at the image border (clipped Gaussians), one-pixel instances, an id split in two parts
+    inst = torch.zeros(2, 1, 72, 120, dtype=torch.int32)
+    inst[0, 0, 0:5, 0:9] = 26001
+    inst[0, 0, 60:72, 100:120] = 26002
+    inst[0, 0, 30:41, 50:53] = 24001
+    inst[0, 0, 10, 60] = 7
+    inst[0, 0, 20:24, 10:30] = 25001
+    inst[0, 0, 50:54, 90:110] = 25001
+    inst[1, 0, :, :] = gi.instance_labels(gi.semantic_labels(1, 72, 120, 74), 75)[0, 0]
+    ctr, off = Mixup.get_off_cen(inst)
+    res["offcen_inst"], res["offcen_center"], res["offcen_offset"] = inst, ctr, off
+    res["meta"] = json.dumps(meta)
+    save("mixup", **res)
+
+
 if __name__ == "__main__":
     jobs = {"geometry": golden_geometry,
             "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
@@ -371,6 +421,6 @@ if __name__ == "__main__":
             "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),
             "recon_odd": lambda: golden_recon("odd", 1, 40, 72, 22, num_scales=3),
             "sem_inst_losses": golden_sem_inst_losses, "panoptic": golden_panoptic,
-            "network_train": golden_network, "network_adapt": golden_adapt}
+            "network_train": golden_network, "network_adapt": golden_adapt, "mixup": golden_mixup}
     for name in (sys.argv[1:] or jobs):          # no arguments = regenerate everything
         jobs[name]()

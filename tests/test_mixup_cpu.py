@@ -1,0 +1,65 @@
+"""oracle/mixup.py against tests/golden/mixup.npz (the REAL reference's Mixup.do_mixup / warp_c2c / get_off_cen run in
+the development container) -- pins the oracle for SURVEY.md section 8f-2."""
+import numpy as np
+import pytest
+
+import inputs as gi
+from helpers import load
+from oracle import mixup as om
+
+
+def case_inputs(c):
+    item = gi.mixup_item(c["b"], c["hs"], c["ws"], c["ht"], c["wt"], c["seed"])
+    item = {k: (v[0].numpy() if isinstance(v, dict) else v.numpy()) for k, v in item.items()}
+    np.random.seed(c["seed"])                                 # the reference's draw: one np.random.choice per batch item
+    ids = [np.random.choice(8, 2, replace=False) for _ in range(c["b"])]
+    return item, ids
+
+
+@pytest.mark.parametrize("name", ["geom", "plain", "geom_same"])
+def test_do_cut_mixup_matches_reference(name):
+    z, meta = load("mixup")
+    c = meta["cases"][name]
+    item, ids = case_inputs(c)
+    out = om.do_cut_mixup(item, meta["thing_list"], ids, c["geom"])
+    for k in ("rgb", "semantic", "instance", "center", "offset"):
+        assert out[k].dtype == z[f"{name}_{k}"].dtype and np.array_equal(out[k], z[f"{name}_{k}"]), f"{name}: {k} differs"
+
+
+@pytest.mark.parametrize("name", ["geom", "geom_same"])
+def test_warp_c2c_matches_reference(name):
+    z, meta = load("mixup")
+    c = meta["cases"][name]
+    item, _ = case_inputs(c)
+    cs, ct, hw = item["camera_model_src"], item["camera_model_tgt"], (c["hs"], c["ws"])
+    for key, src, mode, pad in (("warp_rgb", item["rgb_tgt"], "bilinear", "zeros"), ("warp_rgb_border", item["rgb_tgt"], "bilinear", "border"),
+                                ("warp_inst", z[f"{name}_inst_tgt"], "nearest", "zeros"),
+                                ("warp_sem", item["semantic_pred_tgt_ema"], "nearest", "border")):
+        got, ref = om.warp_c2c(ct, cs, src, hw, mode, pad), z[f"{name}_{key}"]
+        assert got.dtype == np.float64 and got.shape == ref.shape
+        if mode == "nearest":
+            assert np.array_equal(got, ref), key
+        else:
+            # float64 sums: ATen's vectorised kernel contracts the four-term sum into FMAs -> <= 1 ulp(float64); the
+            # reference's own cast to float32 (mixup.py:328) removes it
+            assert np.abs(got - ref).max() <= 1e-15 * max(1.0, np.abs(ref).max()), key
+            assert np.array_equal(got.astype(np.float32), ref.astype(np.float32)), key
+        # the correctly rounded square root (what GPUs compute) moves a sampling coordinate by at most one float32 ulp of
+        # the viewing ray: label maps keep their values, images move by ~1e-6
+        ieee = om.warp_c2c(ct, cs, src, hw, mode, pad, ieee_sqrt=True)
+        if mode == "nearest":
+            assert (ieee != ref).mean() < 1e-3, key
+        else:
+            assert np.abs(ieee - ref).max() < 2e-5, key
+
+
+def test_offset_center_matches_reference():
+    z, _ = load("mixup")
+    center, offset = om.get_off_cen(z["offcen_inst"])
+    assert np.array_equal(center, z["offcen_center"]) and np.array_equal(offset, z["offcen_offset"])
+    assert center.max() == 1.0 and (z["offcen_offset"][0, :, 0, 0] != 0).any()
+
+
+def test_cut_rects_keep_last_row_and_column():
+    r = om.cut_rects([0, 7], 48, 96, 2, 4)
+    assert r.tolist() == [[0, 23, 0, 23], [24, 47, 72, 95]]

@@ -1,0 +1,165 @@
+"""HIP mix-up kernels (codeps_warp_c2c / codeps_cut_mixup / codeps_offset_center, through the C ABI) and the host mirror
+codeps_amd.datasets.Mixup against the oracle and the reference's golden vectors."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+from helpers import load
+from oracle import mixup as om
+from test_mixup_cpu import case_inputs
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _cfg(geom):
+    ns = types.SimpleNamespace
+    return ns(general=ns(geom_augment=geom), cut_mix=ns(nof_vert_splits=2, nof_hor_splits=4, nof_segments=2))
+
+
+def _algo(thing_list):
+    from codeps_amd.algos import InstanceSegAlgo
+    return InstanceSegAlgo(None, None, types.SimpleNamespace(thing_list=thing_list), None)
+
+
+@pytest.mark.parametrize("name", ["geom", "geom_same"])
+def test_warp_c2c(name):
+    from codeps_amd import functional as F
+    z, meta = load("mixup")
+    c = meta["cases"][name]
+    item, _ = case_inputs(c)
+    cs, ct, hw = item["camera_model_src"], item["camera_model_tgt"], (c["hs"], c["ws"])
+    for key, src, mode, pad in (("warp_rgb", item["rgb_tgt"], "bilinear", "zeros"), ("warp_rgb_border", item["rgb_tgt"], "bilinear", "border"),
+                                ("warp_inst", z[f"{name}_inst_tgt"], "nearest", "zeros"),
+                                ("warp_sem", item["semantic_pred_tgt_ema"], "nearest", "border"),
+                                ("warp_inst", z[f"{name}_inst_tgt"].astype(np.int64), "nearest", "zeros")):
+        got = F.warp_c2c(dev(src), dev(ct), dev(cs), hw, mode, pad).cpu().numpy()
+        want = om.warp_c2c(ct, cs, src, hw, mode, pad, ieee_sqrt=True)          # the GPU's correctly rounded sqrtf
+        assert got.dtype == src.dtype
+        assert np.array_equal(got, want.astype(src.dtype)), f"{key}: HIP != oracle"
+        ref = z[f"{name}_{key}"]                                                # the reference itself (torch CPU sqrtf)
+        if mode == "nearest":
+            assert (got != ref.astype(src.dtype)).mean() < 1e-3, key
+        else:
+            assert np.abs(got - ref).max() < 2e-5, key                          # tolerance: one float32 ulp of the viewing ray
+
+
+def test_warp_c2c_far_outside_and_errors():
+    from codeps_amd import functional as F
+    from codeps_amd._lib import CodepsHipError
+    img = dev(gi.smooth_image(1, 16, 24, 5).numpy())
+    wide = dev(np.array([[3.0, 3.0, 12.0, 8.0]], np.float32))                   # very short focal length: most rays miss the image
+    tele = dev(np.array([[400.0, 400.0, 12.0, 8.0]], np.float32))
+    z = F.warp_c2c(img, tele, wide, (16, 24), "bilinear", "zeros")
+    b = F.warp_c2c(img, tele, wide, (16, 24), "bilinear", "border")
+    assert (z[0, :, 0, 0] == 0).all() and torch.equal(b[0, :, 0, 0], img[0, :, 0, 0]) and torch.isfinite(b).all()
+    want = om.warp_c2c(tele.cpu().numpy(), wide.cpu().numpy(), img.cpu().numpy(), (16, 24), "bilinear", "zeros", ieee_sqrt=True)
+    assert np.array_equal(z.cpu().numpy(), want.astype(np.float32))
+    with pytest.raises(TypeError):
+        F.warp_c2c(torch.zeros(1, 1, 8, 8, dtype=torch.int32, device=DEV), tele, wide, (8, 8), "bilinear", "zeros")
+    with pytest.raises(CodepsHipError):
+        F.warp_c2c(torch.zeros(1, 1, 1, 8, device=DEV), tele, wide, (8, 8), "bilinear", "zeros")       # (hs - 1) == 0
+
+
+def test_offset_center():
+    from codeps_amd import functional as F
+    z, _ = load("mixup")
+    center, offset, status = F.offset_center(dev(z["offcen_inst"]))
+    assert status.tolist() == [len(np.unique(m)) - 1 for m in z["offcen_inst"][:, 0]]
+    assert np.array_equal(offset.cpu().numpy(), z["offcen_offset"])            # float64 means, rounded once: bit-exact
+    # heat map: float64 exp on the device vs numpy's, rounded to fp32 -> at most one fp32 ulp apart
+    np.testing.assert_allclose(center.cpu().numpy(), z["offcen_center"], rtol=2e-7, atol=1e-37)
+    # int64 ids, no channel axis, empty image
+    c2, o2, s2 = F.offset_center(dev(z["offcen_inst"][:, 0].astype(np.int64)))
+    assert torch.equal(c2, center) and torch.equal(o2, offset)
+    c3, o3, s3 = F.offset_center(torch.zeros(1, 40, 56, dtype=torch.int32, device=DEV))
+    assert s3.tolist() == [0] and float(c3.abs().max()) == 0 and float(o3.abs().max()) == 0
+
+
+def test_offset_center_fullsize_and_overflow():
+    from codeps_amd import functional as F
+    rng = np.random.default_rng(3)
+    h, w = 512, 1024
+    sem = gi.semantic_labels(2, h, w, 91, block=32)
+    inst = gi.instance_labels(sem, 92, block=32, per_class=40).numpy()
+    inst[1, 0, 100:103, 5:1000] = 77                                            # thin, very wide instance: large coordinate sums
+    center, offset, status = F.offset_center(dev(inst))
+    wc, wo = om.get_off_cen(inst)
+    assert status.tolist() == [len(np.unique(m)) - 1 for m in inst[:, 0]]
+    assert np.array_equal(offset.cpu().numpy(), wo)
+    np.testing.assert_allclose(center.cpu().numpy(), wc, rtol=2e-7, atol=1e-37)
+    many = rng.permutation(64 * 128).astype(np.int32).reshape(1, 64, 128) + 1   # 8192 distinct ids > 4096 slots
+    assert F.offset_center(dev(many))[2].tolist() == [-1]
+
+
+@pytest.mark.parametrize("name", ["geom", "plain", "geom_same"])
+def test_do_mixup_matches_reference(name):
+    from codeps_amd.datasets import Mixup
+    z, meta = load("mixup")
+    c = meta["cases"][name]
+    item = gi.mixup_item(c["b"], c["hs"], c["ws"], c["ht"], c["wt"], c["seed"])
+    data = {k: ({0: v[0].to(DEV)} if isinstance(v, dict) else v.to(DEV)) for k, v in item.items()}
+    np.random.seed(c["seed"])
+    out = Mixup.do_mixup("cut_mixup", data, _algo(meta["thing_list"]), _cfg(c["geom"]))
+    torch.cuda.synchronize()
+    Mixup.check()
+    for k in ("semantic", "instance", "offset"):
+        got = out[k].cpu().numpy()
+        assert got.dtype == z[f"{name}_{k}"].dtype and np.array_equal(got, z[f"{name}_{k}"]), f"{name}: {k}"
+    np.testing.assert_allclose(out["center"].cpu().numpy(), z[f"{name}_center"], rtol=2e-7, atol=1e-37)
+    rgb = out["rgb"][0].cpu().numpy()
+    assert np.abs(rgb - z[f"{name}_rgb"]).max() < (2e-5 if c["geom"] else 0.0) + 1e-38
+    # bit-exact against the oracle with the GPU's square root
+    np_item, ids = case_inputs(c)
+    want = om.do_cut_mixup(np_item, meta["thing_list"], ids, c["geom"], ieee_sqrt=True)
+    assert np.array_equal(rgb, want["rgb"])
+    assert torch.equal(out["camera_model"], data["camera_model_src"])
+    with pytest.raises(NotImplementedError):
+        Mixup.do_mixup("class_mixup", data, _algo(meta["thing_list"]), _cfg(c["geom"]))
+
+
+def test_do_mixup_fullsize_properties():
+    """BASELINE sizes (source 512x1024, KITTI-360 target 384x1408): outside the cut cells the mix IS the source; inside,
+    it is the standalone warp; the regenerated centre / offset maps describe the mixed instance map."""
+    from codeps_amd import functional as F
+    from codeps_amd.datasets import Mixup
+    b, hs, ws, ht, wt = 2, 512, 1024, 384, 1408
+    item = gi.mixup_item(b, hs, ws, ht, wt, 81)
+    data = {k: ({0: v[0].to(DEV)} if isinstance(v, dict) else v.to(DEV)) for k, v in item.items()}
+    np.random.seed(5)
+    rects = Mixup._cut_cells(b, 2, 4, hs, ws, 2)
+    np.random.seed(5)
+    algo = _algo([9, 10, 11, 12, 13])
+    out = Mixup.do_mixup("cut_mixup", data, algo, _cfg(True))
+    mask = torch.zeros(b, hs, ws, dtype=torch.bool, device=DEV)
+    for i in range(b):
+        for y0, y1, x0, x1 in rects[i]:
+            mask[i, y0:y1, x0:x1] = True
+    assert 0.2 < float(mask.float().mean()) < 0.26                              # 2 of 8 cells, minus their last row / column
+    rgb, src = out["rgb"][0], data["rgb_src"][0]
+    m3 = mask.unsqueeze(1).expand_as(rgb)
+    assert torch.equal(rgb[~m3], src[~m3])
+    warped = Mixup.warp_c2c(data["camera_model_tgt"], data["camera_model_src"], data["rgb_tgt"][0], src, interp_mode="bilinear",
+                            padding_mode="zeros")
+    assert torch.equal(rgb[m3], warped[m3])
+    _, inst_t = algo.panoptic_fusion(data["semantic_pred_tgt_ema"], data["center_pred_tgt_ema"], data["offset_pred_tgt_ema"])
+    winst = Mixup.warp_c2c(data["camera_model_tgt"], data["camera_model_src"], inst_t, data["instance_src"], interp_mode="nearest",
+                           padding_mode="zeros")[:, 0]
+    assert torch.equal(out["instance"][mask], winst[mask].to(torch.int32))
+    assert torch.equal(out["instance"][~mask], data["instance_src"][:, 0][~mask])
+    wsem = Mixup.warp_c2c(data["camera_model_tgt"], data["camera_model_src"], data["semantic_pred_tgt_ema"], data["semantic_src"],
+                          interp_mode="nearest", padding_mode="border")[:, 0]
+    assert torch.equal(out["semantic"][mask], wsem[mask]) and torch.equal(out["semantic"][~mask], data["semantic_src"][:, 0][~mask])
+    c, o, _ = F.offset_center(out["instance"])
+    assert torch.equal(c, out["center"]) and torch.equal(o, out["offset"])
+    wc, wo = om.get_off_cen(out["instance"].cpu().numpy())
+    assert np.array_equal(out["offset"].cpu().numpy(), wo)
+    np.testing.assert_allclose(out["center"].cpu().numpy(), wc, rtol=2e-7, atol=1e-37)
