@@ -37,6 +37,10 @@ def build(device, encoder_layers, h, w, mode, target_hw=None):
     cfg.adapt.source_dataset.feed_img_size = [h, w]
     if mode == "train":
         cfg.model.instance_head.use_thing_mask = True
+    # cfg/adapt_cityscapes_kitti_360.yaml:31-43
+    cfg.adapt.mixup.merge({"general": {"mixup_strategies": ["cut_mixup", "cut_mixup"]},
+                           "cut_mix": {"nof_hor_splits": 4, "nof_vert_splits": 2, "nof_segments": 2},
+                           "conf_instance_mix": {"conf_thresh": 0.98, "min_inst_size": 2000}})
     torch.manual_seed(20)                   # the scripts' default seed (scripts/train_codeps.py:51)
     net = gen_models(cfg, device, list(range(9)), [9, 10, 11, 12, 13], [], adaptation_mode=(mode == "adapt"))
     return net, cfg
@@ -237,13 +241,23 @@ def main():
     ema = None
     if frame_mode:
         import copy
+        from codeps_amd import synthetic
         from codeps_amd.codeps import pre_step
+        from codeps_amd.datasets import Mixup
         ema = copy.deepcopy(net)                            # scripts/adapt_codeps.py:146 (CodepsNet.ema_model)
+        th, tw = data["target"]["rgb"][0].shape[-2:]
+        raw_mix = synthetic.mixup_raw_item(data["cut_mixup"]["rgb"][0].shape[0], args.height, args.width, th, tw, device, 4321 + rank)
 
     def one_step():
         if frame_mode:
-            sample = {k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items()}
+            # per incoming frame: teacher / student evaluation passes (scripts/adapt_codeps.py:164-199), then the mix-up item
+            # is built on the device (codeps/online_adap.py:331-335 -> Mixup.do_mixup) into the step's static input buffers
+            sample = {k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items() if not k.endswith("mixup")}
+            sample["cut_mixup"] = dict(raw_mix)
             pre_step(net, ema, ["semantic_head"], sample, [0, -1, 1], True)
+            mixed = Mixup.do_mixup("cut_mixup", sample["cut_mixup"], net.instance_algo, net.cfg_mixup)
+            data["cut_mixup"]["rgb"][0].copy_(mixed["rgb"][0])
+            data["cut_mixup"]["semantic"].copy_(mixed["semantic"])
         if graph is not None:
             graph.replay()
             runner.optimizer_step()

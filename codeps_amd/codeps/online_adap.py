@@ -4,8 +4,10 @@ state-dict export).  Differences, all result-neutral for losses / gradients (SUR
     when there is no flow head (algos/depth.py:389-393).  `faithful_bn_updates=True` restores the
     reference's two extra forwards for bit-faithful BN running statistics in train mode;
   * camera intrinsics stay on the device (no per-sample D2H sync, online_adap.py:95-100,304-313);
-  * '*mixup' items are expected pre-mixed unless a `mixup_fn` is installed (Mixup.do_mixup is the
-    data-augmentation subsystem of SURVEY.md §8f-2).
+  * '*mixup' items holding the reference's raw `mixup_data` (rgb_src / rgb_tgt / ..., datasets/replay_buffer.py:281-305)
+    go through the device-side Mixup.do_mixup (codeps_amd/datasets/mixup.py) exactly where the
+    reference calls it (online_adap.py:331-335); items that are already mixed ("rgb" present) pass through, which is
+    what the graph-captured benchmark step uses.  `mixup_fn` overrides the function.
 """
 import copy
 from collections import OrderedDict
@@ -14,6 +16,7 @@ from typing import Any, Dict, List, Optional
 import torch
 from torch import Tensor, nn
 
+from ..datasets.mixup import Mixup
 from ..misc.camera_model import CameraModel
 
 
@@ -154,8 +157,8 @@ class CodepsNet(nn.Module):
         camera_models = {k: v["camera_model"] for k, v in items.items() if not k.endswith("mixup")}
         images_window = {k: [v["rgb"][o] for o in depth_offsets] for k, v in items.items() if not k.endswith("mixup")}
         for key in list(items):
-            if key.endswith("mixup") and self.mixup_fn is not None:
-                in_data[key] = items[key] = self.mixup_fn(key, items[key], self.instance_algo, self.cfg_mixup)
+            if key.endswith("mixup") and (self.mixup_fn is not None or "rgb_src" in items[key]):
+                in_data[key] = items[key] = (self.mixup_fn or Mixup.do_mixup)(key, items[key], self.instance_algo, self.cfg_mixup)
         po_depth_feats, batched = {}, []
         if not self.backbone_po_depth.training and hasattr(self.backbone_po_depth, "forward_batch"):
             # frozen encoder (eval BatchNorm) is batch-independent: ONE forward per resolution over the centre frames of

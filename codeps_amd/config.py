@@ -50,7 +50,11 @@ def get_cfg_defaults(adapt=False):
         "train": {"optimizer": {"type": "Adam", "learning_rate": 1e-4}},
         "losses": {"weights": {"depth_recon": 10.0, "depth_smth": 0.001, "semantic": 1.0, "center": 20.0, "offset": 0.1,
                                "thing_mask": 0.5}},
-        "adapt": {"mixup": {}, "source_dataset": {"feed_img_size": [512, 1024]},
+        "adapt": {"mixup": {"general": {"active": True, "mixup_strategies": ["cut_mixup", "conf_instance_mixup"], "nof_samples": 2,
+                                        "geom_augment": True},                            # default_config_adapt.py:131-147
+                            "cut_mix": {"nof_hor_splits": 4, "nof_vert_splits": 4, "nof_segments": 1},
+                            "conf_instance_mix": {"conf_thresh": 0.0, "min_inst_size": 0}, "class_mix": {"conf_thresh": 0.0}},
+                  "source_dataset": {"feed_img_size": [512, 1024]},
                   "model": {"backbone_po_depth": False, "backbone_pose_sflow": True, "depth": True, "pose": True, "sflow": False,
                             "semantic": True, "instance": False},
                   "ema": {"alpha": 0.99, "semantic": True, "instance": False}},

@@ -50,3 +50,20 @@ def adapt_batch(h, w, device, seed, n_target=1, n_replay=3, n_source=2, n_mixup=
     mix = triplet_item(n_mixup, h, w, gen, device, labels=True)
     data["cut_mixup"] = {"rgb": {0: mix["rgb"][0]}, "semantic": mix["semantic"]}
     return data, n_target + n_replay + n_source + n_mixup
+
+
+def mixup_raw_item(n, h, w, th, tw, device, seed, num_classes=14):
+    """The raw `mixup_data` of one `*mixup` key as the replay buffer hands it over (datasets/replay_buffer.py:281-305):
+    a labelled source image at (h, w) and a target image at (th, tw); the teacher's predictions are added by
+    codeps.pre_step, the mix itself by datasets.Mixup.do_mixup."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    src = triplet_item(n, h, w, gen, device, labels=True, num_classes=num_classes)
+    tgt = triplet_item(n, th, tw, gen, device)
+    sem = src["semantic"]
+    blk = 32
+    k = torch.randint(1, 6, (n, -(-h // blk), -(-w // blk)), generator=gen, device=device)
+    k = k.repeat_interleave(blk, 1).repeat_interleave(blk, 2)[:, :h, :w]
+    inst = torch.where((sem >= 9) & (sem < 255), sem.to(torch.int32) * 1000 + k.to(torch.int32), torch.zeros_like(k, dtype=torch.int32))
+    return {"rgb_src": {0: src["rgb"][0]}, "rgb_tgt": {0: tgt["rgb"][0]}, "semantic_src": sem.unsqueeze(1).contiguous(),
+            "instance_src": inst.unsqueeze(1).contiguous(), "camera_model_src": src["camera_model"],
+            "camera_model_tgt": tgt["camera_model"], "tgt_is_replay": torch.zeros(n, dtype=torch.long, device=device)}

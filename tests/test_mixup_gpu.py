@@ -163,3 +163,41 @@ def test_do_mixup_fullsize_properties():
     wc, wo = om.get_off_cen(out["instance"].cpu().numpy())
     assert np.array_equal(out["offset"].cpu().numpy(), wo)
     np.testing.assert_allclose(out["center"].cpu().numpy(), wc, rtol=2e-7, atol=1e-37)
+
+
+def test_adapt_builds_the_mixup_item_like_the_reference():
+    """codeps/online_adap.py:331-335: adapt() turns the raw mix-up data (with the teacher's predictions from pre_step) into
+    the mixed item; the losses equal those of a step fed with the same item mixed beforehand."""
+    import copy
+    import bench
+    from codeps_amd import synthetic
+    from codeps_amd.codeps import pre_step
+    from codeps_amd.datasets import Mixup
+    from codeps_amd.step import freeze_for_adaptation
+    net, cfg = bench.build(DEV, 18, 64, 128, "adapt", (64, 160))
+    freeze_for_adaptation(net, cfg)
+    ema = copy.deepcopy(net)
+    data, _ = synthetic.adapt_batch(64, 128, DEV, 5, 1, 1, 1, 2, target_hw=(64, 160))
+    raw = synthetic.mixup_raw_item(2, 64, 128, 64, 160, DEV, 6)
+
+    def sample_with(mix):
+        s = {k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items() if not k.endswith("mixup")}
+        s["cut_mixup"] = mix
+        return s
+
+    s1 = sample_with(dict(raw))
+    pre_step(net, ema, ["semantic_head"], s1, [0, -1, 1], True)
+    assert {"semantic_pred_tgt_ema", "center_pred_tgt_ema", "offset_pred_tgt_ema"} <= set(s1["cut_mixup"])
+    np.random.seed(9)
+    mixed = Mixup.do_mixup("cut_mixup", dict(s1["cut_mixup"]), net.instance_algo, net.cfg_mixup)
+    assert mixed["rgb"][0].shape == raw["rgb_src"][0].shape and mixed["semantic"].dtype == torch.uint8
+    assert not torch.equal(mixed["rgb"][0], raw["rgb_src"][0])
+    net.train()
+    l_pre = net(sample_with(mixed), "adapt", [0, -1, 1], False)[0]
+    np.random.seed(9)
+    l_raw = net(s1, "adapt", [0, -1, 1], False)[0]
+    assert set(l_pre) == set(l_raw) and "semantic_cut_mixup" in l_raw
+    for k in l_pre:                      # same inputs -> same losses (the loss reductions use atomics: last-bit noise)
+        assert (l_pre[k] is None) == (l_raw[k] is None), k
+        if l_pre[k] is not None:
+            assert abs(l_pre[k].item() - l_raw[k].item()) <= 1e-6 * abs(l_pre[k].item()), k
