@@ -1,2 +1,3 @@
 """Host-side mirrors of the reference's `datasets` package that sit on the adapt path."""
 from .mixup import Mixup  # noqa: F401
+from .replay_buffer import DiversityReplayBuffer  # noqa: F401

@@ -323,6 +323,29 @@ size_t codeps_offset_center_workspace_bytes(int batch);
 int codeps_offset_center(const int* instance, int batch, int h, int w, double sigma, float* center, float* offset, int* status,
                          void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K18  Replay-buffer diversity sampler: the maximize_diversity branch of ReplayBuffer.add
+ *      (datasets/replay_buffer.py:387-455, called per frame from scripts/adapt_codeps.py:307) with the faiss inner-product
+ *      index (faiss-gpu==1.7.2: IndexIDMap(IndexFlatIP) + normalize_L2), the pairwise similarity matrix and the ids in
+ *      ONE caller-owned device buffer `state` (codeps_replay_state_bytes; capacity = cfg.replay_buffer.target_size,
+ *      dim = channels of the pooled feature).
+ *      codeps_replay_add: features = the encoder's last NHWC feature map of ONE image ([h][w][stride] fp32, the first
+ *      `dim` channels of every pixel used) -> mean over w then h -> L2-normalise -> cosine similarity to every stored
+ *      vector; stored under id `index` when the largest similarity is < similarity_threshold (an empty index counts as
+ *      similarity 0); when that makes capacity + 1 entries, the entry with the largest column sum of the similarity matrix
+ *      (diagonal excluded, first maximum) is evicted.  force = 1: `features` is an already normalised vector (h = w = 1)
+ *      that is stored unconditionally without eviction (ReplayBuffer.load_state, replay_buffer.py:475-488).
+ *      result (device, int64 [3]) = {1 stored / 0 rejected / -1 no free slot, evicted id or -1, float bits of the
+ *      largest similarity}.  Nothing synchronises. */
+size_t codeps_replay_state_bytes(int capacity, int dim);
+int codeps_replay_reset(void* state, size_t state_bytes, int capacity, int dim, codeps_stream_t stream);
+int codeps_replay_add(void* state, size_t state_bytes, int capacity, int dim, const float* features, int h, int w, int stride,
+                      long long index, float similarity_threshold, int force, long long* result, codeps_stream_t stream);
+/* ids int64 [capacity+1] (-1 = free slot) and stored vectors fp32 [capacity+1][dim] for ReplayBuffer.save_state
+ * (replay_buffer.py:462-473); device-to-device copies. */
+int codeps_replay_export(const void* state, size_t state_bytes, int capacity, int dim, long long* ids, float* feats,
+                         codeps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

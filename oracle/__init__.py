@@ -20,4 +20,7 @@ Parity pinning:
     the published torchvision v0.13 ResNet (v1.5 bottleneck) definition and is **parity unpinned**
     w.r.t. a reference run; it is pinned only by self-consistency checks (state-dict key set/shapes,
     published conv-MAC / parameter counts, per-block composition from torch.nn.functional).
+  * replay-buffer diversity sampler (oracle/replay.py): the search runs inside faiss-gpu==1.7.2, absent here ->
+    **parity unpinned**; restates the reference's call sites on top of faiss's published IndexFlatIP / normalize_L2
+    behaviour (self-consistency test only).
 """
