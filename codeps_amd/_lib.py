@@ -115,6 +115,11 @@ SIGNATURES = {
     "codeps_replay_reset": (c_int, [P, c_size_t, I, I, P]),
     "codeps_replay_add": (c_int, [P, c_size_t, I, I, P, I, I, I, LL, c_float, I, P, P]),
     "codeps_replay_export": (c_int, [P, c_size_t, I, I, P, P, P]),
+    "codeps_depth_metrics_workspace_bytes": (c_size_t, [I]),
+    "codeps_depth_metrics": (c_int, [P, P, P, I, I, I, I, I, c_float, c_float, I, P, P, c_size_t, P]),
+    "codeps_confusion_matrix": (c_int, [P, P, LL, I, I, ctypes.c_ulonglong, P, P, P]),
+    "codeps_panoptic_stats_workspace_bytes": (c_size_t, [I]),
+    "codeps_panoptic_stats": (c_int, [P, P, I, I, I, I, I, I, P, P, P, P, c_size_t, P]),
     "codeps_adam_ema_step": (c_int, [P, P, P, P, P, LL, I, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 

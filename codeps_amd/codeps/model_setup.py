@@ -9,8 +9,14 @@ from .online_adap import CodepsNet
 
 def gen_models(cfg, device, stuff_classes: List[int], thing_classes: List[int], ignore_classes: List[int],
                label_mode: Optional[str] = None, adaptation_mode: bool = False, evaluators=None) -> CodepsNet:
-    """`evaluators` = optional dict(depth=, semantic=, panoptic=) of metric objects (eval/* is outside the hot
-    path, SURVEY.md §2 #27); without them the algos skip metric bookkeeping."""
+    """`evaluators` = optional dict(depth=, semantic=, panoptic=) of metric objects, or "device" for the device-side mirrors of
+    eval/* built from cfg exactly like codeps/model_setup.py:82,110,124-126; without them the algos skip
+    metric bookkeeping."""
+    if evaluators == "device":
+        from ..eval import DepthEvaluator, PanopticEvaluator, SemanticEvaluator
+        evaluators = {"depth": DepthEvaluator(cfg.eval.depth.use_gt_scale, cfg.eval.depth.depth_ranges or [0.1, 80]),
+                      "semantic": SemanticEvaluator(num_classes=len(stuff_classes) + len(thing_classes), ignore_classes=ignore_classes),
+                      "panoptic": PanopticEvaluator(stuff_list=stuff_classes, thing_list=thing_classes, label_divisor=1000, void_label=-1)}
     evaluators = evaluators or {}
     ref_h = {"target": cfg.dataset.feed_img_size[0], "source": None}
     ref_w = {"target": cfg.dataset.feed_img_size[1], "source": None}

@@ -346,6 +346,34 @@ int codeps_replay_add(void* state, size_t state_bytes, int capacity, int dim, co
 int codeps_replay_export(const void* state, size_t state_bytes, int capacity, int dim, long long* ids, float* feats,
                          codeps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * On-device evaluation metrics, run by the reference once per incoming frame in the teacher's "eval" pass
+ * (scripts/adapt_codeps.py:166-172).
+ *
+ * K19  DepthEvaluator.compute_depth_metrics (eval/depth.py:21-68) / _compute_depth_stats (:111-131): per sample, over the
+ *      pixels with depth_gt > 0 (and inside the Garg crop when garg_crop; and of class class_id when class_map != NULL):
+ *      prediction scaled by median(gt) / median(pred) when use_gt_scale (torch.median = lower median), both clamped to
+ *      [min_depth, max_depth]; stats fp32 [B][8] = d_a1, d_a2, d_a3, d_rmse, d_rmse_log, d_abs_rel, d_sq_rel, #valid pixels
+ *      (NaN statistics for a sample without valid pixels).  depth_* fp32 [B,h,w], class_map uint8 [B,h,w]. */
+size_t codeps_depth_metrics_workspace_bytes(int batch);
+int codeps_depth_metrics(const float* depth_gt, const float* depth_pred, const uint8_t* class_map, int class_id, int batch, int h,
+                         int w, int use_gt_scale, float min_depth, float max_depth, int garg_crop, float* stats, void* workspace,
+                         size_t workspace_bytes, codeps_stream_t stream);
+/* K20  SemanticEvaluator.compute_confusion_matrix (eval/semantic.py:52-65): conf int32 [C][C] (row = target, column =
+ *      prediction) += counts over the n pixels whose target is neither ignore_index nor a class of ignore_class_mask (bit c).
+ *      *bad is set to 1 if a valid pixel holds a class >= num_classes (index_add_ would leave its row).  C <= 64. */
+int codeps_confusion_matrix(const uint8_t* pred, const uint8_t* target, long long n, int num_classes, int ignore_index,
+                            unsigned long long ignore_class_mask, int* conf, int* bad, codeps_stream_t stream);
+/* K21  PanopticEvaluator.update (eval/panoptic.py:26-45) -> compute_panoptic_stats (:134-209): pan_* int32 [B,h,w]
+ *      (category * label_divisor + instance, void_label < 0 for unlabelled); iou fp64 [num_categories] += IoU of the matched
+ *      (IoU > 0.5, same category) segment pairs; tp_fp_fn int32 [num_categories][3] += counts (FP skipped for predicted
+ *      segments more than half void).  status int32 [B]: 0 ok, -1 more than 8192 distinct (gt, pred) pairs or 2048 ids in an
+ *      image, -2 negative non-void id, -3 category >= num_categories. */
+size_t codeps_panoptic_stats_workspace_bytes(int batch);
+int codeps_panoptic_stats(const int* pan_gt, const int* pan_pred, int batch, int h, int w, int label_divisor, int void_label,
+                          int num_categories, double* iou, int* tp_fp_fn, int* status, void* workspace, size_t workspace_bytes,
+                          codeps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

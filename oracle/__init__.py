@@ -12,7 +12,8 @@ Rules (enforced by tests/test_layout.py):
   * nothing here reads /root/reference at run time.
 
 Parity pinning:
-  * heads, camera/warp geometry, all losses, panoptic fusion, mix-up (oracle/mixup.py): PINNED against golden vectors produced
+  * heads, camera/warp geometry, all losses, panoptic fusion, mix-up (oracle/mixup.py), evaluation metrics
+    (oracle/metrics.py): PINNED against golden vectors produced
     by importing and running the real reference in the development container
     (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``; checked by ``tests/test_oracle_golden.py``).
   * ResNet trunk arithmetic: the reference delegates it to torchvision==0.13.1 (requirements.txt:2),

@@ -175,3 +175,17 @@ def mixup_item(batch, hs, ws, ht, wt, seed, num_classes=14):
         "camera_model_tgt": intrinsics(batch, ht, wt, seed + 8) * torch.tensor([0.8, 0.8, 1.0, 1.0]),
         "tgt_is_replay": torch.tensor([i % 2 for i in range(batch)]),
     }
+
+
+def panoptic_maps(batch, h, w, seed, num_classes=14, things=(9, 10, 11, 12, 13), block=8, shift=3):
+    """(ground truth, prediction) panoptic id maps [B,H,W] int32 (class * 1000 + instance, -1 void): the prediction is the
+    ground truth of a shifted / partly relabelled scene, so that matched, missed and spurious segments all occur."""
+    sem = semantic_labels(batch, h, w, seed, num_classes, block).numpy().astype(np.int64)
+    inst = instance_labels(torch.from_numpy(sem.astype(np.uint8)), seed + 1, things, block)[:, 0].numpy().astype(np.int64)
+    gt = np.where(sem == 255, -1, np.where(inst > 0, inst, sem * 1000))
+    g = _rng(seed + 31)
+    pred = np.roll(gt, (shift, -shift), (1, 2))
+    flip = np.repeat(np.repeat(g.uniform(0, 1, (batch, -(-h // block), -(-w // block))) < 0.15, block, 1), block, 2)[:, :h, :w]
+    pred = np.where(flip & (pred >= 0), ((pred // 1000 + 1) % num_classes) * 1000 + np.where(pred % 1000 > 0, 7, 0), pred)
+    pred = np.where((pred >= 0) & (pred // 1000 < things[0]), (pred // 1000) * 1000, pred)   # stuff classes carry no instance id
+    return torch.from_numpy(gt.astype(np.int32)), torch.from_numpy(pred.astype(np.int32))

@@ -38,6 +38,7 @@ CPU = torch.device("cpu")
 R18 = np.array([64, 64, 128, 256, 512])
 R50 = np.array([64, 256, 512, 1024, 2048])
 THINGS = [9, 10, 11, 12, 13]
+DEPTH_KEYS = ("d_a1", "d_a2", "d_a3", "d_rmse", "d_rmse_log", "d_abs_rel", "d_sq_rel")
 STUFF = list(range(9))
 
 
@@ -414,6 +415,45 @@ def golden_mixup():
     save("mixup", **res)
 
 
+# ------------------------------------------------------------------------------------------ metrics
+def golden_metrics():
+    res, meta = {}, {"depth": {}, "thing_list": THINGS, "stuff_list": STUFF}
+    b, h, w = 2, 48, 96
+    gt = gi.depth_map(b, h, w, 81)
+    gt = torch.where(gi.uniform((b, 1, h, w), 82) < 0.3, torch.zeros_like(gt), gt)          # 30 % void
+    pred = (gi.depth_map(b, h, w, 81) * (0.4 + 0.2 * gi.uniform((b, 1, h, w), 83)) + 0.05).contiguous()
+    sem = gi.semantic_labels(b, h, w, 84)
+    for name, (scale, garg) in {"scaled": (True, False), "garg": (True, True), "raw": (False, False)}.items():
+        ev = DepthEvaluator(scale, [0.1, 80], garg)
+        out = ev.compute_depth_metrics(gt.clone(), pred.clone())
+        meta["depth"][name] = dict(use_gt_scale=scale, garg=garg)
+        res[f"depth_{name}"] = np.array([float(out[k]) for k in DEPTH_KEYS], np.float64)
+    ev = DepthEvaluator(True, [0.1, 80])
+    pc = ev.compute_depth_metrics_per_class(gt[:, 0].clone(), pred.clone(), sem)
+    meta["per_class_keys"] = sorted(pc)
+    res["depth_per_class"] = np.array([float(pc[k]) for k in sorted(pc)], np.float64)
+    # confusion matrix
+    sev = SemanticEvaluator(14, ignore_classes=[3])
+    spred = gi.semantic_labels(b, h, w, 85, void_frac=0.0)
+    res["conf"] = sev.compute_confusion_matrix(spred, sem)
+    res["conf_noignore"] = SemanticEvaluator(14).compute_confusion_matrix(spred, sem)
+    res["miou"] = sev.compute_sem_miou(res["conf"].clone())
+    # panoptic quality
+    pgt, ppred = gi.panoptic_maps(2, 64, 128, 86, shift=1)
+    pev = PanopticEvaluator(stuff_list=STUFF, thing_list=THINGS, label_divisor=1000, void_label=-1)
+    pev.update(pgt.clone(), ppred.clone())
+    pev.update(ppred.clone(), pgt.clone())
+    cats = sorted(pev.pq_stats.pq_per_cat)
+    res["pq_cats"] = np.array(cats)
+    res["pq_iou"] = np.array([pev.pq_stats[c].iou for c in cats], np.float64)
+    res["pq_counts"] = np.array([[pev.pq_stats[c].tp, pev.pq_stats[c].fp, pev.pq_stats[c].fn] for c in cats])
+    ev = pev.evaluate()
+    res["pq_all"] = np.array([ev["All"]["pq"], ev["All"]["sq"], ev["All"]["rq"], ev["All"]["n"]], np.float64)
+    res["pq_things"] = np.array([ev["Things"]["pq"], ev["Things"]["sq"], ev["Things"]["rq"], ev["Things"]["n"]], np.float64)
+    res["meta"] = json.dumps(meta)
+    save("metrics", **res)
+
+
 if __name__ == "__main__":
     jobs = {"geometry": golden_geometry,
             "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
@@ -421,6 +461,6 @@ if __name__ == "__main__":
             "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),
             "recon_odd": lambda: golden_recon("odd", 1, 40, 72, 22, num_scales=3),
             "sem_inst_losses": golden_sem_inst_losses, "panoptic": golden_panoptic,
-            "network_train": golden_network, "network_adapt": golden_adapt, "mixup": golden_mixup}
+            "network_train": golden_network, "network_adapt": golden_adapt, "mixup": golden_mixup, "metrics": golden_metrics}
     for name in (sys.argv[1:] or jobs):          # no arguments = regenerate everything
         jobs[name]()
