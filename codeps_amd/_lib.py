@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
 LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "codeps_photometric_fwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_photometric_bwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_pack_weights": (c_int, [I, I, I, I, I, I, P, P, P, P]),
+    "codeps_conv2d_packed_weight_floats": (c_size_t, [I, I, I, I, I]),
     "codeps_conv2d_arith": (c_int, [POINTER(ConvDesc), I, I]),
     "codeps_conv2d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),

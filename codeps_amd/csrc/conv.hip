@@ -59,6 +59,9 @@ struct ConvP {
     int ksplit, ksteps;
     float* part;
     size_t part_bytes;
+    // weights of this launch pre-split into three bf16 pieces ([row][K group of 32][piece][32], written by the weight pack
+    // behind its fp32 part); the 3-piece kernel stages its B operand from here with plain copies
+    const void* w3;
 };
 
 
@@ -234,12 +237,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     constexpr bool AGUARD = (BM % RPP) != 0, BGUARD = (BN % RPP) != 0;
     // B rows (weights): row n = n0 + rbase + RPP*i, K-contiguous; rows past N are clamped (their columns are never stored)
     const size_t wrow = (MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct : (size_t)p.KH * p.KW * p.Co;     // floats per packed weight row
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(wq, (size_t)p.N * wrow * 4);
+    // 3-piece arithmetic: the weights arrive pre-split (6 bytes per element, laid out like an LDS row), so the B operand is
+    // staged with copies only -- every weight element would otherwise be converted again by each of the M / BM row tiles
+    constexpr bool BPRE = NP == 3;
+    constexpr int BREGS = BPRE ? NP : SUB;            // 16-byte registers per staged B row chunk
+    const __amdgpu_buffer_rsrc_t rsB = BPRE ? make_rsrc(static_cast<const float*>(p.w3), (size_t)p.N * wrow * 6) : make_rsrc(wq, (size_t)p.N * wrow * 4);
     unsigned boff[BPASS];
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)(((size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow + chunk * KPT) * 4);
+    for (int i = 0; i < BPASS; ++i) {
+        const size_t row = (size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow;
+        boff[i] = BPRE ? (unsigned)(row * 6 + chunk * 16) : (unsigned)((row + chunk * KPT) * 4);
+    }
 
-    f32x4 areg[APASS * SUB], breg[BPASS * SUB];
+    f32x4 areg[APASS * SUB], breg[BPASS * BREGS];
 
     auto load_step = [&](int step) {
         const int tap = step / steps_per_tap;
@@ -264,8 +274,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #pragma unroll
         for (int i = 0; i < BPASS; ++i)
 #pragma unroll
-            for (int u = 0; u < SUB; ++u)
-                breg[i * SUB + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + (unsigned)koff * 4u + 16 * u, 0, 0));
+            for (int u = 0; u < BREGS; ++u)
+                breg[i * BREGS + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rsB, BPRE ? boff[i] + (unsigned)koff * 6u + 64 * u : boff[i] + (unsigned)koff * 4u + 16 * u, 0, 0));
     };
     auto store_step = [&](int buf) {
         float* Ab = As + buf * BM * LDK;
@@ -290,6 +301,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
             if (!BGUARD || rbase + RPP * i < BN) {
                 if constexpr (NP == 0) {
                     *reinterpret_cast<f32x4*>(Bb + (rbase + RPP * i) * LDK + chunk * 4) = breg[i];
+                } else if constexpr (BPRE) {
+                    unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + RPP * i) * LDK);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = __builtin_bit_cast(i32x4, breg[i * BREGS + q]);
                 } else {
                     u16x4 lo[NP > 0 ? NP : 1], hi[NP > 0 ? NP : 1];
                     split_bf16<(NP > 0 ? NP : 1)>(breg[i * SUB], lo);
@@ -1226,6 +1242,19 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// fp32 pack [rows][wrow] -> [rows][wrow / 32][3 pieces][32] bf16 with the same split the kernel applies to activations
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ wq, long long n_chunks, unsigned short* __restrict__ out) {
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += (long long)gridDim.x * 256) {     // chunk = 8 consecutive k
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wq + c * 8), b = *reinterpret_cast<const f32x4*>(wq + c * 8 + 4);
+        u16x4 lo[3], hi[3];
+        split_bf16<3>(a, lo);
+        split_bf16<3>(b, hi);
+        unsigned short* g = out + (c / 4) * 96 + (c % 4) * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(g + q * 32) = pack8(lo[q], hi[q]);
+    }
+}
+
 // ---------------------------------------------------------------------------------- host side
 static int check_conv(const codeps_conv_desc* d, const char* who) {
     CODEPS_REQUIRE(d != nullptr, CODEPS_ERR_ARG, "%s: null descriptor", who);
@@ -1412,8 +1441,23 @@ extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, i
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, out_c, in_c, kh * kw,
                        out_c_pad, in_c_pad, w_fwd, w_dgrad);
+    // pre-split copies behind the fp32 packs (rows whose K extent is a multiple of 32 channels: the 3-piece kernel's shapes)
+    const int sgrid = (int)std::min<long long>((total / 8 + 255) / 256, 4096);
+    if (w_fwd && in_c_pad % 32 == 0)
+        hipLaunchKernelGGL(split_pack_kernel, dim3(sgrid), dim3(256), 0, (hipStream_t)stream, w_fwd, total / 8, reinterpret_cast<unsigned short*>(w_fwd + total));
+    if (w_dgrad && out_c_pad % 32 == 0)
+        hipLaunchKernelGGL(split_pack_kernel, dim3(sgrid), dim3(256), 0, (hipStream_t)stream, w_dgrad, total / 8, reinterpret_cast<unsigned short*>(w_dgrad + total));
     CODEPS_CHECK_LAUNCH("pack_weights_kernel");
     return CODEPS_OK;
+}
+
+// floats a w_fwd / w_dgrad buffer must hold: the fp32 pack, plus its pre-split copy (6 bytes per element) when the pack's K
+// extent (in_c_pad for w_fwd, out_c_pad for w_dgrad) is a multiple of 32 channels
+extern "C" size_t codeps_conv2d_packed_weight_floats(int out_c_pad, int in_c_pad, int kh, int kw, int dgrad) {
+    if (out_c_pad <= 0 || in_c_pad <= 0 || kh <= 0 || kw <= 0) return 0;
+    const size_t total = (size_t)out_c_pad * in_c_pad * kh * kw;
+    const int kext = dgrad ? out_c_pad : in_c_pad;
+    return total + (kext % 32 == 0 ? (total * 6 + 3) / 4 : 0);
 }
 
 // Which arithmetic a launch of this shape uses: 3 / 2 = fp32 operands as 3 / 2 bf16 pieces on v_mfma_f32_32x32x16_bf16 (main
@@ -1458,6 +1502,7 @@ extern "C" int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, con
     ConvP p = make_convp(d);
     p.M = d->batch * d->out_h * d->out_w; p.N = d->out_c;
     if (workspace && codeps_conv2d_fwd_workspace_bytes(d) > 0) { p.part = (float*)workspace; p.part_bytes = workspace_bytes; }
+    p.w3 = w_fwd + (size_t)d->out_c * d->kh * d->kw * (d->c0 + d->c1);         // behind the fp32 pack (codeps_conv2d_packed_weight_floats)
     const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
     dispatch_igemm<MODE_FWD>(p, gran, x0, x1, w_fwd, scale, shift, residual, y, (hipStream_t)stream);
     CODEPS_CHECK_LAUNCH("conv_igemm_kernel<fwd>");
@@ -1481,6 +1526,7 @@ extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const 
     p.N = p.Cs;
     // weights of this source: rows [c_off, c_off + Cs) of the [ci][tap][co] pack
     const float* wsrc = w_dgrad + (size_t)p.c_off * d->kh * d->kw * d->out_c;
+    p.w3 = reinterpret_cast<const char*>(w_dgrad + (size_t)(d->c0 + d->c1) * d->kh * d->kw * d->out_c) + (size_t)p.c_off * d->kh * d->kw * d->out_c * 6;
     if (d->stride == 2 && p.N > 16) {
         // one launch per input-parity class with only the taps that can reach it; classes without taps are zero
         bool need_zero = false;

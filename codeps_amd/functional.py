@@ -216,8 +216,10 @@ def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
         return ent[3], ent[4]
     co, ci, kh, kw = weight.shape
     w = _f32c(weight.detach())
-    wf = torch.empty(out_c_pad * kh * kw * in_c_pad, dtype=torch.float32, device=w.device)
-    wd = torch.empty_like(wf) if need_dgrad else None
+    # each pack carries its pre-split (3 x bf16) copy behind the fp32 part when its K extent allows the split-operand kernel
+    wf = torch.empty(lib().codeps_conv2d_packed_weight_floats(out_c_pad, in_c_pad, kh, kw, 0), dtype=torch.float32, device=w.device)
+    wd = torch.empty(lib().codeps_conv2d_packed_weight_floats(out_c_pad, in_c_pad, kh, kw, 1), dtype=torch.float32,
+                     device=w.device) if need_dgrad else None
     check(lib().codeps_conv2d_pack_weights(co, ci, kh, kw, out_c_pad, in_c_pad, ptr(w), ptr(wf), ptr(wd), stream_ptr()),
           "codeps_conv2d_pack_weights")
     cache[key] = (_weak(weight, cache, key), weight.data_ptr(), weight._version, wf, wd)

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* codeps_stream_t;
 
-int codeps_version(void);                 /* ABI version (3), bumped on any signature change */
+int codeps_version(void);                 /* ABI version (4), bumped on any signature / buffer-contract change */
 const char* codeps_last_error(void);      /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------------------------------------
@@ -83,7 +83,12 @@ typedef struct {
                                   * differ only for the double-pixel stem form, see codeps_nchw_to_nhwc_xpad) */
 } codeps_conv_desc;
 
-/* OIHW [out_c][in_c][kh][kw] -> w_fwd [out_c_pad][kh*kw][in_c_pad] and/or w_dgrad [in_c_pad][kh*kw][out_c_pad]. */
+/* OIHW [out_c][in_c][kh][kw] -> w_fwd [out_c_pad][kh*kw][in_c_pad] and/or w_dgrad [in_c_pad][kh*kw][out_c_pad] (fp32), each
+ * followed -- when its K extent (in_c_pad resp. out_c_pad) is a multiple of 32 channels -- by the same values pre-split into
+ * three bf16 pieces ([row][K group of 32][piece][32], 6 bytes per element) from which the split-operand kernel stages its
+ * weight operand.  Buffers hold codeps_conv2d_packed_weight_floats(..., dgrad = 0 / 1) floats; codeps_conv2d_fwd / _dgrad
+ * expect packs produced by this function. */
+size_t codeps_conv2d_packed_weight_floats(int out_c_pad, int in_c_pad, int kh, int kw, int dgrad);
 int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
                                const float* w_oihw, float* w_fwd, float* w_dgrad, codeps_stream_t stream);
 /* Arithmetic of a launch of this shape (mode 0 forward, 1 data gradient w.r.t. `source`): 3 = every fp32 operand as the exact
