@@ -447,6 +447,196 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------- wave-specialised variant (deep K)
+// Same GEMM, same 3-piece arithmetic and pre-split weights as conv_igemm_kernel<.., 32, 1, 3>, for launches whose K loop is
+// long enough to amortise a block that owns a whole CU: 512 threads = 4 CONSUMER waves (the 2x2 wave grid, fragment reads +
+// MFMAs only) + 4 PRODUCER waves (global loads, bf16 split of the activations, LDS writes), one of each per SIMD, LDS double
+// buffered, ONE barrier per K-step.  In the 256-thread kernel every wave runs load -> convert -> write -> barrier -> read ->
+// MFMA -> barrier in sequence and the matrix pipe idles ~63 % of the time (PMC); here a SIMD's producer wave
+// converts and writes K-step s + 1 while its consumer wave multiplies K-step s.
+template <int MODE, int TN>
+__global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ residual, float* __restrict__ out) {
+    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = 3;
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int LDK = (NP * BK + 8) / 2;            // floats per LDS row: [piece][32 bf16] + pad
+    constexpr int CPR = BK / 8, RPP = 256 / CPR;      // producer threads: 8 consecutive k per thread and row, 64 rows per pass
+    constexpr int APASS = BM / RPP, BPASS = BN / RPP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                 // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;                  // [2][BN][LDK]
+    unsigned* tab = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * LDK);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int cw = wave & 3, wm = cw / WN, wn = cw % WN;
+    const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
+    const int nt = logical % p.n_nt, mt = logical / p.n_nt;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int ntap = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx
+                   : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
+    const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
+    const int steps_per_tap = Kc / BK;
+    const int nsteps = ntap * steps_per_tap;
+    __amdgpu_buffer_rsrc_t rs0, rs1;
+    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1);
+
+    const int s_begin = p.ksplit > 1 ? (int)blockIdx.y * p.ksteps : 0;
+    const int s_end = p.ksplit > 1 ? min(nsteps, s_begin + p.ksteps) : nsteps;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (producer) {
+        const int ptid = tid - 256, chunk = ptid % CPR, rbase = ptid / CPR;
+        const size_t wrow = (MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct : (size_t)p.KH * p.KW * p.Co;
+        const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const float*>(p.w3), (size_t)p.N * wrow * 6);
+        unsigned boff[BPASS];
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)((size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow * 6 + chunk * 16);
+        f32x4 areg[APASS * 2], breg[BPASS * NP];
+        auto load_step = [&](int step) {
+            const int tap = step / steps_per_tap;
+            const int cstep = (step - tap * steps_per_tap) * BK;
+            const bool s1 = MODE == MODE_FWD && cstep >= p.C0;
+            const __amdgpu_buffer_rsrc_t rs = s1 ? rs1 : rs0;
+            const unsigned coff = (unsigned)((s1 ? cstep - p.C0 : cstep) + chunk * 8) * 4u;
+            const unsigned* t = tab + ((s1 ? ntap : 0) + tap) * BM + rbase;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const unsigned off = t[RPP * i];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    areg[i * 2 + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + coff + 16 * u, 0, 0));
+            }
+            int koff;
+            if (MODE == MODE_DGRAD && p.par) koff = ((p.ky0 + 2 * (tap / p.nkx)) * p.KW + p.kx0 + 2 * (tap % p.nkx)) * Kc + cstep;
+            else if (MODE == MODE_DGRAD && p.up0 && p.src == 0) koff = ((tap % (p.KH * p.KW)) * Kc) + cstep;
+            else koff = tap * Kc + cstep;
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i)
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    breg[i * NP + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + (unsigned)koff * 6u + 64 * q, 0, 0));
+        };
+        auto store_step = [&](int buf) {
+            float* Ab = As + buf * BM * LDK;
+            float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                u16x4 lo[NP], hi[NP];
+                split_bf16<NP>(areg[i * 2], lo);
+                split_bf16<NP>(areg[i * 2 + 1], hi);
+                unsigned short* row = reinterpret_cast<unsigned short*>(Ab + (rbase + RPP * i) * LDK);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = pack8(lo[q], hi[q]);
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + RPP * i) * LDK);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = __builtin_bit_cast(i32x4, breg[i * NP + q]);
+            }
+        };
+        load_step(s_begin);
+        store_step(0);
+        if (s_begin + 1 < s_end) load_step(s_begin + 1);
+        __syncthreads();                                          // stage 0 is visible
+        for (int step = s_begin; step < s_end; ++step) {
+            const int buf = (step - s_begin) & 1;
+            if (step + 1 < s_end) store_step(buf ^ 1);            // the consumers read `buf` meanwhile
+            if (step + 2 < s_end) load_step(step + 2);            // stays in flight across the barrier
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int step = s_begin; step < s_end; ++step) {
+            const int buf = (step - s_begin) & 1;
+            const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK;
+            const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK;
+#pragma unroll
+            for (int kc = 0; kc < BK / 16; ++kc) {
+                bf16x8 af[TM][NP], bf[TN][NP];
+                const int ho = kc * 16 + lhalf * 8;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        af[i][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Ab + i * 32 * LDK) + q * BK + ho);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        bf[j][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Bb + j * 32 * LDK) + q * BK + ho);
+#pragma unroll
+                for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+                    for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (as in conv_igemm_kernel; the consumer waves hold the accumulators, all 512 threads move rows)
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;
+    constexpr int V4 = BN / 4, RPASS = 512 / V4;
+    const int c4 = tid % V4, r0 = tid / V4;
+    const int n = n0 + c4 * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_FWD && n < p.N) {
+        if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+        if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i > 0) __syncthreads();
+        if (!producer) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (n < p.N) {
+#pragma unroll 2
+            for (int rr = r0; rr < WM * 32; rr += RPASS) {
+                int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
+                if (m >= p.M) continue;
+                if (MODE == MODE_DGRAD && p.par) {
+                    const int bb = m / (p.Hc * p.Wc), rem = m % (p.Hc * p.Wc);
+                    m = (bb * p.H + 2 * (rem / p.Wc) + p.py) * p.W + 2 * (rem % p.Wc) + p.px;
+                }
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
+                if (p.ksplit > 1) {
+                    *reinterpret_cast<f32x4*>(p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
+                    continue;
+                }
+                if (MODE == MODE_FWD) {
+                    v = v * sc + sh;
+                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- 16-column variant
 // N <= 16 (disparity / class / centre-offset outputs, the 16-channel full-resolution decoder tail and their data
 // gradients): v_mfma_f32_16x16x4_f32 tiles, so no MFMA work is spent on zero-padded output columns.
@@ -1325,6 +1515,33 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     constexpr int LDKf = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // LDS row in floats (split precision: NP pieces x BK bf16 + pad)
     const size_t lds = std::max(((size_t)NBUF * (BM + BN) * LDKf + (size_t)nsrc * ntap * BM) * sizeof(float),
                                 (size_t)WM * 32 * (BN + 4) * sizeof(float));
+    if constexpr (NP == 3 && WM == 2 && WN == 2 && TM == 2) {
+        static const int ws_min = getenv("CODEPS_WS_MIN") ? atoi(getenv("CODEPS_WS_MIN")) : 48;      // K-steps from which the wave-specialised kernel runs
+        const int ntap_ = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
+        const int Kc_ = (MODE == MODE_FWD) ? p.Ct : p.Co, nsteps_ = ntap_ * (Kc_ / BK);
+        // ... and whose grid is a single round of one block per CU: the block owns the CU (111 KB of LDS), so a second round
+        // would run without the co-resident blocks that hide the 256-thread kernel's prologue / epilogue
+        static const int ws_blocks = getenv("CODEPS_WS_BLOCKS") ? atoi(getenv("CODEPS_WS_BLOCKS")) : 256;
+        if (ws_min > 0 && nsteps_ >= ws_min && p.n_mt * p.n_nt <= ws_blocks) {
+            const int nsrc_ = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
+            const size_t lds_ws = std::max(((size_t)2 * (BM + BN) * LDKf + (size_t)nsrc_ * ntap_ * BM) * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            auto kw = conv_igemm_ws_kernel<MODE, TN>;
+            static bool ws_attr = false;
+            if (!ws_attr) { (void)hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ws_attr = true; }
+            const int blocks_ = p.n_mt * p.n_nt;
+            p.ksplit = 1; p.ksteps = nsteps_;
+            const int ks_ = splitk_slices(p, blocks_, nsteps_);
+            if (ks_ >= 2) { p.ksteps = cdiv(nsteps_, ks_); p.ksplit = cdiv(nsteps_, p.ksteps); }
+            hipLaunchKernelGGL(kw, dim3(blocks_, p.ksplit), dim3(512), lds_ws, st, p, a0, a1, scale, shift, residual, out);
+            if (p.ksplit > 1) {
+                const long long MN = (long long)p.M * p.N;
+                hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
+                                   p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, MODE == MODE_FWD ? residual : nullptr,
+                                   MODE == MODE_FWD ? p.act : 0, out);
+            }
+            return;
+        }
+    }
     auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, NP>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }

@@ -31,7 +31,8 @@ def to_nchw(y, c):
 
 
 @pytest.mark.parametrize("b,h,w,ci,co,k,s", [(8, 128, 256, 64, 64, 3, 1), (8, 32, 64, 256, 1024, 1, 1), (12, 128, 256, 64, 128, 3, 2),
-                                             (6, 256, 512, 32, 32, 3, 1)])
+                                             (6, 256, 512, 32, 32, 3, 1),
+                                             (8, 32, 64, 256, 256, 3, 1), (4, 32, 64, 2048, 512, 1, 1)])    # single-round deep-K grids: wave-specialised kernel
 def test_conv_matches_vendor_library_and_is_linear(b, h, w, ci, co, k, s):
     F = _F()
     g = torch.Generator(device=DEV).manual_seed(b * 131 + ci)
