@@ -229,7 +229,10 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                captured = runner.forward_backward(data)       # static outputs, refreshed by every replay
+                out = runner.forward_backward(data)
+                # static output refreshed by every replay; nothing that holds the autograd graph is kept
+                captured = (None, None, {"image_features": out[2]["image_features"].detach()})
+                del out
             graph.replay()
             runner.optimizer_step()
             torch.cuda.synchronize()
