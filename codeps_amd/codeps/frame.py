@@ -76,3 +76,52 @@ def pre_step(model, ema_model, ema_modules: List[str], sample: Dict[str, Dict[st
                 item["center_pred_tgt_ema"] = res["center"].detach().clone()
                 item["offset_pred_tgt_ema"] = res["offset"].detach().clone()
     return results_eval, stats_eval
+
+
+class OnlineAdapter:
+    """The per-frame loop of scripts/adapt_codeps.py:146-310 around one model: teacher / student evaluation passes
+    (`pre_step`), `nof_adaptation_steps` adaptation steps (StepRunner: forward, backward, one gradient all-reduce, fused
+    Adam + EMA), and the frame's offer to the replay buffer.
+
+    The reference keeps the teacher as a deep copy and, after every step, rewrites it parameter by parameter: an EMA for the
+    modules in cfg.adapt.ema, a plain copy (alpha = 0) of the student for every other module (adapt_codeps.py:293-299,
+    online_adap.py:279-289).  Here the teacher's parameters are VIEWS: EMA'd modules look into the EMA buffer that the fused
+    optimizer kernel maintains, the others share the student's storage -- the teacher is current after every step without a
+    single copy kernel.  Frozen modules are equal by construction."""
+
+    def __init__(self, model, cfg, world_size: int = 1, group=None, replay=None, rgb_frame_offsets=(0, -1, 1),
+                 do_panoptic_fusion: bool = True, nof_adaptation_steps: int = 1):
+        from ..step import ADAPT_MODULES, StepRunner
+        from .online_adap import CodepsNet
+        self.model, self.cfg, self.replay = model, cfg, replay
+        self.offsets, self.do_panoptic_fusion, self.steps = list(rgb_frame_offsets), do_panoptic_fusion, int(nof_adaptation_steps)
+        self.runner = StepRunner(model, cfg, "adapt", world_size, group)
+        self.ema_modules = [ADAPT_MODULES[k] for k in ("semantic", "instance", "depth", "pose") if cfg.adapt.ema.get(k, False)]
+        self.ema_model = None
+        if self.ema_modules:                                             # adapt_codeps.py:146-150
+            self.ema_model = CodepsNet.ema_model(model)
+            self._bind_teacher()
+
+    def _bind_teacher(self):
+        teacher_of = {id(p): t for (_, t), (_, p) in zip(self.ema_model.named_parameters(), self.model.named_parameters())}
+        for g in self.runner.groups:
+            off = 0
+            for p in g.params:
+                k = p.numel()
+                t = teacher_of[id(p)]
+                src = g.ema if g.ema is not None else g.flat
+                t.data = src[off:off + k].view_as(p)
+                t._codeps_volatile = True            # rewritten by the optimizer kernel: weight packs must not outlive a step
+                off += k
+
+    def process(self, sample: Dict[str, Dict[str, Any]], index: Optional[int] = None, do_class_wise_depth_stats: bool = False):
+        """One incoming frame -> (results_eval, stats_eval, losses, result) exactly in the script's order: evaluate, adapt,
+        store.  `sample` is the data loader's dict (target / target_replay / source / *mixup raw items)."""
+        results_eval, stats_eval = pre_step(self.model, self.ema_model, self.ema_modules, sample, self.offsets,
+                                            self.do_panoptic_fusion, do_class_wise_depth_stats)
+        losses = result = None
+        for _ in range(self.steps):
+            _, losses, result = self.runner.step(sample)
+        if self.replay is not None and index is not None:                # adapt_codeps.py:307
+            self.replay.add(int(index), result["image_features"][:1])
+        return results_eval, stats_eval, losses, result

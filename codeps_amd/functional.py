@@ -208,7 +208,9 @@ def invalidate_weight_cache(everything=False):
 def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
     """OIHW parameter -> (w_fwd, w_dgrad) packs, cached on (storage, tensor version, weights epoch): frozen
     weights are packed once, trainable ones once per optimizer step (the pose encoder runs 6x per step)."""
-    cache = _pack_cache_train if weight.requires_grad else _pack_cache
+    # trainable parameters, and frozen-looking ones whose storage is rewritten by raw-pointer kernels (an EMA teacher bound to
+    # the optimizer's flat buffers, codeps.frame.OnlineAdapter), are repacked after every optimizer step
+    cache = _pack_cache_train if (weight.requires_grad or getattr(weight, "_codeps_volatile", False)) else _pack_cache
     key = (id(weight), out_c_pad, in_c_pad)
     ent = cache.get(key)          # (weakref to the parameter, storage, version, w_fwd, w_dgrad): ids / addresses get reused
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version and \

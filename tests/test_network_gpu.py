@@ -149,3 +149,65 @@ def test_pre_step_shares_encoder_features_without_changing_results():
         want_sem = ema(data["cut_mixup"], "eval", [0, -1, 1], False, False)[1]["semantic"]
         want_ctr = net(data["cut_mixup"], "eval", [0, -1, 1], False, False)[1]["center"]
     assert torch.equal(m1["semantic_pred_tgt_ema"], want_sem) and torch.equal(m1["center_pred_tgt_ema"], want_ctr)
+
+
+def test_online_adapter_keeps_the_teacher_current():
+    """codeps.OnlineAdapter == the per-frame loop of scripts/adapt_codeps.py:164-307 written out with the reference's own
+    per-parameter teacher update (EMA for cfg.adapt.ema modules, plain copy for the others): same evaluation results, same
+    teacher weights, frame after frame -- i.e. the teacher views into the optimizer's buffers (and the weight packs made
+    from them) never go stale."""
+    import copy
+    import numpy as np
+    import bench
+    from codeps_amd import synthetic
+    from codeps_amd.codeps import CodepsNet, OnlineAdapter, pre_step
+    from codeps_amd.datasets import DiversityReplayBuffer
+    from codeps_amd.step import StepRunner
+    dev = torch.device(DEV)
+    net, cfg = bench.build(dev, 18, 64, 128, "adapt")
+    net_ref = copy.deepcopy(net)
+    replay = DiversityReplayBuffer(100, 4, 2.0, dev, feature_dim=512)
+    adapter = OnlineAdapter(net, cfg, replay=replay)
+    assert adapter.ema_modules == ["semantic_head"]
+    runner_ref = StepRunner(net_ref, cfg, "adapt")
+    teacher_ref = CodepsNet.ema_model(net_ref)
+    others = ["backbone_po_depth", "backbone_pose_sflow", "depth_head", "pose_head", "instance_head"]
+    prev_sem = None
+    for frame in range(3):
+        data, _ = synthetic.adapt_batch(64, 128, dev, 50 + frame, 1, 1, 1, 2)
+        data.pop("cut_mixup")
+        raw = synthetic.mixup_raw_item(2, 64, 128, 64, 128, dev, 70 + frame)
+
+        def sample():
+            s = {k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items()}
+            s["cut_mixup"] = dict(raw)
+            return s
+
+        np.random.seed(frame)
+        res, _stats, losses, result = adapter.process(sample(), index=frame)
+        np.random.seed(frame)
+        s_ref = sample()
+        res_ref, _ = pre_step(net_ref, teacher_ref, ["semantic_head"], s_ref, [0, -1, 1], True)
+        _, losses_ref, _ = runner_ref.step(s_ref)
+        teacher_ref.update_weights(net_ref, ["semantic_head"], cfg.adapt.ema.alpha)        # adapt_codeps.py:293-299
+        teacher_ref.update_weights(net_ref, others, 0)
+        assert torch.equal(res["semantic"], res_ref["semantic"]) or (res["semantic"] != res_ref["semantic"]).float().mean() < 1e-3
+        close(res["depth"], res_ref["depth"], 1e-4, 1e-4, f"frame {frame}: evaluation depth")
+        for k, v in losses_ref.items():
+            if v is not None:
+                assert abs(losses[k].item() - v.item()) <= 1e-4 * max(1.0, abs(v.item())), (frame, k)
+        for (n1, t1), (n2, t2) in zip(adapter.ema_model.named_parameters(), teacher_ref.named_parameters()):
+            # Adam's early steps move every weight by ~lr = 1e-4 whatever the gradient's size, so the sign of a near-zero
+            # gradient (atomics in the loss reductions: last-bit noise) shows up as 2e-4 per step in the copied modules; the
+            # EMA'd head only sees 1 % of that
+            tol = 5e-6 * (frame + 1) if n1.startswith("semantic_head") else 2.5e-4 * (frame + 1)
+            close(t1, t2, tol, 1e-4, f"frame {frame}: teacher {n1}")
+        sem_now = torch.cat([p.detach().reshape(-1) for p in adapter.ema_model.semantic_head.parameters()]).clone()
+        if prev_sem is not None:
+            assert not torch.equal(sem_now, prev_sem)                     # the teacher really moves
+            # ... by an EMA step, not by a copy of the student
+            stu = torch.cat([p.detach().reshape(-1) for p in net.semantic_head.parameters()])
+            assert (sem_now - stu).abs().max() > 0
+        prev_sem = sem_now
+    replay.sync()
+    assert [e[0] for e in replay.log] == [0, 1, 2]
