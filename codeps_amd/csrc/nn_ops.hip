@@ -765,22 +765,37 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 struct GudaBranch { const float* y; int h, w; float rh, rw; };      // y: [B][h][w][144] = 9 taps x 16 channels
 struct GudaP { int B, H, W, nb; GudaBranch br[3]; };
 
+// One thread per (4-pixel strip along x, 4-channel group): the six positions x - 1 .. x + 4 that the strip's taps read fall
+// into at most three low-res columns of a branch (ratio >= 2), so each (tap, source row) costs three 16-byte loads for the
+// whole strip instead of two per pixel -- the kernel is bound by the L1 / texture-address path (108 loads per pixel before).
 __global__ __launch_bounds__(256) void guda_gather_fwd_kernel(GudaP p, const float* __restrict__ base, float* __restrict__ out) {
-    // one thread per (pixel, 4-channel group): out = base + sum_branch sum_tap bilinear(y_branch[tap])(p + delta_tap)
-    const long long total = (long long)p.B * p.H * p.W * 4;
+    const int W4 = (p.W + 3) / 4;
+    const long long total = (long long)p.B * p.H * W4 * 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int g = (int)(i & 3);
-        long long pix = i >> 2;
-        const int x = (int)(pix % p.W); pix /= p.W;
-        const int y = (int)(pix % p.H);
-        const int b = (int)(pix / p.H);
-        f32x4 a = *reinterpret_cast<const f32x4*>(base + ((((size_t)b * p.H + y) * p.W + x) << 4) + g * 4);
+        long long s = i >> 2;
+        const int xs = (int)(s % W4) * 4; s /= W4;
+        const int y = (int)(s % p.H);
+        const int b = (int)(s / p.H);
+        const int npx = min(4, p.W - xs);
+        f32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            a[j] = j < npx ? *reinterpret_cast<const f32x4*>(base + ((((size_t)b * p.H + y) * p.W + xs + j) << 4) + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < p.nb; ++k) {
             const GudaBranch br = p.br[k];
             const float* yb = br.y + (size_t)b * br.h * br.w * 144 + g * 4;
-            int x0[3], x1[3]; float lx0[3], lx1[3];
+            // bilinear sources of the six columns xs - 1 .. xs + 4 (clamped like a zero-padded tap never is: invalid ones get weight 0)
+            int c0[6]; float l1[6]; bool ok[6];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) bil_src(0, br.rw, min(max(x + kx - 1, 0), p.W - 1), br.w, p.W, x0[kx], x1[kx], lx0[kx], lx1[kx]);
+            for (int q = 0; q < 6; ++q) {
+                const int qx = xs + q - 1;
+                ok[q] = qx >= 0 && qx < p.W;
+                int i0, i1; float w0, w1;
+                bil_src(0, br.rw, min(max(qx, 0), p.W - 1), br.w, p.W, i0, i1, w0, w1);
+                c0[q] = i0;
+                l1[q] = i1 > i0 ? w1 : 0.f;              // weight on column i0 + 1; the rest (incl. the clamped last column) on i0
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int qy = y + ky - 1;
@@ -791,17 +806,35 @@ __global__ __launch_bounds__(256) void guda_gather_fwd_kernel(GudaP p, const flo
                 const float* r1 = yb + (size_t)y1 * br.w * 144 + ky * 48;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int qx = x + kx - 1;
-                    if (qx < 0 || qx >= p.W) continue;
-                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + x0[kx] * 144 + kx * 16);
-                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + x1[kx] * 144 + kx * 16);
-                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + x0[kx] * 144 + kx * 16);
-                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + x1[kx] * 144 + kx * 16);
-                    a += ly0 * (lx0[kx] * v00 + lx1[kx] * v01) + ly1 * (lx0[kx] * v10 + lx1[kx] * v11);
+                    const int cb = c0[kx];                // first low-res column of this tap's window (pixel 0 of the strip)
+                    if (c0[kx + 3] + 1 - cb > 2) {        // ratio < 2 would need more than three columns: per-pixel path
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (!ok[j + kx]) continue;
+                            const int x0 = c0[j + kx], x1 = min(x0 + 1, br.w - 1);
+                            const float w1 = l1[j + kx], w0 = 1.f - w1;
+                            a[j] += ly0 * (w0 * *reinterpret_cast<const f32x4*>(r0 + x0 * 144 + kx * 16) + w1 * *reinterpret_cast<const f32x4*>(r0 + x1 * 144 + kx * 16)) +
+                                    ly1 * (w0 * *reinterpret_cast<const f32x4*>(r1 + x0 * 144 + kx * 16) + w1 * *reinterpret_cast<const f32x4*>(r1 + x1 * 144 + kx * 16));
+                        }
+                        continue;
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const int col = min(cb + cc, br.w - 1);
+                        const f32x4 v = ly0 * *reinterpret_cast<const f32x4*>(r0 + col * 144 + kx * 16) + ly1 * *reinterpret_cast<const f32x4*>(r1 + col * 144 + kx * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int q = j + kx, d = cb + cc - c0[q];        // 0: the pixel's left column, 1: its right column
+                            const float w = !ok[q] ? 0.f : (d == 0 ? 1.f - l1[q] : (d == 1 ? l1[q] : 0.f));
+                            a[j] += w * v;
+                        }
+                    }
                 }
             }
         }
-        *reinterpret_cast<f32x4*>(out + ((((size_t)b * p.H + y) * p.W + x) << 4) + g * 4) = a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < npx) *reinterpret_cast<f32x4*>(out + ((((size_t)b * p.H + y) * p.W + xs + j) << 4) + g * 4) = a[j];
     }
 }
 
@@ -1283,7 +1316,7 @@ extern "C" int codeps_guda_gather_fwd(const float* base, int batch, int h, int w
         p.br[k].y = y[k]; p.br[k].h = bh[k]; p.br[k].w = bw[k];
         p.br[k].rh = (float)bh[k] / (float)h; p.br[k].rw = (float)bw[k] / (float)w;
     }
-    hipLaunchKernelGGL(guda_gather_fwd_kernel, dim3(grid_for((long long)batch * h * w * 4)), dim3(256), 0, (hipStream_t)stream, p, base, out);
+    hipLaunchKernelGGL(guda_gather_fwd_kernel, dim3(grid_for((long long)batch * h * ((w + 3) / 4) * 4)), dim3(256), 0, (hipStream_t)stream, p, base, out);
     CODEPS_CHECK_LAUNCH("guda_gather_fwd_kernel");
     return CODEPS_OK;
 }
