@@ -117,9 +117,9 @@ def pmc_traffic(default_workload):
 def conv_roofline(runner, data, steps=2, default_workload=False):
     """Live measurement of the conv engine with HIP events on the launch stream: algorithmic (fp32-equivalent, unpadded) FLOPs
     of every launch / its event-timed duration, per kernel kind, each priced against the peak of the arithmetic it runs:
-      *_split : the main implicit-GEMM kernel (forward / data gradient) -- every fp32 operand as three bf16 pieces, six piece
-                products per multiply on v_mfma_f32_32x32x16_bf16 => peak = dense bf16 MFMA / 6;
-      others  : 16-column kernels, 16-channel K chunks and all weight gradients on the f32 MFMA.
+      *_split : the main implicit-GEMM kernel (forward / data gradient) and the halo-tile weight gradient -- every fp32 operand
+                as three bf16 pieces, six piece products per multiply on v_mfma_f32_32x32x16_bf16 => peak = dense bf16 MFMA / 6;
+      others  : 16-column kernels, 16-channel K chunks and the remaining weight gradients on the f32 MFMA.
     The `roofline` object is the dominant kind's (most time); `by_kind` and `all_conv` carry the rest."""
     from codeps_amd import functional as F
     F._profile["events"].clear()
@@ -148,7 +148,7 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
     if dom:
         dflops, dsecs, dn = (sum(by[k][i] for k in dom) for i in range(3))
         peak = PEAK_BF16_MFMA_TFLOPS / products
-        name = (f"conv_igemm_kernel fwd + dgrad: fp32 operands as {split_pieces} bf16 pieces, {products} products on "
+        name = (f"conv_igemm_kernel fwd + dgrad, wgrad_halo64s_kernel: fp32 operands as {split_pieces} bf16 pieces, {products} products on "
                 f"v_mfma_f32_32x32x16_bf16, fp32 accumulate (peak = dense bf16 MFMA {PEAK_BF16_MFMA_TFLOPS:.0f} / {products})")
     else:
         dflops, dsecs, dn, peak = flops, secs, n, PEAK_F32_MFMA_TFLOPS
@@ -312,9 +312,9 @@ def main():
             "value": round(total_images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": ("fp32 end to end; conv forward / data-gradient operands enter the matrix cores as exact 3-way bf16 splits "
-                           "(six bf16 products per multiply, fp32 accumulate: product error ~6e-9 relative, below fp32 rounding); weight "
-                           "gradients and 16-column kernels on the f32 MFMA") if os.environ.get("CODEPS_SPLIT", "3") == "3" else
+            "arithmetic": ("fp32 end to end; conv forward / data-gradient / halo-tile weight-gradient operands enter the matrix cores as "
+                           "exact 3-way bf16 splits (six bf16 products per multiply, fp32 accumulate: product error ~6e-9 relative, below "
+                           "fp32 rounding); the other weight gradients and the 16-column kernels on the f32 MFMA") if os.environ.get("CODEPS_SPLIT", "3") == "3" else
                           ("CODEPS_SPLIT=" + os.environ.get("CODEPS_SPLIT", "3") + " (non-default arithmetic, see codeps_amd/csrc/conv.hip)"),
             "config": {"workload": (("BASELINE configs[2], YAML-faithful secondary row: online-adapt step cfg/adapt_cityscapes_kitti_360.yaml, "
                                      f"per-GPU batch {n_images} = 1 target + 2 target_replay @ 384x1408 + 2 source + 2 cut_mixup @ "

@@ -1214,6 +1214,180 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
     }
 }
 
+// wgrad_halo64_kernel on the bf16 matrix cores (same tiles, same grid, same partial-sum layout; CODEPS_WGRAD_SPLIT).
+// The weight gradient contracts over PIXELS, and v_mfma_f32_32x32x16_bf16 wants 8 consecutive k values per lane, so both
+// operands are transposed while they are staged: a thread loads 8 pixels x 4 channels (eight 16-byte loads), splits each
+// channel's 8 values into the three bf16 pieces and writes one 16-byte LDS row segment per (channel, piece):
+//   dZs [64 co][piece][64 px]              X rows: [64 ci][piece][6 rows][ -1 | 16 px | 16 ] at elements 7 | 8..23 | 24
+// A tap (ky, kx) reads X row py + ky at column offset kx - 1: the kx = 1 fragment is an aligned 16-byte read, the other two
+// are built in registers from the neighbouring aligned groups (v_alignbit, 4 per fragment) -- no unaligned LDS access, no
+// second copy of the tile.  Every X row's fragments are read once per tile and used by the up to three (py, ky) pairs that
+// touch it: 66 fragment reads for 216 MFMAs (9 taps x 6 piece products x 4 k-chunks) per wave and tile.
+__global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
+                                                            const float* __restrict__ x0, const float* __restrict__ x1,
+                                                            const float* __restrict__ dz, float* __restrict__ part) {
+    constexpr int TH = 4, TW = 16, XH = TH + 2, PIX = TH * TW, XROW = 32;
+    constexpr int ZP = 3 * PIX + 8;                    // halfwords per dZ channel (pad: conflict-free 16-byte fragment reads)
+    constexpr int XQ = XH * XROW, XP = 3 * XQ + 8;     // halfwords per X piece / per X channel
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    unsigned short* dZs = lds16;                       // [64][ZP]
+    unsigned short* Xs = lds16 + 64 * ZP;              // [64][XP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+    const int co_base = blockIdx.y * 64;
+    const int chunk = blockIdx.x % ci_chunks, blk = blockIdx.x / ci_chunks;
+    const int c_base = chunk * 64;
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    const bool s1 = c_base >= p.C0;
+    const float* src = s1 ? x1 : x0;
+    const int cs = s1 ? p.C1 : p.C0, c_src = s1 ? c_base - p.C0 : c_base;
+    const bool up = p.up0 && !s1;
+    const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging tasks: "big" = 8 pixels x 4 channels (128 dZ tasks, then 192 X tasks: 6 rows x 2 groups x 16 channel quads),
+    // "small" = one halo pixel x 4 channels (6 rows x 2 sides x 16).  Thread tid owns big tasks tid and tid + 256 (< 320) and,
+    // from thread 64 on, small task tid - 64.
+    f32x4 bigr[2][8], smallr;
+    auto x_pixel = [&](int b, int iy, int ix, int c4) -> f32x4 {
+        if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
+            if (up) { iy >>= 1; ix >>= 1; }
+            return *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c_src + c4 * 4);
+        }
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto load_tile = [&](int tile) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bt = tid + 256 * u;
+            if (bt >= 320) break;
+            if (bt < 128) {                                          // dZ: channel quad c4, pixel group grp
+                const int c4 = bt & 15, grp = bt >> 4;
+                const int gy = ty0 + (grp >> 1), gx0 = tx0 + (grp & 1) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (gy < p.Ho && gx0 + i < p.Wo && co_base + c4 * 4 < p.Co)
+                        v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * p.Ho + gy) * p.Wo + gx0 + i) * p.Co + co_base + c4 * 4);
+                    bigr[u][i] = v;
+                }
+            } else {                                                 // X interior: row r (image row ty0 + r - 1), group g
+                const int t = bt - 128, c4 = t & 15, rg = t >> 4, r = rg >> 1, g = rg & 1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bigr[u][i] = x_pixel(b, ty0 + r - 1, tx0 + g * 8 + i, c4);
+            }
+        }
+        if (tid >= 64) {
+            const int t = tid - 64, c4 = t & 15, rs = t >> 4, r = rs >> 1, side = rs & 1;
+            smallr = x_pixel(b, ty0 + r - 1, tx0 + (side ? TW : -1), c4);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bt = tid + 256 * u;
+            if (bt >= 320) break;
+            unsigned short* dst;                                     // element 0 of this task's 8-pixel segment, piece 0, channel c4 * 4
+            int cstride, qstride;
+            if (bt < 128) {
+                const int c4 = bt & 15, grp = bt >> 4;
+                dst = dZs + (c4 * 4) * ZP + grp * 8; cstride = ZP; qstride = PIX;
+            } else {
+                const int t = bt - 128, c4 = t & 15, rg = t >> 4, r = rg >> 1, g = rg & 1;
+                dst = Xs + (c4 * 4) * XP + r * XROW + 8 + g * 8; cstride = XP; qstride = XQ;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                            // transpose in registers: channel e of the 8 pixels
+                const f32x4 lo4 = {bigr[u][0][e], bigr[u][1][e], bigr[u][2][e], bigr[u][3][e]};
+                const f32x4 hi4 = {bigr[u][4][e], bigr[u][5][e], bigr[u][6][e], bigr[u][7][e]};
+                u16x4 lo[3], hi[3];
+                split_bf16<3>(lo4, lo);
+                split_bf16<3>(hi4, hi);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(dst + e * cstride + q * qstride) = pack8(lo[q], hi[q]);
+            }
+        }
+        if (tid >= 64) {
+            const int t = tid - 64, c4 = t & 15, rs = t >> 4, r = rs >> 1, side = rs & 1;
+            u16x4 pc[3];
+            split_bf16<3>(smallr, pc);
+            unsigned short* dst = Xs + (c4 * 4) * XP + r * XROW + (side ? 24 : 7);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dst[e * XP + q * XQ] = pc[q][e];
+        }
+    };
+
+    if (t_beg < t_end) load_tile(t_beg);
+    const unsigned short* zrow = dZs + (wco * 32 + l32) * ZP + h * 8;
+    const unsigned short* xrow = Xs + (wci * 32 + l32) * XP + h * 8;
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        __syncthreads();                                            // the previous tile's fragment reads are done
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);
+        bf16x8 zf[TH][3];
+#pragma unroll
+        for (int py = 0; py < TH; ++py)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) zf[py][q] = *reinterpret_cast<const bf16x8*>(zrow + q * PIX + py * TW);
+#pragma unroll
+        for (int r = 0; r < XH; ++r) {
+            bf16x8 xf[3][3];                                         // [kx][piece]
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned short* g0 = xrow + q * XQ + r * XROW;
+                const i32x4 prev = *reinterpret_cast<const i32x4*>(g0), cur = *reinterpret_cast<const i32x4*>(g0 + 8),
+                            next = *reinterpret_cast<const i32x4*>(g0 + 16);
+                i32x4 left, right;
+                left[0] = (int)__builtin_amdgcn_alignbit((unsigned)cur[0], (unsigned)prev[3], 16);
+                right[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)cur[3], 16);
+#pragma unroll
+                for (int i = 1; i < 4; ++i) left[i] = (int)__builtin_amdgcn_alignbit((unsigned)cur[i], (unsigned)cur[i - 1], 16);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) right[i] = (int)__builtin_amdgcn_alignbit((unsigned)cur[i + 1], (unsigned)cur[i], 16);
+                xf[0][q] = __builtin_bit_cast(bf16x8, left);
+                xf[1][q] = __builtin_bit_cast(bf16x8, cur);
+                xf[2][q] = __builtin_bit_cast(bf16x8, right);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int py = r - ky;
+                if (py < 0 || py >= TH) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                        for (int qa = 0; qa <= ord; ++qa)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[py][qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
+            }
+        }
+    }
+    // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 31, row (co) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* dst = part + (size_t)blk * p.Co * 9 * p.Ct;
+    const int ci = c_base + wci * 32 + l32;
+    if (ci < p.Ct) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Co) dst[((size_t)co * 9 + t) * p.Ct + ci] = acc[t][r];
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------- halo-tile wgrad, 64 x 64 channel tiles
 // 3x3 / stride 1 weight gradient for layers with >= 48 channels on both sides.  A block owns a (64 output channels) x
 // (64 input channels) tile of dW for all 9 taps and walks 4x16-pixel output tiles: the dZ tile and the X tile WITH its
@@ -1337,6 +1511,19 @@ __global__ __launch_bounds__(256) void wgrad_halo64_kernel(WgradP p, int ci_chun
 
 struct SmallPlan { bool ok, stem, halo64; int mt, nt, ci_chunks, co_groups, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
 
+// Halo-tile weight gradient on the bf16 matrix cores with 3-piece operands (wgrad_halo64s_kernel); CODEPS_WGRAD_SPLIT=0 or
+// CODEPS_SPLIT != 3 selects the f32-MFMA kernel.
+static bool wgrad_split_on() {
+    static const bool on = (getenv("CODEPS_WGRAD_SPLIT") ? atoi(getenv("CODEPS_WGRAD_SPLIT")) != 0 : true) &&
+                           (getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) == 3 : true);
+    return on;
+}
+// channel tiles (64 x 64) a layer must have for the halo kernel: the split kernel also takes single-tile 64 -> 64 layers
+static int halo_min_tiles() {
+    static const int v = getenv("CODEPS_HALO_MIN_TILES") ? atoi(getenv("CODEPS_HALO_MIN_TILES")) : (wgrad_split_on() ? 1 : 2);
+    return v;
+}
+
 static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
     SmallPlan s;
     memset(&s, 0, sizeof(s));
@@ -1359,15 +1546,16 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
     }
     static const int halo_off = getenv("CODEPS_NO_HALO64") ? 1 : 0;                                    // tuning experiments only
     if (!halo_off && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->stride_w == 1 && d->pad == 1 && d->pad_w == 1 && d->out_c >= 48 && Ct >= 48 &&
-        cdiv(Ct, 64) * cdiv(d->out_c, 64) >= 2 && (d->c1 == 0 || d->c0 % 64 == 0) && d->out_h == d->in_h && d->out_w == d->in_w) {
+        cdiv(Ct, 64) * cdiv(d->out_c, 64) >= halo_min_tiles() && (d->c1 == 0 || d->c0 % 64 == 0) && d->out_h == d->in_h && d->out_w == d->in_w) {
         // 64 x 64 channel tiles over 4x16-pixel tiles with halo (wgrad_halo64_kernel); a single-tile 64 -> 64 layer would need
         // ~768 pixel blocks = 768 partial slabs, where the per-tap kernel measures faster
         s.ok = s.halo64 = true;
         s.ci_chunks = cdiv(Ct, 64); s.co_groups = cdiv(d->out_c, 64);
         s.tiles_x = cdiv(d->out_w, 16); s.tiles_y = cdiv(d->out_h, 4);
         const int total = d->batch * s.tiles_x * s.tiles_y;
-        // 228 VGPRs -> 2 blocks per CU: exactly one balanced round of <= 512 blocks (measured: 512 -> 54.8 ms/step, 448 -> 55.7, 576 -> 56.8)
-        static const int halo_blocks = getenv("CODEPS_HALO_BLOCKS") ? atoi(getenv("CODEPS_HALO_BLOCKS")) : 512;   // env: tuning experiments only
+        // f32 kernel: 228 VGPRs -> 2 blocks per CU: exactly one balanced round of <= 512 blocks (measured: 512 -> 54.8 ms/step,
+        // 448 -> 55.7, 576 -> 56.8); split kernel: 82 KB of LDS -> 1 block per CU, one round of 256 (256 -> 45.9, 512 -> 46.2, 768 -> 46.9)
+        static const int halo_blocks = getenv("CODEPS_HALO_BLOCKS") ? atoi(getenv("CODEPS_HALO_BLOCKS")) : (wgrad_split_on() ? 256 : 512);   // env: tuning experiments only
         const int want = std::max(1, halo_blocks / (s.ci_chunks * s.co_groups));
         s.tiles_per_block = std::max(2, cdiv(total, want));
         s.nblk = cdiv(total, s.tiles_per_block);
@@ -1679,7 +1867,7 @@ extern "C" size_t codeps_conv2d_packed_weight_floats(int out_c_pad, int in_c_pad
 
 // Which arithmetic a launch of this shape uses: 3 / 2 = fp32 operands as 3 / 2 bf16 pieces on v_mfma_f32_32x32x16_bf16 (main
 // kernel, K chunks of 32 channels), 0 = f32 MFMA (16-column kernels, 16-channel K chunks, CODEPS_SPLIT=0).  mode 0 = forward,
-// 1 = data gradient w.r.t. `source`; weight gradients always run on the f32 MFMA.  Used by bench.py to price each launch
+// 1 = data gradient w.r.t. `source`, 2 = weight gradient (3 for the halo-tile layers, else 0).  Used by bench.py to price each launch
 // against the right peak.
 static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
     static const int split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
@@ -1691,6 +1879,7 @@ static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
         const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
         return (d->out_c > 16 && gran % 32 == 0) ? split_np : 0;
     }
+    if (mode == 2) return (split_np == 3 && wgrad_split_on() && wgrad_small_plan(d).halo64) ? 3 : 0;
     const int n = source ? d->c1 : d->c0;
     return (n > 16 && d->out_c % 32 == 0) ? split_np : 0;
 }
@@ -1829,6 +2018,13 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
 #define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS, KS, 1, 1, 8, 32>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \
                                                  sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part)
         if (sp.halo64) {
+            if (wgrad_split_on()) {
+                constexpr size_t lds = (size_t)64 * ((3 * 64 + 8) + (3 * 6 * 32 + 8)) * 2;           // dZs + Xs (halfwords)
+                static bool attr = false;
+                if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_halo64s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+                hipLaunchKernelGGL(wgrad_halo64s_kernel, dim3(g, sp.co_groups), dim3(256), lds, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
+                                   sp.tiles_per_block, x0, x1, dz, part);
+            } else
             hipLaunchKernelGGL(wgrad_halo64_kernel, dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
                                sp.tiles_per_block, x0, x1, dz, part);
         } else if (sp.stem) {

@@ -306,6 +306,8 @@ def _prof_end(start, kind, flops, desc=None, source=0):
             kind = "conv_fwd_split"
         elif kind == "conv_dgrad" and lib().codeps_conv2d_arith(ctypes.byref(desc), 1, source) > 0:
             kind = "conv_dgrad_split"
+        elif kind == "conv_wgrad" and lib().codeps_conv2d_arith(ctypes.byref(desc), 2, 0) > 0:
+            kind = "conv_wgrad_split"
     _profile["events"].append((kind, flops, start, e, tag))
 
 
