@@ -1253,8 +1253,27 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
 
     // staging tasks: "big" = 8 pixels x 4 channels (128 dZ tasks, then 192 X tasks: 6 rows x 2 groups x 16 channel quads),
     // "small" = one halo pixel x 4 channels (6 rows x 2 sides x 16).  Thread tid owns big tasks tid and tid + 256 (< 320) and,
-    // from thread 64 on, small task tid - 64.
+    // from thread 64 on, small task tid - 64.  Task -> (channel quad, pixel group): the quad's low two bits run over four
+    // consecutive lanes (64 contiguous bytes per pixel in HBM), then the pixel group, then the quad's high bits -- with the
+    // quad fastest, eight neighbouring lanes would write LDS rows 4 channels apart, which all fall on two bank groups.
     f32x4 bigr[2][8], smallr;
+    auto task_of = [](int t, int ngrp, int& c4, int& grp) {               // t in [0, 16 * ngrp)
+        c4 = (t & 3) | ((t / (4 * ngrp)) << 2);
+        grp = (t >> 2) % ngrp;
+    };
+    // eight consecutive pixels (iy, ix0 .. ix0 + 7) of the X source, 4 channels from c4 * 4; zero outside the image
+    auto x_row8 = [&](int b, int iy, int ix0, int c4, f32x4 (&dst)[8]) {
+        if (p.pad_mode == 1) iy = reflect_idx(iy, p.H);
+        const bool rowok = iy >= 0 && iy < p.H && c_src + c4 * 4 < cs;
+        const float* rowp = src + ((size_t)b * Hs + (up ? iy >> 1 : iy)) * Ws * cs + c_src + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int ix = ix0 + i;
+            if (p.pad_mode == 1) ix = reflect_idx(ix, p.W);
+            const bool ok = rowok && ix >= 0 && ix < p.W;
+            dst[i] = ok ? *reinterpret_cast<const f32x4*>(rowp + (size_t)(up ? ix >> 1 : ix) * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     auto x_pixel = [&](int b, int iy, int ix, int c4) -> f32x4 {
         if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
@@ -1270,20 +1289,18 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
         for (int u = 0; u < 2; ++u) {
             const int bt = tid + 256 * u;
             if (bt >= 320) break;
-            if (bt < 128) {                                          // dZ: channel quad c4, pixel group grp
-                const int c4 = bt & 15, grp = bt >> 4;
+            int c4, grp;
+            if (bt < 128) {                                          // dZ: channel quad c4, pixel group grp (8 per tile)
+                task_of(bt, 8, c4, grp);
                 const int gy = ty0 + (grp >> 1), gx0 = tx0 + (grp & 1) * 8;
+                const bool rowok = gy < p.Ho && co_base + c4 * 4 < p.Co;
+                const float* rowp = dz + (((size_t)b * p.Ho + gy) * p.Wo + gx0) * p.Co + co_base + c4 * 4;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (gy < p.Ho && gx0 + i < p.Wo && co_base + c4 * 4 < p.Co)
-                        v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * p.Ho + gy) * p.Wo + gx0 + i) * p.Co + co_base + c4 * 4);
-                    bigr[u][i] = v;
-                }
-            } else {                                                 // X interior: row r (image row ty0 + r - 1), group g
-                const int t = bt - 128, c4 = t & 15, rg = t >> 4, r = rg >> 1, g = rg & 1;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) bigr[u][i] = x_pixel(b, ty0 + r - 1, tx0 + g * 8 + i, c4);
+                for (int i = 0; i < 8; ++i)
+                    bigr[u][i] = (rowok && gx0 + i < p.Wo) ? *reinterpret_cast<const f32x4*>(rowp + (size_t)i * p.Co) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {                                                 // X interior: grp = row r * 2 + group g (12 per tile)
+                task_of(bt - 128, 12, c4, grp);
+                x_row8(b, ty0 + (grp >> 1) - 1, tx0 + (grp & 1) * 8, c4, bigr[u]);
             }
         }
         if (tid >= 64) {
@@ -1297,13 +1314,13 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
             const int bt = tid + 256 * u;
             if (bt >= 320) break;
             unsigned short* dst;                                     // element 0 of this task's 8-pixel segment, piece 0, channel c4 * 4
-            int cstride, qstride;
+            int cstride, qstride, c4, grp;
             if (bt < 128) {
-                const int c4 = bt & 15, grp = bt >> 4;
+                task_of(bt, 8, c4, grp);
                 dst = dZs + (c4 * 4) * ZP + grp * 8; cstride = ZP; qstride = PIX;
             } else {
-                const int t = bt - 128, c4 = t & 15, rg = t >> 4, r = rg >> 1, g = rg & 1;
-                dst = Xs + (c4 * 4) * XP + r * XROW + 8 + g * 8; cstride = XP; qstride = XQ;
+                task_of(bt - 128, 12, c4, grp);
+                dst = Xs + (c4 * 4) * XP + (grp >> 1) * XROW + 8 + (grp & 1) * 8; cstride = XP; qstride = XQ;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {                            // transpose in registers: channel e of the 8 pixels
