@@ -637,6 +637,201 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
     }
 }
 
+// ---------------------------------------------------------------------------------- halo-tile variant (3x3, stride 1)
+// conv_igemm_kernel stages a 128-pixel x 32-channel activation tile once per TAP: for a 3x3 layer every activation element is
+// loaded, split and written to LDS nine times per column tile.  Here the block's 128 output pixels are a 4 x 32 rectangle and
+// the 6 x 34 halo rectangle of one 32-channel chunk (of either concat source; nearest x2 of source 0 fused) is staged ONCE; the nine taps read their A fragments from shifted rows
+// of it (a tap is a row offset in the [pixel][piece][32] layout: aligned, no gather table).  Only the pre-split weights of
+// (tap, chunk) move per K-step, through a double buffer: one barrier per tap.  Same arithmetic, same epilogue.
+// MODE_DGRAD (stride 1): input pixel p sums dZ(p + (1 - ky, 1 - kx)) x W[ci][tap][co]: the same kernel with mirrored taps.
+template <int MODE, int TN>
+__global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ residual, float* __restrict__ out) {
+    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = 3;
+    constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;      // 128 outputs, 204 halo pixels
+    constexpr int BN = 32 * WN * TN;
+    constexpr int LDK = (NP * BK + 8) / 2;                                        // floats per LDS row
+    constexpr int APASS = (HPIX * 4 + 255) / 256;                                 // (pixel, 8-channel chunk) tasks per thread
+    constexpr int BPASS = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [HPIX][LDK]
+    float* Bs = smem + HPIX * LDK;                     // [2][BN][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
+    const int nt = logical % p.n_nt, mt = logical / p.n_nt;
+    const int n0 = nt * BN;
+    const int Hm = (MODE == MODE_FWD) ? p.Ho : p.H, Wm = (MODE == MODE_FWD) ? p.Wo : p.W;       // = input size (stride 1, pad 1)
+    const int tiles_x = Wm / TW, tiles_y = Hm / TH;
+    const int b = mt / (tiles_x * tiles_y), tr = mt % (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+    const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;                                           // channels of the staged tensor
+    const int nchunks = Kc / BK;
+    // forward: source 0 (C0 channels, optionally at half resolution: nearest x2 fused into the load) ++ source 1 (C1 channels)
+    const bool up = MODE == MODE_FWD && p.up0;
+    const int H0 = up ? Hm / 2 : Hm, W0 = up ? Wm / 2 : Wm;
+    const int cs0 = (MODE == MODE_FWD) ? p.C0 : p.Co;
+    const float* img0 = a0 + (size_t)b * H0 * W0 * cs0;
+    const float* img1 = (MODE == MODE_FWD && p.C1 > 0) ? a1 + (size_t)b * Hm * Wm * p.C1 : nullptr;
+
+    // A staging roles
+    const int achunk = tid & 3;
+    // B staging roles: 8 consecutive k of row rbase + 64 * i, three pieces
+    const int bchunk = tid & 3, rbase = tid >> 2;
+    const size_t wrow = (size_t)9 * Kc;
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const float*>(p.w3), (size_t)p.N * wrow * 6);
+    unsigned boff[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)((size_t)min(n0 + rbase + 64 * i, p.N - 1) * wrow * 6 + bchunk * 16);
+
+    f32x4 areg[APASS * 2], breg[BPASS * NP];
+    auto load_a = [&](int chunk) {
+        const int cstep = chunk * BK;
+        const bool s1 = MODE == MODE_FWD && cstep >= p.C0;
+        const float* base = s1 ? img1 + (cstep - p.C0) + achunk * 8 : img0 + cstep + achunk * 8;
+        const int cs = s1 ? p.C1 : cs0, ws = s1 ? Wm : W0, sh = (!s1 && up) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int pos = (tid >> 2) + 64 * i;
+            const int iy = y0 + pos / HW - 1, ix = x0 + pos % HW - 1;
+            const bool ok = pos < HPIX && iy >= 0 && iy < Hm && ix >= 0 && ix < Wm;
+            const float* src = base + ((size_t)(iy >> sh) * ws + (ix >> sh)) * cs;
+            areg[i * 2] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            areg[i * 2 + 1] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int pos = (tid >> 2) + 64 * i;
+            if (pos >= HPIX) continue;
+            u16x4 lo[NP], hi[NP];
+            split_bf16<NP>(areg[i * 2], lo);
+            split_bf16<NP>(areg[i * 2 + 1], hi);
+            unsigned short* row = reinterpret_cast<unsigned short*>(As + pos * LDK);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + achunk * 8) = pack8(lo[q], hi[q]);
+        }
+    };
+    auto load_b = [&](int tap, int chunk) {
+        const unsigned koff = (unsigned)(tap * Kc + chunk * BK) * 6u;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                breg[i * NP + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + koff + 64 * q, 0, 0));
+    };
+    auto store_b = [&](int buf) {
+        float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + 64 * i) * LDK);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + bchunk * 8) = __builtin_bit_cast(i32x4, breg[i * NP + q]);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // halo position of this lane's output pixel for row tile i (tap (0, 0)): pixel = wm * 64 + i * 32 + lrow
+    int apos[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pix = wm * 64 + i * 32 + lrow;
+        apos[i] = (pix / TW) * HW + pix % TW;
+    }
+
+    load_a(0);
+    load_b(0, 0);
+    int bbuf = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();                                          // the previous chunk's fragment reads are done
+        store_a();
+        if (chunk == 0) store_b(0);
+        __syncthreads();
+        if (chunk + 1 < nchunks) load_a(chunk + 1);               // in flight during the nine taps
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool last = chunk + 1 == nchunks && tap == 8;
+            if (!last) load_b(tap == 8 ? 0 : tap + 1, tap == 8 ? chunk + 1 : chunk);
+            const int ky = tap / 3, kx = tap % 3;
+            const int toff = (MODE == MODE_FWD) ? ky * HW + kx : (2 - ky) * HW + (2 - kx);
+            const float* Bb = Bs + bbuf * BN * LDK + (wn * TN * 32 + lrow) * LDK;
+#pragma unroll
+            for (int kc = 0; kc < BK / 16; ++kc) {
+                bf16x8 af[TM][NP], bf[TN][NP];
+                const int ho = kc * 16 + lhalf * 8;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        af[i][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(As + (apos[i] + toff) * LDK) + q * BK + ho);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        bf[j][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Bb + j * 32 * LDK) + q * BK + ho);
+#pragma unroll
+                for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+                    for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+            }
+            if (!last) store_b(bbuf ^ 1);                         // the other buffer: nobody reads it during this tap
+            bbuf ^= 1;
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (as in conv_igemm_kernel, rows mapped through the 4 x 32 tile)
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;
+    constexpr int V4 = BN / 4, RPASS = 256 / V4;
+    const int c4 = tid % V4, r0 = tid / V4;
+    const int n = n0 + c4 * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_FWD && n < p.N) {
+        if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+        if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+        __syncthreads();
+        if (n < p.N) {
+#pragma unroll 4
+            for (int rr = r0; rr < WM * 32; rr += RPASS) {
+                const int pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
+                const size_t m = ((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
+                if (MODE == MODE_FWD) {
+                    v = v * sc + sh;
+                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                *reinterpret_cast<f32x4*>(out + m * p.N + n) = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- 16-column variant
 // N <= 16 (disparity / class / centre-offset outputs, the 16-channel full-resolution decoder tail and their data
 // gradients): v_mfma_f32_16x16x4_f32 tiles, so no MFMA work is spent on zero-padded output columns.
@@ -1721,6 +1916,24 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     const size_t lds = std::max(((size_t)NBUF * (BM + BN) * LDKf + (size_t)nsrc * ntap * BM) * sizeof(float),
                                 (size_t)WM * 32 * (BN + 4) * sizeof(float));
     if constexpr (NP == 3 && WM == 2 && WN == 2 && TM == 2) {
+        // 3x3 / stride 1 / zero padding, one source at full resolution: halo-tile kernel (activations staged once per channel chunk)
+        static const int halo3 = getenv("CODEPS_HALO3") ? atoi(getenv("CODEPS_HALO3")) : 2;          // x 128 blocks: smaller grids keep split-K / the 256-thread kernel
+        const int Hm_ = (MODE == MODE_FWD) ? p.Ho : p.H, Wm_ = (MODE == MODE_FWD) ? p.Wo : p.W;
+        static const int halo3_up = getenv("CODEPS_HALO3_UP") ? atoi(getenv("CODEPS_HALO3_UP")) : 1;
+        const bool plain = !p.up0 && p.C1 == 0;
+        if (halo3 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.stride_w == 1 && p.pad == 1 && p.pad_w == 1 && p.pad_mode == 0 &&
+            !p.par && p.Ho == p.H && p.Wo == p.W && Wm_ % 32 == 0 && Hm_ % 4 == 0 &&
+            (MODE == MODE_FWD ? (plain || (halo3_up && p.C0 % 32 == 0 && p.C1 % 32 == 0 && (!p.up0 || (p.H % 2 == 0 && p.W % 2 == 0))))
+                              : (plain && p.src == 0 && p.Cs == p.C0)) &&
+            (long long)p.n_mt * p.n_nt >= halo3 * 128) {
+            constexpr size_t lds_h = std::max((size_t)(204 + 2 * BN) * LDKf * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            auto kh = conv_halo3_kernel<MODE, TN>;
+            static bool h_attr = false;
+            if (!h_attr) { (void)hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); h_attr = true; }
+            p.ksplit = 1;
+            hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
+            return;
+        }
         static const int ws_min = getenv("CODEPS_WS_MIN") ? atoi(getenv("CODEPS_WS_MIN")) : 48;      // K-steps from which the wave-specialised kernel runs
         const int ntap_ = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
         const int Kc_ = (MODE == MODE_FWD) ? p.Ct : p.Co, nsteps_ = ntap_ * (Kc_ / BK);
