@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ residual, float* __restrict__ out) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-    static_assert(NP == 0 || (BK == 32 && NBUF == 1), "split-precision variant: BK = 32, single LDS stage");
+    static_assert(NP == 0 || ((BK == 32 || (BK == 16 && NP == 3)) && NBUF == 1), "split-precision variant: BK = 32 (or 16 with pre-split weights), single LDS stage");
     constexpr int LDK = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // padded LDS row (floats): conflict-free b128 fragment reads (an XOR-swizzled
                                                       // unpadded layout was measured 1 % slower on the whole step)
     constexpr int KPT = NP > 0 ? 8 : 4;               // consecutive k values staged per thread and row (split kernel: 8, so that each bf16
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #pragma unroll
             for (int u = 0; u < BREGS; ++u)
                 breg[i * BREGS + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rsB, BPRE ? boff[i] + (unsigned)koff * 6u + 64 * u : boff[i] + (unsigned)koff * 4u + 16 * u, 0, 0));
+                    rsB, BPRE ? boff[i] + (unsigned)(koff >> 5) * 192u + (unsigned)(koff & 31) * 2u + 64 * u : boff[i] + (unsigned)koff * 4u + 16 * u, 0, 0));
     };
     auto store_step = [&](int buf) {
         float* Ab = As + buf * BM * LDK;
@@ -1915,7 +1915,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     constexpr int LDKf = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // LDS row in floats (split precision: NP pieces x BK bf16 + pad)
     const size_t lds = std::max(((size_t)NBUF * (BM + BN) * LDKf + (size_t)nsrc * ntap * BM) * sizeof(float),
                                 (size_t)WM * 32 * (BN + 4) * sizeof(float));
-    if constexpr (NP == 3 && WM == 2 && WN == 2 && TM == 2) {
+    if constexpr (NP == 3 && WM == 2 && WN == 2 && TM == 2 && BK == 32) {
         // 3x3 / stride 1 / zero padding, one source at full resolution: halo-tile kernel (activations staged once per channel chunk)
         static const int halo3 = getenv("CODEPS_HALO3") ? atoi(getenv("CODEPS_HALO3")) : 2;          // x 128 blocks: smaller grids keep split-K / the 256-thread kernel
         const int Hm_ = (MODE == MODE_FWD) ? p.Ho : p.H, Wm_ = (MODE == MODE_FWD) ? p.Wo : p.W;
@@ -2041,6 +2041,8 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         else if (bk32 && nbuf == 1 && split_np == 2) launch_igemm<MODE, WM, WN, TM, TN, 32, 1, 2>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (bk32 && nbuf == 1) launch_igemm<MODE, WM, WN, TM, TN, 32, 1>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
+        else if (MODE == MODE_FWD && split_np == 3 && nbuf == 1 && p.Ct == 16 && p.C1 == 0 && (p.KH * p.KW * 16) % 32 == 0)   /* stem */ \
+            launch_igemm<MODE, WM, WN, TM, TN, 16, 1, 3>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else      launch_igemm<MODE, WM, WN, TM, TN, 16>(p, a0, a1, wq, scale, shift, residual, out, st); \
     } while (0)
     if (p.N > 64) {
@@ -2067,6 +2069,10 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
 
 }  // namespace
 
+// a pack row ([tap][channel]) gets a pre-split copy when the kernel that reads it can be the split-operand one: 32-channel K
+// chunks, or 16-channel chunks (the stem) as long as the row is a whole number of 32-element groups
+static bool split_tail_ok(int kc, int taps) { return kc % 32 == 0 || (kc == 16 && (taps * kc) % 32 == 0); }
+
 extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
                                           const float* w_oihw, float* w_fwd, float* w_dgrad, codeps_stream_t stream) {
     CODEPS_REQUIRE(out_c > 0 && in_c > 0 && kh > 0 && kw > 0 && out_c_pad >= out_c && in_c_pad >= in_c && w_oihw &&
@@ -2078,9 +2084,9 @@ extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, i
                        out_c_pad, in_c_pad, w_fwd, w_dgrad);
     // pre-split copies behind the fp32 packs (rows whose K extent is a multiple of 32 channels: the 3-piece kernel's shapes)
     const int sgrid = (int)std::min<long long>((total / 8 + 255) / 256, 4096);
-    if (w_fwd && in_c_pad % 32 == 0)
+    if (w_fwd && split_tail_ok(in_c_pad, kh * kw))
         hipLaunchKernelGGL(split_pack_kernel, dim3(sgrid), dim3(256), 0, (hipStream_t)stream, w_fwd, total / 8, reinterpret_cast<unsigned short*>(w_fwd + total));
-    if (w_dgrad && out_c_pad % 32 == 0)
+    if (w_dgrad && split_tail_ok(out_c_pad, kh * kw))
         hipLaunchKernelGGL(split_pack_kernel, dim3(sgrid), dim3(256), 0, (hipStream_t)stream, w_dgrad, total / 8, reinterpret_cast<unsigned short*>(w_dgrad + total));
     CODEPS_CHECK_LAUNCH("pack_weights_kernel");
     return CODEPS_OK;
@@ -2092,7 +2098,7 @@ extern "C" size_t codeps_conv2d_packed_weight_floats(int out_c_pad, int in_c_pad
     if (out_c_pad <= 0 || in_c_pad <= 0 || kh <= 0 || kw <= 0) return 0;
     const size_t total = (size_t)out_c_pad * in_c_pad * kh * kw;
     const int kext = dgrad ? out_c_pad : in_c_pad;
-    return total + (kext % 32 == 0 ? (total * 6 + 3) / 4 : 0);
+    return total + (split_tail_ok(kext, kh * kw) ? (total * 6 + 3) / 4 : 0);
 }
 
 // Which arithmetic a launch of this shape uses: 3 / 2 = fp32 operands as 3 / 2 bf16 pieces on v_mfma_f32_32x32x16_bf16 (main
@@ -2107,6 +2113,7 @@ static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
     if (force_bk == 16 || (nbuf_env && nbuf_env != 1)) return 0;
     if (mode == 0) {
         const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
+        if (d->out_c > 16 && gran == 16 && d->c1 == 0 && split_np == 3 && (d->kh * d->kw * 16) % 32 == 0) return 3;     // the stem
         return (d->out_c > 16 && gran % 32 == 0) ? split_np : 0;
     }
     if (mode == 2) return (split_np == 3 && wgrad_split_on() && wgrad_small_plan(d).halo64) ? 3 : 0;
