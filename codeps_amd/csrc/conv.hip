@@ -1600,6 +1600,157 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     }
 }
 
+// Weight gradient of the double-pixel stem (7 x 4 taps of 16 channels, stride (2, 1), 64 output channels) on the bf16 matrix
+// cores, built like wgrad_halo64s_kernel: 4 x 16 output tiles, operands transposed to [channel][piece][pixel] while staged,
+// x-shifted tap fragments made in registers from two aligned 8-pixel groups (kx = 2 is a pure register rotation).  N is only
+// 16 channels, so the MFMA is v_mfma_f32_16x16x32_bf16 (16 co x 16 ci x 32 pixels); the four waves split the seven tap rows
+// and each keeps all four 16-channel co tiles: 12 dZ + 24 X fragment reads for up to 384 MFMAs per wave and tile.
+__global__ __launch_bounds__(256) void wgrad_stem74s_kernel(WgradP p, int tiles_x, int tiles_y, int tiles_per_block,
+                                                            const float* __restrict__ x0, const float* __restrict__ dz, float* __restrict__ part) {
+    constexpr int TH = 4, TW = 16, KH = 7, KW = 4, XH = (TH - 1) * 2 + KH, PIX = TH * TW, XROW = 24;
+    constexpr int ZP = 3 * PIX + 8;                    // halfwords per dZ channel
+    constexpr int XQ = XH * XROW, XP = 3 * XQ;         // halfwords per X piece / channel (468 dwords: odd multiple of 4 -> conflict-free)
+    __shared__ __attribute__((aligned(16))) unsigned short dZs[64 * ZP];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[16 * XP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
+    const int blk = blockIdx.x;
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+
+    f32x4 acc[4][2][KW];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < KW; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging tasks of 8 pixels x 4 channels: 128 for dZ (16 channel quads x 8 groups), 156 for X (4 quads x 13 rows x 3 groups);
+    // thread tid owns tasks tid and tid + 256 (< 284); quad index fastest over four lanes (64 contiguous bytes per pixel)
+    f32x4 bigr[2][8];
+    auto load_tile = [&](int tile) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bt = tid + 256 * u;
+            if (bt >= 284) break;
+            if (bt < 128) {
+                const int c4 = (bt & 3) | ((bt >> 5) << 2), grp = (bt >> 2) & 7;
+                const int gy = ty0 + (grp >> 1), gx0 = tx0 + (grp & 1) * 8;
+                const bool rowok = gy < p.Ho;
+                const float* rowp = dz + (((size_t)b * p.Ho + gy) * p.Wo + gx0) * p.Co + c4 * 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    bigr[u][i] = (rowok && gx0 + i < p.Wo) ? *reinterpret_cast<const f32x4*>(rowp + (size_t)i * p.Co) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int t = bt - 128, c4 = t & 3, grp = t >> 2, row = grp / 3, g = grp % 3;
+                const int iy = ty0 * 2 + row - p.pad, ix0 = tx0 + g * 8 - p.pad_w;
+                const bool rowok = iy >= 0 && iy < p.H;
+                const float* rowp = x0 + ((size_t)b * p.H + iy) * p.W * 16 + c4 * 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ix = ix0 + i;
+                    bigr[u][i] = (rowok && ix >= 0 && ix < p.W) ? *reinterpret_cast<const f32x4*>(rowp + (size_t)ix * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bt = tid + 256 * u;
+            if (bt >= 284) break;
+            unsigned short* dst;
+            int cstride, qstride;
+            if (bt < 128) {
+                const int c4 = (bt & 3) | ((bt >> 5) << 2), grp = (bt >> 2) & 7;
+                dst = dZs + (c4 * 4) * ZP + grp * 8; cstride = ZP; qstride = PIX;
+            } else {
+                const int t = bt - 128, c4 = t & 3, grp = t >> 2, row = grp / 3, g = grp % 3;
+                dst = Xs + (c4 * 4) * XP + row * XROW + g * 8; cstride = XP; qstride = XQ;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 lo4 = {bigr[u][0][e], bigr[u][1][e], bigr[u][2][e], bigr[u][3][e]};
+                const f32x4 hi4 = {bigr[u][4][e], bigr[u][5][e], bigr[u][6][e], bigr[u][7][e]};
+                u16x4 lo[3], hi[3];
+                split_bf16<3>(lo4, lo);
+                split_bf16<3>(hi4, hi);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(dst + e * cstride + q * qstride) = pack8(lo[q], hi[q]);
+            }
+        }
+    };
+
+    if (t_beg < t_end) load_tile(t_beg);
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                           // K-step = 32 output pixels = tile rows 2 ks, 2 ks + 1
+            bf16x8 zf[4][3];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    zf[a][q] = *reinterpret_cast<const bf16x8*>(dZs + (a * 16 + l16) * ZP + q * PIX + ks * 32 + kg * 8);
+#pragma unroll
+            for (int kyl = 0; kyl < 2; ++kyl) {
+                const int ky = wave * 2 + kyl;
+                if (ky >= KH) continue;
+                const int r = 2 * (2 * ks + (kg >> 1)) + ky;       // input row of this lane's 8 pixels through tap row ky
+                bf16x8 xf[KW][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const unsigned short* g0 = Xs + l16 * XP + q * XQ + r * XROW + (kg & 1) * 8;
+                    const i32x4 cur = *reinterpret_cast<const i32x4*>(g0), next = *reinterpret_cast<const i32x4*>(g0 + 8);
+                    i32x4 s1, s2, s3;
+                    s2[0] = cur[1]; s2[1] = cur[2]; s2[2] = cur[3]; s2[3] = next[0];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) s1[i] = (int)__builtin_amdgcn_alignbit((unsigned)cur[i + 1], (unsigned)cur[i], 16);
+                    s1[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)cur[3], 16);
+                    s3[0] = (int)__builtin_amdgcn_alignbit((unsigned)cur[2], (unsigned)cur[1], 16);
+                    s3[1] = (int)__builtin_amdgcn_alignbit((unsigned)cur[3], (unsigned)cur[2], 16);
+                    s3[2] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)cur[3], 16);
+                    s3[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[1], (unsigned)next[0], 16);
+                    xf[0][q] = __builtin_bit_cast(bf16x8, cur);
+                    xf[1][q] = __builtin_bit_cast(bf16x8, s1);
+                    xf[2][q] = __builtin_bit_cast(bf16x8, s2);
+                    xf[3][q] = __builtin_bit_cast(bf16x8, s3);
+                }
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                    for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                        for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+                                acc[a][kyl][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[a][qa], xf[kx][ord - qa], acc[a][kyl][kx], 0, 0, 0);
+            }
+        }
+    }
+    // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + reg
+    float* dst = part + (size_t)blk * p.Co * (KH * KW) * p.Ct;
+#pragma unroll
+    for (int kyl = 0; kyl < 2; ++kyl) {
+        const int ky = wave * 2 + kyl;
+        if (ky >= KH) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = a * 16 + kg * 4 + r;
+                    dst[((size_t)co * (KH * KW) + ky * KW + kx) * p.Ct + l16] = acc[a][kyl][kx][r];
+                }
+    }
+}
+
 // ---------------------------------------------------------------------------------- halo-tile wgrad, 64 x 64 channel tiles
 // 3x3 / stride 1 weight gradient for layers with >= 48 channels on both sides.  A block owns a (64 output channels) x
 // (64 input channels) tile of dW for all 9 taps and walks 4x16-pixel output tiles: the dZ tile and the X tile WITH its
@@ -1748,10 +1899,13 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
         // 16-channel output group per block
         s.ok = s.stem = true;
         s.mt = 1; s.nt = 1; s.ci_chunks = 1; s.co_groups = d->out_c / 16;
+        const bool stem_split = stem74 && d->out_c == 64 && wgrad_split_on() && !(getenv("CODEPS_STEM_SPLIT") && atoi(getenv("CODEPS_STEM_SPLIT")) == 0);
+        if (stem_split) s.co_groups = 1;                          // wgrad_stem74s_kernel: all 64 output channels in one block
         s.tiles_x = cdiv(d->out_w, 16); s.tiles_y = cdiv(d->out_h, 4);
         const int total = d->batch * s.tiles_x * s.tiles_y;
         static const int stem_blocks = getenv("CODEPS_STEM_BLOCKS") ? atoi(getenv("CODEPS_STEM_BLOCKS")) : 768;   // env: tuning experiments only
-        s.tiles_per_block = std::max(8, cdiv(total, std::max(1, stem_blocks / s.co_groups)));
+        static const int stem_sblocks = getenv("CODEPS_STEM_SBLOCKS") ? atoi(getenv("CODEPS_STEM_SBLOCKS")) : 256;   // split kernel: 312 VGPRs -> 1 block / CU, one round
+        s.tiles_per_block = std::max(8, cdiv(total, std::max(1, (stem_split ? stem_sblocks : stem_blocks) / s.co_groups)));
         s.nblk = cdiv(total, s.tiles_per_block);
         s.splits = s.nblk;
         return s;
@@ -2268,6 +2422,8 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
             if (d->kw == 7)
                 hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 7, 2, 2, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks,
                                    sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
+            else if (sp.co_groups == 1)                // ... on the bf16 matrix cores (3-piece operands)
+                hipLaunchKernelGGL(wgrad_stem74s_kernel, dim3(g), dim3(256), 0, st, p, sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, dz, part);
             else                                       // double-pixel stem: 7 x 4 taps of 16 (2 pixels x 8 channels), stride (2, 1)
                 hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 4, 2, 1, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks,
                                    sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
