@@ -2270,7 +2270,11 @@ static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
         if (d->out_c > 16 && gran == 16 && d->c1 == 0 && split_np == 3 && (d->kh * d->kw * 16) % 32 == 0) return 3;     // the stem
         return (d->out_c > 16 && gran % 32 == 0) ? split_np : 0;
     }
-    if (mode == 2) return (split_np == 3 && wgrad_split_on() && wgrad_small_plan(d).halo64) ? 3 : 0;
+    if (mode == 2) {
+        if (split_np != 3 || !wgrad_split_on()) return 0;
+        const SmallPlan sp = wgrad_small_plan(d);
+        return (sp.ok && (sp.halo64 || (sp.stem && sp.co_groups == 1))) ? 3 : 0;       // halo-tile kernel / split stem kernel
+    }
     const int n = source ? d->c1 : d->c0;
     return (n > 16 && d->out_c % 32 == 0) ? split_np : 0;
 }
