@@ -56,7 +56,7 @@ def main():
     for k, (n, rd, wr) in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
         rows.append({"kernel": k, "launches_per_step": round(n / a.steps, 2), "read_mb_per_launch": round(rd / n / 1e6, 3),
                      "write_mb_per_launch": round(wr / n / 1e6, 3), "hbm_gb_per_step": round((rd + wr) / a.steps / 1e9, 4)})
-    conv = [r for r in rows if r["kernel"].startswith(("conv_igemm", "conv_wgrad", "wgrad_small"))]
+    conv = [r for r in rows if r["kernel"].startswith(("conv_igemm", "conv_halo3", "conv_wgrad", "wgrad_small", "wgrad_halo64", "wgrad_stem74"))]
     n_conv = sum(r["launches_per_step"] for r in conv)
     gb_conv = sum(r["hbm_gb_per_step"] for r in conv)
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE x2 (gfx950), KiB -> bytes",
