@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                  // [HPIX][LDK]
     float* Bs = smem + HPIX * LDK;                     // [2][BN][LDK]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
     const int nt = logical % p.n_nt, mt = logical / p.n_nt;
@@ -732,19 +732,21 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
         }
     };
 
-    f32x16 acc[TM][TN];
+    // v_mfma_f32_16x16x32_bf16: one MFMA per 16 x 16 tile and 32-channel K-step (lane = (row l16, k group kg of 8)); the wave's
+    // 64 x (32 TN) tile is 4 x (2 TN) of them
+    constexpr int NA = 4, NB = 2 * TN;
+    const int l16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[NA][NB];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // halo position of this lane's output pixel for row tile i (tap (0, 0)): pixel = wm * 64 + i * 32 + lrow
-    int apos[TM];
+    // halo position of this lane's output pixel for row tile i (tap (0, 0)): pixel = wm * 64 + i * 16 + l16
+    int apos[NA];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int pix = wm * 64 + i * 32 + lrow;
+    for (int i = 0; i < NA; ++i) {
+        const int pix = wm * 64 + i * 16 + l16;
         apos[i] = (pix / TW) * HW + pix % TW;
     }
 
@@ -763,30 +765,28 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
             if (!last) load_b(tap == 8 ? 0 : tap + 1, tap == 8 ? chunk + 1 : chunk);
             const int ky = tap / 3, kx = tap % 3;
             const int toff = (MODE == MODE_FWD) ? ky * HW + kx : (2 - ky) * HW + (2 - kx);
-            const float* Bb = Bs + bbuf * BN * LDK + (wn * TN * 32 + lrow) * LDK;
+            const float* Bb = Bs + bbuf * BN * LDK + (wn * TN * 32 + l16) * LDK;
+            {
+                bf16x8 af[NA][NP], bf[NB][NP];
 #pragma unroll
-            for (int kc = 0; kc < BK / 16; ++kc) {
-                bf16x8 af[TM][NP], bf[TN][NP];
-                const int ho = kc * 16 + lhalf * 8;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < NA; ++i)
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        af[i][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(As + (apos[i] + toff) * LDK) + q * BK + ho);
+                        af[i][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(As + (apos[i] + toff) * LDK) + q * BK + kg * 8);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < NB; ++j)
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        bf[j][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Bb + j * 32 * LDK) + q * BK + ho);
+                        bf[j][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Bb + j * 16 * LDK) + q * BK + kg * 8);
 #pragma unroll
                 for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
                     for (int qa = 0; qa <= ord; ++qa)
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+                        for (int i = 0; i < NA; ++i)
 #pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < NB; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
             }
             if (!last) store_b(bbuf ^ 1);                         // the other buffer: nobody reads it during this tap
             bbuf ^= 1;
@@ -808,11 +808,14 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if (i > 0) __syncthreads();
+        // pass i holds row tiles 2 i, 2 i + 1 of every wave; C layout of the 16 x 16 tile: column = l16, row = 4 kg + reg
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int ih = 0; ih < 2; ++ih)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cs[(wm * 32 + ih * 16 + 4 * kg + r) * LDC + (wn * NB + j) * 16 + l16] = acc[2 * i + ih][j][r];
         __syncthreads();
         if (n < p.N) {
 #pragma unroll 4
