@@ -9,7 +9,10 @@ install it with `net.mixup_fn = Mixup.do_mixup`).  Differences in HOW, not WHAT:
     per-image D2H copy -> numpy loop -> H2D copy (mixup.py:243-257);
   * nothing synchronises the host: the cell choice is the reference's own `np.random.choice` call sequence (host RNG,
     mixup.py:108), everything else is enqueued on the current stream.
-`class_mixup` / `conf_instance_mixup` are not selected by either adaptation YAML (cfg/adapt_*.yaml:34) and raise.
+`class_mixup` (mixup.py:261-311, not selected by either adaptation YAML) is offered through the same kernels: the float64
+warps as three codeps_warp_c2c launches, the class mask and the masked copies as tensor ops, the centre / offset ground
+truth on the device; its `torch.unique` over the source labels synchronises like the reference's.  `conf_instance_mixup`
+(kornia distance transforms) raises NotImplementedError.
 """
 from typing import Any, Dict, List, Optional
 
@@ -87,12 +90,62 @@ class Mixup:
                 rects[b, s] = (mul_y * crop_h, (mul_y + 1) * crop_h - 1, mul_x * crop_w, (mul_x + 1) * crop_w - 1)
         return rects
 
+    @staticmethod
+    def _get_cls_msk(lbl_sem: Tensor) -> Tensor:
+        """mixup.py:69-87: half of the classes present in the (whole batch of) source labels, drawn with the reference's
+        np.random.choice call -> [B,H,W] count mask (> 0 where the pixel's class was drawn)."""
+        all_classes = torch.unique(lbl_sem)                                     # host sync, as in the reference
+        num_classes = all_classes.shape[0]
+        pick = np.random.choice(num_classes, int((num_classes + num_classes % 2) / 2), replace=False)
+        classes = all_classes[torch.as_tensor(pick, device=all_classes.device).long()]
+        return torch.eq(lbl_sem, classes.view(1, -1, 1, 1)).sum(1)
+
+    @staticmethod
+    def class_mixup(img_src, img_tgt, lbl_instance_src, lbl_sem_src, semantic_pred_tgt_ema, instance_pred_tgt_ema, geom_augment,
+                    conf_thresh, get_off_cen=True):
+        """mixup.py:261-311.  img_* [B,3,H,W]; lbl_*_src [B,1,H,W]; *_pred_tgt_ema [B,H,W] (already warped when geom_augment)."""
+        lbl_instance_tgt, lbl_sem_tgt = instance_pred_tgt_ema, semantic_pred_tgt_ema
+        if not geom_augment:
+            size = img_src.shape[-2:]
+            img_tgt = torch.nn.functional.interpolate(img_tgt, size, mode="bilinear", align_corners=False)
+            lbl_sem_tgt = torch.nn.functional.interpolate(lbl_sem_tgt.unsqueeze(1), size, mode="nearest").squeeze(1)
+            lbl_instance_tgt = torch.nn.functional.interpolate(lbl_instance_tgt.unsqueeze(1).float(), size,
+                                                               mode="nearest").type(torch.int32).squeeze(1)
+        cls_msk = (Mixup._get_cls_msk(lbl_sem_src) > 0).unsqueeze(1)            # [B,1,H,W]
+        rgb_mixup = torch.where(cls_msk, img_tgt.float(), img_src.float())
+        lbl_sem_mixup = torch.where(cls_msk, lbl_sem_tgt.unsqueeze(1), lbl_sem_src).squeeze(1)
+        lbl_inst_mixup = torch.where(cls_msk, lbl_instance_tgt.unsqueeze(1).type(torch.int32), lbl_instance_src).squeeze(1)
+        if get_off_cen:
+            lbl_center_mixup, lbl_offset_mixup = Mixup.get_off_cen(lbl_inst_mixup)
+            return rgb_mixup, lbl_sem_mixup, lbl_inst_mixup, lbl_center_mixup, lbl_offset_mixup
+        return rgb_mixup, lbl_sem_mixup, lbl_inst_mixup
+
+    @staticmethod
+    def _do_class_mixup(mixup_data: Dict[str, Any], instance_algo, cfg_mixup) -> Dict[str, Any]:
+        img_src, img_tgt = mixup_data["rgb_src"][0], mixup_data["rgb_tgt"][0]
+        semantic_src, instance_src = mixup_data["semantic_src"], mixup_data["instance_src"]
+        semantic_pred = mixup_data["semantic_pred_tgt_ema"].detach()
+        _, instance_pred = instance_algo.panoptic_fusion(semantic_pred, mixup_data["center_pred_tgt_ema"].detach(),
+                                                         mixup_data["offset_pred_tgt_ema"].detach())
+        geom = bool(cfg_mixup.general.geom_augment)
+        if geom:                                                                 # mixup.py:419-441
+            cs, ct = mixup_data["camera_model_src"], mixup_data["camera_model_tgt"]
+            img_tgt = Mixup.warp_c2c(ct, cs, img_tgt, img_src, interp_mode="bilinear", padding_mode="zeros")
+            instance_pred = Mixup.warp_c2c(ct, cs, instance_pred, instance_src, interp_mode="nearest", padding_mode="zeros").squeeze(1)
+            semantic_pred = Mixup.warp_c2c(ct, cs, semantic_pred, semantic_src, interp_mode="nearest", padding_mode="border").squeeze(1)
+        rgb, sem, inst, center, offset = Mixup.class_mixup(img_src, img_tgt, instance_src, semantic_src, semantic_pred, instance_pred,
+                                                           geom, cfg_mixup.class_mix.conf_thresh)
+        return {"rgb": {0: rgb}, "camera_model": mixup_data["camera_model_src"], "semantic": sem, "center": center, "offset": offset,
+                "instance": inst}
+
     # ------------------------------------------------------------------ entry point
     @staticmethod
     def do_mixup(mixup_strategy: str, mixup_data: Dict[str, Any], instance_algo, cfg_mixup) -> Dict[str, Any]:
         Mixup.check()
+        if mixup_strategy == "class_mixup":
+            return Mixup._do_class_mixup(mixup_data, instance_algo, cfg_mixup)
         if mixup_strategy != "cut_mixup":
-            raise NotImplementedError(f"mixup strategy {mixup_strategy!r}: only 'cut_mixup' (cfg/adapt_*.yaml:34) is built")
+            raise NotImplementedError(f"mixup strategy {mixup_strategy!r}: 'cut_mixup' (cfg/adapt_*.yaml:34) and 'class_mixup' are built")
         img_src = mixup_data["rgb_src"][0]
         img_tgt = mixup_data["rgb_tgt"][0]
         semantic_src, instance_src = mixup_data["semantic_src"], mixup_data["instance_src"]          # [B,1,H,W]

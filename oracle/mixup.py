@@ -154,3 +154,36 @@ def do_cut_mixup(item, thing_list, split_ids, geom_augment=True, nof_vert_split=
             inst[i, y0:y1, x0:x1] = inst_tgt[i, y0:y1, x0:x1].astype(np.int32)
     center, offset = get_off_cen(inst)
     return {"rgb": rgb, "semantic": sem, "instance": inst, "center": center, "offset": offset}
+
+
+def do_class_mixup(item, thing_list, pick, geom_augment=True, ieee_sqrt=False):
+    """Mixup.do_mixup("class_mixup", ...) (mixup.py:261-311,406-449) on numpy inputs; `pick` = the indices np.random.choice drew
+    from the sorted unique source labels (mixup.py:69-75).  -> dict(rgb, semantic, instance, center, offset)."""
+    import torch
+    img_src, img_tgt = item["rgb_src"], item["rgb_tgt"]
+    sem_src, inst_src = item["semantic_src"], item["instance_src"]              # [B,1,H,W]
+    sem_tgt = item["semantic_pred_tgt_ema"]
+    b, _, h, w = img_src.shape
+    inst_tgt = panoptic.panoptic_fusion(sem_tgt, item["center_pred_tgt_ema"], item["offset_pred_tgt_ema"], thing_list)[1]
+    if geom_augment:
+        cs, ct = item["camera_model_src"], item["camera_model_tgt"]
+        img_tgt = warp_c2c(ct, cs, img_tgt, (h, w), "bilinear", "zeros", ieee_sqrt=ieee_sqrt).astype(np.float32)
+        inst_tgt = warp_c2c(ct, cs, inst_tgt, (h, w), "nearest", "zeros", ieee_sqrt=ieee_sqrt)[:, 0].astype(inst_tgt.dtype)
+        sem_tgt = warp_c2c(ct, cs, sem_tgt, (h, w), "nearest", "border", ieee_sqrt=ieee_sqrt)[:, 0].astype(sem_tgt.dtype)
+    else:                                                                        # mixup.py:270-278: plain resizes
+        f = torch.nn.functional.interpolate
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(1)             # the CPU kernel's rounding depends on how the work is split (goldens: one thread)
+        try:
+            img_tgt = f(torch.from_numpy(img_tgt), (h, w), mode="bilinear", align_corners=False).numpy()
+        finally:
+            torch.set_num_threads(nthreads)
+        sem_tgt = f(torch.from_numpy(sem_tgt)[:, None], (h, w), mode="nearest")[:, 0].numpy()
+        inst_tgt = f(torch.from_numpy(inst_tgt)[:, None].float(), (h, w), mode="nearest")[:, 0].numpy().astype(np.int32)
+    classes = np.unique(sem_src)[np.asarray(pick)]
+    msk = np.isin(sem_src, classes)                                              # [B,1,H,W]
+    rgb = np.where(msk, img_tgt.astype(np.float32), img_src.astype(np.float32))
+    sem = np.where(msk[:, 0], sem_tgt, sem_src[:, 0])
+    inst = np.where(msk[:, 0], inst_tgt.astype(np.int32), inst_src[:, 0])
+    center, offset = get_off_cen(inst)
+    return {"rgb": rgb, "semantic": sem, "instance": inst, "center": center, "offset": offset}

@@ -400,6 +400,14 @@ def golden_mixup():
                                                       padding_mode="zeros")
             res[f"{name}_warp_sem"] = Mixup.warp_c2c(ct, cs, item["semantic_pred_tgt_ema"], item["semantic_src"],
                                                      interp_mode="nearest", padding_mode="border")
+    # class_mixup (mixup.py:261-311) on the "geom" and "plain" inputs
+    for name, (b, hs, ws, ht, wt, geom, seed) in {"cls_geom": (2, 48, 96, 40, 112, True, 76), "cls_plain": (2, 48, 96, 40, 112, False, 77)}.items():
+        item = gi.mixup_item(b, hs, ws, ht, wt, seed)
+        np.random.seed(seed)
+        out = Mixup.do_mixup("class_mixup", {k: (dict(v) if isinstance(v, dict) else v) for k, v in item.items()}, algo, _cfg_mixup(geom))
+        meta["cases"][name] = dict(b=b, hs=hs, ws=ws, ht=ht, wt=wt, geom=geom, seed=seed, strategy="class_mixup")
+        res[f"{name}_rgb"], res[f"{name}_semantic"], res[f"{name}_instance"] = out["rgb"][0], out["semantic"], out["instance"]
+        res[f"{name}_center"], res[f"{name}_offset"] = out["center"], out["offset"]
     # Mixup.get_off_cen on its own: ids at the image border (clipped Gaussians), one-pixel instances, an id split in two parts
     inst = torch.zeros(2, 1, 72, 120, dtype=torch.int32)
     inst[0, 0, 0:5, 0:9] = 26001

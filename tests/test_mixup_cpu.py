@@ -63,3 +63,17 @@ def test_offset_center_matches_reference():
 def test_cut_rects_keep_last_row_and_column():
     r = om.cut_rects([0, 7], 48, 96, 2, 4)
     assert r.tolist() == [[0, 23, 0, 23], [24, 47, 72, 95]]
+
+
+@pytest.mark.parametrize("name", ["cls_geom", "cls_plain"])
+def test_do_class_mixup_matches_reference(name):
+    z, meta = load("mixup")
+    c = meta["cases"][name]
+    item = gi.mixup_item(c["b"], c["hs"], c["ws"], c["ht"], c["wt"], c["seed"])
+    item = {k: (v[0].numpy() if isinstance(v, dict) else v.numpy()) for k, v in item.items()}
+    n = np.unique(item["semantic_src"]).size
+    np.random.seed(c["seed"])                                 # the reference's single draw (mixup.py:72-75)
+    pick = np.random.choice(n, int((n + n % 2) / 2), replace=False)
+    out = om.do_class_mixup(item, meta["thing_list"], pick, c["geom"])
+    for k in ("rgb", "semantic", "instance", "center", "offset"):
+        assert out[k].dtype == z[f"{name}_{k}"].dtype and np.array_equal(out[k], z[f"{name}_{k}"]), f"{name}: {k} differs"

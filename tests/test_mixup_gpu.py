@@ -22,7 +22,8 @@ def dev(a):
 
 def _cfg(geom):
     ns = types.SimpleNamespace
-    return ns(general=ns(geom_augment=geom), cut_mix=ns(nof_vert_splits=2, nof_hor_splits=4, nof_segments=2))
+    return ns(general=ns(geom_augment=geom), cut_mix=ns(nof_vert_splits=2, nof_hor_splits=4, nof_segments=2),
+              class_mix=ns(conf_thresh=0.98))
 
 
 def _algo(thing_list):
@@ -123,7 +124,7 @@ def test_do_mixup_matches_reference(name):
     assert np.array_equal(rgb, want["rgb"])
     assert torch.equal(out["camera_model"], data["camera_model_src"])
     with pytest.raises(NotImplementedError):
-        Mixup.do_mixup("class_mixup", data, _algo(meta["thing_list"]), _cfg(c["geom"]))
+        Mixup.do_mixup("conf_instance_mixup", data, _algo(meta["thing_list"]), _cfg(c["geom"]))
 
 
 def test_do_mixup_fullsize_properties():
@@ -201,3 +202,22 @@ def test_adapt_builds_the_mixup_item_like_the_reference():
         assert (l_pre[k] is None) == (l_raw[k] is None), k
         if l_pre[k] is not None:
             assert abs(l_pre[k].item() - l_raw[k].item()) <= 1e-6 * abs(l_pre[k].item()), k
+
+
+@pytest.mark.parametrize("name", ["cls_geom", "cls_plain"])
+def test_class_mixup_matches_reference(name):
+    from codeps_amd.datasets import Mixup
+    z, meta = load("mixup")
+    c = meta["cases"][name]
+    item = gi.mixup_item(c["b"], c["hs"], c["ws"], c["ht"], c["wt"], c["seed"])
+    data = {k: ({0: v[0].to(DEV)} if isinstance(v, dict) else v.to(DEV)) for k, v in item.items()}
+    np.random.seed(c["seed"])
+    out = Mixup.do_mixup("class_mixup", data, _algo(meta["thing_list"]), _cfg(c["geom"]))
+    torch.cuda.synchronize()
+    Mixup.check()
+    for k in ("semantic", "instance", "offset"):
+        got = out[k].cpu().numpy()
+        assert got.dtype == z[f"{name}_{k}"].dtype and np.array_equal(got, z[f"{name}_{k}"]), f"{name}: {k}"
+    np.testing.assert_allclose(out["center"].cpu().numpy(), z[f"{name}_center"], rtol=2e-7, atol=1e-37)
+    # image: the GPU's correctly rounded sqrtf in the warp (geom) / the device's bilinear resize (plain) vs the CPU reference
+    assert np.abs(out["rgb"][0].cpu().numpy() - z[f"{name}_rgb"]).max() < (2e-5 if c["geom"] else 2e-6)
