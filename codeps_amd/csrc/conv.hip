@@ -420,10 +420,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+        // the residual rows of this pass are requested before the barrier: their latency overlaps the LDS round trip (short-K
+        // 1x1 layers spend a fifth of a block's life in this epilogue)
+        constexpr int NRES = (WM * 32 + RPASS - 1) / RPASS;
+        f32x4 resv[NRES];
+        const bool use_res = MODE == MODE_FWD && residual != nullptr && p.ksplit <= 1 && n < p.N;
+        if (use_res) {
+#pragma unroll
+            for (int u = 0; u < NRES; ++u) {
+                const int rr = r0 + u * RPASS;
+                const int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
+                resv[u] = (rr < WM * 32 && m < p.M) ? *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         __syncthreads();
         if (n < p.N) {
-#pragma unroll 4
-            for (int rr = r0; rr < WM * 32; rr += RPASS) {
+#pragma unroll
+            for (int u = 0; u < NRES; ++u) {
+                const int rr = r0 + u * RPASS;
+                if (rr >= WM * 32) break;
                 int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
                 if (m >= p.M) continue;
                 if (MODE == MODE_DGRAD && p.par) {            // class row -> pixel of the full-resolution gradient
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                 }
                 if (MODE == MODE_FWD) {
                     v = v * sc + sh;
-                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
+                    if (use_res) v += resv[u];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
                 }
