@@ -58,6 +58,27 @@ def test_conv_matches_vendor_library_and_is_linear(b, h, w, ci, co, k, s):
     assert rel(ya, yb) < 1e-5
 
 
+@pytest.mark.parametrize("b,h,w,c0,c1,co", [(4, 128, 256, 64, 64, 64), (2, 64, 128, 128, 512, 128)])
+def test_decoder_conv_up_concat_matches_vendor_library(b, h, w, c0, c1, co):
+    """conv3x3(cat(nearest_x2(x0), x1)) at sizes where the halo-tile forward kernel takes the fused up-sample / concat path
+    (>= 256 blocks), against F.conv2d on the materialised input: output, both data gradients and the weight gradient."""
+    F = _F()
+    g = torch.Generator(device=DEV).manual_seed(h + c0)
+    x0 = torch.randn(b, c0, h // 2, w // 2, device=DEV, generator=g)
+    x1 = torch.randn(b, c1, h, w, device=DEV, generator=g)
+    wt = torch.randn(co, c0 + c1, 3, 3, device=DEV, generator=g) * (1.0 / ((c0 + c1) * 9) ** 0.5)
+    gy = torch.randn(b, co, h, w, device=DEV, generator=g)
+    r0, r1, rw = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ry = TF.elu(TF.conv2d(torch.cat([TF.interpolate(r0, scale_factor=2, mode="nearest"), r1], 1), rw, None, 1, 1))
+    ry.backward(gy)
+    d0, d1, dw = to_nhwc(x0).requires_grad_(True), to_nhwc(x1).requires_grad_(True), wt.clone().requires_grad_(True)
+    y = F.conv2d(d0, dw, x1=d1, up0=True, pad=1, act="elu")
+    y.backward(to_nhwc(gy))
+    assert rel(to_nchw(y, co), ry) < 2e-4
+    assert rel(to_nchw(d0.grad, c0), r0.grad) < 2e-4 and rel(to_nchw(d1.grad, c1), r1.grad) < 2e-4
+    assert rel(dw.grad, rw.grad) < 2e-4
+
+
 def test_stem_double_pixel_equals_generic_path_full_size():
     """conv1 of the pose net (6 channels, 7x7 / 2 / 3) at 512x1024: double-pixel layout vs the 16-channel padded form."""
     F = _F()
