@@ -668,7 +668,6 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
     constexpr int BN = 32 * WN * TN;
     constexpr int LDK = (NP * BK + 8) / 2;                                        // floats per LDS row
     constexpr int APASS = (HPIX * 4 + 255) / 256;                                 // (pixel, 8-channel chunk) tasks per thread
-    constexpr int BPASS = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                  // [HPIX][LDK]
     float* Bs = smem + HPIX * LDK;                     // [2][BN][LDK]
@@ -692,15 +691,21 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 
     // A staging roles
     const int achunk = tid & 3;
-    // B staging roles: 8 consecutive k of row rbase + 64 * i, three pieces
-    const int bchunk = tid & 3, rbase = tid >> 2;
+    // B staging roles: a (tap, chunk) row of the pre-split pack is 192 contiguous bytes = 12 16-byte segments, and so is its LDS
+    // row ([piece][32]): task t = tid + 256 i copies segment t % 12 of row t / 12 -- twelve neighbouring lanes move one row, so
+    // both the global read and the LDS write are contiguous (the 4-lanes-per-row mapping left the writes on a 2-way bank conflict)
+    constexpr int BTASK = BN * 12 / 256;
     const size_t wrow = (size_t)9 * Kc;
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const float*>(p.w3), (size_t)p.N * wrow * 6);
-    unsigned boff[BPASS];
+    unsigned boff[BTASK], bdst[BTASK];
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)((size_t)min(n0 + rbase + 64 * i, p.N - 1) * wrow * 6 + bchunk * 16);
+    for (int i = 0; i < BTASK; ++i) {
+        const int t = tid + 256 * i, row = t / 12, seg = t % 12;
+        boff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * 6 + seg * 16);
+        bdst[i] = (unsigned)(row * LDK * 4 + seg * 16);
+    }
 
-    f32x4 areg[APASS * 2], breg[BPASS * NP];
+    f32x4 areg[APASS * 2], breg[BTASK];
     auto load_a = [&](int chunk) {
         const int cstep = chunk * BK;
         const bool s1 = MODE == MODE_FWD && cstep >= p.C0;
@@ -732,19 +737,13 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
     auto load_b = [&](int tap, int chunk) {
         const unsigned koff = (unsigned)(tap * Kc + chunk * BK) * 6u;
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i)
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-                breg[i * NP + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + koff + 64 * q, 0, 0));
+        for (int i = 0; i < BTASK; ++i)
+            breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + koff, 0, 0));
     };
     auto store_b = [&](int buf) {
-        float* Bb = Bs + buf * BN * LDK;
+        char* Bb = reinterpret_cast<char*>(Bs + buf * BN * LDK);
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + 64 * i) * LDK);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + bchunk * 8) = __builtin_bit_cast(i32x4, breg[i * NP + q]);
-        }
+        for (int i = 0; i < BTASK; ++i) *reinterpret_cast<i32x4*>(Bb + bdst[i]) = __builtin_bit_cast(i32x4, breg[i]);
     };
 
     // v_mfma_f32_16x16x32_bf16: one MFMA per 16 x 16 tile and 32-channel K-step (lane = (row l16, k group kg of 8)); the wave's
