@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
 LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -59,7 +59,7 @@ SIGNATURES = {
     "codeps_version": (c_int, []),
     "codeps_last_error": (c_char_p, []),
     "codeps_photometric_workspace_bytes": (c_size_t, [POINTER(PhotometricDesc)]),
-    "codeps_photometric_fwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "codeps_photometric_fwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_photometric_bwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_pack_weights": (c_int, [I, I, I, I, I, I, P, P, P, P]),
     "codeps_conv2d_packed_weight_floats": (c_size_t, [I, I, I, I, I]),
@@ -122,6 +122,11 @@ SIGNATURES = {
     "codeps_panoptic_stats_workspace_bytes": (c_size_t, [I]),
     "codeps_panoptic_stats": (c_int, [P, P, I, I, I, I, I, I, P, P, P, P, c_size_t, P]),
     "codeps_adam_ema_step": (c_int, [P, P, P, P, P, LL, I, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "codeps_step_counter_add": (c_int, [P, c_uint64, P]),
+    "codeps_depth_rule_state_floats": (c_size_t, [I]),
+    "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, P, P]),
+    "codeps_weighted_sum_fwd": (c_int, [P, P, P, I, P, P, P]),
+    "codeps_weighted_sum_bwd": (c_int, [P, P, P, I, P, P, P]),
 }
 
 

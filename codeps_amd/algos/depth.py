@@ -75,6 +75,7 @@ class DepthAlgo:
         self.labels = None
         self.adaptation_cache = {"target_dist": [], "is_car_moving": False}
         self.skip_rule_length = 300
+        self._rule_state = None         # device window of the "car not moving" rule (check_car_moving == "device")
 
     @staticmethod
     def _forward(images, depth_feats_window, depth_head, body_pose_sflow, pose_head, flow_head=None):
@@ -124,8 +125,9 @@ class DepthAlgo:
     def adaptation(self, images: Dict[str, Tuple[Tensor, Tensor, Tensor]], depth_feats_window, camera_models, depth_head,
                    body_pose_sflow, pose_head, flow_head=None, check_car_moving: bool = True, batched=None):
         """Per-key losses (source uses its own ReconstructionLoss geometry), image-count weighted mean
-        (algos/depth.py:507-577).  The reference's rolling "car not moving" rule (depth.py:537-558) needs the
-        pose norm on the host every frame; it is evaluated only when `check_car_moving` (one small D2H copy).
+        (algos/depth.py:507-577).  The reference's rolling "car not moving" rule (depth.py:537-558) reads the pose norm on
+        the host every frame: `check_car_moving` True keeps that form (one small D2H copy), "device" (CodepsNet's default)
+        evaluates the identical rule in a scalar kernel with the window kept in device memory, False switches it off.
 
         `batched` (optional, from CodepsNet.adapt): [(feats_of_one_resolution, {key: (b0, b1)})].  The depth head has
         no batch-dependent op, so it runs ONCE per resolution over all keys' items (8x larger GEMMs than the
@@ -181,7 +183,8 @@ class DepthAlgo:
                     images[key], depth_feats_window[key], camera_models[key], depth_head, body_pose_sflow, pose_head, flow_head,
                     None, key == "source", return_disparity=True)
             skip = False
-            if key == "target" and check_car_moving:
+            if key == "target" and check_car_moving is True:
+                # the reference's host-side form (one D2H copy per frame); "device" below evaluates the same rule on the stream
                 t0, t1 = transformations[key]
                 dist = float(((torch.linalg.norm(t0[0, :3, 3]) + torch.linalg.norm(t1[0, :3, 3])) / 2).detach())
                 cache = self.adaptation_cache["target_dist"]
@@ -196,11 +199,25 @@ class DepthAlgo:
                 smth.pop(key)
             else:
                 num_images[key] = images[key][0].shape[0]
-        total = sum(num_images.values())
-        if total > 0:
-            depth_recon_loss = sum(recon[k] * num_images[k] for k in recon) / total
-            depth_smth_loss = sum(smth[k] * num_images[k] for k in smth) / total
+        live = [k for k in keys if k in recon]
+        if not live:
+            return {"recon": None, "smth": None}, {"smth": None, "sparsity": None}, depth_pred.get("target"), \
+                transformations.get("target"), None, None
+        # image-count weighted means (algos/depth.py:562-577): (sum_k loss_k n_k keep_k) / sum_k n_k keep_k, the weights built
+        # on the device -- with check_car_moving == "device" the rolling rule of depth.py:537-558 is evaluated there as well
+        # (no host sync; a skipped target key gets weight 0 instead of leaving the sum)
+        dev = recon[live[0]].device
+        on_device = check_car_moving == "device" and "target" in live
+        if on_device:
+            if self._rule_state is None or self._rule_state.device != dev:
+                self._rule_state = F.depth_rule_state(dev, self.skip_rule_length)
+            coef = F.depth_key_weights([num_images[k] for k in live], dev, live.index("target"), transformations["target"],
+                                       self._rule_state, self.skip_rule_length)
+            self.adaptation_cache["is_car_moving"] = self._rule_state[2:3].view(torch.int32)     # device flag, read lazily
         else:
-            depth_recon_loss = depth_smth_loss = None
+            coef = F.depth_key_weights([num_images[k] for k in live], dev)
+        factors, ones = [coef[i] for i in range(len(live))], [1.0] * len(live)
+        depth_recon_loss = F.weighted_sum([recon[k] for k in live], ones, factors, coef[len(live)])
+        depth_smth_loss = F.weighted_sum([smth[k] for k in live], ones, factors, coef[len(live)])
         return {"recon": depth_recon_loss, "smth": depth_smth_loss}, {"smth": None, "sparsity": None}, \
             depth_pred.get("target"), transformations.get("target"), None, None

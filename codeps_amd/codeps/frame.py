@@ -91,12 +91,12 @@ class OnlineAdapter:
 
     def __init__(self, model, cfg, world_size: int = 1, group=None, replay=None, rgb_frame_offsets=(0, -1, 1),
                  do_panoptic_fusion: bool = True, nof_adaptation_steps: int = 1):
-        from ..step import ADAPT_MODULES, StepRunner
+        from ..step import StepRunner, ema_module_lists
         from .online_adap import CodepsNet
         self.model, self.cfg, self.replay = model, cfg, replay
         self.offsets, self.do_panoptic_fusion, self.steps = list(rgb_frame_offsets), do_panoptic_fusion, int(nof_adaptation_steps)
         self.runner = StepRunner(model, cfg, "adapt", world_size, group)
-        self.ema_modules = [ADAPT_MODULES[k] for k in ("semantic", "instance", "depth", "pose") if cfg.adapt.ema.get(k, False)]
+        self.ema_modules, _ = ema_module_lists(cfg, self.runner.frozen)
         self.ema_model = None
         if self.ema_modules:                                             # adapt_codeps.py:146-150
             self.ema_model = CodepsNet.ema_model(model)
@@ -120,8 +120,8 @@ class OnlineAdapter:
         results_eval, stats_eval = pre_step(self.model, self.ema_model, self.ema_modules, sample, self.offsets,
                                             self.do_panoptic_fusion, do_class_wise_depth_stats)
         losses = result = None
-        for _ in range(self.steps):
-            _, losses, result = self.runner.step(sample)
+        for i in range(self.steps):          # the EMA filter runs once per frame, after the last optimizer step (adapt_codeps.py:293-299)
+            _, losses, result = self.runner.step(sample, apply_ema=(i == self.steps - 1))
         if self.replay is not None and index is not None:                # adapt_codeps.py:307
             self.replay.add(int(index), result["image_features"][:1])
         return results_eval, stats_eval, losses, result

@@ -40,7 +40,7 @@ class CodepsNet(nn.Module):
         self.depth_algo, self.semantic_algo, self.instance_algo = depth_algo, semantic_algo, instance_algo
         self.faithful_bn_updates = False
         self.mixup_fn = None
-        self.check_car_moving = True
+        self.check_car_moving = "device"       # the rule of algos/depth.py:537-558 on the stream (True: host form, False: off)
 
     # ------------------------------------------------------------------ helpers
     @staticmethod

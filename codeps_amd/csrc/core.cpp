@@ -13,5 +13,5 @@ void codeps_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int codeps_version(void) { return 4; }
+extern "C" int codeps_version(void) { return 5; }
 extern "C" const char* codeps_last_error(void) { return g_err; }

@@ -269,10 +269,13 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(Levels L, const float* _
                                                         const float* __restrict__ pose_m,
                                                         const float* __restrict__ pose_p,
                                                         const float* __restrict__ intr, const float* __restrict__ noise,
-                                                        uint64_t seed, float alpha, float one_minus_alpha,
+                                                        uint64_t seed, const uint64_t* __restrict__ seed_ctr,
+                                                        float alpha, float one_minus_alpha,
                                                         const float* __restrict__ pyr, uint8_t* __restrict__ sel,
                                                         float* __restrict__ loss_part) {
-    __shared__ float sm[15][FPN];         // tgt[3], im[3], ip[3], pred_m[3], pred_p[3]
+    __shared__ float sm[15][FPN];
+    // device-side step counter (bumped once per step by codeps_step_counter_add): a replayed HIP graph draws fresh noise
+    if (seed_ctr) seed += *seed_ctr * 0xD1B54A32D192ED03ull;         // tgt[3], im[3], ip[3], pred_m[3], pred_p[3]
     __shared__ float red[4];
     const int bid = blockIdx.x;
     int s = 0;
@@ -614,8 +617,8 @@ extern "C" size_t codeps_photometric_workspace_bytes(const codeps_photometric_de
 
 extern "C" int codeps_photometric_fwd(const codeps_photometric_desc* d, const float* img_t, const float* img_m,
                                       const float* img_p, const float* depth, const float* pose_m, const float* pose_p,
-                                      const float* intr, const float* noise, float* loss, void* workspace,
-                                      size_t workspace_bytes, codeps_stream_t stream) {
+                                      const float* intr, const float* noise, const uint64_t* noise_counter, float* loss,
+                                      void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     int rc = check_desc(d);
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(img_t && img_m && img_p && depth && pose_m && pose_p && intr && loss && workspace, CODEPS_ERR_ARG,
@@ -633,7 +636,7 @@ extern "C" int codeps_photometric_fwd(const codeps_photometric_desc* d, const fl
     }
     const int nblk = L.fblk[L.num_scales];
     hipLaunchKernelGGL(photo_fwd_kernel, dim3(nblk), dim3(256), 0, st, L, img_t, img_m, img_p, depth, pose_m, pose_p, intr,
-                       noise, (uint64_t)d->noise_seed, d->alpha, (float)(1.0 - (double)d->alpha),
+                       noise, (uint64_t)d->noise_seed, noise_counter, d->alpha, (float)(1.0 - (double)d->alpha),
                        (const float*)(ws + W.pyr), (uint8_t*)(ws + W.sel), (float*)(ws + W.loss_part));
     CODEPS_CHECK_LAUNCH("photo_fwd_kernel");
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + W.loss_part), nblk, loss);

@@ -9,9 +9,25 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import check, lib, ptr, require_cuda, stream_ptr
+from ._lib import CodepsHipError, check, lib, ptr, require_cuda, stream_ptr
 
 _seed_counter = [0x5EED]
+_noise_counter = [None]       # device uint64 step counter mixed into the photometric tie-break seed (set by the step harness)
+
+
+def set_noise_stream(counter, seed_base=None):
+    """Bind the photometric tie-break noise to a DEVICE step counter (int64 tensor [1], bumped on the stream by
+    `step_counter_add`) and, optionally, restart the host-side per-call seed sequence.  With both, the seeds a step uses are a
+    function of (call position within the step, device counter): a captured HIP graph then draws fresh noise on every replay and
+    agrees bit for bit with the eagerly launched step."""
+    _noise_counter[0] = counter
+    if seed_base is not None:
+        _seed_counter[0] = int(seed_base)
+
+
+def step_counter_add(counter, increment=1):
+    require_cuda(counter)
+    check(lib().codeps_step_counter_add(ptr(counter), int(increment), stream_ptr()), "codeps_step_counter_add")
 
 
 def _f32c(t):
@@ -25,8 +41,8 @@ class _PhotometricLoss(torch.autograd.Function):
     """Fused multi-scale photometric loss (C ABI: codeps_photometric_{fwd,bwd})."""
 
     @staticmethod
-    def forward(ctx, img_t, img_m, img_p, depth, pose_m, pose_p, intr, noise, num_scales, alpha, seed):
-        require_cuda(img_t, img_m, img_p, depth, pose_m, pose_p, intr, noise)
+    def forward(ctx, img_t, img_m, img_p, depth, pose_m, pose_p, intr, noise, num_scales, alpha, seed, counter=None):
+        require_cuda(img_t, img_m, img_p, depth, pose_m, pose_p, intr, noise, counter)
         img_t, img_m, img_p, depth = (_f32c(x) for x in (img_t, img_m, img_p, depth))
         pose_m, pose_p, intr = _f32c(pose_m), _f32c(pose_p), _f32c(intr)
         noise = None if noise is None else _f32c(noise)
@@ -38,7 +54,7 @@ class _PhotometricLoss(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=img_t.device)
         loss = torch.empty(1, dtype=torch.float32, device=img_t.device)
         check(lib().codeps_photometric_fwd(ctypes.byref(desc), ptr(img_t), ptr(img_m), ptr(img_p), ptr(depth),
-                                           ptr(pose_m), ptr(pose_p), ptr(intr), ptr(noise), ptr(loss), ptr(ws),
+                                           ptr(pose_m), ptr(pose_p), ptr(intr), ptr(noise), ptr(counter), ptr(loss), ptr(ws),
                                            nbytes, stream_ptr()), "codeps_photometric_fwd")
         ctx.save_for_backward(img_t, img_m, img_p, depth, pose_m, pose_p, intr, ws)
         ctx.desc = desc
@@ -53,7 +69,7 @@ class _PhotometricLoss(torch.autograd.Function):
         check(lib().codeps_photometric_bwd(ctypes.byref(ctx.desc), ptr(img_t), ptr(img_m), ptr(img_p), ptr(depth),
                                            ptr(pose_m), ptr(pose_p), ptr(intr), ptr(g), ptr(gd), ptr(gpm), ptr(gpp),
                                            ptr(ws), ws.numel(), stream_ptr()), "codeps_photometric_bwd")
-        return None, None, None, gd, gpm, gpp, None, None, None, None, None
+        return None, None, None, gd, gpm, gpp, None, None, None, None, None, None
 
 
 def photometric_loss(images, depth, poses, intrinsics, num_scales=5, alpha=0.85, noise=None, seed=None):
@@ -70,7 +86,7 @@ def photometric_loss(images, depth, poses, intrinsics, num_scales=5, alpha=0.85,
         seed = _seed_counter[0]
     return _PhotometricLoss.apply(images[0], images[1], images[2], depth, poses[0].reshape(-1, 16),
                                   poses[1].reshape(-1, 16), intrinsics, noise, int(num_scales), float(alpha),
-                                  int(seed))
+                                  int(seed), _noise_counter[0] if noise is None else None)
 
 
 # =============================================================================================
@@ -193,38 +209,45 @@ def _workspace(nbytes, device, tag):
 
 
 _pack_cache = {}           # frozen parameters: valid while (storage, version) is unchanged
-_pack_cache_train = {}     # trainable parameters: valid until the next optimizer step
+_pack_cache_train = {}     # trainable parameters: PERSISTENT pack buffers, re-filled in place once per weights epoch
 _weights_epoch = [0]       # bumped by every in-place optimizer update done through this library
 
 
 def invalidate_weight_cache(everything=False):
-    """Call after modifying parameters in place by means torch cannot see (raw-pointer kernels)."""
+    """Call after modifying parameters in place by means torch cannot see (raw-pointer kernels), and immediately BEFORE
+    capturing a HIP graph of a step: the packs of trainable parameters keep their buffers (a captured graph reads those
+    addresses for as long as it lives) and are re-filled in place by the next `pack_weights` call of the new epoch -- inside a
+    capture that re-fill is recorded, so every replay repacks the weights the optimizer has just written."""
     _weights_epoch[0] += 1
-    _pack_cache_train.clear()
     if everything:
         _pack_cache.clear()
 
 
 def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
-    """OIHW parameter -> (w_fwd, w_dgrad) packs, cached on (storage, tensor version, weights epoch): frozen
-    weights are packed once, trainable ones once per optimizer step (the pose encoder runs 6x per step)."""
-    # trainable parameters, and frozen-looking ones whose storage is rewritten by raw-pointer kernels (an EMA teacher bound to
-    # the optimizer's flat buffers, codeps.frame.OnlineAdapter), are repacked after every optimizer step
-    cache = _pack_cache_train if (weight.requires_grad or getattr(weight, "_codeps_volatile", False)) else _pack_cache
+    """OIHW parameter -> (w_fwd, w_dgrad) packs.  Frozen weights are packed once per (storage, tensor version).  Trainable
+    ones (and frozen-looking ones whose storage is rewritten by raw-pointer kernels: an EMA teacher bound to the optimizer's
+    flat buffers, codeps.frame.OnlineAdapter) own persistent pack buffers that are re-filled once per weights epoch, i.e.
+    once per optimizer step (the pose encoder runs 6x per step)."""
+    volatile = weight.requires_grad or getattr(weight, "_codeps_volatile", False)
+    cache = _pack_cache_train if volatile else _pack_cache
     key = (id(weight), out_c_pad, in_c_pad)
-    ent = cache.get(key)          # (weakref to the parameter, storage, version, w_fwd, w_dgrad): ids / addresses get reused
-    if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version and \
-            (ent[4] is not None or not need_dgrad):
+    stamp = (weight._version, _weights_epoch[0] if volatile else 0)
+    ent = cache.get(key)          # [weakref to the parameter, storage, stamp, w_fwd, w_dgrad]: ids / addresses get reused
+    same = ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr()
+    if same and ent[2] == stamp and (ent[4] is not None or not need_dgrad):
         return ent[3], ent[4]
     co, ci, kh, kw = weight.shape
     w = _f32c(weight.detach())
     # each pack carries its pre-split (3 x bf16) copy behind the fp32 part when its K extent allows the split-operand kernel
-    wf = torch.empty(lib().codeps_conv2d_packed_weight_floats(out_c_pad, in_c_pad, kh, kw, 0), dtype=torch.float32, device=w.device)
-    wd = torch.empty(lib().codeps_conv2d_packed_weight_floats(out_c_pad, in_c_pad, kh, kw, 1), dtype=torch.float32,
-                     device=w.device) if need_dgrad else None
+    wf = ent[3] if same else torch.empty(lib().codeps_conv2d_packed_weight_floats(out_c_pad, in_c_pad, kh, kw, 0),
+                                         dtype=torch.float32, device=w.device)
+    wd = ent[4] if same else None
+    if wd is None and need_dgrad:
+        wd = torch.empty(lib().codeps_conv2d_packed_weight_floats(out_c_pad, in_c_pad, kh, kw, 1), dtype=torch.float32,
+                         device=w.device)
     check(lib().codeps_conv2d_pack_weights(co, ci, kh, kw, out_c_pad, in_c_pad, ptr(w), ptr(wf), ptr(wd), stream_ptr()),
           "codeps_conv2d_pack_weights")
-    cache[key] = (_weak(weight, cache, key), weight.data_ptr(), weight._version, wf, wd)
+    cache[key] = [_weak(weight, cache, key), weight.data_ptr(), stamp, wf, wd]
     return wf, wd
 
 
@@ -1047,6 +1070,66 @@ def offset_loss(pred_nhwc, target):
 def binary_mask_loss(probs_nhwc, target, ignore_index=255):
     """mean CE on thing probabilities (algos/instance_seg.py:44-51); target u8 [B,H,W]."""
     return _InstanceLoss.apply(probs_nhwc, 2, target, 2, int(ignore_index))
+
+
+# ---------------------------------------------------------------------------------------- step control
+def depth_rule_state(device, length=300):
+    """Zero-initialised device state of the rolling "car not moving" rule (algos/depth.py:537-558)."""
+    return torch.zeros(lib().codeps_depth_rule_state_floats(int(length)), dtype=torch.float32, device=device)
+
+
+def depth_key_weights(counts, device, target_index=-1, poses=None, rule_state=None, length=300):
+    """Image-count weights of DepthAlgo.adaptation's per-key losses (algos/depth.py:562-577) as a device vector
+    [n_keys + 1] = (n_k * keep_k ..., their sum), with the "car not moving" rule (depth.py:537-558) evaluated on the device
+    for key `target_index` from that key's (T_t->t-1, T_t->t+1): no host synchronisation, so the rule stays live inside a
+    replayed HIP graph.  `rule_state` (depth_rule_state) carries the rolling window across frames; it is updated in place."""
+    n = len(counts)
+    coef = torch.empty(n + 1, dtype=torch.float32, device=device)
+    require_cuda(coef)
+    kc = (ctypes.c_float * n)(*[float(c) for c in counts])
+    tp = tn = None
+    if target_index >= 0:
+        tp, tn = _f32c(poses[0].detach()).reshape(-1, 16), _f32c(poses[1].detach()).reshape(-1, 16)
+        require_cuda(tp, tn, rule_state)
+    check(lib().codeps_depth_key_weights(ptr(tp), ptr(tn), ptr(rule_state), int(length), n, kc, int(target_index), ptr(coef),
+                                         stream_ptr()), "codeps_depth_key_weights")
+    return coef
+
+
+class _WeightedSum(torch.autograd.Function):
+    """out = sum_i w_i f_i loss_i / D in ONE launch (and one for all gradients) instead of ~3 scalar ATen kernels per term."""
+
+    @staticmethod
+    def forward(ctx, weights, factors, denom, *losses):
+        require_cuda(*losses)
+        n = len(losses)
+        ls = [_f32c(l).reshape(1) for l in losses]
+        dev = ls[0].device
+        lp = (ctypes.c_void_p * n)(*[l.data_ptr() for l in ls])
+        fp = None if factors is None else (ctypes.c_void_p * n)(*[None if f is None else f.data_ptr() for f in factors])
+        w = (ctypes.c_float * n)(*[float(x) for x in weights])
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        check(lib().codeps_weighted_sum_fwd(lp, w, fp, n, ptr(denom), ptr(out), stream_ptr()), "codeps_weighted_sum_fwd")
+        ctx.pack = (w, fp, factors, denom, n)          # `factors` / `denom` tensors are kept alive with the ctypes arrays
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        w, fp, _factors, denom, n = ctx.pack
+        gv = torch.empty(n, dtype=torch.float32, device=g.device)
+        gp = (ctypes.c_void_p * n)(*[gv.data_ptr() + 4 * i if ctx.needs_input_grad[3 + i] else None for i in range(n)])
+        check(lib().codeps_weighted_sum_bwd(ptr(_f32c(g).reshape(1)), w, fp, n, ptr(denom), gp, stream_ptr()),
+              "codeps_weighted_sum_bwd")
+        return (None, None, None, *[gv[i] if ctx.needs_input_grad[3 + i] else None for i in range(n)])
+
+
+def weighted_sum(losses, weights, factors=None, denom=None):
+    """sum_i weights[i] * factors[i] * losses[i] / denom over 0-dim device losses (scripts/adapt_codeps.py:274-288;
+    algos/depth.py:562-577).  weights: host floats; factors: optional per-term 0-dim DEVICE tensors (None = 1);
+    denom: optional 0-dim DEVICE tensor (<= 0 -> result 0, zero gradients)."""
+    if len(losses) != len(weights) or (factors is not None and len(factors) != len(losses)):
+        raise CodepsHipError("weighted_sum: one weight (and one factor) per loss")
+    return _WeightedSum.apply(list(weights), None if factors is None else list(factors), denom, *losses)
 
 
 # ---------------------------------------------------------------------------------------- optimiser

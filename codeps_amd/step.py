@@ -37,6 +37,21 @@ def freeze_for_adaptation(net, cfg):
     return frozen
 
 
+def ema_module_lists(cfg, frozen):
+    """scripts/adapt_codeps.py:56-72: (modules the EMA filter is applied to, modules the teacher copies from the student).
+    `adapt.ema.depth` raises like the reference (its consistency loss does not exist)."""
+    if cfg.adapt.ema.get("depth", False):
+        raise NotImplementedError("Consistency loss for depth is not implemented yet")         # adapt_codeps.py:70-72
+    ema = []
+    if cfg.adapt.ema.get("semantic", False) and cfg.adapt.model.get("semantic", False):
+        ema.append("semantic_head")
+    if cfg.adapt.ema.get("instance", False) and cfg.adapt.model.get("instance", False):
+        ema.append("instance_head")
+    inverted = [m for m in ("backbone_po_depth", "backbone_pose_sflow", "depth_head", "pose_head", "semantic_head", "instance_head")
+                if m not in ema and m not in frozen]
+    return ema, inverted
+
+
 class FlatState:
     """Flat parameter / gradient / Adam / EMA buffers over a list of parameters."""
 
@@ -84,7 +99,7 @@ class StepRunner:
         ema_mods = []
         if mode == "adapt":
             self.frozen = freeze_for_adaptation(net, cfg)
-            ema_mods = [ADAPT_MODULES[k] for k in ("semantic", "instance", "depth", "pose") if cfg.adapt.ema.get(k, False)]
+            ema_mods, _ = ema_module_lists(cfg, self.frozen)
             self.ema_alpha = float(cfg.adapt.ema.alpha)
         else:
             net.train()
@@ -103,36 +118,94 @@ class StepRunner:
                     (ema_params if attr in ema_mods else other).append(p)
         self.groups = [FlatState(ps, with_ema) for ps, with_ema in ((ema_params, True), (other, False)) if ps]
         self.step_count = 0
-        self.net.check_car_moving = False          # host-side rolling rule needs a D2H sync; evaluated by the caller
+        # device step counter mixed into the photometric tie-break noise (bumped on the stream at the start of every step, so a
+        # replayed HIP graph draws new noise) + this runner's host seed base for the calls within one step
+        self.noise_counter = torch.zeros(1, dtype=torch.int64, device=self.groups[0].flat.device)
+        self.seed_base = 0x5EED
+        self._graph = None
 
     @property
     def grad_bytes(self):
         return sum(g.numel * 4 for g in self.groups)
 
     def forward_backward(self, data):
+        F.set_noise_stream(self.noise_counter, self.seed_base)
+        F.step_counter_add(self.noise_counter, 1)
         for g in self.groups:
             g.grad.zero_()
         if self.mode == "adapt":
             losses, result, _, _ = self.net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
         else:
             losses, result, _ = self.net(data, "train", [0, -1, 1])
-        total = None
+        terms, wts = [], []
         for k, v in losses.items():
             w = self.weights.get(k)
             if v is None or w is None or not v.requires_grad:        # scripts/adapt_codeps.py:274-288
                 continue
-            total = v * w if total is None else total + v * w
+            terms.append(v)
+            wts.append(float(w))
+        total = F.weighted_sum(terms, wts)
         total.backward()
         return total.detach(), losses, result
 
-    def optimizer_step(self):
+    def optimizer_step(self, apply_ema=True):
+        """One all-reduce + fused Adam per flat group.  apply_ema False leaves the EMA copy alone: the reference filters the
+        teacher once per FRAME, after its `nof_adaptation_steps` optimizer steps (scripts/adapt_codeps.py:266-299)."""
         self.step_count += 1
         for g in self.groups:
             allreduce_flat_gradients(g.grad, self.group)
             F.adam_ema_step(g.flat, g.grad, g.m, g.v, self.step_count, lr=self.lr, grad_scale=1.0 / self.world,
-                            ema_params=g.ema, ema_alpha=self.ema_alpha)
+                            ema_params=g.ema if apply_ema else None, ema_alpha=self.ema_alpha)
 
-    def step(self, data):
+    def step(self, data, apply_ema=True):
         out = self.forward_backward(data)
-        self.optimizer_step()
+        self.optimizer_step(apply_ema)
         return out
+
+    # ------------------------------------------------------------------ HIP-graph form of the same step
+    def capture(self, data):
+        """Capture forward + backward of THIS batch's buffers into a HIP graph.  `data` holds the static input tensors (refill
+        them in place between replays).  Everything a step decides per frame lives on the stream: the weight packs of the
+        trainable parameters are re-filled inside the graph (the cache epoch is bumped right before the capture, so the pack
+        kernels are recorded and write persistent buffers), the tie-break noise is seeded from a device counter and the
+        "car not moving" rule runs in a kernel -- a replay is a real adaptation step on the current weights
+        (tests/test_graph_gpu.py compares K replayed steps with K eagerly launched ones bit for bit).  The gradient
+        all-reduce and the optimizer stay outside the graph (Adam's bias correction is a host scalar)."""
+        counter_before = self.noise_counter.clone()
+        rule = getattr(self.net.depth_algo, "_rule_state", None) if getattr(self.net, "depth_algo", None) is not None else None
+        rule_before = None if rule is None else rule.clone()
+        bn_before = [(b, b.clone()) for b in self._bn_buffers()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                     # warm-up on a side stream: allocations + lazily created state
+            self.forward_backward(data)
+        torch.cuda.current_stream().wait_stream(side)
+        F.invalidate_weight_cache()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            total, losses, result = self.forward_backward(data)
+            static = (total, OrderedDict((k, None if v is None else v.detach()) for k, v in losses.items()),
+                      OrderedDict((k, v.detach() if torch.is_tensor(v) else v) for k, v in result.items()))
+            del total, losses, result                     # nothing that holds the autograd tape survives the capture
+        # the warm-up advanced per-step state: put it back so that the first replay is the step the eager path would run next
+        self.noise_counter.copy_(counter_before)
+        rule = getattr(self.net.depth_algo, "_rule_state", None) if getattr(self.net, "depth_algo", None) is not None else None
+        if rule is not None:
+            rule.copy_(rule_before) if rule_before is not None else rule.zero_()
+        for b, old in bn_before:
+            b.copy_(old)
+        self._graph, self._static = graph, static
+        return static
+
+    def _bn_buffers(self):
+        return [b for m in self.net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training
+                for b in (m.running_mean, m.running_var, m.num_batches_tracked) if b is not None]
+
+    def replay(self, apply_ema=True):
+        """One step from the captured graph: forward + backward replayed, then all-reduce + Adam/EMA.  Returns the static
+        (total, losses, result) tensors the replay has just refreshed."""
+        if self._graph is None:
+            raise RuntimeError("StepRunner.replay: call capture(data) first")
+        self._graph.replay()
+        self.optimizer_step(apply_ema)
+        return self._static

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* codeps_stream_t;
 
-int codeps_version(void);                 /* ABI version (4), bumped on any signature / buffer-contract change */
+int codeps_version(void);                 /* ABI version (5), bumped on any signature / buffer-contract change */
 const char* codeps_last_error(void);      /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------------------------------------
@@ -36,7 +36,10 @@ const char* codeps_last_error(void);      /* thread-local, valid until the next 
  *   img_*   [B,3,H,W] fp32 NCHW planar (t, t-1, t+1);   depth [B,1,H,W];
  *   pose_*  [B,16] row-major 4x4 (t->t-1, t->t+1);      intr [B,4] = fx,fy,cx,cy at (H,W).
  *   noise   optional [sum_s B*2*Hs*Ws] tie-break noise ALREADY scaled by 1e-5 (scale-major, then
- *           b, k, y, x); NULL => in-kernel counter-based N(0,1)*1e-5 from `noise_seed`.
+ *           b, k, y, x); NULL => in-kernel counter-based N(0,1)*1e-5 from `noise_seed`, mixed with
+ *           *noise_counter when that optional DEVICE counter is given (codeps_step_counter_add bumps it once
+ *           per step ON THE STREAM, so a replayed HIP graph draws new noise every step; the reference
+ *           draws fresh randn per call, algos/depth.py:316-318).
  *   loss    [1].   Scale s has size (H >> s, W >> s) (floor division), s < num_scales <= 8.
  * The workspace written by _fwd (image/depth pyramids + per-pixel selected-branch map) must be
  * handed unchanged to _bwd.
@@ -50,7 +53,8 @@ typedef struct {
 size_t codeps_photometric_workspace_bytes(const codeps_photometric_desc* d);
 int codeps_photometric_fwd(const codeps_photometric_desc* d, const float* img_t, const float* img_m,
                            const float* img_p, const float* depth, const float* pose_m,
-                           const float* pose_p, const float* intr, const float* noise, float* loss,
+                           const float* pose_p, const float* intr, const float* noise,
+                           const uint64_t* noise_counter, float* loss,
                            void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 /* grad_loss [1] (device scalar: d total / d loss); grad_depth [B,1,H,W]; grad_pose_* [B,16]. */
 int codeps_photometric_bwd(const codeps_photometric_desc* d, const float* img_t, const float* img_m,
@@ -273,6 +277,32 @@ int codeps_reflect_pad_fold(const float* grad_padded, int batch, int h, int w, i
 int codeps_adam_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                          float* ema_params, long long n, int step, float lr, float beta1, float beta2,
                          float eps, float grad_scale, float ema_alpha, codeps_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Step control on the stream (csrc/step_ctl.hip): the per-frame decisions the reference takes on the
+ * host, kept on the device so that a captured HIP graph replays a REAL adaptation step.
+ * codeps_step_counter_add: *counter += increment (the counter codeps_photometric_fwd mixes into its
+ *   tie-break noise seed; one launch at the start of every step).
+ * codeps_depth_key_weights: DepthAlgo.adaptation's image-count weights (algos/depth.py:562-577) with
+ *   the rolling "car not moving" rule (depth.py:537-558) evaluated on the device: key_counts is a HOST
+ *   array of n_keys image counts (order of the losses: source, target, target_replay); target_index
+ *   = position of the "target" key or -1 (rule off); pose_prev / pose_next = the target key's [.,16]
+ *   transformations (item 0 is read); rule_state = codeps_depth_rule_state_floats(length) zero-
+ *   initialised floats kept by the caller across frames (length = 300 in the reference).
+ *   coef [n_keys + 1] <- n_k * keep_k, then their sum (0 when every key is skipped).
+ * codeps_weighted_sum_{fwd,bwd}: out = sum_i w_i f_i loss_i / D  (scripts/adapt_codeps.py:274-288 and
+ *   depth.py:562-577): losses / factors / grads are HOST arrays of n DEVICE scalar pointers (factors
+ *   may be NULL or hold NULL entries = 1; grads entries may be NULL), weights a HOST array, denom an
+ *   optional DEVICE scalar (D <= 0 gives out = 0 and zero gradients).  n <= 16. */
+int codeps_step_counter_add(uint64_t* counter, uint64_t increment, codeps_stream_t stream);
+size_t codeps_depth_rule_state_floats(int length);
+int codeps_depth_key_weights(const float* pose_prev, const float* pose_next, float* rule_state, int length,
+                             int n_keys, const float* key_counts, int target_index, float* coef,
+                             codeps_stream_t stream);
+int codeps_weighted_sum_fwd(const float* const* losses, const float* weights, const float* const* factors,
+                            int n, const float* denom, float* out, codeps_stream_t stream);
+int codeps_weighted_sum_bwd(const float* grad_out, const float* weights, const float* const* factors, int n,
+                            const float* denom, float* const* grads, codeps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Panoptic fusion (K14): InstanceSegAlgo.panoptic_fusion (algos/instance_seg.py:207-258) ->

@@ -1,0 +1,203 @@
+"""The HIP-graph form of the adaptation step (StepRunner.capture / replay) must BE the eagerly launched step:
+K replayed steps == K eager steps bit for bit (parameters, Adam moments, EMA copy, BatchNorm running statistics, losses),
+the weight packs are re-filled inside the graph, the tie-break noise advances per replay, and the "car not moving" rule
+(algos/depth.py:537-558) stays live.  Reference region: scripts/adapt_codeps.py:260-299."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(seed=20, replay_items=2):
+    from codeps_amd import synthetic
+    from codeps_amd.codeps import gen_models
+    from codeps_amd.config import get_cfg_defaults
+    torch.manual_seed(seed)
+    cfg = get_cfg_defaults(adapt=True)
+    cfg.model.po_depth_net.params.nof_layers = 18
+    ht, wt, hs, ws = 64, 160, 64, 128
+    cfg.dataset.feed_img_size = [ht, wt]
+    cfg.adapt.source_dataset.feed_img_size = [hs, ws]
+    net = gen_models(cfg, torch.device(DEV), list(range(9)), [9, 10, 11, 12, 13], [], adaptation_mode=True)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    data = {"target": synthetic.triplet_item(1, ht, wt, gen, DEV), "target_replay": synthetic.triplet_item(replay_items, ht, wt, gen, DEV),
+            "source": synthetic.triplet_item(2, hs, ws, gen, DEV, labels=True)}
+    mix = synthetic.triplet_item(1, hs, ws, gen, DEV, labels=True)
+    data["cut_mixup"] = {"rgb": {0: mix["rgb"][0]}, "semantic": mix["semantic"]}
+    return net, cfg, data
+
+
+def _state(runner):
+    out = {}
+    for i, g in enumerate(runner.groups):
+        out[f"flat{i}"], out[f"m{i}"], out[f"v{i}"] = g.flat.clone(), g.m.clone(), g.v.clone()
+        if g.ema is not None:
+            out[f"ema{i}"] = g.ema.clone()
+    for n, b in runner.net.named_buffers():
+        out["buf." + n] = b.clone()
+    out["noise_counter"] = runner.noise_counter.clone()
+    return out
+
+
+def test_replayed_steps_equal_eager_steps_bitwise():
+    from codeps_amd import functional as F
+    from codeps_amd.step import StepRunner
+    K = 3
+    net_a, cfg, data = _setup()
+    net_b = copy.deepcopy(net_a)
+    # lr large enough that three Adam steps visibly move every weight (the default 1e-4 does too; this makes the
+    # "graph sees the new weights" assertion below robust)
+    ra, rb = StepRunner(net_a, cfg, "adapt", 1, lr=1e-3), StepRunner(net_b, cfg, "adapt", 1, lr=1e-3)
+    eager = []
+    for _ in range(K):
+        total, losses, _ = ra.step(data)
+        eager.append({k: v.detach().clone() for k, v in losses.items() if v is not None} | {"total": total.clone()})
+    sa = _state(ra)
+
+    rb.capture(data)
+    graphed = []
+    for _ in range(K):
+        total, losses, _ = rb.replay()
+        graphed.append({k: v.clone() for k, v in losses.items() if v is not None} | {"total": total.clone()})
+    sb = _state(rb)
+    torch.cuda.synchronize()
+
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), f"{k}: graph-replayed steps differ from eager steps (max |d| = " \
+                                          f"{float((sa[k].double() - sb[k].double()).abs().max()):.3e})"
+    for i, (e, g) in enumerate(zip(eager, graphed)):
+        assert e.keys() == g.keys()
+        for k in e:
+            assert torch.equal(e[k], g[k]), f"step {i}: loss {k}: eager {float(e[k])!r} vs graph {float(g[k])!r}"
+    # the replays really trained: losses move from step to step, i.e. the graph read the weights Adam had just written
+    assert float(graphed[0]["total"]) != float(graphed[K - 1]["total"])
+    assert int(rb.noise_counter) == K and int(ra.noise_counter) == K
+    # and a step on stale weights WOULD have been visible: re-running step 1's inputs on the final weights gives another loss
+    assert not torch.equal(graphed[0]["depth_recon"], graphed[1]["depth_recon"])
+    del F
+
+
+def test_capture_records_the_weight_packs():
+    """The defect of round 1: the capture hit the per-step pack cache, no pack kernel was recorded and every replay ran
+    on capture-time weights.  Here: zero the pack buffers behind the graph's back -- a replay must re-fill them."""
+    from codeps_amd import functional as F
+    from codeps_amd.step import StepRunner
+    net, cfg, data = _setup()
+    r = StepRunner(net, cfg, "adapt", 1)
+    r.capture(data)
+    r.replay()
+    torch.cuda.synchronize()
+    packs = [e for e in F._pack_cache_train.values() if e[0]() is not None]
+    assert len(packs) >= 20, "trainable conv weights must own persistent pack buffers"
+    ptrs = [(e[3].data_ptr(), None if e[4] is None else e[4].data_ptr()) for e in packs]
+    ref = [e[3].clone() for e in packs]
+    changed = 0
+    for e in packs:
+        e[3].zero_()
+    r.replay()
+    torch.cuda.synchronize()
+    for e, p, old in zip(packs, ptrs, ref):
+        assert (e[3].data_ptr(), None if e[4] is None else e[4].data_ptr()) == p, "pack buffers must be persistent"
+        assert float(e[3].abs().sum()) > 0, "a replay must re-fill the weight packs (pack kernels recorded in the graph)"
+        changed += int(not torch.equal(e[3], old))
+    assert changed >= len(packs) // 2, "the packs must follow the weights Adam has just written"
+
+
+def test_noise_advances_per_replay_and_matches_eager_seeding():
+    """Two consecutive forward passes on IDENTICAL weights differ only through the tie-break noise (depth.py:316-318):
+    the selected-branch map of the auto-mask changes where identity and warped losses tie."""
+    from codeps_amd import functional as F
+    dev = torch.device(DEV)
+    b, h, w = 1, 64, 128
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    img = torch.rand(b, 3, h, w, generator=gen, device=dev)
+    imgs = (img, img.clone(), img.clone())             # identical frames: every pixel ties up to the noise
+    depth = torch.rand(b, 1, h, w, generator=gen, device=dev) * 20 + 1
+    eye = torch.eye(4, device=dev).repeat(b, 1, 1)
+    intr = torch.tensor([[100.0, 100.0, w / 2, h / 2]], device=dev)
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    F.set_noise_stream(ctr, 0x5EED)
+    l0 = F.photometric_loss(imgs, depth, (eye, eye), intr)
+    F.set_noise_stream(ctr, 0x5EED)
+    l0_again = F.photometric_loss(imgs, depth, (eye, eye), intr)
+    F.step_counter_add(ctr, 1)
+    F.set_noise_stream(ctr, 0x5EED)
+    l1 = F.photometric_loss(imgs, depth, (eye, eye), intr)
+    F.set_noise_stream(None)
+    assert torch.equal(l0, l0_again), "same host seed + same device counter must reproduce the noise"
+    assert not torch.equal(l0, l1), "bumping the device counter must change the noise"
+
+
+def test_car_not_moving_rule_on_the_device_matches_the_host_rule():
+    """algos/depth.py:537-558 restated on the host (Python list semantics) against the scalar kernel, frame by frame,
+    through warm-up (< 300 frames), steady state, and stretches of stationary frames."""
+    from codeps_amd import functional as F
+    dev = torch.device(DEV)
+    L = 12                                               # the reference uses 300; the rule is length-agnostic
+    gen = torch.Generator().manual_seed(0)
+    n = 80
+    tr = torch.rand(n, 2, 3, generator=gen) * 2.0
+    tr[30:38] *= 0.01                                    # the car stops
+    tr[60:63] *= 0.05
+    state = F.depth_rule_state(dev, L)
+    cache, expect, got = [], [], []
+    for i in range(n):
+        tp, tn = torch.eye(4).repeat(2, 1, 1), torch.eye(4).repeat(2, 1, 1)
+        tp[0, :3, 3], tn[0, :3, 3] = tr[i, 0], tr[i, 1]
+        tp[1, :3, 3] = 99.0                             # only item 0 is read
+        dist = (torch.linalg.norm(tp[0, :3, 3]) + torch.linalg.norm(tn[0, :3, 3])) / 2
+        if len(cache) > L:
+            cache.pop(0)
+        skip = len(cache) == L and bool(sum(cache) / L > 10 * dist)
+        if not skip:
+            cache.append(dist)
+        expect.append(skip)
+        coef = F.depth_key_weights([2, 1, 3], dev, 1, (tp.to(dev), tn.to(dev)), state, L)
+        got.append(coef.cpu())
+    assert any(expect) and not all(expect)
+    for i, (e, c) in enumerate(zip(expect, got)):
+        want = [2.0, 0.0 if e else 1.0, 3.0]
+        assert c.tolist() == want + [sum(want)], f"frame {i}: skip {e}, device weights {c.tolist()}"
+    assert int(state[:1].view(torch.int32)) == len(cache)
+
+
+def test_adaptation_drops_the_target_losses_when_the_car_stands():
+    """DepthAlgo.adaptation with the device rule == the host rule (check_car_moving=True) == the reference's re-weighted means."""
+    from codeps_amd import functional as F
+    from codeps_amd.step import StepRunner
+    net, cfg, data = _setup()
+    r = StepRunner(net, cfg, "adapt", 1)
+    algo = net.depth_algo
+    algo.skip_rule_length = 4
+    net.check_car_moving = "device"
+    # fill the window with large distances by hand: the next frame (tiny network pose, |t| ~ 1e-3) must be skipped
+    algo._rule_state = F.depth_rule_state(torch.device(DEV), 4)
+    st = algo._rule_state
+    st[4:8] = 5.0
+    st[:1].view(torch.int32).fill_(4)
+    grads = lambda: [g.grad.clone() for g in r.groups]          # noqa: E731
+    r.noise_counter.zero_()                              # same tie-break noise in all three passes
+    _, losses_dev, _ = r.forward_backward(data)
+    assert int(algo.adaptation_cache["is_car_moving"]) == 1
+    g_dev = grads()
+    # host form of the rule on the same weights
+    net.check_car_moving = True
+    algo.adaptation_cache["target_dist"] = [torch.tensor(5.0)] * 4
+    r.noise_counter.zero_()
+    _, losses_host, _ = r.forward_backward(data)
+    assert bool(algo.adaptation_cache["is_car_moving"]) is True
+    g_host = grads()
+    # rule off: the target key counts
+    net.check_car_moving = False
+    r.noise_counter.zero_()
+    _, losses_off, _ = r.forward_backward(data)
+    torch.cuda.synchronize()
+    for k in ("depth_recon", "depth_smth"):
+        assert torch.allclose(losses_dev[k], losses_host[k], rtol=1e-6, atol=0), k
+        assert not torch.allclose(losses_dev[k], losses_off[k], rtol=1e-4, atol=0), f"{k}: the skipped key still counts"
+    for a, b in zip(g_dev, g_host):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-9 + 1e-6 * float(b.abs().max()))
