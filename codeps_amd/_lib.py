@@ -98,8 +98,8 @@ SIGNATURES = {
     "codeps_loss_workspace_bytes": (c_size_t, [LL]),
     "codeps_smoothness_fwd": (c_int, [P, P, I, I, I, P, P, P, c_size_t, P]),
     "codeps_smoothness_bwd": (c_int, [P, P, P, P, I, I, I, P, P, c_size_t, P]),
-    "codeps_semantic_loss_fwd": (c_int, [P, I, I, P, P, P, I, LL, c_double, P, P, c_size_t, P]),
-    "codeps_semantic_loss_bwd": (c_int, [P, I, I, P, P, P, I, LL, c_double, P, P, P, c_size_t, P]),
+    "codeps_semantic_loss_fwd": (c_int, [P, I, I, P, P, P, I, ctypes.c_ulonglong, LL, c_double, P, P, c_size_t, P]),
+    "codeps_semantic_loss_bwd": (c_int, [P, I, I, P, P, P, I, ctypes.c_ulonglong, LL, c_double, P, P, P, c_size_t, P]),
     "codeps_instance_loss_fwd": (c_int, [I, P, I, I, P, P, I, I, I, P, P, c_size_t, P]),
     "codeps_instance_loss_bwd": (c_int, [I, P, I, I, P, P, I, I, I, P, P, P]),
     "codeps_pose_fwd": (c_int, [P, I, I, I, I, P, P, P]),
@@ -107,7 +107,9 @@ SIGNATURES = {
     "codeps_reflect_pad_fold": (c_int, [P, I, I, I, I, I, P, P]),
     "codeps_panoptic_workspace_bytes": (c_size_t, [I, I, I]),
     "codeps_panoptic_fusion": (c_int, [P, P, P, I, I, I, ctypes.c_ulonglong, I, I, c_float, I, I, P, P, P, P, P, c_size_t, P]),
-    "codeps_image_warp": (c_int, [P, P, P, P, I, I, I, I, I, P, P, P]),
+    "codeps_image_warp": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P, P]),
+    "codeps_image_warp_bwd_workspace_bytes": (c_size_t, [I]),
+    "codeps_image_warp_bwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, c_size_t, P]),
     "codeps_warp_c2c": (c_int, [P, I, P, P, I, I, I, I, I, I, I, I, ctypes.c_double, P, P]),
     "codeps_cut_mixup": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, ctypes.c_double, P, P, P, P]),
     "codeps_offset_center_workspace_bytes": (c_size_t, [I]),
@@ -122,6 +124,9 @@ SIGNATURES = {
     "codeps_panoptic_stats_workspace_bytes": (c_size_t, [I]),
     "codeps_panoptic_stats": (c_int, [P, P, I, I, I, I, I, I, P, P, P, P, c_size_t, P]),
     "codeps_adam_ema_step": (c_int, [P, P, P, P, P, LL, I, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "codeps_ssim_fwd": (c_int, [P, P, I, I, I, c_float, c_float, P, P]),
+    "codeps_ssim_bwd_workspace_bytes": (c_size_t, [I, I, I]),
+    "codeps_ssim_bwd": (c_int, [P, P, P, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),
     "codeps_step_counter_add": (c_int, [P, c_uint64, P]),
     "codeps_depth_rule_state_floats": (c_size_t, [I]),
     "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, P, P]),

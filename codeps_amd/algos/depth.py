@@ -18,14 +18,17 @@ class EdgeAwareSmoothnessLoss:
 
 
 class SSIMLoss:
-    """Constructor-compatible stand-in for algos/depth.py:110-155.  The 3x3 reflect-padded SSIM itself is
-    computed inside the fused photometric kernel; only window_size=3 is coherent in the reference
-     and only that is supported."""
+    """algos/depth.py:110-155.  Callable and differentiable like the reference's (csrc/ssim.hip); inside ReconstructionLoss the
+    same 3x3 reflect-padded SSIM is evaluated by the fused photometric kernel.  Only window_size = 3 is coherent in the
+    reference (its second AvgPool2d argument is the STRIDE) and only that is supported."""
 
     def __init__(self, window_size: int = 3):
         if window_size != 3:
-            raise ValueError("SSIMLoss: the fused photometric kernel implements the 3x3 window only")
+            raise ValueError("SSIMLoss: only the 3x3 window is coherent in the reference and implemented here")
         self.c1, self.c2 = .01 ** 2, .03 ** 2
+
+    def __call__(self, src_img: Tensor, target_img: Tensor) -> Tensor:
+        return F.ssim_loss_map(src_img, target_img, self.c1, self.c2)
 
 
 def _intrinsics(camera_models, device) -> Tensor:

@@ -27,9 +27,10 @@ class SemanticLoss:
         if return_per_pixel:
             raise NotImplementedError("return_per_pixel is only used by the reference's dead SemanticConsistencyLoss")
         if self.ignore_labels:
-            # the reference remaps ignore_labels to 255 IN PLACE on the caller's target and drops those channels
-            # (algos/semantic_seg.py:50-55); no shipped config sets ignore labels (datasets/dataset.py:236-238)
-            raise NotImplementedError("ignore_labels != [] is not supported by the HIP path")
+            # the reference remaps ignore_labels to 255 IN PLACE on the caller's target and slices those channels away
+            # (algos/semantic_seg.py:50-55); the kernel does the slicing through a channel mask
+            for ignore_label in self.ignore_labels:
+                target.masked_fill_(target == ignore_label, self.ignore_index)
         probs = F.from_nchw(prediction_softmax)
         c = prediction_softmax.shape[1]
         cw = None
@@ -37,7 +38,8 @@ class SemanticLoss:
             if self._cw_dev is None or self._cw_dev.device != probs.device:
                 self._cw_dev = self.class_weights.to(probs.device)
             cw = self._cw_dev
-        return F.semantic_loss(probs, c, target, pixel_weights, cw, self.top_k_percent_pixels, self.ignore_index)
+        return F.semantic_loss(probs, c, target, pixel_weights, cw, self.top_k_percent_pixels, self.ignore_index,
+                               self.ignore_labels or None)
 
 
 class SemanticSegAlgo:

@@ -117,16 +117,35 @@ __device__ __forceinline__ float ce_of_probs(const float* __restrict__ p, int C,
     lse = mx + logf(s);
     return lse - p[t];
 }
+// The same over the channels NOT in `drop` (SemanticLoss with ignore_labels, algos/semantic_seg.py:50-55: the reference slices
+// the preserved channels out of the probabilities and keeps indexing them with the ORIGINAL label values, so label t selects
+// the t-th preserved channel).  ct <- that channel, or -1 when t is past the preserved set (the reference raises there).
+__device__ __forceinline__ float ce_of_probs_kept(const float* __restrict__ p, int C, unsigned long long drop, int t, float& lse, int& ct) {
+    float mx = -INFINITY;
+    int r = 0;
+    ct = -1;
+    for (int c = 0; c < C; ++c) {
+        if ((drop >> c) & 1ull) continue;
+        mx = fmaxf(mx, p[c]);
+        if (r == t) ct = c;
+        ++r;
+    }
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) if (!((drop >> c) & 1ull)) s += expf(p[c] - mx);
+    lse = mx + logf(s);
+    return ct >= 0 ? lse - p[ct] : 0.f;
+}
 
 __global__ __launch_bounds__(256) void sem_px_kernel(const float* __restrict__ probs, int C, int Cp, const uint8_t* __restrict__ target,
                                                      const uint8_t* __restrict__ pw, const float* __restrict__ cw, int ignore,
-                                                     long long N, float* __restrict__ loss_px) {
+                                                     unsigned long long drop, long long N, float* __restrict__ loss_px) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const int t = target[i];
         float l = 0.f;
-        if (t != ignore && t < C) {
+        if (t != ignore && t < C && !(drop && ((drop >> t) & 1ull))) {
             float lse;
-            l = ce_of_probs(probs + (size_t)i * Cp, C, t, lse);
+            if (drop) { int ct; l = ce_of_probs_kept(probs + (size_t)i * Cp, C, drop, t, lse, ct); }
+            else l = ce_of_probs(probs + (size_t)i * Cp, C, t, lse);
             if (cw) l *= cw[t];
             if (pw) l *= (float)pw[i];
         }
@@ -200,7 +219,8 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const float* __restric
 
 // d probs: selected pixels get gout/k * w_t * pw * (softmax(p) - onehot); ties at tau share (k-n_gt)/n_eq
 __global__ __launch_bounds__(256) void sem_bwd_kernel(const float* __restrict__ probs, int C, int Cp, const uint8_t* __restrict__ target,
-                                                      const uint8_t* __restrict__ pw, const float* __restrict__ cw, int ignore, long long N,
+                                                      const uint8_t* __restrict__ pw, const float* __restrict__ cw, int ignore,
+                                                      unsigned long long drop, long long N,
                                                       const float* __restrict__ loss_px, const uint32_t* __restrict__ state, uint32_t k,
                                                       const float* __restrict__ gout, float* __restrict__ dprobs) {
     const float tau = state ? __uint_as_float(state[0]) : -1.f;
@@ -211,18 +231,22 @@ __global__ __launch_bounds__(256) void sem_bwd_kernel(const float* __restrict__ 
         const int t = target[i];
         const float l = fmaxf(loss_px[i], 0.f);
         float sel = l > tau ? 1.f : (l == tau ? frac : 0.f);
-        if (t == ignore || t >= C) sel = 0.f;
+        if (t == ignore || t >= C || (drop && ((drop >> t) & 1ull))) sel = 0.f;
+        const float* p = probs + (size_t)i * Cp;
+        float lse;
+        int ct = t;
+        if (sel != 0.f) {
+            if (drop) ce_of_probs_kept(p, C, drop, t, lse, ct); else ce_of_probs(p, C, t, lse);
+            if (ct < 0) sel = 0.f;
+        }
         if (sel == 0.f) {
             for (int c = 0; c < Cp; ++c) d[c] = 0.f;
             continue;
         }
-        const float* p = probs + (size_t)i * Cp;
-        float lse;
-        ce_of_probs(p, C, t, lse);
         float coef = go * sel;
         if (cw) coef *= cw[t];
         if (pw) coef *= (float)pw[i];
-        for (int c = 0; c < C; ++c) d[c] = coef * (expf(p[c] - lse) - (c == t ? 1.f : 0.f));
+        for (int c = 0; c < C; ++c) d[c] = ((drop >> c) & 1ull) ? 0.f : coef * (expf(p[c] - lse) - (c == ct ? 1.f : 0.f));
         for (int c = C; c < Cp; ++c) d[c] = 0.f;
     }
 }
@@ -465,10 +489,12 @@ __global__ void radix_init_kernel(uint32_t* state, uint32_t* hist, uint32_t k) {
 }
 
 extern "C" int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, const uint8_t* target, const uint8_t* pixel_weights,
-                                        const float* class_weights, int ignore_index, long long pixels, double top_k, float* loss,
-                                        void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+                                        const float* class_weights, int ignore_index, unsigned long long dropped_channels, long long pixels,
+                                        double top_k, float* loss, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     CODEPS_REQUIRE(probs && target && loss && workspace && pixels > 0 && c > 0 && c <= c_pad && c <= 255 && top_k > 0.0 && top_k <= 1.0,
                    CODEPS_ERR_ARG, "semantic_loss_fwd: bad arguments");
+    CODEPS_REQUIRE(dropped_channels == 0 || c <= 64, CODEPS_ERR_ARG, "semantic_loss_fwd: ignore labels need <= 64 classes");
+    const unsigned long long drop = dropped_channels;
     CODEPS_REQUIRE(workspace_bytes >= codeps_loss_workspace_bytes(pixels), CODEPS_ERR_WORKSPACE, "semantic_loss_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* lpx = (float*)workspace;
@@ -476,7 +502,7 @@ extern "C" int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, co
     uint32_t* state = (uint32_t*)(part + (size_t)RB * 32);
     uint32_t* hist = state + 16;
     hipLaunchKernelGGL(sem_px_kernel, dim3(blocks_for(pixels)), dim3(256), 0, st, probs, c, c_pad, target, pixel_weights, class_weights, ignore_index,
-                       pixels, lpx);
+                       drop, pixels, lpx);
     CODEPS_CHECK_LAUNCH("sem_px_kernel");
     const int nblk = blocks_for(pixels);
     if (top_k < 1.0) {
@@ -497,8 +523,9 @@ extern "C" int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, co
 }
 
 extern "C" int codeps_semantic_loss_bwd(const float* probs, int c, int c_pad, const uint8_t* target, const uint8_t* pixel_weights,
-                                        const float* class_weights, int ignore_index, long long pixels, double top_k, const float* grad_loss,
-                                        float* grad_probs, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+                                        const float* class_weights, int ignore_index, unsigned long long dropped_channels, long long pixels,
+                                        double top_k, const float* grad_loss, float* grad_probs, void* workspace, size_t workspace_bytes,
+                                        codeps_stream_t stream) {
     CODEPS_REQUIRE(probs && target && grad_loss && grad_probs && workspace && pixels > 0 && c > 0 && c <= c_pad, CODEPS_ERR_ARG,
                    "semantic_loss_bwd: bad arguments");
     CODEPS_REQUIRE(workspace_bytes >= codeps_loss_workspace_bytes(pixels), CODEPS_ERR_WORKSPACE, "semantic_loss_bwd: workspace too small");
@@ -508,7 +535,7 @@ extern "C" int codeps_semantic_loss_bwd(const float* probs, int c, int c_pad, co
     const bool topk = top_k < 1.0;
     const uint32_t k = topk ? (uint32_t)((double)top_k * (double)pixels) : (uint32_t)pixels;
     hipLaunchKernelGGL(sem_bwd_kernel, dim3(blocks_for(pixels)), dim3(256), 0, (hipStream_t)stream, probs, c, c_pad, target, pixel_weights,
-                       class_weights, ignore_index, pixels, lpx, topk ? state : (const uint32_t*)nullptr, k, grad_loss, grad_probs);
+                       class_weights, ignore_index, dropped_channels, pixels, lpx, topk ? state : (const uint32_t*)nullptr, k, grad_loss, grad_probs);
     CODEPS_CHECK_LAUNCH("sem_bwd_kernel");
     return CODEPS_OK;
 }

@@ -994,7 +994,7 @@ def smoothness_loss(img, disp):
 
 class _SemanticLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, probs, c, target, pixel_weights, class_weights, top_k, ignore_index):
+    def forward(ctx, probs, c, target, pixel_weights, class_weights, top_k, ignore_index, drop=0):
         require_cuda(probs, target, pixel_weights, class_weights)
         probs = probs.contiguous()
         cp = probs.shape[-1]
@@ -1007,26 +1007,36 @@ class _SemanticLoss(torch.autograd.Function):
         cw = None if class_weights is None else _f32c(class_weights)
         ws = _loss_ws(n, probs.device)
         loss = torch.empty(1, dtype=torch.float32, device=probs.device)
-        check(lib().codeps_semantic_loss_fwd(ptr(probs), c, cp, ptr(target), ptr(pixel_weights), ptr(cw), ignore_index, n, top_k,
+        check(lib().codeps_semantic_loss_fwd(ptr(probs), c, cp, ptr(target), ptr(pixel_weights), ptr(cw), ignore_index, drop, n, top_k,
                                              ptr(loss), ptr(ws), ws.numel(), stream_ptr()), "codeps_semantic_loss_fwd")
         ctx.save_for_backward(probs, target, pixel_weights, cw, ws)
-        ctx.meta = (c, cp, n, top_k, ignore_index)
+        ctx.meta = (c, cp, n, top_k, ignore_index, drop)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         probs, target, pw, cw, ws = ctx.saved_tensors
-        c, cp, n, top_k, ign = ctx.meta
+        c, cp, n, top_k, ign, drop = ctx.meta
         dp = torch.empty_like(probs)
-        check(lib().codeps_semantic_loss_bwd(ptr(probs), c, cp, ptr(target), ptr(pw), ptr(cw), ign, n, top_k,
+        check(lib().codeps_semantic_loss_bwd(ptr(probs), c, cp, ptr(target), ptr(pw), ptr(cw), ign, drop, n, top_k,
                                              ptr(_f32c(g).reshape(1)), ptr(dp), ptr(ws), ws.numel(), stream_ptr()),
               "codeps_semantic_loss_bwd")
-        return dp, None, None, None, None, None, None
+        return dp, None, None, None, None, None, None, None
 
 
-def semantic_loss(probs_nhwc, num_classes, target, pixel_weights=None, class_weights=None, top_k=0.2, ignore_index=255):
-    """Hard-pixel-mined CE on softmax probabilities (algos/semantic_seg.py:45-67); probs NHWC [B,H,W,Cp]."""
-    return _SemanticLoss.apply(probs_nhwc, int(num_classes), target, pixel_weights, class_weights, float(top_k), int(ignore_index))
+def semantic_loss(probs_nhwc, num_classes, target, pixel_weights=None, class_weights=None, top_k=0.2, ignore_index=255,
+                  ignore_labels=None):
+    """Hard-pixel-mined CE on softmax probabilities (algos/semantic_seg.py:45-67); probs NHWC [B,H,W,Cp].
+    ignore_labels: labels whose pixels are ignored and whose channels leave the CE (semantic_seg.py:50-55; the preserved
+    channels are indexed with the original label values like the reference does; class_weights: one per preserved channel)."""
+    drop = 0
+    for label in (ignore_labels or ()):
+        if not 0 <= int(label) < 64:
+            raise CodepsHipError(f"semantic_loss: ignore label {label} outside [0, 64)")
+        drop |= 1 << int(label)
+    if class_weights is not None and class_weights.numel() != int(num_classes) - bin(drop & ((1 << int(num_classes)) - 1)).count("1"):
+        raise CodepsHipError("semantic_loss: weight tensor should be defined either for all preserved classes or no classes")
+    return _SemanticLoss.apply(probs_nhwc, int(num_classes), target, pixel_weights, class_weights, float(top_k), int(ignore_index), drop)
 
 
 class _InstanceLoss(torch.autograd.Function):
@@ -1070,6 +1080,38 @@ def offset_loss(pred_nhwc, target):
 def binary_mask_loss(probs_nhwc, target, ignore_index=255):
     """mean CE on thing probabilities (algos/instance_seg.py:44-51); target u8 [B,H,W]."""
     return _InstanceLoss.apply(probs_nhwc, 2, target, 2, int(ignore_index))
+
+
+class _Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, c1, c2):
+        require_cuda(x, y)
+        x, y = _f32c(x), _f32c(y)
+        if x.shape != y.shape or x.dim() != 4:
+            raise CodepsHipError(f"ssim: expects two [B,C,H,W] tensors of one shape, got {tuple(x.shape)} and {tuple(y.shape)}")
+        b, c, h, w = x.shape
+        out = torch.empty_like(x)
+        check(lib().codeps_ssim_fwd(ptr(x), ptr(y), b * c, h, w, c1, c2, ptr(out), stream_ptr()), "codeps_ssim_fwd")
+        ctx.save_for_backward(x, y)
+        ctx.c = (c1, c2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        b, c, h, w = x.shape
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        nbytes = lib().codeps_ssim_bwd_workspace_bytes(b * c, h, w)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(lib().codeps_ssim_bwd(ptr(x), ptr(y), ptr(_f32c(g)), b * c, h, w, ctx.c[0], ctx.c[1], ptr(gx), ptr(gy), ptr(ws), nbytes,
+                                    stream_ptr()), "codeps_ssim_bwd")
+        return gx, gy, None, None
+
+
+def ssim_loss_map(x, y, c1=1e-4, c2=9e-4):
+    """SSIMLoss.__call__ (algos/depth.py:128-155): per-pixel, per-channel clamp((1 - SSIM) / 2, 0, 1) of two [B,C,H,W] images."""
+    return _Ssim.apply(x, y, float(c1), float(c2))
 
 
 # ---------------------------------------------------------------------------------------- step control

@@ -242,15 +242,20 @@ int codeps_smoothness_bwd(const float* img, const float* disp, const float* mean
 /* SemanticLoss.__call__ (algos/semantic_seg.py:45-67): CE applied to softmax PROBABILITIES
  * (probs NHWC [pixels][c_pad], first c real), target / pixel_weights u8 [pixels] (pixel_weights and
  * class_weights nullable), ignore_index 255, hard-pixel mining over the whole flattened batch with
- * k = int(top_k * pixels) via an integer radix select (top_k = 1.0: plain mean). */
+ * k = int(top_k * pixels) via an integer radix select (top_k = 1.0: plain mean).
+ * dropped_channels: bit c set = label c is in SemanticLoss.ignore_labels (semantic_seg.py:50-55): such
+ * targets are ignored and the CE runs over the preserved channels only, which the reference keeps
+ * indexing with the ORIGINAL label values (label t -> t-th preserved channel; class_weights hold one
+ * entry per preserved channel).  0 = no ignore labels. */
 int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, const uint8_t* target,
                              const uint8_t* pixel_weights, const float* class_weights, int ignore_index,
-                             long long pixels, double top_k, float* loss, void* workspace,
-                             size_t workspace_bytes, codeps_stream_t stream);
+                             unsigned long long dropped_channels, long long pixels, double top_k, float* loss,
+                             void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 int codeps_semantic_loss_bwd(const float* probs, int c, int c_pad, const uint8_t* target,
                              const uint8_t* pixel_weights, const float* class_weights, int ignore_index,
-                             long long pixels, double top_k, const float* grad_loss, float* grad_probs,
-                             void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+                             unsigned long long dropped_channels, long long pixels, double top_k,
+                             const float* grad_loss, float* grad_probs, void* workspace, size_t workspace_bytes,
+                             codeps_stream_t stream);
 /* CenterLoss (kind 0, MSE), OffsetLoss (kind 1, L1), BinaryMaskLoss (kind 2, CE on probabilities,
  * ignore 255) -- algos/instance_seg.py:12-51.  pred NHWC [batch*hw][c_pad]; target planar NCHW fp32
  * [batch][c][hw] (kinds 0/1) or u8 [batch*hw] (kind 2).  Plain mean; pixel weights are ignored like
@@ -277,6 +282,17 @@ int codeps_reflect_pad_fold(const float* grad_padded, int batch, int h, int w, i
 int codeps_adam_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                          float* ema_params, long long n, int step, float lr, float beta1, float beta2,
                          float eps, float grad_scale, float ema_alpha, codeps_stream_t stream);
+
+/* SSIMLoss.__call__ (algos/depth.py:128-155) on its own (the training path evaluates it inside
+ * codeps_photometric_*): x, y, out [planes][h][w] (planes = B * C of NCHW tensors); ReflectionPad2d(1),
+ * 3x3 mean pooling, out = clamp((1 - n / d) / 2, 0, 1).  _bwd: grad_out [planes][h][w] -> grad_x,
+ * grad_y (either nullable); workspace = codeps_ssim_bwd_workspace_bytes. */
+int codeps_ssim_fwd(const float* x, const float* y, int planes, int h, int w, float c1, float c2, float* out,
+                    codeps_stream_t stream);
+size_t codeps_ssim_bwd_workspace_bytes(int planes, int h, int w);
+int codeps_ssim_bwd(const float* x, const float* y, const float* grad_out, int planes, int h, int w, float c1,
+                    float c2, float* grad_x, float* grad_y, void* workspace, size_t workspace_bytes,
+                    codeps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Step control on the stream (csrc/step_ctl.hip): the per-frame decisions the reference takes on the
@@ -320,12 +336,23 @@ int codeps_panoptic_fusion(const uint8_t* semantic, const float* center, const f
                            int* centers, int* state, void* workspace, size_t workspace_bytes,
                            codeps_stream_t stream);
 
-/* ImageWarper / CoordinateWarper forward (misc/image_warper.py:100-184) for the reference's public
- * (non-training) API: src [B,c,H,W] NCHW, depth [B,1,H,W], pose [B,16], intr [B,4];
+/* ImageWarper / CoordinateWarper (misc/image_warper.py:92-184), the reference's public warping API
+ * (the training path's warp is fused into codeps_photometric_*): src [B,c,H,W] NCHW, depth [B,1,H,W],
+ * pose [B,16], intr [B,4], motion = optional object_motion_map [B,3,H,W] added to the transformed
+ * points (image_warper.py:133-134);
  * out [B,c,H,W] (nullable) = grid_sample(border, align_corners=True; nearest=1 for interp_mode
- * "nearest"); grid [B,H,W,2] (nullable) = normalised sampling coordinates. */
-int codeps_image_warp(const float* src, const float* depth, const float* pose, const float* intr, int batch,
-                      int c, int h, int w, int nearest, float* out, float* grid, codeps_stream_t stream);
+ * "nearest"); grid [B,H,W,2] (nullable) = normalised sampling coordinates.
+ * _bwd: transpose of both outputs.  grad_out [B,c,H,W] and / or grad_grid [B,H,W,2] ->
+ * grad_src [B,c,H,W] (ZERO-INITIALISED by the caller; accumulated with float atomics, the only ones in
+ * this library), grad_depth [B,1,H,W], grad_pose [B,16], grad_motion [B,3,H,W] -- all nullable. */
+int codeps_image_warp(const float* src, const float* depth, const float* pose, const float* intr,
+                      const float* motion, int batch, int c, int h, int w, int nearest, float* out,
+                      float* grid, codeps_stream_t stream);
+size_t codeps_image_warp_bwd_workspace_bytes(int batch);
+int codeps_image_warp_bwd(const float* src, const float* depth, const float* pose, const float* intr,
+                          const float* motion, const float* grad_out, const float* grad_grid, int batch, int c,
+                          int h, int w, int nearest, float* grad_src, float* grad_depth, float* grad_pose,
+                          float* grad_motion, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pseudo-label mix-up on the device (Mixup.do_mixup, datasets/mixup.py:406-489, called from

@@ -117,10 +117,20 @@ def smoothness_loss(img, disp):
 
 
 # ----------------------------------------------------------------------------- semantic / instance
-def semantic_loss(probs, target, pixel_weights, class_weights=None, top_k=0.2, ignore_index=255):
+def semantic_loss(probs, target, pixel_weights, class_weights=None, top_k=0.2, ignore_index=255, ignore_labels=None):
     """Hard-pixel-mined CE applied to *softmax probabilities* (algos/semantic_seg.py:45-67):
     CE(=log_softmax again + weighted NLL, ignore 255, reduction none) * pixel_weights; flatten the
-    whole batch; top-k (k=int(top_k*numel)); mean."""
+    whole batch; top-k (k=int(top_k*numel)); mean.  ignore_labels (semantic_seg.py:50-55, with the weight filter of
+    :34-40): targets with those labels become ignore_index IN PLACE, their channels are sliced out of the probabilities
+    (the remaining targets keep indexing the sliced tensor with their original values) and class_weights (one per original
+    class) is filtered the same way."""
+    if ignore_labels:
+        for label in ignore_labels:
+            target[target == label] = ignore_index
+        keep = [c for c in range(probs.shape[1]) if c not in ignore_labels]
+        probs = probs[:, keep]
+        if class_weights is not None:
+            class_weights = [w_ for c, w_ in enumerate(class_weights) if c not in ignore_labels]
     w = None if class_weights is None else torch.as_tensor(class_weights, dtype=probs.dtype)
     per_px = F.cross_entropy(probs, target.long(), w, ignore_index=ignore_index, reduction="none")
     per_px = per_px * pixel_weights

@@ -64,13 +64,23 @@ def train_forward(sds, cfg, sample, noise=None, do_panoptic=True):
     return out, res
 
 
-def adapt_forward(sds, cfg, data, noise=None):
+def adapt_forward(sds, cfg, data, noise=None, mixup_cells=None):
     """Adaptation-step losses (codeps/online_adap.py:291-436 with algos/depth.py:507-577,
-    algos/semantic_seg.py:200-249).  data: {"target","target_replay","source": sample dicts,
-    "<x>mixup": pre-mixed sample dicts}.  Depth losses are the image-count weighted mean over
-    source/target/target_replay; the rolling "car not moving" rule (depth.py:537-558) is host state
-    and not part of this function.  ``noise``: {key: [per-scale tensors]} or None."""
+    algos/semantic_seg.py:200-249, algos/instance_seg.py:141-206).  data: {"target","target_replay","source": sample dicts,
+    "<x>mixup": pre-mixed sample dicts, or RAW mixup items (keys rgb_src / rgb_tgt / ..., online_adap.py:331-335) that are
+    mixed here by oracle.mixup.do_cut_mixup with the cells `mixup_cells[key]` np.random.choice drew}.  Depth losses are the
+    image-count weighted mean over source/target/target_replay; the rolling "car not moving" rule (depth.py:537-558) is host
+    state and not part of this function.  ``noise``: {key: [per-scale tensors]} or None."""
+    from . import mixup as omix
     out, res = OrderedDict(), OrderedDict()
+    data = dict(data)
+    for key, item in list(data.items()):
+        if key.endswith("mixup") and "rgb_src" in item:
+            raw = {k: (v[0].numpy() if isinstance(v, dict) else v.numpy()) for k, v in item.items()}
+            m = omix.do_cut_mixup(raw, THINGS, mixup_cells[key], cfg.get("geom_augment", True), cfg.get("nof_vert_splits", 2),
+                                  cfg.get("nof_hor_splits", 4))
+            data[key] = {"rgb": {0: torch.from_numpy(m["rgb"])}, "semantic": torch.from_numpy(m["semantic"])}
+            res["mix_" + key] = data[key]
     recon, smth, n = {}, {}, {}
     feats = {}
     for key in ("source", "target", "target_replay"):
@@ -100,6 +110,17 @@ def adapt_forward(sds, cfg, data, noise=None):
         out["semantic_source"] = losses.semantic_loss(sem(feats["source"]), data["source"]["semantic"],
                                                       data["source"]["semantic_weights"],
                                                       cfg.get("class_weights"), cfg.get("top_k", 0.2))
+    if "instance_head" in sds and cfg.get("instance", True):
+        inst = lambda f: heads.instance_head(sds["instance_head"], f, cfg.get("use_thing_mask", False))[:2]  # noqa: E731
+        res["center"], res["offset"] = inst(feats["target"])               # instance_seg.py:155-157 (target inference)
+        if "source" in data and "center" in data["source"]:                 # instance_seg.py:176-183
+            c_src, o_src = inst(feats["source"])
+            out["center_source"] = losses.center_loss(c_src, data["source"]["center"])
+            out["offset_source"] = losses.offset_loss(o_src, data["source"]["offset"])
+        pan, ins, _ = panoptic.panoptic_fusion(res["semantic"].to(torch.uint8).numpy(), res["center"].detach().numpy(),
+                                               res["offset"].detach().numpy(), THINGS)
+        res["panoptic"], res["instance"] = torch.from_numpy(pan), torch.from_numpy(ins)
+    res["image_features"] = feats["target"][-1].detach()
     return out, res
 
 

@@ -144,6 +144,43 @@ def golden_geometry(seed=11):
     save("geometry", **res)
 
 
+def golden_geometry_grad(seed=12):
+    """Gradients of the reference's public ImageWarper / CoordinateWarper / SSIMLoss (misc/image_warper.py:92-184,
+    algos/depth.py:128-155) under fixed upstream gradients, incl. nearest mode and an object-motion map."""
+    b, h, w = 2, 24, 40
+    intr = gi.intrinsics(b, h, w, seed)
+    cm = cams(intr, w, h)
+    res = {"meta": json.dumps({"b": b, "h": h, "w": w, "seed": seed})}
+
+    def leaves():
+        return (gi.smooth_image(b, h, w, seed + 1).requires_grad_(True), gi.depth_map(b, h, w, seed).requires_grad_(True),
+                gi.pose(b, seed, rot=0.05, trans=0.6).requires_grad_(True))
+
+    src, depth, T = leaves()
+    out = ImageWarper(w, h, CPU)(cm, src, depth, T)
+    (out * gi.normal(tuple(out.shape), seed + 5)).sum().backward()
+    res.update(warped=out, warped_dsrc=src.grad, warped_ddepth=depth.grad, warped_dT=T.grad)
+    src, depth, T = leaves()
+    grid = CoordinateWarper(w, h, CPU)(cm, depth, T)
+    (grid * gi.normal(tuple(grid.shape), seed + 6)).sum().backward()
+    res.update(grid=grid, grid_ddepth=depth.grad, grid_dT=T.grad)
+    src, depth, T = leaves()
+    out = ImageWarper(w, h, CPU)(cm, src, depth, T, interp_mode="nearest")
+    (out * gi.normal(tuple(out.shape), seed + 5)).sum().backward()
+    res.update(nearest=out, nearest_dsrc=src.grad)
+    src, depth, T = leaves()
+    motion = gi.normal((b, 3, h, w), seed + 7, 0.05).requires_grad_(True)
+    out = ImageWarper(w, h, CPU)(cm, src, depth, T, object_motion_map=motion)
+    (out * gi.normal(tuple(out.shape), seed + 5)).sum().backward()
+    res.update(motion_warped=out, motion_dmotion=motion.grad, motion_ddepth=depth.grad, motion_dT=T.grad)
+    a = gi.smooth_image(b, h, w, seed + 2).requires_grad_(True)
+    c = gi.smooth_image(b, h, w, seed + 3).requires_grad_(True)
+    sm = SSIMLoss()(a, c)
+    (sm * gi.normal(tuple(sm.shape), seed + 8)).sum().backward()
+    res.update(ssim=sm, ssim_da=a.grad, ssim_dc=c.grad)
+    save("geometry_grad", **res)
+
+
 # ------------------------------------------------------------------------------------------ losses
 def golden_recon(tag, b, h, w, seed, num_scales=5):
     intr = gi.intrinsics(b, h, w, seed)
@@ -187,6 +224,20 @@ def golden_sem_inst_losses(seed=31):
     res["sem_cw"] = loss
     res["sem_cw_dprobs"] = probs.grad.clone()
     res["class_weights"] = np.array(cw, np.float32)
+    # ignore_labels (algos/semantic_seg.py:50-55): labels remapped to 255 in place, channels sliced away; the targets must
+    # stay below the number of preserved channels or the reference's CrossEntropyLoss raises -> labels drawn from 0..10
+    ign = [3, 7, 12]
+    tgt_small = gi.semantic_labels(b, h, w, seed + 9, 11)
+    for name, topk in (("ign_topk", 0.2), ("ign_full", 1.0)):
+        sl = SemanticLoss(device=CPU, class_weights=cw, top_k_percent_pixels=topk, ignore_labels=ign)
+        probs.grad = None
+        tgt = tgt_small.clone()
+        loss = sl(probs, tgt, pw)
+        loss.backward()
+        res[f"sem_{name}"] = loss
+        res[f"sem_{name}_dprobs"] = probs.grad.clone()
+        res[f"sem_{name}_target_after"] = tgt
+    res["ignore_labels"] = np.array(ign, np.int32)
     # instance losses
     cp = gi.normal((b, 1, h, w), seed + 1).requires_grad_(True)
     ct = gi.center_heatmap(b, h, w, seed)
@@ -365,6 +416,40 @@ def golden_adapt(seed=61):
     save("network_adapt", **res)
 
 
+def golden_adapt_real(seed=63):
+    """The REAL CodepsNet.adapt (codeps/online_adap.py:291-436) on target / target_replay / source items at two resolutions
+    and a RAW cut_mixup item (Mixup.do_mixup runs inside adapt, online_adap.py:331-335), followed by the step's loss
+    weighting and backward (scripts/adapt_codeps.py:266-288)."""
+    ht, wt, hs, ws = 64, 160, 64, 128
+    net = _build_net(seed, False, wt, ht, adaptation=True, src_wh=(ws, hs))
+    net.cfg_mixup = _cfg_mixup(True)
+    data = {"target": _sample(1, ht, wt, seed, labels=False),
+            "target_replay": _sample(2, ht, wt, seed + 1, labels=False),
+            "source": _sample(2, hs, ws, seed + 2),
+            "cut_mixup": gi.mixup_item(2, hs, ws, ht, wt, seed + 3)}
+    torch.manual_seed(3000 + seed)
+    np.random.seed(seed)
+    losses, result, _stats, out_data = net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
+    wts = dict(depth_recon=10.0, depth_smth=0.001, semantic_source=1.0, semantic_cut_mixup=1.0, center_source=20.0, offset_source=0.1)
+    live = OrderedDict((k, v.mean()) for k, v in losses.items() if v is not None and v.requires_grad)
+    total = sum(wts[k] * v for k, v in live.items())
+    total.backward()
+    with torch.no_grad():
+        top2 = net.semantic_head(net.backbone_po_depth(data["target"]["rgb"][0])).topk(2, dim=1).values
+    res = {"meta": json.dumps({"ht": ht, "wt": wt, "hs": hs, "ws": ws, "seed": seed, "weights": wts, "noise_seed": 3000 + seed,
+                               "np_seed": seed, "live": list(live), "loss_keys": [k for k, v in losses.items() if v is not None]}),
+           "total": total, "res_semantic_margin": top2[:, 0] - top2[:, 1]}
+    for k, v in losses.items():
+        if v is not None:
+            res["loss_" + k] = v
+    for k in ("depth", "semantic", "center", "offset", "panoptic", "instance", "image_features"):
+        res["res_" + k] = result[k]
+    res["mix_rgb"], res["mix_semantic"] = out_data["cut_mixup"]["rgb"][0], out_data["cut_mixup"]["semantic"]
+    for name in ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"):
+        res["pgrad_" + name] = grad_stats(getattr(net, name))
+    save("network_adapt_real", **res)
+
+
 # ------------------------------------------------------------------------------------------ mix-up (SURVEY 8f-2)
 def _cfg_mixup(geom):
     from yacs.config import CfgNode as CN
@@ -463,7 +548,7 @@ def golden_metrics():
 
 
 if __name__ == "__main__":
-    jobs = {"geometry": golden_geometry,
+    jobs = {"geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real,
             "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
             "heads_r50": lambda: golden_heads("r50", R50, 1, 32, 64, 5, full=False),
             "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),

@@ -58,6 +58,26 @@ def test_semantic_and_instance_losses_golden():
     close(tp.grad[..., :2].permute(0, 3, 1, 2), z["dmask"], 1e-10, 1e-3)
 
 
+def test_semantic_loss_ignore_labels_golden():
+    """SemanticLoss(ignore_labels=[...]) (algos/semantic_seg.py:34-40,50-55): in-place remap of the targets, CE over the
+    preserved channels indexed with the original label values, filtered class weights."""
+    from codeps_amd.algos import SemanticLoss
+    z, meta = load("sem_inst_losses")
+    b, h, w, c, seed = meta["b"], meta["h"], meta["w"], meta["c"], meta["seed"]
+    ign = z["ignore_labels"].tolist()
+    pw = gi.pixel_weights(b, h, w, seed).to(DEV)
+    for name, topk in (("ign_topk", 0.2), ("ign_full", 1.0)):
+        probs = torch.softmax(gi.normal((b, c, h, w), seed, 2.0), 1).to(DEV).requires_grad_(True)
+        tgt = gi.semantic_labels(b, h, w, seed + 9, 11).to(DEV)
+        sl = SemanticLoss(device=DEV, class_weights=z["class_weights"].tolist(), top_k_percent_pixels=topk, ignore_labels=ign)
+        loss = sl(probs, tgt, pw)
+        loss.backward()
+        close(loss, z["sem_" + name], 1e-6, 2e-5, name)
+        close(probs.grad, z[f"sem_{name}_dprobs"], 1e-9, 1e-3, name + " grad")
+        assert np.array_equal(tgt.cpu().numpy(), z[f"sem_{name}_target_after"]), "targets are remapped in place like the reference"
+        assert float(probs.grad[:, ign].abs().max()) == 0.0, "dropped channels receive no gradient"
+
+
 def test_topk_properties_full_size():
     """512x1024 batch: value equals sort-based top-k mean; heavy ties (80 % zero-loss pixels) handled."""
     from codeps_amd import functional as F

@@ -56,7 +56,8 @@ def test_heads_against_reference_golden(tag):
     _run(z, "poseinv", PoseHead(ch, 1, 2), lambda m_, f: [m_(f, True)], seed + 6, feats, (1e-6, 1e-5))
 
 
-@pytest.mark.parametrize("layers,in_ch,train", [(18, 3, False), (18, 6, True), (50, 3, False), (50, 3, True), (34, 3, False)])
+@pytest.mark.parametrize("layers,in_ch,train", [(18, 3, False), (18, 6, True), (50, 3, False), (50, 3, True), (34, 3, False),
+                                                (101, 3, False)])      # 101 eval = the frozen encoder of the benchmarked adapt step
 def test_encoder_against_oracle(layers, in_ch, train):
     """Trunk vs the oracle's torchvision restatement (fwd, BN running stats, grads)."""
     from codeps_amd.models import ResnetEncoder
@@ -108,3 +109,9 @@ def test_encoder_against_oracle(layers, in_ch, train):
         for k, v in enc.encoder.state_dict().items():
             if "running" in k:
                 close(v, ref_sd[k], 1e-5, 1e-4, k)
+    else:       # the batched form CodepsNet.adapt uses for a frozen encoder (one forward over all keys' centre frames)
+        with torch.no_grad():
+            xb = x.to(DEV)
+            fb = enc.forward_batch([xb[:1], xb[1:]])
+        for i, (a, b) in enumerate(zip(fb, feats)):
+            assert torch.equal(a, b.detach()), f"forward_batch feat{i} differs from the plain forward"

@@ -117,6 +117,46 @@ def test_adaptation_step_against_reference():
     _check_pgrads(net, z, ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"))
 
 
+def test_real_codepsnet_adapt_against_reference():
+    """tests/golden/network_adapt_real.npz is the reference's own CodepsNet.adapt (codeps/online_adap.py:291-436) incl. the
+    Mixup.do_mixup call on a RAW cut_mixup item inside it, then the loss weighting of scripts/adapt_codeps.py:266-288."""
+    z, meta = load("network_adapt_real")
+    ht, wt, hs, ws, seed = meta["ht"], meta["wt"], meta["hs"], meta["ws"], meta["seed"]
+    net = _build(seed, False, wt, ht, adaptation=True, src_hw=(hs, ws))
+    net.cfg_mixup.merge({"general": {"geom_augment": True}, "cut_mix": {"nof_vert_splits": 2, "nof_hor_splits": 4, "nof_segments": 2}})
+    n_src, n_tgt, n_rep = _noise(meta["noise_seed"], [(2, hs, ws), (1, ht, wt), (2, ht, wt)])
+    net.depth_algo.reconstruction_loss_adapt_source.noise = [n_src]
+    net.depth_algo.reconstruction_loss.noise = [n_tgt, n_rep]
+    raw = gi.mixup_item(2, hs, ws, ht, wt, seed + 3)
+    raw = {k: ({o: t_.to(DEV) for o, t_ in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in raw.items()}
+    data = {"target": _sample(1, ht, wt, seed, False), "target_replay": _sample(2, ht, wt, seed + 1, False),
+            "source": _sample(2, hs, ws, seed + 2), "cut_mixup": raw}
+    np.random.seed(meta["np_seed"])
+    losses, result, _, out_data = net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
+    assert [k for k, v in losses.items() if v is not None] == meta["loss_keys"]
+    live = [k for k, v in losses.items() if v is not None and v.requires_grad]
+    assert live == meta["live"]
+    total = sum(meta["weights"][k] * losses[k] for k in live)
+    total.backward()
+    # the mixed item built inside adapt()
+    assert np.array_equal(out_data["cut_mixup"]["semantic"].cpu().numpy(), z["mix_semantic"])
+    close(out_data["cut_mixup"]["rgb"][0], z["mix_rgb"], 2e-5, 0, "mixed image")
+    for k in meta["loss_keys"]:
+        close(losses[k], z["loss_" + k], 1e-6, 5e-5, k)
+    close(total, z["total"], 1e-5, 5e-5)
+    close(result["depth"], z["res_depth"], 1e-3, 1e-4, "depth")
+    for k in ("center", "offset"):
+        close(result[k], z["res_" + k], 2e-5 * float(np.abs(z["res_" + k]).max()), 1e-4, k)
+    close(result["image_features"], z["res_image_features"], 1e-4 * float(np.abs(z["res_image_features"]).max()), 1e-4, "image_features")
+    bad = result["semantic"].cpu().numpy() != z["res_semantic"]
+    assert bad.mean() < 1e-3 and (z["res_semantic_margin"][bad] < 1e-4).all(), (int(bad.sum()), z["res_semantic_margin"][bad])
+    if not bad.any():                                       # panoptic ids are a function of (semantic, centre, offset)
+        for k in ("panoptic", "instance"):
+            same = (result[k].cpu().numpy() == z["res_" + k]).mean()
+            assert same > 0.999, f"{k}: only {same:.6f} of the pixels agree"
+    _check_pgrads(net, z, ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"))
+
+
 def test_pre_step_shares_encoder_features_without_changing_results():
     """the per-frame evaluation passes (scripts/adapt_codeps.py:164-199) with the frozen encoder run once per
     image for teacher and student == the reference's separate calls, bit for bit."""

@@ -115,6 +115,15 @@ def test_semantic_and_instance_losses():
         loss.backward()
         close(loss, z["sem_" + name], 1e-6, 1e-5, name)
         close(probs.grad, z[f"sem_{name}_dprobs"], 1e-8, 1e-4, name + " grad")
+    ign = z["ignore_labels"].tolist()                       # algos/semantic_seg.py:50-55
+    for name, topk in (("ign_topk", 0.2), ("ign_full", 1.0)):
+        probs.grad = None
+        tgt = gi.semantic_labels(b, h, w, seed + 9, 11)
+        loss = losses.semantic_loss(probs, tgt, pw, z["class_weights"].tolist(), topk, ignore_labels=ign)
+        loss.backward()
+        close(loss, z["sem_" + name], 1e-6, 1e-5, name)
+        close(probs.grad, z[f"sem_{name}_dprobs"], 1e-8, 1e-4, name + " grad")
+        assert np.array_equal(tgt.numpy(), z[f"sem_{name}_target_after"]), "targets are remapped in place"
     cp = gi.normal((b, 1, h, w), seed + 1).requires_grad_(True)
     op = gi.normal((b, 2, h, w), seed + 2, 10.0).requires_grad_(True)
     tp = torch.softmax(gi.normal((b, 2, h, w), seed + 3), 1).requires_grad_(True)
@@ -220,6 +229,42 @@ def test_network_adapt_step():
     close(res["depth"], z["res_depth"], 1e-3)
     close(res["T"][0], z["res_T0"], 1e-6, 1e-5)
     assert np.array_equal(res["semantic"].numpy(), z["res_semantic"])
+    for name in ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"):
+        st = grad_stats([sds[name][k].grad for k in groups[name]])
+        ref = z["pgrad_" + name]
+        assert (np.abs(st - ref) / (np.abs(ref[:, 1:2]) + 1e-6)).max() < 5e-3, name
+
+
+def test_network_adapt_real():
+    """The oracle's adaptation step against the reference's own CodepsNet.adapt incl. Mixup.do_mixup on a raw item."""
+    z, meta = load("network_adapt_real")
+    ht, wt, hs, ws, seed = meta["ht"], meta["wt"], meta["hs"], meta["ws"], meta["seed"]
+    sds = _sds(seed, False)
+    groups = _req_grad(sds)
+    for k, v in sds["instance_head"].items():                  # the golden's instance head is trainable
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    data = {"target": _sample(1, ht, wt, seed, False), "target_replay": _sample(2, ht, wt, seed + 1, False),
+            "source": _sample(2, hs, ws, seed + 2), "cut_mixup": gi.mixup_item(2, hs, ws, ht, wt, seed + 3)}
+    torch.manual_seed(meta["noise_seed"])
+    noise = {}
+    for key, (bb, hh, ww) in (("source", (2, hs, ws)), ("target", (1, ht, wt)), ("target_replay", (2, ht, wt))):
+        noise[key] = [torch.randn(bb, 2, hh // 2 ** s, ww // 2 ** s) * .00001 for s in range(5)]
+    np.random.seed(meta["np_seed"])                             # the reference's cell draw, one per batch item (mixup.py:108)
+    cells = [np.random.choice(8, 2, replace=False) for _ in range(2)]
+    out, res = network.adapt_forward(sds, dict(nof_layers=18), data, noise, {"cut_mixup": cells})
+    assert np.array_equal(res["mix_cut_mixup"]["semantic"].numpy(), z["mix_semantic"])
+    close(res["mix_cut_mixup"]["rgb"][0], z["mix_rgb"], 0, 0, "mixed image")
+    total = sum(meta["weights"][k] * out[k] for k in meta["live"])
+    total.backward()
+    for k in meta["loss_keys"]:
+        close(out[k], z["loss_" + k], 1e-6, 2e-5, k)
+    close(total, z["total"], 1e-5, 2e-5)
+    close(res["depth"], z["res_depth"], 1e-3)
+    assert np.array_equal(res["semantic"].numpy(), z["res_semantic"])
+    close(res["center"], z["res_center"], 1e-5 * float(np.abs(z["res_center"]).max()), 1e-5)
+    assert np.array_equal(res["panoptic"].numpy(), z["res_panoptic"]) and np.array_equal(res["instance"].numpy(), z["res_instance"])
+    close(res["image_features"], z["res_image_features"], 1e-5 * float(np.abs(z["res_image_features"]).max()), 1e-5)
     for name in ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"):
         st = grad_stats([sds[name][k].grad for k in groups[name]])
         ref = z["pgrad_" + name]
