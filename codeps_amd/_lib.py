@@ -64,6 +64,7 @@ SIGNATURES = {
     "codeps_conv2d_pack_weights": (c_int, [I, I, I, I, I, I, P, P, P, P]),
     "codeps_conv2d_packed_weight_floats": (c_size_t, [I, I, I, I, I]),
     "codeps_conv2d_arith": (c_int, [POINTER(ConvDesc), I, I]),
+    "codeps_conv2d_last_kernel": (c_char_p, []),
     "codeps_conv2d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_dgrad": (c_int, [POINTER(ConvDesc), I, P, P, P, P]),
@@ -80,7 +81,7 @@ SIGNATURES = {
     "codeps_bn_bwd_apply": (c_int, [P, P, P, P, P, P, P, c_float, I, LL, I, P, P, P]),
     "codeps_bn_mg_workspace_bytes": (c_size_t, [I, I]),
     "codeps_bn_fwd_mg": (c_int, [P, I, P, P, I, I, P, P, P, I, c_float, c_float, P, P, P, P, P, P, I, I, P, c_size_t, P]),
-    "codeps_bn_sync_combine": (c_int, [P, I, I, P, I, I, c_float, c_float, P, P, P, P, P, P]),
+    "codeps_bn_sync_combine": (c_int, [P, I, I, P, P, I, I, c_float, c_float, P, P, P, P, P, P]),
     "codeps_bn_bwd_mg": (c_int, [P, P, P, I, P, P, I, I, P, P, P, P, P, I, P, P, P, I, P, P, I, I, P, c_size_t, P]),
     "codeps_maxpool3x3s2_fwd": (c_int, [P, I, I, I, I, P, P, P]),
     "codeps_maxpool3x3s2_bwd": (c_int, [P, P, I, I, I, I, P, P]),
@@ -129,7 +130,7 @@ SIGNATURES = {
     "codeps_ssim_bwd": (c_int, [P, P, P, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),
     "codeps_step_counter_add": (c_int, [P, c_uint64, P]),
     "codeps_depth_rule_state_floats": (c_size_t, [I]),
-    "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, P, P]),
+    "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, c_float, c_float, I, P, I, P, P]),
     "codeps_weighted_sum_fwd": (c_int, [P, P, P, I, P, P, P]),
     "codeps_weighted_sum_bwd": (c_int, [P, P, P, I, P, P, P]),
 }

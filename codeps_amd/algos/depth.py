@@ -79,6 +79,29 @@ class DepthAlgo:
         self.adaptation_cache = {"target_dist": [], "is_car_moving": False}
         self.skip_rule_length = 300
         self._rule_state = None         # device window of the "car not moving" rule (check_car_moving == "device")
+        # batch-sharded step with UNEQUAL shards (codeps_amd.step.StepRunner.set_key_counts): dict(world, rank, group,
+        # items = {key: [items on rank 0, 1, ...]}, res = {key: (h, w)}); None = single process or equal shards
+        self.shard_layout = None
+        self._plan_cache = {}
+
+    def _group_plan(self, local_keys, device):
+        """SyncBatchNorm statistic groups of one batched pose-encoder forward when ranks hold different item counts: every key of
+        the GLOBAL batch that shares this resolution contributes two groups (prev pair, next pair) in the reference's call
+        order; this rank fills the slots of the keys it holds (functional._BatchNormTrain)."""
+        lay = self.shard_layout
+        if lay is None:
+            return None
+        res = lay["res"]
+        gkeys = [k for k in ("source", "target", "target_replay") if sum(lay["items"].get(k, [])) > 0 and res[k] == res[local_keys[0]]]
+        key = (tuple(gkeys), tuple(local_keys), str(device))
+        plan = self._plan_cache.get(key)
+        if plan is None:
+            l2g = [2 * gkeys.index(k) + j for k in local_keys for j in (0, 1)]
+            items = [[lay["items"][k][r] for k in gkeys for _ in (0, 1)] for r in range(lay["world"])]
+            idx = torch.tensor(l2g, dtype=torch.long, device=device)
+            plan = {"n_global": 2 * len(gkeys), "local_to_global": l2g, "items": items, "index": lambda _dev, t=idx: t}
+            self._plan_cache[key] = plan
+        return plan
 
     @staticmethod
     def _forward(images, depth_feats_window, depth_head, body_pose_sflow, pose_head, flow_head=None):
@@ -166,7 +189,7 @@ class DepthAlgo:
                         pairs.append((a, b))
                         spans.append((k, inv, off, off + a.shape[0]))
                         off += a.shape[0]
-                feats = body_pose_sflow.forward_pair_groups(pairs)
+                feats = body_pose_sflow.forward_pair_groups(pairs, self._group_plan(ks, images[ks[0]][0].device))
                 if hasattr(pose_head, "forward_spans"):
                     mats = pose_head.forward_spans(feats, [(b0, b1, inv) for _k, inv, b0, b1 in spans])
                 else:
@@ -210,15 +233,31 @@ class DepthAlgo:
         # on the device -- with check_car_moving == "device" the rolling rule of depth.py:537-558 is evaluated there as well
         # (no host sync; a skipped target key gets weight 0 instead of leaving the sum)
         dev = recon[live[0]].device
-        on_device = check_car_moving == "device" and "target" in live
-        if on_device:
-            if self._rule_state is None or self._rule_state.device != dev:
-                self._rule_state = F.depth_rule_state(dev, self.skip_rule_length)
-            coef = F.depth_key_weights([num_images[k] for k in live], dev, live.index("target"), transformations["target"],
-                                       self._rule_state, self.skip_rule_length)
+        lay = self.shard_layout
+        on_device = check_car_moving == "device" and ("target" in live if lay is None else sum(lay["items"].get("target", [0])) > 0)
+        if on_device and (self._rule_state is None or self._rule_state.device != dev):
+            self._rule_state = F.depth_rule_state(dev, self.skip_rule_length)
+        counts = [num_images[k] for k in live]
+        if lay is not None:
+            # batch-sharded step: local counts over the global image count / world; the rule is evaluated by the rank that owns the
+            # global batch's first target item and its keep flag is broadcast (codeps_amd.functional.depth_key_weights)
+            if check_car_moving is True:
+                raise NotImplementedError("the host form of the car-not-moving rule is single-process; use 'device' when sharded")
+            owner_rank = next((r for r, n in enumerate(lay["items"].get("target", [])) if n > 0), 0)
+            shard = dict(world=lay["world"], group=lay.get("group"), rule=on_device, owner=lay["rank"] == owner_rank, owner_rank=owner_rank,
+                         global_total=sum(sum(lay["items"].get(k, [])) for k in ("source", "target", "target_replay")),
+                         global_target=sum(lay["items"].get("target", [])))
+            ti = live.index("target") if "target" in live else -1
+            coef = F.depth_key_weights(counts, dev, ti, transformations.get("target") if shard["owner"] else None, self._rule_state,
+                                       self.skip_rule_length, shard)
+            if on_device:
+                self.adaptation_cache["is_car_moving"] = coef._codeps_keep          # device flag: 1 = kept (read lazily)
+        elif on_device:
+            coef = F.depth_key_weights(counts, dev, live.index("target"), transformations["target"], self._rule_state,
+                                       self.skip_rule_length)
             self.adaptation_cache["is_car_moving"] = self._rule_state[2:3].view(torch.int32)     # device flag, read lazily
         else:
-            coef = F.depth_key_weights([num_images[k] for k in live], dev)
+            coef = F.depth_key_weights(counts, dev)
         factors, ones = [coef[i] for i in range(len(live))], [1.0] * len(live)
         depth_recon_loss = F.weighted_sum([recon[k] for k in live], ones, factors, coef[len(live)])
         depth_smth_loss = F.weighted_sum([smth[k] for k in live], ones, factors, coef[len(live)])

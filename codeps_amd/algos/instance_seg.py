@@ -66,7 +66,9 @@ class InstanceSegAlgo:
                    center_ema: Optional[Tensor] = None, offset_ema: Optional[Tensor] = None):
         if center_ema is not None or offset_ema is not None:
             raise NotImplementedError("EMA consistency branch is dormant in the reference (no caller sets *_ema)")
-        center_pred, offset_pred, thing_mask_pred = self.inference(feats["target"][0], instance_head)
+        center_pred = offset_pred = thing_mask_pred = None
+        if "target" in feats:           # (a rank of a batch-sharded step may hold no target item)
+            center_pred, offset_pred, thing_mask_pred = self.inference(feats["target"][0], instance_head)
         sc = so = sm = None
         if "source" in feats:
             sc, so, _, _, sm, _ = self.training(feats["source"][0], center["source"], offset["source"], center_weights["source"],

@@ -80,9 +80,11 @@ class SemanticSegAlgo:
         """algos/semantic_seg.py:200-249.  `batched` (optional, from CodepsNet.adapt): the semantic head has no
         batch-dependent op, so all supervised keys of one resolution (source + *mixup) run through it in ONE call;
         the hard-pixel mining stays per key (separate top-k over each key's pixels, like the reference)."""
-        with torch.no_grad():           # target prediction only feeds argmax / panoptic fusion
-            target_probs = semantic_head(feats['target'][0])
-        semantic_pred = torch.argmax(target_probs, dim=1)
+        semantic_pred = None
+        if 'target' in feats:           # (a rank of a batch-sharded step may hold no target item: nothing to predict there)
+            with torch.no_grad():       # target prediction only feeds argmax / panoptic fusion
+                target_probs = semantic_head(feats['target'][0])
+            semantic_pred = torch.argmax(target_probs, dim=1)
         losses = {'source': None}
         sup = [k for k in feats if k.endswith('mixup') or k == 'source']
         probs = {}
@@ -102,5 +104,5 @@ class SemanticSegAlgo:
                 losses['source'] = self.semantic_loss(p, semantic_gt['source'], semantic_weights['source'])
             else:
                 losses[key] = self.semantic_loss(p, semantic_gt[key], None)          # weights = ones
-        confusion_matrix = self._confusion(semantic_pred, semantic_gt.get('target'))
+        confusion_matrix = None if semantic_pred is None else self._confusion(semantic_pred, semantic_gt.get('target'))
         return losses, confusion_matrix, semantic_pred

@@ -187,7 +187,7 @@ class CodepsNet(nn.Module):
             get = lambda name: {k: v.get(name) for k, v in items.items()}      # noqa: E731
             out = self.instance_algo.adaptation(po_depth_feats, get("center"), get("offset"), get("center_weights"),
                                                 get("offset_weights"), get("thing_mask"), self.instance_head,
-                                                items["target"].get("center_ema"), items["target"].get("offset_ema"))
+                                                items.get("target", {}).get("center_ema"), items.get("target", {}).get("offset_ema"))
             center_losses, offset_losses, center_pred, offset_pred = out[:4]
             if self.instance_head.use_thing_mask:
                 thing_mask_pred = out[5]
@@ -199,7 +199,7 @@ class CodepsNet(nn.Module):
                 {k: v.get("semantic_weights") for k, v in items.items()}, batched=batched)
 
         panoptic_pred, instance_pred = None, None
-        if do_panoptic_fusion:
+        if do_panoptic_fusion and semantic_pred is not None:
             panoptic_pred, instance_pred = self.instance_algo.panoptic_fusion(semantic_pred, center_pred, offset_pred)
 
         depth_losses, depth_pred = {}, None
@@ -219,7 +219,8 @@ class CodepsNet(nn.Module):
         losses["offset_source"] = offset_losses.get("source")
         result = OrderedDict(depth=depth_pred, object_motion_map=None, semantic=semantic_pred, center=center_pred,
                              offset=offset_pred, panoptic=panoptic_pred, instance=instance_pred, thing_mask=thing_mask_pred)
-        result["image_features"] = po_depth_feats["target"][0][-1].detach()
+        # (batch-sharded step: a rank without a target item has no frame to offer to the replay buffer)
+        result["image_features"] = po_depth_feats["target"][0][-1].detach() if "target" in po_depth_feats else None
         stats = OrderedDict(sem_conf=confusion_matrix)
         return losses, result, stats, in_data
 

@@ -2038,6 +2038,9 @@ static int check_conv(const codeps_conv_desc* d, const char* who) {
     return CODEPS_OK;
 }
 
+// name of the kernel variant the last conv entry point of this thread launched (tests select variants by shape and check it)
+static thread_local const char* g_last_kernel = "";
+
 static ConvP make_convp(const codeps_conv_desc* d) {
     ConvP p;
     memset(&p, 0, sizeof(p));
@@ -2102,6 +2105,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             static bool h_attr = false;
             if (!h_attr) { (void)hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); h_attr = true; }
             p.ksplit = 1;
+            g_last_kernel = "conv_halo3_kernel";
             hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
             return;
         }
@@ -2121,6 +2125,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             p.ksplit = 1; p.ksteps = nsteps_;
             const int ks_ = splitk_slices(p, blocks_, nsteps_);
             if (ks_ >= 2) { p.ksteps = cdiv(nsteps_, ks_); p.ksplit = cdiv(nsteps_, p.ksteps); }
+            g_last_kernel = "conv_igemm_ws_kernel";
             hipLaunchKernelGGL(kw, dim3(blocks_, p.ksplit), dim3(512), lds_ws, st, p, a0, a1, scale, shift, residual, out);
             if (p.ksplit > 1) {
                 const long long MN = (long long)p.M * p.N;
@@ -2142,6 +2147,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         p.ksteps = cdiv(nsteps, ks);
         p.ksplit = cdiv(nsteps, p.ksteps);
     }
+    g_last_kernel = NP == 3 ? (BK == 16 ? "conv_igemm_kernel<split3,bk16>" : "conv_igemm_kernel<split3>") : (NP == 2 ? "conv_igemm_kernel<split2>" : "conv_igemm_kernel<f32>");
     hipLaunchKernelGGL(k, dim3(blocks, p.ksplit), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
     if (p.ksplit > 1) {
         const long long MN = (long long)p.M * p.N;
@@ -2177,6 +2183,7 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         const int kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
         const bool single = (MODE != MODE_FWD) || p.C1 == 0;
         (void)single;
+        g_last_kernel = kc >= 96 ? "conv_igemm16_lds_kernel" : "conv_igemm16_kernel";
         if (kc >= 96) {                        // deep K per tap (GUDA 240 channels): LDS-staged flavour
             if (bk32) hipLaunchKernelGGL((conv_igemm16_lds_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
             else      hipLaunchKernelGGL((conv_igemm16_lds_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
@@ -2400,6 +2407,8 @@ extern "C" size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d)
     return (size_t)splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
 }
 
+extern "C" const char* codeps_conv2d_last_kernel(void) { return g_last_kernel; }
+
 extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float* x1, const float* dz, float* dw_oihw,
                                    int out_c_real, int in_c_real, int accumulate, void* workspace, size_t workspace_bytes,
                                    codeps_stream_t stream) {
@@ -2429,7 +2438,9 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
         const int g = sp.nblk * sp.ci_chunks;
 #define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS, KS, 1, 1, 8, 32>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \
                                                  sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part)
+        g_last_kernel = "wgrad_small_kernel";
         if (sp.halo64) {
+            g_last_kernel = wgrad_split_on() ? "wgrad_halo64s_kernel" : "wgrad_halo64_kernel";
             if (wgrad_split_on()) {
                 constexpr size_t lds = (size_t)64 * ((3 * 64 + 8) + (3 * 6 * 32 + 8)) * 2;           // dZs + Xs (halfwords)
                 static bool attr = false;
@@ -2443,9 +2454,10 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
             if (d->kw == 7)
                 hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 7, 2, 2, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks,
                                    sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
-            else if (sp.co_groups == 1)                // ... on the bf16 matrix cores (3-piece operands)
+            else if (sp.co_groups == 1) {              // ... on the bf16 matrix cores (3-piece operands)
+                g_last_kernel = "wgrad_stem74s_kernel";
                 hipLaunchKernelGGL(wgrad_stem74s_kernel, dim3(g), dim3(256), 0, st, p, sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, dz, part);
-            else                                       // double-pixel stem: 7 x 4 taps of 16 (2 pixels x 8 channels), stride (2, 1)
+            } else                                       // double-pixel stem: 7 x 4 taps of 16 (2 pixels x 8 channels), stride (2, 1)
                 hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 4, 2, 1, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks,
                                    sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
         } else if (d->kh == 3) {
@@ -2469,6 +2481,7 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
         const size_t lds = (size_t)2 * BKP_ * (BM_ + 4 + BN_ + 4) * sizeof(float);                             \
         hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), lds, st, p, x0, x1, dz, part); \
     } while (0)
+    g_last_kernel = "conv_wgrad_kernel";
     if (bm == 128 && bn == 128) WG_LAUNCH(2, 2, 2, 2);
     else if (bm == 128 && bn == 64) WG_LAUNCH(2, 2, 2, 1);
     else if (bm == 128 && bn == 32) WG_LAUNCH(4, 1, 1, 1);

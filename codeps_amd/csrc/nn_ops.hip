@@ -324,11 +324,13 @@ __global__ __launch_bounds__(256) void bn_finalize_mg_kernel(const float* __rest
     if (upd && sub == 0) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
-// SyncBatchNorm: merge the per-rank (mean, biased var) of every statistic group after the all-gather -- equal element counts
-// on all ranks, so the parallel-variance formula reduces to plain averages -- and apply the running-stat momentum updates
-// group after group with the GLOBAL count (torch.nn.SyncBatchNorm semantics).  gathered: [world][2][G][C].
+// SyncBatchNorm: merge the per-rank (mean, biased var) of every statistic group after the all-gather with the parallel-variance
+// formula and apply the running-stat momentum updates group after group with the GLOBAL count (torch.nn.SyncBatchNorm
+// semantics).  gathered: [world][2][G][C].  Equal element counts on all ranks (rc.on == 0) reduce the merge to plain averages;
+// otherwise rank r weighs in with rc.n[r * G + g] elements (0 = the rank holds nothing of that group: its slot is ignored).
 // One thread per channel; replaces ~45 tiny tensor ops per layer.
-__global__ __launch_bounds__(256) void bn_sync_combine_kernel(const float* __restrict__ gathered, int world, BnGroups gr, int C, int c_real,
+struct RankCounts { int on; float n[64]; };
+__global__ __launch_bounds__(256) void bn_sync_combine_kernel(const float* __restrict__ gathered, int world, BnGroups gr, RankCounts rc, int C, int c_real,
                                                               float eps, float momentum, float* __restrict__ mean, float* __restrict__ var,
                                                               float* __restrict__ invstd, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var) {
@@ -339,15 +341,31 @@ __global__ __launch_bounds__(256) void bn_sync_combine_kernel(const float* __res
     const float inv_w = 1.f / (float)world;
     const size_t rank_stride = (size_t)2 * gr.n * C;
     for (int g = 0; g < gr.n; ++g) {
-        float m = 0.f;
-        for (int r = 0; r < world; ++r) m += gathered[r * rank_stride + (size_t)g * C + c];
-        m *= inv_w;
-        float v = 0.f;
-        for (int r = 0; r < world; ++r) {
-            const float mr = gathered[r * rank_stride + (size_t)g * C + c], vr = gathered[r * rank_stride + (size_t)(gr.n + g) * C + c];
-            v += vr + (mr - m) * (mr - m);
+        float m = 0.f, v = 0.f;
+        if (!rc.on) {
+            for (int r = 0; r < world; ++r) m += gathered[r * rank_stride + (size_t)g * C + c];
+            m *= inv_w;
+            for (int r = 0; r < world; ++r) {
+                const float mr = gathered[r * rank_stride + (size_t)g * C + c], vr = gathered[r * rank_stride + (size_t)(gr.n + g) * C + c];
+                v += vr + (mr - m) * (mr - m);
+            }
+            v *= inv_w;
+        } else {
+            float tot = 0.f;
+            for (int r = 0; r < world; ++r) {
+                const float w = rc.n[r * gr.n + g];
+                if (w > 0.f) { m += w * gathered[r * rank_stride + (size_t)g * C + c]; tot += w; }
+            }
+            m /= tot;
+            for (int r = 0; r < world; ++r) {
+                const float w = rc.n[r * gr.n + g];
+                if (w > 0.f) {
+                    const float mr = gathered[r * rank_stride + (size_t)g * C + c], vr = gathered[r * rank_stride + (size_t)(gr.n + g) * C + c];
+                    v += w * (vr + (mr - m) * (mr - m));
+                }
+            }
+            v /= tot;
         }
-        v *= inv_w;
         mean[g * C + c] = m; var[g * C + c] = v; invstd[g * C + c] = rsqrtf(v + eps);
         if (upd) {
             const float n = gr.inv_count[g];                     // here: the GLOBAL element count of the group
@@ -1176,16 +1194,26 @@ extern "C" int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* r
     return CODEPS_OK;
 }
 
-extern "C" int codeps_bn_sync_combine(const float* gathered, int world, int n_groups, const float* global_counts, int c, int c_real, float eps,
-                                      float momentum, float* running_mean, float* running_var, float* mean, float* var, float* invstd,
-                                      codeps_stream_t stream) {
+extern "C" int codeps_bn_sync_combine(const float* gathered, int world, int n_groups, const float* global_counts, const float* rank_counts,
+                                      int c, int c_real, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                      float* var, float* invstd, codeps_stream_t stream) {
     CODEPS_REQUIRE(gathered && global_counts && mean && var && invstd && world >= 1 && n_groups >= 1 && n_groups <= 8 && c > 0 && c_real <= c,
                    CODEPS_ERR_ARG, "bn_sync_combine: bad arguments");
+    CODEPS_REQUIRE(!rank_counts || world * n_groups <= 64, CODEPS_ERR_ARG, "bn_sync_combine: per-rank counts support world x groups <= 64");
+    RankCounts rc;
+    rc.on = rank_counts ? 1 : 0;
+    for (int i = 0; i < 64; ++i) rc.n[i] = (rank_counts && i < world * n_groups) ? rank_counts[i] : 0.f;
+    if (rank_counts)
+        for (int g = 0; g < n_groups; ++g) {
+            float tot = 0.f;
+            for (int r = 0; r < world; ++r) tot += rank_counts[r * n_groups + g];
+            CODEPS_REQUIRE(tot > 0.f, CODEPS_ERR_ARG, "bn_sync_combine: statistic group %d is empty on every rank", g);
+        }
     BnGroups gr;
     gr.n = n_groups;
     for (int i = 0; i < 8; ++i) { gr.row0[i] = 0; gr.rows[i] = 0; gr.inv_count[i] = 0.f; }
     for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = global_counts[i];
-    hipLaunchKernelGGL(bn_sync_combine_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world, gr, c, c_real, eps, momentum,
+    hipLaunchKernelGGL(bn_sync_combine_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world, gr, rc, c, c_real, eps, momentum,
                        mean, var, invstd, running_mean, running_var);
     CODEPS_CHECK_LAUNCH("bn_sync_combine_kernel");
     return CODEPS_OK;

@@ -28,10 +28,13 @@ __global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long i
 // append otherwise -- so the list alternates between `length` and `length + 1` entries once it is full.
 __global__ void depth_key_weights_kernel(const float* __restrict__ pose_prev, const float* __restrict__ pose_next,
                                          float* __restrict__ state, int length, KeyCounts kc, int nk, int target,
+                                         float global_total, float global_target, int world, float* __restrict__ keep_io, int mode,
                                          float* __restrict__ coef) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float keep = 1.f;
-    if (target >= 0 && state != nullptr) {
+    if (mode == 2) {
+        if (keep_io) keep = *keep_io;
+    } else if (target >= 0 && state != nullptr) {
         const float a0 = pose_prev[3], a1 = pose_prev[7], a2 = pose_prev[11];
         const float b0 = pose_next[3], b1 = pose_next[7], b2 = pose_next[11];
         const float na = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(a0, a0), __fmul_rn(a1, a1)), __fmul_rn(a2, a2)));
@@ -53,13 +56,17 @@ __global__ void depth_key_weights_kernel(const float* __restrict__ pose_prev, co
         state[3] = dist;
         keep = skip ? 0.f : 1.f;
     }
+    if (keep_io && mode != 2) *keep_io = keep;
+    if (mode == 1) return;
     float total = 0.f;
     for (int k = 0; k < nk; ++k) {
         const float c = kc.n[k] * (k == target ? keep : 1.f);
         coef[k] = c;
         total += c;
     }
-    coef[nk] = total;                                       // the denominator; 0 when every key was skipped
+    // the denominator; 0 when every key was skipped.  Sharded: the global image count / world, so that DDP's mean over ranks
+    // of (sum_k n_k^r loss_k^r) / denominator is the global count-weighted mean
+    coef[nk] = global_total > 0.f ? (global_total - (1.f - keep) * global_target) / (float)world : total;
 }
 
 __global__ void weighted_sum_fwd_kernel(SumArgs a, int n, const float* __restrict__ denom, float* __restrict__ out) {
@@ -97,15 +104,19 @@ extern "C" int codeps_step_counter_add(uint64_t* counter, uint64_t increment, co
 extern "C" size_t codeps_depth_rule_state_floats(int length) { return length > 0 ? (size_t)length + 5 : 0; }
 
 extern "C" int codeps_depth_key_weights(const float* pose_prev, const float* pose_next, float* rule_state, int length, int n_keys,
-                                        const float* key_counts, int target_index, float* coef, codeps_stream_t stream) {
-    CODEPS_REQUIRE(n_keys >= 1 && n_keys <= MAXK && key_counts && coef, CODEPS_ERR_ARG, "depth_key_weights: 1..%d keys, counts and coef required", MAXK);
-    CODEPS_REQUIRE(target_index < n_keys, CODEPS_ERR_ARG, "depth_key_weights: target index %d of %d keys", target_index, n_keys);
-    CODEPS_REQUIRE(target_index < 0 || (pose_prev && pose_next && rule_state && length > 0), CODEPS_ERR_ARG,
+                                        const float* key_counts, int target_index, float global_total, float global_target, int world,
+                                        float* keep_io, int mode, float* coef, codeps_stream_t stream) {
+    CODEPS_REQUIRE(n_keys >= 0 && n_keys <= MAXK && (n_keys == 0 || key_counts) && mode >= 0 && mode <= 2 && world >= 1, CODEPS_ERR_ARG,
+                   "depth_key_weights: up to %d keys, mode 0..2, world >= 1", MAXK);
+    CODEPS_REQUIRE(mode == 1 || (coef && n_keys >= 1), CODEPS_ERR_ARG, "depth_key_weights: the weights need >= 1 key and the coef buffer");
+    CODEPS_REQUIRE(target_index < std::max(n_keys, 1), CODEPS_ERR_ARG, "depth_key_weights: target index %d of %d keys", target_index, n_keys);
+    CODEPS_REQUIRE(mode == 2 || target_index < 0 || (pose_prev && pose_next && rule_state && length > 0), CODEPS_ERR_ARG,
                    "depth_key_weights: the rule needs both target poses, its state buffer and a window length");
+    CODEPS_REQUIRE(mode != 1 || keep_io, CODEPS_ERR_ARG, "depth_key_weights: mode 1 writes the keep flag to keep_io");
     KeyCounts kc;
     for (int k = 0; k < MAXK; ++k) kc.n[k] = k < n_keys ? key_counts[k] : 0.f;
     hipLaunchKernelGGL(depth_key_weights_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pose_prev, pose_next, rule_state, length, kc,
-                       n_keys, target_index, coef);
+                       n_keys, target_index, global_total, global_target, world, keep_io, mode, coef);
     CODEPS_CHECK_LAUNCH("depth_key_weights_kernel");
     return CODEPS_OK;
 }

@@ -513,6 +513,7 @@ class _BatchNormTrain(torch.autograd.Function):
         c = gamma.numel()
         bsz = x.shape[0]
         per_item = x.numel() // cp // bsz
+        plan = getattr(groups, "plan", None) if reduce_fn is not None else None
         groups = [(0, bsz)] if not groups else list(groups)
         ng, row0, rows = _group_arrays(groups, per_item)
         g, b_ = _pad_vec(gamma, cp), _pad_vec(beta, cp)
@@ -529,6 +530,30 @@ class _BatchNormTrain(torch.autograd.Function):
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, ptr(rm),
                                          ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 0,
                                          ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+        elif plan is not None:
+            # SyncBN over UNEQUAL shards (BASELINE configs[3]: ranks hold different numbers of items of a key, or none): the
+            # packet has one slot per GLOBAL statistic group, this rank fills the slots of the groups it holds, and the combine
+            # kernel weighs every rank's slot with its element count (0 = ignored)
+            G, l2g = plan["n_global"], plan["index"](dev)
+            pk_local = torch.empty(2, ng, cp, dtype=torch.float32, device=dev)
+            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(pk_local[0]),
+                                         ptr(pk_local[1]), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+            pk = torch.zeros(2, G, cp, dtype=torch.float32, device=dev)
+            pk.index_copy_(1, l2g, pk_local)
+            gathered = reduce_fn.gather(pk)                                     # [world, 2, G, cp]
+            world = gathered.shape[0]
+            rank_counts = [plan["items"][r][g] * per_item for r in range(world) for g in range(G)]
+            gcounts = [sum(plan["items"][r][g] for r in range(world)) * per_item for g in range(G)]
+            mean_g = torch.empty(G, cp, dtype=torch.float32, device=dev)
+            var_g, invstd_g = torch.empty_like(mean_g), torch.empty_like(mean_g)
+            check(lib().codeps_bn_sync_combine(ptr(gathered), world, G, (ctypes.c_float * G)(*gcounts), (ctypes.c_float * (world * G))(*rank_counts),
+                                               cp, c, eps, momentum, ptr(rm), ptr(running_var) if rm is not None else None, ptr(mean_g),
+                                               ptr(var_g), ptr(invstd_g), stream_ptr()), "codeps_bn_sync_combine")
+            mean, var, invstd = mean_g.index_select(0, l2g), var_g.index_select(0, l2g), invstd_g.index_select(0, l2g)
+            counts = [gcounts[g] for g in plan["local_to_global"]]
+            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, None, None,
+                                         ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1, ptr(ws), ws.numel(), stream_ptr()),
+                  "codeps_bn_fwd_mg")
         else:       # SyncBN: local statistics -> all-gather -> one combine kernel (merge + running stats + invstd) -> apply
             pk = torch.empty(2, ng, cp, dtype=torch.float32, device=dev)        # [mean | var] = the all-gather packet, no packing pass
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(pk[0]),
@@ -537,7 +562,7 @@ class _BatchNormTrain(torch.autograd.Function):
             world = gathered.shape[0]
             counts = [n * world for n in counts]                                # equal shards on every rank by construction
             gc = (ctypes.c_float * ng)(*counts)
-            check(lib().codeps_bn_sync_combine(ptr(gathered), world, ng, gc, cp, c, eps, momentum, ptr(rm),
+            check(lib().codeps_bn_sync_combine(ptr(gathered), world, ng, gc, None, cp, c, eps, momentum, ptr(rm),
                                                ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd),
                                                stream_ptr()), "codeps_bn_sync_combine")
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, None, None,
@@ -547,6 +572,7 @@ class _BatchNormTrain(torch.autograd.Function):
         # ReLU without a residual: the backward recomputes the mask from x (y is neither kept nor re-read)
         ctx.save_for_backward(x, y if (act and residual is not None) else None, g, b_, mean, invstd)
         ctx.act, ctx.c, ctx.reduce_fn, ctx.has_res, ctx.groups, ctx.per_item = act, c, reduce_fn, residual is not None, groups, per_item
+        ctx.plan = plan
         # flat-gradient sinks of the affine parameters (codeps_amd.step): the backward accumulates dgamma / dbeta in place
         gs, bs = grad_sink(gamma), grad_sink(beta)
         ctx.sinks = (gs, bs) if (gs is not None and bs is not None and gamma.requires_grad and beta.requires_grad) else None
@@ -577,7 +603,13 @@ class _BatchNormTrain(torch.autograd.Function):
             check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), ptr(b_), None,
                                          ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), acc, None, None, 1, 0, ptr(ws), ws.numel(), stream_ptr()),
                   "codeps_bn_bwd_mg")
-            sums = ctx.reduce_fn.sum(sums)
+            if ctx.plan is not None:           # unequal shards: sum the groups in their global slots
+                l2g = ctx.plan["index"](dev)
+                sums_g = torch.zeros(ctx.plan["n_global"], 2, cp, dtype=torch.float32, device=dev)
+                sums_g.index_copy_(0, l2g, sums)
+                sums = ctx.reduce_fn.sum(sums_g).index_select(0, l2g)
+            else:
+                sums = ctx.reduce_fn.sum(sums)
             check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), ptr(b_), inv_count,
                                          ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(dres), 0, 1, ptr(ws), ws.numel(),
                                          stream_ptr()), "codeps_bn_bwd_mg")
@@ -1120,21 +1152,40 @@ def depth_rule_state(device, length=300):
     return torch.zeros(lib().codeps_depth_rule_state_floats(int(length)), dtype=torch.float32, device=device)
 
 
-def depth_key_weights(counts, device, target_index=-1, poses=None, rule_state=None, length=300):
+def depth_key_weights(counts, device, target_index=-1, poses=None, rule_state=None, length=300, shard=None):
     """Image-count weights of DepthAlgo.adaptation's per-key losses (algos/depth.py:562-577) as a device vector
-    [n_keys + 1] = (n_k * keep_k ..., their sum), with the "car not moving" rule (depth.py:537-558) evaluated on the device
+    [n_keys + 1] = (n_k * keep_k ..., the denominator), with the "car not moving" rule (depth.py:537-558) evaluated on the device
     for key `target_index` from that key's (T_t->t-1, T_t->t+1): no host synchronisation, so the rule stays live inside a
-    replayed HIP graph.  `rule_state` (depth_rule_state) carries the rolling window across frames; it is updated in place."""
+    replayed HIP graph.  `rule_state` (depth_rule_state) carries the rolling window across frames; it is updated in place.
+
+    shard (batch-sharded step, world > 1): dict(world, global_total, global_target, rule: bool, owner: bool, group).  `counts`
+    are this rank's; the denominator is the global image count / world.  With `rule`, the rank that owns the global batch's
+    first target item (`owner`, rank 0 by construction) evaluates the rule and the keep flag is broadcast -- one 4-byte
+    collective per step -- so that every rank drops / keeps the target key together."""
     n = len(counts)
     coef = torch.empty(n + 1, dtype=torch.float32, device=device)
     require_cuda(coef)
-    kc = (ctypes.c_float * n)(*[float(c) for c in counts])
+    kc = (ctypes.c_float * max(n, 1))(*[float(c) for c in counts])
     tp = tn = None
-    if target_index >= 0:
+    if target_index >= 0 and poses is not None:
         tp, tn = _f32c(poses[0].detach()).reshape(-1, 16), _f32c(poses[1].detach()).reshape(-1, 16)
         require_cuda(tp, tn, rule_state)
-    check(lib().codeps_depth_key_weights(ptr(tp), ptr(tn), ptr(rule_state), int(length), n, kc, int(target_index), ptr(coef),
-                                         stream_ptr()), "codeps_depth_key_weights")
+    if shard is None:
+        check(lib().codeps_depth_key_weights(ptr(tp), ptr(tn), ptr(rule_state), int(length), n, kc, int(target_index), 0.0, 0.0, 1,
+                                             None, 0, ptr(coef), stream_ptr()), "codeps_depth_key_weights")
+        return coef
+    keep = None
+    if shard.get("rule"):
+        import torch.distributed as dist
+        keep = torch.ones(1, dtype=torch.float32, device=device)
+        if shard.get("owner"):
+            check(lib().codeps_depth_key_weights(ptr(tp), ptr(tn), ptr(rule_state), int(length), n, kc, int(target_index), 0.0, 0.0, 1,
+                                                 ptr(keep), 1, None, stream_ptr()), "codeps_depth_key_weights")
+        dist.broadcast(keep, src=shard.get("owner_rank", 0), group=shard.get("group"))
+    check(lib().codeps_depth_key_weights(None, None, None, int(length), n, kc, int(target_index), float(shard["global_total"]),
+                                         float(shard["global_target"]), int(shard["world"]), ptr(keep), 2, ptr(coef), stream_ptr()),
+          "codeps_depth_key_weights")
+    coef._codeps_keep = keep
     return coef
 
 

@@ -127,10 +127,11 @@ class ResnetEncoder(nn.Module):
         cp, xpad = (8, F.STEM_XPAD) if stem else (16, (0, 0))
         if isinstance(input_image, _PairGroups):
             x = F.frame_pairs_to_nhwc(list(input_image), cp, xpad)
-            groups, off = [], 0
+            groups, off = _Groups(), 0
             for fa, _fb in input_image:
                 groups.append((off, off + fa.shape[0]))
                 off += fa.shape[0]
+            groups.plan = getattr(input_image, "plan", None)
         elif isinstance(input_image, _BatchOf):
             x = F.image_batches_to_nhwc(list(input_image), cp, xpad)
         elif isinstance(input_image, (tuple, list)):
@@ -149,12 +150,14 @@ class ResnetEncoder(nn.Module):
         flush_bn_counters()
         return [F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]
 
-    def forward_pair_groups(self, pairs):
+    def forward_pair_groups(self, pairs, plan=None):
         """pairs = [(frame_a, frame_b), ...]: every pair is what the reference feeds to ONE call of this encoder
         (`torch.cat([a, b], 1)`, algos/depth.py:408-413).  All pairs run through one set of batched convolutions while
         every BatchNorm keeps per-pair batch statistics and applies the running-stat momentum updates pair by pair in
         list order -- bit-for-bit the semantics of len(pairs) separate calls, at len(pairs) x larger GEMMs."""
-        return self.forward(_PairGroups(pairs))
+        pg = _PairGroups(pairs)
+        pg.plan = plan          # SyncBatchNorm over unequal shards: slots of the global statistic groups (algos.depth._group_plan)
+        return self.forward(pg)
 
     def forward_batch(self, images):
         """Several NCHW image batches of one resolution -> ONE forward over their concatenation along the batch
@@ -165,6 +168,11 @@ class ResnetEncoder(nn.Module):
 
 class _BatchOf(list):
     """Marker: list of NCHW tensors to be concatenated along the batch axis."""
+
+
+class _Groups(list):
+    """Batch ranges of the BatchNorm statistic groups; `.plan` = their slots in the global group list when ranks hold unequal shards."""
+    plan = None
 
 
 class _PairGroups(list):

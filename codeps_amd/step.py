@@ -123,6 +123,28 @@ class StepRunner:
         self.noise_counter = torch.zeros(1, dtype=torch.int64, device=self.groups[0].flat.device)
         self.seed_base = 0x5EED
         self._graph = None
+        self.key_scale = {}             # per-loss re-weighting of a batch-sharded step with unequal shards (set_key_counts)
+
+    def set_key_counts(self, items, rank):
+        """Batch-sharded step whose ranks hold DIFFERENT numbers of items per key (BASELINE configs[3], SURVEY.md 8d: ranks
+        0-3 hold 1 target + 1 replay item, ranks 4-7 two replay items).  items = {key: [items on rank 0, 1, ...]}.
+        With it the step reproduces the single-process step on the concatenated batch: the count-weighted depth means use the
+        global image counts, every other per-key mean is re-weighted by local / (global / world) items, SyncBatchNorm weighs each
+        rank's statistics with its element count, and the car-not-moving rule is evaluated by the rank that owns the first
+        target item.  Equal shards need none of this (the plain DDP mean is exact)."""
+        world = self.world
+        assert all(len(v) == world for v in items.values()), "one item count per rank and key"
+        h, w = self.cfg.dataset.feed_img_size
+        hs, ws = self.cfg.adapt.source_dataset.feed_img_size
+        res = {k: ((hs, ws) if k == "source" or k.endswith("mixup") else (h, w)) for k in items}
+        self.net.depth_algo.shard_layout = dict(world=world, rank=rank, group=self.group, items={k: list(v) for k, v in items.items()}, res=res)
+        self.key_scale = {}
+        for loss_name, key in (("semantic_source", "source"), ("center_source", "source"), ("offset_source", "source")):
+            if key in items and sum(items[key]) > 0:
+                self.key_scale[loss_name] = items[key][rank] * world / sum(items[key])
+        for key in items:
+            if key.endswith("mixup") and sum(items[key]) > 0:
+                self.key_scale["semantic_" + key] = items[key][rank] * world / sum(items[key])
 
     @property
     def grad_bytes(self):
@@ -143,7 +165,7 @@ class StepRunner:
             if v is None or w is None or not v.requires_grad:        # scripts/adapt_codeps.py:274-288
                 continue
             terms.append(v)
-            wts.append(float(w))
+            wts.append(float(w) * self.key_scale.get(k, 1.0))
         total = F.weighted_sum(terms, wts)
         total.backward()
         return total.detach(), losses, result

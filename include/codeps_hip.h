@@ -100,6 +100,8 @@ int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pa
  * relative, below fp32 rounding); 0 = v_mfma_f32_*_f32 (16-column kernels, 16-channel K chunks, all weight gradients).
  * Reporting only (bench.py prices each launch against the matching peak). */
 int codeps_conv2d_arith(const codeps_conv_desc* d, int mode, int source);
+/* Name of the kernel variant the last conv2d_{fwd,dgrad,wgrad} call of this thread launched (diagnostics / tests). */
+const char* codeps_conv2d_last_kernel(void);
 /* workspace (optional, may be NULL): scratch for split-K partial sums; codeps_conv2d_fwd_workspace_bytes(d) is the size
  * that enables it for this shape (0 = never splits).  Small-M / deep-K launches (B = 1 inference, 1/32-resolution
  * layers) are cut into K slices + a fixed-order finish pass so that they still fill the 256 CUs. */
@@ -173,11 +175,14 @@ int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* row0, const 
                      float* invstd, float* y, int stats_only, int apply_only, void* workspace,
                      size_t workspace_bytes, codeps_stream_t stream);
 /* SyncBatchNorm (misc/train_utils.py:50-51, torch.nn.SyncBatchNorm): after the all-gather of every rank's per-group
- * (mean, biased var) -- gathered [world][2][n_groups][c], equal element counts on all ranks -- merge them, compute invstd
- * and apply the running-stat momentum updates group by group with the global counts (host array [n_groups]). */
-int codeps_bn_sync_combine(const float* gathered, int world, int n_groups, const float* global_counts, int c,
-                           int c_real, float eps, float momentum, float* running_mean, float* running_var,
-                           float* mean, float* var, float* invstd, codeps_stream_t stream);
+ * (mean, biased var) -- gathered [world][2][n_groups][c] -- merge them (parallel-variance formula), compute invstd and
+ * apply the running-stat momentum updates group by group with the global counts (host array [n_groups]).
+ * rank_counts: NULL = equal element counts on all ranks; else a HOST array [world][n_groups] of element counts (0 = the
+ * rank holds nothing of that group, its slot of `gathered` is ignored) -- the unequal shards of BASELINE configs[3]. */
+int codeps_bn_sync_combine(const float* gathered, int world, int n_groups, const float* global_counts,
+                           const float* rank_counts, int c, int c_real, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* var, float* invstd,
+                           codeps_stream_t stream);
 int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x, int n_groups, const long long* row0,
                      const long long* rows, int c, int c_real, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, const float* inv_count, int act, float* sums,
@@ -305,7 +310,12 @@ int codeps_ssim_bwd(const float* x, const float* y, const float* grad_out, int p
  *   = position of the "target" key or -1 (rule off); pose_prev / pose_next = the target key's [.,16]
  *   transformations (item 0 is read); rule_state = codeps_depth_rule_state_floats(length) zero-
  *   initialised floats kept by the caller across frames (length = 300 in the reference).
- *   coef [n_keys + 1] <- n_k * keep_k, then their sum (0 when every key is skipped).
+ *   coef [n_keys + 1] <- n_k * keep_k, then the denominator (their sum; 0 when every key is skipped).
+ *   Batch-sharded step (world > 1): key_counts are this rank's image counts, global_total / global_target the image counts
+ *   of all ranks (all depth keys / the target key); the denominator becomes (global_total - (1 - keep) * global_target) /
+ *   world so that the mean over ranks of the local losses is the global count-weighted mean.  The rule is evaluated by ONE
+ *   rank (mode 1: rule only, keep flag -> *keep_io), broadcast by the caller, and consumed by all (mode 2: keep flag <-
+ *   *keep_io, no rule).  mode 0 = rule + weights in one launch (single rank; keep_io may be NULL).
  * codeps_weighted_sum_{fwd,bwd}: out = sum_i w_i f_i loss_i / D  (scripts/adapt_codeps.py:274-288 and
  *   depth.py:562-577): losses / factors / grads are HOST arrays of n DEVICE scalar pointers (factors
  *   may be NULL or hold NULL entries = 1; grads entries may be NULL), weights a HOST array, denom an
@@ -313,7 +323,8 @@ int codeps_ssim_bwd(const float* x, const float* y, const float* grad_out, int p
 int codeps_step_counter_add(uint64_t* counter, uint64_t increment, codeps_stream_t stream);
 size_t codeps_depth_rule_state_floats(int length);
 int codeps_depth_key_weights(const float* pose_prev, const float* pose_next, float* rule_state, int length,
-                             int n_keys, const float* key_counts, int target_index, float* coef,
+                             int n_keys, const float* key_counts, int target_index, float global_total,
+                             float global_target, int world, float* keep_io, int mode, float* coef,
                              codeps_stream_t stream);
 int codeps_weighted_sum_fwd(const float* const* losses, const float* weights, const float* const* factors,
                             int n, const float* denom, float* out, codeps_stream_t stream);

@@ -1,0 +1,101 @@
+"""Worker of tests/test_distributed_gpu.py::test_sharded_step_equals_single_process_step.
+
+    python tests/dist_equiv_worker.py <out_file> [--asym]
+
+world == 1 (no torchrun env): the adaptation step on the WHOLE batch.  world == 2 (RANK / WORLD_SIZE / MASTER_* set by the
+test): every rank builds the identical whole batch, keeps its slice of every key, and runs the sharded step -- SyncBatchNorm
+statistics exchange in the train-mode pose encoder, ONE all-reduce of each flat gradient buffer, 1 / world in the optimizer
+(codeps_amd/distributed.py, codeps_amd/step.py; DDP + SyncBN semantics of misc/train_utils.py:47-59).  Both ranks sit on
+GPU 0 and talk over gloo (RCCL needs one GPU per rank).  Top-k hard-pixel mining is rank-local by design, so
+the comparison runs with top_k = 1.0; the tie-break noise is given explicitly, sliced like the items."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+H, W = 64, 128
+ITEMS = {"target": 2, "target_replay": 4, "source": 2, "cut_mixup": 2}
+
+
+def split_of(rank, world, asym):
+    """{key: (lo, hi)} of this rank.  Symmetric: equal contiguous slices.  asym (BASELINE configs[3]): rank 0 holds
+    the 2 target items' first + ... -- here: rank 0 = 1 target + 1 replay, rank 1 = 2 replay would leave a target item out, so
+    the asymmetric layout of this test is target (2, 0), replay (1, 3): 3 depth items per rank, source / mixup 1 + 1."""
+    if world == 1:
+        return {k: (0, n) for k, n in ITEMS.items()}
+    if not asym:
+        return {k: (rank * n // world, (rank + 1) * n // world) for k, n in ITEMS.items()}
+    lay = {"target": [(0, 2), (2, 2)], "target_replay": [(0, 1), (1, 4)], "source": [(0, 1), (1, 2)], "cut_mixup": [(0, 1), (1, 2)]}
+    return {k: v[rank] for k, v in lay.items()}
+
+
+def main():
+    out_file = sys.argv[1]
+    asym = "--asym" in sys.argv
+    from codeps_amd import synthetic
+    from codeps_amd.codeps import gen_models
+    from codeps_amd.config import get_cfg_defaults
+    from codeps_amd.distributed import SyncBatchNormReducer, init_from_env
+    from codeps_amd.step import StepRunner
+    rank, _local, world = init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.manual_seed(20)
+    cfg = get_cfg_defaults(adapt=True)
+    cfg.model.po_depth_net.params.nof_layers = 18
+    cfg.dataset.feed_img_size = [H, W]
+    cfg.adapt.source_dataset.feed_img_size = [H, W]
+    cfg.semantics.top_k = 1.0
+    net = gen_models(cfg, dev, list(range(9)), [9, 10, 11, 12, 13], [], adaptation_mode=True)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    full = {"target": synthetic.triplet_item(ITEMS["target"], H, W, gen, dev),
+            "target_replay": synthetic.triplet_item(ITEMS["target_replay"], H, W, gen, dev),
+            "source": synthetic.triplet_item(ITEMS["source"], H, W, gen, dev, labels=True)}
+    mix = synthetic.triplet_item(ITEMS["cut_mixup"], H, W, gen, dev, labels=True)
+    full["cut_mixup"] = {"rgb": {0: mix["rgb"][0]}, "semantic": mix["semantic"]}
+    torch.manual_seed(1)
+    noise = {k: [torch.randn(ITEMS[k], 2, H >> s, W >> s) * 1e-5 for s in range(5)] for k in ("source", "target", "target_replay")}
+
+    sl = split_of(rank, world, asym)
+
+    def cut(v, lo, hi):
+        if isinstance(v, dict):
+            return {k: cut(x, lo, hi) for k, x in v.items()}
+        return v[lo:hi].contiguous()
+
+    data = {k: cut(v, *sl[k]) for k, v in full.items() if sl[k][1] > sl[k][0]}
+    flat = lambda k: torch.cat([n[sl[k][0]:sl[k][1]].reshape(-1) for n in noise[k]]).to(dev)      # noqa: E731
+    net.depth_algo.reconstruction_loss_adapt_source.noise = [flat("source")] if "source" in data else []
+    net.depth_algo.reconstruction_loss.noise = [flat(k) for k in ("target", "target_replay") if k in data]
+    runner = StepRunner(net, cfg, "adapt", world)
+    if world > 1:
+        counts = {k: [split_of(r, world, asym)[k][1] - split_of(r, world, asym)[k][0] for r in range(world)] for k in ITEMS}
+        red = SyncBatchNormReducer()
+        net.backbone_po_depth.sync_bn = net.backbone_pose_sflow.sync_bn = red
+        if asym:
+            runner.set_key_counts(counts, rank)
+    total, losses, _ = runner.forward_backward(data)
+    from codeps_amd.distributed import allreduce_flat_gradients
+    grads = []
+    for g in runner.groups:
+        allreduce_flat_gradients(g.grad, runner.group)
+        grads.append((g.grad / world).cpu())
+    runner.step_count += 1
+    from codeps_amd import functional as F
+    for g in runner.groups:
+        F.adam_ema_step(g.flat, g.grad, g.m, g.v, 1, lr=runner.lr, grad_scale=1.0 / world, ema_params=g.ema, ema_alpha=runner.ema_alpha)
+    torch.cuda.synchronize()
+    bufs = {n: b.cpu() for n, b in net.backbone_pose_sflow.named_buffers()}
+    torch.save({"grads": grads, "bufs": bufs, "losses": {k: (None if v is None else float(v)) for k, v in losses.items()},
+                "params": [g.flat.cpu() for g in runner.groups], "names": [[tuple(p.shape) for p in g.params] for g in runner.groups]},
+               out_file)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

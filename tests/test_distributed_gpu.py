@@ -3,19 +3,87 @@ statistics exchange through codeps_bn_sync_combine, flat-gradient all-reduce, th
 completion and report a finite rate.  (RCCL itself needs one GPU per rank; the driver exercises it at round end.)"""
 import json
 import os
+import socket
 import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_worker(out_file, world, extra=()):
+    worker = os.path.join(ROOT, "tests", "dist_equiv_worker.py")
+    if world == 1:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        out = subprocess.run([sys.executable, worker, out_file, *extra], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return
+    port = str(_free_port())
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, worker, out_file.replace(".pt", f"_r{r}.pt"), *extra], cwd=ROOT, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        _o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+
+
+@pytest.mark.parametrize("asym", [False, True])
+def test_sharded_step_equals_single_process_step(tmp_path, asym):
+    """DDP + SyncBatchNorm semantics of misc/train_utils.py:47-59 on the REAL adaptation step: two ranks, each with its slice of
+    every key (asym: unequal slices -- rank 0 holds both target items, rank 1 three of the four replay items, the layout idea of
+    BASELINE configs[3]), against one process on the concatenated batch: the all-reduced flat gradients (x 1 / world), the
+    parameters after the fused Adam step and the pose encoder's SyncBN running statistics agree; both ranks end bit-identical."""
+    extra = ("--asym",) if asym else ()
+    single = str(tmp_path / "single.pt")
+    _run_worker(single, 1, extra)
+    _run_worker(str(tmp_path / "shard.pt"), 2, extra)
+    ref = torch.load(single)
+    r0, r1 = torch.load(str(tmp_path / "shard_r0.pt")), torch.load(str(tmp_path / "shard_r1.pt"))
+    for a, b in zip(r0["grads"] + r0["params"], r1["grads"] + r1["params"]):
+        assert torch.equal(a, b), "ranks disagree after the all-reduce"
+    for k, v in ref["bufs"].items():
+        if v.is_floating_point():
+            err = float((r0["bufs"][k].double() - v.double()).abs().max() / (v.double().abs().max() + 1e-12))
+            assert err < 1e-5, f"SyncBN running statistic {k}: {err:.2e}"
+            assert torch.equal(r0["bufs"][k], r1["bufs"][k])
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))      # noqa: E731
+    for gi, (g, gr) in enumerate(zip(r0["grads"], ref["grads"])):
+        # whole flat buffer, then parameter by parameter (a few summation orders differ: per-rank conv tiles, the order of the
+        # all-reduce): 1e-5 of the buffer's norm, 1e-4 per parameter against its own norm with a floor at 1e-6 of the largest
+        assert rel(g, gr) < 1e-5, f"flat gradient group {gi}: rel-L2 {rel(g, gr):.2e}"
+        off, worst = 0, 0.0
+        floor = 1e-6 * max(float(gr[o:o + 1].abs().max()) for o in range(1)) + 1e-30
+        big = max(float(gr.abs().max()), 1e-30)
+        for shape in ref["names"][gi]:
+            n = 1
+            for d in shape:
+                n *= d
+            a, b = g[off:off + n], gr[off:off + n]
+            worst = max(worst, float((a.double() - b.double()).norm()) / (float(b.double().norm()) + 1e-4 * big * n ** 0.5))
+            off += n
+        assert worst < 1e-4, f"group {gi}: worst per-parameter gradient error {worst:.2e}"
+        del floor
+    for gi, (p, pr) in enumerate(zip(r0["params"], ref["params"])):
+        assert float((p - pr).abs().max()) <= 2.05e-4, "one Adam step moves a weight by at most lr = 1e-4"
+        assert rel(p, pr) < 1e-5
+
+
 def test_two_ranks_on_one_gpu_complete_with_default_flags():
     env = dict(os.environ, CODEPS_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
            "--encoder", "18", "--height", "128", "--width", "256", "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]

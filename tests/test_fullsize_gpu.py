@@ -48,9 +48,11 @@ def test_conv_matches_vendor_library_and_is_linear(b, h, w, ci, co, k, s):
     dx, dw = to_nhwc(x1).requires_grad_(True), wt.clone().requires_grad_(True)
     y = F.conv2d(dx, dw, stride=s, pad=k // 2)
     y.backward(to_nhwc(gy))
-    assert rel(to_nchw(y, co), ry) < 2e-4
-    assert rel(to_nchw(dx.grad, ci), rx.grad) < 2e-4
-    assert rel(dw.grad, rw.grad) < 2e-4
+    # two fp32 implementations with different summation orders: 5e-6 relative L2 (the rejected 2-piece split arithmetic sits at
+    # 4.5e-6 on the forward alone and fails this on the gradients; per-kernel float64 bounds: tests/test_precision_gpu.py)
+    assert rel(to_nchw(y, co), ry) < 5e-6
+    assert rel(to_nchw(dx.grad, ci), rx.grad) < 5e-6
+    assert rel(dw.grad, rw.grad) < 5e-6
     # linearity (same kernel, exact property): conv(2 x1 - 3 x2) = 2 conv(x1) - 3 conv(x2)
     with torch.no_grad():
         ya = F.conv2d(to_nhwc(2.0 * x1 - 3.0 * x2), wt, stride=s, pad=k // 2)
@@ -74,9 +76,9 @@ def test_decoder_conv_up_concat_matches_vendor_library(b, h, w, c0, c1, co):
     d0, d1, dw = to_nhwc(x0).requires_grad_(True), to_nhwc(x1).requires_grad_(True), wt.clone().requires_grad_(True)
     y = F.conv2d(d0, dw, x1=d1, up0=True, pad=1, act="elu")
     y.backward(to_nhwc(gy))
-    assert rel(to_nchw(y, co), ry) < 2e-4
-    assert rel(to_nchw(d0.grad, c0), r0.grad) < 2e-4 and rel(to_nchw(d1.grad, c1), r1.grad) < 2e-4
-    assert rel(dw.grad, rw.grad) < 2e-4
+    assert rel(to_nchw(y, co), ry) < 5e-6
+    assert rel(to_nchw(d0.grad, c0), r0.grad) < 5e-6 and rel(to_nchw(d1.grad, c1), r1.grad) < 5e-6
+    assert rel(dw.grad, rw.grad) < 5e-6
 
 
 def test_stem_double_pixel_equals_generic_path_full_size():
@@ -95,7 +97,7 @@ def test_stem_double_pixel_equals_generic_path_full_size():
     assert rel(y1, y2) < 1e-5
     assert rel(w1.grad, w2.grad) < 1e-5
     ref = TF.conv2d(torch.cat([fa, fb], 1), wt, None, 2, 3)          # vendor library
-    assert rel(to_nchw(y1, 64), ref) < 2e-4
+    assert rel(to_nchw(y1, 64), ref) < 5e-6
 
 
 def test_guda_fusion_equals_concat_conv_full_size():

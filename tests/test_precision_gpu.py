@@ -1,0 +1,148 @@
+"""Precision of EVERY split-operand conv kernel variant, pinned per kernel.
+
+The conv engine feeds fp32 operands to the bf16 matrix cores as exact 3-way bf16 splits (six piece products, fp32 accumulate:
+csrc/conv.hip).  The claim "indistinguishable from an fp32 convolution" (reference arithmetic: fp32 convs,
+models/resnet_encoder.py:115-126) is checked here against float64 for each variant the adaptation step spends its time in --
+`conv_halo3_kernel` (forward, data gradient, fused up-sample + concat), `conv_igemm_ws_kernel`, `conv_igemm_kernel<split3>`,
+the split stem forward (16-channel K-steps), `wgrad_halo64s_kernel`, `wgrad_stem74s_kernel` -- on well-scaled, on
+wide-dynamic-range and on cancelling inputs: the error against float64 must stay within 3x (sums over pixels / long chains: 4x)
+of the error torch's own fp32 CPU convolution makes on the same tensors.  `codeps_conv2d_last_kernel` proves that the shape
+really selected the variant under test."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _F():
+    from codeps_amd import functional as F
+    return F
+
+
+def _last():
+    from codeps_amd._lib import lib
+    return lib().codeps_conv2d_last_kernel().decode()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(y, c):
+    return y[..., :c].permute(0, 3, 1, 2).cpu()
+
+
+def l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+def _inputs(kind, shape_x, shape_w, seed):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "normal":                 # post-ReLU activations, He-scaled weights
+        x = torch.relu(torch.randn(shape_x, generator=g))
+        w = torch.randn(shape_w, generator=g) * (2.0 / (shape_w[1] * shape_w[2] * shape_w[3])) ** 0.5
+    elif kind == "wide":                 # magnitudes spread over 2^-12 .. 2^12 (activations) and 2^-6 .. 2^6 (weights)
+        x = torch.randn(shape_x, generator=g) * torch.exp2(torch.randint(-12, 13, shape_x, generator=g).float())
+        w = torch.randn(shape_w, generator=g) * torch.exp2(torch.randint(-6, 7, shape_w, generator=g).float())
+    else:                                # "cancel": near-constant activations against zero-sum filters
+        x = 1.0 + 1e-3 * torch.randn(shape_x, generator=g)
+        w = torch.randn(shape_w, generator=g)
+        w = w - w.mean(dim=(1, 2, 3), keepdim=True)
+    return x, w, g
+
+
+def _reference(x, w, gy, stride, pad, dtype):
+    xr, wr = x.to(dtype).requires_grad_(True), w.to(dtype).requires_grad_(True)
+    y = TF.conv2d(xr, wr, None, stride, pad)
+    y.backward(gy.to(dtype))
+    return y.detach(), xr.grad, wr.grad
+
+
+CASES = {
+    # name: (B, H, W, Cin, Cout, k, expected forward kernel, expected dgrad kernel, expected wgrad kernel)
+    "halo3_64": (4, 64, 128, 64, 64, 3, "conv_halo3_kernel", "conv_halo3_kernel", "wgrad_halo64s_kernel"),
+    "halo3_128": (2, 64, 128, 128, 128, 3, "conv_halo3_kernel", "conv_halo3_kernel", "wgrad_halo64s_kernel"),
+    "ws_3x3_256": (8, 32, 64, 256, 256, 3, "conv_igemm_ws_kernel", "conv_igemm_ws_kernel", None),
+    "ws_1x1_2048": (4, 32, 64, 2048, 512, 1, "conv_igemm_ws_kernel", None, None),
+    "igemm_1x1": (8, 32, 64, 256, 1024, 1, "conv_igemm_kernel<split3>", "conv_igemm_kernel<split3>", None),
+}
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide", "cancel"])
+@pytest.mark.parametrize("case", list(CASES))
+def test_split_kernels_are_at_fp32_rounding_level(case, kind):
+    F = _F()
+    torch.set_num_threads(8)
+    b, h, w_, ci, co, k, k_fwd, k_dg, k_wg = CASES[case]
+    x, wt, g = _inputs(kind, (b, ci, h, w_), (co, ci, k, k), 1000 + len(case) * 7 + len(kind))
+    gy = torch.randn(b, co, h, w_, generator=g)
+    if kind == "wide":
+        gy = gy * torch.exp2(torch.randint(-8, 9, gy.shape, generator=g).float())
+    y64, dx64, dw64 = _reference(x, wt, gy, 1, k // 2, torch.float64)
+    y32, dx32, dw32 = _reference(x, wt, gy, 1, k // 2, torch.float32)
+    wd = wt.to(DEV)
+    # forward (+ data gradient only: the weight takes no gradient, so the last launch of backward() is the data gradient)
+    dx = nhwc(x).requires_grad_(True)
+    y = F.conv2d(dx, wd, pad=k // 2)
+    assert _last() == k_fwd, f"forward ran {_last()}, the case is meant to select {k_fwd}"
+    y.backward(nhwc(gy))
+    if k_dg is not None:
+        assert _last() == k_dg, f"data gradient ran {_last()}, the case is meant to select {k_dg}"
+    e_fwd, t_fwd = l2(nchw(y.detach(), co), y64), l2(y32, y64)
+    assert e_fwd <= 3 * t_fwd + 1e-9, f"{case}/{kind} forward: {e_fwd:.3e} vs torch fp32 {t_fwd:.3e}"
+    e_dx, t_dx = l2(nchw(dx.grad, ci), dx64), l2(dx32, dx64)
+    assert e_dx <= 4 * t_dx + 1e-9, f"{case}/{kind} data gradient: {e_dx:.3e} vs torch fp32 {t_dx:.3e}"
+    # weight gradient
+    ww = wd.clone().requires_grad_(True)
+    y2 = F.conv2d(nhwc(x), ww, pad=k // 2)
+    y2.backward(nhwc(gy))
+    if k_wg is not None:
+        assert _last() == k_wg, f"weight gradient ran {_last()}, the case is meant to select {k_wg}"
+    e_dw, t_dw = l2(ww.grad.cpu(), dw64), l2(dw32, dw64)
+    assert e_dw <= 4 * t_dw + 1e-9, f"{case}/{kind} weight gradient ({_last()}): {e_dw:.3e} vs torch fp32 {t_dw:.3e}"
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide", "cancel"])
+def test_halo3_with_fused_upsample_and_concat(kind):
+    """The decoder's conv3x3(cat(nearest_x2(x0), x1)) (models/depth_head.py:60-71) on the halo-tile kernel."""
+    F = _F()
+    b, h, w_, c0, c1, co = 4, 64, 128, 64, 32, 64
+    x0, wt, g = _inputs(kind, (b, c0, h // 2, w_ // 2), (co, c0 + c1, 3, 3), 55)
+    x1 = _inputs(kind, (b, c1, h, w_), (1, 1, 1, 1), 56)[0]
+    gy = torch.randn(b, co, h, w_, generator=g)
+    cat = torch.cat([TF.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1)
+    y64, dc64, dw64 = _reference(cat, wt, gy, 1, 1, torch.float64)
+    y32, dc32, dw32 = _reference(cat, wt, gy, 1, 1, torch.float32)
+    a0, a1, ww = nhwc(x0).requires_grad_(True), nhwc(x1).requires_grad_(True), wt.to(DEV).requires_grad_(True)
+    y = F.conv2d(a0, ww, x1=a1, pad=1, up0=True)
+    assert _last() == "conv_halo3_kernel", _last()
+    y.backward(nhwc(gy))
+    assert l2(nchw(y.detach(), co), y64) <= 3 * l2(y32, y64) + 1e-9
+    d1_64, d1_32 = dc64[:, c0:], dc32[:, c0:]
+    assert l2(nchw(a1.grad, c1), d1_64) <= 4 * l2(d1_32, d1_64) + 1e-9
+    up_t = lambda d: d[:, :c0].reshape(b, c0, h // 2, 2, w_ // 2, 2).sum((3, 5))      # noqa: E731  transpose of nearest x2
+    assert l2(nchw(a0.grad, c0), up_t(dc64)) <= 4 * l2(up_t(dc32), up_t(dc64)) + 1e-9
+    assert l2(ww.grad.cpu(), dw64) <= 4 * l2(dw32, dw64) + 1e-9
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide", "cancel"])
+@pytest.mark.parametrize("in_ch", [3, 6])
+def test_split_stem_forward_and_weight_gradient(in_ch, kind):
+    """ResNet conv1 (7x7 / 2 / 3) in its double-pixel form: split forward with 16-channel K-steps and `wgrad_stem74s_kernel`."""
+    F = _F()
+    b, h, w_ = 4, 128, 256
+    x, wt, g = _inputs(kind, (b, in_ch, h, w_), (64, in_ch, 7, 7), 91 + in_ch)
+    gy = torch.randn(b, 64, h // 2, w_ // 2, generator=g)
+    y64, _, dw64 = _reference(x, wt, gy, 2, 3, torch.float64)
+    y32, _, dw32 = _reference(x, wt, gy, 2, 3, torch.float32)
+    frames = [x[:, i:i + 3].contiguous().to(DEV) for i in range(0, in_ch, 3)]
+    xin = F.images_to_nhwc(frames, 8, F.STEM_XPAD)
+    ww = wt.to(DEV).requires_grad_(True)
+    y = F.stem_conv2d(xin, ww)
+    assert _last() == "conv_igemm_kernel<split3,bk16>", _last()
+    y.backward(nhwc(gy))
+    assert _last() == "wgrad_stem74s_kernel", _last()
+    assert l2(nchw(y.detach(), 64), y64) <= 3 * l2(y32, y64) + 1e-9
+    assert l2(ww.grad.cpu(), dw64) <= 4 * l2(dw32, dw64) + 1e-9
