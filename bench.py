@@ -253,6 +253,10 @@ def main():
     net, cfg = build(device, enc, args.height, args.width, args.mode, (384, 1408) if args.yaml_faithful else None)
     data, n_images = make_data(args.mode, args.height, args.width, device, rank, per_gpu, args.yaml_faithful, world)
     runner = StepRunner(net, cfg, args.mode, world)
+    if world > 1 and args.mode == "adapt" and per_gpu == 4 and not args.yaml_faithful:
+        # BASELINE configs[3]: the ranks hold different numbers of target / replay items -> count-aware SyncBN and loss means
+        splits = [adapt_split(per_gpu, r, world) for r in range(world)]
+        runner.set_key_counts({k: [sp[i] for sp in splits] for i, k in enumerate(("target", "target_replay", "source", "cut_mixup"))}, rank)
     if world > 1:
         from codeps_amd.distributed import SyncBatchNormReducer
         red = SyncBatchNormReducer()

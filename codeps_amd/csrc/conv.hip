@@ -1893,14 +1893,24 @@ struct SmallPlan { bool ok, stem, halo64; int mt, nt, ci_chunks, co_groups, tile
 
 // Halo-tile weight gradient on the bf16 matrix cores with 3-piece operands (wgrad_halo64s_kernel); CODEPS_WGRAD_SPLIT=0 or
 // CODEPS_SPLIT != 3 selects the f32-MFMA kernel.
+// Operand arithmetic of the conv engine: 3 (default) = exact 3-way bf16 split on the bf16 MFMA, 0 = f32 MFMA, 2 = two pieces
+// (experiments only).  Initialised from CODEPS_SPLIT; codeps_conv2d_set_arith switches it at run time (A/B runs and the
+// precision tests, which compare the split kernels with the f32-MFMA kernels on the same tensors in one process).
+static int g_split_np = -1;
+static int split_pieces() {
+    if (g_split_np < 0) g_split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
+    return g_split_np;
+}
+
 static bool wgrad_split_on() {
-    static const bool on = (getenv("CODEPS_WGRAD_SPLIT") ? atoi(getenv("CODEPS_WGRAD_SPLIT")) != 0 : true) &&
-                           (getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) == 3 : true);
+    static const bool env_on = getenv("CODEPS_WGRAD_SPLIT") ? atoi(getenv("CODEPS_WGRAD_SPLIT")) != 0 : true;
+    const bool on = env_on && split_pieces() == 3;
     return on;
 }
 // channel tiles (64 x 64) a layer must have for the halo kernel: the split kernel also takes single-tile 64 -> 64 layers
 static int halo_min_tiles() {
-    static const int v = getenv("CODEPS_HALO_MIN_TILES") ? atoi(getenv("CODEPS_HALO_MIN_TILES")) : (wgrad_split_on() ? 1 : 2);
+    static const int env_v = getenv("CODEPS_HALO_MIN_TILES") ? atoi(getenv("CODEPS_HALO_MIN_TILES")) : 0;
+    const int v = env_v ? env_v : (wgrad_split_on() ? 1 : 2);
     return v;
 }
 
@@ -1938,7 +1948,8 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
         const int total = d->batch * s.tiles_x * s.tiles_y;
         // f32 kernel: 228 VGPRs -> 2 blocks per CU: exactly one balanced round of <= 512 blocks (measured: 512 -> 54.8 ms/step,
         // 448 -> 55.7, 576 -> 56.8); split kernel: 82 KB of LDS -> 1 block per CU, one round of 256 (256 -> 45.9, 512 -> 46.2, 768 -> 46.9)
-        static const int halo_blocks = getenv("CODEPS_HALO_BLOCKS") ? atoi(getenv("CODEPS_HALO_BLOCKS")) : (wgrad_split_on() ? 256 : 512);   // env: tuning experiments only
+        static const int env_halo_blocks = getenv("CODEPS_HALO_BLOCKS") ? atoi(getenv("CODEPS_HALO_BLOCKS")) : 0;   // env: tuning experiments only
+        const int halo_blocks = env_halo_blocks ? env_halo_blocks : (wgrad_split_on() ? 256 : 512);
         const int want = std::max(1, halo_blocks / (s.ci_chunks * s.co_groups));
         s.tiles_per_block = std::max(2, cdiv(total, want));
         s.nblk = cdiv(total, s.tiles_per_block);
@@ -2038,8 +2049,8 @@ static int check_conv(const codeps_conv_desc* d, const char* who) {
     return CODEPS_OK;
 }
 
-// name of the kernel variant the last conv entry point of this thread launched (tests select variants by shape and check it)
-static thread_local const char* g_last_kernel = "";
+// name of the kernel variant the last conv entry point launched (tests select variants by shape and check it)
+static const char* volatile g_last_kernel = "";      // process-wide on purpose: autograd runs backward launches on its own thread
 
 static ConvP make_convp(const codeps_conv_desc* d) {
     ConvP p;
@@ -2208,7 +2219,7 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
     // product error ~6e-9 relative, below fp32 rounding (tools/split_precision_study.py), 192 instead of 512 MFMA cycles per
     // 16-deep chunk.  0: v_mfma_f32_32x32x2_f32.  2: two pieces / three products, ~4e-6 relative: faster still but NOT inside this
     // repo's parity bar (6 network / trunk tests fail) -- experiments only.
-    static const int split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
+    const int split_np = split_pieces();
     static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;          // tuning experiments only
 #define IG(WM, WN, TM, TN)                                                                          \
     do {                                                                                            \
@@ -2284,7 +2295,7 @@ extern "C" size_t codeps_conv2d_packed_weight_floats(int out_c_pad, int in_c_pad
 // 1 = data gradient w.r.t. `source`, 2 = weight gradient (3 for the halo-tile layers, else 0).  Used by bench.py to price each launch
 // against the right peak.
 static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
-    static const int split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
+    const int split_np = split_pieces();
     static const int force_bk = getenv("CODEPS_FORCE_BK") ? atoi(getenv("CODEPS_FORCE_BK")) : 0;
     static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;
     if (split_np != 2 && split_np != 3) return 0;
@@ -2408,6 +2419,12 @@ extern "C" size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d)
 }
 
 extern "C" const char* codeps_conv2d_last_kernel(void) { return g_last_kernel; }
+
+extern "C" int codeps_conv2d_set_arith(int pieces) {
+    const int prev = split_pieces();
+    if (pieces == 0 || pieces == 2 || pieces == 3) g_split_np = pieces;
+    return prev;
+}
 
 extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float* x1, const float* dz, float* dw_oihw,
                                    int out_c_real, int in_c_real, int accumulate, void* workspace, size_t workspace_bytes,

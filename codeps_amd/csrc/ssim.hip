@@ -5,6 +5,11 @@
 // (12 B read, 16 B written) + one gather pass (9 x 16 B from L2 + 8 B read, 8 B written).
 #include "common.h"
 
+// The local variances are differences of nearly equal numbers (E[x^2] - mu^2 against C2 = 9e-4): a fused multiply-add in
+// place of the reference's separately rounded products moves the result by 1e-5.  No contraction in this file -- every
+// product and sum is rounded like the ATen ops it mirrors (x ** 2, avg_pool2d = sequential sum / 9, mu_x ** 2, ...).
+#pragma clang fp contract(off)
+
 namespace {
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }

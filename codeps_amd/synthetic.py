@@ -44,11 +44,14 @@ def adapt_batch(h, w, device, seed, n_target=1, n_replay=3, n_source=2, n_mixup=
     384x1408 KITTI-360 crops)."""
     gen = torch.Generator(device=device).manual_seed(seed)
     th, tw = target_hw if target_hw is not None else (h, w)
-    data = {"target": triplet_item(n_target, th, tw, gen, device),
-            "target_replay": triplet_item(n_replay, th, tw, gen, device),
-            "source": triplet_item(n_source, h, w, gen, device, labels=True)}
-    mix = triplet_item(n_mixup, h, w, gen, device, labels=True)
-    data["cut_mixup"] = {"rgb": {0: mix["rgb"][0]}, "semantic": mix["semantic"]}
+    data = {}
+    for key, n, (hh, ww), lab in (("target", n_target, (th, tw), False), ("target_replay", n_replay, (th, tw), False),
+                                  ("source", n_source, (h, w), True)):
+        if n > 0:                  # a rank of a batch-sharded step may hold no item of a key (BASELINE configs[3])
+            data[key] = triplet_item(n, hh, ww, gen, device, labels=lab)
+    if n_mixup > 0:
+        mix = triplet_item(n_mixup, h, w, gen, device, labels=True)
+        data["cut_mixup"] = {"rgb": {0: mix["rgb"][0]}, "semantic": mix["semantic"]}
     return data, n_target + n_replay + n_source + n_mixup
 
 

@@ -100,8 +100,13 @@ int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pa
  * relative, below fp32 rounding); 0 = v_mfma_f32_*_f32 (16-column kernels, 16-channel K chunks, all weight gradients).
  * Reporting only (bench.py prices each launch against the matching peak). */
 int codeps_conv2d_arith(const codeps_conv_desc* d, int mode, int source);
-/* Name of the kernel variant the last conv2d_{fwd,dgrad,wgrad} call of this thread launched (diagnostics / tests). */
+/* Name of the kernel variant the last conv2d_{fwd,dgrad,wgrad} call of this PROCESS launched (diagnostics / tests; not
+ * synchronised: meaningful when one thread at a time drives the library, e.g. forward, then backward, then the query). */
 const char* codeps_conv2d_last_kernel(void);
+/* Process-wide operand arithmetic of the conv engine: 3 (default; CODEPS_SPLIT) = fp32 operands as three exact bf16 pieces on
+ * the bf16 MFMA, 0 = v_mfma_f32_32x32x2_f32, 2 = two pieces (experiments; outside the parity bar).  Returns the previous value;
+ * any other argument only queries.  Weight packs made under one arithmetic stay valid under the others (they carry both forms). */
+int codeps_conv2d_set_arith(int pieces);
 /* workspace (optional, may be NULL): scratch for split-K partial sums; codeps_conv2d_fwd_workspace_bytes(d) is the size
  * that enables it for this shape (0 = never splits).  Small-M / deep-K launches (B = 1 inference, 1/32-resolution
  * layers) are cut into K slices + a fixed-order finish pass so that they still fill the 256 CUs. */

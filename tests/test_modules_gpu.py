@@ -110,8 +110,9 @@ def test_encoder_against_oracle(layers, in_ch, train):
             if "running" in k:
                 close(v, ref_sd[k], 1e-5, 1e-4, k)
     else:       # the batched form CodepsNet.adapt uses for a frozen encoder (one forward over all keys' centre frames)
-        with torch.no_grad():
+        with torch.no_grad():           # (both without the autograd tape: eval BatchNorm folded into the conv epilogues)
             xb = x.to(DEV)
-            fb = enc.forward_batch([xb[:1], xb[1:]])
-        for i, (a, b) in enumerate(zip(fb, feats)):
-            assert torch.equal(a, b.detach()), f"forward_batch feat{i} differs from the plain forward"
+            fb, fp = enc.forward_batch([xb[:1], xb[1:]]), enc(xb)
+        for i, (a, b, c_) in enumerate(zip(fb, fp, feats)):
+            assert torch.equal(a, b), f"forward_batch feat{i} differs from the plain forward"
+            close(a, c_.detach(), 2e-5 * float(c_.detach().abs().max()), 0, f"folded vs separate BatchNorm, feat{i}")

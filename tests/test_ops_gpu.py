@@ -320,9 +320,27 @@ def test_sync_bn_combine_matches_parallel_variance():
     mean, var, invstd = (torch.empty(ng, c, device=DEV) for _ in range(3))
     rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
     counts = (ctypes.c_float * ng)(*[float(per * world)] * ng)
-    check(lib().codeps_bn_sync_combine(ptr(gathered), world, ng, counts, c, c, 1e-5, 0.1, ptr(rm), ptr(rv), ptr(mean), ptr(var), ptr(invstd),
+    check(lib().codeps_bn_sync_combine(ptr(gathered), world, ng, counts, None, c, c, 1e-5, 0.1, ptr(rm), ptr(rv), ptr(mean), ptr(var), ptr(invstd),
                                        stream_ptr()), "codeps_bn_sync_combine")
     assert rel_err(mean.cpu(), ref_mean) < 1e-5 and rel_err(var.cpu(), ref_var) < 1e-5
+    # unequal shards (BASELINE configs[3]): rank r holds r + 1 items of group 0 and (2, 0, 1) items of group 1
+    items = [[1, 2], [2, 0], [3, 1]]
+    u_shards = [[torch.randn(items[r][gi] * 7, c, generator=g) * (1 + r) + gi for gi in range(ng)] for r in range(world)]
+    pk = torch.zeros(world, 2, ng, c)
+    for r in range(world):
+        for gi in range(ng):
+            if items[r][gi]:
+                pk[r, 0, gi], pk[r, 1, gi] = u_shards[r][gi].double().mean(0).float(), u_shards[r][gi].double().var(0, unbiased=False).float()
+            else:
+                pk[r, :, gi] = float("nan")                  # an empty slot must be ignored, whatever it holds
+    allg = [torch.cat([u_shards[r][gi] for r in range(world)]).double() for gi in range(ng)]
+    rc = (ctypes.c_float * (world * ng))(*[float(items[r][gi] * 7) for r in range(world) for gi in range(ng)])
+    gc = (ctypes.c_float * ng)(*[float(a.shape[0]) for a in allg])
+    m2, v2, i2 = (torch.empty(ng, c, device=DEV) for _ in range(3))
+    check(lib().codeps_bn_sync_combine(ptr(pk.to(DEV)), world, ng, gc, rc, c, c, 1e-5, 0.1, None, None, ptr(m2), ptr(v2), ptr(i2), stream_ptr()),
+          "codeps_bn_sync_combine")
+    assert rel_err(m2.cpu(), torch.stack([a.mean(0) for a in allg])) < 1e-5
+    assert rel_err(v2.cpu(), torch.stack([a.var(0, unbiased=False) for a in allg])) < 1e-5
     assert rel_err(invstd.cpu(), 1.0 / torch.sqrt(ref_var + 1e-5)) < 1e-5
     erm, erv = torch.zeros(c).double(), torch.ones(c).double()
     n = per * world
