@@ -368,7 +368,8 @@ def main():
                           ("CODEPS_SPLIT=" + os.environ.get("CODEPS_SPLIT", "3") + " (non-default arithmetic, see codeps_amd/csrc/conv.hip)"),
             "config": {"workload": workload,
                        "global_batch": n_images * world, "parallelism": f"dp{world}", "launch": "hip-graph" if graph is not None else "eager",
-                       "grad_allreduce_mb": round(runner.grad_bytes / 1e6, 1)},
+                       "grad_allreduce_mb": round(runner.grad_bytes / 1e6, 1),
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
         }
         if roof is not None:
             line["roofline"] = roof

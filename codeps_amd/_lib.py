@@ -63,6 +63,9 @@ SIGNATURES = {
     "codeps_photometric_bwd": (c_int, [POINTER(PhotometricDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_pack_weights": (c_int, [I, I, I, I, I, I, P, P, P, P]),
     "codeps_conv2d_packed_weight_floats": (c_size_t, [I, I, I, I, I]),
+    "codeps_pack_item_bytes": (c_size_t, []),
+    "codeps_pack_item_fill": (LL, [P, P, P, I, I, I, I, I, I, I, LL]),
+    "codeps_conv2d_pack_weights_multi": (c_int, [P, I, LL, P]),
     "codeps_conv2d_arith": (c_int, [POINTER(ConvDesc), I, I]),
     "codeps_conv2d_last_kernel": (c_char_p, []),
     "codeps_conv2d_set_arith": (c_int, [I]),
@@ -104,8 +107,12 @@ SIGNATURES = {
     "codeps_semantic_loss_bwd": (c_int, [P, I, I, P, P, P, I, ctypes.c_ulonglong, LL, c_double, P, P, P, c_size_t, P]),
     "codeps_instance_loss_fwd": (c_int, [I, P, I, I, P, P, I, I, I, P, P, c_size_t, P]),
     "codeps_instance_loss_bwd": (c_int, [I, P, I, I, P, P, I, I, I, P, P, P]),
-    "codeps_pose_fwd": (c_int, [P, I, I, I, I, P, P, P]),
-    "codeps_pose_bwd": (c_int, [P, P, I, I, I, I, P, P]),
+    "codeps_pose_fwd": (c_int, [P, I, I, I, ctypes.c_ulonglong, P, P, P]),
+    "codeps_pose_bwd": (c_int, [P, P, I, I, I, ctypes.c_ulonglong, P, P]),
+    "codeps_stem_weight_fwd": (c_int, [P, I, I, P, P]),
+    "codeps_stem_weight_bwd": (c_int, [P, I, I, I, P, P]),
+    "codeps_guda_weight_fwd": (c_int, [P, I, I, I, P, P, P]),
+    "codeps_guda_weight_bwd": (c_int, [P, I, I, I, P, I, P, P]),
     "codeps_reflect_pad_fold": (c_int, [P, I, I, I, I, I, P, P]),
     "codeps_panoptic_workspace_bytes": (c_size_t, [I, I, I]),
     "codeps_panoptic_fusion": (c_int, [P, P, P, I, I, I, ctypes.c_ulonglong, I, I, c_float, I, I, P, P, P, P, P, c_size_t, P]),

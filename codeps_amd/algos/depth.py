@@ -169,10 +169,10 @@ class DepthAlgo:
             if sum(b1 - b0 for b0, b1 in mine) != hi - lo:
                 continue                                    # not contiguous: fall back to per-key calls
             depth_all, disp_all = depth_head([f[lo:hi] for f in feats_b], return_disparity=True)
-            for k in keys:
-                if k in slices:
-                    b0, b1 = slices[k]
-                    pre[k] = (depth_all[b0 - lo:b1 - lo], disp_all[b0 - lo:b1 - lo])
+            ks = sorted((k for k in keys if k in slices), key=lambda k_: slices[k_][0])
+            bounds = [(slices[k][0] - lo, slices[k][1] - lo) for k in ks]
+            for k, dpt, dsp in zip(ks, F.split_batch(depth_all, bounds), F.split_batch(disp_all, bounds)):
+                pre[k] = (dpt, dsp)
         recon, smth, depth_pred, transformations, num_images = {}, {}, {}, {}, {k: 0 for k in keys}
         # pose nets of all keys of one resolution in ONE batched forward with per-call BatchNorm groups (exactly the
         # statistics of the reference's 2 x len(keys) separate calls, in the reference's call order)

@@ -96,8 +96,9 @@ class SemanticSegAlgo:
             if sum(b1 - b0 for (b0, b1), _ in mine) != hi - lo:
                 continue
             base = semantic_head.forward_nhwc([f[lo:hi] for f in feats_b])
-            for (b0, b1), k in mine:
-                probs[k] = F.to_nchw(base[b0 - lo:b1 - lo], semantic_head.num_classes)
+            parts = F.split_batch(base, [(b0 - lo, b1 - lo) for (b0, b1), _ in mine])
+            for ((b0, b1), k), part in zip(mine, parts):
+                probs[k] = F.to_nchw(part, semantic_head.num_classes)
         for key in sup:
             p = probs[key] if key in probs else semantic_head(feats[key][0])
             if key == 'source':

@@ -2027,6 +2027,53 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     }
 }
 
+// All trainable weights of a step in ONE launch (instead of one pack + up to two split launches per layer and step): `items`
+// is a device table, one entry per (parameter, pack kind); a thread produces 8 consecutive k of one pack row -- the fp32 pack
+// (32 contiguous bytes) and, when the row takes the split-operand kernel, its three bf16 pieces (3 x 16 bytes) -- straight
+// from the OIHW parameter.  Blocks find their item by bisection over the items' first work-group index.
+struct PackItem {
+    const float* w;              // OIHW parameter
+    float* out;                  // fp32 pack [rows][taps * cols] (+ the split copy behind it when `split`)
+    int co_real, ci_real, taps, rows, cols;      // rows x cols = padded (Co x Ci) for the forward pack, (Ci x Co) for the dgrad pack
+    int dgrad, split;
+    long long first_group, groups;               // work in units of 256 threads x 8 k
+};
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem* __restrict__ items, int n_items) {
+    int lo = 0, hi = n_items - 1;
+    const long long g = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_group <= g) lo = mid; else hi = mid - 1;
+    }
+    const PackItem it = items[lo];
+    const long long wrow = (long long)it.taps * it.cols;                   // k extent of a pack row
+    const long long chunk = (g - it.first_group) * 256 + threadIdx.x;      // 8 consecutive k
+    const long long total = (long long)it.rows * wrow;
+    if (chunk * 8 >= total) return;
+    const int row = (int)(chunk * 8 / wrow);
+    const int k0 = (int)(chunk * 8 % wrow), tap = k0 / it.cols, c0 = k0 % it.cols;     // cols % 8 == 0: a chunk stays inside one tap
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = c0 + e;
+        const int co = it.dgrad ? col : row, ci = it.dgrad ? row : col;
+        v[e] = (co < it.co_real && ci < it.ci_real) ? it.w[((size_t)co * it.ci_real + ci) * it.taps + tap] : 0.f;
+    }
+    const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    float* dst = it.out + chunk * 8;
+    *reinterpret_cast<f32x4*>(dst) = a;
+    *reinterpret_cast<f32x4*>(dst + 4) = b;
+    if (it.split) {
+        u16x4 pl[3], ph[3];
+        split_bf16<3>(a, pl);
+        split_bf16<3>(b, ph);
+        unsigned short* sp = reinterpret_cast<unsigned short*>(it.out + total) + (chunk / 4) * 96 + (chunk % 4) * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(sp + q * 32) = pack8(pl[q], ph[q]);
+    }
+}
+
 // ---------------------------------------------------------------------------------- host side
 static int check_conv(const codeps_conv_desc* d, const char* who) {
     CODEPS_REQUIRE(d != nullptr, CODEPS_ERR_ARG, "%s: null descriptor", who);
@@ -2278,6 +2325,35 @@ extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, i
     if (w_dgrad && split_tail_ok(out_c_pad, kh * kw))
         hipLaunchKernelGGL(split_pack_kernel, dim3(sgrid), dim3(256), 0, (hipStream_t)stream, w_dgrad, total / 8, reinterpret_cast<unsigned short*>(w_dgrad + total));
     CODEPS_CHECK_LAUNCH("pack_weights_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" size_t codeps_pack_item_bytes(void) { return sizeof(PackItem); }
+
+// Fills ONE host-side table entry (the caller copies the table to the device once and keeps it); returns the number of
+// 256-thread work groups the entry needs, 0 on bad arguments.
+extern "C" long long codeps_pack_item_fill(void* item, const float* w_oihw, float* out, int out_c, int in_c, int kh, int kw, int out_c_pad,
+                                           int in_c_pad, int dgrad, long long first_group) {
+    if (!item || !w_oihw || !out || out_c <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || out_c_pad < out_c || in_c_pad < in_c ||
+        (out_c_pad % 8) != 0 || (in_c_pad % 8) != 0) {
+        codeps_set_error("pack_item_fill: bad arguments");
+        return 0;
+    }
+    PackItem it;
+    it.w = w_oihw; it.out = out; it.co_real = out_c; it.ci_real = in_c; it.taps = kh * kw; it.dgrad = dgrad ? 1 : 0;
+    it.rows = dgrad ? in_c_pad : out_c_pad; it.cols = dgrad ? out_c_pad : in_c_pad;
+    it.split = split_tail_ok(it.cols, it.taps) ? 1 : 0;
+    it.first_group = first_group;
+    const long long total = (long long)it.rows * it.cols * it.taps;
+    it.groups = (total / 8 + 255) / 256;
+    memcpy(item, &it, sizeof(it));
+    return it.groups;
+}
+
+extern "C" int codeps_conv2d_pack_weights_multi(const void* items_device, int n_items, long long total_groups, codeps_stream_t stream) {
+    CODEPS_REQUIRE(items_device && n_items > 0 && total_groups > 0 && total_groups < (1ll << 31), CODEPS_ERR_ARG, "pack_weights_multi: bad arguments");
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_groups), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_device, n_items);
+    CODEPS_CHECK_LAUNCH("pack_weights_multi_kernel");
     return CODEPS_OK;
 }
 

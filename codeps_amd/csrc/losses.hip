@@ -303,11 +303,12 @@ __global__ __launch_bounds__(256) void inst_bwd_kernel(int kind, const float* __
 
 // ================================================================================ pose matrix
 // feat [B][HW][Cp] -> vec = 0.01 * mean over HW of channels 0..5 -> T [B][16]
-__global__ __launch_bounds__(256) void pose_fwd_kernel(const float* __restrict__ feat, int HW, int Cp, int invert, float* __restrict__ vec,
-                                                       float* __restrict__ T) {
+__global__ __launch_bounds__(256) void pose_fwd_kernel(const float* __restrict__ feat, int HW, int Cp, unsigned long long invert_mask,
+                                                       float* __restrict__ vec, float* __restrict__ T) {
     __shared__ float red[4];
     __shared__ float v[6];
     const int b = blockIdx.x;
+    const bool invert = (invert_mask >> (b & 63)) & 1ull;
     for (int c = 0; c < 6; ++c) {
         float a = 0.f;
         for (int i = threadIdx.x; i < HW; i += 256) a += feat[((size_t)b * HW + i) * Cp + c];
@@ -335,10 +336,11 @@ __global__ __launch_bounds__(256) void pose_fwd_kernel(const float* __restrict__
     M[12] = 0.f; M[13] = 0.f; M[14] = 0.f; M[15] = 1.f;
 }
 
-__global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__ dT, const float* __restrict__ vec, int HW, int Cp, int invert,
-                                                       float* __restrict__ dfeat) {
+__global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__ dT, const float* __restrict__ vec, int HW, int Cp,
+                                                       unsigned long long invert_mask, float* __restrict__ dfeat) {
     __shared__ float dv[6];
     const int b = blockIdx.x;
+    const bool invert = (invert_mask >> (b & 63)) & 1ull;
     if (threadIdx.x == 0) {
         const float* v = vec + b * 6;
         const float* dM = dT + b * 16;
@@ -572,17 +574,20 @@ extern "C" int codeps_instance_loss_bwd(int kind, const float* pred, int c, int 
     return CODEPS_OK;
 }
 
-extern "C" int codeps_pose_fwd(const float* feat, int batch, int hw, int c_pad, int invert, float* vec6, float* T, codeps_stream_t stream) {
+extern "C" int codeps_pose_fwd(const float* feat, int batch, int hw, int c_pad, unsigned long long invert_mask, float* vec6, float* T,
+                               codeps_stream_t stream) {
     CODEPS_REQUIRE(feat && vec6 && T && batch > 0 && hw > 0 && c_pad >= 6, CODEPS_ERR_ARG, "pose_fwd: bad arguments");
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, feat, hw, c_pad, invert, vec6, T);
+    CODEPS_REQUIRE(batch <= 64 || invert_mask == 0 || invert_mask == ~0ull, CODEPS_ERR_ARG, "pose_fwd: a per-item invert mask covers 64 items");
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, feat, hw, c_pad, invert_mask, vec6, T);
     CODEPS_CHECK_LAUNCH("pose_fwd_kernel");
     return CODEPS_OK;
 }
 
-extern "C" int codeps_pose_bwd(const float* grad_T, const float* vec6, int batch, int hw, int c_pad, int invert, float* grad_feat,
-                               codeps_stream_t stream) {
+extern "C" int codeps_pose_bwd(const float* grad_T, const float* vec6, int batch, int hw, int c_pad, unsigned long long invert_mask,
+                               float* grad_feat, codeps_stream_t stream) {
     CODEPS_REQUIRE(grad_T && vec6 && grad_feat && batch > 0 && hw > 0 && c_pad >= 6, CODEPS_ERR_ARG, "pose_bwd: bad arguments");
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, grad_T, vec6, hw, c_pad, invert, grad_feat);
+    CODEPS_REQUIRE(batch <= 64 || invert_mask == 0 || invert_mask == ~0ull, CODEPS_ERR_ARG, "pose_bwd: a per-item invert mask covers 64 items");
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, grad_T, vec6, hw, c_pad, invert_mask, grad_feat);
     CODEPS_CHECK_LAUNCH("pose_bwd_kernel");
     return CODEPS_OK;
 }

@@ -251,14 +251,85 @@ def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
     return wf, wd
 
 
+_pack_table = {"dev": None, "n": 0, "groups": 0, "entries": [], "epoch": -1}
+
+
+def build_pack_table():
+    """Gather the persistent packs of all live trainable nn.Parameters (the entries `pack_weights` has created so far) into ONE
+    device table for `refresh_weight_packs`.  Call after a first step has touched every layer; packs created later, and the
+    packs of per-step temporaries (re-laid-out stem / GUDA tap weights), keep the one-by-one path."""
+    live = []
+    for key, ent in list(_pack_cache_train.items()):
+        w = ent[0]()
+        if w is None or not isinstance(w, torch.nn.Parameter) or not w.is_contiguous() or w.dtype != torch.float32:
+            continue
+        live.append((key, ent, w))
+    _pack_table.update(dev=None, n=0, groups=0, entries=[], epoch=-1)
+    if not live:
+        return 0
+    item = lib().codeps_pack_item_bytes()
+    n_items = sum(1 + (e[4] is not None) for _k, e, _w in live)
+    host = ctypes.create_string_buffer(item * n_items)
+    base = ctypes.addressof(host)
+    i, groups = 0, 0
+    for (key, ent, w) in live:
+        co, ci, kh, kw = w.shape
+        _id, cop, cip = key
+        for dgrad, buf in ((0, ent[3]), (1, ent[4])):
+            if buf is None:
+                continue
+            g = lib().codeps_pack_item_fill(ctypes.c_void_p(base + i * item), ptr(w), ptr(buf), co, ci, kh, kw, cop, cip, dgrad, groups)
+            if g <= 0:
+                raise CodepsHipError("codeps_pack_item_fill: " + lib().codeps_last_error().decode())
+            groups += g
+            i += 1
+    dev = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(live[0][2].device)
+    _pack_table.update(dev=dev, n=n_items, groups=groups, epoch=-1,
+                       entries=[(e, w.data_ptr(), weakref.ref(w), e[4] is not None) for _k, e, w in live])
+    _pack_table["builds"] = _pack_table.get("builds", 0) + 1
+    return n_items
+
+
+def refresh_weight_packs():
+    """Re-fill every pack of the table for the current weights epoch in ONE launch (no-op when they are current).  Falls back
+    to the one-by-one path (drops the table) as soon as a parameter of the table died or moved."""
+    t = _pack_table
+    if t["dev"] is None or t["epoch"] == _weights_epoch[0]:
+        return
+    for ent, dptr, ref, had_wd in t["entries"]:
+        w = ref()
+        if w is None or w.data_ptr() != dptr or ent[0]() is not w or (ent[4] is not None) != had_wd:
+            t.update(dev=None, n=0, groups=0, entries=[], epoch=-1)      # (a pack buffer the table does not know must not be stamped)
+            return
+    check(lib().codeps_conv2d_pack_weights_multi(ptr(t["dev"]), t["n"], t["groups"], stream_ptr()), "codeps_conv2d_pack_weights_multi")
+    t["epoch"] = _weights_epoch[0]
+    for ent, _dptr, ref, _had in t["entries"]:
+        ent[2] = (ref()._version, _weights_epoch[0])
+
+
+_padvec_cache = {}
+
+
 def _pad_vec(v, n):
+    """Per-channel vector zero-padded to n entries.  A padded copy lives in a persistent buffer per source tensor and is
+    re-filled by ONE copy when the source may have changed (tensor version / weights epoch): no per-call zeros + slice copy."""
     if v is None:
         return None
+    src = v
     v = _f32c(v.detach())
     if v.numel() == n:
         return v
+    key = (id(src), n)
+    stamp = (v.data_ptr(), src._version, _weights_epoch[0])
+    hit = _padvec_cache.get(key)
+    if hit is not None and hit[4]() is src and hit[0] == stamp[0] and hit[3].device == v.device:
+        if (hit[1], hit[2]) != stamp[1:]:
+            hit[3][:v.numel()].copy_(v)
+            hit[1], hit[2] = stamp[1], stamp[2]
+        return hit[3]
     out = torch.zeros(n, dtype=torch.float32, device=v.device)
     out[:v.numel()] = v
+    _padvec_cache[key] = [stamp[0], stamp[1], stamp[2], out, _weak(src, _padvec_cache, key)]
     return out
 
 
@@ -452,23 +523,49 @@ def conv2d(x0, weight, bias=None, *, x1=None, scale=None, shift=None, residual=N
 _stem_cache = {}
 
 
+class _StemWeight(torch.autograd.Function):
+    """conv1 weight -> double-pixel form, one launch each way (C ABI: codeps_stem_weight_{fwd,bwd}); the gradient goes straight
+    into the flat gradient buffer when the step harness registered one for the parameter."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        w = _f32c(weight.detach())
+        co, ci = w.shape[:2]
+        out = torch.empty(co, 16, 7, 4, dtype=torch.float32, device=w.device)
+        check(lib().codeps_stem_weight_fwd(ptr(w), co, ci, ptr(out), stream_ptr()), "codeps_stem_weight_fwd")
+        ctx.meta = (co, ci)
+        ctx.sink = grad_sink(weight) if weight.requires_grad else None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        co, ci = ctx.meta
+        sink = ctx.sink
+        gw = sink if sink is not None else torch.empty(co, ci, 7, 7, dtype=torch.float32, device=g.device)
+        check(lib().codeps_stem_weight_bwd(ptr(g.contiguous()), co, ci, 1 if sink is not None else 0, ptr(gw), stream_ptr()),
+              "codeps_stem_weight_bwd")
+        return None if sink is not None else gw
+
+
 def stem_weight(weight):
     """ResNet conv1 weight [co, ci <= 8, 7, 7] -> its double-pixel form [co, 16, 7, 4]:
     W'[o][p * 8 + c][ky][j] = W[o][c][ky][2 j + p - 1]  (tap 2j + p - 1 = -1 and channels >= ci are zero).
-    Differentiable (pad / view / permute), cached for frozen weights."""
+    Differentiable, cached for frozen weights."""
     co, ci, kh, kw = weight.shape
     if (kh, kw) != (7, 7) or ci > 8:
         raise _lib.CodepsHipError("stem_weight: expects a 7x7 kernel over <= 8 input channels")
+    require_cuda(weight)
     frozen = not (weight.requires_grad and torch.is_grad_enabled())
     if frozen:
         hit = _stem_cache.get(id(weight))
-        if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
+        if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version, _weights_epoch[0] if weight.requires_grad else 0):
             return hit[2]
-    w8 = torch.nn.functional.pad(weight if not frozen else weight.detach(), (1, 0, 0, 0, 0, 8 - ci))      # [co, 8, 7, 8]: kx' = kx + 1
-    wp = w8.view(co, 8, 7, 4, 2).permute(0, 4, 1, 2, 3).reshape(co, 16, 7, 4)
-    if frozen:
-        _stem_cache[id(weight)] = (_weak(weight, _stem_cache, id(weight)), (weight.data_ptr(), weight._version), wp)
-    return wp
+        with torch.no_grad():
+            wp = _StemWeight.apply(weight)
+        _stem_cache[id(weight)] = (_weak(weight, _stem_cache, id(weight)),
+                                   (weight.data_ptr(), weight._version, _weights_epoch[0] if weight.requires_grad else 0), wp)
+        return wp
+    return _StemWeight.apply(weight)
 
 
 def stem_conv2d(x, weight, *, scale=None, shift=None, act=None):
@@ -743,11 +840,9 @@ class _BilinearConcat(torch.autograd.Function):
         off, geoms = 0, []
         for x in xs:
             _, h, w, c = x.shape
-            if (h, w) == (out_h, out_w):
-                out[..., off:off + c] = x            # same size: plain strided copy
-            else:
-                check(lib().codeps_bilinear_fwd(ptr(x), b, h, w, c, out_h, out_w, int(align), ptr(out), ctot, off,
-                                                stream_ptr()), "codeps_bilinear_fwd")
+            # (same size: the interpolation is the identity under both align_corners conventions -- the kernel copies)
+            check(lib().codeps_bilinear_fwd(ptr(x), b, h, w, c, out_h, out_w, int(align), ptr(out), ctot, off,
+                                            stream_ptr()), "codeps_bilinear_fwd")
             geoms.append((h, w, c, off))
             off += c
         ctx.geoms, ctx.meta = geoms, (b, out_h, out_w, int(align), ctot)
@@ -813,6 +908,41 @@ class _GudaGather(torch.autograd.Function):
         return (dout if ctx.needs_input_grad[0] else None, *grads)
 
 
+class _GudaWeights(torch.autograd.Function):
+    """semconv_guda weight [n, Ct, 3, 3] -> (taps_k [144, c_k] per coarse branch ..., base [n, c_f, 3, 3]) and back
+    (C ABI: codeps_guda_weight_{fwd,bwd})."""
+
+    @staticmethod
+    def forward(ctx, weight, chans):
+        w = _f32c(weight.detach())
+        n, ct = w.shape[:2]
+        nc = len(chans) - 1
+        sizes = [144 * c for c in chans[:-1]] + [n * chans[-1] * 9]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=w.device)
+        outs, off = [], 0
+        for i, sz in enumerate(sizes):
+            outs.append(flat[off:off + sz].view(144, chans[i]) if i < nc else flat[off:off + sz].view(n, chans[-1], 3, 3))
+            off += sz
+        ca = (ctypes.c_int * (nc + 1))(*chans)
+        pa = (ctypes.c_void_p * (nc + 1))(*[o.data_ptr() for o in outs])
+        check(lib().codeps_guda_weight_fwd(ptr(w), n, ct, nc, ca, pa, stream_ptr()), "codeps_guda_weight_fwd")
+        ctx.meta = (n, ct, nc, tuple(chans))
+        ctx.sink = grad_sink(weight) if weight.requires_grad else None
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, ct, nc, chans = ctx.meta
+        gs = [None if g is None else g.contiguous() for g in gs]
+        dev = next(g for g in gs if g is not None).device
+        sink = ctx.sink
+        gw = sink if sink is not None else torch.empty(n, ct, 3, 3, dtype=torch.float32, device=dev)
+        ca = (ctypes.c_int * (nc + 1))(*chans)
+        pa = (ctypes.c_void_p * (nc + 1))(*[None if g is None else g.data_ptr() for g in gs])
+        check(lib().codeps_guda_weight_bwd(pa, n, ct, nc, ca, 1 if sink is not None else 0, ptr(gw), stream_ptr()), "codeps_guda_weight_bwd")
+        return (None if sink is not None else gw), None
+
+
 def guda_fusion(coarse, fine, weight, bias):
     """conv3x3(cat([bilinear_up(c) for c in coarse] + [fine], channel), weight, bias, padding=1) without the
     concatenated tensor (GUDA fusion, models/semantic_head.py:64-72).  Convolution and up-sampling are both linear and the
@@ -822,16 +952,12 @@ def guda_fusion(coarse, fine, weight, bias):
     n = weight.shape[0]
     if n > 16 or weight.shape[-2:] != (3, 3):
         raise CodepsHipError("guda_fusion: expects a 3x3 convolution to <= 16 classes")
-    c0, ys = 0, []
-    for t in coarse:
-        ck = t.shape[-1]
-        taps = weight[:, c0:c0 + ck].permute(2, 3, 0, 1).reshape(9, n, ck)
-        taps = torch.nn.functional.pad(taps, (0, 0, 0, 16 - n)).reshape(144, ck, 1, 1)
-        ys.append(conv2d(t, taps))
-        c0 += ck
-    if c0 + fine.shape[-1] != weight.shape[1]:
+    chans = [t.shape[-1] for t in coarse] + [fine.shape[-1]]
+    if sum(chans) != weight.shape[1]:
         raise CodepsHipError("guda_fusion: channel counts of the branches do not add up to the weight's input channels")
-    base = conv2d(fine, weight[:, c0:].contiguous(), bias, pad=1)
+    parts = _GudaWeights.apply(weight, tuple(chans))            # ONE launch: per-branch tap matrices + the fine branch's block
+    ys = [conv2d(t, taps.view(144, ck, 1, 1)) for t, taps, ck in zip(coarse, parts[:-1], chans[:-1])]
+    base = conv2d(fine, parts[-1], bias, pad=1)
     return _GudaGather.apply(base, *ys)
 
 
@@ -971,9 +1097,9 @@ class _Pose(torch.autograd.Function):
         b, h, w, cp = feat.shape
         vec = torch.empty(b, 6, dtype=torch.float32, device=feat.device)
         T = torch.empty(b, 4, 4, dtype=torch.float32, device=feat.device)
-        check(lib().codeps_pose_fwd(ptr(feat), b, h * w, cp, int(invert), ptr(vec), ptr(T), stream_ptr()), "codeps_pose_fwd")
+        check(lib().codeps_pose_fwd(ptr(feat), b, h * w, cp, invert, ptr(vec), ptr(T), stream_ptr()), "codeps_pose_fwd")
         ctx.save_for_backward(vec)
-        ctx.meta = (b, h, w, cp, int(invert))
+        ctx.meta = (b, h, w, cp, invert)
         return T
 
     @staticmethod
@@ -986,8 +1112,51 @@ class _Pose(torch.autograd.Function):
 
 
 def pose_matrix(feat, invert=False):
-    """NHWC pose features [B,h,w,Cp] -> [B,4,4] (spatial mean * 0.01, frame 0, Rodrigues; models/pose_head.py:46-54)."""
-    return _Pose.apply(feat, bool(invert))
+    """NHWC pose features [B,h,w,Cp] -> [B,4,4] (spatial mean * 0.01, frame 0, Rodrigues; models/pose_head.py:46-54).
+    invert: bool for the whole batch, or a per-item sequence of bools (B <= 64): several reference-style calls in one launch."""
+    if isinstance(invert, (list, tuple)):
+        if len(invert) != feat.shape[0] or len(invert) > 64:
+            raise CodepsHipError("pose_matrix: one invert flag per item, at most 64 items")
+        mask = sum(1 << i for i, v in enumerate(invert) if v)
+    else:
+        mask = 0xFFFFFFFFFFFFFFFF if invert else 0
+    return _Pose.apply(feat, mask)
+
+
+class _SplitBatch(torch.autograd.Function):
+    """x -> (x[b0:b1] for every span) as views; the backward writes the spans' gradients into ONE buffer (a single cat launch)
+    instead of autograd's zeros + slice copy per span and an add per extra span."""
+
+    @staticmethod
+    def forward(ctx, x, bounds):
+        ctx.bounds, ctx.shape = bounds, tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        return tuple(x[b0:b1] for b0, b1 in bounds)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None, None
+        like = next(g for g in gs if g is not None)
+        covered, parts, pos = True, [], 0
+        for (b0, b1), g in zip(ctx.bounds, gs):
+            covered = covered and b0 == pos
+            pos = b1
+            parts.append(g if g is not None else torch.zeros((b1 - b0,) + ctx.shape[1:], dtype=like.dtype, device=like.device))
+        if covered and pos == ctx.shape[0]:
+            return torch.cat(parts, 0), None
+        out = torch.zeros(ctx.shape, dtype=like.dtype, device=like.device)       # overlapping / partial spans: accumulate
+        for (b0, b1), g in zip(ctx.bounds, gs):
+            if g is not None:
+                out[b0:b1] += g
+        return out, None
+
+
+def split_batch(x, bounds):
+    """Views x[b0:b1] for bounds = [(b0, b1), ...] along dim 0 with a single-launch backward when the spans tile the batch."""
+    if not x.requires_grad or not torch.is_grad_enabled():
+        return tuple(x[b0:b1] for b0, b1 in bounds)
+    return _SplitBatch.apply(x, tuple((int(a), int(b)) for a, b in bounds))
 
 
 # ---------------------------------------------------------------------------------------- losses

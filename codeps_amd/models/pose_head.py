@@ -42,7 +42,17 @@ class PoseHead(nn.Module):
         """One batched pass of the (batch-independent) convs, then one pose-matrix kernel per (b0, b1, invert) span:
         equivalent to calling forward() on every slice."""
         x = self._features(input_features)
-        return [F.pose_matrix(x[b0:b1], inv) for b0, b1, inv in spans]
+        b = x.shape[0]
+        flags, pos = [False] * b, 0
+        for b0, b1, inv in spans:
+            if b0 != pos:
+                return [F.pose_matrix(x[s0:s1], i) for s0, s1, i in spans]      # (spans that do not tile the batch: one launch each)
+            flags[b0:b1] = [bool(inv)] * (b1 - b0)
+            pos = b1
+        if pos != b or b > 64:
+            return [F.pose_matrix(x[s0:s1], i) for s0, s1, i in spans]
+        T = F.pose_matrix(x, flags)                  # all calls in ONE launch (per-item invert flags)
+        return list(F.split_batch(T, [(b0, b1) for b0, b1, _ in spans]))
 
     @staticmethod
     def transformation_from_parameters(axisangle: Tensor, translation: Tensor, invert: bool = False) -> Tensor:

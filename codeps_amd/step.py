@@ -153,6 +153,7 @@ class StepRunner:
     def forward_backward(self, data):
         F.set_noise_stream(self.noise_counter, self.seed_base)
         F.step_counter_add(self.noise_counter, 1)
+        F.refresh_weight_packs()                 # every trainable weight's packs in one launch (after the first step built the table)
         for g in self.groups:
             g.grad.zero_()
         if self.mode == "adapt":
@@ -168,6 +169,8 @@ class StepRunner:
             wts.append(float(w) * self.key_scale.get(k, 1.0))
         total = F.weighted_sum(terms, wts)
         total.backward()
+        if F._pack_table["dev"] is None and F._pack_table.get("builds", 0) < 8 and not torch.cuda.is_current_stream_capturing():
+            F.build_pack_table()                 # the first step created every layer's persistent pack buffers: table them
         return total.detach(), losses, result
 
     def optimizer_step(self, apply_ema=True):

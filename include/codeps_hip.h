@@ -93,6 +93,16 @@ typedef struct {
  * weight operand.  Buffers hold codeps_conv2d_packed_weight_floats(..., dgrad = 0 / 1) floats; codeps_conv2d_fwd / _dgrad
  * expect packs produced by this function. */
 size_t codeps_conv2d_packed_weight_floats(int out_c_pad, int in_c_pad, int kh, int kw, int dgrad);
+/* All weight packs of a step in ONE launch.  A table of codeps_pack_item_bytes()-sized entries, one per (parameter, pack
+ * kind), is filled on the HOST by codeps_pack_item_fill (first_group = running sum of the returned work-group counts; `out`
+ * = a buffer of codeps_conv2d_packed_weight_floats floats; dgrad 0 = forward pack, 1 = data-gradient pack), copied to the
+ * device once by the caller, and replayed every step by codeps_conv2d_pack_weights_multi: same bytes as
+ * codeps_conv2d_pack_weights writes, one kernel instead of up to three per parameter and kind. */
+size_t codeps_pack_item_bytes(void);
+long long codeps_pack_item_fill(void* item, const float* w_oihw, float* out, int out_c, int in_c, int kh, int kw,
+                                int out_c_pad, int in_c_pad, int dgrad, long long first_group);
+int codeps_conv2d_pack_weights_multi(const void* items_device, int n_items, long long total_groups,
+                                     codeps_stream_t stream);
 int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
                                const float* w_oihw, float* w_fwd, float* w_dgrad, codeps_stream_t stream);
 /* Arithmetic of a launch of this shape (mode 0 forward, 1 data gradient w.r.t. `source`): 3 = every fp32 operand as the exact
@@ -277,11 +287,24 @@ int codeps_instance_loss_bwd(int kind, const float* pred, int c, int c_pad, cons
                              const uint8_t* target_u8, int ignore_index, int batch, int hw,
                              const float* grad_loss, float* grad_pred, codeps_stream_t stream);
 /* PoseHead tail (models/pose_head.py:46-137): feat NHWC [batch][hw][c_pad] -> vec6 = 0.01 * spatial mean
- * of channels 0..5 (frame 0: axis-angle, translation) -> T [batch][16] = T*R, or R^T*T(-t) if invert. */
-int codeps_pose_fwd(const float* feat, int batch, int hw, int c_pad, int invert, float* vec6, float* T,
-                    codeps_stream_t stream);
-int codeps_pose_bwd(const float* grad_T, const float* vec6, int batch, int hw, int c_pad, int invert,
-                    float* grad_feat, codeps_stream_t stream);
+ * of channels 0..5 (frame 0: axis-angle, translation) -> T [batch][16] = T*R, or R^T*T(-t) for the items whose bit of
+ * invert_mask is set (bit b & 63: 0 = none, ~0 = all; per-item masks need batch <= 64). */
+int codeps_pose_fwd(const float* feat, int batch, int hw, int c_pad, unsigned long long invert_mask, float* vec6,
+                    float* T, codeps_stream_t stream);
+int codeps_pose_bwd(const float* grad_T, const float* vec6, int batch, int hw, int c_pad,
+                    unsigned long long invert_mask, float* grad_feat, codeps_stream_t stream);
+/* Weight re-layouts as single launches (csrc/weight_ops.hip).  stem: conv1 weight [out_c][in_c <= 8][7][7] <-> its
+ * double-pixel form [out_c][16][7][4] (W'[o][p*8+c][ky][j] = W[o][c][ky][2j+p-1]).  guda: semconv_guda weight
+ * [n_classes][in_c][3][3] (models/semantic_head.py:64-72) <-> n_coarse tap matrices [9*16][channels[k]] (row = tap * 16 +
+ * class) followed by the fine branch's [n_classes][channels[n_coarse]][3][3] block; channels / outs are HOST arrays of
+ * n_coarse + 1 entries (outs: device pointers; grad_outs entries may be NULL = zero).  accumulate: grad_w += . */
+int codeps_stem_weight_fwd(const float* w, int out_c, int in_c, float* w_double_pixel, codeps_stream_t stream);
+int codeps_stem_weight_bwd(const float* grad_double_pixel, int out_c, int in_c, int accumulate, float* grad_w,
+                           codeps_stream_t stream);
+int codeps_guda_weight_fwd(const float* w, int n_classes, int in_c, int n_coarse, const int* channels,
+                           float* const* outs, codeps_stream_t stream);
+int codeps_guda_weight_bwd(float* const* grad_outs, int n_classes, int in_c, int n_coarse, const int* channels,
+                           int accumulate, float* grad_w, codeps_stream_t stream);
 /* Transpose of nn.ReflectionPad2d(pad) on NHWC: grad_padded [B][h+2p][w+2p][c] -> grad_x [B][h][w][c]. */
 int codeps_reflect_pad_fold(const float* grad_padded, int batch, int h, int w, int c, int pad, float* grad_x,
                             codeps_stream_t stream);
