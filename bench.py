@@ -152,12 +152,24 @@ def pmc_traffic(default_workload):
     """HBM bytes per conv launch from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE passes of this same
     command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  Counters cannot be read from inside
     the process, so the value is the one measured when profiles/ was last refreshed -- None for other workloads."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     if not default_workload or not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
-    return round(d["conv"]["hbm_mb_per_launch"] * 1e6), "profiles/r01_pmc_traffic.json (avg HBM bytes per conv launch)"
+    return round(d["conv"]["hbm_mb_per_launch"] * 1e6), "profiles/r02_pmc_traffic.json (avg HBM bytes per conv launch)"
+
+
+def photometric_pmc(default_workload):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    if not default_workload or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rows = {r["kernel"]: r for r in json.load(f)["kernels"]}
+    ks = [rows[k] for k in ("photo_fwd_kernel", "photo_bwd_kernel") if k in rows]
+    if not ks:
+        return None
+    return round(sum((r["read_mb_per_launch"] + r["write_mb_per_launch"]) * 1e6 for r in ks) / len(ks))
 
 
 def conv_roofline(runner, data, steps=2, default_workload=False):
@@ -174,8 +186,14 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
         runner.step(data)
     torch.cuda.synchronize()
     F._profile["on"] = False
-    by = {}
+    by, photo = {}, {}
     for kind, flops, a, b, _tag in F._profile["events"]:
+        if kind.startswith("photo_"):                     # HBM-bound loss kernels: `flops` carries algorithmic BYTES here
+            d = photo.setdefault(kind, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += a.elapsed_time(b) * 1e-3
+            d[2] += 1
+            continue
         d = by.setdefault(kind, [0.0, 0.0, 0])
         d[0] += flops
         d[1] += a.elapsed_time(b) * 1e-3
@@ -201,7 +219,18 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
         name = "conv_igemm_kernel + conv_wgrad_kernel (f32 MFMA 32x32x2)"
     ach = dflops / dsecs / 1e12
     traffic, traffic_src = pmc_traffic(default_workload)
-    return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+    secondary = None
+    if photo:
+        pb, ps, pn = (sum(v[i] for v in photo.values()) for i in range(3))
+        ptraffic = photometric_pmc(default_workload)
+        secondary = {"bound": "hbm", "kernel": "photometric loss: pyramid_kernel + photo_fwd_kernel + reduce, photo_bwd_kernel + pose_reduce + depth_combine "
+                                              "(depth-warp + bilinear sample + 3x3 SSIM + auto-mask, all 5 scales per launch)",
+                     "achieved": round(pb / ps / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(pb / ps / 1e9 / PEAK_HBM_GBS, 4),
+                     "algorithmic_mb_per_launch": round(pb / pn / 1e6, 2), "avg_launch_us": round(ps / pn * 1e6, 1),
+                     "launches_per_step": pn // steps, "ms_per_step": round(ps / steps * 1e3, 3), "traffic": ptraffic,
+                     "note": "84 B per pixel and batch item (40 forward + 44 backward, SURVEY.md 8d); VALU-bound in practice (~1.1 kFLOP of fp32 warp / SSIM "
+                             "arithmetic per pixel and scale), so the HBM fraction is low by construction; traffic = PMC HBM bytes per launch"}
+    return {"bound": "mfma", "secondary": secondary, "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": dn // steps, "avg_launch_us": round(dsecs / dn * 1e6, 2),
             "all_conv": {"launches_per_step": n // steps, "tflops": round(flops / secs / 1e12, 2), "ms_per_step": round(secs / steps * 1e3, 3),
@@ -372,7 +401,10 @@ def main():
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
         }
         if roof is not None:
+            sec = roof.pop("secondary", None)
             line["roofline"] = roof
+            if sec is not None:
+                line["roofline_hbm"] = sec           # the HBM-bound half of north_star: the photometric pipeline
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

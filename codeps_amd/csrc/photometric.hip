@@ -86,6 +86,14 @@ static WsLayout make_layout(const Levels& L) {
 }
 
 // ---------------------------------------------------------------------------------- device helpers
+// Blocks are dispatched round-robin over the 8 XCDs (MI355X_MICROARCH.md, workgroup dispatch), each with its own L2.  Tiles that
+// are neighbours in the image share halo rows / columns and the gathered source pixels: give every XCD one CONTIGUOUS run of
+// tile ids so that a halo is fetched from HBM once per XCD boundary instead of once per tile (bijective for any grid size).
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ATen upsample_bilinear2d (align_corners=False) source index / lambdas for one axis.
 __device__ __forceinline__ void src_index(float ratio, int dst, int in_size, int out_size, int& i0, int& i1,
                                           float& l0, float& l1) {
@@ -273,11 +281,11 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(Levels L, const float* _
                                                         float alpha, float one_minus_alpha,
                                                         const float* __restrict__ pyr, uint8_t* __restrict__ sel,
                                                         float* __restrict__ loss_part) {
-    __shared__ float sm[15][FPN];
-    // device-side step counter (bumped once per step by codeps_step_counter_add): a replayed HIP graph draws fresh noise
-    if (seed_ctr) seed += *seed_ctr * 0xD1B54A32D192ED03ull;         // tgt[3], im[3], ip[3], pred_m[3], pred_p[3]
+    __shared__ float sm[15][FPN];         // tgt[3], im[3], ip[3], pred_m[3], pred_p[3]
     __shared__ float red[4];
-    const int bid = blockIdx.x;
+    // device-side step counter (bumped once per step by codeps_step_counter_add): a replayed HIP graph draws fresh noise
+    if (seed_ctr) seed += *seed_ctr * 0xD1B54A32D192ED03ull;
+    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
     int s = 0;
     while (bid >= L.fblk[s + 1]) ++s;
     const int local = bid - L.fblk[s];
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* _
     __shared__ float cf[9][BP1N];        // A[3], B[3], C[3] of the selected branch on the halo-1 tile
     __shared__ int sk[BP1N];             // selected branch (0,1 = warped; >= 2 or -1 = no gradient)
     __shared__ float red[4][32];
-    const int bid = blockIdx.x;
+    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
     int s = 0;
     while (bid >= L.bblk[s + 1]) ++s;
     const int local = bid - L.bblk[s];

@@ -53,9 +53,11 @@ class _PhotometricLoss(torch.autograd.Function):
             raise _lib.CodepsHipError("photometric: " + lib().codeps_last_error().decode())
         ws = torch.empty(nbytes, dtype=torch.uint8, device=img_t.device)
         loss = torch.empty(1, dtype=torch.float32, device=img_t.device)
+        t0 = _prof_begin()
         check(lib().codeps_photometric_fwd(ctypes.byref(desc), ptr(img_t), ptr(img_m), ptr(img_p), ptr(depth),
                                            ptr(pose_m), ptr(pose_p), ptr(intr), ptr(noise), ptr(counter), ptr(loss), ptr(ws),
                                            nbytes, stream_ptr()), "codeps_photometric_fwd")
+        _prof_end(t0, "photo_fwd", 40.0 * b * h * w)          # algorithmic bytes: 9 image planes + depth read once
         ctx.save_for_backward(img_t, img_m, img_p, depth, pose_m, pose_p, intr, ws)
         ctx.desc = desc
         return loss[0]
@@ -66,9 +68,11 @@ class _PhotometricLoss(torch.autograd.Function):
         g = _f32c(grad_loss).reshape(1)
         gd = torch.empty_like(depth)
         gpm, gpp = torch.empty_like(pose_m), torch.empty_like(pose_p)
+        t0 = _prof_begin()
         check(lib().codeps_photometric_bwd(ctypes.byref(ctx.desc), ptr(img_t), ptr(img_m), ptr(img_p), ptr(depth),
                                            ptr(pose_m), ptr(pose_p), ptr(intr), ptr(g), ptr(gd), ptr(gpm), ptr(gpp),
                                            ptr(ws), ws.numel(), stream_ptr()), "codeps_photometric_bwd")
+        _prof_end(t0, "photo_bwd", 44.0 * depth.numel())       # the same planes again + d depth written
         return None, None, None, gd, gpm, gpp, None, None, None, None, None, None
 
 

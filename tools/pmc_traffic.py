@@ -63,7 +63,7 @@ def main():
                "steps_profiled": a.steps, "unmatched_dispatches": unmatched,
                "conv": {"launches_per_step": round(n_conv, 1), "hbm_gb_per_step": round(gb_conv, 3),
                         "hbm_mb_per_launch": round(gb_conv * 1e3 / max(n_conv, 1), 2)},
-               "total_hbm_gb_per_step": round(sum(r["hbm_gb_per_step"] for r in rows), 3), "kernels": rows[:40]}, sys.stdout, indent=1)
+               "total_hbm_gb_per_step": round(sum(r["hbm_gb_per_step"] for r in rows), 3), "kernels": rows}, sys.stdout, indent=1)
     print()
 
 
