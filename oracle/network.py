@@ -124,6 +124,33 @@ def adapt_forward(sds, cfg, data, noise=None, mixup_cells=None):
     return out, res
 
 
+def eval_forward(sds, cfg, sample, mode="eval", do_panoptic=True, class_wise_depth_stats=False):
+    """CodepsNet.forward in modes "eval" / "infer" (codeps/online_adap.py:140-268): predictions of the centre frame and, in
+    "eval" with ground truth present, the depth statistics (eval/depth.py) and the confusion matrix (eval/semantic.py).
+    -> (result, stats)."""
+    from . import metrics
+    rgb = sample["rgb"] if "rgb" in sample else sample["rgb_tgt"]              # online_adap.py:143 (mix-up items)
+    feats = encode(sds["backbone_po_depth"], rgb[0], cfg["nof_layers"])
+    res, stats = OrderedDict(), OrderedDict(sem_conf=None)
+    res["depth"], _ = heads.depth_head(sds["depth_head"], feats)
+    probs = heads.semantic_head(sds["semantic_head"], feats, cfg.get("use_guda_fusion", True))
+    res["semantic"], res["semantic_soft"] = probs.argmax(1).to(torch.uint8), probs
+    res["center"], res["offset"], _ = heads.instance_head(sds["instance_head"], feats, cfg.get("use_thing_mask", False))
+    if mode == "eval":
+        if sample.get("depth") is not None:
+            stats.update(metrics.depth_metrics(sample["depth"].numpy(), res["depth"].numpy(), cfg.get("use_gt_scale", True), cfg["depth_ranges"]))
+        if sample.get("semantic") is not None:
+            stats["sem_conf"] = metrics.confusion_matrix(res["semantic"].numpy(), sample.get("semantic_eval", sample["semantic"]).numpy(),
+                                                         probs.shape[1], cfg.get("ignore_classes", ()))
+    if do_panoptic:
+        pan, ins, _ = panoptic.panoptic_fusion(res["semantic"].numpy(), res["center"].numpy(), res["offset"].numpy(), THINGS)
+        res["panoptic"], res["instance"] = torch.from_numpy(pan), torch.from_numpy(ins)
+    if class_wise_depth_stats and "semantic" in sample and sample.get("depth") is not None:
+        stats.update(metrics.depth_metrics_per_class(sample["depth"].numpy(), res["depth"].numpy(), sample["semantic"].numpy(),
+                                                     cfg.get("use_gt_scale", True), cfg["depth_ranges"]))
+    return res, stats
+
+
 def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
     """torch.optim.Adam defaults used by misc/train_utils.py:194-201 (no weight decay, no amsgrad)."""
     m.mul_(b1).add_(g, alpha=1 - b1)

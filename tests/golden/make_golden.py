@@ -320,7 +320,7 @@ class _StandInEncoder(torch.nn.Module):
         return self._resnet.features(self.sd, x, 18, training=False)
 
 
-def _build_net(seed, use_thing_mask, w, h, adaptation=False, src_wh=None):
+def _build_net(seed, use_thing_mask, w, h, adaptation=False, src_wh=None, depth_ranges=None):
     enc = _StandInEncoder(3, seed + 1)
     penc = _StandInEncoder(6, seed + 2)
     heads = OrderedDict(depth_head=DepthHead(R18, True), pose_head=PoseHead(R18, 1, 2),
@@ -331,7 +331,7 @@ def _build_net(seed, use_thing_mask, w, h, adaptation=False, src_wh=None):
     ssim = SSIMLoss()
     rec = ReconstructionLoss(w, h, ssim, 5, CPU)
     rec_src = ReconstructionLoss(src_wh[0], src_wh[1], ssim, 5, CPU) if adaptation else None
-    dalgo = DepthAlgo(rec, EdgeAwareSmoothnessLoss(), DepthEvaluator(True, None), None, None, rec_src, None)
+    dalgo = DepthAlgo(rec, EdgeAwareSmoothnessLoss(), DepthEvaluator(True, depth_ranges), None, None, rec_src, None)
     salgo = SemanticSegAlgo(SemanticLoss(device=CPU, class_weights=[1.0] * 14, top_k_percent_pixels=0.2,
                                          ignore_labels=[]), SemanticEvaluator(num_classes=14, ignore_classes=[]))
     ialgo = InstanceSegAlgo(CenterLoss(), OffsetLoss(),
@@ -450,6 +450,53 @@ def golden_adapt_real(seed=63):
     save("network_adapt_real", **res)
 
 
+def golden_eval_infer(seed=67):
+    """the reference's own CodepsNet.forward in modes "eval" (with depth / semantic ground truth, panoptic
+    fusion, class-wise depth statistics) and "infer", and the teacher / student sequence of scripts/adapt_codeps.py:164-199
+    that fills the mix-up item's pseudo labels -- run line by line with the reference's model objects (the script's
+    `adapt()` is not importable without its data loaders; the calls below are its lines 166-199 with `ema_modules =
+    ["semantic_head"]`, the shipped configuration)."""
+    import copy
+    h, w, hs, ws = 64, 160, 64, 128
+    net = _build_net(seed, False, w, h, adaptation=True, src_wh=(ws, hs), depth_ranges=[0.1, 80])
+    teacher = _build_net(seed, False, w, h, adaptation=True, src_wh=(ws, hs), depth_ranges=[0.1, 80])     # = CodepsNet.ema_model(net)
+    with torch.no_grad():                                   # an EMA'd semantic head differs from the student's
+        for p_ in teacher.semantic_head.parameters():
+            p_.mul_(0.97)
+    target = _sample(1, h, w, seed)                          # labels present: semantic GT, instance GT
+    target["depth"] = torch.where(gi.uniform((1, 1, h, w), seed + 5) < 0.3, torch.zeros(1, 1, h, w), gi.depth_map(1, h, w, seed + 4))[:, 0]   # [B,H,W]
+    res = {"meta": json.dumps({"h": h, "w": w, "hs": hs, "ws": ws, "seed": seed, "teacher_scale": 0.97})}
+    teacher.eval()
+    with torch.no_grad():
+        _, r_eval, s_eval = teacher(target, "eval", [0, -1, 1], True, True)
+        _, r_inf, s_inf = net.eval()(target, "infer", [0, -1, 1], True, False)
+        assert s_inf["sem_conf"] is None
+        mix = gi.mixup_item(2, hs, ws, h, w, seed + 3)
+        for k in ("semantic_pred_tgt_ema", "center_pred_tgt_ema", "offset_pred_tgt_ema"):
+            mix.pop(k)
+        _, r_pl, _ = teacher(mix, "eval", [0, -1, 1], False, False)         # adapt_codeps.py:173-177 (key_rgb = "rgb_tgt")
+        mix["semantic_pred_tgt_ema"] = r_pl["semantic"].detach().clone()
+    _, r_st, _ = net(mix, "eval", [0, -1, 1], False, False)                # adapt_codeps.py:193-199 (student, grad enabled)
+    for k in ("depth", "semantic", "semantic_soft", "center", "offset", "panoptic", "instance"):
+        res["eval_" + k] = r_eval[k]
+        res["infer_" + k] = r_inf[k]
+    res["eval_sem_conf"] = s_eval["sem_conf"]
+    stat_keys = [k for k in s_eval if k != "sem_conf"]
+    res["eval_stat_keys"] = json.dumps(stat_keys)
+    res["eval_stats"] = np.array([float(s_eval[k]) for k in stat_keys], np.float64)
+    with torch.no_grad():
+        top2 = teacher.semantic_head(teacher.backbone_po_depth(target["rgb"][0])).topk(2, dim=1).values
+        res["eval_margin"] = top2[:, 0] - top2[:, 1]
+        top2 = net.semantic_head(net.backbone_po_depth(target["rgb"][0])).topk(2, dim=1).values
+        res["infer_margin"] = top2[:, 0] - top2[:, 1]
+        top2 = teacher.semantic_head(teacher.backbone_po_depth(mix["rgb_tgt"][0])).topk(2, dim=1).values
+        res["mix_margin"] = top2[:, 0] - top2[:, 1]
+    res["mix_semantic_pred_tgt_ema"] = mix["semantic_pred_tgt_ema"]
+    res["mix_center_pred_tgt_ema"], res["mix_offset_pred_tgt_ema"] = r_st["center"].detach(), r_st["offset"].detach()
+    save("eval_infer", **res)
+    del copy
+
+
 # ------------------------------------------------------------------------------------------ mix-up (SURVEY 8f-2)
 def _cfg_mixup(geom):
     from yacs.config import CfgNode as CN
@@ -548,7 +595,7 @@ def golden_metrics():
 
 
 if __name__ == "__main__":
-    jobs = {"geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real,
+    jobs = {"geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer,
             "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
             "heads_r50": lambda: golden_heads("r50", R50, 1, 32, 64, 5, full=False),
             "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),

@@ -157,6 +157,70 @@ def test_real_codepsnet_adapt_against_reference():
     _check_pgrads(net, z, ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"))
 
 
+def test_eval_infer_modes_and_pre_step_against_reference():
+    """SURVEY 8f-1 pinned by the reference: CodepsNet.forward("eval") with depth / semantic ground truth, panoptic fusion and
+    class-wise depth statistics, forward("infer"), and codeps.pre_step (scripts/adapt_codeps.py:164-199) filling a raw mix-up
+    item's pseudo labels -- against tests/golden/eval_infer.npz (the reference's own CodepsNet, device evaluators here)."""
+    import copy
+    import json
+    from codeps_amd.codeps import pre_step
+    from codeps_amd.eval import DepthEvaluator, SemanticEvaluator
+    z, meta = load("eval_infer")
+    h, w, hs, ws, seed = meta["h"], meta["w"], meta["hs"], meta["ws"], meta["seed"]
+    net = _build(seed, False, w, h, adaptation=True, src_hw=(hs, ws))
+    net.depth_algo.evaluator = DepthEvaluator(True, [0.1, 80])
+    net.semantic_algo.evaluator = SemanticEvaluator(14, ignore_classes=[])
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    teacher = copy.deepcopy(net)
+    with torch.no_grad():
+        for p_ in teacher.semantic_head.parameters():
+            p_.mul_(meta["teacher_scale"])
+    target = _sample(1, h, w, seed)
+    target["depth"] = torch.where(gi.uniform((1, 1, h, w), seed + 5) < 0.3, torch.zeros(1, 1, h, w),
+                                  gi.depth_map(1, h, w, seed + 4))[:, 0].to(DEV)
+    raw = gi.mixup_item(2, hs, ws, h, w, seed + 3)
+    for k in ("semantic_pred_tgt_ema", "center_pred_tgt_ema", "offset_pred_tgt_ema"):
+        raw.pop(k)
+    raw = {k: ({o: t_.to(DEV) for o, t_ in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in raw.items()}
+    sample = {"target": target, "cut_mixup": raw}
+    r_eval, s_eval = pre_step(net, teacher, ["semantic_head"], sample, [0, -1, 1], True, do_class_wise_depth_stats=True)
+    with torch.no_grad():
+        _, r_inf, s_inf = net(target, "infer", [0, -1, 1], True, False)
+    assert s_inf["sem_conf"] is None
+
+    def check(tag, r, margin):
+        close(r["depth"], z[tag + "_depth"], 1e-3, 1e-4, tag + " depth")
+        close(r["semantic_soft"], z[tag + "_semantic_soft"], 2e-5, 1e-4, tag + " semantic_soft")
+        bad = r["semantic"].cpu().numpy() != z[tag + "_semantic"]
+        assert bad.mean() < 1e-3 and (margin[bad] < 1e-4).all(), (tag, int(bad.sum()))
+        for k in ("center", "offset"):
+            close(r[k], z[f"{tag}_{k}"], 2e-5 * float(np.abs(z[f"{tag}_{k}"]).max()), 1e-4, f"{tag} {k}")
+        if not bad.any():
+            for k in ("panoptic", "instance"):
+                same = (r[k].cpu().numpy() == z[f"{tag}_{k}"]).mean()
+                assert same > 0.999, f"{tag} {k}: only {same:.6f} of the pixels agree"
+        assert r["panoptic"].dtype == torch.int16 and r["semantic"].dtype == torch.uint8
+        return bad
+
+    bad_eval = check("eval", r_eval, z["eval_margin"])
+    check("infer", r_inf, z["infer_margin"])
+    if not bad_eval.any():
+        assert np.array_equal(s_eval["sem_conf"].cpu().numpy(), z["eval_sem_conf"])
+    keys = json.loads(str(z["eval_stat_keys"]))
+    assert [k for k in s_eval if k != "sem_conf"] == keys
+    got = np.array([float(s_eval[k]) for k in keys])
+    # depth = 1 / (0.01 + 9.99 sigmoid): fp32 logit noise of 1e-5 moves a 40 m depth by 2e-3; the statistics are means of
+    # per-pixel errors and thresholded counts over a few hundred pixels per class
+    assert np.allclose(got, z["eval_stats"], rtol=2e-3, atol=2e-3), np.abs(got - z["eval_stats"]).max()
+    m = sample["cut_mixup"]
+    bad = m["semantic_pred_tgt_ema"].cpu().numpy() != z["mix_semantic_pred_tgt_ema"]
+    assert bad.mean() < 1e-3 and (z["mix_margin"][bad] < 1e-4).all()
+    for k in ("center", "offset"):
+        ref = z[f"mix_{k}_pred_tgt_ema"]
+        close(m[f"{k}_pred_tgt_ema"], ref, 2e-5 * float(np.abs(ref).max()), 1e-4, "student " + k)
+
+
 def test_pre_step_shares_encoder_features_without_changing_results():
     """the per-frame evaluation passes (scripts/adapt_codeps.py:164-199) with the frozen encoder run once per
     image for teacher and student == the reference's separate calls, bit for bit."""

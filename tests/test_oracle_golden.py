@@ -1,5 +1,7 @@
 """The CPU oracle (oracle/) against golden vectors produced by the REAL reference
 (tests/golden/make_golden.py).  This is what pins the oracle."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -269,6 +271,42 @@ def test_network_adapt_real():
         st = grad_stats([sds[name][k].grad for k in groups[name]])
         ref = z["pgrad_" + name]
         assert (np.abs(st - ref) / (np.abs(ref[:, 1:2]) + 1e-6)).max() < 5e-3, name
+
+
+def test_eval_and_infer_modes():
+    """the oracle's "eval" / "infer" composition against the reference's own CodepsNet.forward, incl. the depth
+    statistics, the confusion matrix, panoptic fusion and the pseudo labels of the per-frame evaluation passes."""
+    z, meta = load("eval_infer")
+    h, w, hs, ws, seed = meta["h"], meta["w"], meta["hs"], meta["ws"], meta["seed"]
+    sds = _sds(seed, False)
+    teacher = _sds(seed, False)
+    for k, v in teacher["semantic_head"].items():
+        if v.is_floating_point():
+            v.mul_(meta["teacher_scale"])
+    cfg = dict(nof_layers=18, depth_ranges=[0.1, 80])
+    target = _sample(1, h, w, seed)
+    target["depth"] = torch.where(gi.uniform((1, 1, h, w), seed + 5) < 0.3, torch.zeros(1, 1, h, w), gi.depth_map(1, h, w, seed + 4))[:, 0]
+    with torch.no_grad():
+        r_eval, s_eval = network.eval_forward(teacher, cfg, target, "eval", True, True)
+        r_inf, s_inf = network.eval_forward(sds, cfg, target, "infer", True)
+        mix = gi.mixup_item(2, hs, ws, h, w, seed + 3)
+        r_pl, _ = network.eval_forward(teacher, cfg, mix, "eval", False)
+        r_st, _ = network.eval_forward(sds, cfg, mix, "eval", False)
+    assert s_inf["sem_conf"] is None and len(s_inf) == 1
+    for tag, r in (("eval", r_eval), ("infer", r_inf)):
+        close(r["depth"], z[tag + "_depth"], 1e-3)
+        close(r["semantic_soft"], z[tag + "_semantic_soft"], 1e-6, 1e-5)
+        for k in ("semantic", "panoptic", "instance"):
+            assert np.array_equal(r[k].numpy(), z[f"{tag}_{k}"]), (tag, k)
+        for k in ("center", "offset"):
+            close(r[k], z[f"{tag}_{k}"], 1e-5 * float(np.abs(z[f"{tag}_{k}"]).max()), 1e-5)
+    assert np.array_equal(np.asarray(s_eval["sem_conf"]), z["eval_sem_conf"])
+    keys = json.loads(str(z["eval_stat_keys"]))
+    assert [k for k in s_eval if k != "sem_conf"] == keys
+    close(np.array([float(s_eval[k]) for k in keys]), z["eval_stats"], 1e-6, 2e-5, "depth statistics")
+    assert np.array_equal(r_pl["semantic"].numpy(), z["mix_semantic_pred_tgt_ema"])
+    close(r_st["center"], z["mix_center_pred_tgt_ema"], 1e-5 * float(np.abs(z["mix_center_pred_tgt_ema"]).max()), 1e-5)
+    close(r_st["offset"], z["mix_offset_pred_tgt_ema"], 1e-5 * float(np.abs(z["mix_offset_pred_tgt_ema"]).max()), 1e-5)
 
 
 def test_resnet_self_consistency():
