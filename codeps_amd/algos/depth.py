@@ -148,8 +148,34 @@ class DepthAlgo:
         return [pose_head(body_pose_sflow(pair(images[1], images[0])), invert_pose=True),
                 pose_head(body_pose_sflow(pair(images[0], images[2])))]
 
+    def poses_batched(self, images, keys, body_pose_sflow, pose_head):
+        """{key: [T_t->t-1, T_t->t+1]}: the pose nets of all keys of one resolution in ONE batched forward with per-call
+        BatchNorm groups (exactly the statistics of the reference's 2 x len(keys) separate calls, in the reference's call
+        order: algos/depth.py:405-417 per key, keys in the order of depth.py:514)."""
+        pre_pose = {}
+        if not hasattr(body_pose_sflow, "forward_pair_groups"):
+            return pre_pose
+        by_res = OrderedDict()
+        for k in keys:
+            by_res.setdefault(tuple(images[k][0].shape[2:]), []).append(k)
+        for ks in by_res.values():
+            pairs, spans, off = [], [], 0
+            for k in ks:                                           # call order of the reference: prev pair, next pair
+                for a, b, inv in ((images[k][1], images[k][0], True), (images[k][0], images[k][2], False)):
+                    pairs.append((a, b))
+                    spans.append((k, inv, off, off + a.shape[0]))
+                    off += a.shape[0]
+            feats = body_pose_sflow.forward_pair_groups(pairs, self._group_plan(ks, images[ks[0]][0].device))
+            if hasattr(pose_head, "forward_spans"):
+                mats = pose_head.forward_spans(feats, [(b0, b1, inv) for _k, inv, b0, b1 in spans])
+            else:
+                mats = [pose_head([feats[-1][b0:b1]], invert_pose=inv) for _k, inv, b0, b1 in spans]
+            for (k, _inv, _b0, _b1), m in zip(spans, mats):
+                pre_pose.setdefault(k, []).append(m)
+        return pre_pose
+
     def adaptation(self, images: Dict[str, Tuple[Tensor, Tensor, Tensor]], depth_feats_window, camera_models, depth_head,
-                   body_pose_sflow, pose_head, flow_head=None, check_car_moving: bool = True, batched=None):
+                   body_pose_sflow, pose_head, flow_head=None, check_car_moving: bool = True, batched=None, pre_pose=None):
         """Per-key losses (source uses its own ReconstructionLoss geometry), image-count weighted mean
         (algos/depth.py:507-577).  The reference's rolling "car not moving" rule (depth.py:537-558) reads the pose norm on
         the host every frame: `check_car_moving` True keeps that form (one small D2H copy), "device" (CodepsNet's default)
@@ -174,28 +200,8 @@ class DepthAlgo:
             for k, dpt, dsp in zip(ks, F.split_batch(depth_all, bounds), F.split_batch(disp_all, bounds)):
                 pre[k] = (dpt, dsp)
         recon, smth, depth_pred, transformations, num_images = {}, {}, {}, {}, {k: 0 for k in keys}
-        # pose nets of all keys of one resolution in ONE batched forward with per-call BatchNorm groups (exactly the
-        # statistics of the reference's 2 x len(keys) separate calls, in the reference's call order)
-        pre_pose = {}
-        if hasattr(body_pose_sflow, "forward_pair_groups"):
-            by_res = OrderedDict()
-            for k in keys:
-                if k in pre:
-                    by_res.setdefault(tuple(images[k][0].shape[2:]), []).append(k)
-            for ks in by_res.values():
-                pairs, spans, off = [], [], 0
-                for k in ks:                                           # call order of the reference: prev pair, next pair
-                    for a, b, inv in ((images[k][1], images[k][0], True), (images[k][0], images[k][2], False)):
-                        pairs.append((a, b))
-                        spans.append((k, inv, off, off + a.shape[0]))
-                        off += a.shape[0]
-                feats = body_pose_sflow.forward_pair_groups(pairs, self._group_plan(ks, images[ks[0]][0].device))
-                if hasattr(pose_head, "forward_spans"):
-                    mats = pose_head.forward_spans(feats, [(b0, b1, inv) for _k, inv, b0, b1 in spans])
-                else:
-                    mats = [pose_head([feats[-1][b0:b1]], invert_pose=inv) for _k, inv, b0, b1 in spans]
-                for (k, _inv, _b0, _b1), m in zip(spans, mats):
-                    pre_pose.setdefault(k, []).append(m)
+        if pre_pose is None:
+            pre_pose = self.poses_batched(images, [k for k in keys if k in pre], body_pose_sflow, pose_head)
         for key in keys:
             if key in pre:
                 depth, disp = pre[key]

@@ -75,16 +75,16 @@ class SemanticSegAlgo:
         semantic_pred, semantic_logits = self.inference(feats, semantic_head)
         return self._confusion(semantic_pred, semantic_gt), semantic_pred, semantic_logits
 
-    def adaptation(self, feats: Dict[str, list], semantic_head, semantic_gt: Dict[str, Tensor],
-                   semantic_weights: Dict[str, Tensor], batched=None):
-        """algos/semantic_seg.py:200-249.  `batched` (optional, from CodepsNet.adapt): the semantic head has no
-        batch-dependent op, so all supervised keys of one resolution (source + *mixup) run through it in ONE call;
-        the hard-pixel mining stays per key (separate top-k over each key's pixels, like the reference)."""
-        semantic_pred = None
-        if 'target' in feats:           # (a rank of a batch-sharded step may hold no target item: nothing to predict there)
-            with torch.no_grad():       # target prediction only feeds argmax / panoptic fusion
-                target_probs = semantic_head(feats['target'][0])
-            semantic_pred = torch.argmax(target_probs, dim=1)
+    def adaptation_target(self, feats, semantic_head):
+        """The target frame's prediction (algos/semantic_seg.py:208-213); None when this rank holds no target item."""
+        if 'target' not in feats:       # (a rank of a batch-sharded step may hold no target item: nothing to predict there)
+            return None
+        with torch.no_grad():           # the target prediction only feeds argmax / panoptic fusion
+            target_probs = semantic_head(feats['target'][0])
+        return torch.argmax(target_probs, dim=1)
+
+    def adaptation_supervised(self, feats, semantic_head, semantic_gt, semantic_weights, batched=None):
+        """The supervised losses of the source and the mix-up keys (algos/semantic_seg.py:215-234)."""
         losses = {'source': None}
         sup = [k for k in feats if k.endswith('mixup') or k == 'source']
         probs = {}
@@ -105,5 +105,15 @@ class SemanticSegAlgo:
                 losses['source'] = self.semantic_loss(p, semantic_gt['source'], semantic_weights['source'])
             else:
                 losses[key] = self.semantic_loss(p, semantic_gt[key], None)          # weights = ones
+        return losses
+
+    def adaptation(self, feats: Dict[str, list], semantic_head, semantic_gt: Dict[str, Tensor],
+                   semantic_weights: Dict[str, Tensor], batched=None, target_pred=None):
+        """algos/semantic_seg.py:200-249.  `batched` (optional, from CodepsNet.adapt): the semantic head has no
+        batch-dependent op, so all supervised keys of one resolution (source + *mixup) run through it in ONE call;
+        the hard-pixel mining stays per key (separate top-k over each key's pixels, like the reference)."""
+        # target_pred: the target prediction when the caller has already computed it (CodepsNet.adapt runs it on a side stream)
+        semantic_pred = self.adaptation_target(feats, semantic_head) if target_pred is None else target_pred
+        losses = self.adaptation_supervised(feats, semantic_head, semantic_gt, semantic_weights, batched)
         confusion_matrix = None if semantic_pred is None else self._confusion(semantic_pred, semantic_gt.get('target'))
         return losses, confusion_matrix, semantic_pred

@@ -20,6 +20,17 @@ from ..datasets.mixup import Mixup
 from ..misc.camera_model import CameraModel
 
 
+class _StreamRef:
+    """Holder of a HIP stream that deep-copies to an empty holder (CodepsNet.ema_model deep-copies the network; a stream is a
+    process resource, not model state)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __deepcopy__(self, memo):
+        return _StreamRef(None)
+
+
 class CodepsNet(nn.Module):
 
     def __init__(self, cfg_mixup, backbone_po_depth, backbone_pose_sflow, depth_head, pose_head, flow_head, semantic_head,
@@ -40,7 +51,27 @@ class CodepsNet(nn.Module):
         self.depth_algo, self.semantic_algo, self.instance_algo = depth_algo, semantic_algo, instance_algo
         self.faithful_bn_updates = False
         self.mixup_fn = None
+        # optional side stream for the pose networks: they depend on the images only, so their forward (and, through autograd's
+        # stream bookkeeping, their backward) can overlap the shared encoder and the heads (StepRunner sets it; None = serial)
+        self._pose_stream_ref = _StreamRef(None)
+        self._branch_stream_ref = _StreamRef(None)
         self.check_car_moving = "device"       # the rule of algos/depth.py:537-558 on the stream (True: host form, False: off)
+
+    @property
+    def pose_stream(self):
+        return self._pose_stream_ref.stream
+
+    @pose_stream.setter
+    def pose_stream(self, stream):
+        self._pose_stream_ref = _StreamRef(stream)
+
+    @property
+    def branch_stream(self):
+        return self._branch_stream_ref.stream
+
+    @branch_stream.setter
+    def branch_stream(self, stream):
+        self._branch_stream_ref = _StreamRef(stream)
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -122,11 +153,14 @@ class CodepsNet(nn.Module):
 
         if do_panoptic_fusion:
             R["panoptic"], R["instance"] = self.instance_algo.panoptic_fusion(R["semantic"], R["center"], R["offset"])
+        depth_stats_classes = None
         if do_class_wise_depth_stats and R["depth"] is not None and "semantic" in in_data:
-            stats.update(self.depth_algo.evaluator.compute_depth_metrics_per_class(in_data["depth"], R["depth"],
-                                                                                   in_data["semantic"]))
-        if depth_stats is not None:
+            depth_stats_classes = self.depth_algo.evaluator.compute_depth_metrics_per_class(in_data["depth"], R["depth"],
+                                                                                            in_data["semantic"])
+        if depth_stats is not None:                 # key order of the reference's stats dict (online_adap.py:262-268)
             stats.update(depth_stats)
+        if depth_stats_classes is not None:
+            stats.update(depth_stats_classes)
         return L, R, stats
 
     # ------------------------------------------------------------------ EMA
@@ -159,6 +193,16 @@ class CodepsNet(nn.Module):
         for key in list(items):
             if key.endswith("mixup") and (self.mixup_fn is not None or "rgb_src" in items[key]):
                 in_data[key] = items[key] = (self.mixup_fn or Mixup.do_mixup)(key, items[key], self.instance_algo, self.cfg_mixup)
+        pre_pose, side = None, None
+        if self.pose_stream is not None and self.depth_algo is not None and not self.backbone_po_depth.training:
+            side, cur = self.pose_stream, torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                pre_pose = self.depth_algo.poses_batched(images_window, [k for k in ("source", "target", "target_replay") if k in images_window],
+                                                         self.backbone_pose_sflow, self.pose_head)
+            for mats in pre_pose.values():
+                for m in mats:
+                    m.record_stream(cur)
         po_depth_feats, batched = {}, []
         if not self.backbone_po_depth.training and hasattr(self.backbone_po_depth, "forward_batch"):
             # frozen encoder (eval BatchNorm) is batch-independent: ONE forward per resolution over the centre frames of
@@ -182,6 +226,36 @@ class CodepsNet(nn.Module):
                 po_depth_feats[k] = [self.backbone_po_depth(v["rgb"][0])] if k.endswith("mixup") else \
                     self._encode_window(v["rgb"], depth_offsets)
 
+        # second optional side stream: the (frozen, small-grid) instance head next to the semantic branch; joined before the
+        # panoptic fusion.  (The whole semantic + instance branch on a stream of its own next to the depth branch measured
+        # SLOWER than serial: three concurrent GEMM streams evict each other's operands from L2.)
+        import contextlib
+        branch = self.branch_stream if self.depth_algo is not None else None
+        if branch is not None:
+            branch.wait_stream(torch.cuda.current_stream())
+        panoptic_pred, instance_pred, target_pred = None, None, None
+        with (torch.cuda.stream(branch) if branch is not None else contextlib.nullcontext()):
+            # everything of the (B = 1) target frame that feeds no loss: instance head, semantic prediction, panoptic fusion
+            center_losses, offset_losses, center_pred, offset_pred, thing_mask_pred = self._instance_branch(items, po_depth_feats)
+            if self.semantic_algo is not None:
+                target_pred = self.semantic_algo.adaptation_target(po_depth_feats, self.semantic_head)
+            if do_panoptic_fusion and target_pred is not None:
+                panoptic_pred, instance_pred = self.instance_algo.panoptic_fusion(target_pred, center_pred, offset_pred)
+        semantic_losses, confusion_matrix, semantic_pred = self._semantic_branch(items, po_depth_feats, batched, target_pred)
+        if branch is not None:
+            torch.cuda.current_stream().wait_stream(branch)
+
+        depth_losses, depth_pred = {}, None
+        if self.depth_algo is not None:
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            depth_losses, _, depth_pred, _, _, _ = self.depth_algo.adaptation(
+                images_window, po_depth_feats, camera_models, self.depth_head, self.backbone_pose_sflow, self.pose_head, None,
+                check_car_moving=self.check_car_moving, batched=batched, pre_pose=pre_pose)
+        return self._adapt_outputs(in_data, po_depth_feats, depth_losses, depth_pred, semantic_losses, center_losses, offset_losses,
+                                   semantic_pred, center_pred, offset_pred, panoptic_pred, instance_pred, thing_mask_pred, confusion_matrix)
+
+    def _instance_branch(self, items, po_depth_feats):
         center_losses, offset_losses, center_pred, offset_pred, thing_mask_pred = {}, {}, None, None, None
         if self.instance_algo is not None:
             get = lambda name: {k: v.get(name) for k, v in items.items()}      # noqa: E731
@@ -191,23 +265,19 @@ class CodepsNet(nn.Module):
             center_losses, offset_losses, center_pred, offset_pred = out[:4]
             if self.instance_head.use_thing_mask:
                 thing_mask_pred = out[5]
+        return center_losses, offset_losses, center_pred, offset_pred, thing_mask_pred
 
+    def _semantic_branch(self, items, po_depth_feats, batched, target_pred):
         semantic_losses, confusion_matrix, semantic_pred = {"source": None}, None, None
         if self.semantic_algo is not None:
             semantic_losses, confusion_matrix, semantic_pred = self.semantic_algo.adaptation(
                 po_depth_feats, self.semantic_head, {k: v.get("semantic") for k, v in items.items()},
-                {k: v.get("semantic_weights") for k, v in items.items()}, batched=batched)
+                {k: v.get("semantic_weights") for k, v in items.items()}, batched=batched, target_pred=target_pred)
+        return semantic_losses, confusion_matrix, semantic_pred
 
-        panoptic_pred, instance_pred = None, None
-        if do_panoptic_fusion and semantic_pred is not None:
-            panoptic_pred, instance_pred = self.instance_algo.panoptic_fusion(semantic_pred, center_pred, offset_pred)
-
-        depth_losses, depth_pred = {}, None
-        if self.depth_algo is not None:
-            depth_losses, _, depth_pred, _, _, _ = self.depth_algo.adaptation(
-                images_window, po_depth_feats, camera_models, self.depth_head, self.backbone_pose_sflow, self.pose_head, None,
-                check_car_moving=self.check_car_moving, batched=batched)
-
+    @staticmethod
+    def _adapt_outputs(in_data, po_depth_feats, depth_losses, depth_pred, semantic_losses, center_losses, offset_losses, semantic_pred,
+                       center_pred, offset_pred, panoptic_pred, instance_pred, thing_mask_pred, confusion_matrix):
         losses = OrderedDict()
         losses["depth_recon"] = depth_losses.get("recon")
         losses["depth_smth"] = depth_losses.get("smth")

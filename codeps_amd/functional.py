@@ -204,12 +204,25 @@ def _weak(obj, cache, key):
 
 def _workspace(nbytes, device, tag):
     """Per-(device, tag) scratch buffer, grown on demand (stream-ordered reuse, like a cuDNN workspace)."""
-    key = (device.index, tag)
+    key = (device.index, tag, torch.cuda.current_stream(device).cuda_stream)     # per stream: concurrent branches must not share scratch
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def _mark_written():
+    """(event, stream id) after a cached buffer was (re)written on the current stream: a user on ANOTHER stream must wait for it
+    (branches of a step run on side streams, codeps_amd.codeps.online_adap)."""
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev, torch.cuda.current_stream().cuda_stream
+
+
+def _wait_written(mark):
+    if mark is not None and mark[1] != torch.cuda.current_stream().cuda_stream:
+        torch.cuda.current_stream().wait_event(mark[0])
 
 
 _pack_cache = {}           # frozen parameters: valid while (storage, version) is unchanged
@@ -239,6 +252,7 @@ def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
     ent = cache.get(key)          # [weakref to the parameter, storage, stamp, w_fwd, w_dgrad]: ids / addresses get reused
     same = ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr()
     if same and ent[2] == stamp and (ent[4] is not None or not need_dgrad):
+        _wait_written(ent[5])
         return ent[3], ent[4]
     co, ci, kh, kw = weight.shape
     w = _f32c(weight.detach())
@@ -251,7 +265,7 @@ def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
                          device=w.device)
     check(lib().codeps_conv2d_pack_weights(co, ci, kh, kw, out_c_pad, in_c_pad, ptr(w), ptr(wf), ptr(wd), stream_ptr()),
           "codeps_conv2d_pack_weights")
-    cache[key] = [_weak(weight, cache, key), weight.data_ptr(), stamp, wf, wd]
+    cache[key] = [_weak(weight, cache, key), weight.data_ptr(), stamp, wf, wd, _mark_written()]
     return wf, wd
 
 
@@ -307,8 +321,10 @@ def refresh_weight_packs():
             return
     check(lib().codeps_conv2d_pack_weights_multi(ptr(t["dev"]), t["n"], t["groups"], stream_ptr()), "codeps_conv2d_pack_weights_multi")
     t["epoch"] = _weights_epoch[0]
+    mark = _mark_written()
     for ent, _dptr, ref, _had in t["entries"]:
         ent[2] = (ref()._version, _weights_epoch[0])
+        ent[5] = mark
 
 
 _padvec_cache = {}
@@ -327,13 +343,14 @@ def _pad_vec(v, n):
     stamp = (v.data_ptr(), src._version, _weights_epoch[0])
     hit = _padvec_cache.get(key)
     if hit is not None and hit[4]() is src and hit[0] == stamp[0] and hit[3].device == v.device:
+        _wait_written(hit[5])
         if (hit[1], hit[2]) != stamp[1:]:
             hit[3][:v.numel()].copy_(v)
-            hit[1], hit[2] = stamp[1], stamp[2]
+            hit[1], hit[2], hit[5] = stamp[1], stamp[2], _mark_written()
         return hit[3]
     out = torch.zeros(n, dtype=torch.float32, device=v.device)
     out[:v.numel()] = v
-    _padvec_cache[key] = [stamp[0], stamp[1], stamp[2], out, _weak(src, _padvec_cache, key)]
+    _padvec_cache[key] = [stamp[0], stamp[1], stamp[2], out, _weak(src, _padvec_cache, key), _mark_written()]
     return out
 
 

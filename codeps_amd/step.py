@@ -123,6 +123,15 @@ class StepRunner:
         self.noise_counter = torch.zeros(1, dtype=torch.int64, device=self.groups[0].flat.device)
         self.seed_base = 0x5EED
         self._graph = None
+        # Branch concurrency: the pose networks (they depend on the images only) and the instance / semantic branch run on side
+        # streams next to the shared encoder / the depth branch -- forward by these forks, backward through autograd's stream
+        # bookkeeping (every backward op runs on its forward's stream); inside the captured HIP graph they become parallel
+        # branches.  Measured at config 3: 41.4 -> 37.5 ms per step with the pose stream alone.  CODEPS_STREAMS=0 serialises.
+        import os
+        if mode == "adapt" and os.environ.get("CODEPS_STREAMS", "1") != "0":
+            net.pose_stream = torch.cuda.Stream()
+            if os.environ.get("CODEPS_STREAMS", "1") != "1p":
+                net.branch_stream = torch.cuda.Stream()
         self.key_scale = {}             # per-loss re-weighting of a batch-sharded step with unequal shards (set_key_counts)
 
     def set_key_counts(self, items, rank):
@@ -169,6 +178,9 @@ class StepRunner:
             wts.append(float(w) * self.key_scale.get(k, 1.0))
         total = F.weighted_sum(terms, wts)
         total.backward()
+        for side in (getattr(self.net, "pose_stream", None), getattr(self.net, "branch_stream", None)):
+            if side is not None:      # the gradient sinks are written by kernels autograd does not track: join the side streams by hand
+                torch.cuda.current_stream().wait_stream(side)
         if F._pack_table["dev"] is None and F._pack_table.get("builds", 0) < 8 and not torch.cuda.is_current_stream_capturing():
             F.build_pack_table()                 # the first step created every layer's persistent pack buffers: table them
         return total.detach(), losses, result
