@@ -136,6 +136,15 @@ SIGNATURES = {
     "codeps_ssim_fwd": (c_int, [P, P, I, I, I, c_float, c_float, P, P]),
     "codeps_ssim_bwd_workspace_bytes": (c_size_t, [I, I, I]),
     "codeps_ssim_bwd": (c_int, [P, P, P, I, I, I, c_float, c_float, P, P, P, c_size_t, P]),
+    "codeps_lanczos_coeffs": (c_int, [I, I, P, P]),
+    "codeps_resample_u8": (c_int, [P, I, I, I, I, I, P, P, I, P, P]),
+    "codeps_color_jitter_u8": (c_int, [P, I, I, I, P, P, P, P, P, P, P]),
+    "codeps_match_histograms_workspace_bytes": (c_size_t, [I]),
+    "codeps_match_histograms_u8": (c_int, [P, P, I, I, I, I, I, P, P, c_size_t, P]),
+    "codeps_u8_to_tensor": (c_int, [P, I, I, I, P, P, ctypes.c_uint, P, P]),
+    "codeps_cityscapes_labels_workspace_bytes": (c_size_t, []),
+    "codeps_cityscapes_labels": (c_int, [P, P, I, I, I, I, P, ctypes.c_ulonglong, c_float, I, P, P, P, P, P, P, P, c_size_t, P]),
+    "codeps_disparity_to_depth": (c_int, [P, I, I, I, I, c_float, P, P]),
     "codeps_step_counter_add": (c_int, [P, c_uint64, P]),
     "codeps_depth_rule_state_floats": (c_size_t, [I]),
     "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, c_float, c_float, I, P, I, P, P]),

@@ -328,6 +328,42 @@ int codeps_ssim_bwd(const float* x, const float* y, const float* grad_out, int p
                     codeps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Image-file data path on the device (csrc/preprocess.hip): datasets/dataset.py:66-67 (Resize LANCZOS),
+ * datasets/preprocessing.py:12-105 (colour jitter, flip, ToTensor + Normalize, histogram style transfer), datasets/
+ * cityscapes.py:166-262 (label path, disparity -> depth).  Images are uint8 [batch][h][w][3] as the PNG decoder (host)
+ * leaves them.
+ * codeps_lanczos_coeffs (HOST function): Pillow's 8.22 fixed-point Lanczos tables for in_size -> out_size; returns ksize
+ *   (bounds / coeffs NULL: size query); bounds int [out_size][2], coeffs int [out_size][ksize].  The caller uploads them.
+ * codeps_resample_u8: one separable pass (axis 1 = along x, 0 = along y); PIL resizes x first, then y, 8-bit in between.
+ * codeps_color_jitter_u8: n_ops / ops / factors are HOST arrays ([batch], [batch][4], [batch][4]; op 0 brightness, 1 contrast,
+ *   2 saturation, 3 hue; application order = array order, preprocessing.py:102-104); tmp = second image buffer, grey_sums =
+ *   192 bytes of device scratch; batch <= 16.
+ * codeps_match_histograms_u8: transfer_histogram_style(mode="rgb") = skimage match_histograms per channel.
+ * codeps_u8_to_tensor: flip (bit b of flip_mask), ToTensor, Normalize (mean / std HOST arrays [3] or both NULL) -> fp32 NCHW.
+ * codeps_cityscapes_labels: labelIds u8 / instanceIds u16 [h][w] -> network-resolution maps (cv2.INTER_NEAREST resize,
+ *   label_map256 = HOST table labelId -> train id (255 = ignore), thing ids as a bit mask, small-instance weights by area).
+ * codeps_disparity_to_depth: Cityscapes 16-bit disparity -> depth [out_h][out_w] (baseline_times_fx = baseline * fx). */
+int codeps_lanczos_coeffs(int in_size, int out_size, int* bounds, int* coeffs);
+int codeps_resample_u8(const uint8_t* src, int batch, int h, int w, int axis, int out_size, const int* bounds,
+                       const int* coeffs, int ksize, uint8_t* dst, codeps_stream_t stream);
+int codeps_color_jitter_u8(const uint8_t* src, int batch, int h, int w, const int* n_ops, const int* ops,
+                           const float* factors, uint8_t* dst, uint8_t* tmp, unsigned long long* grey_sums,
+                           codeps_stream_t stream);
+size_t codeps_match_histograms_workspace_bytes(int batch);
+int codeps_match_histograms_u8(const uint8_t* img, const uint8_t* ref, int batch, int h, int w, int ref_h, int ref_w,
+                               uint8_t* out, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+int codeps_u8_to_tensor(const uint8_t* img, int batch, int h, int w, const float* mean, const float* std_,
+                        unsigned flip_mask, float* out, codeps_stream_t stream);
+size_t codeps_cityscapes_labels_workspace_bytes(void);
+int codeps_cityscapes_labels(const uint8_t* semantic_ids, const uint16_t* instance_ids, int h, int w, int out_h,
+                             int out_w, const uint8_t* label_map256, unsigned long long thing_class_mask,
+                             float small_instance_area, int small_instance_weight, uint8_t* semantic, int* instance,
+                             uint8_t* thing_mask, uint8_t* semantic_weights, uint8_t* center_weights,
+                             uint8_t* offset_weights, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+int codeps_disparity_to_depth(const uint16_t* disparity, int h, int w, int out_h, int out_w, float baseline_times_fx,
+                              float* depth, codeps_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Step control on the stream (csrc/step_ctl.hip): the per-frame decisions the reference takes on the
  * host, kept on the device so that a captured HIP graph replays a REAL adaptation step.
  * codeps_step_counter_add: *counter += increment (the counter codeps_photometric_fwd mixes into its

@@ -497,6 +497,40 @@ def golden_eval_infer(seed=67):
     del copy
 
 
+def golden_preprocessing(seed=91):
+    """what the reference's data loader does to a decoded image, produced by the libraries it calls -- Pillow for
+    `transforms.Resize(size, LANCZOS)` (datasets/dataset.py:66-67) and, behind torchvision 0.13.1's F.adjust_* wrappers,
+    for the colour jitter (datasets/preprocessing.py:78-105); ToTensor + Normalize written out (preprocessing.py:12-18).
+    torchvision itself is not installed (its wrappers are one Pillow call each and are written out below)."""
+    from PIL import Image, ImageEnhance
+    h, w, size = 96, 160, (48, 96)
+    r = np.random.default_rng(seed)
+    a = np.kron(r.random((h // 8 + 2, w // 8 + 2, 3)), np.ones((8, 8, 1)))[:h, :w]
+    a = (a * 255 + r.normal(0, 8, (h, w, 3))).clip(0, 255).astype(np.uint8)
+    img = Image.fromarray(a).resize((size[1], size[0]), Image.LANCZOS)
+    resized = np.array(img)
+    ops = [("contrast", 1.13), ("hue", -0.06), ("brightness", 0.85), ("saturation", 1.17)]
+    for name, f in ops:
+        if name == "brightness":
+            img = ImageEnhance.Brightness(img).enhance(f)
+        elif name == "contrast":
+            img = ImageEnhance.Contrast(img).enhance(f)
+        elif name == "saturation":
+            img = ImageEnhance.Color(img).enhance(f)
+        else:                                               # F.adjust_hue (functional_pil.py of torchvision 0.13.1)
+            hh, ss, vv = img.convert("HSV").split()
+            np_h = np.array(hh, dtype=np.uint8)
+            np_h = (np_h.astype(np.int32) + (int(f * 255) & 0xFF)).astype(np.uint8)      # np_h += np.uint8(hue_factor * 255)
+            img = Image.merge("HSV", (Image.fromarray(np_h, "L"), ss, vv)).convert("RGB")
+    jittered = np.array(img)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    ten = torch.from_numpy(jittered).permute(2, 0, 1).float().div(255)                 # ToTensor
+    ten = (ten - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)   # Normalize
+    save("preprocessing", meta=json.dumps({"h": h, "w": w, "seed": seed, "size": list(size), "ops": [list(o) for o in ops],
+                                           "mean": list(mean), "std": list(std)}),
+         resized=resized, jittered=jittered, tensor=ten)
+
+
 # ------------------------------------------------------------------------------------------ mix-up (SURVEY 8f-2)
 def _cfg_mixup(geom):
     from yacs.config import CfgNode as CN
@@ -595,7 +629,7 @@ def golden_metrics():
 
 
 if __name__ == "__main__":
-    jobs = {"geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer,
+    jobs = {"geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer, "preprocessing": golden_preprocessing,
             "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
             "heads_r50": lambda: golden_heads("r50", R50, 1, 32, 64, 5, full=False),
             "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),
