@@ -119,9 +119,17 @@ class DepthAlgo:
 
     def training(self, images, depth_feats_window, camera_models, depth_head, body_pose_sflow, pose_head, flow_head=None,
                  depth_gt: Optional[Tensor] = None, use_reconstruction_loss_adapt_source: bool = False,
-                 return_disparity: bool = False):
-        depth_maps, disparity_maps, transformations, object_motion_maps = self._forward(
-            images, depth_feats_window, depth_head, body_pose_sflow, pose_head, flow_head)
+                 return_disparity: bool = False, pre_pose=None):
+        """pre_pose (not in the reference): [T_t->t-1, T_t->t+1] already computed by the caller (CodepsNet runs the pose networks,
+        which depend on the images only, on a side stream next to the shared encoder)."""
+        if pre_pose is not None:
+            if flow_head is not None:
+                raise NotImplementedError("flow head is out of scope (make_sflow is False in every shipped config)")
+            depth, disp = depth_head(depth_feats_window[0], return_disparity=True)
+            depth_maps, disparity_maps, transformations, object_motion_maps = [depth], [disp], list(pre_pose), None
+        else:
+            depth_maps, disparity_maps, transformations, object_motion_maps = self._forward(
+                images, depth_feats_window, depth_head, body_pose_sflow, pose_head, flow_head)
         depth_stats = None
         if depth_gt is not None and self.evaluator is not None:
             depth_stats = self.evaluator.compute_depth_metrics(depth_gt, depth_maps[0])

@@ -113,11 +113,21 @@ class CodepsNet(nn.Module):
             rgb = in_data["rgb"]
             images_window = [rgb[o] for o in depth_offsets]
             if self.depth_algo is not None:
+                pre_pose, side = None, self.pose_stream
+                if side is not None:                    # the pose networks need the images only: side stream, next to the encoder
+                    cur = torch.cuda.current_stream()
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        pre_pose = self.depth_algo._pose_pair(images_window, self.backbone_pose_sflow, self.pose_head)
+                    for m in pre_pose:
+                        m.record_stream(cur)
                 feats = self._encode_window(rgb, depth_offsets)
                 cams = self._camera_models(rgb[0], in_data["camera_model"])
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side)
                 L["depth_recon"], L["depth_smth"], _, _, R["depth"], _, _, depth_stats = self.depth_algo.training(
                     images_window, feats, in_data["camera_model"] if isinstance(in_data["camera_model"], Tensor) else cams,
-                    self.depth_head, self.backbone_pose_sflow, self.pose_head, None, in_data.get("depth"))
+                    self.depth_head, self.backbone_pose_sflow, self.pose_head, None, in_data.get("depth"), pre_pose=pre_pose)
             else:
                 feats = [self.backbone_po_depth(rgb[0])]
             if self.semantic_algo is not None:
