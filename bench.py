@@ -182,10 +182,18 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
     from codeps_amd import functional as F
     F._profile["events"].clear()
     F._profile["on"] = True
+    # per-launch durations are taken with the branches SERIALISED (no side streams): with them, a launch's events also span the
+    # time it shares the chip with the other branch's kernels, which is a property of the schedule, not of the kernel -- and it
+    # is what `rocprofv3 --kernel-trace` reports too (the tracer serialises dispatches)
+    streams = (getattr(runner.net, "pose_stream", None), getattr(runner.net, "branch_stream", None))
+    if streams[0] is not None or streams[1] is not None:
+        runner.net.pose_stream = runner.net.branch_stream = None
     for _ in range(steps):
         runner.step(data)
     torch.cuda.synchronize()
     F._profile["on"] = False
+    if streams[0] is not None or streams[1] is not None:
+        runner.net.pose_stream, runner.net.branch_stream = streams
     by, photo = {}, {}
     for kind, flops, a, b, _tag in F._profile["events"]:
         if kind.startswith("photo_"):                     # HBM-bound loss kernels: `flops` carries algorithmic BYTES here
