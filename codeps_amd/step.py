@@ -129,7 +129,7 @@ class StepRunner:
         # branches.  Measured at config 3: 41.4 -> 37.5 ms per step with the pose stream alone.  CODEPS_STREAMS=0 serialises.
         import os
         if os.environ.get("CODEPS_STREAMS", "1") != "0" and getattr(net, "depth_algo", None) is not None:
-            net.pose_stream = torch.cuda.Stream()
+            net.pose_stream = torch.cuda.Stream()          # (a HIGH-priority pose stream starves the critical path: 178 vs 213 images/s)
             if mode == "adapt" and os.environ.get("CODEPS_STREAMS", "1") != "1p":
                 net.branch_stream = torch.cuda.Stream()
         self.key_scale = {}             # per-loss re-weighting of a batch-sharded step with unequal shards (set_key_counts)
