@@ -145,6 +145,9 @@ SIGNATURES = {
     "codeps_cityscapes_labels_workspace_bytes": (c_size_t, []),
     "codeps_cityscapes_labels": (c_int, [P, P, I, I, I, I, P, ctypes.c_ulonglong, c_float, I, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_disparity_to_depth": (c_int, [P, I, I, I, I, c_float, P, P]),
+    "codeps_kitti360_labels": (c_int, [P, P, I, I, I, I, P, ctypes.c_ulonglong, c_float, I, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "codeps_lidar_depth_workspace_bytes": (c_size_t, [I, I]),
+    "codeps_lidar_depth": (c_int, [P, I, P, P, I, I, I, I, P, P, c_size_t, P]),
     "codeps_step_counter_add": (c_int, [P, c_uint64, P]),
     "codeps_depth_rule_state_floats": (c_size_t, [I]),
     "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, c_float, c_float, I, P, I, P, P]),

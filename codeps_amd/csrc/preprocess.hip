@@ -194,10 +194,13 @@ __device__ __forceinline__ int nearest_src(int dst, int src_size, int dst_size) 
 }
 
 // pass 1: maps + per-instance areas (open-addressing table of (id, count))
+// flavor 0 = Cityscapes (cityscapes.py:166-246: "iscrowd" instances dropped, centre weights = not ignore, offset weights = instance mask),
+// flavor 1 = KITTI-360 (kitti_360.py:252-300: every thing pixel is an instance pixel, centre and offset weights = thing mask)
 __global__ __launch_bounds__(256) void city_labels_kernel(const uint8_t* __restrict__ sem_ids, const uint16_t* __restrict__ inst_ids, int H, int W,
-                                                          int oh, int ow, LabelP P, uint8_t* __restrict__ sem, int* __restrict__ inst,
+                                                          int oh, int ow, LabelP P, int flavor, uint8_t* __restrict__ sem, int* __restrict__ inst,
                                                           uint8_t* __restrict__ thing, uint8_t* __restrict__ sem_w, uint8_t* __restrict__ center_w,
-                                                          uint8_t* __restrict__ offset_w, int* __restrict__ table /* [ISLOTS][2] */) {
+                                                          uint8_t* __restrict__ offset_w, uint8_t* __restrict__ sem_eval,
+                                                          int* __restrict__ table /* [ISLOTS][2] */) {
     const int total = oh * ow;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int y = i / ow, x = i % ow;
@@ -205,10 +208,13 @@ __global__ __launch_bounds__(256) void city_labels_kernel(const uint8_t* __restr
         const int s_raw = sem_ids[so], i_raw = inst_ids[so];
         const int sc = P.map[s_raw];
         const bool th = sc < 64 && ((P.thing_mask >> sc) & 1ull);
-        const bool msk = th && i_raw >= 1000;                                 // "remove iscrowd instances"
+        const bool msk = th && (flavor == 1 || i_raw >= 1000);                // Cityscapes: "remove iscrowd instances"
         const int ic = msk ? (int)(uint16_t)(sc * 1000 + (i_raw - s_raw * 1000)) : 0;
         sem[i] = (uint8_t)sc; inst[i] = ic; thing[i] = th ? 1 : 0;
-        sem_w[i] = sc == 255 ? 0 : 1; center_w[i] = sc == 255 ? 0 : 1; offset_w[i] = msk ? 1 : 0;
+        sem_w[i] = sc == 255 ? 0 : 1;
+        center_w[i] = flavor == 1 ? (th ? 1 : 0) : (sc == 255 ? 0 : 1);
+        offset_w[i] = flavor == 1 ? (th ? 1 : 0) : (msk ? 1 : 0);
+        if (sem_eval) sem_eval[i] = (uint8_t)sc;
         if (ic != 0) {
             unsigned slot = ((unsigned)ic * 2654435761u) >> 20;               // 12 bits
             for (int probe = 0; probe < ISLOTS; ++probe, slot = (slot + 1) & (ISLOTS - 1)) {
@@ -221,14 +227,19 @@ __global__ __launch_bounds__(256) void city_labels_kernel(const uint8_t* __restr
 
 // pass 2: pixels of instances smaller than the area threshold get the small-instance weight
 __global__ __launch_bounds__(256) void city_small_kernel(const int* __restrict__ inst, int total, const int* __restrict__ table, float small_area,
-                                                         int small_weight, uint8_t* __restrict__ sem_w) {
+                                                         int small_weight, uint8_t* __restrict__ sem_w, uint8_t* __restrict__ sem_eval) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int ic = inst[i];
         if (ic == 0) continue;
         unsigned slot = ((unsigned)ic * 2654435761u) >> 20;
         for (int probe = 0; probe < ISLOTS; ++probe, slot = (slot + 1) & (ISLOTS - 1)) {
             const int id = table[slot * 2];
-            if (id == ic) { if ((float)table[slot * 2 + 1] < small_area) sem_w[i] = (uint8_t)small_weight; break; }
+            if (id == ic) {
+                const float area = (float)table[slot * 2 + 1];
+                if (area < small_area) sem_w[i] = (uint8_t)small_weight;
+                if (sem_eval && area < small_area * .1f) sem_eval[i] = 255;           // kitti_360.py:283-285
+                break;
+            }
             if (id == 0) break;
         }
     }
@@ -241,6 +252,34 @@ __global__ __launch_bounds__(256) void disparity_depth_kernel(const uint16_t* __
         const int y = i / ow, x = i % ow;
         const float d = (float)disp[(size_t)nearest_src(y, H, oh) * W + nearest_src(x, W, ow)];
         depth[i] = d > 0.f ? bf / ((d - 1.f) / 256.f) : 0.f;
+    }
+}
+
+// KITTI-360 depth from the Velodyne sweep (kitti_360.py:303-330): project every point, keep 0 < depth < 80 inside the image, and let
+// the LAST point in file order win a pixel (numpy fancy-index assignment) -- a 64-bit atomicMax on (point index << 32 | depth bits).
+struct LidarP { double M[12]; double K[9]; };
+__global__ __launch_bounds__(256) void lidar_scatter_kernel(const float* __restrict__ pts, int n, LidarP P, int W, int H,
+                                                            unsigned long long* __restrict__ keys) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double x = pts[i * 4], y = pts[i * 4 + 1], z = pts[i * 4 + 2];
+        const double cx = P.M[0] * x + P.M[1] * y + P.M[2] * z + P.M[3], cy = P.M[4] * x + P.M[5] * y + P.M[6] * z + P.M[7];
+        const double cz = P.M[8] * x + P.M[9] * y + P.M[10] * z + P.M[11];
+        const double px = P.K[0] * cx + P.K[1] * cy + P.K[2] * cz, py = P.K[3] * cx + P.K[4] * cy + P.K[5] * cz;
+        double d = P.K[6] * cx + P.K[7] * cy + P.K[8] * cz;
+        if (d == 0.0) d = -1e-6;
+        const long long u = (long long)rint(px / fabs(d)), v = (long long)rint(py / fabs(d));      // np.round: half to even
+        if (u < 0 || u >= W || v < 0 || v >= H || !(d > 0.0) || !(d < 80.0)) continue;
+        const unsigned long long key = ((unsigned long long)(unsigned)(i + 1) << 32) | __float_as_uint((float)d);
+        atomicMax(keys + (size_t)v * W + u, key);
+    }
+}
+
+__global__ __launch_bounds__(256) void lidar_gather_kernel(const unsigned long long* __restrict__ keys, int H, int W, int oh, int ow,
+                                                           float* __restrict__ depth) {
+    const int total = oh * ow;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const unsigned long long k = keys[(size_t)nearest_src(i / ow, H, oh) * W + nearest_src(i % ow, W, ow)];
+        depth[i] = k ? __uint_as_float((unsigned)(k & 0xFFFFFFFFull)) : 0.f;
     }
 }
 
@@ -433,27 +472,67 @@ extern "C" int codeps_u8_to_tensor(const uint8_t* img, int batch, int h, int w, 
 
 extern "C" size_t codeps_cityscapes_labels_workspace_bytes(void) { return (size_t)ISLOTS * 2 * sizeof(int); }
 
-extern "C" int codeps_cityscapes_labels(const uint8_t* semantic_ids, const uint16_t* instance_ids, int h, int w, int out_h, int out_w,
-                                        const uint8_t* label_map256, unsigned long long thing_class_mask, float small_instance_area,
-                                        int small_instance_weight, uint8_t* semantic, int* instance, uint8_t* thing_mask, uint8_t* semantic_weights,
-                                        uint8_t* center_weights, uint8_t* offset_weights, void* workspace, size_t workspace_bytes,
-                                        codeps_stream_t stream) {
+static int label_maps(int flavor, const uint8_t* semantic_ids, const uint16_t* instance_ids, int h, int w, int out_h, int out_w,
+                      const uint8_t* label_map256, unsigned long long thing_class_mask, float small_instance_area, int small_instance_weight,
+                      uint8_t* semantic, int* instance, uint8_t* thing_mask, uint8_t* semantic_weights, uint8_t* center_weights,
+                      uint8_t* offset_weights, uint8_t* semantic_eval, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     CODEPS_REQUIRE(semantic_ids && instance_ids && label_map256 && semantic && instance && thing_mask && semantic_weights && center_weights &&
                        offset_weights && workspace && h > 0 && w > 0 && out_h > 0 && out_w > 0,
-                   CODEPS_ERR_ARG, "cityscapes_labels: bad arguments");
-    CODEPS_REQUIRE(workspace_bytes >= codeps_cityscapes_labels_workspace_bytes(), CODEPS_ERR_WORKSPACE, "cityscapes_labels: workspace too small");
+                   CODEPS_ERR_ARG, "label maps: bad arguments");
+    CODEPS_REQUIRE(workspace_bytes >= codeps_cityscapes_labels_workspace_bytes(), CODEPS_ERR_WORKSPACE, "label maps: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     LabelP P;
     memcpy(P.map, label_map256, 256);
     P.thing_mask = thing_class_mask;
     hipError_t e = hipMemsetAsync(workspace, 0, codeps_cityscapes_labels_workspace_bytes(), st);
-    CODEPS_REQUIRE(e == hipSuccess, CODEPS_ERR_LAUNCH, "cityscapes_labels: memset failed");
+    CODEPS_REQUIRE(e == hipSuccess, CODEPS_ERR_LAUNCH, "label maps: memset failed");
     const int total = out_h * out_w;
-    hipLaunchKernelGGL(city_labels_kernel, dim3(grid1(total)), dim3(256), 0, st, semantic_ids, instance_ids, h, w, out_h, out_w, P, semantic, instance,
-                       thing_mask, semantic_weights, center_weights, offset_weights, (int*)workspace);
+    hipLaunchKernelGGL(city_labels_kernel, dim3(grid1(total)), dim3(256), 0, st, semantic_ids, instance_ids, h, w, out_h, out_w, P, flavor, semantic,
+                       instance, thing_mask, semantic_weights, center_weights, offset_weights, semantic_eval, (int*)workspace);
     hipLaunchKernelGGL(city_small_kernel, dim3(grid1(total)), dim3(256), 0, st, (const int*)instance, total, (const int*)workspace, small_instance_area,
-                       small_instance_weight, semantic_weights);
-    CODEPS_CHECK_LAUNCH("cityscapes_labels kernels");
+                       small_instance_weight, semantic_weights, semantic_eval);
+    CODEPS_CHECK_LAUNCH("label map kernels");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_cityscapes_labels(const uint8_t* semantic_ids, const uint16_t* instance_ids, int h, int w, int out_h, int out_w,
+                                        const uint8_t* label_map256, unsigned long long thing_class_mask, float small_instance_area,
+                                        int small_instance_weight, uint8_t* semantic, int* instance, uint8_t* thing_mask, uint8_t* semantic_weights,
+                                        uint8_t* center_weights, uint8_t* offset_weights, void* workspace, size_t workspace_bytes,
+                                        codeps_stream_t stream) {
+    return label_maps(0, semantic_ids, instance_ids, h, w, out_h, out_w, label_map256, thing_class_mask, small_instance_area, small_instance_weight,
+                      semantic, instance, thing_mask, semantic_weights, center_weights, offset_weights, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int codeps_kitti360_labels(const uint8_t* semantic_ids, const uint16_t* instance_ids, int h, int w, int out_h, int out_w,
+                                      const uint8_t* label_map256, unsigned long long thing_class_mask, float small_instance_area,
+                                      int small_instance_weight, uint8_t* semantic, int* instance, uint8_t* thing_mask, uint8_t* semantic_weights,
+                                      uint8_t* center_weights, uint8_t* offset_weights, uint8_t* semantic_eval, void* workspace,
+                                      size_t workspace_bytes, codeps_stream_t stream) {
+    CODEPS_REQUIRE(semantic_eval, CODEPS_ERR_ARG, "kitti360_labels: semantic_eval is required");
+    return label_maps(1, semantic_ids, instance_ids, h, w, out_h, out_w, label_map256, thing_class_mask, small_instance_area, small_instance_weight,
+                      semantic, instance, thing_mask, semantic_weights, center_weights, offset_weights, semantic_eval, workspace, workspace_bytes,
+                      stream);
+}
+
+extern "C" size_t codeps_lidar_depth_workspace_bytes(int h, int w) { return h > 0 && w > 0 ? (size_t)h * w * sizeof(unsigned long long) : 0; }
+
+// points: device [n][4] fp32 (x, y, z, reflectance); lidar_to_rect: HOST double [3][4]; camera_matrix: HOST double [3][3].
+extern "C" int codeps_lidar_depth(const float* points, int n, const double* lidar_to_rect, const double* camera_matrix, int h, int w, int out_h,
+                                  int out_w, float* depth, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    CODEPS_REQUIRE(points && lidar_to_rect && camera_matrix && depth && workspace && n >= 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0, CODEPS_ERR_ARG,
+                   "lidar_depth: bad arguments");
+    CODEPS_REQUIRE(workspace_bytes >= codeps_lidar_depth_workspace_bytes(h, w), CODEPS_ERR_WORKSPACE, "lidar_depth: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    LidarP P;
+    for (int i = 0; i < 12; ++i) P.M[i] = lidar_to_rect[i];
+    for (int i = 0; i < 9; ++i) P.K[i] = camera_matrix[i];
+    hipError_t e = hipMemsetAsync(workspace, 0, codeps_lidar_depth_workspace_bytes(h, w), st);
+    CODEPS_REQUIRE(e == hipSuccess, CODEPS_ERR_LAUNCH, "lidar_depth: memset failed");
+    if (n > 0) hipLaunchKernelGGL(lidar_scatter_kernel, dim3(grid1(n)), dim3(256), 0, st, points, n, P, w, h, (unsigned long long*)workspace);
+    hipLaunchKernelGGL(lidar_gather_kernel, dim3(grid1((long long)out_h * out_w)), dim3(256), 0, st, (const unsigned long long*)workspace, h, w, out_h,
+                       out_w, depth);
+    CODEPS_CHECK_LAUNCH("lidar_depth kernels");
     return CODEPS_OK;
 }
 

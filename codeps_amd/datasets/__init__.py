@@ -3,3 +3,4 @@ from .mixup import Mixup  # noqa: F401
 from .replay_buffer import DiversityReplayBuffer  # noqa: F401
 from . import preprocessing  # noqa: F401
 from .cityscapes import Cityscapes  # noqa: F401
+from .kitti_360 import Kitti360  # noqa: F401

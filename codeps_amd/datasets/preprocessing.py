@@ -211,9 +211,37 @@ CITYSCAPES_TO_CITYSCAPES = [(7, 0), (8, 1), (11, 2), (12, 3), (13, 4), (17, 5), 
                             (25, 12), (26, 13), (27, 14), (28, 15), (31, 16), (32, 17), (33, 18)]    # cityscapes.py:266-289
 
 
+KITTI360_TO_CODEPS = [(7, 0), (8, 1), (11, 2), (34, 2), (12, 2), (13, 3), (35, 3), (17, 4), (37, 4), (20, 5), (21, 6), (22, 7), (23, 8), (24, 9),
+                      (25, 10), (26, 11), (27, 12), (32, 13), (33, 13)]                          # datasets/kitti_360.py:370-390
+KITTI360_TO_CITYSCAPES = CITYSCAPES_TO_CITYSCAPES + [(34, 2), (35, 4), (37, 5)]                 # kitti_360.py:342-367
+
+
+def kitti360_labels(semantic_ids, instance_ids, out_size, full_size, mapping=None, thing_classes=(9, 10, 11, 12, 13),
+                    small_instance_area_full_res: float = 4096, small_instance_weight: int = 3, sigma: float = 8.0):
+    """The label half of Kitti360.__getitem__ (datasets/kitti_360.py:236-300), incl. `semantic_eval`."""
+    return cityscapes_labels(semantic_ids, instance_ids, out_size, full_size, KITTI360_TO_CODEPS if mapping is None else mapping,
+                             thing_classes, small_instance_area_full_res, small_instance_weight, sigma, _kitti=True)
+
+
+def lidar_depth(points: torch.Tensor, lidar_to_rect, camera_matrix, full_size: Sequence[int], out_size: Sequence[int]) -> torch.Tensor:
+    """datasets/kitti_360.py:303-330: Velodyne points (device fp32 [N,4]) -> sparse depth [out_h,out_w] (fp32; the reference's
+    map is float64).  lidar_to_rect [>=3,4] / camera_matrix [3,>=3]: host arrays as `_read_lidar_to_rect` returns them."""
+    require_cuda(points)
+    pts = points.float().contiguous()
+    m = np.ascontiguousarray(np.asarray(lidar_to_rect, np.float64)[:3, :4])
+    k = np.ascontiguousarray(np.asarray(camera_matrix, np.float64)[:3, :3])
+    h, w = int(full_size[0]), int(full_size[1])
+    out = torch.empty(int(out_size[0]), int(out_size[1]), dtype=torch.float32, device=pts.device)
+    nbytes = lib().codeps_lidar_depth_workspace_bytes(h, w)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    check(lib().codeps_lidar_depth(ptr(pts), pts.shape[0], m.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p), h, w,
+                                   int(out_size[0]), int(out_size[1]), ptr(out), ptr(ws), nbytes, stream_ptr()), "codeps_lidar_depth")
+    return out
+
+
 def cityscapes_labels(semantic_ids: torch.Tensor, instance_ids: torch.Tensor, out_size: Sequence[int], full_size: Sequence[int],
                       mapping=None, thing_classes=(9, 10, 11, 12, 13), small_instance_area_full_res: float = 4096,
-                      small_instance_weight: int = 3, sigma: float = 8.0) -> Dict[str, torch.Tensor]:
+                      small_instance_weight: int = 3, sigma: float = 8.0, _kitti: bool = False) -> Dict[str, torch.Tensor]:
     """The label half of Cityscapes.__getitem__ (datasets/cityscapes.py:166-246): labelIds (uint8 [H,W]) and instanceIds
     (16-bit, any integer dtype [H,W]) at file resolution -> the network-resolution maps incl. centre heat map and offsets."""
     from .. import functional as F
@@ -235,10 +263,17 @@ def cityscapes_labels(semantic_ids: torch.Tensor, instance_ids: torch.Tensor, ou
     nbytes = lib().codeps_cityscapes_labels_workspace_bytes()
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     small = small_instance_area_full_res * (oh / full_size[0]) * (ow / full_size[1])
-    check(lib().codeps_cityscapes_labels(ptr(sem8), ptr(inst16), h, w, oh, ow, table.ctypes.data_as(ctypes.c_void_p), mask, float(small),
-                                         int(small_instance_weight), ptr(out["semantic"]), ptr(out["instance"]), ptr(out["thing_mask"]),
-                                         ptr(out["semantic_weights"]), ptr(out["center_weights"]), ptr(out["offset_weights"]), ptr(ws), nbytes,
-                                         stream_ptr()), "codeps_cityscapes_labels")
+    if _kitti:
+        out["semantic_eval"] = torch.empty(oh, ow, dtype=torch.uint8, device=dev)
+        check(lib().codeps_kitti360_labels(ptr(sem8), ptr(inst16), h, w, oh, ow, table.ctypes.data_as(ctypes.c_void_p), mask, float(small),
+                                           int(small_instance_weight), ptr(out["semantic"]), ptr(out["instance"]), ptr(out["thing_mask"]),
+                                           ptr(out["semantic_weights"]), ptr(out["center_weights"]), ptr(out["offset_weights"]),
+                                           ptr(out["semantic_eval"]), ptr(ws), nbytes, stream_ptr()), "codeps_kitti360_labels")
+    else:
+        check(lib().codeps_cityscapes_labels(ptr(sem8), ptr(inst16), h, w, oh, ow, table.ctypes.data_as(ctypes.c_void_p), mask, float(small),
+                                             int(small_instance_weight), ptr(out["semantic"]), ptr(out["instance"]), ptr(out["thing_mask"]),
+                                             ptr(out["semantic_weights"]), ptr(out["center_weights"]), ptr(out["offset_weights"]), ptr(ws), nbytes,
+                                             stream_ptr()), "codeps_cityscapes_labels")
     center, offset, _status = F.offset_center(out["instance"].unsqueeze(0), sigma)          # Dataset.get_offset_center on the device
     out["center"], out["offset"] = center[0], offset[0]
     return out

@@ -362,6 +362,18 @@ int codeps_cityscapes_labels(const uint8_t* semantic_ids, const uint16_t* instan
                              uint8_t* offset_weights, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 int codeps_disparity_to_depth(const uint16_t* disparity, int h, int w, int out_h, int out_w, float baseline_times_fx,
                               float* depth, codeps_stream_t stream);
+/* KITTI-360 flavour of the label path (datasets/kitti_360.py:236-300): every thing pixel is an instance pixel, centre and offset
+ * weights = thing mask, plus semantic_eval (instances below a tenth of the small-instance area -> 255).  codeps_lidar_depth:
+ * the Velodyne projection of kitti_360.py:303-330 (points [n][4] fp32 on the device; lidar_to_rect [3][4] and camera_matrix [3][3]
+ * HOST doubles; the last point in file order wins a pixel; nearest resize to [out_h][out_w]). */
+int codeps_kitti360_labels(const uint8_t* semantic_ids, const uint16_t* instance_ids, int h, int w, int out_h, int out_w,
+                           const uint8_t* label_map256, unsigned long long thing_class_mask, float small_instance_area,
+                           int small_instance_weight, uint8_t* semantic, int* instance, uint8_t* thing_mask,
+                           uint8_t* semantic_weights, uint8_t* center_weights, uint8_t* offset_weights,
+                           uint8_t* semantic_eval, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+size_t codeps_lidar_depth_workspace_bytes(int h, int w);
+int codeps_lidar_depth(const float* points, int n, const double* lidar_to_rect, const double* camera_matrix, int h, int w,
+                       int out_h, int out_w, float* depth, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Step control on the stream (csrc/step_ctl.hip): the per-frame decisions the reference takes on the

@@ -269,3 +269,53 @@ def disparity_to_depth(disparity_u16, fx, baseline, out_h, out_w):
     depth = np.zeros_like(d)
     depth[pos] = (baseline * fx) / d[pos]
     return nearest_resize(depth, out_h, out_w)
+
+
+KITTI360_TO_CODEPS = [(7, 0), (8, 1), (11, 2), (34, 2), (12, 2), (13, 3), (35, 3), (17, 4), (37, 4), (20, 5), (21, 6), (22, 7), (23, 8), (24, 9),
+                      (25, 10), (26, 11), (27, 12), (32, 13), (33, 13)]                       # kitti_360.py:370-390
+
+
+def kitti360_labels(semantic_ids, instance_ids, out_h, out_w, full_h, full_w, mapping=KITTI360_TO_CODEPS, things=CODEPS_THINGS,
+                    small_instance_area_full_res=4096, small_instance_weight=3):
+    """kitti_360.py:236-300 without the centre / offset maps: every thing pixel belongs to an instance, `semantic_eval` drops
+    instances below a tenth of the small-instance area, centre and offset weights are the thing mask."""
+    sem = nearest_resize(semantic_ids, out_h, out_w)
+    inst = nearest_resize(instance_ids, out_h, out_w)
+    sem_city = np.full_like(sem, 255, dtype=np.uint8)
+    for a, b in mapping:
+        sem_city[sem == a] = b
+    class_instance = inst.astype(np.int64) - sem.astype(np.int64) * 1000
+    thing = np.isin(sem_city, things)
+    inst_city = np.zeros(inst.shape, np.uint16)
+    inst_city[thing] = (sem_city[thing].astype(np.int64) * 1000 + class_instance[thing]).astype(np.uint16)
+    weights = np.ones(inst.shape, np.uint8)
+    weights[sem_city == 255] = 0
+    sem_eval = sem_city.copy()
+    small = small_instance_area_full_res * (out_h / full_h) * (out_w / full_w)
+    ids, areas = np.unique(inst_city, return_counts=True)
+    for i, a in zip(ids, areas):
+        if i == 0:
+            continue
+        if a < small:
+            weights[inst_city == i] = small_instance_weight
+        if a < small * .1:
+            sem_eval[inst_city == i] = 255
+    tm = thing.astype(np.uint8)
+    return {"semantic": sem_city, "semantic_eval": sem_eval, "semantic_weights": weights, "instance": inst_city.astype(np.int32),
+            "thing_mask": tm, "center_weights": tm[None], "offset_weights": tm[None]}
+
+
+def lidar_depth(points, lidar_to_rect, camera_matrix, full_h, full_w, out_h, out_w):
+    """kitti_360.py:303-330: Velodyne points [N,4] float32 -> sparse depth map at the network resolution."""
+    pcl = points.astype(np.float32).reshape(-1, 4).copy()
+    pcl[:, 3] = 1
+    cam = (lidar_to_rect @ pcl.T).T[:, :3].T[None]
+    proj = camera_matrix[:3, :3].reshape(1, 3, 3) @ cam
+    depth = proj[:, 2, :]
+    depth[depth == 0] = -1e-6
+    u = np.round(proj[:, 0, :] / np.abs(depth)).astype(int)
+    v = np.round(proj[:, 1, :] / np.abs(depth)).astype(int)
+    dm = np.zeros((full_h, full_w))
+    mask = (u >= 0) & (u < full_w) & (v >= 0) & (v < full_h) & (depth > 0) & (depth < 80)
+    dm[v[mask], u[mask]] = depth[mask]
+    return nearest_resize(dm, out_h, out_w)

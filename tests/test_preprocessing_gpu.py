@@ -203,3 +203,67 @@ def test_cityscapes_dataset_item_from_png_files(tmp_path):
     assert item["rgb"][0].shape == (3, oh, ow) and np.array_equal(item["rgb"][0].cpu().numpy(), ref)
     sem_ref = want["semantic"][:, ::-1] if flip else want["semantic"]
     assert np.array_equal(item["semantic"].cpu().numpy(), sem_ref)
+
+
+def test_kitti360_dataset_item_from_files(tmp_path):
+    """A miniature KITTI-360 tree (frame list, raw images, semantic / instance PNGs, calibration, one Velodyne sweep) through
+    `Kitti360.__getitem__` == the oracle's restatement of datasets/kitti_360.py:183-338 on the decoded arrays."""
+    from PIL import Image
+    from codeps_amd.config import CfgNode
+    from codeps_amd.datasets import Kitti360
+    rng = np.random.default_rng(21)
+    h, w, oh, ow = 96, 256, 48, 128
+    seq = "2013_05_28_drive_0000_sync"
+    raw = tmp_path / "data_2d_raw" / seq / "image_00" / "data_rect"
+    semd = tmp_path / "data_2d_semantics" / "train" / seq / "image_00" / "semantic"
+    insd = tmp_path / "data_2d_semantics" / "train" / seq / "image_00" / "instance"
+    velo = tmp_path / "data_3d_raw" / seq / "velodyne_points" / "data"
+    for d in (raw, semd, insd, velo, tmp_path / "calibration"):
+        d.mkdir(parents=True)
+    frames = {}
+    for n in (249, 250, 251):
+        frames[n] = _img(h, w, 40 + n)
+        Image.fromarray(frames[n]).save(raw / f"{n:010d}.png")
+    sem = np.kron(rng.choice([7, 8, 11, 34, 35, 37, 21, 23, 24, 26, 33, 1], size=(h // 16, w // 16)), np.ones((16, 16))).astype(np.uint8)
+    k = np.kron(rng.integers(0, 3, (h // 8, w // 8)), np.ones((8, 8))).astype(np.int32)
+    inst = (sem.astype(np.int32) * 1000 + k).astype(np.uint16)
+    inst[40:42, 100:103] = 26 * 1000 + 7
+    sem[40:42, 100:103] = 26                                                      # a 6-pixel instance: dropped from semantic_eval
+    Image.fromarray(sem).save(semd / "0000000250.png")
+    Image.fromarray(inst).save(insd / "0000000250.png")
+    (tmp_path / "data_2d_semantics" / "train" / "2013_05_28_drive_train_frames.txt").write_text(
+        f"data_2d_raw/{seq}/image_00/data_rect/0000000250.png data_2d_semantics/train/{seq}/image_00/semantic/0000000250.png\n")
+    fx, fy, cx, cy = 180.0, 182.0, 127.3, 47.6
+    (tmp_path / "calibration" / "perspective.txt").write_text(
+        f"S_rect_00: {w} {h}\nR_rect_00: 0.9999 0.01 -0.005 -0.01 0.9999 0.003 0.005 -0.003 0.9999\n"
+        f"P_rect_00: {fx} 0.0 {cx} 0.0 0.0 {fy} {cy} 0.0 0.0 0.0 1.0 0.0\n")
+    (tmp_path / "calibration" / "calib_cam_to_velo.txt").write_text("0.04 -0.99 0.02 0.26 -0.03 -0.02 -0.99 -0.11 0.99 0.04 -0.03 -0.83\n")
+    pts = np.concatenate([rng.uniform(2, 60, (4000, 1)), rng.uniform(-20, 20, (4000, 1)), rng.uniform(-2, 1, (4000, 1)), rng.random((4000, 1))], 1)
+    pts.astype(np.float32).tofile(velo / "0000000250.bin")
+    cfg = CfgNode(name="kitti_360", path=str(tmp_path), feed_img_size=[oh, ow], offsets=[1], center_heatmap_sigma=8, small_instance_weight=3,
+                  small_instance_area_full_res=800, remove_classes=[],
+                  augmentation=CfgNode(active=False), normalization=CfgNode(active=True, rgb_mean=(0.485, 0.456, 0.406), rgb_std=(0.229, 0.224, 0.225)))
+    ds = Kitti360("train", cfg, return_depth=True, device=DEV)
+    assert len(ds) == 1
+    # a sweep whose points land inside the image: camera-frame points of random pixels / depths taken back to the Velodyne frame
+    n = 3000
+    dpt = rng.uniform(1.0, 95.0, n)                                               # some beyond the 80 m cut
+    uv = np.stack([rng.uniform(-10, w + 10, n), rng.uniform(-5, h + 5, n)], 1)     # some outside the image
+    cam = np.stack([(uv[:, 0] - cx) / fx * dpt, (uv[:, 1] - cy) / fy * dpt, dpt, np.ones(n)], 1)
+    velo_pts = (np.linalg.inv(ds.lidar_to_rect) @ cam.T).T
+    velo_pts[:, 3] = rng.random(n)
+    velo_pts.astype(np.float32).tofile(velo / "0000000250.bin")
+    item = ds.__getitem__(0, do_network_preparation=False)
+    for off, n in ((-1, 249), (0, 250), (1, 251)):
+        assert np.array_equal(item["rgb"][off].cpu().numpy(), op.lanczos_resize(frames[n], oh, ow)), off
+    want = op.kitti360_labels(sem, inst, oh, ow, h, w, small_instance_area_full_res=800)
+    for key, v in want.items():
+        assert np.array_equal(item[key].cpu().numpy(), v), key
+    assert (want["semantic_eval"] != want["semantic"]).any() and (want["semantic_weights"] == 3).any()
+    assert np.allclose(item["camera_model"].numpy(), [fx * ow / w, fy * oh / h, cx * ow / w, cy * oh / h])
+    d_ref = op.lidar_depth(np.fromfile(velo / "0000000250.bin", dtype=np.float32), ds.lidar_to_rect, ds.camera_matrix, h, w, oh, ow)
+    d = item["depth"].cpu().numpy()
+    assert (d_ref > 0).sum() > 50 and np.array_equal(d > 0, d_ref > 0)
+    assert np.allclose(d, d_ref.astype(np.float32), rtol=1e-6, atol=0)
+    ten = ds[0]["rgb"][0]
+    assert ten.shape == (3, oh, ow) and ten.dtype == torch.float32
