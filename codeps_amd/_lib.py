@@ -153,6 +153,8 @@ SIGNATURES = {
     "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, c_float, c_float, I, P, I, P, P]),
     "codeps_weighted_sum_fwd": (c_int, [P, P, P, I, P, P, P]),
     "codeps_weighted_sum_bwd": (c_int, [P, P, P, I, P, P, P]),
+    "codeps_diag_mfma_rate": (c_int, [I, I, I, I, I, P, P, P, P]),
+    "codeps_diag_stream_triad": (c_int, [P, P, P, LL, I, P, P]),
 }
 
 

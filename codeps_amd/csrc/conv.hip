@@ -2167,7 +2167,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
             return;
         }
-        static const int ws_min = getenv("CODEPS_WS_MIN") ? atoi(getenv("CODEPS_WS_MIN")) : 48;      // K-steps from which the wave-specialised kernel runs
+        static const int ws_min = getenv("CODEPS_WS_MIN") ? atoi(getenv("CODEPS_WS_MIN")) : 32;      // K-steps from which the wave-specialised kernel runs
         const int ntap_ = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
         const int Kc_ = (MODE == MODE_FWD) ? p.Ct : p.Co, nsteps_ = ntap_ * (Kc_ / BK);
         // ... and whose grid is a single round of one block per CU: the block owns the CU (111 KB of LDS), so a second round
@@ -2283,10 +2283,10 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
     } while (0)
     if (p.N > 64) {
         static const float pen1 = getenv("CODEPS_PEN1") ? atof(getenv("CODEPS_PEN1")) : 1.1f, pen2 = getenv("CODEPS_PEN2") ? atof(getenv("CODEPS_PEN2")) : 1.3f;   // tuning experiments only
-        // short K (<= 32 K-steps, the 1x1 layers): a single round of 128x128 blocks runs its prologue / epilogue phases in lock-step
+        // short K (< 32 K-steps, the 1x1 layers): a single round of 128x128 blocks runs its prologue / epilogue phases in lock-step
         // on every CU; twice as many 128x64 blocks desynchronise and overlap them (measured -0.5 ms per step)
         static const float pens = getenv("CODEPS_PENS") ? atof(getenv("CODEPS_PENS")) : 0.5f;
-        static const int shortk = getenv("CODEPS_SHORTK") ? atoi(getenv("CODEPS_SHORTK")) : 32;
+        static const int shortk = getenv("CODEPS_SHORTK") ? atoi(getenv("CODEPS_SHORTK")) : 31;       // 32-step 1x1 layers (K = 1024, N = 256): one round of 128x128 blocks on the wave-specialised kernel, 57 vs 62 us
         const TileOpt o[3] = {{128, 128, 1.0f}, {128, 64, nsteps32 <= shortk ? pens : pen1}, {64, 64, pen2}};
         switch (pick_tile(p, o, 3, nsteps32)) {
             case 0: IG(2, 2, 2, 2); break;

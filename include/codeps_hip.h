@@ -523,6 +523,18 @@ int codeps_panoptic_stats(const int* pan_gt, const int* pan_pred, int batch, int
                           int num_categories, double* iou, int* tp_fp_fn, int* status, void* workspace, size_t workspace_bytes,
                           codeps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Diagnostics (csrc/diag.hip): the two rooflines of SURVEY.md 8d as THIS box delivers them -- bench.py reports them beside the
+ * vendor figures.  Both time `reps` launches with HIP events on `stream` and return milliseconds per launch.
+ * codeps_diag_mfma_rate: register-resident MFMA loop, no memory traffic (mode 0 v_mfma_f32_32x32x16_bf16, 1 v_mfma_f32_32x32x2_f32,
+ *   2 v_mfma_f32_16x16x32_bf16; random_data 0: zero operands, 1: operand fragments that change between consecutive MFMAs);
+ *   blocks of 256 threads, 16 * iters MFMAs per wave; scratch float [blocks * 256]; *flops_per_launch = the FLOPs of one launch.
+ * codeps_diag_stream_triad: a[i] = b[i] + 1.5 c[i], n floats (n % 4 == 0): 12 n bytes of HBM traffic per launch. */
+int codeps_diag_mfma_rate(int mode, int random_data, int blocks, int iters, int reps, float* scratch, double* flops_per_launch,
+                          float* ms_per_launch, codeps_stream_t stream);
+int codeps_diag_stream_triad(float* a, const float* b, const float* c, long long n, int reps, float* ms_per_launch,
+                             codeps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
