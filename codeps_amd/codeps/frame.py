@@ -36,32 +36,61 @@ def _same_frozen_encoder(a, b) -> bool:
 
 def pre_step(model, ema_model, ema_modules: List[str], sample: Dict[str, Dict[str, Any]], rgb_frame_offsets: List[int],
              do_panoptic_fusion: bool, do_class_wise_depth_stats: bool = False,
-             share_encoder: bool = True) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+             share_encoder: bool = True, batch_encoder: bool = True, needed_heads_only: bool = True) -> Tuple[Dict[str, Any], Dict[str, Any]]:
     """-> (results_eval, stats_eval) of the target frame; fills `semantic_pred_tgt_ema`, `center_pred_tgt_ema`,
     `offset_pred_tgt_ema` of every `*mixup` item in place, exactly as scripts/adapt_codeps.py:164-199 does.
-    `model` is left in whatever train / eval state it is in (the reference does not switch the student here)."""
+    `model` is left in whatever train / eval state it is in (the reference does not switch the student here).
+
+    Three things the reference's call sequence leaves on the table (each switchable, results unchanged):
+      share_encoder      teacher and student hold the same frozen encoder -> it runs once per mix-up batch, not twice;
+      batch_encoder      ... and the target frame joins that pass when it has the mix-up images' size (one B = 1 + n launch
+                         sequence instead of a B = 1 and a B = n one; the convolution kernels then tile / split K for the
+                         larger batch, so values agree to fp32 rounding rather than bit for bit);
+      needed_heads_only  the passes over the mix-up items evaluate the heads whose predictions are kept (teacher: semantic,
+                         plus instance when it is EMA-filtered; student: instance), not all three."""
     mixup_keys = [k for k in sample if k.endswith("mixup")]
     shared: Dict[str, Optional[List[torch.Tensor]]] = {k: None for k in mixup_keys}
+    teacher_heads = student_heads = None
+    if needed_heads_only:
+        teacher_heads = tuple(h for h, on in (("semantic", "semantic_head" in ema_modules or "instance_head" in ema_modules),
+                                              ("instance", "instance_head" in ema_modules)) if on)
+        student_heads = ("instance",)
     with torch.no_grad():
         if ema_model is not None:
             ema_model.eval()
-            results_eval, stats_eval = ema_model(sample["target"], "eval", rgb_frame_offsets, do_panoptic_fusion,
-                                                 do_class_wise_depth_stats)[1:]
             student_needs = "instance_head" not in ema_modules
-            share = share_encoder and student_needs and bool(mixup_keys) and _same_frozen_encoder(model, ema_model)
+            same_enc = share_encoder and bool(mixup_keys) and _same_frozen_encoder(model, ema_model)
+            share = same_enc and student_needs
+            tgt = sample["target"]
+            tgt_rgb = tgt["rgb" if "rgb" in tgt else "rgb_tgt"][0]
+            mix_rgb = {k: sample[k]["rgb" if "rgb" in sample[k] else "rgb_tgt"][0] for k in mixup_keys}
+            tgt_feats = None
+            joined = [k for k in mixup_keys if mix_rgb[k].shape[1:] == tgt_rgb.shape[1:]] if (batch_encoder and share_encoder) else []
+            if joined:                                      # one encoder pass over the target frame and the mix-up images
+                cat = torch.cat([tgt_rgb] + [mix_rgb[k] for k in joined], 0)
+                feats_all = ema_model.backbone_po_depth(cat)
+                n0 = tgt_rgb.shape[0]
+                tgt_feats = [f[:n0] for f in feats_all]
+                for k in joined:
+                    n1 = n0 + mix_rgb[k].shape[0]
+                    shared[k] = [f[n0:n1] for f in feats_all]
+                    n0 = n1
+            results_eval, stats_eval = ema_model(tgt, "eval", rgb_frame_offsets, do_panoptic_fusion,
+                                                 do_class_wise_depth_stats, feats=tgt_feats)[1:]
             for key in mixup_keys:
                 item = sample[key]
-                feats = None
-                if share:                                   # one encoder pass per mix-up batch for teacher AND student
-                    key_rgb = "rgb" if "rgb" in item else "rgb_tgt"
-                    feats = ema_model.backbone_po_depth(item[key_rgb][0])
-                    shared[key] = feats
-                res = ema_model(item, "eval", rgb_frame_offsets, False, False, feats=feats)[1]
-                if "semantic_head" in ema_modules or "instance_head" in ema_modules:
-                    item["semantic_pred_tgt_ema"] = res["semantic"].detach().clone()
-                if "instance_head" in ema_modules:
-                    item["center_pred_tgt_ema"] = res["center"].detach().clone()
-                    item["offset_pred_tgt_ema"] = res["offset"].detach().clone()
+                feats = shared[key]
+                if feats is None and share:                 # one encoder pass per mix-up batch for teacher AND student
+                    feats = shared[key] = ema_model.backbone_po_depth(mix_rgb[key])
+                if teacher_heads is None or teacher_heads:
+                    res = ema_model(item, "eval", rgb_frame_offsets, False, False, feats=feats, heads=teacher_heads)[1]
+                    if "semantic_head" in ema_modules or "instance_head" in ema_modules:
+                        item["semantic_pred_tgt_ema"] = res["semantic"].detach().clone()
+                    if "instance_head" in ema_modules:
+                        item["center_pred_tgt_ema"] = res["center"].detach().clone()
+                        item["offset_pred_tgt_ema"] = res["offset"].detach().clone()
+                if not (same_enc and student_needs):
+                    shared[key] = None                      # the student's encoder differs: it runs its own
         else:
             model.eval()
             results_eval, stats_eval = model(sample["target"], "eval", rgb_frame_offsets, do_panoptic_fusion,
@@ -72,7 +101,7 @@ def pre_step(model, ema_model, ema_modules: List[str], sample: Dict[str, Dict[st
         with torch.no_grad():
             for key in mixup_keys:
                 item = sample[key]
-                res = model(item, "eval", rgb_frame_offsets, False, False, feats=shared[key])[1]
+                res = model(item, "eval", rgb_frame_offsets, False, False, feats=shared[key], heads=student_heads)[1]
                 item["center_pred_tgt_ema"] = res["center"].detach().clone()
                 item["offset_pred_tgt_ema"] = res["offset"].detach().clone()
     return results_eval, stats_eval

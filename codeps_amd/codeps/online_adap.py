@@ -11,7 +11,7 @@ state-dict export).  Differences, all result-neutral for losses / gradients (SUR
 """
 import copy
 from collections import OrderedDict
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -90,9 +90,12 @@ class CodepsNet(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, in_data: Dict[str, Any], mode: str = "infer", depth_offsets: Optional[List[int]] = None,
                 do_panoptic_fusion: bool = False, do_class_wise_depth_stats: bool = False,
-                sem_ignore_classes: Optional[List[int]] = None, feats: Optional[List[Tensor]] = None):
+                sem_ignore_classes: Optional[List[int]] = None, feats: Optional[List[Tensor]] = None,
+                heads: Optional[Tuple[str, ...]] = None):
         """feats ("eval" / "infer" only, not in the reference): the shared encoder's features of the centre frame computed
-        by the caller, so that a teacher and a student with the same frozen encoder run it once (codeps.frame.pre_step)."""
+        by the caller, so that a teacher and a student with the same frozen encoder run it once (codeps.frame.pre_step).
+        heads ("eval" / "infer" only, not in the reference): subset of ("depth", "semantic", "instance") to evaluate -- the
+        per-frame passes over the mix-up items consume one head's predictions each; None = all, as the reference does."""
         assert mode in ["train", "eval", "infer", "adapt"], f"Unsupported mode: {mode}"
         if mode == "adapt":
             return self.adapt(in_data, depth_offsets, do_panoptic_fusion)
@@ -143,20 +146,21 @@ class CodepsNet(nn.Module):
         else:       # eval / infer: predictions (and statistics) only
             key_rgb = "rgb" if "rgb" in in_data else "rgb_tgt"
             feats0 = feats if feats is not None else self.backbone_po_depth(in_data[key_rgb][0])
-            if self.depth_algo is not None:
+            want = (lambda h: True) if heads is None else (lambda h: h in heads)
+            if self.depth_algo is not None and want("depth"):
                 depth_gt = in_data.get("depth") if mode == "eval" else None
                 if depth_gt is None:
                     R["depth"] = self.depth_algo.inference(feats0, self.depth_head)
                 else:
                     depth_stats, R["depth"] = self.depth_algo.evaluation(feats0, self.depth_head, depth_gt)
-            if self.semantic_algo is not None:
+            if self.semantic_algo is not None and want("semantic"):
                 semantic_gt = in_data.get("semantic") if mode == "eval" else None
                 if semantic_gt is None:
                     R["semantic"], R["semantic_soft"] = self.semantic_algo.inference(feats0, self.semantic_head)
                 else:
                     stats["sem_conf"], R["semantic"], R["semantic_soft"] = self.semantic_algo.evaluation(
                         feats0, self.semantic_head, in_data.get("semantic_eval", semantic_gt))
-            if self.instance_algo is not None:
+            if self.instance_algo is not None and want("instance"):
                 R["center"], R["offset"], R["thing_mask"] = self.instance_algo.inference(feats0, self.instance_head)
                 if mode == "infer" and not self.instance_head.use_thing_mask:
                     R["thing_mask"] = None
