@@ -76,6 +76,43 @@ class FlatState:
             off += k
         self.ema = self.flat.clone() if with_ema else None
         self.numel = n
+        self.offsets = [0]
+        for p in params:
+            self.offsets.append(self.offsets[-1] + p.numel())
+        # torch.optim.Adam keeps one step count per parameter and skips parameters whose .grad is None (the reference zeroes
+        # with set_to_none): `steps` is that count -- an int while every parameter has received every step, else a list
+        self.steps = 0
+
+    def adam(self, touched, lr, grad_scale, ema_alpha, apply_ema):
+        """One optimizer step.  touched: None (every parameter has a gradient) or one bool per parameter -- the parameters the
+        step's losses reach; the others keep value, moments and step count, exactly as torch.optim.Adam treats grad None
+        (scripts/adapt_codeps.py:289-291).  The EMA teacher filter runs over every parameter either way (online_adap.py:279-289)."""
+        ema = self.ema if apply_ema else None
+        if (touched is None or all(touched)) and isinstance(self.steps, int):
+            self.steps += 1
+            F.adam_ema_step(self.flat, self.grad, self.m, self.v, self.steps, lr=lr, grad_scale=grad_scale, ema_params=ema, ema_alpha=ema_alpha)
+            return
+        n = len(self.params)
+        if isinstance(self.steps, int):
+            self.steps = [self.steps] * n
+        touched = [True] * n if touched is None else list(touched)
+        i = 0
+        while i < n:                                       # runs of neighbouring parameters with the same fate and step count
+            j = i + 1
+            while j < n and touched[j] == touched[i] and self.steps[j] == self.steps[i]:
+                j += 1
+            a, b = self.offsets[i], self.offsets[j]
+            if touched[i]:
+                step = self.steps[i] + 1
+                for k in range(i, j):
+                    self.steps[k] = step
+                F.adam_ema_step(self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b], step, lr=lr, grad_scale=grad_scale,
+                                ema_params=None if ema is None else ema[a:b], ema_alpha=ema_alpha)
+            elif ema is not None:
+                ema[a:b].mul_(ema_alpha).add_(self.flat[a:b], alpha=1.0 - ema_alpha)
+            i = j
+        if len(set(self.steps)) == 1:
+            self.steps = self.steps[0]
 
 
 def _mark_conv_biases(net):
@@ -133,6 +170,9 @@ class StepRunner:
             if mode == "adapt" and os.environ.get("CODEPS_STREAMS", "1") != "1p":
                 net.branch_stream = torch.cuda.Stream()
         self.key_scale = {}             # per-loss re-weighting of a batch-sharded step with unequal shards (set_key_counts)
+        self._reach_cache = {}          # active losses -> per group, which parameters the backward pass reaches
+        self._unequal_shards = False
+        self._touched = None
 
     def set_key_counts(self, items, rank):
         """Batch-sharded step whose ranks hold DIFFERENT numbers of items per key (BASELINE configs[3], SURVEY.md 8d: ranks
@@ -143,6 +183,7 @@ class StepRunner:
         target item.  Equal shards need none of this (the plain DDP mean is exact)."""
         world = self.world
         assert all(len(v) == world for v in items.values()), "one item count per rank and key"
+        self._unequal_shards = True
         h, w = self.cfg.dataset.feed_img_size
         hs, ws = self.cfg.adapt.source_dataset.feed_img_size
         res = {k: ((hs, ws) if k == "source" or k.endswith("mixup") else (h, w)) for k in items}
@@ -177,6 +218,7 @@ class StepRunner:
             terms.append(v)
             wts.append(float(w) * self.key_scale.get(k, 1.0))
         total = F.weighted_sum(terms, wts)
+        self._touched = self._reached(tuple(k for k, v in losses.items() if any(v is t for t in terms)), total)
         total.backward()
         for side in (getattr(self.net, "pose_stream", None), getattr(self.net, "branch_stream", None)):
             if side is not None:      # the gradient sinks are written by kernels autograd does not track: join the side streams by hand
@@ -185,14 +227,37 @@ class StepRunner:
             F.build_pack_table()                 # the first step created every layer's persistent pack buffers: table them
         return total.detach(), losses, result
 
+    def _reached(self, active, total):
+        """Which parameters receive a gradient from this step's losses (one bool per parameter and group; None = all).  A
+        property of the autograd graph, not of the values: the graph is walked once per set of active losses.  The conv / BN
+        kernels write their weight gradients straight into the flat buffer, but the weights are inputs of the autograd
+        Functions that launch them, so they appear as leaves of the graph like any other parameter.  Batch-sharded steps whose
+        ranks hold different keys (set_key_counts) would need the union over ranks: they treat every parameter as reached."""
+        if self.world > 1 and self._unequal_shards:
+            return None
+        hit = self._reach_cache.get(active)
+        if hit is None:
+            seen, found, stack = set(), set(), [total.grad_fn]
+            while stack:
+                fn = stack.pop()
+                if fn is None or fn in seen:
+                    continue
+                seen.add(fn)
+                var = getattr(fn, "variable", None)
+                if var is not None:
+                    found.add(id(var))
+                stack.extend(nf for nf, _ in fn.next_functions)
+            masks = [[id(p) in found for p in g.params] for g in self.groups]
+            hit = self._reach_cache[active] = (None if all(all(m) for m in masks) else masks,)
+        return hit[0]
+
     def optimizer_step(self, apply_ema=True):
         """One all-reduce + fused Adam per flat group.  apply_ema False leaves the EMA copy alone: the reference filters the
         teacher once per FRAME, after its `nof_adaptation_steps` optimizer steps (scripts/adapt_codeps.py:266-299)."""
         self.step_count += 1
-        for g in self.groups:
+        for i, g in enumerate(self.groups):
             allreduce_flat_gradients(g.grad, self.group)
-            F.adam_ema_step(g.flat, g.grad, g.m, g.v, self.step_count, lr=self.lr, grad_scale=1.0 / self.world,
-                            ema_params=g.ema if apply_ema else None, ema_alpha=self.ema_alpha)
+            g.adam(None if self._touched is None else self._touched[i], self.lr, 1.0 / self.world, self.ema_alpha, apply_ema)
 
     def step(self, data, apply_ema=True):
         out = self.forward_backward(data)
