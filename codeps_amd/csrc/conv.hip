@@ -1973,30 +1973,50 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
     return s;
 }
 
-// sum the split slabs and scatter into the OIHW gradient: dw[co][ci][ky][kx] (+= if accumulate)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int Co, int Ct,
-                                                           int taps, int co_real, int ci_real, float* __restrict__ dw,
-                                                           int accumulate) {
-    const long long total = (long long)Co * Ct * taps;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        // i enumerates the packed (channel-padded) layout [co][tap][ci] (coalesced reads)
-        const int ci = (int)(i % Ct);
-        const int tap = (int)((i / Ct) % taps);
-        const int co = (int)(i / ((long long)Ct * taps));
-        if (co >= co_real || ci >= ci_real) continue;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;            // 4 independent chains (fixed order -> deterministic)
-        int s = 0;
-        for (; s + 3 < splits; s += 4) {
-            a0 += part[(size_t)s * total + i];
-            a1 += part[(size_t)(s + 1) * total + i];
-            a2 += part[(size_t)(s + 2) * total + i];
-            a3 += part[(size_t)(s + 3) * total + i];
-        }
-        for (; s < splits; ++s) a0 += part[(size_t)s * total + i];
-        const float a = (a0 + a1) + (a2 + a3);
-        const size_t o = ((size_t)co * ci_real + ci) * taps + tap;
-        dw[o] = accumulate ? dw[o] + a : a;
+// sum the split slabs and scatter into the OIHW gradient: dw[co][ci][ky][kx] (+= if accumulate).
+// The slabs are [split][co][tap][ci] with ci padded to a multiple of 16: a thread owns four neighbouring ci of one (co, tap) and
+// every SG-th slab (16-byte loads, four in flight), the SG partial sums of a column meet in LDS in a fixed order -- the layers
+// with one 64 x 64 channel tile have 256 slabs of 36 864 elements, where one thread per element walked 256 slabs alone.
+template <int SG>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ part, int splits, long long total4, int Ct,
+                                                           int taps, int co_real, int ci_real, float* __restrict__ dw, int accumulate) {
+    constexpr int IL = 256 / SG;                       // float4 columns per block
+    __shared__ f32x4 red[SG][IL];
+    const int il = threadIdx.x % IL, sg = threadIdx.x / IL;
+    const long long i4 = (long long)blockIdx.x * IL + il;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < total4) {
+#pragma unroll 4
+        for (int s = sg; s < splits; s += SG) a += part[(size_t)s * total4 + i4];
     }
+    red[sg][il] = a;
+    __syncthreads();
+    if (sg != 0 || i4 >= total4) return;
+#pragma unroll
+    for (int k = 1; k < SG; ++k) a += red[k][il];
+    const long long i = i4 * 4;
+    const int ci = (int)(i % Ct);
+    const int tap = (int)((i / Ct) % taps);
+    const int co = (int)(i / ((long long)Ct * taps));
+    if (co >= co_real) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (ci + e >= ci_real) break;
+        const size_t o = ((size_t)co * ci_real + ci + e) * taps + tap;
+        dw[o] = accumulate ? dw[o] + a[e] : a[e];
+    }
+}
+
+static void launch_wgrad_reduce(const float* part, int splits, int Co, int Ct, int taps, int co_real, int ci_real, float* dw, int accumulate,
+                                hipStream_t st) {
+    const long long total4 = (long long)Co * Ct * taps / 4;      // Ct is a multiple of 16
+    // few columns and many slabs: 16 slab groups per block (16 columns), else 4 (64 columns)
+    if (total4 / 64 < 1024 && splits >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((int)((total4 + 15) / 16)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(part), splits,
+                           total4, Ct, taps, co_real, ci_real, dw, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((int)((total4 + 63) / 64)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(part), splits,
+                           total4, Ct, taps, co_real, ci_real, dw, accumulate);
 }
 
 // OIHW -> forward pack [co][tap][ci] and dgrad pack [ci][tap][co]
@@ -2563,8 +2583,8 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
 #undef WS_LAUNCH
         CODEPS_CHECK_LAUNCH("wgrad_small_kernel");
         const long long total = (long long)d->out_c * (d->c0 + d->c1) * d->kh * d->kw;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, part, splits,
-                           d->out_c, d->c0 + d->c1, d->kh * d->kw, out_c_real, in_c_real, dw_oihw, accumulate);
+        (void)total;
+        launch_wgrad_reduce(part, splits, d->out_c, d->c0 + d->c1, d->kh * d->kw, out_c_real, in_c_real, dw_oihw, accumulate, st);
         CODEPS_CHECK_LAUNCH("wgrad_reduce_kernel");
         return CODEPS_OK;
     }
@@ -2587,8 +2607,8 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
 #undef WG_LAUNCH
     CODEPS_CHECK_LAUNCH("conv_wgrad_kernel");
     const long long total = (long long)d->out_c * (d->c0 + d->c1) * d->kh * d->kw;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, part, splits,
-                       d->out_c, d->c0 + d->c1, d->kh * d->kw, out_c_real, in_c_real, dw_oihw, accumulate);
+    (void)total;
+    launch_wgrad_reduce(part, splits, d->out_c, d->c0 + d->c1, d->kh * d->kw, out_c_real, in_c_real, dw_oihw, accumulate, st);
     CODEPS_CHECK_LAUNCH("wgrad_reduce_kernel");
     return CODEPS_OK;
 }

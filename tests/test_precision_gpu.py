@@ -90,7 +90,8 @@ CASES = {
     "halo3_128": (2, 64, 128, 128, 128, 3, "conv_halo3_kernel", "conv_halo3_kernel", "wgrad_halo64s_kernel"),
     "ws_3x3_256": (7, 32, 64, 256, 256, 3, "conv_igemm_ws_kernel", "conv_igemm_ws_kernel", None),
     "ws_1x1_2048": (4, 32, 64, 2048, 512, 1, "conv_igemm_ws_kernel", None, None),
-    "igemm_1x1": (8, 32, 64, 256, 1024, 1, "conv_igemm_kernel<split3>", "conv_igemm_kernel<split3>", None),
+    "igemm_1x1": (8, 32, 64, 256, 1024, 1, "conv_igemm_kernel<split3>", "conv_igemm_ws_kernel", None),      # dgrad: K = 1024, one round of 128x128 blocks
+    "igemm_1x1_dgrad": (8, 32, 64, 512, 2048, 1, "conv_igemm_kernel<split3>", "conv_igemm_kernel<split3>", None),
 }
 
 
