@@ -45,6 +45,9 @@ def train_forward(sds, cfg, sample, noise=None, do_panoptic=True):
     out["depth_recon"] = losses.reconstruction_loss(sample["camera_model"], (rgb[0], rgb[-1], rgb[1]),
                                                     depth, poses, cfg.get("num_scales", 5), noise)
     out["depth_smth"] = losses.smoothness_loss(rgb[0], disp)
+    if "semantic_head" not in sds:                 # depth-only network (BASELINE configs[0]: make_semantic = make_instance = False)
+        res.update(depth=depth)
+        return out, res
     probs = heads.semantic_head(sds["semantic_head"], feats, cfg.get("use_guda_fusion", True))
     out["semantic"] = losses.semantic_loss(probs, sample["semantic"], sample["semantic_weights"],
                                            cfg.get("class_weights"), cfg.get("top_k", 0.2))

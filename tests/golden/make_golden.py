@@ -378,6 +378,35 @@ def golden_network(seed=51):
     save("network_train", **res)
 
 
+def golden_config0(seed=71):
+    """BASELINE configs[0]: one 192x640 frame triplet, ResNet-18 encoder, depth head only (no semantic / instance head),
+    CodepsNet.forward("train") + backward of the reference on the CPU."""
+    b, h, w = 1, 192, 640
+    enc, penc = _StandInEncoder(3, seed + 1), _StandInEncoder(6, seed + 2)
+    dh, ph = DepthHead(R18, True), PoseHead(R18, 1, 2)
+    for i, m in enumerate((dh, ph)):
+        m.load_state_dict(gi.fill_state_dict(gi.shapes_of(m.state_dict()), seed + 10 + i))
+    rec = ReconstructionLoss(w, h, SSIMLoss(), 5, CPU)
+    dalgo = DepthAlgo(rec, EdgeAwareSmoothnessLoss(), DepthEvaluator(True, None), None, None, None, None)
+    net = CodepsNet(None, enc, penc, dh, ph, None, None, None, dalgo, None, None)
+    net.eval()
+    sample = _sample(b, h, w, seed, labels=False)
+    torch.manual_seed(3000 + seed)
+    losses, result, _stats = net(sample, "train", [0, -1, 1], do_panoptic_fusion=False)
+    wts = dict(depth_recon=10.0, depth_smth=0.001)
+    total = sum(wts[k] * v for k, v in losses.items() if v is not None and k in wts)
+    total.backward()
+    res = {"meta": json.dumps({"b": b, "h": h, "w": w, "seed": seed, "weights": wts, "noise_seed": 3000 + seed})}
+    for k, v in losses.items():
+        if v is not None:
+            res["loss_" + k] = v
+    res["total"] = total
+    res["res_depth"] = result["depth"]
+    for name in ("depth_head", "pose_head", "backbone_po_depth", "backbone_pose_sflow"):
+        res["pgrad_" + name] = grad_stats(getattr(net, name))
+    save("config0", **res)
+
+
 def golden_adapt(seed=61):
     """DepthAlgo.adaptation weighted mean over keys with two resolutions + semantic adaptation losses
     (algos/depth.py:507-595, algos/semantic_seg.py:200-249), mixup items given pre-mixed."""
@@ -629,7 +658,7 @@ def golden_metrics():
 
 
 if __name__ == "__main__":
-    jobs = {"geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer, "preprocessing": golden_preprocessing,
+    jobs = {"config0": golden_config0, "geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer, "preprocessing": golden_preprocessing,
             "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
             "heads_r50": lambda: golden_heads("r50", R50, 1, 32, 64, 5, full=False),
             "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),

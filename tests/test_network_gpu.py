@@ -89,6 +89,41 @@ def test_train_forward_backward_against_reference():
                            "backbone_pose_sflow"))
 
 
+def test_config0_depth_only_train_step_against_reference():
+    """BASELINE configs[0]: one 192x640 frame triplet, ResNet-18 encoder, depth head only -- CodepsNet.forward("train") +
+    backward against the reference's own run (tests/golden/config0.npz)."""
+    from codeps_amd.codeps import gen_models
+    from codeps_amd.config import get_cfg_defaults
+    z, meta = load("config0")
+    b, h, w, seed = meta["b"], meta["h"], meta["w"], meta["seed"]
+    cfg = get_cfg_defaults(False)
+    cfg.model.po_depth_net.params.nof_layers = 18
+    cfg.model.make_semantic = cfg.model.make_instance = False
+    cfg.dataset.feed_img_size = [h, w]
+    net = gen_models(cfg, None, STUFF, THINGS, [], adaptation_mode=False)
+    assert net.semantic_head is None and net.instance_head is None
+    for name, in_ch, s_ in (("backbone_po_depth", 3, seed + 1), ("backbone_pose_sflow", 6, seed + 2)):
+        sd = gi.fill_state_dict(gi.shapes_of(oresnet.make_state_dict(18, in_ch, 0, False)), s_)
+        getattr(net, name).load_state_dict({"encoder." + k: v for k, v in sd.items()}, strict=False)
+    for i, name in enumerate(("depth_head", "pose_head")):
+        getattr(net, name).load_state_dict(gi.fill_state_dict(head_shapes(name), seed + 10 + i))
+    net = net.to(DEV).eval()
+    net.depth_algo.reconstruction_loss.noise = _noise(meta["noise_seed"], [(b, h, w)])
+    losses, result, _ = net(_sample(b, h, w, seed, labels=False), "train", [0, -1, 1], do_panoptic_fusion=False)
+    assert [k for k, v in losses.items() if v is not None] == ["depth_recon", "depth_smth"]
+    total = sum(meta["weights"][k] * losses[k] for k in meta["weights"])
+    total.backward()
+    for k in meta["weights"]:
+        close(losses[k], z["loss_" + k], 1e-6, 5e-5, "loss " + k)
+    close(total, z["total"], 1e-5, 5e-5)
+    # depth = 1 / (0.01 + 9.99 sigmoid(logit)): d depth / d logit ~ 24 at 40 m, so two valid fp32 summation orders of the
+    # 192x640 decoder already differ by ~1e-3 there (SURVEY.md section 7 "fp32 accuracy budget"): 1e-3 + 1e-4 relative, and
+    # tight in disparity space, as in the adaptation test below
+    close(result["depth"], z["res_depth"], 1e-3, 1e-4, "depth")
+    close(1.0 / result["depth"], 1.0 / z["res_depth"], 2e-4, 5e-5, "scaled disparity (range 0.01..10)")
+    _check_pgrads(net, z, ("depth_head", "pose_head", "backbone_po_depth", "backbone_pose_sflow"))
+
+
 def test_adaptation_step_against_reference():
     z, meta = load("network_adapt")
     ht, wt, hs, ws, seed = meta["ht"], meta["wt"], meta["hs"], meta["ws"], meta["seed"]

@@ -211,6 +211,29 @@ def test_network_train_step():
         assert (np.abs(st - ref) / (np.abs(ref[:, 1:2]) + 1e-6)).max() < 5e-3, name
 
 
+def test_config0_depth_only_train_step():
+    """BASELINE configs[0] (one 192x640 triplet, ResNet-18, depth head only) as the reference's CodepsNet computes it."""
+    z, meta = load("config0")
+    b, h, w, seed = meta["b"], meta["h"], meta["w"], meta["seed"]
+    sds = _sds(seed, False)
+    for name in ("semantic_head", "instance_head"):
+        sds.pop(name)
+    groups = _req_grad(sds)
+    noise = _draw_noise(meta["noise_seed"], [(b, 2, h // 2 ** s, w // 2 ** s) for s in range(5)])
+    out, res = network.train_forward(sds, dict(nof_layers=18), _sample(b, h, w, seed, labels=False), noise, do_panoptic=False)
+    assert list(out) == ["depth_recon", "depth_smth"]
+    total = sum(meta["weights"][k] * v for k, v in out.items())
+    total.backward()
+    for k, v in out.items():
+        close(v, z["loss_" + k], 1e-6, 2e-5, "loss " + k)
+    close(total, z["total"], 1e-5, 2e-5)
+    close(res["depth"], z["res_depth"], 1e-3, 0, "depth")
+    for name, ps in groups.items():
+        st = grad_stats([sds[name][k].grad for k in ps])
+        ref = z["pgrad_" + name]
+        assert (np.abs(st - ref) / (np.abs(ref[:, 1:2]) + 1e-6)).max() < 5e-3, name
+
+
 def test_network_adapt_step():
     z, meta = load("network_adapt")
     ht, wt, hs, ws, seed = meta["ht"], meta["wt"], meta["hs"], meta["ws"], meta["seed"]
