@@ -1,0 +1,33 @@
+#!/bin/bash
+# Regenerate every artefact under profiles/ for round $1 (e.g. r02) on the GPU box; results land in gpurun_out/profiles_$1/.
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'      then: cp gpurun_out/profiles_r02/* profiles/
+set -u
+R=${1:-r02}
+OUT=gpurun_out/profiles_$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+line() { grep '^{"metric"' | tail -1; }
+# 1. the driver's command
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | line > $OUT/${R}_bench_n1.json
+# 2. rocprofv3 kernel stats of the same command (shorter; no CPU baseline)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o r -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+cp $(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${R}_adapt_step_kernel_stats.csv
+python3 tools/trace_steps.py gpurun_out/prof_stats > $OUT/${R}_step_trace_graph.json 2>/dev/null
+rm -rf gpurun_out/prof_stats
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_eager -o r -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --graph 0 > /dev/null 2>&1
+python3 tools/trace_steps.py gpurun_out/prof_eager > $OUT/${R}_step_trace_eager.json 2>/dev/null
+rm -rf gpurun_out/prof_eager
+# 3. PMC traffic: separate passes, counters only with --kernel-trace
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o r -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --graph 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o r -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --graph 0 > /dev/null 2>&1
+python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps 3 > $OUT/${R}_pmc_traffic.json 2>/dev/null
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
+# 4. the other configurations that fit one GPU, secondary rows
+python3 bench.py --mode train --no-cpu-baseline 2>/dev/null | line > $OUT/${R}_bench_n1_configs1_pretrain.json
+python3 bench.py --per-gpu-batch 4 --no-cpu-baseline 2>/dev/null | line > $OUT/${R}_bench_n1_configs3_slice.json
+python3 bench.py --mode train --encoder 101 --height 1024 --width 2048 --per-gpu-batch 2 --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | line > $OUT/${R}_bench_n1_configs4_slice.json
+python3 bench.py --mode frame --no-cpu-baseline --no-roofline 2>/dev/null | line > $OUT/${R}_bench_n1_frame.json
+python3 bench.py --yaml-faithful --no-cpu-baseline --no-roofline 2>/dev/null | line > $OUT/${R}_bench_n1_yaml_faithful.json
+python3 tools/peaks.py --json $OUT/${R}_peaks.json > /dev/null 2>&1
+python3 tools/conv_layers.py --json $OUT/${R}_conv_layers.json > $OUT/${R}_conv_layers.txt 2>/dev/null
+ls -la $OUT
