@@ -50,9 +50,14 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_forward_backward(case):
+    run_conv_case(case, 1000 + CONV_CASES.index(case))
+
+
+def run_conv_case(case, seed):
+    """One fused convolution (forward, data / weight / bias / residual gradients) against float64 on the CPU."""
     F = _F()
     b, h, w, c0, c1, up0, co, k, stride, pad, pad_mode, act, bias, affine, residual = case
-    g = torch.Generator().manual_seed(1000 + CONV_CASES.index(case))
+    g = torch.Generator().manual_seed(seed)
     hs, ws_ = (h // 2, w // 2) if up0 else (h, w)
     if up0:
         h, w = hs * 2, ws_ * 2
@@ -81,8 +86,13 @@ def test_conv2d_forward_backward(case):
         y = y * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
     if residual:
         y = y + rres
+    pre = y.detach()
     y = TF.elu(y) if act == "elu" else (TF.relu(y) if act == "relu" else y)
     gy = torch.randn(y.shape, generator=g).double()
+    if act == "relu":
+        # an fp32 pre-activation within rounding of zero may land on the other side of the kink than the float64 one: one
+        # flipped mask element moves a weight-gradient entry by 1/sqrt(pixels) of its size.  Such outputs get no gradient.
+        gy = gy * (pre.abs() > 1e-5)
     (y * gy).sum().backward()
 
     # ---- HIP
