@@ -121,9 +121,12 @@ def run_conv_case(case, seed):
 
 @pytest.mark.parametrize("c,act,res", [(64, "relu", True), (256, None, False), (2048, "relu", False), (48, "relu", True)])
 def test_batch_norm_train(c, act, res):
+    run_bn_case(c, act, res, 3, 9, 13, c)
+
+
+def run_bn_case(c, act, res, b, h, w, seed):
     F = _F()
-    g = torch.Generator().manual_seed(c)
-    b, h, w = 3, 9, 13
+    g = torch.Generator().manual_seed(seed)
     x = torch.randn(b, c, h, w, generator=g) * 2 + 0.5
     gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
     r = torch.randn(b, c, h, w, generator=g) if res else None
@@ -137,6 +140,8 @@ def test_batch_norm_train(c, act, res):
     if act:
         y = TF.relu(y)
     gy = torch.randn(y.shape, generator=g).double()
+    if act:
+        gy = gy * (y.detach().abs() > 1e-5)                 # outputs on the ReLU kink take no gradient (see run_conv_case)
     (y * gy).sum().backward()
     dx, dg, dbt = nhwc(x).requires_grad_(True), gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
     dr = nhwc(r).requires_grad_(True) if res else None
@@ -152,35 +157,43 @@ def test_batch_norm_train(c, act, res):
 
 
 def test_maxpool():
+    run_maxpool_case(2, 64, 17, 22, 3)
+
+
+def run_maxpool_case(b, c, h, w, seed):
     F = _F()
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 64, 17, 22, generator=g)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, c, h, w, generator=g)
     rx = x.double().requires_grad_(True)
     y = TF.max_pool2d(rx, 3, 2, 1)
     gy = torch.randn(y.shape, generator=g).double()
     (y * gy).sum().backward()
     dx = nhwc(x).requires_grad_(True)
     out = F.max_pool3x3s2(dx)
-    assert torch.equal(nchw(out, 64), y.detach().float())
+    assert torch.equal(nchw(out, c), y.detach().float())
     out.backward(nhwc(gy.float()))
-    assert rel_err(nchw(dx.grad, 64), rx.grad) < 1e-6
+    assert rel_err(nchw(dx.grad, c), rx.grad) < 1e-6
 
 
 @pytest.mark.parametrize("align,h,w,oh,ow", [(False, 8, 12, 64, 96), (False, 16, 24, 32, 48), (True, 5, 7, 10, 14),
                                              (True, 4, 8, 8, 16), (True, 6, 9, 11, 20)])
 def test_bilinear(align, h, w, oh, ow):
+    run_bilinear_case(align, 2, 32, h, w, oh, ow, h)
+
+
+def run_bilinear_case(align, b, c, h, w, oh, ow, seed):
     F = _F()
-    g = torch.Generator().manual_seed(h)
-    x = torch.randn(2, 32, h, w, generator=g)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, c, h, w, generator=g)
     rx = x.double().requires_grad_(True)
     y = TF.interpolate(rx, (oh, ow), mode="bilinear", align_corners=align)
     gy = torch.randn(y.shape, generator=g).double()
     (y * gy).sum().backward()
     dx = nhwc(x).requires_grad_(True)
     out = F.bilinear_resize(dx, oh, ow, align)
-    assert rel_err(nchw(out, 32), y.detach()) < 1e-5
+    assert rel_err(nchw(out, c), y.detach()) < 1e-5
     out.backward(nhwc(gy.float()))
-    assert rel_err(nchw(dx.grad, 32), rx.grad) < 1e-5
+    assert rel_err(nchw(dx.grad, c), rx.grad) < 1e-5
 
 
 def test_bilinear_concat_guda():
