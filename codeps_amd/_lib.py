@@ -123,6 +123,12 @@ SIGNATURES = {
     "codeps_cut_mixup": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, ctypes.c_double, P, P, P, P]),
     "codeps_offset_center_workspace_bytes": (c_size_t, [I]),
     "codeps_offset_center": (c_int, [P, I, I, I, ctypes.c_double, P, P, P, P, c_size_t, P]),
+    "codeps_conf_stats_bytes": (c_size_t, []),
+    "codeps_conf_instance_stats": (c_int, [P, I, I, P, P]),
+    "codeps_conf_place_workspace_bytes": (c_size_t, [I]),
+    "codeps_conf_place": (c_int, [P, I, I, I, P, P, P, c_size_t, P]),
+    "codeps_conf_apply": (c_int, [P, I, I, I, P, I, P, P, P, P, P]),
+    "codeps_conf_paste": (c_int, [P, P, P, P, P, P, P, P, I, I, I, P, P, P, P]),
     "codeps_replay_state_bytes": (c_size_t, [I, I]),
     "codeps_replay_reset": (c_int, [P, c_size_t, I, I, P]),
     "codeps_replay_add": (c_int, [P, c_size_t, I, I, P, I, I, I, LL, c_float, I, P, P]),

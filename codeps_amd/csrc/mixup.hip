@@ -8,6 +8,7 @@
 //   K17 offset_center per-instance (count, sum y, sum x) through a small hash table with wave-aggregated atomics,
 //                     then the Gaussian splat (atomic max) and the per-pixel offsets; no host round trip
 // All HBM-bound byte / index work: one read of each input, one write of each output.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -259,6 +260,153 @@ __global__ __launch_bounds__(256) void oc_offsets_kernel(const int* __restrict__
     offset[((size_t)b * 2 + 1) * n + i] = ox;
 }
 
+
+// ------------------------------------------------------------------------------------------------ conf_instance_mixup
+// Mixup.get_conf_mask (datasets/mixup.py:542-652) places the teacher's instances one after the other: each goes to the column of
+// its centre row that is farthest -- kornia.contrib.distance_transform -- from every thing already in the image.  The
+// reference runs the transform's cascade (max(H, W) 3x3 convolutions over the whole image) per instance and reads ONE row of it.
+// The cascade has a closed form: a pixel is reached in iteration i = D - 1, D its Chebyshev distance to the nearest thing
+// pixel, and its value is  (3 i) / 2 - h log(sum of exp(-|d| / h) over the neighbours (replicate border) that were reached
+// earlier or are things).  So the row costs three column scans, three W x W min-max passes and one block -- no iteration.
+// kornia is not vendored by the reference (requirements.txt:16, unpinned): this follows oracle/mixup.py's restatement of
+// its published algorithm, nine products summed in row-major kernel order.
+struct ConfStats { long long n, sy, sx, min_x, max_x; };            // per instance id (256 per image)
+constexpr int CONF_IDS = 256;
+constexpr int CONF_FAR = 1 << 28;
+
+__global__ void conf_stats_init_kernel(ConfStats* tab) {
+    const int i = threadIdx.x;
+    tab[i].n = tab[i].sy = tab[i].sx = 0;
+    tab[i].min_x = CONF_FAR;
+    tab[i].max_x = -1;
+}
+
+__global__ __launch_bounds__(256) void conf_stats_kernel(const int* __restrict__ inst, int h, int w, ConfStats* __restrict__ tab) {
+    const long long n = (long long)h * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int id = inst[i];
+        if (id <= 0 || id >= CONF_IDS) continue;
+        const int y = (int)(i / w), x = (int)(i % w);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&tab[id].n), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&tab[id].sy), (unsigned long long)y);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&tab[id].sx), (unsigned long long)x);
+        atomicMin(&tab[id].min_x, (long long)x);
+        atomicMax(&tab[id].max_x, (long long)x);
+    }
+}
+
+// v[j][c] = vertical distance from row r_j (rows row - 1, row, row + 1 clamped into the image) to the nearest thing of column c
+__global__ __launch_bounds__(256) void conf_rows_kernel(const uint8_t* __restrict__ things, int h, int w, int row, int* __restrict__ v) {
+    const int c = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (c >= w) return;
+    const int r = min(max(row + j - 1, 0), h - 1);
+    int best = CONF_FAR;
+    for (int y = 0; y < h; ++y)
+        if (things[(size_t)y * w + c]) best = min(best, abs(y - r));
+    v[j * w + c] = best;
+}
+
+// d[j][x] = Chebyshev distance of pixel (r_j, x) to the nearest thing = min over columns c of max(|c - x|, v[j][c])
+__global__ __launch_bounds__(256) void conf_cheb_kernel(const int* __restrict__ v, int w, int* __restrict__ d) {
+    const int x = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (x >= w) return;
+    int best = CONF_FAR;
+    for (int c = 0; c < w; ++c) best = min(best, max(abs(c - x), v[j * w + c]));
+    d[j * w + x] = best;
+}
+
+// the transform along the row and the first column of its maximum (torch.argmax): one block
+__global__ __launch_bounds__(256) void conf_row_dt_kernel(const uint8_t* __restrict__ things, int h, int w, int row, const int* __restrict__ d,
+                                                          float* __restrict__ dist_row, int* __restrict__ argmax) {
+#pragma clang fp contract(off)
+    // exp(-1 / 0.35), exp(-sqrt(2) / 0.35) of the float32 arguments, rounded to float32 (numpy, torch and the correctly
+    // rounded double agree on these bits); centre tap = 1 (it multiplies the pixel's own, still empty, boundary value)
+    const float k_edge = __uint_as_float(1030438518u), k_diag = __uint_as_float(1016074767u), hval = 0.35f;
+    __shared__ float best_v[256];
+    __shared__ int best_i[256];
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int x = threadIdx.x; x < w; x += 256) {
+        float val = 0.f;
+        const int d0 = d[w + x];
+        if (!things[(size_t)row * w + x] && d0 < CONF_FAR) {
+            float s = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int r = min(max(row + ky - 1, 0), h - 1);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int qx = min(max(x + kx - 1, 0), w - 1);
+                    const bool in = things[(size_t)r * w + qx] != 0 || d[ky * w + qx] < d0;
+                    const float kv = (ky == 1 && kx == 1) ? 1.f : ((ky == 1 || kx == 1) ? k_edge : k_diag);
+                    s = s + kv * (in ? 1.f : 0.f);
+                }
+            }
+            const float cdt = -hval * logf(s);
+            val = (float)(((d0 - 1) * 3) / 2) + cdt;
+        }
+        if (dist_row) dist_row[x] = val;
+        if (val > bv) { bv = val; bi = x; }                  // x ascends within a thread: the first maximum stays
+    }
+    best_v[threadIdx.x] = bv;
+    best_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float ov = best_v[threadIdx.x + o];
+            const int oi = best_i[threadIdx.x + o];
+            if (ov > best_v[threadIdx.x] || (ov == best_v[threadIdx.x] && oi < best_i[threadIdx.x])) { best_v[threadIdx.x] = ov; best_i[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *argmax = best_i[0];
+}
+
+// horizontal shift of instance `cid`: to the farthest column, then back inside the image (mixup.py:586-601)
+__global__ void conf_shift_kernel(const ConfStats* __restrict__ tab, int cid, int cx, const int* __restrict__ argmax, int w, int* __restrict__ shift) {
+    int dx = *argmax - cx;
+    const int lo = (int)tab[cid].min_x + dx, hi = (int)tab[cid].max_x + dx;
+    if (lo < 0) dx -= lo;
+    if (hi > w - 1) dx -= hi - (w - 1);
+    shift[cid] = dx;
+}
+
+// paste bookkeeping of one instance (mixup.py:606-645 on masks): pixels the shifted instance covers become things; those no
+// earlier instance holds are this instance's (a later instance is cropped where it overlaps an earlier one)
+__global__ __launch_bounds__(256) void conf_apply_kernel(const int* __restrict__ inst, int h, int w, int cid, const int* __restrict__ shift,
+                                                         uint8_t* __restrict__ dst, uint8_t* __restrict__ things) {
+    const int dx = shift[cid];
+    const long long n = (long long)h * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / w), x = (int)(i % w), xs = x - dx;
+        if (xs < 0 || xs >= w || inst[(size_t)y * w + xs] != cid) continue;
+        things[i] = 1;
+        if (dst[i] == 0) dst[i] = (uint8_t)cid;
+    }
+}
+
+// the mixed item (mixup.py:366-381): a pixel held by instance c shows the target's pixel `shift[c]` columns to its left
+__global__ __launch_bounds__(256) void conf_paste_kernel(const float* __restrict__ img_src, const float* __restrict__ img_tgt,
+                                                         const int* __restrict__ sem_src, const int* __restrict__ sem_tgt,
+                                                         const int* __restrict__ inst_src, const int* __restrict__ inst_conf,
+                                                         const uint8_t* __restrict__ dst, const int* __restrict__ shift, int c, int h, int w,
+                                                         float* __restrict__ rgb, int* __restrict__ sem, int* __restrict__ inst) {
+    const long long n = (long long)h * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int cid = dst[i];
+        if (cid == 0) {
+            for (int k = 0; k < c; ++k) rgb[k * n + i] = img_src[k * n + i];
+            sem[i] = sem_src[i];
+            inst[i] = inst_src[i];
+        } else {
+            const long long j = i - shift[cid];
+            for (int k = 0; k < c; ++k) rgb[k * n + i] = img_tgt[k * n + j];
+            sem[i] = sem_tgt[j];
+            inst[i] = inst_conf[j];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int codeps_warp_c2c(const void* in, int dtype, const float* intr_in, const float* intr_out, int batch, int c, int hs, int ws,
@@ -322,5 +470,58 @@ extern "C" int codeps_offset_center(const int* instance, int batch, int h, int w
     hipLaunchKernelGGL(oc_splat_kernel, dim3(OC_CAP, batch), dim3(256), 0, st, h, w, sigma, tabs, center, status);
     hipLaunchKernelGGL(oc_offsets_kernel, pix, dim3(256), 0, st, instance, h, w, tabs, offset);
     CODEPS_CHECK_LAUNCH("codeps_offset_center");
+    return CODEPS_OK;
+}
+
+
+extern "C" size_t codeps_conf_stats_bytes(void) { return (size_t)CONF_IDS * sizeof(ConfStats); }
+
+extern "C" int codeps_conf_instance_stats(const int* instance, int h, int w, void* table, codeps_stream_t stream) {
+    CODEPS_REQUIRE(instance && table && h > 0 && w > 0, CODEPS_ERR_ARG, "codeps_conf_instance_stats: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conf_stats_init_kernel, dim3(1), dim3(CONF_IDS), 0, st, static_cast<ConfStats*>(table));
+    hipLaunchKernelGGL(conf_stats_kernel, dim3((unsigned)std::min<long long>(((long long)h * w + 255) / 256, 2048)), dim3(256), 0, st, instance, h, w,
+                       static_cast<ConfStats*>(table));
+    CODEPS_CHECK_LAUNCH("conf_stats_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" size_t codeps_conf_place_workspace_bytes(int w) { return w > 0 ? (size_t)6 * w * sizeof(int) : 0; }
+
+extern "C" int codeps_conf_place(const uint8_t* things, int h, int w, int row, float* dist_row, int* argmax, void* workspace,
+                                 size_t workspace_bytes, codeps_stream_t stream) {
+    CODEPS_REQUIRE(things && argmax && workspace && h > 0 && w > 0 && row >= 0 && row < h, CODEPS_ERR_ARG, "codeps_conf_place: bad arguments");
+    CODEPS_REQUIRE(workspace_bytes >= codeps_conf_place_workspace_bytes(w), CODEPS_ERR_WORKSPACE, "codeps_conf_place: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int* v = static_cast<int*>(workspace);
+    int* d = v + 3 * (size_t)w;
+    const dim3 grid((unsigned)((w + 255) / 256), 3);
+    hipLaunchKernelGGL(conf_rows_kernel, grid, dim3(256), 0, st, things, h, w, row, v);
+    hipLaunchKernelGGL(conf_cheb_kernel, grid, dim3(256), 0, st, v, w, d);
+    hipLaunchKernelGGL(conf_row_dt_kernel, dim3(1), dim3(256), 0, st, things, h, w, row, d, dist_row, argmax);
+    CODEPS_CHECK_LAUNCH("codeps_conf_place");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_conf_apply(const int* instance, int h, int w, int cid, const void* table, int cx, const int* argmax, int* shift,
+                                 uint8_t* dst, uint8_t* things, codeps_stream_t stream) {
+    CODEPS_REQUIRE(instance && table && argmax && shift && dst && things && h > 0 && w > 0 && cid > 0 && cid < CONF_IDS, CODEPS_ERR_ARG,
+                   "codeps_conf_apply: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conf_shift_kernel, dim3(1), dim3(1), 0, st, static_cast<const ConfStats*>(table), cid, cx, argmax, w, shift);
+    hipLaunchKernelGGL(conf_apply_kernel, dim3((unsigned)std::min<long long>(((long long)h * w + 255) / 256, 2048)), dim3(256), 0, st, instance, h, w,
+                       cid, shift, dst, things);
+    CODEPS_CHECK_LAUNCH("codeps_conf_apply");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_conf_paste(const float* img_src, const float* img_tgt, const int* sem_src, const int* sem_tgt, const int* inst_src,
+                                 const int* inst_conf, const uint8_t* dst, const int* shift, int c, int h, int w, float* rgb_mix,
+                                 int* sem_mix, int* inst_mix, codeps_stream_t stream) {
+    CODEPS_REQUIRE(img_src && img_tgt && sem_src && sem_tgt && inst_src && inst_conf && dst && shift && rgb_mix && sem_mix && inst_mix &&
+                       c > 0 && h > 0 && w > 0, CODEPS_ERR_ARG, "codeps_conf_paste: bad arguments");
+    hipLaunchKernelGGL(conf_paste_kernel, dim3((unsigned)std::min<long long>(((long long)h * w + 255) / 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, img_src, img_tgt, sem_src, sem_tgt, inst_src, inst_conf, dst, shift, c, h, w, rgb_mix, sem_mix, inst_mix);
+    CODEPS_CHECK_LAUNCH("conf_paste_kernel");
     return CODEPS_OK;
 }

@@ -11,8 +11,16 @@ install it with `net.mixup_fn = Mixup.do_mixup`).  Differences in HOW, not WHAT:
     mixup.py:108), everything else is enqueued on the current stream.
 `class_mixup` (mixup.py:261-311, not selected by either adaptation YAML) is offered through the same kernels: the float64
 warps as three codeps_warp_c2c launches, the class mask and the masked copies as tensor ops, the centre / offset ground
-truth on the device; its `torch.unique` over the source labels synchronises like the reference's.  `conf_instance_mixup`
-(kornia distance transforms) raises NotImplementedError.
+truth on the device; its `torch.unique` over the source labels synchronises like the reference's.
+`conf_instance_mixup` (mixup.py:347-404, 542-652; in the DEFAULT strategy list, default_config_adapt.py:138, overridden by both
+YAMLs) places the teacher's instances with kornia's distance transform: the reference runs the transform's cascade of
+max(H, W) convolutions per instance and reads one row of it; here that row comes from the cascade's closed form
+(codeps_conf_place), the per-instance bookkeeping from one statistics table per image (one host read per image instead of
+several per instance) and mask kernels (codeps_conf_apply / codeps_conf_paste).  kornia is not vendored by the reference
+(requirements.txt:16, unpinned) and not installed here: oracle/mixup.py restates its published algorithm (parity unpinned
+for that one function), everything built around it is pinned by tests/golden/conf_mixup.npz -- the reference's own
+conf_instance_mixup run with that restatement in kornia's place.  Like the reference (mixup.py:581 reads batch item 0's
+instance map for every item's centre) it is meaningful at batch size 1.
 """
 from typing import Any, Dict, List, Optional
 
@@ -138,14 +146,91 @@ class Mixup:
         return {"rgb": {0: rgb}, "camera_model": mixup_data["camera_model_src"], "semantic": sem, "center": center, "offset": offset,
                 "instance": inst}
 
+    # ------------------------------------------------------------------ conf_instance_mixup
+    @staticmethod
+    def get_conf_mask(semantic_pred_ema, center_ema_plabel_det, offset_ema_plabel_det, instance_algo, src_shape, threshold: float,
+                      min_inst_size: int, thing_msk_src):
+        """mixup.py:542-652, on masks instead of index lists: the teacher's instances (panoptic fusion at `threshold`) are placed
+        one after the other, in ascending id order, at the column of their centre row that kornia's distance transform
+        (closed form, `F.conf_place`) ranks farthest from every thing already in the image; a later instance is cropped where it
+        overlaps an earlier one.  -> (dst uint8 [B,H,W]: instance held by a source pixel, 0 = none; shift int32 [B,256]: a held
+        pixel (y, x) shows target pixel (y, x - shift[id]); instance_plabel_ema [B,H,W]).  One host read per image (the
+        per-instance table) -- the reference synchronises several times per instance."""
+        _, inst = instance_algo.panoptic_fusion(semantic_pred_ema, center_ema_plabel_det, offset_ema_plabel_det,
+                                                threshold_center=threshold)
+        b, h, w = inst.shape
+        if tuple(src_shape[-2:]) != (h, w):
+            raise AssertionError("Not implemented")                                    # the reference's index arithmetic needs equal sizes
+        dev = inst.device
+        inst32 = inst.to(torch.int32).contiguous()
+        dst = torch.zeros(b, h, w, dtype=torch.uint8, device=dev)
+        shift = torch.zeros(b, 256, dtype=torch.int32, device=dev)
+        things = (thing_msk_src.reshape(b, h, w) != 0).to(torch.uint8).contiguous()
+        tables = [F.conf_instance_stats(inst32[i]) for i in range(b)]
+        host = torch.stack(tables).cpu()                                               # the one synchronisation
+        for i in range(b):
+            for cid in range(1, 256):
+                n = int(host[i, cid, 0])
+                if n == 0 or n < min_inst_size:
+                    continue
+                n0 = int(host[0, cid, 0])                                              # mixup.py:581 reads batch item 0's map
+                if n0 == 0:
+                    raise ValueError(f"conf_instance_mixup: instance {cid} of batch item {i} does not exist in item 0, whose map the "
+                                     "reference reads for every item's centre (datasets/mixup.py:581): use batch size 1")
+                # torch.round (half to even) of the float32 mean of the pixel coordinates
+                cy, cx = (int(np.rint(np.float32(int(host[0, cid, k]) / n0))) for k in (1, 2))
+                argmax, _ = F.conf_place(things[i], cy)
+                F.conf_apply(inst32[i], cid, tables[i], cx, argmax, shift[i], dst[i], things[i])
+        return dst, shift, inst
+
+    @staticmethod
+    def conf_instance_mixup(img_src, img_tgt, lbl_instance_src, lbl_sem_src, semantic_pred_tgt_ema, center_pred_tgt_ema,
+                            offset_pred_tgt_ema, instance_algo, threshold: float, min_inst_size: int, get_off_cen: bool = True):
+        """mixup.py:347-404.  img_* [B,3,H,W]; lbl_*_src [B,1,H,W]; *_pred_tgt_ema: the teacher's (warped) predictions."""
+        dst, shift, inst_conf = Mixup.get_conf_mask(semantic_pred_tgt_ema, center_pred_tgt_ema, offset_pred_tgt_ema, instance_algo,
+                                                    img_src.shape, threshold, min_inst_size, lbl_instance_src != 0)
+        b, _, h, w = img_src.shape
+        i32 = lambda t: t.reshape(b, h, w).to(torch.int32).contiguous()                 # noqa: E731
+        sem_src, sem_tgt, inst_src, inst_tgt = i32(lbl_sem_src), i32(semantic_pred_tgt_ema), i32(lbl_instance_src), i32(inst_conf)
+        img_src, img_tgt = img_src.float().contiguous(), img_tgt.float().contiguous()
+        outs = [F.conf_paste(img_src[i], img_tgt[i], sem_src[i], sem_tgt[i], inst_src[i], inst_tgt[i], dst[i], shift[i]) for i in range(b)]
+        rgb_mixup = torch.stack([o[0] for o in outs])
+        lbl_sem_mixup = torch.stack([o[1] for o in outs]).to(lbl_sem_src.dtype)
+        lbl_inst_mixup = torch.stack([o[2] for o in outs]).unsqueeze(1).to(lbl_instance_src.dtype)
+        if get_off_cen:
+            lbl_center_mixup, lbl_offset_mixup = Mixup.get_off_cen(lbl_inst_mixup)
+            return rgb_mixup, lbl_sem_mixup, lbl_inst_mixup, lbl_center_mixup, lbl_offset_mixup
+        return rgb_mixup, lbl_sem_mixup, lbl_inst_mixup
+
+    @staticmethod
+    def _do_conf_instance_mixup(mixup_data: Dict[str, Any], instance_algo, cfg_mixup) -> Dict[str, Any]:
+        img_src, img_tgt = mixup_data["rgb_src"][0], mixup_data["rgb_tgt"][0]
+        semantic_src, instance_src = mixup_data["semantic_src"], mixup_data["instance_src"]
+        semantic_pred = mixup_data["semantic_pred_tgt_ema"].detach()
+        _, instance_pred = instance_algo.panoptic_fusion(semantic_pred, mixup_data["center_pred_tgt_ema"].detach(),
+                                                         mixup_data["offset_pred_tgt_ema"].detach())
+        if bool(cfg_mixup.general.geom_augment):                                        # mixup.py:419-441
+            cs, ct = mixup_data["camera_model_src"], mixup_data["camera_model_tgt"]
+            img_tgt = Mixup.warp_c2c(ct, cs, img_tgt, img_src, interp_mode="bilinear", padding_mode="zeros")
+            instance_pred = Mixup.warp_c2c(ct, cs, instance_pred, instance_src, interp_mode="nearest", padding_mode="zeros").squeeze(1)
+            semantic_pred = Mixup.warp_c2c(ct, cs, semantic_pred, semantic_src, interp_mode="nearest", padding_mode="border").squeeze(1)
+        center_pred, offset_pred = Mixup.get_off_cen(instance_pred)                     # mixup.py:444: labels of the (warped) prediction
+        cm = cfg_mixup.conf_instance_mix
+        rgb, sem, inst, center, offset = Mixup.conf_instance_mixup(img_src, img_tgt, instance_src, semantic_src, semantic_pred, center_pred,
+                                                                   offset_pred, instance_algo, cm.conf_thresh, cm.min_inst_size)
+        return {"rgb": {0: rgb}, "camera_model": mixup_data["camera_model_src"], "semantic": sem, "center": center, "offset": offset,
+                "instance": inst.squeeze(1)}
+
     # ------------------------------------------------------------------ entry point
     @staticmethod
     def do_mixup(mixup_strategy: str, mixup_data: Dict[str, Any], instance_algo, cfg_mixup) -> Dict[str, Any]:
         Mixup.check()
         if mixup_strategy == "class_mixup":
             return Mixup._do_class_mixup(mixup_data, instance_algo, cfg_mixup)
+        if mixup_strategy == "conf_instance_mixup":
+            return Mixup._do_conf_instance_mixup(mixup_data, instance_algo, cfg_mixup)
         if mixup_strategy != "cut_mixup":
-            raise NotImplementedError(f"mixup strategy {mixup_strategy!r}: 'cut_mixup' (cfg/adapt_*.yaml:34) and 'class_mixup' are built")
+            raise NotImplementedError("The requested mixup strategy is not implemented yet")      # mixup.py:477
         img_src = mixup_data["rgb_src"][0]
         img_tgt = mixup_data["rgb_tgt"][0]
         semantic_src, instance_src = mixup_data["semantic_src"], mixup_data["instance_src"]          # [B,1,H,W]

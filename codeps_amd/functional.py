@@ -1506,6 +1506,54 @@ def cut_mixup(img_src, img_tgt, sem_src, sem_tgt, inst_src, inst_tgt, rects, int
     return rgb, sem, inst
 
 
+def conf_instance_stats(instance):
+    """Per instance id 1..255 of one label map [H,W] (the teacher's panoptic fusion): int64 [256,5] = (pixels, sum y, sum x,
+    min x, max x) on the device (C ABI: codeps_conf_instance_stats; datasets/mixup.py:572-581,590-592)."""
+    require_cuda(instance)
+    inst = instance.contiguous() if instance.dtype == torch.int32 else instance.to(torch.int32).contiguous()
+    h, w = inst.shape
+    table = torch.empty(lib().codeps_conf_stats_bytes() // 8, dtype=torch.int64, device=inst.device)
+    check(lib().codeps_conf_instance_stats(ptr(inst), h, w, ptr(table), stream_ptr()), "codeps_conf_instance_stats")
+    return table.view(256, 5)
+
+
+def conf_place(things, row, want_row=False):
+    """kornia.contrib.distance_transform of the uint8 thing mask [H,W] along `row` and the first column of its maximum
+    (datasets/mixup.py:583-587), closed form, no iteration (C ABI: codeps_conf_place).  -> (argmax int32 [1] on the device,
+    dist_row fp32 [W] or None)."""
+    require_cuda(things)
+    assert things.dtype == torch.uint8 and things.is_contiguous()
+    h, w = things.shape
+    dev = things.device
+    argmax = torch.empty(1, dtype=torch.int32, device=dev)
+    dist = torch.empty(w, dtype=torch.float32, device=dev) if want_row else None
+    nbytes = lib().codeps_conf_place_workspace_bytes(w)
+    ws = _workspace(nbytes, dev, "conf_place")
+    check(lib().codeps_conf_place(ptr(things), h, w, int(row), ptr(dist), ptr(argmax), ptr(ws), nbytes, stream_ptr()), "codeps_conf_place")
+    return argmax, dist
+
+
+def conf_apply(instance, cid, table, cx, argmax, shift, dst, things):
+    """Place instance `cid` (datasets/mixup.py:586-645): shift[cid] from the placement column, its centre column and its column
+    range; dst / things updated in place (C ABI: codeps_conf_apply)."""
+    h, w = instance.shape
+    check(lib().codeps_conf_apply(ptr(instance), h, w, int(cid), ptr(table), int(cx), ptr(argmax), ptr(shift), ptr(dst), ptr(things),
+                                  stream_ptr()), "codeps_conf_apply")
+
+
+def conf_paste(img_src, img_tgt, sem_src, sem_tgt, inst_src, inst_conf, dst, shift):
+    """The mixed item of one image (datasets/mixup.py:366-381; C ABI: codeps_conf_paste).  img_* [C,H,W] fp32, label maps int32
+    [H,W], dst uint8 [H,W], shift int32 [256] -> (rgb fp32 [C,H,W], semantic int32 [H,W], instance int32 [H,W])."""
+    c, h, w = img_src.shape
+    dev = img_src.device
+    rgb = torch.empty(c, h, w, dtype=torch.float32, device=dev)
+    sem = torch.empty(h, w, dtype=torch.int32, device=dev)
+    inst = torch.empty(h, w, dtype=torch.int32, device=dev)
+    check(lib().codeps_conf_paste(ptr(img_src), ptr(img_tgt), ptr(sem_src), ptr(sem_tgt), ptr(inst_src), ptr(inst_conf), ptr(dst), ptr(shift),
+                                  c, h, w, ptr(rgb), ptr(sem), ptr(inst), stream_ptr()), "codeps_conf_paste")
+    return rgb, sem, inst
+
+
 def offset_center(instance, sigma=8.0):
     """Mixup.get_off_cen (datasets/mixup.py:243-257 -> datasets/dataset.py:126-177) on the device: instance [B,(1,)H,W]
     integer ids -> (center fp32 [B,1,H,W], offset fp32 [B,2,H,W], status int32 [B] = #instances or -1 on overflow).

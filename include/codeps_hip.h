@@ -471,6 +471,28 @@ int codeps_cut_mixup(const float* img_src, const float* img_tgt, const int* sem_
 size_t codeps_offset_center_workspace_bytes(int batch);
 int codeps_offset_center(const int* instance, int batch, int h, int w, double sigma, float* center, float* offset, int* status,
                          void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* Mixup.conf_instance_mixup / get_conf_mask (mixup.py:347-404, 542-652), one image at a time; label maps int32 [h][w]:
+ *  codeps_conf_instance_stats: per instance id 1..255 of `instance` (the teacher's panoptic fusion) five int64
+ *      (pixels, sum y, sum x, min x, max x; min x = 2^28 / max x = -1 when absent) into table (codeps_conf_stats_bytes).
+ *  codeps_conf_place: kornia.contrib.distance_transform(things) (kernel 3, h 0.35; mixup.py:583-587) along `row` in closed
+ *      form (Chebyshev ring index * 3 / 2 - h log(sum of the kernel over the neighbours reached earlier), replicate
+ *      border) -> dist_row fp32 [w] (nullable) and *argmax = first column of its maximum.  things uint8 [h][w].
+ *      kornia is not vendored by the reference (requirements.txt:16, unpinned): oracle/mixup.py restates its algorithm.
+ *  codeps_conf_apply: shift[cid] = *argmax - cx, moved back inside the image with the instance's column range from
+ *      `table` (mixup.py:586-601); the shifted instance's pixels become things and, where no earlier instance holds
+ *      them, dst = cid (the later instance is cropped, mixup.py:611-628).  dst / things uint8 [h][w], shift int32 [256].
+ *  codeps_conf_paste: the mixed item (mixup.py:366-381): dst == 0 -> source pixel, else the target pixel shift[dst]
+ *      columns to the left (image, teacher semantic map, teacher instance map).  img_* [c][h][w] fp32. */
+size_t codeps_conf_stats_bytes(void);
+int codeps_conf_instance_stats(const int* instance, int h, int w, void* table, codeps_stream_t stream);
+size_t codeps_conf_place_workspace_bytes(int w);
+int codeps_conf_place(const uint8_t* things, int h, int w, int row, float* dist_row, int* argmax, void* workspace,
+                      size_t workspace_bytes, codeps_stream_t stream);
+int codeps_conf_apply(const int* instance, int h, int w, int cid, const void* table, int cx, const int* argmax, int* shift,
+                      uint8_t* dst, uint8_t* things, codeps_stream_t stream);
+int codeps_conf_paste(const float* img_src, const float* img_tgt, const int* sem_src, const int* sem_tgt, const int* inst_src,
+                      const int* inst_conf, const uint8_t* dst, const int* shift, int c, int h, int w, float* rgb_mix,
+                      int* sem_mix, int* inst_mix, codeps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K18  Replay-buffer diversity sampler: the maximize_diversity branch of ReplayBuffer.add

@@ -187,3 +187,102 @@ def do_class_mixup(item, thing_list, pick, geom_augment=True, ieee_sqrt=False):
     inst = np.where(msk[:, 0], inst_tgt.astype(np.int32), inst_src[:, 0])
     center, offset = get_off_cen(inst)
     return {"rgb": rgb, "semantic": sem, "instance": inst, "center": center, "offset": offset}
+
+
+# ------------------------------------------------------------------------------------------ conf_instance_mixup
+def kornia_distance_transform(image, kernel_size=3, h=0.35):
+    """kornia.contrib.distance_transform (kornia is listed UNPINNED in the reference's requirements.txt:16 and is not in this
+    image: **parity unpinned** for this one function -- restated from kornia's published algorithm, Pham et al., "DTLayer",
+    2021, as kornia 0.6 implements it): cascaded 3x3 convolutions of the growing boundary with exp(-|d| / h), replicate
+    border; a pixel reached in iteration i gets  i * kernel_size // 2 - h log(sum)  once, float32 throughout.
+    image [H, W] float32 (non-zero = object) -> [H, W] float32.  The nine products are summed in row-major kernel order;
+    that order is this restatement's definition (a library convolution leaves it open) and the HIP kernel follows it."""
+    img = np.ascontiguousarray(image, np.float32)
+    hh, ww = img.shape
+    n_iters = int(np.ceil(max(hh, ww) / (kernel_size // 2)))
+    r = kernel_size // 2
+    ax = np.arange(kernel_size, dtype=np.float32) - np.float32(r)
+    kern = np.exp(np.hypot(ax[:, None], ax[None, :]).astype(np.float32) / np.float32(-h)).astype(np.float32)
+    out = np.zeros_like(img)
+    boundary = img.copy()
+    for i in range(n_iters):
+        pad = np.pad(boundary, r, mode="edge")
+        s = np.zeros_like(img)
+        for ky in range(kernel_size):
+            for kx in range(kernel_size):
+                s = (s + kern[ky, kx] * pad[ky:ky + hh, kx:kx + ww]).astype(np.float32)
+        with np.errstate(divide="ignore"):
+            cdt = (np.float32(-h) * np.log(s)).astype(np.float32)
+        cdt[np.isposinf(cdt)] = 0.0
+        mask = cdt > 0
+        if not mask.any():
+            break
+        offset = i * kernel_size // 2
+        out = np.where(mask, (out + (np.float32(offset) + cdt)).astype(np.float32), out)
+        boundary = np.where(mask, np.float32(1.0), boundary)
+    return out
+
+
+def conf_mask(inst_tgt, thing_src, min_inst_size):
+    """Mixup.get_conf_mask (mixup.py:542-652) for ONE batch item, on masks instead of index lists.  inst_tgt [H,W]: instance ids
+    of the teacher's panoptic fusion (0 = no thing); thing_src [H,W] bool: thing pixels of the source labels.
+    Instances are placed in ascending id order, each at the column of its centre row that is farthest (kornia distance
+    transform) from every thing already in the image, shifted back inside the image; where a new instance overlaps one pasted
+    earlier, the NEW one is cropped.  -> (dst [H,W] int64: id of the instance pasted on a source pixel, 0 = none,
+    shift {id: dx}: the pasted pixel (y, x) shows target pixel (y, x - dx))."""
+    h, w = inst_tgt.shape
+    things = thing_src.astype(bool).copy()
+    dst = np.zeros((h, w), np.int64)
+    shift = {}
+    for cid in np.unique(inst_tgt):
+        cid = int(cid)
+        t = inst_tgt == cid
+        if cid == 0 or t.sum() < min_inst_size:
+            continue
+        ys, xs = np.nonzero(t)
+        # round half to even of the float32 mean (torch.round of .float().mean(0), mixup.py:580-581)
+        cy, cx = (int(np.rint(np.float32(v.astype(np.float32).mean(dtype=np.float32)))) for v in (ys, xs))
+        dist_row = kornia_distance_transform(things.astype(np.float32))[cy]
+        dx = int(np.argmax(dist_row)) - cx
+        lo, hi = int(xs.min()) + dx, int(xs.max()) + dx
+        if lo < 0:
+            dx -= lo
+        if hi > w - 1:
+            dx -= hi - (w - 1)
+        s = np.zeros_like(t)
+        s[ys, xs + dx] = True
+        shift[cid] = dx
+        dst[s & (dst == 0)] = cid                       # overlap with an earlier instance: the earlier one keeps the pixel
+        things |= s
+    return dst, shift
+
+
+def do_conf_instance_mixup(item, thing_list, geom_augment, conf_thresh, min_inst_size, ieee_sqrt=False):
+    """Mixup.do_mixup("conf_instance_mixup", ...) (mixup.py:347-404, 406-466, 542-652) on numpy inputs, batch size 1 (the
+    reference reads batch item 0's instance map for every item's centre, mixup.py:581).
+    -> dict(rgb, semantic, instance, center, offset)."""
+    img_src, img_tgt = item["rgb_src"], item["rgb_tgt"]
+    sem_src, inst_src = item["semantic_src"], item["instance_src"]              # [B,1,H,W]
+    sem_tgt = item["semantic_pred_tgt_ema"]
+    b, _, h, w = img_src.shape
+    assert b == 1, "mixup.py:581 indexes batch item 0"
+    inst_tgt = panoptic.panoptic_fusion(sem_tgt, item["center_pred_tgt_ema"], item["offset_pred_tgt_ema"], thing_list)[1]
+    if geom_augment:
+        cs, ct = item["camera_model_src"], item["camera_model_tgt"]
+        img_tgt = warp_c2c(ct, cs, img_tgt, (h, w), "bilinear", "zeros", ieee_sqrt=ieee_sqrt).astype(np.float32)
+        inst_tgt = warp_c2c(ct, cs, inst_tgt, (h, w), "nearest", "zeros", ieee_sqrt=ieee_sqrt)[:, 0].astype(inst_tgt.dtype)
+        sem_tgt = warp_c2c(ct, cs, sem_tgt, (h, w), "nearest", "border", ieee_sqrt=ieee_sqrt)[:, 0].astype(sem_tgt.dtype)
+    assert img_tgt.shape == img_src.shape, "differently sized images need geom_augment"
+    center_t, offset_t = get_off_cen(inst_tgt)                                   # mixup.py:444: labels of the (warped) prediction
+    inst_conf = panoptic.panoptic_fusion(sem_tgt, center_t, offset_t, thing_list, conf_thresh)[1]       # mixup.py:546-550
+    rgb = img_src.astype(np.float32).copy()
+    sem, inst = sem_src[:, 0].copy(), inst_src[:, 0].copy()
+    for i in range(b):
+        dst, shift = conf_mask(inst_conf[i].astype(np.int64), inst_src[i, 0] != 0, min_inst_size)
+        for cid, dx in shift.items():
+            ys, xs = np.nonzero(dst == cid)
+            rgb[i][:, ys, xs] = img_tgt[i][:, ys, xs - dx].astype(np.float32)
+            sem[i][ys, xs] = sem_tgt[i][ys, xs - dx]
+            inst[i][ys, xs] = inst_conf[i][ys, xs - dx].astype(np.int32)
+    center, offset = get_off_cen(inst)
+    return {"rgb": rgb, "semantic": sem, "instance": inst, "center": center, "offset": offset}

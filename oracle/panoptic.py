@@ -49,10 +49,10 @@ def group_pixels(centers, offsets):
     return idx + 1
 
 
-def instance_segmentation(sem, ctr, offsets, thing_list):
+def instance_segmentation(sem, ctr, offsets, thing_list, threshold=THRESHOLD):
     """-> (ins_seg [H,W] int64, centers) (post_processing_panoptic.py:112-152)."""
     thing = np.isin(sem, np.asarray(thing_list))
-    centers = find_centers(ctr)
+    centers = find_centers(ctr, threshold)
     if centers.shape[0] == 0:
         return np.zeros(sem.shape, np.int64), centers
     return thing.astype(np.int64) * group_pixels(centers, offsets), centers
@@ -83,7 +83,7 @@ def merge(sem, ins, thing_list):
     return pan
 
 
-def panoptic_fusion(semantic, center, offset, thing_list):
+def panoptic_fusion(semantic, center, offset, thing_list, threshold=THRESHOLD):
     """semantic [B,H,W] (uint8/int64), center [B,1,H,W], offset [B,2,H,W] (numpy) ->
     (panoptic int16 [B,H,W], instance [B,H,W] of semantic's dtype, [centers per image])
     (algos/instance_seg.py:207-258)."""
@@ -92,7 +92,7 @@ def panoptic_fusion(semantic, center, offset, thing_list):
     inst = np.empty(semantic.shape, semantic.dtype)
     pts = []
     for i in range(b):
-        ins, c = instance_segmentation(semantic[i], center[i, 0], offset[i], thing_list)
+        ins, c = instance_segmentation(semantic[i], center[i, 0], offset[i], thing_list, threshold)
         pan[i] = merge(semantic[i], ins, thing_list)
         inst[i] = ins.astype(semantic.dtype)
         pts.append(c)

@@ -39,6 +39,18 @@ def install():
               "mmcv.parallel", "mmcv.parallel.data_container", "wandb", "seaborn"):
         sys.modules[m] = MagicMock()
 
+    def _distance_transform(image, kernel_size=3, h=0.35):
+        """kornia is absent: the reference's `conf_instance_mixup` runs on the oracle's restatement of
+        kornia.contrib.distance_transform (oracle/mixup.py; parity unpinned for that function, pinned for everything the
+        reference builds around it)."""
+        import numpy as np
+        import torch
+        from oracle.mixup import kornia_distance_transform
+        out = np.stack([np.stack([kornia_distance_transform(c.numpy(), kernel_size, h) for c in b]) for b in image])
+        return torch.from_numpy(out)
+
+    sys.modules["kornia.contrib"].distance_transform = _distance_transform
+
     class CfgNode(dict):
         def __getattr__(self, k):
             if k in self:

@@ -618,6 +618,31 @@ def golden_mixup():
     save("mixup", **res)
 
 
+def golden_conf_mixup():
+    """Mixup.do_mixup("conf_instance_mixup") of the real reference (datasets/mixup.py:347-404, 542-660) with the oracle's
+    distance transform standing in for kornia's (see _ref_import.py).  B = 1: the reference reads batch item 0's instance map
+    for every item's centre (mixup.py:581)."""
+    from datasets.mixup import Mixup
+    from yacs.config import CfgNode as CN
+    algo = InstanceSegAlgo(CenterLoss(), OffsetLoss(),
+                           PanopticEvaluator(stuff_list=STUFF, thing_list=THINGS, label_divisor=1000,
+                                             void_label=-1), BinaryMaskLoss())
+    res, meta = {}, {"cases": {}, "thing_list": THINGS}
+    for name, (hs, ws, ht, wt, geom, seed, thr, min_size) in {"geom": (64, 128, 56, 120, True, 171, 0.3, 12),
+                                                              "plain": (64, 128, 64, 128, False, 172, 0.3, 12),
+                                                              "big": (96, 160, 96, 160, False, 173, 0.1, 40)}.items():
+        item = gi.mixup_item(1, hs, ws, ht, wt, seed)
+        cfg = CN(general=CN(geom_augment=geom), conf_instance_mix=CN(conf_thresh=thr, min_inst_size=min_size))
+        out = Mixup.do_mixup("conf_instance_mixup", {k: (dict(v) if isinstance(v, dict) else v) for k, v in item.items()}, algo, cfg)
+        meta["cases"][name] = dict(hs=hs, ws=ws, ht=ht, wt=wt, geom=geom, seed=seed, conf_thresh=thr, min_inst_size=min_size)
+        res[f"{name}_rgb"], res[f"{name}_semantic"], res[f"{name}_instance"] = out["rgb"][0], out["semantic"], out["instance"]
+        res[f"{name}_center"], res[f"{name}_offset"] = out["center"], out["offset"]
+        pasted = int((out["instance"] != item["instance_src"].squeeze(1)).sum())
+        print(name, "pixels whose instance id changed:", pasted, "ids:", out["instance"].unique().tolist()[:12])
+    res["meta"] = json.dumps(meta)
+    save("conf_mixup", **res)
+
+
 # ------------------------------------------------------------------------------------------ metrics (SURVEY 8f-4)
 def golden_metrics():
     res, meta = {}, {"depth": {}, "thing_list": THINGS, "stuff_list": STUFF}
@@ -658,7 +683,7 @@ def golden_metrics():
 
 
 if __name__ == "__main__":
-    jobs = {"config0": golden_config0, "geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer, "preprocessing": golden_preprocessing,
+    jobs = {"conf_mixup": golden_conf_mixup, "config0": golden_config0, "geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer, "preprocessing": golden_preprocessing,
             "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
             "heads_r50": lambda: golden_heads("r50", R50, 1, 32, 64, 5, full=False),
             "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),

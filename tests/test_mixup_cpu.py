@@ -77,3 +77,34 @@ def test_do_class_mixup_matches_reference(name):
     out = om.do_class_mixup(item, meta["thing_list"], pick, c["geom"])
     for k in ("rgb", "semantic", "instance", "center", "offset"):
         assert out[k].dtype == z[f"{name}_{k}"].dtype and np.array_equal(out[k], z[f"{name}_{k}"]), f"{name}: {k} differs"
+
+
+@pytest.mark.parametrize("name", ["geom", "plain", "big"])
+def test_do_conf_instance_mixup_matches_reference(name):
+    """Mixup.do_mixup("conf_instance_mixup") of the real reference (run with the oracle's restatement of kornia's distance
+    transform in kornia's place, tests/golden/_ref_import.py) against the oracle's mask formulation of it."""
+    z, meta = load("conf_mixup")
+    c = meta["cases"][name]
+    item = gi.mixup_item(1, c["hs"], c["ws"], c["ht"], c["wt"], c["seed"])
+    item = {k: (v[0].numpy() if isinstance(v, dict) else v.numpy()) for k, v in item.items()}
+    out = om.do_conf_instance_mixup(item, meta["thing_list"], c["geom"], c["conf_thresh"], c["min_inst_size"])
+    pasted = out["instance"] != item["instance_src"][:, 0]
+    assert pasted.sum() > 500, "the case must paste instances"
+    for k in ("rgb", "semantic", "instance", "center", "offset"):
+        assert out[k].dtype == z[f"{name}_{k}"].dtype and np.array_equal(out[k], z[f"{name}_{k}"]), f"{name}: {k} differs"
+
+
+def test_kornia_distance_transform_restatement_properties():
+    """No kornia here (parity unpinned): what the restatement must satisfy by construction -- zero on the objects, the
+    Chebyshev ring index times 3 // 2 plus a term in (0, 1.42) elsewhere, all zeros without an object."""
+    m = np.zeros((20, 31), np.float32)
+    m[4:7, 5:9] = 1
+    m[15, 28] = 1
+    d = om.kornia_distance_transform(m)
+    ys, xs = np.nonzero(m)
+    yy, xx = np.mgrid[:20, :31]
+    cheb = np.min(np.maximum(np.abs(yy[..., None] - ys), np.abs(xx[..., None] - xs)), -1)
+    assert (d[m > 0] == 0).all()
+    ring = (cheb - 1) * 3 // 2
+    assert ((d - ring)[m == 0] > 0).all() and ((d - ring)[m == 0] < 1.42).all()
+    assert (om.kornia_distance_transform(np.zeros((6, 9), np.float32)) == 0).all()
