@@ -27,6 +27,9 @@ SHAPES = {               # name: (B, H, W, Cin, Cout, k, stride)
     "pose_l4": (12, 16, 32, 512, 512, 3, 1),
     "dec_2048": (6, 16, 32, 2048, 256, 3, 1),
 }
+# K sweeps of the 1x1 expand shape (fixed M x N): time = intercept (prologue, epilogue, tail) + slope x K
+SHAPES.update({f"exp_k{k}": (8, 32, 64, k, 1024, 1, 1) for k in (64, 128, 256, 512, 1024, 2048)})
+SHAPES.update({f"red_k{k}": (8, 32, 64, k, 256, 1, 1) for k in (64, 128, 256, 512, 1024, 2048)})
 
 
 def main():
