@@ -159,6 +159,9 @@ SIGNATURES = {
     "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, c_float, c_float, I, P, I, P, P]),
     "codeps_weighted_sum_fwd": (c_int, [P, P, P, I, P, P, P]),
     "codeps_weighted_sum_bwd": (c_int, [P, P, P, I, P, P, P]),
+    "codeps_disp_head_fwd": (c_int, [P, P, P, I, I, I, I, c_float, c_float, P, P, P]),
+    "codeps_disp_head_bwd_workspace_bytes": (c_size_t, [I, I, I]),
+    "codeps_disp_head_bwd": (c_int, [P, P, P, P, P, I, I, I, I, c_float, c_float, P, P, P, I, P, c_size_t, P]),
     "codeps_diag_mfma_rate": (c_int, [I, I, I, I, I, P, P, P, P]),
     "codeps_diag_stream_triad": (c_int, [P, P, P, LL, I, P, P]),
 }

@@ -1,0 +1,231 @@
+// The disparity output of the depth decoder in one pass each way (models/depth_head.py:44-49,73-77: ReflectionPad2d(1) ->
+// Conv2d(16, 1, 3) -> Sigmoid -> disp_to_depth).  Through the generic conv engine this layer wrote a 16-channel padded logit
+// tensor of which one channel is real (201 MB per 6 images at 512 x 1024), read it back for the sigmoid, and mirrored all of
+// it in the backward pass (padded logit gradient, data gradient w.r.t. the reflection-padded tensor + fold, weight gradient on
+// 15/16 zero columns): 1.3 ms per adaptation step for 0.03 GFLOP of real work.  Here every kernel moves the 16-channel
+// activation tensor exactly once (read forward, written in the data gradient, read in the weight gradient) and one float per
+// pixel otherwise -- plain fp32 FMAs, HBM-bound:
+//   disp_head_fwd_kernel   8 x 32 pixel tile with a reflected halo in LDS (80-byte pixel pitch: conflict-free 16-byte reads),
+//                          one thread per pixel: 144 FMAs, sigmoid, disp_to_depth
+//   disp_head_g_kernel     dlogit = (ddisp + ddepth d depth / d disp) s (1 - s)
+//   disp_head_dx_kernel    gather form of the transposed reflection-padded convolution: a border pixel also collects what the
+//                          reference adds back from the padding ring
+//   disp_head_dw_kernel    persistent blocks, 144 + 1 register accumulators per thread over its tiles, one fixed-order block
+//                          reduction, partials summed by disp_head_dw_finish_kernel in block order (deterministic)
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C = 16, C4 = C / 4;
+constexpr int TH = 8, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW, PITCH4 = 5;      // pixel pitch: 5 float4 = 80 bytes
+constexpr int NW = 9 * C;                                                                 // weights
+
+__device__ __forceinline__ int reflect1(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return min(max(i, 0), n - 1);                   // tiles overhanging the image: any valid pixel (never used)
+}
+
+// x [B][H][W][16] halo tile of (y0 - 1 .., x0 - 1 ..) into LDS, reflected at the image border
+__device__ __forceinline__ void load_halo(const float* __restrict__ x, int b, int H, int W, int y0, int x0, f32x4* xs) {
+    for (int i = threadIdx.x; i < HPIX * C4; i += 256) {
+        const int px = i / C4, q = i % C4;
+        const int iy = reflect1(y0 - 1 + px / HW, H), ix = reflect1(x0 - 1 + px % HW, W);
+        xs[px * PITCH4 + q] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + q * 4);
+    }
+}
+
+// OIHW [1][16][3][3] -> ws[tap][16] in LDS
+__device__ __forceinline__ void load_weights(const float* __restrict__ w, float* ws) {
+    for (int i = threadIdx.x; i < NW; i += 256) ws[i] = w[(i % C) * 9 + i / C];
+}
+
+__global__ __launch_bounds__(256) void disp_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            int H, int W, int tiles_x, float min_disp, float max_disp,
+                                                            float* __restrict__ disp, float* __restrict__ depth) {
+    __shared__ f32x4 xs[HPIX * PITCH4];
+    __shared__ __attribute__((aligned(16))) float ws[NW];
+    const int b = blockIdx.y, y0 = (blockIdx.x / tiles_x) * TH, x0 = (blockIdx.x % tiles_x) * TW;
+    load_halo(x, b, H, W, y0, x0, xs);
+    load_weights(w, ws);
+    __syncthreads();
+    const int ty = threadIdx.x / TW, tx = threadIdx.x % TW, y = y0 + ty, xx = x0 + tx;
+    if (y >= H || xx >= W) return;
+    float acc = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4* px = xs + ((ty + t / 3) * HW + tx + t % 3) * PITCH4;
+        const f32x4* wt = reinterpret_cast<const f32x4*>(ws + t * C);
+#pragma unroll
+        for (int q = 0; q < C4; ++q) {
+            const f32x4 a = px[q], k = wt[q];
+            acc += a[0] * k[0] + a[1] * k[1] + a[2] * k[2] + a[3] * k[3];
+        }
+    }
+    const size_t r = ((size_t)b * H + y) * W + xx;
+    const float s = 1.f / (1.f + expf(-acc));
+    disp[r] = s;
+    depth[r] = 1.f / (min_disp + (max_disp - min_disp) * s);
+}
+
+__global__ __launch_bounds__(256) void disp_head_g_kernel(const float* __restrict__ ddisp, const float* __restrict__ ddepth,
+                                                          const float* __restrict__ disp, long long M, float min_disp, float max_disp,
+                                                          float* __restrict__ g) {
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+        const float s = disp[r];
+        const float sd = min_disp + (max_disp - min_disp) * s;
+        float v = 0.f;
+        if (ddisp) v += ddisp[r];
+        if (ddepth) v += ddepth[r] * (-(max_disp - min_disp) / (sd * sd));
+        g[r] = v * s * (1.f - s);
+    }
+}
+
+// dx[q][c] = sum over padded positions u that reflect onto q and taps t with p = u - t inside the image of g[p] w[t][c]
+__global__ __launch_bounds__(256) void disp_head_dx_kernel(const float* __restrict__ g, const float* __restrict__ w, int B, int H, int W,
+                                                           float* __restrict__ dx) {
+    __shared__ __attribute__((aligned(16))) float ws[NW];
+    load_weights(w, ws);
+    __syncthreads();
+    const long long n = (long long)B * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int xq = (int)(i % W), yq = (int)((i / W) % H);
+        const float* gb = g + (i / ((long long)H * W)) * (long long)H * W;
+        f32x4 acc[C4];
+#pragma unroll
+        for (int q = 0; q < C4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // padded rows / columns that land on this pixel: itself, row -1 (on row 1), row H (on row H - 2)
+        const int uys[3] = {yq, yq == 1 ? -1 : -2, yq == H - 2 ? H : -2};
+        const int uxs[3] = {xq, xq == 1 ? -1 : -2, xq == W - 2 ? W : -2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int uy = uys[a];
+            if (uy == -2) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int ux = uxs[c];
+                if (ux == -2) continue;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int py = uy - (t / 3 - 1), px = ux - (t % 3 - 1);
+                    if (py < 0 || py >= H || px < 0 || px >= W) continue;
+                    const float gv = gb[(size_t)py * W + px];
+                    const f32x4* wt = reinterpret_cast<const f32x4*>(ws + t * C);
+#pragma unroll
+                    for (int q = 0; q < C4; ++q) acc[q] += gv * wt[q];
+                }
+            }
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(dx + i * C);
+#pragma unroll
+        for (int q = 0; q < C4; ++q) o[q] = acc[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void disp_head_dw_kernel(const float* __restrict__ x, const float* __restrict__ g, int B, int H, int W,
+                                                           int tiles_x, int tiles_y, float* __restrict__ part) {
+    __shared__ f32x4 xs[HPIX * PITCH4];
+    __shared__ float red[4][NW + 1];
+    const int ty = threadIdx.x / TW, tx = threadIdx.x % TW, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[9][C4];
+    float accb = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < C4; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = B * tiles_y * tiles_x;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+        __syncthreads();                                 // the previous tile's reads are done
+        load_halo(x, b, H, W, y0, x0, xs);
+        __syncthreads();
+        const int y = y0 + ty, xx = x0 + tx;
+        const float gv = (y < H && xx < W) ? g[((size_t)b * H + y) * W + xx] : 0.f;
+        accb += gv;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const f32x4* px = xs + ((ty + t / 3) * HW + tx + t % 3) * PITCH4;
+#pragma unroll
+            for (int q = 0; q < C4; ++q) acc[t][q] += gv * px[q];
+        }
+    }
+    // block reduction in a fixed order: 64 lanes by shuffles, then the four waves
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < C4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = wave_sum(acc[t][q][e]);
+                if (lane == 0) red[wave][t * C + q * 4 + e] = v;
+            }
+    {
+        const float v = wave_sum(accb);
+        if (lane == 0) red[wave][NW] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= NW; i += 256) part[(size_t)blockIdx.x * (NW + 1) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// partials [nblk][145] (tap-major weights, then the bias) -> OIHW weight gradient [1][16][3][3] and the bias gradient
+__global__ __launch_bounds__(256) void disp_head_dw_finish_kernel(const float* __restrict__ part, int nblk, int accumulate, float* __restrict__ dw,
+                                                                  float* __restrict__ dbias) {
+    const int i = threadIdx.x;
+    if (i > NW) return;
+    float a = 0.f;
+    for (int b = 0; b < nblk; ++b) a += part[(size_t)b * (NW + 1) + i];
+    if (i == NW) {
+        if (dbias) dbias[0] = accumulate ? dbias[0] + a : a;
+        return;
+    }
+    if (!dw) return;
+    const int o = (i % C) * 9 + i / C;
+    dw[o] = accumulate ? dw[o] + a : a;
+}
+
+}  // namespace
+
+extern "C" int codeps_disp_head_fwd(const float* x, const float* weight, const float* bias, int batch, int h, int w, int c, float min_depth,
+                                    float max_depth, float* disp, float* depth, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && weight && disp && depth && batch > 0 && h >= 2 && w >= 2, CODEPS_ERR_ARG, "codeps_disp_head_fwd: bad arguments");
+    CODEPS_REQUIRE(c == C, CODEPS_ERR_ARG, "codeps_disp_head_fwd: %d input channels (the decoder's last stage has %d)", c, C);
+    const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
+    hipLaunchKernelGGL(disp_head_fwd_kernel, dim3(tiles_x * tiles_y, batch), dim3(256), 0, (hipStream_t)stream, x, weight, bias, h, w, tiles_x,
+                       (float)(1.0 / (double)max_depth), (float)(1.0 / (double)min_depth), disp, depth);
+    CODEPS_CHECK_LAUNCH("disp_head_fwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" size_t codeps_disp_head_bwd_workspace_bytes(int batch, int h, int w) {
+    return batch > 0 ? align_up((size_t)batch * h * w * sizeof(float), 256) + (size_t)512 * (NW + 1) * sizeof(float) : 0;
+}
+
+extern "C" int codeps_disp_head_bwd(const float* x, const float* weight, const float* disp, const float* ddisp, const float* ddepth, int batch,
+                                    int h, int w, int c, float min_depth, float max_depth, float* dx, float* dweight, float* dbias,
+                                    int accumulate, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && weight && disp && (ddisp || ddepth) && workspace && batch > 0 && h >= 2 && w >= 2, CODEPS_ERR_ARG,
+                   "codeps_disp_head_bwd: bad arguments");
+    CODEPS_REQUIRE(c == C, CODEPS_ERR_ARG, "codeps_disp_head_bwd: %d input channels (the decoder's last stage has %d)", c, C);
+    CODEPS_REQUIRE(workspace_bytes >= codeps_disp_head_bwd_workspace_bytes(batch, h, w), CODEPS_ERR_WORKSPACE, "codeps_disp_head_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long long M = (long long)batch * h * w;
+    float* g = static_cast<float*>(workspace);
+    float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)M * sizeof(float), 256));
+    const float mind = (float)(1.0 / (double)max_depth), maxd = (float)(1.0 / (double)min_depth);
+    const int grid = (int)std::min<long long>((M + 255) / 256, 4096);
+    hipLaunchKernelGGL(disp_head_g_kernel, dim3(grid), dim3(256), 0, st, ddisp, ddepth, disp, M, mind, maxd, g);
+    if (dx) hipLaunchKernelGGL(disp_head_dx_kernel, dim3(grid), dim3(256), 0, st, (const float*)g, weight, batch, h, w, dx);
+    if (dweight || dbias) {
+        const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
+        const int nblk = std::min(batch * tiles_x * tiles_y, 512);
+        hipLaunchKernelGGL(disp_head_dw_kernel, dim3(nblk), dim3(256), 0, st, x, (const float*)g, batch, h, w, tiles_x, tiles_y, part);
+        hipLaunchKernelGGL(disp_head_dw_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, accumulate, dweight, dbias);
+    }
+    CODEPS_CHECK_LAUNCH("codeps_disp_head_bwd");
+    return CODEPS_OK;
+}

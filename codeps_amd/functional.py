@@ -1109,6 +1109,61 @@ def disp_depth(logits, min_depth=0.1, max_depth=100.0):
     return _DispDepth.apply(logits, float(min_depth), float(max_depth))
 
 
+class _DispHead(torch.autograd.Function):
+    """ReflectionPad2d(1) -> Conv2d(16, 1, 3) -> Sigmoid -> disp_to_depth in one kernel each way (C ABI: codeps_disp_head_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, min_depth, max_depth):
+        require_cuda(x, weight)
+        x = x.contiguous()
+        b, h, w, c = x.shape
+        wt = _f32c(weight.detach())
+        bs = None if bias is None else _f32c(bias.detach())
+        disp = torch.empty(b, 1, h, w, dtype=torch.float32, device=x.device)
+        depth = torch.empty_like(disp)
+        check(lib().codeps_disp_head_fwd(ptr(x), ptr(wt), ptr(bs), b, h, w, c, min_depth, max_depth, ptr(disp), ptr(depth), stream_ptr()),
+              "codeps_disp_head_fwd")
+        ctx.save_for_backward(x, wt, disp)
+        ctx.meta = (min_depth, max_depth, bias is not None)
+        ctx.w_sink = grad_sink(weight) if weight.requires_grad else None
+        ctx.b_sink = grad_sink(bias) if (bias is not None and bias.requires_grad) else None
+        return depth, disp
+
+    @staticmethod
+    def backward(ctx, ddepth, ddisp):
+        x, wt, disp = ctx.saved_tensors
+        mn, mx, has_bias = ctx.meta
+        b, h, w, c = x.shape
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_w, need_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        # weight and bias gradients leave through one launch: both accumulate into the flat buffer, or neither
+        sinks = ctx.w_sink is not None and (ctx.b_sink is not None or not need_b)
+        dw = db = None
+        if need_w:
+            dw = ctx.w_sink if sinks else torch.empty(1, c, 3, 3, dtype=torch.float32, device=dev)
+        if need_b:
+            db = ctx.b_sink if sinks else torch.empty(1, dtype=torch.float32, device=dev)
+        nbytes = lib().codeps_disp_head_bwd_workspace_bytes(b, h, w)
+        ws = _workspace(nbytes, dev, "disp_head")
+        check(lib().codeps_disp_head_bwd(ptr(x), ptr(wt), ptr(disp), ptr(None if ddisp is None else ddisp.contiguous()),
+                                         ptr(None if ddepth is None else ddepth.contiguous()), b, h, w, c, mn, mx, ptr(dx), ptr(dw), ptr(db),
+                                         1 if sinks else 0, ptr(ws), nbytes, stream_ptr()), "codeps_disp_head_bwd")
+        if sinks:
+            dw = db = None              # accumulated in place into the flat gradient buffer
+        elif ctx.w_sink is not None and dw is not None:
+            ctx.w_sink.add_(dw.view_as(ctx.w_sink))
+            dw = None
+        return dx, dw, db, None, None
+
+
+def disp_head(x, weight, bias, min_depth=0.1, max_depth=100.0):
+    """The depth decoder's output stage (models/depth_head.py:44-59,73-77) on NHWC features x [B,H,W,16]: reflection-padded
+    3x3 convolution to one channel, sigmoid, disp_to_depth -> (depth, disp), both [B,1,H,W]; the 16-channel tensor is moved once
+    each way."""
+    return _DispHead.apply(x, weight, bias, float(min_depth), float(max_depth))
+
+
 # ---------------------------------------------------------------------------------------- pose
 class _Pose(torch.autograd.Function):
     @staticmethod

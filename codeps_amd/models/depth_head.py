@@ -61,8 +61,11 @@ class DepthHead(nn.Module):
     def forward(self, in_feats, return_disparity: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
         x, _ = _run_decoder(self, in_feats)
         conv = self.dispconvs["0"][1]
-        logits = F.conv2d(x, conv.weight, conv.bias, pad=1, pad_mode="reflect")
-        depth_map, disp_map = F.disp_depth(logits)          # sigmoid + disp_to_depth, one kernel
+        if conv.in_channels == 16 and x.shape[-1] == 16:
+            depth_map, disp_map = F.disp_head(x, conv.weight, conv.bias)    # padded conv + sigmoid + disp_to_depth, one pass each way
+        else:
+            logits = F.conv2d(x, conv.weight, conv.bias, pad=1, pad_mode="reflect")
+            depth_map, disp_map = F.disp_depth(logits)      # sigmoid + disp_to_depth, one kernel
         # detached: a module attribute that holds the autograd graph of the last call keeps its AccumulateGrad nodes (and
         # their streams) alive across iterations, which breaks HIP-graph capture of the next step
         self.outputs = {0: disp_map.detach()}

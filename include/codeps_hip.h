@@ -546,6 +546,18 @@ int codeps_panoptic_stats(const int* pan_gt, const int* pan_pred, int batch, int
                           codeps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The depth decoder's disparity output in one pass each way (csrc/disp_head.hip): dispconvs["0"] = ReflectionPad2d(1) ->
+ * Conv2d(16, 1, 3), Sigmoid, DepthHead.disp_to_depth (models/depth_head.py:44-59,73-77).  x [B][h][w][16] NHWC fp32, weight
+ * [1][16][3][3] (OIHW), bias [1] (nullable); disp / depth [B][1][h][w].  _bwd: ddisp / ddepth [B][1][h][w] (either nullable)
+ * -> dx [B][h][w][16] (nullable), dweight [1][16][3][3], dbias [1] (nullable; += when accumulate); deterministic. */
+int codeps_disp_head_fwd(const float* x, const float* weight, const float* bias, int batch, int h, int w, int c, float min_depth,
+                         float max_depth, float* disp, float* depth, codeps_stream_t stream);
+size_t codeps_disp_head_bwd_workspace_bytes(int batch, int h, int w);
+int codeps_disp_head_bwd(const float* x, const float* weight, const float* disp, const float* ddisp, const float* ddepth, int batch,
+                         int h, int w, int c, float min_depth, float max_depth, float* dx, float* dweight, float* dbias,
+                         int accumulate, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Diagnostics (csrc/diag.hip): the two rooflines of SURVEY.md 8d as THIS box delivers them -- bench.py reports them beside the
  * vendor figures.  Both time `reps` launches with HIP events on `stream` and return milliseconds per launch.
  * codeps_diag_mfma_rate: register-resident MFMA loop, no memory traffic (mode 0 v_mfma_f32_32x32x16_bf16, 1 v_mfma_f32_32x32x2_f32,

@@ -39,3 +39,34 @@ def test_random_bilinear_shapes(i):
     h, w = rng.randint(1, 24), rng.randint(1, 30)
     oh, ow = h * rng.randint(1, 4) + rng.randint(0, 3), w * rng.randint(1, 4) + rng.randint(0, 3)
     run_bilinear_case(rng.random() < 0.5, rng.randint(1, 3), rng.choice([16, 32, 64, 144]), h, w, oh, ow, i)
+
+
+@pytest.mark.parametrize("i", range(14))
+def test_random_disparity_head_shapes(i):
+    """The fused output stage of the depth decoder (reflection-padded 16 -> 1 convolution, sigmoid, disp_to_depth; one pass each
+    way) against float64: outputs, data / weight / bias gradients, image sizes down to 2 x 2 (every pixel on the border)."""
+    import torch
+    import torch.nn.functional as TF
+    from codeps_amd import functional as F
+    rng = random.Random(2900 + i)
+    b = rng.randint(1, 3)
+    h, w = [(2, 2), (2, 5), (3, 3), (8, 32), (9, 33), (17, 70)][i] if i < 6 else (rng.randint(2, 40), rng.randint(2, 80))
+    g = torch.Generator().manual_seed(500 + i)
+    x = torch.randn(b, 16, h, w, generator=g)
+    wt = torch.randn(1, 16, 3, 3, generator=g) * 0.2
+    bs = torch.randn(1, generator=g) * 0.1
+    gd, gs = torch.randn(b, 1, h, w, generator=g), torch.randn(b, 1, h, w, generator=g)
+    rx, rw, rb = x.double().requires_grad_(True), wt.double().requires_grad_(True), bs.double().requires_grad_(True)
+    disp = torch.sigmoid(TF.conv2d(TF.pad(rx, (1, 1, 1, 1), mode="reflect"), rw, rb))
+    depth = 1 / (1 / 100 + (1 / 0.1 - 1 / 100) * disp)
+    ((depth * gd.double()).sum() + (disp * gs.double()).sum()).backward()
+    dx = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    dw, db = wt.cuda().requires_grad_(True), bs.cuda().requires_grad_(True)
+    d_depth, d_disp = F.disp_head(dx, dw, db)
+    ((d_depth * gd.cuda()).sum() + (d_disp * gs.cuda()).sum()).backward()
+
+    def rel(a, ref):
+        return float((a.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
+    assert rel(d_disp, disp.detach()) < 2e-6 and rel(d_depth, depth.detach()) < 2e-5
+    assert rel(dx.grad.permute(0, 3, 1, 2), rx.grad) < 2e-5
+    assert rel(dw.grad, rw.grad) < 2e-5 and rel(db.grad, rb.grad) < 2e-5
