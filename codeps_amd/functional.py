@@ -1109,6 +1109,79 @@ def disp_depth(logits, min_depth=0.1, max_depth=100.0):
     return _DispDepth.apply(logits, float(min_depth), float(max_depth))
 
 
+class _UpConv16(torch.autograd.Function):
+    """act(conv3x3(nearest_x2(x)) + bias), 16 -> 16 channels, as four 2x2 convolutions of the half-resolution tensor
+    (C ABI: codeps_upconv16_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        require_cuda(x, weight)
+        x = x.contiguous()
+        b, hs, ws_, c = x.shape
+        wt = _f32c(weight.detach())
+        bs = None if bias is None else _f32c(bias.detach())
+        y = torch.empty(b, 2 * hs, 2 * ws_, 16, dtype=torch.float32, device=x.device)
+        flops = 2.0 * b * 4 * hs * ws_ * 16 * 16 * 9                    # algorithmic: the 3x3 layer the reference runs
+        t0 = _prof_begin()
+        nb = lib().codeps_upconv16_workspace_bytes()
+        wsp = _workspace(nb, x.device, "upconv16_w")
+        check(lib().codeps_upconv16_fwd(ptr(x), ptr(wt), ptr(bs), b, hs, ws_, act, ptr(y), ptr(wsp), nb, stream_ptr()), "codeps_upconv16_fwd")
+        _prof_end(t0, "conv_fwd", flops)
+        ctx.act, ctx.flops, ctx.has_bias = act, flops, bias is not None
+        ctx.w_sink = grad_sink(weight) if weight.requires_grad else None
+        ctx.b_sink = grad_sink(bias) if (bias is not None and bias.requires_grad) else None
+        ctx.save_for_backward(x, wt, y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        b, hs, ws_, c = x.shape
+        rows = dy.numel() // 16
+        dev = dy.device
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dbias = None
+        if need_b:
+            dbias = ctx.b_sink if ctx.b_sink is not None else torch.empty(16, dtype=torch.float32, device=dev)
+        dz = dy
+        if ctx.act or need_b:
+            wsb = lib().codeps_colsum_workspace_bytes(rows, 16, 1)
+            ws = _workspace(wsb, dev, "colsum")
+            dz = torch.empty_like(dy) if ctx.act else dy
+            check(lib().codeps_act_bwd(ptr(dy), ptr(y), None, ctx.act, rows, 16, ptr(dz) if dz is not dy else None, ptr(dbias), 16,
+                                       1 if ctx.b_sink is not None else 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_act_bwd")
+            if ctx.b_sink is not None:
+                dbias = None
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            t0 = _prof_begin()
+            nb = lib().codeps_upconv16_workspace_bytes()
+            wsp = _workspace(nb, dev, "upconv16_w")
+            check(lib().codeps_upconv16_dgrad(ptr(dz), ptr(wt), b, hs, ws_, ptr(dx), ptr(wsp), nb, stream_ptr()), "codeps_upconv16_dgrad")
+            _prof_end(t0, "conv_dgrad", ctx.flops)
+        if ctx.needs_input_grad[1]:
+            sink = ctx.w_sink
+            dw = sink if sink is not None else torch.empty(16, 16, 3, 3, dtype=torch.float32, device=dev)
+            nbytes = lib().codeps_upconv16_wgrad_workspace_bytes()
+            ws = _workspace(nbytes, dev, "upconv16")
+            t0 = _prof_begin()
+            check(lib().codeps_upconv16_wgrad(ptr(x), ptr(dz), b, hs, ws_, ptr(dw), 1 if sink is not None else 0, ptr(ws), nbytes, stream_ptr()),
+                  "codeps_upconv16_wgrad")
+            _prof_end(t0, "conv_wgrad", ctx.flops)
+            if sink is not None:
+                dw = None
+        return dx, dw, dbias, None
+
+
+def upconv16(x, weight, bias=None, act=None):
+    """act(conv3x3(nearest_x2(x), weight) + bias) for 16 -> 16 channels without a skip tensor (the decoders' last stage,
+    models/depth_head.py:60-71): x [B,hs,ws,16] NHWC -> [B,2hs,2ws,16].  Same values as conv2d(..., up0=True) to fp32 rounding
+    (the taps that read one source pixel are summed in the weights first)."""
+    return _UpConv16.apply(x, weight, bias, ACT[act])
+
+
 class _DispHead(torch.autograd.Function):
     """ReflectionPad2d(1) -> Conv2d(16, 1, 3) -> Sigmoid -> disp_to_depth in one kernel each way (C ABI: codeps_disp_head_*)."""
 

@@ -3,6 +3,8 @@ depth).  Each decoder stage is two fused kernels: conv3x3+bias+ELU, and
 [nearest x2 upsample + concat skip + conv3x3 + bias + ELU] with the upsample / concat done on load."""
 from typing import Tuple, Union
 
+import os
+
 import numpy as np
 from numpy.typing import ArrayLike
 from torch import Tensor, nn
@@ -23,6 +25,9 @@ def _make_decoder(module, num_ch_enc, num_ch_dec, use_skips):
                                                  nn.ELU(inplace=True))
 
 
+_UPCONV16 = os.environ.get("CODEPS_UPCONV16", "1") != "0"      # A/B switch: 0 = the generic engine's fused-gather form
+
+
 def _run_decoder(module, in_feats, keep=()):
     """-> NHWC decoder output at scale 0 (and the scales listed in `keep`)."""
     x = F.from_nchw(in_feats[-1])
@@ -31,7 +36,10 @@ def _run_decoder(module, in_feats, keep=()):
         c0, c1 = module.upconvs_0[str(i)][0], module.upconvs_1[str(i)][0]
         x = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu")
         skip = F.from_nchw(in_feats[i - 1]) if (module.use_skips and i > 0) else None
-        x = F.conv2d(x, c1.weight, c1.bias, x1=skip, pad=1, act="elu", up0=True)
+        if skip is None and c1.in_channels == 16 and c1.out_channels == 16 and x.shape[-1] == 16 and _UPCONV16:
+            x = F.upconv16(x, c1.weight, c1.bias, act="elu")      # scale 0: four 2x2 convolutions of the half-resolution tensor
+        else:
+            x = F.conv2d(x, c1.weight, c1.bias, x1=skip, pad=1, act="elu", up0=True)
         if i in keep:
             kept[i] = x
     return x, kept

@@ -557,6 +557,21 @@ int codeps_disp_head_bwd(const float* x, const float* weight, const float* disp,
                          int h, int w, int c, float min_depth, float max_depth, float* dx, float* dweight, float* dbias,
                          int accumulate, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 
+/* The decoders' last up-convolution (csrc/upconv16.hip): nearest x2 -> Conv2d(16, 16, 3, padding 1) (+ bias, act 0 none / 1 ReLU /
+ * 2 ELU) with no skip tensor (models/depth_head.py:60-71 at scale 0) as four 2 x 2 convolutions of the half-resolution tensor
+ * (taps that read the same source pixel pre-summed), exact fp32 on the f32 MFMA.  x [B][hs][ws][16] NHWC, weight [16][16][3][3],
+ * y / dz [B][2 hs][2 ws][16]; workspace (forward, _dgrad) = codeps_upconv16_workspace_bytes: the pre-summed weights.
+ * _dgrad: dz -> dx [B][hs][ws][16]; _wgrad: dweight [16][16][3][3] (+= when accumulate; workspace =
+ * codeps_upconv16_wgrad_workspace_bytes, deterministic block order). */
+size_t codeps_upconv16_workspace_bytes(void);
+int codeps_upconv16_fwd(const float* x, const float* weight, const float* bias, int batch, int hs, int ws, int act, float* y,
+                        void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+int codeps_upconv16_dgrad(const float* dz, const float* weight, int batch, int hs, int ws, float* dx, void* workspace,
+                          size_t workspace_bytes, codeps_stream_t stream);
+size_t codeps_upconv16_wgrad_workspace_bytes(void);
+int codeps_upconv16_wgrad(const float* x, const float* dz, int batch, int hs, int ws, float* dweight, int accumulate, void* workspace,
+                          size_t workspace_bytes, codeps_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Diagnostics (csrc/diag.hip): the two rooflines of SURVEY.md 8d as THIS box delivers them -- bench.py reports them beside the
  * vendor figures.  Both time `reps` launches with HIP events on `stream` and return milliseconds per launch.

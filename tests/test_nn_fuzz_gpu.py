@@ -70,3 +70,45 @@ def test_random_disparity_head_shapes(i):
     assert rel(d_disp, disp.detach()) < 2e-6 and rel(d_depth, depth.detach()) < 2e-5
     assert rel(dx.grad.permute(0, 3, 1, 2), rx.grad) < 2e-5
     assert rel(dw.grad, rw.grad) < 2e-5 and rel(db.grad, rb.grad) < 2e-5
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_random_upconv16_shapes(i):
+    """The decoders' last up-convolution as four 2 x 2 convolutions of the half-resolution tensor (pre-summed taps, f32 MFMA)
+    against float64 nearest-x2 + 3 x 3 convolution + ELU: outputs and data / weight / bias gradients; source sizes from one pixel
+    to several tiles with ragged edges."""
+    import torch
+    import torch.nn.functional as TF
+    from codeps_amd import functional as F
+    rng = random.Random(3900 + i)
+    b = rng.randint(1, 3)
+    hs, ws = [(1, 1), (1, 7), (2, 2), (8, 16), (9, 17), (16, 32), (5, 40)][i] if i < 7 else (rng.randint(1, 30), rng.randint(1, 50))
+    act = [None, "elu", "relu"][i % 3]
+    g = torch.Generator().manual_seed(700 + i)
+    x = torch.randn(b, 16, hs, ws, generator=g)
+    wt = torch.randn(16, 16, 3, 3, generator=g) / 12.0
+    bs = torch.randn(16, generator=g) * 0.1 if i % 4 else None
+    gy = torch.randn(b, 16, 2 * hs, 2 * ws, generator=g)
+    rx, rw = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    rb = bs.double().requires_grad_(True) if bs is not None else None
+    pre = TF.conv2d(TF.interpolate(rx, scale_factor=2, mode="nearest"), rw, rb, padding=1)
+    y = TF.elu(pre) if act == "elu" else (TF.relu(pre) if act == "relu" else pre)
+    gy64 = gy.double() * ((pre.detach().abs() > 1e-5) if act == "relu" else 1.0)      # no gradient on the ReLU kink
+    (y * gy64).sum().backward()
+    dx = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    dw = wt.cuda().requires_grad_(True)
+    db = bs.cuda().requires_grad_(True) if bs is not None else None
+    out = F.upconv16(dx, dw, db, act)
+    assert out.shape == (b, 2 * hs, 2 * ws, 16)
+    out.backward(gy64.float().permute(0, 2, 3, 1).contiguous().cuda())
+
+    def rel(a, ref):
+        return float((a.detach().double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
+    assert rel(out.permute(0, 3, 1, 2), y.detach()) < 5e-6
+    assert rel(dx.grad.permute(0, 3, 1, 2), rx.grad) < 2e-5
+    assert rel(dw.grad, rw.grad) < 2e-5
+    if bs is not None:
+        assert rel(db.grad, rb.grad) < 2e-5
+    # and against the generic engine's fused-gather form
+    ref = F.conv2d(dx.detach(), dw.detach(), None if db is None else db.detach(), pad=1, act=act, up0=True)
+    assert rel(out, ref.detach().double().cpu()) < 5e-6
