@@ -2007,9 +2007,55 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
     }
 }
 
+// 3x3 layers: one block per (output channel, 64 input channels) owns all nine taps, so that the OIHW scatter ([ci][tap]: a
+// 36-byte stride per tap-major element) becomes one contiguous run of 576 floats through an LDS transpose.  Slab s goes to lane
+// group s mod 16; the groups meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const f32x4* __restrict__ part, int splits, long long total4, int Ct, int n_chunks,
+                                                            int co_real, int ci_real, float* __restrict__ dw, int accumulate) {
+    __shared__ f32x4 red[16][9 * 16];
+    __shared__ float outt[9 * 64 + 8];
+    const int co = blockIdx.x / n_chunks, ci0 = (blockIdx.x % n_chunks) * 64;
+    const int l = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int cw = min(64, Ct - ci0);                                 // padded channels of this chunk (a multiple of 16)
+    if (co >= co_real) return;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (l * 4 < cw) {
+        const size_t base = ((size_t)co * 9 * Ct + ci0) / 4 + l;
+        for (int sl = g; sl < splits; sl += 16) {
+            const f32x4* ps = part + (size_t)sl * total4 + base;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] += ps[(size_t)t * (Ct / 4)];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[g][t * 16 + l] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < 9 * 16) {
+        f32x4 a = red[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) a += red[k][threadIdx.x];
+        const int t = threadIdx.x / 16, c4 = threadIdx.x % 16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) outt[(c4 * 4 + e) * 9 + t] = a[e];   // [ci][tap]
+    }
+    __syncthreads();
+    const int n_real = min(cw, ci_real - ci0);
+    float* dst = dw + ((size_t)co * ci_real + ci0) * 9;
+    for (int i = threadIdx.x; i < n_real * 9; i += 256) dst[i] = accumulate ? dst[i] + outt[i] : outt[i];
+}
+
 static void launch_wgrad_reduce(const float* part, int splits, int Co, int Ct, int taps, int co_real, int ci_real, float* dw, int accumulate,
                                 hipStream_t st) {
     const long long total4 = (long long)Co * Ct * taps / 4;      // Ct is a multiple of 16
+    static const int red9 = getenv("CODEPS_REDUCE9") ? atoi(getenv("CODEPS_REDUCE9")) : 1;
+    if (red9 && taps == 9 && Ct >= 64 && ci_real > 0) {
+        const int n_chunks = cdiv(Ct, 64);
+        hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3(Co * n_chunks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(part), splits, total4, Ct,
+                           n_chunks, co_real, ci_real, dw, accumulate);
+        return;
+    }
     // few columns and many slabs: 16 slab groups per block (16 columns), else 4 (64 columns)
     if (total4 / 64 < 1024 && splits >= 32)
         hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((int)((total4 + 15) / 16)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(part), splits,
