@@ -113,6 +113,7 @@ SIGNATURES = {
     "codeps_stem_weight_bwd": (c_int, [P, I, I, I, P, P]),
     "codeps_guda_weight_fwd": (c_int, [P, I, I, I, P, P, P]),
     "codeps_guda_weight_bwd": (c_int, [P, I, I, I, P, I, P, P]),
+    "codeps_up_dgrad_weight": (c_int, [P, I, I, I, P, P]),
     "codeps_reflect_pad_fold": (c_int, [P, I, I, I, I, I, P, P]),
     "codeps_panoptic_workspace_bytes": (c_size_t, [I, I, I]),
     "codeps_panoptic_fusion": (c_int, [P, P, P, I, I, I, ctypes.c_ulonglong, I, I, c_float, I, I, P, P, P, P, P, c_size_t, P]),

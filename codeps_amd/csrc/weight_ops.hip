@@ -5,6 +5,8 @@
 //            [9 * 16][c_k] (row = tap * 16 + class, classes >= n zero) and the fine branch's own [n][c_f][3][3] block
 // Both maps are injective on the source, so the backward is a gather as well (no atomics); `accumulate` adds into the
 // flat gradient buffer of the step harness.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -77,6 +79,25 @@ static int fill_seg(GudaSeg& s, int n, int ct, int n_coarse, const int* channels
     return CODEPS_OK;
 }
 
+
+// Data gradient of "nearest x2 -> conv3x3 (padding 1)" w.r.t. the half-resolution tensor = a 4 x 4, stride-2, padding-1 FORWARD
+// convolution of dz: the 36 (sub-pixel, tap) pairs that reach a source pixel fall on 16 distinct output pixels 2 q + d,
+// d in {-1, 0, 1, 2} per axis, with the taps that coincide pre-summed: d = -1: W[2]; 0: W[1] + W[2]; 1: W[0] + W[1]; 2: W[0].
+// w [co][ci_total][3][3] (the up-sampled source are input channels 0 .. c0 - 1) -> wt [c0][co][4][4] (OIHW of that forward conv).
+__global__ __launch_bounds__(256) void up_dgrad_weight_kernel(const float* __restrict__ w, int co, int ci_total, int c0, float* __restrict__ wt) {
+    const long long n = (long long)c0 * co * 16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int tx = (int)(i & 3), ty = (int)((i >> 2) & 3), o = (int)((i >> 4) % co), c = (int)(i / (16LL * co));
+        const float* src = w + ((size_t)o * ci_total + c) * 9;
+        const int ky0 = ty == 0 ? 2 : (ty == 1 ? 1 : 0), ky1 = ty == 0 ? 2 : (ty == 1 ? 2 : (ty == 2 ? 1 : 0));
+        const int kx0 = tx == 0 ? 2 : (tx == 1 ? 1 : 0), kx1 = tx == 0 ? 2 : (tx == 1 ? 2 : (tx == 2 ? 1 : 0));
+        float s = 0.f;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) s += src[ky * 3 + kx];
+        wt[i] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" int codeps_stem_weight_fwd(const float* w, int out_c, int in_c, float* w_double_pixel, codeps_stream_t stream) {
@@ -115,5 +136,14 @@ extern "C" int codeps_guda_weight_bwd(float* const* grad_outs, int n_classes, in
     hipLaunchKernelGGL(guda_weight_bwd_kernel, dim3(cdiv(n_classes * in_c * 9, 256)), dim3(256), 0, (hipStream_t)stream, s, n_classes, in_c,
                        accumulate, grad_w);
     CODEPS_CHECK_LAUNCH("guda_weight_bwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_up_dgrad_weight(const float* w, int out_c, int in_c_total, int c0, float* wt, codeps_stream_t stream) {
+    CODEPS_REQUIRE(w && wt && out_c > 0 && c0 > 0 && c0 <= in_c_total, CODEPS_ERR_ARG, "codeps_up_dgrad_weight: bad arguments");
+    const long long n = (long long)c0 * out_c * 16;
+    hipLaunchKernelGGL(up_dgrad_weight_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, w, out_c,
+                       in_c_total, c0, wt);
+    CODEPS_CHECK_LAUNCH("up_dgrad_weight_kernel");
     return CODEPS_OK;
 }

@@ -4,6 +4,7 @@ PyTorch supplies device memory (caching allocator), the current HIP stream and t
 all arithmetic happens in libcodeps_hip.so.  Every function raises on CPU tensors -- no fallback.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -426,6 +427,9 @@ def _prof_end(start, kind, flops, desc=None, source=0):
     _profile["events"].append((kind, flops, start, e, tag))
 
 
+_UP_DGRAD16 = os.environ.get("CODEPS_UP_DGRAD16", "1") != "0"     # A/B switch: 0 = the 36-pair gather form of the data-gradient kernel
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv(cat(up(x0), x1), W) * scale + shift + residual) on NHWC tensors (C ABI conv2d)."""
 
@@ -457,6 +461,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.w_sink = grad_sink(weight) if weight.requires_grad else None
         ctx.b_sink = grad_sink(bias) if (bias is not None and bias.requires_grad) else None
         ctx.c0_real = min(ci, x0.shape[3])
+        ctx.weight_ref = weakref.ref(weight)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x0, x1, y if act else None, wd, sc)
         return y
@@ -501,6 +506,24 @@ class _Conv2d(torch.autograd.Function):
             dx0 = torch.empty_like(x0)
             check(lib().codeps_reflect_pad_fold(ptr(dxp), desc.batch, desc.in_h, desc.in_w, desc.c0, p_, ptr(dx0), stream_ptr()),
                   "codeps_reflect_pad_fold")
+        elif ctx.needs_input_grad[0] and _UP_DGRAD16 and desc.up0 and (desc.kh, desc.kw, desc.stride, desc.pad) == (3, 3, 1, 1) and \
+                ctx.c0_real == x0.shape[3] and ctx.c0_real > 16:
+            # nearest x2 + 3x3: the gradient w.r.t. the half-resolution source is a 4x4 / stride-2 forward convolution of dz with
+            # pre-summed taps (16 instead of 36 (sub-pixel, tap) pairs) -- and it runs on the forward kernels
+            wsrc = ctx.weight_ref()
+            wt = torch.empty(ctx.c0_real, ctx.co, 4, 4, dtype=torch.float32, device=dy.device)
+            check(lib().codeps_up_dgrad_weight(ptr(_f32c(wsrc.detach())), ctx.co, ctx.ci, ctx.c0_real, ptr(wt), stream_ptr()),
+                  "codeps_up_dgrad_weight")
+            c0p = x0.shape[3]
+            wf2, _ = pack_weights(wt, c0p, cop, False)
+            d2 = _conv_desc(dz, None, c0p, 4, 4, (2, 2), (1, 1), 0, 0, False)
+            dx0 = torch.empty_like(x0)
+            t0 = _prof_begin()
+            wsb = lib().codeps_conv2d_fwd_workspace_bytes(ctypes.byref(d2))
+            ws2 = _workspace(wsb, dy.device, "splitk") if wsb else None
+            check(lib().codeps_conv2d_fwd(ctypes.byref(d2), ptr(dz), None, ptr(wf2), None, None, None, ptr(dx0), ptr(ws2),
+                                          ws2.numel() if ws2 is not None else 0, stream_ptr()), "codeps_conv2d_fwd (up-conv data gradient)")
+            _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci), d2)
         elif ctx.needs_input_grad[0]:
             dx0 = torch.empty_like(x0)
             t0 = _prof_begin()

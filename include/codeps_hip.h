@@ -305,6 +305,11 @@ int codeps_guda_weight_fwd(const float* w, int n_classes, int in_c, int n_coarse
                            float* const* outs, codeps_stream_t stream);
 int codeps_guda_weight_bwd(float* const* grad_outs, int n_classes, int in_c, int n_coarse, const int* channels,
                            int accumulate, float* grad_w, codeps_stream_t stream);
+/* The data gradient of "nearest x2 -> conv3x3(padding 1)" w.r.t. the half-resolution source (the decoders' up-convolutions,
+ * models/depth_head.py:60-71) is a 4 x 4 / stride-2 / padding-1 forward convolution of dz: w [out_c][in_c_total][3][3] -> wt
+ * [c0][out_c][4][4], the OIHW weight of that convolution with the coinciding taps pre-summed (16 taps instead of 36 (sub-pixel,
+ * tap) pairs); c0 = channels of the up-sampled source (input channels 0 .. c0 - 1). */
+int codeps_up_dgrad_weight(const float* w, int out_c, int in_c_total, int c0, float* wt, codeps_stream_t stream);
 /* Transpose of nn.ReflectionPad2d(pad) on NHWC: grad_padded [B][h+2p][w+2p][c] -> grad_x [B][h][w][c]. */
 int codeps_reflect_pad_fold(const float* grad_padded, int batch, int h, int w, int c, int pad, float* grad_x,
                             codeps_stream_t stream);
