@@ -523,7 +523,7 @@ class _Conv2d(torch.autograd.Function):
             ws2 = _workspace(wsb, dy.device, "splitk") if wsb else None
             check(lib().codeps_conv2d_fwd(ctypes.byref(d2), ptr(dz), None, ptr(wf2), None, None, None, ptr(dx0), ptr(ws2),
                                           ws2.numel() if ws2 is not None else 0, stream_ptr()), "codeps_conv2d_fwd (up-conv data gradient)")
-            _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci), d2)
+            _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci) * (16.0 / 36.0), d2)      # the FLOPs this form performs
         elif ctx.needs_input_grad[0]:
             dx0 = torch.empty_like(x0)
             t0 = _prof_begin()
@@ -1144,7 +1144,7 @@ class _UpConv16(torch.autograd.Function):
         wt = _f32c(weight.detach())
         bs = None if bias is None else _f32c(bias.detach())
         y = torch.empty(b, 2 * hs, 2 * ws_, 16, dtype=torch.float32, device=x.device)
-        flops = 2.0 * b * 4 * hs * ws_ * 16 * 16 * 9                    # algorithmic: the 3x3 layer the reference runs
+        flops = 2.0 * b * 4 * hs * ws_ * 16 * 16 * 4                    # performed: four 2x2 convolutions (the reference's 3x3 form: x 9 / 4)
         t0 = _prof_begin()
         nb = lib().codeps_upconv16_workspace_bytes()
         wsp = _workspace(nb, x.device, "upconv16_w")
