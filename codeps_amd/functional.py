@@ -507,7 +507,7 @@ class _Conv2d(torch.autograd.Function):
             check(lib().codeps_reflect_pad_fold(ptr(dxp), desc.batch, desc.in_h, desc.in_w, desc.c0, p_, ptr(dx0), stream_ptr()),
                   "codeps_reflect_pad_fold")
         elif ctx.needs_input_grad[0] and _UP_DGRAD16 and desc.up0 and (desc.kh, desc.kw, desc.stride, desc.pad) == (3, 3, 1, 1) and \
-                ctx.c0_real == x0.shape[3] and ctx.c0_real > 16:
+                ctx.c0_real == x0.shape[3] and ctx.c0_real > 16 and ctx.weight_ref() is not None:
             # nearest x2 + 3x3: the gradient w.r.t. the half-resolution source is a 4x4 / stride-2 forward convolution of dz with
             # pre-summed taps (16 instead of 36 (sub-pixel, tap) pairs) -- and it runs on the forward kernels
             wsrc = ctx.weight_ref()
