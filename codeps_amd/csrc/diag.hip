@@ -82,14 +82,14 @@ int timed(hipStream_t st, int reps, float* ms, F&& launch) {
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return CODEPS_ERR_LAUNCH;
     launch();                                                    // warm-up (code object load, clocks)
-    hipEventRecord(e0, st);
+    (void)hipEventRecord(e0, st);
     for (int r = 0; r < reps; ++r) launch();
-    hipEventRecord(e1, st);
+    (void)hipEventRecord(e1, st);
     hipError_t e = hipEventSynchronize(e1);
     float t = 0.f;
-    hipEventElapsedTime(&t, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     if (e != hipSuccess) { codeps_set_error("diagnostic kernel failed: %s", hipGetErrorString(e)); return CODEPS_ERR_LAUNCH; }
     *ms = t / (float)reps;
     return CODEPS_OK;

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void conf_row_dt_kernel(const uint8_t* __restr
     best_i[threadIdx.x] = bi;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
+        if ((int)threadIdx.x < o) {
             const float ov = best_v[threadIdx.x + o];
             const int oi = best_i[threadIdx.x + o];
             if (ov > best_v[threadIdx.x] || (ov == best_v[threadIdx.x] && oi < best_i[threadIdx.x])) { best_v[threadIdx.x] = ov; best_i[threadIdx.x] = oi; }

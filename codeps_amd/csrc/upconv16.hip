@@ -22,7 +22,6 @@ constexpr int SH = 8, SW = 16;                         // source tile: 8 x 16 pi
 constexpr int XH = SH + 2, XW = SW + 2, XPIX = XH * XW;
 constexpr int P4 = 5;                                  // pixel pitch in float4 (80 bytes: conflict-free 16-byte reads)
 constexpr int NWC = 4 * 4 * C * C;                     // collapsed weights [class][tap][ci][co]
-constexpr int OH_ = 2 * SH, OW_ = 2 * SW;              // output tile
 
 // source-row offset of collapsed tap a for parity p, and the set of 3x3 taps it sums
 __device__ __forceinline__ int off_of(int p, int a) { return a - 1 + p; }
