@@ -849,6 +849,253 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------- halo-tile variant, weights by LDS DMA
+// conv_halo3_kernel re-timed around two facts.  (1) The pre-split weights are plain copies, so they go global -> LDS without
+// passing registers: `buffer_load_dwordx4 ... lds` into a ring of four (tap, chunk) tiles, issued as soon as a slot's
+// fragments have been read, two taps before the tile is needed.  (2) The activation tile is constant for the nine taps of
+// a chunk, so tap t + 1's A and B fragments are read while tap t's MFMAs run (taps fully unrolled, one fragment read per
+// four MFMAs pinned with sched_group_barrier -- left alone the scheduler sinks the reads behind the MFMAs).  One barrier per
+// tap.  The DMA is issued through inline assembly and its completion is counted by hand (vector-memory operations return
+// in order): through the builtin the compiler orders every later LDS read behind the transfer with vmcnt(0), which
+// also drains the activation loads in flight.  Measured on the ResNet-101 layer3 3x3 (B 8, 32 x 64, 256 -> 256): 120 -> 105 us
+// back to back, -0.37 ms per step with the streams serialised, -0.13 ms with them overlapped (149 KB of LDS: nothing of
+// the pose stream shares the CU).  128 output columns only: with 64 (two chunks of nine taps per block, 96 KB) it loses
+// the second block per CU and measures 10 % slower than conv_halo3_kernel.  CODEPS_HALO_RING=0 selects conv_halo3_kernel.
+template <int MODE, int TN>
+__global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ residual, float* __restrict__ out) {
+    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = 3;
+    constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;
+    constexpr int BN = 32 * WN * TN;
+    constexpr int LDK = (NP * BK + 8) / 2;
+    constexpr int APASS = (HPIX * 4 + 255) / 256, NALOAD = APASS * 2;
+    constexpr int RING = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [HPIX + 1][LDK]  (row HPIX: staging tasks past the tile)
+    float* Bs = smem + (HPIX + 1) * LDK;               // [RING][BN][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
+    const int nt = logical % p.n_nt, mt = logical / p.n_nt;
+    const int n0 = nt * BN;
+    const int Hm = (MODE == MODE_FWD) ? p.Ho : p.H, Wm = (MODE == MODE_FWD) ? p.Wo : p.W;
+    const int tiles_x = Wm / TW, tiles_y = Hm / TH;
+    const int b = mt / (tiles_x * tiles_y), tr = mt % (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+    const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
+    const int nchunks = Kc / BK;
+    const bool up = MODE == MODE_FWD && p.up0;
+    const int H0 = up ? Hm / 2 : Hm, W0 = up ? Wm / 2 : Wm;
+    const int cs0 = (MODE == MODE_FWD) ? p.C0 : p.Co;
+    const float* img0 = a0 + (size_t)b * H0 * W0 * cs0;
+    const float* img1 = (MODE == MODE_FWD && p.C1 > 0) ? a1 + (size_t)b * Hm * Wm * p.C1 : nullptr;
+    const int achunk = tid & 3;
+
+    // weights: lane L of the tile's linear 16-byte segment index copies segment L % 13 of row L / 13 (13th = pad); every wave
+    // issues BPW instructions per tile (the waves past the last partial group repeat their previous instruction)
+    const size_t wrow = (size_t)9 * Kc;
+    constexpr int BINS = BN * 13 / 64, BPW = (BINS + 3) / 4;
+    static_assert((BN * 13) % 64 == 0 && LDK * 4 == 13 * 16 && BPW + NALOAD < 16, "linear DMA layout; vmcnt immediates");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned boff[BPW], bins[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int ins = wave_u + 4 * i < BINS ? wave_u + 4 * i : wave_u + 4 * (i - 1);
+        const int L = ins * 64 + lane, row = L / 13, seg = L % 13;
+        bins[i] = (unsigned)ins * 1024u;
+        boff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * 6 + (seg < 12 ? seg : 0) * 16);
+    }
+    i32x4 rsBv;
+    {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(p.w3);
+        const size_t bytes = (size_t)p.N * wrow * 6;
+        rsBv[0] = (int)__builtin_amdgcn_readfirstlane((unsigned)a);
+        rsBv[1] = (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xFFFFu);
+        rsBv[2] = (int)__builtin_amdgcn_readfirstlane((unsigned)(bytes < (size_t)GATHER_OOB ? bytes : (size_t)GATHER_OOB));
+        rsBv[3] = 0x00020000;
+    }
+    const unsigned bs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(Bs);
+    auto dma_b = [&](int tap, int chunk, int slot) {
+        const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((tap * Kc + chunk * BK) * 6);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(bs_lds + slot * BN * LDK * 4 + bins[i]);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(boff[i]), "s"(rsBv), "s"(koff) : "memory");
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t rsA0 = make_rsrc(img0, (size_t)H0 * W0 * cs0 * 4);
+    const __amdgpu_buffer_rsrc_t rsA1 = make_rsrc(img1 ? img1 : img0, img1 ? (size_t)Hm * Wm * p.C1 * 4 : 0);
+    f32x4 areg[NALOAD];
+    auto load_a = [&](int chunk) {
+        const int cstep = chunk * BK;
+        const bool s1 = MODE == MODE_FWD && cstep >= p.C0;
+        const int cs = s1 ? p.C1 : cs0, ws = s1 ? Wm : W0, sh = (!s1 && up) ? 1 : 0;
+        const unsigned cbyte = (unsigned)((s1 ? cstep - p.C0 : cstep) + achunk * 8) * 4u;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int pos = (tid >> 2) + 64 * i;
+            const int iy = y0 + pos / HW - 1, ix = x0 + pos % HW - 1;
+            const bool ok = pos < HPIX && iy >= 0 && iy < Hm && ix >= 0 && ix < Wm;
+            const unsigned off = ok ? (unsigned)(((iy >> sh) * ws + (ix >> sh)) * cs) * 4u + cbyte : GATHER_OOB;
+            if (s1) {
+                areg[i * 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA1, off, 0, 0));
+                areg[i * 2 + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA1, off, 16, 0));
+            } else {
+                areg[i * 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA0, off, 0, 0));
+                areg[i * 2 + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA0, off, 16, 0));
+            }
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int pos = min((tid >> 2) + 64 * i, HPIX);
+            u16x4 lo[NP], hi[NP];
+            split_bf16<NP>(areg[i * 2], lo);
+            split_bf16<NP>(areg[i * 2 + 1], hi);
+            unsigned short* row = reinterpret_cast<unsigned short*>(As + pos * LDK);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + achunk * 8) = pack8(lo[q], hi[q]);
+        }
+    };
+
+    constexpr int NA = 4, NB = 2 * TN;
+    const int l16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned short* arow[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int pix = wm * 64 + i * 16 + l16;
+        arow[i] = reinterpret_cast<const unsigned short*>(As + ((pix / TW) * HW + pix % TW) * LDK) + kg * 8;
+    }
+    const unsigned short* brow = reinterpret_cast<const unsigned short*>(Bs + (wn * TN * 32 + l16) * LDK) + kg * 8;
+
+    struct Frag { bf16x8 a[NA][NP], b[NB][NP]; };
+    auto read_frags = [&](int tap, int slot, Frag& f) {             // tap: compile-time after unrolling; slot: wave-uniform
+        const int ky = tap / 3, kx = tap % 3;
+        const int toff = ((MODE == MODE_FWD) ? ky * HW + kx : (2 - ky) * HW + (2 - kx)) * LDK * 2;      // halfwords
+        const unsigned short* bp = brow + slot * (BN * LDK * 2);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) f.a[i][q] = *reinterpret_cast<const bf16x8*>(arow[i] + toff + q * BK);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) f.b[j][q] = *reinterpret_cast<const bf16x8*>(bp + j * 16 * LDK * 2 + q * BK);
+    };
+    auto mfmas = [&](const Frag& f) {
+#pragma unroll
+        for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+            for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i][qa], f.b[j][ord - qa], acc[i][j], 0, 0, 0);
+    };
+    const int T = 9 * nchunks;
+    load_a(0);
+#pragma unroll
+    for (int g = 0; g < RING; ++g) dma_b(g, 0, g);                // nchunks >= 1: taps 0 .. 3 exist
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // the first activation tile and four weight tiles have landed
+#pragma unroll
+    for (int i = 0; i < NALOAD; ++i) asm volatile("" : "+v"(areg[i]));
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int g0 = chunk * 9;
+        const bool more = chunk + 1 < nchunks;
+        __syncthreads();                                          // the previous chunk's fragment reads are done
+        store_a();
+        __syncthreads();
+        Frag fr[2];
+        read_frags(0, g0 & 3, fr[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_a(chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int g = g0 + tap;
+            if (tap < 8) read_frags(tap + 1, (g + 1) & 3, fr[(tap + 1) & 1]);   // tile g + 1 landed before the barrier that ended tap g - 1
+            mfmas(fr[tap & 1]);
+            if (tap < 8) {                                         // one fragment read per four MFMAs (the scheduler would sink the reads)
+#pragma unroll
+                for (int k = 0; k < NA * NP + NB * NP; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, (NA * NB * 6) / (NA * NP + NB * NP), 0);
+                }
+            }
+            // End of tap g: tile g + 2 (issued after the barrier that ended tap g - 2) must have landed.  Younger operations
+            // that may stay in flight: tile g + 3 (BPW instructions, if it exists) and, at taps 0 and 1, the next chunk's
+            // activation loads (issued at the chunk's start, after tiles g0 + 2 and g0 + 3).  Tile g0 + 4 is younger than
+            // those loads, so tap 2's wait completes them -- told to the compiler there (an empty asm that "uses" the
+            // registers), or it would count them against the DMA instructions in flight when store_a reads them.
+            const bool t3 = g + 3 < T;
+            if (tap < 2 && more) {
+                if (t3) __builtin_amdgcn_s_waitcnt(0x0F70 | (BPW + NALOAD));
+                else __builtin_amdgcn_s_waitcnt(0x0F70 | NALOAD);
+            } else {
+                if (t3) __builtin_amdgcn_s_waitcnt(0x0F70 | BPW);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            if (tap == 2) {                                        // unconditional: the waitcnt pass is not path-sensitive
+#pragma unroll
+                for (int i = 0; i < NALOAD; ++i) asm volatile("" : "+v"(areg[i]));
+            }
+            __syncthreads();
+            // every wave has read tile g's fragments (during tap g - 1, or at the chunk's start): its slot takes tile g + 4
+            if (g + 4 < T) dma_b((tap + 4) % 9, chunk + (tap + 4) / 9, g & 3);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    // ---- epilogue (as in conv_halo3_kernel)
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;
+    constexpr int V4 = BN / 4, RPASS = 256 / V4;
+    const int c4 = tid % V4, r0 = tid / V4;
+    const int n = n0 + c4 * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_FWD && n < p.N) {
+        if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+        if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cs[(wm * 32 + ih * 16 + 4 * kg + r) * LDC + (wn * NB + j) * 16 + l16] = acc[2 * i + ih][j][r];
+        __syncthreads();
+        if (n < p.N) {
+#pragma unroll 4
+            for (int rr = r0; rr < WM * 32; rr += RPASS) {
+                const int pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
+                const size_t m = ((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
+                if (MODE == MODE_FWD) {
+                    v = v * sc + sh;
+                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                *reinterpret_cast<f32x4*>(out + m * p.N + n) = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- 16-column variant
 // N <= 16 (disparity / class / centre-offset outputs, the 16-channel full-resolution decoder tail and their data
 // gradients): v_mfma_f32_16x16x4_f32 tiles, so no MFMA work is spent on zero-padded output columns.
@@ -2225,6 +2472,19 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                               : (plain && p.src == 0 && p.Cs == p.C0)) &&
             (long long)p.n_mt * p.n_nt >= halo3 * 128) {
             constexpr size_t lds_h = std::max((size_t)(204 + 2 * BN) * LDKf * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            static const int halo_ring = getenv("CODEPS_HALO_RING") ? atoi(getenv("CODEPS_HALO_RING")) : 1;
+            if constexpr (TN == 2) {
+                if (halo_ring) {
+                    constexpr size_t lds_r = (size_t)(205 + 4 * BN) * LDKf * sizeof(float);
+                    auto kr = conv_halo3r_kernel<MODE, TN>;
+                    static bool r_attr = false;
+                    if (!r_attr) { (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); r_attr = true; }
+                    p.ksplit = 1;
+                    g_last_kernel = "conv_halo3r_kernel";
+                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt), dim3(256), lds_r, st, p, a0, a1, scale, shift, residual, out);
+                    return;
+                }
+            }
             auto kh = conv_halo3_kernel<MODE, TN>;
             static bool h_attr = false;
             if (!h_attr) { (void)hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); h_attr = true; }

@@ -3,7 +3,7 @@
 The conv engine feeds fp32 operands to the bf16 matrix cores as exact 3-way bf16 splits (six piece products, fp32 accumulate:
 csrc/conv.hip).  The claim "indistinguishable from an fp32 convolution" (reference arithmetic: fp32 convs,
 models/resnet_encoder.py:115-126) is checked here against float64 for each variant the adaptation step spends its time in --
-`conv_halo3_kernel` (forward, data gradient, fused up-sample + concat), `conv_igemm_ws_kernel`, `conv_igemm_kernel<split3>`,
+`conv_halo3_kernel` / `conv_halo3r_kernel` (forward, data gradient, fused up-sample + concat), `conv_igemm_ws_kernel`, `conv_igemm_kernel<split3>`,
 the split stem forward (16-channel K-steps), `wgrad_halo64s_kernel`, `wgrad_stem74s_kernel` -- on well-scaled, on
 wide-dynamic-range and on cancelling inputs: the error against float64 must stay within 3x of the error torch's own fp32 CPU
 convolution makes on the same tensors, or (long accumulation chains) within 1.5x of this library's f32-MFMA kernels on them.  `codeps_conv2d_last_kernel` proves that the shape
@@ -88,6 +88,8 @@ CASES = {
     # name: (B, H, W, Cin, Cout, k, expected forward kernel, expected dgrad kernel, expected wgrad kernel)
     "halo3_64": (4, 64, 128, 64, 64, 3, "conv_halo3_kernel", "conv_halo3_kernel", "wgrad_halo64s_kernel"),
     "halo3_128": (2, 64, 128, 128, 128, 3, "conv_halo3_kernel", "conv_halo3_kernel", "wgrad_halo64s_kernel"),
+    "halo3r_256": (2, 64, 128, 128, 256, 3, "conv_halo3r_kernel", None, "wgrad_halo64s_kernel"),      # 128-column tiles: weights by LDS DMA
+    "halo3r_dgrad": (2, 64, 128, 256, 256, 3, "conv_halo3r_kernel", "conv_halo3r_kernel", None),
     "ws_3x3_256": (7, 32, 64, 256, 256, 3, "conv_igemm_ws_kernel", "conv_igemm_ws_kernel", None),
     "ws_1x1_2048": (4, 32, 64, 2048, 512, 1, "conv_igemm_ws_kernel", None, None),
     "igemm_1x1": (8, 32, 64, 256, 1024, 1, "conv_igemm_kernel<split3>", "conv_igemm_ws_kernel", None),      # dgrad: K = 1024, one round of 128x128 blocks
@@ -136,10 +138,12 @@ def test_split_kernels_are_at_fp32_rounding_level(case, kind):
 
 
 @pytest.mark.parametrize("kind", ["normal", "wide", "cancel"])
-def test_halo3_with_fused_upsample_and_concat(kind):
-    """The decoder's conv3x3(cat(nearest_x2(x0), x1)) (models/depth_head.py:60-71) on the halo-tile kernel."""
+@pytest.mark.parametrize("co,kernel", [(64, "conv_halo3_kernel"), (256, "conv_halo3r_kernel")])
+def test_halo3_with_fused_upsample_and_concat(kind, co, kernel):
+    """The decoder's conv3x3(cat(nearest_x2(x0), x1)) (models/depth_head.py:60-71) on the halo-tile kernels (64 columns: weights
+    staged through registers; 128 columns: weights by LDS DMA)."""
     F = _F()
-    b, h, w_, c0, c1, co = 4, 64, 128, 64, 32, 64
+    b, h, w_, c0, c1 = 4, 64, 128, 64, (32 if co == 64 else 64)        # 36 K-steps for the wide case: 128-column tiles
     x0, wt, g = _inputs(kind, (b, c0, h // 2, w_ // 2), (co, c0 + c1, 3, 3), 55)
     x1 = _inputs(kind, (b, c1, h, w_), (1, 1, 1, 1), 56)[0]
     gy = torch.randn(b, co, h, w_, generator=g)
@@ -156,7 +160,7 @@ def test_halo3_with_fused_upsample_and_concat(kind):
         return (l2(nchw(y.detach(), co), y64), l2(nchw(a1.grad, c1), dc64[:, c0:]), l2(nchw(a0.grad, c0), up_t(dc64)),
                 l2(ww.grad.cpu(), dw64))
 
-    got = run("conv_halo3_kernel")
+    got = run(kernel)
     with _arith(0):
         mfma = run("f32")
     torch32 = (l2(y32, y64), l2(dc32[:, c0:], dc64[:, c0:]), l2(up_t(dc32), up_t(dc64)), l2(dw32, dw64))
