@@ -170,6 +170,7 @@ SIGNATURES = {
     "codeps_upconv16_wgrad": (c_int, [P, P, I, I, I, P, I, P, c_size_t, P]),
     "codeps_diag_mfma_rate": (c_int, [I, I, I, I, I, P, P, P, P]),
     "codeps_diag_stream_triad": (c_int, [P, P, P, LL, I, P, P]),
+    "codeps_diag_feed_rate": (c_int, [I, I, I, I, I, P, LL, P, P, P]),
 }
 
 

@@ -77,6 +77,115 @@ __global__ __launch_bounds__(256) void triad_kernel(const f32x4* __restrict__ b,
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) a[i] = b[i] + s * c[i];
 }
 
+// How many bytes per clock can a CU take in NEXT TO a full-rate MFMA stream?  One block of four waves per CU; per iteration
+// every wave issues 96 v_mfma_f32_16x16x32_bf16 on register operands (a 128 x 128 x 32 six-product K-step) and the block
+// brings `kb` KiB from an L2-resident window into LDS:
+//   mode 0: no loads;  mode 1: buffer loads into VGPRs, ds_write_b128 after the MFMAs (how the conv kernels stage);
+//   mode 2: buffer_load_dwordx4 ... lds (LDS DMA, no VGPR round trip), waited before the barrier.
+// The loads of iteration i + 1 are issued before the MFMAs of iteration i (double-buffered LDS), as in the kernels.
+typedef int i32x4d __attribute__((ext_vector_type(4)));
+template <int MODE, int FRAGS>
+__global__ __launch_bounds__(256) void feed_kernel(const char* __restrict__ src, unsigned window_bytes, int iters, int kb, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int MAXL = 16;                                     // 16-byte loads per thread and iteration: up to 64 KiB per block
+    const int nl = kb * 1024 / (256 * 16);
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[q][e] = (__bf16)unit(mix(0x1234u + tid * 64 + q * 16 + e));
+            b[q][e] = (__bf16)unit(mix(0x9876u + tid * 64 + q * 16 + e));
+        }
+    f32x4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    i32x4d rs;
+    {
+        const unsigned long long p = reinterpret_cast<unsigned long long>(src);
+        rs[0] = (int)__builtin_amdgcn_readfirstlane((unsigned)p);
+        rs[1] = (int)(__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xFFFFu);
+        rs[2] = (int)window_bytes;
+        rs[3] = 0x00020000;
+    }
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, (int)window_bytes, 0x00020000);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds);
+    const unsigned span = (unsigned)kb * 1024u;
+    f32x4 regs[MAXL];
+    unsigned pos = (blockIdx.x * 7919u * 1024u) % (window_bytes - span);
+    auto issue = [&](int buf) {
+        const unsigned g0 = pos & ~1023u;
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i)
+                if (i < nl) regs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, g0 + (i * 256 + tid) * 16, 0, 0));
+        } else if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i)
+                if (i < nl) {
+                    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds_base + buf * span + (i * 4 + wave) * 1024);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                                 :: "s"(dst), "v"((unsigned)(lane * 16)), "s"(rs), "s"(g0 + (i * 4 + wave) * 1024) : "memory");
+                }
+        }
+        pos = (pos + span * 13u) % (window_bytes - span);
+    };
+    issue(0);
+    float sink = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i)
+                if (i < nl) *reinterpret_cast<f32x4*>(lds + buf * span + (i * 256 + tid) * 16) = regs[i];
+        } else if (MODE == 2) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __syncthreads();
+        issue(buf ^ 1);
+        if (FRAGS) {
+            // the conv kernels' fragment traffic: 24 ds_read_b128 per wave and K-step (conflict-free 208-byte row pitch), read one
+            // step ahead of the MFMAs that use them, one read per four MFMAs
+            bf16x8 fa[12], fb[12];
+            const char* fbase = lds + buf * span + ((lane & 15) * 208 + (lane >> 4) * 16) % (span - 4096);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                fa[q] = *reinterpret_cast<const bf16x8*>(fbase + (q % 3) * 64 + (q / 3) * 16 * 208 % 2048);
+                fb[q] = *reinterpret_cast<const bf16x8*>(fbase + 2048 + (q % 3) * 64 + (q / 3) * 16 * 208 % 2048);
+            }
+#pragma unroll
+            for (int u = 0; u < 96; ++u)
+                acc[u & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(u + (u >> 4)) & 3], b[(u >> 2) & 3], acc[u & 15], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 24; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a[q] = fa[q * 3]; b[q] = fb[q * 3 + 1]; }     // the next iteration's operands
+#pragma unroll
+            for (int q = 0; q < 12; ++q) sink += (float)fa[q][0] + (float)fb[q][0];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 96; ++u)
+                acc[u & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(u + (u >> 4)) & 3], b[(u >> 2) & 3], acc[u & 15], 0, 0, 0);
+        }
+        if (kb > 0) sink += *reinterpret_cast<const float*>(lds + buf * span + ((tid * 68 + it * 4) % span & ~3u));
+        __syncthreads();
+    }
+    if (MODE == 2) __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sink += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < MAXL; ++i)
+            if (i < nl) sink += regs[i][0];
+    }
+    out[blockIdx.x * 256 + tid] = sink;
+}
+
 template <typename F>
 int timed(hipStream_t st, int reps, float* ms, F&& launch) {
     hipEvent_t e0, e1;
@@ -122,5 +231,40 @@ extern "C" int codeps_diag_stream_triad(float* a, const float* b, const float* c
                            n / 4, reinterpret_cast<f32x4*>(a));
     });
     CODEPS_CHECK_LAUNCH("triad_kernel");
+    return rc;
+}
+
+extern "C" int codeps_diag_feed_rate(int mode, int kb, int blocks, int iters, int reps, const void* window, long long window_bytes,
+                                     float* scratch, float* ms_per_launch, codeps_stream_t stream) {
+    CODEPS_REQUIRE(mode >= 0 && (mode & 3) <= 2 && mode < 8 && kb >= 0 && kb <= 64 && (kb % 4) == 0 && blocks > 0 && iters > 0 && reps > 0 && window &&
+                       window_bytes >= (1 << 20) && window_bytes < (1LL << 31) && scratch && ms_per_launch,
+                   CODEPS_ERR_ARG, "codeps_diag_feed_rate: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)2 * (kb ? kb : 4) * 1024;
+    CODEPS_REQUIRE(!(mode & 4) || kb >= 8, CODEPS_ERR_ARG, "codeps_diag_feed_rate: the fragment reads need kb >= 8");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)feed_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)feed_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)feed_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)feed_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)feed_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)feed_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const char* w = static_cast<const char*>(window);
+    int rc = timed(st, reps, ms_per_launch, [&]() {
+#define FEED(M, F) hipLaunchKernelGGL((feed_kernel<M, F>), dim3(blocks), dim3(256), lds, st, w, (unsigned)window_bytes, iters, kb, scratch)
+        switch (mode) {
+            case 0: FEED(0, 0); break;
+            case 1: FEED(1, 0); break;
+            case 2: FEED(2, 0); break;
+            case 4: FEED(0, 1); break;
+            case 5: FEED(1, 1); break;
+            default: FEED(2, 1); break;
+        }
+#undef FEED
+    });
+    CODEPS_CHECK_LAUNCH("feed_kernel");
     return rc;
 }

@@ -588,6 +588,14 @@ int codeps_diag_mfma_rate(int mode, int random_data, int blocks, int iters, int 
                           float* ms_per_launch, codeps_stream_t stream);
 int codeps_diag_stream_triad(float* a, const float* b, const float* c, long long n, int reps, float* ms_per_launch,
                              codeps_stream_t stream);
+/* codeps_diag_feed_rate: how many bytes per clock a CU takes in next to a full-rate MFMA stream.  One block of four waves per
+ *      CU; per iteration each wave issues 96 v_mfma_f32_16x16x32_bf16 on register operands and the block brings `kb` KiB
+ *      (multiple of 4, <= 64) from `window` (device memory, 1 MiB <= window_bytes < 2 GiB; keep it L2-sized) into LDS.
+ *      mode 0: no loads; 1: buffer loads into VGPRs + ds_write_b128 (how the conv kernels stage); 2: buffer_load ... lds
+ *      (LDS DMA); + 4: every wave also reads 24 ds_read_b128 fragments per iteration from the tile (one per four MFMAs, the
+ *      conv kernels' fragment traffic; kb >= 8).  scratch: blocks * 256 floats.  Returns the time per launch. */
+int codeps_diag_feed_rate(int mode, int kb, int blocks, int iters, int reps, const void* window, long long window_bytes,
+                          float* scratch, float* ms_per_launch, codeps_stream_t stream);
 
 #ifdef __cplusplus
 }
