@@ -856,6 +856,90 @@ __global__ __launch_bounds__(256) void guda_gather_fwd_kernel(GudaP p, const flo
     }
 }
 
+// Tiled form of guda_gather_fwd_kernel for branches at <= 1/2 of the output resolution.  The bilinear weights are separable, so
+// for an 8 x 64 output tile and one branch the block first blends VERTICALLY and sums the three ky taps at the branch's own
+// column resolution:  R[ty][col][kx][c] = sum_ky (wy0 Y[y0][col][ky, kx, c] + wy1 Y[y1][col][ky, kx, c])   (rows of tap ky outside
+// the image contribute nothing) -- 8 x <= 36 x 48 values in LDS, read from Y in 192-byte runs -- and every output pixel then
+// blends HORIZONTALLY: out += sum_kx (wx0 R[ty][x0][kx] + wx1 R[ty][x1][kx]) at position x + kx - 1 (outside the image: nothing).
+// 6 Y loads per R element instead of 36 per output pixel and channel quad; column pitch 52 floats keeps the 16-byte LDS reads of
+// neighbouring pixels on different banks.  Rounding differs from the direct form in the order of the blends only.
+constexpr int GT_TH = 8, GT_TW = 64, GT_COLS = 36, GT_PITCH = 52;
+__global__ __launch_bounds__(256) void guda_gather_fwd_tiled_kernel(GudaP p, int tiles_x, int tiles_y, const float* __restrict__ base,
+                                                                    float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float R[GT_TH * GT_COLS * GT_PITCH];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
+    const int ty0 = (tr / tiles_x) * GT_TH, tx0 = (tr % tiles_x) * GT_TW;
+    const int prow = tid >> 5, px0 = (tid & 31) * 2;               // this thread's two pixels: row ty0 + prow, columns tx0 + px0, + 1
+    const int oy = ty0 + prow;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.nb; ++k) {
+        const GudaBranch br = p.br[k];
+        const float* yb = br.y + (size_t)b * br.h * br.w * 144;
+        // low-res columns the tile's taps can touch: sources of output columns tx0 - 1 .. tx0 + GT_TW (clamped to the image)
+        int c_lo, c_hi, dummy;
+        float fd0, fd1;
+        bil_src(0, br.rw, max(tx0 - 1, 0), br.w, p.W, c_lo, dummy, fd0, fd1);
+        bil_src(0, br.rw, min(tx0 + GT_TW, p.W - 1), br.w, p.W, dummy, c_hi, fd0, fd1);
+        const int ncols = c_hi - c_lo + 1;                          // <= GT_COLS (checked by the launcher)
+        __syncthreads();                                            // the previous branch's reads of R are done
+        for (int e = tid; e < GT_TH * ncols * 12; e += 256) {
+            const int k4 = e % 12, col = (e / 12) % ncols, ty = e / (12 * ncols);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int y = ty0 + ty;
+            if (y < p.H) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int qy = y + ky - 1;
+                    if (qy < 0 || qy >= p.H) continue;
+                    int y0, y1; float ly0, ly1;
+                    bil_src(0, br.rh, qy, br.h, p.H, y0, y1, ly0, ly1);
+                    const float* src = yb + (size_t)(c_lo + col) * 144 + ky * 48 + k4 * 4;
+                    v += ly0 * *reinterpret_cast<const f32x4*>(src + (size_t)y0 * br.w * 144) +
+                         ly1 * *reinterpret_cast<const f32x4*>(src + (size_t)y1 * br.w * 144);
+                }
+            }
+            *reinterpret_cast<f32x4*>(R + (ty * GT_COLS + col) * GT_PITCH + k4 * 4) = v;
+        }
+        __syncthreads();
+        if (oy < p.H) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ox = tx0 + px0 + j;
+                if (ox >= p.W) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int qx = ox + kx - 1;
+                    if (qx < 0 || qx >= p.W) continue;
+                    int x0, x1; float lx0, lx1;
+                    bil_src(0, br.rw, qx, br.w, p.W, x0, x1, lx0, lx1);
+                    const float* r0 = R + (prow * GT_COLS + (x0 - c_lo)) * GT_PITCH + kx * 16;
+                    const float* r1 = R + (prow * GT_COLS + (x1 - c_lo)) * GT_PITCH + kx * 16;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[j][c] += lx0 * *reinterpret_cast<const f32x4*>(r0 + c * 4) + lx1 * *reinterpret_cast<const f32x4*>(r1 + c * 4);
+                }
+            }
+        }
+    }
+    if (oy < p.H) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = tx0 + px0 + j;
+            if (ox >= p.W) continue;
+            const size_t o = (((size_t)b * p.H + oy) * p.W + ox) << 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<f32x4*>(out + o + c * 4) = *reinterpret_cast<const f32x4*>(base + o + c * 4) + acc[j][c];
+        }
+    }
+}
+
 // d y_branch[b][qy][qx][tap][c] = sum_oy wy(oy; qy) sum_ox wx(ox; qx) dout[b][oy - dky][ox - dkx][c]   (dk = tap offset -1..1,
 // w = bilinear weight of low-res row / column q for full-res row / column o).  The weights are separable, so the transpose
 // runs as two 1-D passes (4x fewer loads than the 2-D footprint sum at x8):
@@ -1343,6 +1427,17 @@ extern "C" int codeps_guda_gather_fwd(const float* base, int batch, int h, int w
         CODEPS_REQUIRE(y[k] && bh[k] > 0 && bw[k] > 0 && bh[k] < h && bw[k] < w, CODEPS_ERR_ARG, "guda_gather_fwd: branch %d must be coarser than the output", k);
         p.br[k].y = y[k]; p.br[k].h = bh[k]; p.br[k].w = bw[k];
         p.br[k].rh = (float)bh[k] / (float)h; p.br[k].rw = (float)bw[k] / (float)w;
+    }
+    // tiled form when every branch's column footprint of a 64-pixel tile (+ the taps' halo) fits the LDS tile: ratios <= ~1/2
+    static const int tiled_env = getenv("CODEPS_GUDA_TILED") ? atoi(getenv("CODEPS_GUDA_TILED")) : 1;
+    bool tiled = tiled_env != 0;
+    for (int k = 0; k < n_branches; ++k)
+        if ((int)ceilf((float)(GT_TW + 2) * p.br[k].rw) + 3 > GT_COLS) tiled = false;
+    if (tiled) {
+        const int tiles_x = (w + GT_TW - 1) / GT_TW, tiles_y = (h + GT_TH - 1) / GT_TH;
+        hipLaunchKernelGGL(guda_gather_fwd_tiled_kernel, dim3(batch * tiles_x * tiles_y), dim3(256), 0, (hipStream_t)stream, p, tiles_x, tiles_y, base, out);
+        CODEPS_CHECK_LAUNCH("guda_gather_fwd_tiled_kernel");
+        return CODEPS_OK;
     }
     hipLaunchKernelGGL(guda_gather_fwd_kernel, dim3(grid_for((long long)batch * h * ((w + 3) / 4) * 4)), dim3(256), 0, (hipStream_t)stream, p, base, out);
     CODEPS_CHECK_LAUNCH("guda_gather_fwd_kernel");

@@ -234,7 +234,7 @@ def test_stem_conv_double_pixel_layout(ci, h, w, b):
     assert rel_err(dw.grad.cpu(), rw.grad) < 1e-5
 
 
-@pytest.mark.parametrize("h,w,b", [(32, 48, 2), (24, 40, 1)])
+@pytest.mark.parametrize("h,w,b", [(32, 48, 2), (24, 40, 1), (37, 150, 1), (16, 200, 2)])      # the last two: several 8 x 64 tiles, ragged edges, non-integer ratios
 def test_guda_fusion_matches_concat_conv(h, w, b):
     """conv3x3(cat(up(d_k))) evaluated as per-tap 1x1 convs at low resolution + tap gather (semantic_head.py:64-72)."""
     F = _F()
