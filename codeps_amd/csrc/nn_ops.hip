@@ -119,15 +119,19 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblk, int K, int C,
                                                             float* __restrict__ out, int c_real, int accumulate) {
-    // part: [nblk][K][C] -> out [K][c_real]; 16 lanes per output walk the blocks (fixed assignment + fixed shuffle tree)
+    // part: [nblk][K][C] -> out [K][c_real]; one wave per output walks the blocks (fixed assignment: lane l takes blocks l, l + 64, ...
+    // in order, then a fixed shuffle tree) -- with <= 1024 blocks that is <= 16 dependent loads per lane (16 lanes per output
+    // walked 64 each and the kernel took 11 us of pure latency, 25 times per step)
     const int total = K * C;
-    const int i = blockIdx.x * 16 + threadIdx.x / 16, sub = threadIdx.x % 16;
+    const int i = blockIdx.x * 4 + threadIdx.x / 64, sub = threadIdx.x % 64;
     const bool in = i < total;
     float a = 0.f;
-    if (in)
-        for (int b = sub; b < nblk; b += 16) a += part[(size_t)b * total + i];
+    if (in) {
+#pragma unroll 4
+        for (int b = sub; b < nblk; b += 64) a += part[(size_t)b * total + i];
+    }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     if (!in || sub != 0) return;
     const int c = i % C, k = i / C;
     if (c >= c_real) return;
@@ -1183,7 +1187,7 @@ extern "C" int codeps_act_bwd(const float* dy, const float* y, const float* scal
     hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, dy, y, scale, act, rows, c, dz, part, rpb);
     CODEPS_CHECK_LAUNCH("act_bwd_kernel");
     if (dbias) {
-        hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(c, 16)), dim3(256), 0, st, part, nblk, 1, c, dbias, c_real, accumulate);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(c, 4)), dim3(256), 0, st, part, nblk, 1, c, dbias, c_real, accumulate);
         CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     }
     return CODEPS_OK;
@@ -1200,7 +1204,7 @@ extern "C" int codeps_bn_stats(const float* x, long long rows, int c, float* sum
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, rows, c, (float*)workspace, rpb);
     CODEPS_CHECK_LAUNCH("bn_stats_kernel");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 16)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 4)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     return CODEPS_OK;
 }
@@ -1227,7 +1231,7 @@ extern "C" int codeps_bn_bwd_reduce(const float* dy, const float* y, const float
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, dy, y, x, mean, invstd, act, rows, c, (float*)workspace, rpb);
     CODEPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 16)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(2 * c, 4)), dim3(256), 0, st, (const float*)workspace, nblk, 2, c, sums, c, 0);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     return CODEPS_OK;
 }
@@ -1391,7 +1395,7 @@ extern "C" int codeps_dwconv5x5_wgrad(const float* x, const float* dz, int batch
     const int ipb = (int)((items + nblk - 1) / nblk);
     hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, dz, batch, h, w, c, (float*)workspace, ipb);
     CODEPS_CHECK_LAUNCH("dwconv5_wgrad_kernel");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(25 * c, 16)), dim3(256), 0, st, (const float*)workspace, nblk, 25, c, dw25c, c, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(25 * c, 4)), dim3(256), 0, st, (const float*)workspace, nblk, 25, c, dw25c, c, 0);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     return CODEPS_OK;
 }
