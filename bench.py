@@ -30,17 +30,12 @@ PEAK_HBM_GBS = 8000.0
 
 def build(device, encoder_layers, h, w, mode, target_hw=None):
     from codeps_amd.codeps import gen_models
-    from codeps_amd.config import get_cfg_defaults
-    cfg = get_cfg_defaults(adapt=(mode == "adapt"))
+    from codeps_amd.config import get_cfg_shipped
+    # defaults + the shipped YAML of the mode (cfg/adapt_cityscapes_kitti_360.yaml / cfg/train_cityscapes.yaml), io_utils.py:220-237
+    cfg = get_cfg_shipped(adapt=(mode == "adapt"))
     cfg.model.po_depth_net.params.nof_layers = encoder_layers
     cfg.dataset.feed_img_size = list(target_hw) if target_hw is not None else [h, w]
     cfg.adapt.source_dataset.feed_img_size = [h, w]
-    if mode == "train":
-        cfg.model.instance_head.use_thing_mask = True
-    # cfg/adapt_cityscapes_kitti_360.yaml:31-43
-    cfg.adapt.mixup.merge({"general": {"mixup_strategies": ["cut_mixup", "cut_mixup"]},
-                           "cut_mix": {"nof_hor_splits": 4, "nof_vert_splits": 2, "nof_segments": 2},
-                           "conf_instance_mix": {"conf_thresh": 0.98, "min_inst_size": 2000}})
     torch.manual_seed(20)                   # the scripts' default seed (scripts/train_codeps.py:51)
     net = gen_models(cfg, device, list(range(9)), [9, 10, 11, 12, 13], [], adaptation_mode=(mode == "adapt"))
     return net, cfg

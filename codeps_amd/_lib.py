@@ -15,9 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
 LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
+DIAG_LIB_PATH = os.path.join(_HERE, "libcodeps_diag.so")
 
 _lib = None
+_diag = None
 
 
 class CodepsHipError(RuntimeError):
@@ -168,6 +170,12 @@ SIGNATURES = {
     "codeps_upconv16_dgrad": (c_int, [P, P, I, I, I, P, P, c_size_t, P]),
     "codeps_upconv16_wgrad_workspace_bytes": (c_size_t, []),
     "codeps_upconv16_wgrad": (c_int, [P, P, I, I, I, P, I, P, c_size_t, P]),
+}
+
+# include/codeps_diag.h: libcodeps_diag.so (micro-benchmarks + the pre-split 1x1 prototype; not part of the product ABI)
+DIAG_SIGNATURES = {
+    "codeps_diag_version": (c_int, []),
+    "codeps_diag_last_error": (c_char_p, []),
     "codeps_diag_mfma_rate": (c_int, [I, I, I, I, I, P, P, P, P]),
     "codeps_diag_stream_triad": (c_int, [P, P, P, LL, I, P, P]),
     "codeps_diag_feed_rate": (c_int, [I, I, I, I, I, P, LL, P, P, P]),
@@ -193,9 +201,27 @@ def lib():
     return _lib
 
 
+def diag_lib():
+    """libcodeps_diag.so (tools/, bench.py's measured peaks, the diagnostics tests); never needed by the hot path."""
+    global _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise CodepsHipError(f"{DIAG_LIB_PATH} not found: build it with `make -C codeps_amd/csrc`")
+        handle = ctypes.CDLL(DIAG_LIB_PATH)
+        for name, (res, args) in DIAG_SIGNATURES.items():
+            _sig(getattr(handle, name), res, *args)
+        _diag = handle
+    return _diag
+
+
 def check(rc, what):
     if rc != 0:
         raise CodepsHipError(f"{what} failed ({rc}): {lib().codeps_last_error().decode()}")
+
+
+def check_diag(rc, what):
+    if rc != 0:
+        raise CodepsHipError(f"{what} failed ({rc}): {diag_lib().codeps_diag_last_error().decode()}")
 
 
 def stream_ptr():

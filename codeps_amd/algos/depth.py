@@ -265,7 +265,7 @@ class DepthAlgo:
             coef = F.depth_key_weights(counts, dev, ti, transformations.get("target") if shard["owner"] else None, self._rule_state,
                                        self.skip_rule_length, shard)
             if on_device:
-                self.adaptation_cache["is_car_moving"] = coef._codeps_keep          # device flag: 1 = kept (read lazily)
+                self.adaptation_cache["is_car_moving"] = 1.0 - coef._codeps_keep    # device flag, 1 = skipped like the reference's `= skip_image` (read lazily)
         elif on_device:
             coef = F.depth_key_weights(counts, dev, live.index("target"), transformations["target"], self._rule_state,
                                        self.skip_rule_length)

@@ -20,8 +20,15 @@ void codeps_set_error(const char* fmt, ...);
         }                                        \
     } while (0)
 
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (kernel, device); thread-safe.
+// A failure sets the error string and is remembered for the calling thread: the next CODEPS_CHECK_LAUNCH returns it instead
+// of the generic launch error the kernel would produce.
+void codeps_allow_lds(const void* kernel, int bytes, const char* name);
+bool codeps_take_attr_failure(void);
+
 #define CODEPS_CHECK_LAUNCH(name)                                                      \
     do {                                                                               \
+        if (codeps_take_attr_failure()) { (void)hipGetLastError(); return CODEPS_ERR_LAUNCH; } \
         hipError_t e__ = hipGetLastError();                                            \
         if (e__ != hipSuccess) {                                                       \
             codeps_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \

@@ -2477,8 +2477,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                 if (halo_ring) {
                     constexpr size_t lds_r = (size_t)(205 + 4 * BN) * LDKf * sizeof(float);
                     auto kr = conv_halo3r_kernel<MODE, TN>;
-                    static bool r_attr = false;
-                    if (!r_attr) { (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); r_attr = true; }
+                    codeps_allow_lds((const void*)kr, 160 * 1024, "kr");
                     p.ksplit = 1;
                     g_last_kernel = "conv_halo3r_kernel";
                     hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt), dim3(256), lds_r, st, p, a0, a1, scale, shift, residual, out);
@@ -2486,8 +2485,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                 }
             }
             auto kh = conv_halo3_kernel<MODE, TN>;
-            static bool h_attr = false;
-            if (!h_attr) { (void)hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); h_attr = true; }
+            codeps_allow_lds((const void*)kh, 160 * 1024, "kh");
             p.ksplit = 1;
             g_last_kernel = "conv_halo3_kernel";
             hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
@@ -2503,8 +2501,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             const int nsrc_ = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
             const size_t lds_ws = std::max(((size_t)2 * (BM + BN) * LDKf + (size_t)nsrc_ * ntap_ * BM) * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
             auto kw = conv_igemm_ws_kernel<MODE, TN>;
-            static bool ws_attr = false;
-            if (!ws_attr) { (void)hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ws_attr = true; }
+            codeps_allow_lds((const void*)kw, 160 * 1024, "kw");
             const int blocks_ = p.n_mt * p.n_nt;
             p.ksplit = 1; p.ksteps = nsteps_;
             const int ks_ = splitk_slices(p, blocks_, nsteps_);
@@ -2521,8 +2518,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         }
     }
     auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, NP>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    codeps_allow_lds((const void*)k, 160 * 1024, "k");
     // split-K when the tile grid cannot fill the chip and K is deep (B = 1 target inference, 1/32-resolution decoder inputs)
     const int blocks = p.n_mt * p.n_nt, Kc = (MODE == MODE_FWD) ? p.Ct : p.Co, nsteps = ntap * (Kc / BK);
     p.ksplit = 1; p.ksteps = nsteps;
@@ -2574,12 +2570,8 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         } else {
             const int ntap = (MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW;
             const size_t lds = (size_t)((MODE == MODE_FWD && p.C1 > 0) ? 2 : 1) * ntap * 256 * sizeof(unsigned);
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)conv_igemm16_kernel<MODE, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-                (void)hipFuncSetAttribute((const void*)conv_igemm16_kernel<MODE, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-                attr_set = true;
-            }
+            codeps_allow_lds((const void*)conv_igemm16_kernel<MODE, 32>, 120 * 1024, "conv_igemm16_kernel<32>");
+            codeps_allow_lds((const void*)conv_igemm16_kernel<MODE, 16>, 120 * 1024, "conv_igemm16_kernel<16>");
             if (bk32) hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
             else      hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
         }
@@ -2862,8 +2854,7 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
             g_last_kernel = wgrad_split_on() ? "wgrad_halo64s_kernel" : "wgrad_halo64_kernel";
             if (wgrad_split_on()) {
                 constexpr size_t lds = (size_t)64 * ((3 * 64 + 8) + (3 * 6 * 32 + 8)) * 2;           // dZs + Xs (halfwords)
-                static bool attr = false;
-                if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_halo64s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+                codeps_allow_lds((const void*)wgrad_halo64s_kernel, 160 * 1024, "wgrad_halo64s_kernel");
                 hipLaunchKernelGGL(wgrad_halo64s_kernel, dim3(g, sp.co_groups), dim3(256), lds, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
                                    sp.tiles_per_block, x0, x1, dz, part);
             } else

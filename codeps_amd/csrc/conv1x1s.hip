@@ -11,6 +11,7 @@
 // registers in the K loop.  80 KB of LDS: two blocks per CU, the second block's MFMAs cover the first one's DMA wait.
 // Arithmetic: identical to conv.hip (six products of order <= 2 per multiply, fp32 accumulation).
 #include "common.h"
+#include "../../include/codeps_diag.h"
 #include <algorithm>
 
 namespace {
@@ -240,8 +241,7 @@ extern "C" int codeps_conv1x1_split_fwd(const void* a_split, long long rows, int
     C1P p;
     p.M = (int)rows; p.N = out_c; p.K = in_c; p.act = act;
     p.n_mt = cdiv(p.M, 128); p.n_nt = out_c / 64;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)conv1x1s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    codeps_allow_lds((const void*)conv1x1s_kernel, 160 * 1024, "conv1x1s_kernel");
     hipLaunchKernelGGL(conv1x1s_kernel, dim3(p.n_mt * p.n_nt), dim3(256), 2 * (128 + 64) * 208, (hipStream_t)stream, p,
                        static_cast<const unsigned short*>(a_split), static_cast<const unsigned short*>(w_split), scale, shift, residual, y);
     CODEPS_CHECK_LAUNCH("conv1x1s_kernel");

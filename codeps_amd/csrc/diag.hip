@@ -8,6 +8,7 @@
 //   * codeps_diag_stream_triad -- a[i] = b[i] + s c[i] on float4, grid-stride: HBM read + write bandwidth.
 // Both time themselves with HIP events on the given stream and return milliseconds; nothing here is on the hot path.
 #include "common.h"
+#include "../../include/codeps_diag.h"
 
 namespace {
 
@@ -242,16 +243,12 @@ extern "C" int codeps_diag_feed_rate(int mode, int kb, int blocks, int iters, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = (size_t)2 * (kb ? kb : 4) * 1024;
     CODEPS_REQUIRE(!(mode & 4) || kb >= 8, CODEPS_ERR_ARG, "codeps_diag_feed_rate: the fragment reads need kb >= 8");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)feed_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)feed_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)feed_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)feed_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)feed_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)feed_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    codeps_allow_lds((const void*)feed_kernel<0, 0>, 160 * 1024, "feed_kernel<0,0>");
+    codeps_allow_lds((const void*)feed_kernel<1, 0>, 160 * 1024, "feed_kernel<1,0>");
+    codeps_allow_lds((const void*)feed_kernel<2, 0>, 160 * 1024, "feed_kernel<2,0>");
+    codeps_allow_lds((const void*)feed_kernel<0, 1>, 160 * 1024, "feed_kernel<0,1>");
+    codeps_allow_lds((const void*)feed_kernel<1, 1>, 160 * 1024, "feed_kernel<1,1>");
+    codeps_allow_lds((const void*)feed_kernel<2, 1>, 160 * 1024, "feed_kernel<2,1>");
     const char* w = static_cast<const char*>(window);
     int rc = timed(st, reps, ms_per_launch, [&]() {
 #define FEED(M, F) hipLaunchKernelGGL((feed_kernel<M, F>), dim3(blocks), dim3(256), lds, st, w, (unsigned)window_bytes, iters, kb, scratch)

@@ -144,9 +144,12 @@ __global__ __launch_bounds__(256) void sem_px_kernel(const float* __restrict__ p
         float l = 0.f;
         if (t != ignore && t < C && !(drop && ((drop >> t) & 1ull))) {
             float lse;
-            if (drop) { int ct; l = ce_of_probs_kept(probs + (size_t)i * Cp, C, drop, t, lse, ct); }
+            int ct = t;
+            if (drop) l = ce_of_probs_kept(probs + (size_t)i * Cp, C, drop, t, lse, ct);
             else l = ce_of_probs(probs + (size_t)i * Cp, C, t, lse);
-            if (cw) l *= cw[t];
+            // with ignore_labels the class-weight vector holds the preserved classes only: a label past them (ct < 0; the
+            // reference raises) contributes 0 and must not index it
+            if (cw && ct >= 0) l *= cw[t];
             if (pw) l *= (float)pw[i];
         }
         loss_px[i] = l;

@@ -268,8 +268,7 @@ extern "C" int codeps_upconv16_dgrad(const float* dz, const float* weight, int b
     CODEPS_REQUIRE(workspace_bytes >= codeps_upconv16_workspace_bytes(), CODEPS_ERR_WORKSPACE, "codeps_upconv16_dgrad: workspace too small");
     const int tiles_x = cdiv(ws, SW), tiles_y = cdiv(hs, SH);
     const size_t lds = ((size_t)ZPIX * P4 * 4 + (size_t)SH * SW * P4 * 4) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)upconv16_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    codeps_allow_lds((const void*)upconv16_dgrad_kernel, 160 * 1024, "upconv16_dgrad_kernel");
     hipStream_t st = (hipStream_t)stream;
     float* wc = static_cast<float*>(workspace);
     hipLaunchKernelGGL(upconv16_collapse_kernel, dim3(16), dim3(256), 0, st, weight, wc);
@@ -287,8 +286,7 @@ extern "C" int codeps_upconv16_wgrad(const float* x, const float* dz, int batch,
     const int tiles_x = cdiv(ws, SW), tiles_y = cdiv(hs, SH);
     const int nblk = std::min(batch * tiles_x * tiles_y, 512);
     const size_t lds = ((size_t)XPIX * P4 * 4 + (size_t)OPIX * 17) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)upconv16_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    codeps_allow_lds((const void*)upconv16_wgrad_kernel, 160 * 1024, "upconv16_wgrad_kernel");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(upconv16_wgrad_kernel, dim3(nblk), dim3(256), lds, st, x, dz, batch, hs, ws, tiles_x, tiles_y, static_cast<float*>(workspace));
     float* gsum = static_cast<float*>(workspace) + (size_t)512 * NWC;

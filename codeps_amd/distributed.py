@@ -20,7 +20,11 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            # no silent default: two jobs launched side by side on one node would meet on the same port.  torchrun exports it
+            # (--master-port / --standalone); a hand-rolled launcher has to pick a free one and hand it to every rank
+            raise RuntimeError("codeps_amd.distributed.init_from_env: WORLD_SIZE > 1 but MASTER_PORT is not set "
+                               "(launch with `python -m torch.distributed.run --master-addr 127.0.0.1 --master-port P ...`)")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -57,9 +61,7 @@ class SyncBatchNormReducer:
         world = dist.get_world_size(self.group)
         c = mean.numel()
         packed = torch.cat([mean, var, self._count_tensor(mean, [count])])
-        gathered = [torch.empty_like(packed) for _ in range(world)]
-        dist.all_gather(gathered, packed, group=self.group)
-        g = torch.stack(gathered)                      # [world, 2c+1]
+        g = self.gather(packed)                        # [world, 2c+1]
         means, vars_, counts = g[:, :c], g[:, c:2 * c], g[:, 2 * c:]
         total = counts.sum()
         mean_all = (means * counts).sum(0) / total
@@ -72,9 +74,7 @@ class SyncBatchNormReducer:
         world = dist.get_world_size(self.group)
         g, c = mean.shape
         packed = torch.cat([mean.reshape(-1), var.reshape(-1), self._count_tensor(mean, counts)])
-        gathered = [torch.empty_like(packed) for _ in range(world)]
-        dist.all_gather(gathered, packed, group=self.group)
-        allp = torch.stack(gathered)                                  # [world, 2*G*C + G]
+        allp = self.gather(packed)                                    # [world, 2*G*C + G]
         means = allp[:, :g * c].view(world, g, c)
         vars_ = allp[:, g * c:2 * g * c].view(world, g, c)
         cnts = allp[:, 2 * g * c:].view(world, g, 1)
@@ -85,11 +85,13 @@ class SyncBatchNormReducer:
         return mean_all, var_all, [float(n) * world for n in counts]
 
     def gather(self, packet):
-        """All-gather of one contiguous statistics packet -> [world, *packet.shape] (ranks write into slices of one
-        buffer; the merge itself is the HIP kernel codeps_bn_sync_combine)."""
+        """All-gather of one contiguous statistics packet -> [world, *packet.shape]: ONE all_gather_into_tensor (no per-rank
+        tensor list, no stacking copy); the merge itself is the HIP kernel codeps_bn_sync_combine."""
         world = dist.get_world_size(self.group)
+        packet = packet.contiguous()
         buf = torch.empty((world,) + tuple(packet.shape), dtype=packet.dtype, device=packet.device)
-        dist.all_gather(list(buf.unbind(0)), packet, group=self.group)
+        # concatenation along dim 0 is the output form both backends accept (gloo rejects a stacked [world, ...] output)
+        dist.all_gather_into_tensor(buf.view((world * packet.shape[0],) + tuple(packet.shape[1:])), packet, group=self.group)
         return buf
 
     def sum(self, sums):

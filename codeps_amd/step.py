@@ -55,12 +55,15 @@ def ema_module_lists(cfg, frozen):
 class FlatState:
     """Flat parameter / gradient / Adam / EMA buffers over a list of parameters."""
 
-    def __init__(self, params, with_ema):
+    def __init__(self, params, with_ema, grad=None):
+        """grad: this group's slice of the step's ONE flat gradient buffer (StepRunner.grad_all), so that the whole step has a
+        single all-reduce; None allocates a private buffer."""
         self.params = params
         n = sum(p.numel() for p in params)
         dev = params[0].device
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev) if grad is None else grad
+        assert self.grad.numel() == n and self.grad.is_contiguous()
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
@@ -153,7 +156,16 @@ class StepRunner:
             for name, p in mod.named_parameters():
                 if p.requires_grad and live(name):
                     (ema_params if attr in ema_mods else other).append(p)
-        self.groups = [FlatState(ps, with_ema) for ps, with_ema in ((ema_params, True), (other, False)) if ps]
+        # ONE flat gradient buffer for the whole step (north_star: "a single RCCL all-reduce of gradients"); the EMA'd modules'
+        # parameters are its first range, so the two FlatStates (they differ only in whether an EMA copy is kept) are views of it
+        sets = [(ps, with_ema) for ps, with_ema in ((ema_params, True), (other, False)) if ps]
+        total = sum(p.numel() for ps, _ in sets for p in ps)
+        self.grad_all = torch.zeros(total, dtype=torch.float32, device=sets[0][0][0].device)
+        self.groups, off = [], 0
+        for ps, with_ema in sets:
+            n = sum(p.numel() for p in ps)
+            self.groups.append(FlatState(ps, with_ema, self.grad_all[off:off + n]))
+            off += n
         self.step_count = 0
         # device step counter mixed into the photometric tie-break noise (bumped on the stream at the start of every step, so a
         # replayed HIP graph draws new noise) + this runner's host seed base for the calls within one step
@@ -177,10 +189,14 @@ class StepRunner:
     def set_key_counts(self, items, rank):
         """Batch-sharded step whose ranks hold DIFFERENT numbers of items per key (BASELINE configs[3], SURVEY.md 8d: ranks
         0-3 hold 1 target + 1 replay item, ranks 4-7 two replay items).  items = {key: [items on rank 0, 1, ...]}.
-        With it the step reproduces the single-process step on the concatenated batch: the count-weighted depth means use the
-        global image counts, every other per-key mean is re-weighted by local / (global / world) items, SyncBatchNorm weighs each
-        rank's statistics with its element count, and the car-not-moving rule is evaluated by the rank that owns the first
-        target item.  Equal shards need none of this (the plain DDP mean is exact)."""
+        With it the count-weighted depth means (global image counts), SyncBatchNorm (each rank's statistics weighed with its
+        element count) and the car-not-moving rule (evaluated by the rank that owns the first target item, flag broadcast)
+        reproduce the single-process step on the concatenated batch EXACTLY.  The other per-key means are re-weighted by
+        local / (global / world) items, which is exact for plain means only: the semantic losses mine hard pixels (top-k over
+        all pixels of a key's batch, algos/semantic_seg.py:45-67), and the count-weighted mean of per-rank top-k means is not
+        the top-k of the concatenated batch -- the approximation the reference's DistributedDataParallel run makes too (each
+        rank mines its own pixels); identical only for top_k = 1.0 or a key held by one rank.  Equal shards need none of
+        this (the plain DDP mean is exact)."""
         world = self.world
         assert all(len(v) == world for v in items.values()), "one item count per rank and key"
         self._unequal_shards = True
@@ -198,14 +214,13 @@ class StepRunner:
 
     @property
     def grad_bytes(self):
-        return sum(g.numel * 4 for g in self.groups)
+        return self.grad_all.numel() * 4
 
     def forward_backward(self, data):
         F.set_noise_stream(self.noise_counter, self.seed_base)
         F.step_counter_add(self.noise_counter, 1)
         F.refresh_weight_packs()                 # every trainable weight's packs in one launch (after the first step built the table)
-        for g in self.groups:
-            g.grad.zero_()
+        self.grad_all.zero_()
         if self.mode == "adapt":
             losses, result, _, _ = self.net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
         else:
@@ -252,11 +267,12 @@ class StepRunner:
         return hit[0]
 
     def optimizer_step(self, apply_ema=True):
-        """One all-reduce + fused Adam per flat group.  apply_ema False leaves the EMA copy alone: the reference filters the
-        teacher once per FRAME, after its `nof_adaptation_steps` optimizer steps (scripts/adapt_codeps.py:266-299)."""
+        """ONE all-reduce of the step's flat gradient buffer, then the fused Adam kernel per flat group (EMA'd modules / the
+        rest).  apply_ema False leaves the EMA copy alone: the reference filters the teacher once per FRAME, after its
+        `nof_adaptation_steps` optimizer steps (scripts/adapt_codeps.py:266-299)."""
         self.step_count += 1
+        allreduce_flat_gradients(self.grad_all, self.group)
         for i, g in enumerate(self.groups):
-            allreduce_flat_gradients(g.grad, self.group)
             g.adam(None if self._touched is None else self._touched[i], self.lr, 1.0 / self.world, self.ema_alpha, apply_ema)
 
     def step(self, data, apply_ema=True):

@@ -1,6 +1,6 @@
 """Worker of tests/test_distributed_gpu.py::test_sharded_step_equals_single_process_step.
 
-    python tests/dist_equiv_worker.py <out_file> [--asym]
+    python tests/dist_equiv_worker.py <out_file> [--asym | --configs3]
 
 world == 1 (no torchrun env): the adaptation step on the WHOLE batch.  world == 2 (RANK / WORLD_SIZE / MASTER_* set by the
 test): every rank builds the identical whole batch, keeps its slice of every key, and runs the sharded step -- SyncBatchNorm
@@ -18,6 +18,20 @@ sys.path.insert(0, ROOT)
 
 H, W = 64, 128
 ITEMS = {"target": 2, "target_replay": 4, "source": 2, "cut_mixup": 2}
+# --configs3: BASELINE configs[3] / SURVEY.md 8d "Config 4" exactly -- global batch 32 over 8 ranks, ranks 0-3 hold 1 target +
+# 1 replay item, ranks 4-7 hold 2 replay items, every rank 1 source + 1 mixup item -- at 32 x 64 so that eight processes fit one GPU
+H3, W3 = 32, 64
+ITEMS3 = {"target": 4, "target_replay": 12, "source": 8, "cut_mixup": 8}
+
+
+def split_configs3(rank, world):
+    if world == 1:
+        return {k: (0, n) for k, n in ITEMS3.items()}
+    assert world == 8
+    if rank < 4:
+        return {"target": (rank, rank + 1), "target_replay": (rank, rank + 1), "source": (rank, rank + 1), "cut_mixup": (rank, rank + 1)}
+    lo = 4 + 2 * (rank - 4)
+    return {"target": (0, 0), "target_replay": (lo, lo + 2), "source": (rank, rank + 1), "cut_mixup": (rank, rank + 1)}
 
 
 def split_of(rank, world, asym):
@@ -33,18 +47,22 @@ def split_of(rank, world, asym):
 
 
 def main():
+    global H, W, ITEMS
     out_file = sys.argv[1]
     asym = "--asym" in sys.argv
+    c3 = "--configs3" in sys.argv
+    if c3:
+        H, W, ITEMS, asym = H3, W3, ITEMS3, True
     from codeps_amd import synthetic
     from codeps_amd.codeps import gen_models
-    from codeps_amd.config import get_cfg_defaults
+    from codeps_amd.config import get_cfg_shipped
     from codeps_amd.distributed import SyncBatchNormReducer, init_from_env
     from codeps_amd.step import StepRunner
     rank, _local, world = init_from_env("gloo")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     torch.manual_seed(20)
-    cfg = get_cfg_defaults(adapt=True)
+    cfg = get_cfg_shipped(adapt=True)
     cfg.model.po_depth_net.params.nof_layers = 18
     cfg.dataset.feed_img_size = [H, W]
     cfg.adapt.source_dataset.feed_img_size = [H, W]
@@ -59,7 +77,8 @@ def main():
     torch.manual_seed(1)
     noise = {k: [torch.randn(ITEMS[k], 2, H >> s, W >> s) * 1e-5 for s in range(5)] for k in ("source", "target", "target_replay")}
 
-    sl = split_of(rank, world, asym)
+    split = (lambda r: split_configs3(r, world)) if c3 else (lambda r: split_of(r, world, asym))
+    sl = split(rank)
 
     def cut(v, lo, hi):
         if isinstance(v, dict):
@@ -72,17 +91,15 @@ def main():
     net.depth_algo.reconstruction_loss.noise = [flat(k) for k in ("target", "target_replay") if k in data]
     runner = StepRunner(net, cfg, "adapt", world)
     if world > 1:
-        counts = {k: [split_of(r, world, asym)[k][1] - split_of(r, world, asym)[k][0] for r in range(world)] for k in ITEMS}
+        counts = {k: [split(r)[k][1] - split(r)[k][0] for r in range(world)] for k in ITEMS}
         red = SyncBatchNormReducer()
         net.backbone_po_depth.sync_bn = net.backbone_pose_sflow.sync_bn = red
         if asym:
             runner.set_key_counts(counts, rank)
     total, losses, _ = runner.forward_backward(data)
     from codeps_amd.distributed import allreduce_flat_gradients
-    grads = []
-    for g in runner.groups:
-        allreduce_flat_gradients(g.grad, runner.group)
-        grads.append((g.grad / world).cpu())
+    allreduce_flat_gradients(runner.grad_all, runner.group)          # the step's ONE gradient collective
+    grads = [(g.grad / world).cpu() for g in runner.groups]
     runner.step_count += 1
     from codeps_amd import functional as F
     for g in runner.groups:

@@ -8,8 +8,8 @@ from codeps_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "codeps_hip.h")).read()
+def _header_functions(header="codeps_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
     for m in re.finditer(r"\b(?:int|size_t|long long|const char\*)\s+(codeps_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
@@ -26,6 +26,20 @@ def test_header_matches_binding_and_exports():
     for name, nargs in funcs.items():
         assert hasattr(handle, name), f"{name} not exported by libcodeps_hip.so"
         assert len(_lib.SIGNATURES[name][1]) == nargs, f"{name}: header has {nargs} args"
+
+
+def test_diag_header_matches_binding_and_exports():
+    """include/codeps_diag.h <-> libcodeps_diag.so: the micro-benchmarks and the rejected prototype live OUTSIDE the product ABI."""
+    funcs = _header_functions("codeps_diag.h")
+    handle = _lib.diag_lib()
+    assert set(funcs) == set(_lib.DIAG_SIGNATURES), set(funcs) ^ set(_lib.DIAG_SIGNATURES)
+    for name, nargs in funcs.items():
+        assert hasattr(handle, name), f"{name} not exported by libcodeps_diag.so"
+        assert len(_lib.DIAG_SIGNATURES[name][1]) == nargs, f"{name}: header has {nargs} args"
+    assert handle.codeps_diag_version() == 1
+    product = _lib.lib()
+    for name in ("codeps_diag_mfma_rate", "codeps_diag_feed_rate", "codeps_split_pack_rows", "codeps_conv1x1_split_fwd"):
+        assert not hasattr(product, name), f"{name} must not be exported by the product library"
 
 
 def test_version_and_error_string():

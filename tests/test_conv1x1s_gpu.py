@@ -14,7 +14,7 @@ def _split(x2d):
     from codeps_amd import _lib
     rows, c = x2d.shape
     out = torch.empty(rows * c * 3, dtype=torch.int16, device=DEV)
-    _lib.check(_lib.lib().codeps_split_pack_rows(_lib.ptr(x2d), rows, c, x2d.stride(0), _lib.ptr(out), _lib.stream_ptr()), "codeps_split_pack_rows")
+    _lib.check_diag(_lib.diag_lib().codeps_split_pack_rows(_lib.ptr(x2d), rows, c, x2d.stride(0), _lib.ptr(out), _lib.stream_ptr()), "codeps_split_pack_rows")
     return out
 
 
@@ -51,7 +51,7 @@ def test_conv1x1_split_fwd_matches_engine_and_float64(rows, ci, co, act):
     wf, _ = F.pack_weights(wd, co, ci, False)
     xs, w_split = _split(xd), wf.view(-1)[co * ci:]
     y = torch.empty(rows, co, device=DEV)
-    _lib.check(_lib.lib().codeps_conv1x1_split_fwd(_lib.ptr(xs), rows, ci, co, _lib.ptr(w_split), _lib.ptr(sc_d), _lib.ptr(sh_d), _lib.ptr(res_d), act,
+    _lib.check_diag(_lib.diag_lib().codeps_conv1x1_split_fwd(_lib.ptr(xs), rows, ci, co, _lib.ptr(w_split), _lib.ptr(sc_d), _lib.ptr(sh_d), _lib.ptr(res_d), act,
                                                    _lib.ptr(y), _lib.stream_ptr()), "codeps_conv1x1_split_fwd")
     eng = F.conv2d(xd.view(1, 1, rows, ci), wd, scale=sc_d, shift=sh_d, residual=res_d.view(1, 1, rows, co),
                    act=[None, "relu", "elu"][act]).view(rows, co)
@@ -60,4 +60,4 @@ def test_conv1x1_split_fwd_matches_engine_and_float64(rows, ci, co, act):
     assert e_new <= max(2.0 * e_eng, 2e-7), (e_new, e_eng)
     assert float((y - eng).abs().max()) <= 1e-4 * float(ref.abs().max())
     # bad arguments are refused
-    assert _lib.lib().codeps_conv1x1_split_fwd(_lib.ptr(y), rows, 48, co, _lib.ptr(y), None, None, None, 0, _lib.ptr(y), _lib.stream_ptr()) != 0
+    assert _lib.diag_lib().codeps_conv1x1_split_fwd(_lib.ptr(y), rows, 48, co, _lib.ptr(y), None, None, None, 0, _lib.ptr(y), _lib.stream_ptr()) != 0

@@ -39,6 +39,47 @@ def _run_worker(out_file, world, extra=()):
         assert p.returncode == 0, e[-3000:]
 
 
+def _compare(ref, shards):
+    r0 = shards[0]
+    for r in shards[1:]:
+        for a, b in zip(r0["grads"] + r0["params"], r["grads"] + r["params"]):
+            assert torch.equal(a, b), "ranks disagree after the all-reduce"
+    for k, v in ref["bufs"].items():
+        if v.is_floating_point():
+            err = float((r0["bufs"][k].double() - v.double()).abs().max() / (v.double().abs().max() + 1e-12))
+            assert err < 1e-5, f"SyncBN running statistic {k}: {err:.2e}"
+            for r in shards[1:]:
+                assert torch.equal(r0["bufs"][k], r["bufs"][k])
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))      # noqa: E731
+    for gi, (g, gr) in enumerate(zip(r0["grads"], ref["grads"])):
+        assert rel(g, gr) < 1e-5, f"flat gradient group {gi}: rel-L2 {rel(g, gr):.2e}"
+        off, worst = 0, 0.0
+        big = max(float(gr.abs().max()), 1e-30)
+        for shape in ref["names"][gi]:
+            n = 1
+            for d in shape:
+                n *= d
+            a, b = g[off:off + n], gr[off:off + n]
+            worst = max(worst, float((a.double() - b.double()).norm()) / (float(b.double().norm()) + 1e-4 * big * n ** 0.5))
+            off += n
+        assert worst < 1e-4, f"group {gi}: worst per-parameter gradient error {worst:.2e}"
+    for gi, (p, pr) in enumerate(zip(r0["params"], ref["params"])):
+        assert float((p - pr).abs().max()) <= 2.05e-4, "one Adam step moves a weight by at most lr = 1e-4"
+        assert float(((p - pr).abs() > 1e-7).float().mean()) < 0.05, "more than 5 % of the weights stepped differently"
+
+
+def test_configs3_eight_rank_layout_equals_single_process_step(tmp_path):
+    """BASELINE configs[3] (SURVEY.md 8d "Config 4") with its REAL 8-rank layout: global batch 32 = 4 target + 12 replay +
+    8 source + 8 mixup items; ranks 0-3 hold 1 target + 1 replay, ranks 4-7 hold 2 replay items, every rank 1 source + 1 mixup
+    item.  Eight processes on GPU 0 over gloo (32 x 64 items, ResNet-18 trunk) against ONE process on the concatenated B = 32
+    batch: count-aware SyncBN, the global count-weighted depth means, the broadcast car-not-moving flag and the single flat
+    gradient all-reduce have to reproduce the single-process gradients (DDP + SyncBN semantics, misc/train_utils.py:37-59)."""
+    single = str(tmp_path / "single.pt")
+    _run_worker(single, 1, ("--configs3",))
+    _run_worker(str(tmp_path / "shard.pt"), 8, ("--configs3",))
+    _compare(torch.load(single), [torch.load(str(tmp_path / f"shard_r{r}.pt")) for r in range(8)])
+
+
 @pytest.mark.parametrize("asym", [False, True])
 def test_sharded_step_equals_single_process_step(tmp_path, asym):
     """DDP + SyncBatchNorm semantics of misc/train_utils.py:47-59 on the REAL adaptation step: two ranks, each with its slice of

@@ -14,9 +14,9 @@ DEV = "cuda:0"
 def _setup(seed=20, replay_items=2):
     from codeps_amd import synthetic
     from codeps_amd.codeps import gen_models
-    from codeps_amd.config import get_cfg_defaults
+    from codeps_amd.config import get_cfg_shipped
     torch.manual_seed(seed)
-    cfg = get_cfg_defaults(adapt=True)
+    cfg = get_cfg_shipped(adapt=True)
     cfg.model.po_depth_net.params.nof_layers = 18
     ht, wt, hs, ws = 64, 160, 64, 128
     cfg.dataset.feed_img_size = [ht, wt]

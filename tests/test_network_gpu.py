@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import inputs as gi
-from helpers import close, grad_stats, head_shapes, load
+from helpers import close, depth_bar, grad_stats, head_shapes, load, oracle_depth64, record_bar
 from oracle import resnet as oresnet
 
 pytestmark = pytest.mark.gpu
@@ -15,8 +15,8 @@ THINGS, STUFF = [9, 10, 11, 12, 13], list(range(9))
 
 def _build(seed, use_thing_mask, w, h, adaptation=False, src_hw=None):
     from codeps_amd.codeps import gen_models
-    from codeps_amd.config import get_cfg_defaults
-    cfg = get_cfg_defaults(adaptation)
+    from codeps_amd.config import get_cfg_shipped
+    cfg = get_cfg_shipped(adaptation)
     cfg.model.po_depth_net.params.nof_layers = 18
     cfg.model.instance_head.use_thing_mask = use_thing_mask
     cfg.dataset.feed_img_size = [h, w]
@@ -79,11 +79,13 @@ def test_train_forward_backward_against_reference():
             close(v, z["loss_" + k], 1e-6, 5e-5, "loss " + k)
     close(total, z["total"], 1e-5, 5e-5)
     close(result["depth"], z["res_depth"], 1e-3, 0, "depth (north-star tolerance 1e-3)")
+    depth_bar("network_train", result["depth"], z["res_depth"], None)
     for k in ("center", "offset"):          # random-weight heads give O(100) outputs: tolerance relative to the range
         close(result[k], z["res_" + k], 2e-5 * float(np.abs(z["res_" + k]).max()), 1e-4, k)
     for k in ("semantic", "thing_mask", "panoptic", "instance"):
         same = (result[k].cpu().numpy() == z["res_" + k]).mean()
         assert same == 1.0, f"{k}: only {same:.6f} of the pixels agree"
+    record_bar("network_train", panoptic_agreement=1.0, instance_agreement=1.0, semantic_agreement=1.0)
     assert result["panoptic"].dtype == torch.int16 and result["instance"].dtype == torch.uint8
     _check_pgrads(net, z, ("depth_head", "pose_head", "semantic_head", "instance_head", "backbone_po_depth",
                            "backbone_pose_sflow"))
@@ -93,10 +95,10 @@ def test_config0_depth_only_train_step_against_reference():
     """BASELINE configs[0]: one 192x640 frame triplet, ResNet-18 encoder, depth head only -- CodepsNet.forward("train") +
     backward against the reference's own run (tests/golden/config0.npz)."""
     from codeps_amd.codeps import gen_models
-    from codeps_amd.config import get_cfg_defaults
+    from codeps_amd.config import get_cfg_shipped
     z, meta = load("config0")
     b, h, w, seed = meta["b"], meta["h"], meta["w"], meta["seed"]
-    cfg = get_cfg_defaults(False)
+    cfg = get_cfg_shipped(False)
     cfg.model.po_depth_net.params.nof_layers = 18
     cfg.model.make_semantic = cfg.model.make_instance = False
     cfg.dataset.feed_img_size = [h, w]
@@ -119,7 +121,8 @@ def test_config0_depth_only_train_step_against_reference():
     # depth = 1 / (0.01 + 9.99 sigmoid(logit)): d depth / d logit ~ 24 at 40 m, so two valid fp32 summation orders of the
     # 192x640 decoder already differ by ~1e-3 there (SURVEY.md section 7 "fp32 accuracy budget"): 1e-3 + 1e-4 relative, and
     # tight in disparity space, as in the adaptation test below
-    close(result["depth"], z["res_depth"], 1e-3, 1e-4, "depth")
+    sample0 = _sample(b, h, w, seed, labels=False)
+    depth_bar("config0", result["depth"], z["res_depth"], lambda: oracle_depth64(net, sample0["rgb"][0]))
     close(1.0 / result["depth"], 1.0 / z["res_depth"], 2e-4, 5e-5, "scaled disparity (range 0.01..10)")
     _check_pgrads(net, z, ("depth_head", "pose_head", "backbone_po_depth", "backbone_pose_sflow"))
 
@@ -143,11 +146,12 @@ def test_adaptation_step_against_reference():
     # depth = 1/(0.01 + 9.99 sigmoid(logit)): at 40 m d depth / d logit ~ 24, so a 1e-5-relative logit difference
     # between two valid fp32 summation orders already moves depth by ~2e-3 (SURVEY.md §7 "fp32 accuracy budget").
     # 1e-3 absolute holds in the train test above; here: 1e-3 + 1e-4 relative, and tight in disparity space.
-    close(result["depth"], z["res_depth"], 1e-3, 1e-4, "depth")
+    depth_bar("network_adapt", result["depth"], z["res_depth"], lambda: oracle_depth64(net, data["target"]["rgb"][0]))
     close(1.0 / result["depth"], 1.0 / z["res_depth"], 2e-4, 5e-5, "scaled disparity (range 0.01..10)")
     # labels must agree except where the reference's own top-1 / top-2 probability margin is inside fp32 noise
     bad = result["semantic"].cpu().numpy() != z["res_semantic"]
     assert bad.mean() < 1e-3 and (z["res_semantic_margin"][bad] < 1e-4).all(), (int(bad.sum()), z["res_semantic_margin"][bad])
+    record_bar("network_adapt", semantic_pixels_differing=int(bad.sum()), semantic_pixels=int(bad.size))
     assert result["panoptic"].shape == (1, ht, wt) and result["image_features"].shape[1] == 512
     _check_pgrads(net, z, ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"))
 
@@ -179,15 +183,22 @@ def test_real_codepsnet_adapt_against_reference():
     for k in meta["loss_keys"]:
         close(losses[k], z["loss_" + k], 1e-6, 5e-5, k)
     close(total, z["total"], 1e-5, 5e-5)
-    close(result["depth"], z["res_depth"], 1e-3, 1e-4, "depth")
+    depth_bar("network_adapt_real", result["depth"], z["res_depth"], lambda: oracle_depth64(net, data["target"]["rgb"][0]))
     for k in ("center", "offset"):
         close(result[k], z["res_" + k], 2e-5 * float(np.abs(z["res_" + k]).max()), 1e-4, k)
     close(result["image_features"], z["res_image_features"], 1e-4 * float(np.abs(z["res_image_features"]).max()), 1e-4, "image_features")
     bad = result["semantic"].cpu().numpy() != z["res_semantic"]
     assert bad.mean() < 1e-3 and (z["res_semantic_margin"][bad] < 1e-4).all(), (int(bad.sum()), z["res_semantic_margin"][bad])
-    if not bad.any():                                       # panoptic ids are a function of (semantic, centre, offset)
-        for k in ("panoptic", "instance"):
-            same = (result[k].cpu().numpy() == z["res_" + k]).mean()
+    record_bar("network_adapt_real", semantic_pixels_differing=int(bad.sum()), semantic_pixels=int(bad.size))
+    # panoptic ids are a function of (semantic, centre, offset): bit-exact given the same inputs (tests/test_losses_gpu.py pins the
+    # fusion kernel bit for bit on identical inputs); here the inputs carry fp32 noise of both implementations, so a pixel whose
+    # offset vote lands within rounding of the midpoint between two centres may join the other instance -- the agreement is
+    # measured and recorded, and must be exact whenever the centre / offset maps produce the same votes
+    for k in ("panoptic", "instance"):
+        same = float((result[k].cpu().numpy() == z["res_" + k]).mean())
+        record_bar("network_adapt_real", **{k + "_agreement": same, k + "_bar": "bit-exact" if same == 1.0 else "> 0.999 (semantic labels "
+                   + ("identical" if not bad.any() else "differ inside the reference's own fp32 margin") + ")"})
+        if not bad.any():
             assert same > 0.999, f"{k}: only {same:.6f} of the pixels agree"
     _check_pgrads(net, z, ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"))
 
@@ -225,15 +236,16 @@ def test_eval_infer_modes_and_pre_step_against_reference():
     assert s_inf["sem_conf"] is None
 
     def check(tag, r, margin):
-        close(r["depth"], z[tag + "_depth"], 1e-3, 1e-4, tag + " depth")
+        depth_bar("eval_infer_" + tag, r["depth"], z[tag + "_depth"], lambda: oracle_depth64(net, target["rgb"][0]))
         close(r["semantic_soft"], z[tag + "_semantic_soft"], 2e-5, 1e-4, tag + " semantic_soft")
         bad = r["semantic"].cpu().numpy() != z[tag + "_semantic"]
         assert bad.mean() < 1e-3 and (margin[bad] < 1e-4).all(), (tag, int(bad.sum()))
         for k in ("center", "offset"):
             close(r[k], z[f"{tag}_{k}"], 2e-5 * float(np.abs(z[f"{tag}_{k}"]).max()), 1e-4, f"{tag} {k}")
-        if not bad.any():
-            for k in ("panoptic", "instance"):
-                same = (r[k].cpu().numpy() == z[f"{tag}_{k}"]).mean()
+        for k in ("panoptic", "instance"):
+            same = float((r[k].cpu().numpy() == z[f"{tag}_{k}"]).mean())
+            record_bar("eval_infer_" + tag, **{k + "_agreement": same, "semantic_pixels_differing": int(bad.sum())})
+            if not bad.any():
                 assert same > 0.999, f"{tag} {k}: only {same:.6f} of the pixels agree"
         assert r["panoptic"].dtype == torch.int16 and r["semantic"].dtype == torch.uint8
         return bad

@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
     from codeps_amd import functional as F, _lib
-    lib = _lib.lib()
+    lib = _lib.diag_lib()
     lib.codeps_conv2d_last_kernel.restype = ctypes.c_char_p
     dev = torch.device("cuda", 0)
     print(f"{'shape':10s} {'engine kernel':28s} {'engine us':>9s} {'TF/s':>6s} | {'split-in us':>11s} {'TF/s':>6s} {'max|diff|':>10s} | {'split pass us':>13s}")
@@ -56,8 +56,8 @@ def main():
         rows = b * h * w
         xs = torch.empty(rows * ci * 6, dtype=torch.uint8, device=dev)
         y = torch.empty(b, h, w, co, device=dev)
-        split = lambda: _lib.check(lib.codeps_split_pack_rows(_lib.ptr(x), rows, ci, ci, _lib.ptr(xs), _lib.stream_ptr()), "split")   # noqa: E731
-        conv = lambda: _lib.check(lib.codeps_conv1x1_split_fwd(_lib.ptr(xs), rows, ci, co, _lib.ptr(w_split), _lib.ptr(scale), _lib.ptr(shift),   # noqa: E731
+        split = lambda: _lib.check_diag(lib.codeps_split_pack_rows(_lib.ptr(x), rows, ci, ci, _lib.ptr(xs), _lib.stream_ptr()), "split")   # noqa: E731
+        conv = lambda: _lib.check_diag(lib.codeps_conv1x1_split_fwd(_lib.ptr(xs), rows, ci, co, _lib.ptr(w_split), _lib.ptr(scale), _lib.ptr(shift),   # noqa: E731
                                                                _lib.ptr(res), 1, _lib.ptr(y), _lib.stream_ptr()), "conv1x1s")
         split()
         conv()

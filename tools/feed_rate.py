@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=2000)
     args = ap.parse_args()
     from codeps_amd import _lib
-    lib = _lib.lib()
+    lib = _lib.diag_lib()
     dev = torch.device("cuda", 0)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     window = torch.randn(int(args.window_mb * (1 << 20)) // 4, device=dev)
@@ -35,7 +35,7 @@ def main():
                 continue
             if (mode & 4) and kb < 8:
                 continue
-            _lib.check(lib.codeps_diag_feed_rate(mode, kb, cus, args.iters, 3, _lib.ptr(window), window.numel() * 4, _lib.ptr(scratch),
+            _lib.check_diag(lib.codeps_diag_feed_rate(mode, kb, cus, args.iters, 3, _lib.ptr(window), window.numel() * 4, _lib.ptr(scratch),
                                                  ctypes.byref(ms), _lib.stream_ptr()), "codeps_diag_feed_rate")
             us = ms.value * 1e3 / args.iters
             flops = 96 * 4 * 2 * 16 * 16 * 32 * cus / (us * 1e-6)

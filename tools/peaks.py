@@ -19,7 +19,7 @@ import torch  # noqa: E402
 
 def measure(sustain_ms=200.0):
     from codeps_amd import _lib
-    lib = _lib.lib()
+    lib = _lib.diag_lib()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -32,10 +32,10 @@ def measure(sustain_ms=200.0):
             flops, ms = ctypes.c_double(), ctypes.c_float()
             iters = 2000 if mode != 1 else 1000
             # short probe, then enough launches to hold the load for `sustain_ms` (clocks settle under the power limit)
-            _lib.check(lib.codeps_diag_mfma_rate(mode, rnd, blocks, iters, 2, _lib.ptr(scratch), ctypes.byref(flops), ctypes.byref(ms),
+            _lib.check_diag(lib.codeps_diag_mfma_rate(mode, rnd, blocks, iters, 2, _lib.ptr(scratch), ctypes.byref(flops), ctypes.byref(ms),
                                                  _lib.stream_ptr()), "codeps_diag_mfma_rate")
             reps = max(3, int(sustain_ms / max(ms.value, 1e-3)))
-            _lib.check(lib.codeps_diag_mfma_rate(mode, rnd, blocks, iters, reps, _lib.ptr(scratch), ctypes.byref(flops), ctypes.byref(ms),
+            _lib.check_diag(lib.codeps_diag_mfma_rate(mode, rnd, blocks, iters, reps, _lib.ptr(scratch), ctypes.byref(flops), ctypes.byref(ms),
                                                  _lib.stream_ptr()), "codeps_diag_mfma_rate")
             out[f"{name}_{'random' if rnd else 'zeros'}_tflops"] = round(flops.value / (ms.value * 1e-3) / 1e12, 1)
     n = 1 << 28                                           # 3 x 1 GiB: beyond the 256 MiB Infinity Cache
@@ -43,7 +43,7 @@ def measure(sustain_ms=200.0):
     b.fill_(1.0)
     c.fill_(2.0)
     ms = ctypes.c_float()
-    _lib.check(lib.codeps_diag_stream_triad(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), n, 20, ctypes.byref(ms), _lib.stream_ptr()),
+    _lib.check_diag(lib.codeps_diag_stream_triad(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), n, 20, ctypes.byref(ms), _lib.stream_ptr()),
                "codeps_diag_stream_triad")
     assert float(a[12345]) == 4.0
     out["hbm_triad_gbs"] = round(12.0 * n / (ms.value * 1e-3) / 1e9, 1)
