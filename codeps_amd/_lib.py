@@ -73,7 +73,8 @@ SIGNATURES = {
     "codeps_conv2d_set_arith": (c_int, [I]),
     "codeps_conv2d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
-    "codeps_conv2d_dgrad": (c_int, [POINTER(ConvDesc), I, P, P, P, P]),
+    "codeps_conv2d_dgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc), I]),
+    "codeps_conv2d_dgrad": (c_int, [POINTER(ConvDesc), I, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, I, I, I, P, c_size_t, P]),
     "codeps_nchw_to_nhwc": (c_int, [P, I, I, I, I, P, I, I, I, P]),

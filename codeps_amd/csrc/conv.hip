@@ -884,7 +884,10 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     const int b = mt / (tiles_x * tiles_y), tr = mt % (tiles_x * tiles_y);
     const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
     const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
-    const int nchunks = Kc / BK;
+    // split-K (grids that cannot fill the chip: gridDim.y slices of p.ksteps channel chunks each; raw partial sums go to
+    // p.part[slice][M][N] and splitk_finish_kernel applies the epilogue): this block walks chunks [cbase, cbase + nchunks)
+    const int cbase = p.ksplit > 1 ? (int)blockIdx.y * p.ksteps : 0;
+    const int nchunks = p.ksplit > 1 ? min(p.ksteps, Kc / BK - cbase) : Kc / BK;
     const bool up = MODE == MODE_FWD && p.up0;
     const int H0 = up ? Hm / 2 : Hm, W0 = up ? Wm / 2 : Wm;
     const int cs0 = (MODE == MODE_FWD) ? p.C0 : p.Co;
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     }
     const unsigned bs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(Bs);
     auto dma_b = [&](int tap, int chunk, int slot) {
-        const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((tap * Kc + chunk * BK) * 6);
+        const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((tap * Kc + (cbase + chunk) * BK) * 6);
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(bs_lds + slot * BN * LDK * 4 + bins[i]);
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     const __amdgpu_buffer_rsrc_t rsA1 = make_rsrc(img1 ? img1 : img0, img1 ? (size_t)Hm * Wm * p.C1 * 4 : 0);
     f32x4 areg[NALOAD];
     auto load_a = [&](int chunk) {
-        const int cstep = chunk * BK;
+        const int cstep = (cbase + chunk) * BK;
         const bool s1 = MODE == MODE_FWD && cstep >= p.C0;
         const int cs = s1 ? p.C1 : cs0, ws = s1 ? Wm : W0, sh = (!s1 && up) ? 1 : 0;
         const unsigned cbyte = (unsigned)((s1 ? cstep - p.C0 : cstep) + achunk * 8) * 4u;
@@ -1084,6 +1087,10 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
                 const int pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
                 const size_t m = ((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
+                if (p.ksplit > 1) {                           // raw partial sum of this K slice; splitk_finish_kernel does the rest
+                    *reinterpret_cast<f32x4*>(p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
+                    continue;
+                }
                 if (MODE == MODE_FWD) {
                     v = v * sc + sh;
                     if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
@@ -2432,6 +2439,26 @@ static int splitk_slices(const ConvP& p, int blocks, int nsteps) {
     return std::max(ks, 1);
 }
 
+// K slices (over 32-channel chunks) of the halo-tile ring kernel for grids of fewer than 256 blocks (it runs one block per CU).
+// Model in units of one chunk (nine taps, ~11.5 us): rounds x (chunks per slice + 1.5 for fill / epilogue) + the finish pass
+// (a launch + (slices + 1) x M x N floats of traffic).  0 = leave the layer to the gather kernels (too few blocks and nothing
+// to cut), 1 = the ring kernel without split, >= 2 = that many slices.
+static int halo_splitk_slices(const ConvP& p, int blocks, int nchunks) {
+    static const int on = getenv("CODEPS_HALO_SPLITK") ? atoi(getenv("CODEPS_HALO_SPLITK")) : 1;             // tuning experiments only
+    if (!on || blocks >= 256) return 0;
+    int best = blocks >= 128 ? 1 : 0;
+    double best_t = blocks >= 128 ? nchunks + 1.5 : 1e300;
+    if (p.part && nchunks >= 8)
+        for (int ks = 2; ks <= 8 && nchunks / ks >= 4; ++ks) {
+            if ((size_t)ks * p.M * p.N * sizeof(float) > p.part_bytes) break;
+            const int per = cdiv(nchunks, ks), slices = cdiv(nchunks, per);
+            const double finish = 0.35 + (double)p.M * p.N * 4.0 * (slices + 1) / 5e12 / 11.5e-6;
+            const double t = (double)cdiv(blocks * slices, 256) * (per + 1.5) + finish;
+            if (t < best_t - 1e-9) { best_t = t; best = slices; }
+        }
+    return best;
+}
+
 // split-K finish: out = act((sum_z part[z]) * scale + shift + residual), fixed summation order
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, long long MN, int N,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
@@ -2449,6 +2476,18 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     }
 }
 
+// 3x3 / stride 1 / zero padding layers the halo-tile kernels take (forward: also the decoder's concat + fused nearest-x2 input)
+template <int MODE>
+static bool halo3_shape_ok(const ConvP& p) {
+    static const int halo3_up = getenv("CODEPS_HALO3_UP") ? atoi(getenv("CODEPS_HALO3_UP")) : 1;
+    const int Hm_ = (MODE == MODE_FWD) ? p.Ho : p.H, Wm_ = (MODE == MODE_FWD) ? p.Wo : p.W;
+    const bool plain = !p.up0 && p.C1 == 0;
+    return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.stride_w == 1 && p.pad == 1 && p.pad_w == 1 && p.pad_mode == 0 &&
+           !p.par && p.Ho == p.H && p.Wo == p.W && Wm_ % 32 == 0 && Hm_ % 4 == 0 &&
+           (MODE == MODE_FWD ? (plain || (halo3_up && p.C0 % 32 == 0 && p.C1 % 32 == 0 && (!p.up0 || (p.H % 2 == 0 && p.W % 2 == 0))))
+                             : (plain && p.src == 0 && p.Cs == p.C0));
+}
+
 template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF = 2, int NP = 0>
 static void launch_igemm(ConvP p, const float* a0, const float* a1, const float* wq, const float* scale, const float* shift,
                          const float* residual, float* out, hipStream_t st) {
@@ -2463,24 +2502,29 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     if constexpr (NP == 3 && WM == 2 && WN == 2 && TM == 2 && BK == 32) {
         // 3x3 / stride 1 / zero padding, one source at full resolution: halo-tile kernel (activations staged once per channel chunk)
         static const int halo3 = getenv("CODEPS_HALO3") ? atoi(getenv("CODEPS_HALO3")) : 2;          // x 128 blocks: smaller grids keep split-K / the 256-thread kernel
-        const int Hm_ = (MODE == MODE_FWD) ? p.Ho : p.H, Wm_ = (MODE == MODE_FWD) ? p.Wo : p.W;
-        static const int halo3_up = getenv("CODEPS_HALO3_UP") ? atoi(getenv("CODEPS_HALO3_UP")) : 1;
-        const bool plain = !p.up0 && p.C1 == 0;
-        if (halo3 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.stride_w == 1 && p.pad == 1 && p.pad_w == 1 && p.pad_mode == 0 &&
-            !p.par && p.Ho == p.H && p.Wo == p.W && Wm_ % 32 == 0 && Hm_ % 4 == 0 &&
-            (MODE == MODE_FWD ? (plain || (halo3_up && p.C0 % 32 == 0 && p.C1 % 32 == 0 && (!p.up0 || (p.H % 2 == 0 && p.W % 2 == 0))))
-                              : (plain && p.src == 0 && p.Cs == p.C0)) &&
-            (long long)p.n_mt * p.n_nt >= halo3 * 128) {
+        if (halo3 && halo3_shape_ok<MODE>(p) &&
+            ((long long)p.n_mt * p.n_nt >= halo3 * 128 || (TN == 2 && halo_splitk_slices(p, p.n_mt * p.n_nt, ((MODE == MODE_FWD) ? p.Ct : p.Co) / BK) >= 1))) {
             constexpr size_t lds_h = std::max((size_t)(204 + 2 * BN) * LDKf * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
             static const int halo_ring = getenv("CODEPS_HALO_RING") ? atoi(getenv("CODEPS_HALO_RING")) : 1;
             if constexpr (TN == 2) {
-                if (halo_ring) {
+                const int nchunks_ = ((MODE == MODE_FWD) ? p.Ct : p.Co) / BK;
+                const int hks = halo_splitk_slices(p, p.n_mt * p.n_nt, nchunks_);
+                if (halo_ring || hks >= 2) {
                     constexpr size_t lds_r = (size_t)(205 + 4 * BN) * LDKf * sizeof(float);
                     auto kr = conv_halo3r_kernel<MODE, TN>;
-                    codeps_allow_lds((const void*)kr, 160 * 1024, "kr");
-                    p.ksplit = 1;
-                    g_last_kernel = "conv_halo3r_kernel";
-                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt), dim3(256), lds_r, st, p, a0, a1, scale, shift, residual, out);
+                    codeps_allow_lds((const void*)kr, 160 * 1024, "conv_halo3r_kernel");
+                    p.ksplit = 1; p.ksteps = nchunks_;
+                    // grids below one block per CU (the 1/16- and 1/32-resolution layers of the pose encoder and the decoders): cut the
+                    // channel chunks into K slices so that the ring kernel (one block per CU) runs whole rounds of 256 blocks
+                    if (hks >= 2) { p.ksteps = cdiv(nchunks_, hks); p.ksplit = cdiv(nchunks_, p.ksteps); }
+                    g_last_kernel = p.ksplit > 1 ? "conv_halo3r_kernel<splitk>" : "conv_halo3r_kernel";
+                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(256), lds_r, st, p, a0, a1, scale, shift, residual, out);
+                    if (p.ksplit > 1) {
+                        const long long MN = (long long)p.M * p.N;
+                        hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
+                                           p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, MODE == MODE_FWD ? residual : nullptr,
+                                           MODE == MODE_FWD ? p.act : 0, out);
+                    }
                     return;
                 }
             }
@@ -2606,7 +2650,11 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         static const float pens = getenv("CODEPS_PENS") ? atof(getenv("CODEPS_PENS")) : 0.5f;
         static const int shortk = getenv("CODEPS_SHORTK") ? atoi(getenv("CODEPS_SHORTK")) : 31;       // 32-step 1x1 layers (K = 1024, N = 256): one round of 128x128 blocks on the wave-specialised kernel, 57 vs 62 us
         const TileOpt o[3] = {{128, 128, 1.0f}, {128, 64, nsteps32 <= shortk ? pens : pen1}, {64, 64, pen2}};
-        switch (pick_tile(p, o, 3, nsteps32)) {
+        // 3x3 layers whose 128 x 128 grid is below one block per CU: the halo ring kernel (215 TFLOP/s class) on >= 128 CUs, or
+        // with its channel chunks cut into K slices that make whole rounds of 256 blocks, instead of the gather kernels (140-160)
+        const bool halo_sk = bk32 && split_np == 3 && p.N % 128 == 0 && halo3_shape_ok<MODE>(p) &&
+                             halo_splitk_slices(p, cdiv(p.M, 128) * cdiv(p.N, 128), ((MODE == MODE_FWD) ? p.Ct : p.Co) / 32) >= 1;
+        switch (halo_sk ? 0 : pick_tile(p, o, 3, nsteps32)) {
             case 0: IG(2, 2, 2, 2); break;
             case 1: IG(2, 2, 2, 1); break;
             default: IG(2, 2, 1, 1); break;
@@ -2739,8 +2787,20 @@ extern "C" int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, con
     return CODEPS_OK;
 }
 
+// Split-K workspace of the data gradient (same rule as the forward's: small-M launches with a deep K); 0 = never splits.
+extern "C" size_t codeps_conv2d_dgrad_workspace_bytes(const codeps_conv_desc* d, int source) {
+    if (check_conv(d, "conv2d_dgrad_workspace_bytes") != CODEPS_OK) return 0;
+    const bool up = d->up0 && source == 0;
+    const long long M = (long long)d->batch * (up ? (d->in_h / 2) * (d->in_w / 2) : d->in_h * d->in_w);
+    const long long K = (long long)d->kh * d->kw * d->out_c;
+    const int n = source ? d->c1 : d->c0;
+    static const long long sk_m = getenv("CODEPS_SPLITK_M") ? atoll(getenv("CODEPS_SPLITK_M")) : 12288;
+    if (n <= 16 || M > sk_m || K < 512 || d->stride != 1) return 0;
+    return (size_t)16 * M * n * sizeof(float);
+}
+
 extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, float* dx,
-                                   codeps_stream_t stream) {
+                                   void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     int rc = check_conv(d, "conv2d_dgrad");
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(dz && w_dgrad && dx && (source == 0 || (source == 1 && d->c1 > 0)), CODEPS_ERR_ARG, "conv2d_dgrad: bad arguments");
@@ -2754,6 +2814,7 @@ extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const 
     const bool up = d->up0 && source == 0;
     p.M = d->batch * (up ? (d->in_h / 2) * (d->in_w / 2) : d->in_h * d->in_w);
     p.N = p.Cs;
+    if (workspace && codeps_conv2d_dgrad_workspace_bytes(d, source) > 0) { p.part = (float*)workspace; p.part_bytes = workspace_bytes; }
     // weights of this source: rows [c_off, c_off + Cs) of the [ci][tap][co] pack
     const float* wsrc = w_dgrad + (size_t)p.c_off * d->kh * d->kw * d->out_c;
     p.w3 = reinterpret_cast<const char*>(w_dgrad + (size_t)(d->c0 + d->c1) * d->kh * d->kw * d->out_c) + (size_t)p.c_off * d->kh * d->kw * d->out_c * 6;

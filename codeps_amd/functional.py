@@ -501,7 +501,7 @@ class _Conv2d(torch.autograd.Function):
             dpad = _lib.ConvDesc(desc.batch, desc.in_h + 2 * p_, desc.in_w + 2 * p_, desc.c0, 0, 0, desc.out_c, desc.out_h,
                                  desc.out_w, desc.kh, desc.kw, desc.stride, 0, 0, desc.act, desc.stride, 0)
             dxp = torch.empty(desc.batch, desc.in_h + 2 * p_, desc.in_w + 2 * p_, desc.c0, dtype=torch.float32, device=dy.device)
-            check(lib().codeps_conv2d_dgrad(ctypes.byref(dpad), 0, ptr(dz), ptr(wd), ptr(dxp), stream_ptr()),
+            check(lib().codeps_conv2d_dgrad(ctypes.byref(dpad), 0, ptr(dz), ptr(wd), ptr(dxp), None, 0, stream_ptr()),
                   "codeps_conv2d_dgrad")
             dx0 = torch.empty_like(x0)
             check(lib().codeps_reflect_pad_fold(ptr(dxp), desc.batch, desc.in_h, desc.in_w, desc.c0, p_, ptr(dx0), stream_ptr()),
@@ -527,14 +527,18 @@ class _Conv2d(torch.autograd.Function):
         elif ctx.needs_input_grad[0]:
             dx0 = torch.empty_like(x0)
             t0 = _prof_begin()
-            check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(dx0), stream_ptr()),
-                  "codeps_conv2d_dgrad")
+            wsb = lib().codeps_conv2d_dgrad_workspace_bytes(ctypes.byref(desc), 0)            # split-K scratch (small-M, deep-K shapes only)
+            ws2 = _workspace(wsb, dy.device, "splitk") if wsb else None
+            check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(dx0), ptr(ws2), ws2.numel() if ws2 is not None else 0,
+                                            stream_ptr()), "codeps_conv2d_dgrad")
             _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci), desc)
         if x1 is not None and ctx.needs_input_grad[1]:
             dx1 = torch.empty_like(x1)
             t0 = _prof_begin()
-            check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 1, ptr(dz), ptr(wd), ptr(dx1), stream_ptr()),
-                  "codeps_conv2d_dgrad")
+            wsb = lib().codeps_conv2d_dgrad_workspace_bytes(ctypes.byref(desc), 1)
+            ws2 = _workspace(wsb, dy.device, "splitk") if wsb else None
+            check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 1, ptr(dz), ptr(wd), ptr(dx1), ptr(ws2), ws2.numel() if ws2 is not None else 0,
+                                            stream_ptr()), "codeps_conv2d_dgrad")
             _prof_end(t0, "conv_dgrad", ctx.flops * (1 - ctx.c0_real / ctx.ci), desc, 1)
         if ctx.needs_input_grad[2]:
             sink = ctx.w_sink

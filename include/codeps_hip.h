@@ -126,8 +126,10 @@ int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, const float* x
                       void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 /* dz = gradient w.r.t. the pre-activation conv output [B,out_h,out_w,out_c]; dx = gradient of `source`
  * at ITS stored resolution (the x2-upsample transpose, a 2x2 sum, is fused for source 0 when up0). */
+/* workspace (optional, may be NULL): split-K scratch as in the forward; codeps_conv2d_dgrad_workspace_bytes(d, source) sizes it. */
+size_t codeps_conv2d_dgrad_workspace_bytes(const codeps_conv_desc* d, int source);
 int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad,
-                        float* dx, codeps_stream_t stream);
+                        float* dx, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d);
 /* dw_oihw [out_c_real][in_c_real][kh][kw] (= or += when accumulate); split-K slabs + fixed-order reduce. */
 int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float* x1, const float* dz,

@@ -125,48 +125,55 @@ def test_r50_four_heads_train_step_composition_against_oracle():
     total.backward()
     torch.cuda.synchronize()
 
-    # ---- oracle: same weights, train-mode BatchNorm everywhere the product trains it
-    leaves = {}
-    for n in names:
-        for k, v in sds[n].items():
-            if v.is_floating_point() and "running" not in k and ".fc." not in k and not k.startswith("fc."):
-                v.requires_grad_(True)
-                leaves[(n, k)] = v
+    # ---- oracle: same weights, train-mode BatchNorm everywhere the product trains it -- in fp32 (losses, label maps: what the
+    # reference computes) and in FLOAT64 (the yardstick for the gradients: batch statistics over 16 values per channel at 1/32
+    # resolution make the fp32 oracle itself differ from float64 by 3e-2 on the shared encoder's gradients)
     cpu = lambda d: {k: (cpu(v) if isinstance(v, dict) else v.cpu()) for k, v in d.items()}      # noqa: E731
-    ocfg = dict(nof_layers=50, train_encoder=True, use_thing_mask=True, train_instance_bn=True)
     ref_in = cpu(sample)
-    out, res = _oracle_train(network, sds, ocfg, ref_in, nz)
-    ototal = sum(float(weights[k]) * v for k, v in out.items() if v is not None and k in weights)
-    ototal.backward()
+
+    def oracle(dt):
+        osd = {n: {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sds[n].items()} for n in names}
+        leaves = {}
+        for n in names:
+            for k, v in osd[n].items():
+                if v.is_floating_point() and "running" not in k and ".fc." not in k and not k.startswith("fc."):
+                    v.requires_grad_(True)
+                    leaves[(n, k)] = v
+        cast = lambda d: {k: (cast(v) if isinstance(v, dict) else (v.to(dt) if v.is_floating_point() else v)) for k, v in d.items()}   # noqa: E731
+        out, res = _oracle_train(network, osd, dict(nof_layers=50), cast(ref_in), [n.to(dt) for n in nz])
+        sum(float(weights[k]) * v for k, v in out.items() if v is not None and k in weights).backward()
+        return out, res, leaves
+
+    out, res, l32 = oracle(torch.float32)
+    _out64, _res64, l64 = oracle(torch.float64)
 
     assert [k for k, v in losses.items() if v is not None] == [k for k, v in out.items() if v is not None]
     for k, v in out.items():
-        a, r = float(losses[k]), float(v)
+        a, r = float(losses[k].detach()), float(v.detach())
         assert abs(a - r) <= 1e-6 + 1e-4 * abs(r), f"loss {k}: hip {a!r} vs oracle {r!r}"
-    derr = (result["depth"].cpu() - res["depth"]).abs()
-    assert float((derr - 1e-4 * res["depth"].abs()).max()) <= 1e-3, f"depth differs by {float(derr.max()):.3e}"
+    derr = (result["depth"].cpu() - res["depth"].detach()).abs()
+    assert float(derr.max()) <= 1e-3, f"depth differs by {float(derr.max()):.3e} (north_star bar: 1e-3 absolute)"
     for k in ("semantic", "thing_mask"):
         same = (result[k].cpu() == res[k]).float().mean()
         assert same > 0.999, f"{k}: only {float(same):.6f} of the pixels agree"
-    # gradients: per parameter against the oracle's autograd, relative to its norm with a floor at 1e-3 of the module's largest;
-    # train-mode BatchNorm + ReLU: one pre-activation of ~1e-7 on the other side of 0 moves upstream gradients by ~2e-3
-    # (DESIGN.md section 4), hence 2e-2 per parameter and 5e-3 on each module's concatenated gradient
+    # gradients per module (concatenated over its parameters), relative L2 against FLOAT64: at most 3 x the fp32 oracle's own
+    # error against float64, with a floor of 2e-3 where both are at rounding level
     for n in names:
         mod = getattr(net, n)
-        pairs = []
+        num_h = num_o = den = 0.0
+        count = 0
         for k, p in mod.named_parameters():
-            if (n, k) in leaves and leaves[(n, k)].grad is not None:
+            if (n, k) in l64 and l64[(n, k)].grad is not None:
                 assert p.grad is not None, f"{n}.{k}: the oracle has a gradient, the HIP path has none"
-                pairs.append((k, p.grad.detach().cpu().double(), leaves[(n, k)].grad.double()))
-        assert pairs, n
-        floor = 1e-3 * max(float(r.norm()) for _k, _g, r in pairs)
-        num = sum(float((g - r).norm()) ** 2 for _k, g, r in pairs) ** 0.5
-        den = sum(float(r.norm()) ** 2 for _k, _g, r in pairs) ** 0.5
-        tol_mod = 5e-2 if n == "semantic_head" else 5e-3      # saturated random-weight softmax: see tests/test_network_gpu.py::_check_pgrads
-        assert num / (den + 1e-30) < tol_mod, f"{n}: module gradient rel-L2 {num / den:.2e}"
-        for k, g, r in pairs:
-            err = float((g - r).norm()) / (float(r.norm()) + floor)
-            assert err < (1e-1 if n == "semantic_head" else 2e-2), f"{n}.{k}: gradient rel-L2 {err:.2e}"
+                g64 = l64[(n, k)].grad
+                num_h += float((p.grad.detach().cpu().double() - g64).norm()) ** 2
+                num_o += float((l32[(n, k)].grad.double() - g64).norm()) ** 2
+                den += float(g64.norm()) ** 2
+                count += 1
+        assert count > 0 and den > 0, n
+        e_hip, e_o32 = (num_h / den) ** 0.5, (num_o / den) ** 0.5
+        print(f"[composition] {n}: gradient rel-L2 vs float64: hip {e_hip:.2e}, fp32 oracle {e_o32:.2e}")
+        assert e_hip <= max(2e-3, 3.0 * e_o32), f"{n}: gradient error vs float64 {e_hip:.2e}, the fp32 oracle's own {e_o32:.2e}"
 
 
 def _oracle_train(network, sds, ocfg, sample, noise):

@@ -90,7 +90,11 @@ CASES = {
     "halo3_128": (2, 64, 128, 128, 128, 3, "conv_halo3_kernel", "conv_halo3_kernel", "wgrad_halo64s_kernel"),
     "halo3r_256": (2, 64, 128, 128, 256, 3, "conv_halo3r_kernel", None, "wgrad_halo64s_kernel"),      # 128-column tiles: weights by LDS DMA
     "halo3r_dgrad": (2, 64, 128, 256, 256, 3, "conv_halo3r_kernel", "conv_halo3r_kernel", None),
-    "ws_3x3_256": (7, 32, 64, 256, 256, 3, "conv_igemm_ws_kernel", "conv_igemm_ws_kernel", None),
+    # grids below one block per CU: the ring kernel on >= 128 CUs without split, or with its channel chunks cut into K slices
+    "halo3r_small_grid": (6, 32, 64, 256, 256, 3, "conv_halo3r_kernel", "conv_halo3r_kernel", None),
+    "halo3r_splitk": (4, 32, 64, 1024, 256, 3, "conv_halo3r_kernel<splitk>", None, None),
+    "halo3r_splitk_dgrad": (4, 32, 64, 256, 1024, 3, None, "conv_halo3r_kernel<splitk>", None),
+    "ws_3x3_256": (7, 32, 48, 256, 256, 3, "conv_igemm_ws_kernel", "conv_igemm_ws_kernel", None),      # W % 32 != 0: not a halo-tile shape
     "ws_1x1_2048": (4, 32, 64, 2048, 512, 1, "conv_igemm_ws_kernel", None, None),
     "igemm_1x1": (8, 32, 64, 256, 1024, 1, "conv_igemm_kernel<split3>", "conv_igemm_ws_kernel", None),      # dgrad: K = 1024, one round of 128x128 blocks
     "igemm_1x1_dgrad": (8, 32, 64, 512, 2048, 1, "conv_igemm_kernel<split3>", "conv_igemm_kernel<split3>", None),
@@ -113,7 +117,8 @@ def test_split_kernels_are_at_fp32_rounding_level(case, kind):
     # forward (+ data gradient only: the weight takes no gradient, so the last launch of backward() is the data gradient)
     dx = nhwc(x).requires_grad_(True)
     y = F.conv2d(dx, wd, pad=k // 2)
-    assert _last() == k_fwd, f"forward ran {_last()}, the case is meant to select {k_fwd}"
+    if k_fwd is not None:
+        assert _last() == k_fwd, f"forward ran {_last()}, the case is meant to select {k_fwd}"
     y.backward(nhwc(gy))
     if k_dg is not None:
         assert _last() == k_dg, f"data gradient ran {_last()}, the case is meant to select {k_dg}"
