@@ -92,8 +92,8 @@ CASES = {
     "halo3r_dgrad": (2, 64, 128, 256, 256, 3, "conv_halo3r_kernel", "conv_halo3r_kernel", None),
     # grids below one block per CU: the ring kernel on >= 128 CUs without split, or with its channel chunks cut into K slices
     "halo3r_small_grid": (6, 32, 64, 256, 256, 3, "conv_halo3r_kernel", "conv_halo3r_kernel", None),
-    "halo3r_splitk": (4, 32, 64, 1024, 256, 3, "conv_halo3r_kernel<splitk>", None, None),
-    "halo3r_splitk_dgrad": (4, 32, 64, 256, 1024, 3, None, "conv_halo3r_kernel<splitk>", None),
+    "halo3r_splitk": (4, 32, 64, 512, 256, 3, "conv_halo3r_kernel<splitk>", None, None),           # 128 blocks x 2 slices of 8 chunks
+    "halo3r_splitk_dgrad": (4, 32, 64, 256, 512, 3, None, "conv_halo3r_kernel<splitk>", None),
     "ws_3x3_256": (7, 32, 48, 256, 256, 3, "conv_igemm_ws_kernel", "conv_igemm_ws_kernel", None),      # W % 32 != 0: not a halo-tile shape
     "ws_1x1_2048": (4, 32, 64, 2048, 512, 1, "conv_igemm_ws_kernel", None, None),
     "igemm_1x1": (8, 32, 64, 256, 1024, 1, "conv_igemm_kernel<split3>", "conv_igemm_ws_kernel", None),      # dgrad: K = 1024, one round of 128x128 blocks
