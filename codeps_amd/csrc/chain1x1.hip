@@ -1,0 +1,282 @@
+// Register-chained pair of 1x1 convolutions of the FROZEN ResNet bottleneck stack (inference only):
+//
+//     out[m][n2] = relu(scale2[n2] * sum_c  W2[n2][c] * y1[m][c]  + shift2[n2] + res[m][n2])        expand   (K = 256 -> N2)
+//     y0n[m][c'] = relu(scale3[c'] * sum_n2 W3[c'][n2] * out[m][n2] + shift3[c'])                    next block's reduce (N2 -> 256)
+//
+// i.e. conv3 + bn3 + residual + ReLU of bottleneck i and conv1 + bn1 + ReLU of bottleneck i + 1 (models/resnet_encoder.py:115-126
+// -> torchvision Bottleneck.forward) in ONE launch: in the unfused form the 22 expand / reduce pairs of ResNet-101's layer3
+// are 2.8 ms of the adaptation step at 133 / 147 TFLOP/s -- the expand is all prologue / epilogue (8 K-steps per tile), the
+// reduce re-reads, re-splits and re-stages the 67 MB tensor the expand has just written.
+//
+// Same arithmetic as the conv engine (csrc/conv.hip): every fp32 operand is the exact sum of three bf16 pieces, six piece
+// products of order <= 2 on v_mfma_f32_16x16x32_bf16, fp32 accumulation.  What is different is where operands live:
+//   * both GEMMs are computed TRANSPOSED, D[channel][pixel]: the accumulator of a 16 x 16 tile then holds, per lane, FOUR
+//     CONSECUTIVE CHANNELS of one pixel (rows 4 kg + r, column l16) -- which is (a) a 16-byte NHWC store / residual load and
+//     (b) after the in-register epilogue and bf16 split, directly the B operand of the next MFMA that contracts over
+//     channels (guide: "an accumulator tile as the next MFMA's operand"): `out` never goes through LDS or back from HBM.
+//     The k order inside a 32-deep step is permuted (element j of lane group kg = channel 16 (j >> 2) + 4 kg + (j & 3)); the
+//     reduce weights are stored in that order (host side: codeps_amd.functional.chain_weights).
+//   * the activations of the expand (y1: 16 pixels x 256 channels per wave) are loaded ONCE, straight from HBM in B-fragment
+//     layout, split in registers and kept there (96 VGPRs) for all N2 / 32 stages.
+//   * LDS holds nothing but weights: a ring of three 52 KB tiles filled by `buffer_load_dwordx4 ... lds` (no VGPR round trip,
+//     no ds_write), consumed alternately as E_s (32 expand rows x K 256) and R_s (256 reduce rows x 32 k) -- both are images
+//     of 256 rows x 208 bytes (192 data + 16 pad, conflict-free ds_read_b128 fragment reads).  The pad of an E row carries the
+//     row's folded BatchNorm (scale, shift): the affine of the expand reaches the epilogue through the same DMA.
+//   * every vector-memory operation of the main loop is issued through inline assembly and its completion is counted by hand
+//     (vmcnt: loads, stores and LDS DMA retire in issue order), so a tile has a full stage (two MFMA phases) to land.
+// One block = 64 pixels (M = 16384 at config 3: 256 blocks = one per CU), four waves x 16 pixels.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KMID = 256;                 // channels of y1 (K of the expand) = output channels of the reduce
+constexpr int ROWB = 208;                 // bytes per LDS row: [piece][32 bf16] + 16 pad
+constexpr int TILE_B = 256 * ROWB;        // one ring slot
+constexpr int W2ROW = KMID * 6 + 16;      // bytes per expand-weight row in HBM: 8 groups x [3 pieces][32 bf16] + (scale, shift, 0, 0)
+constexpr int NDMA = 13;                  // DMA instructions per wave and tile (4 waves x 13 x 64 lanes x 16 B = 256 x 208 B)
+
+struct ChainP {
+    long long M;                          // pixels (multiple of 64)
+    int N2;                               // expand output channels (multiple of 32)
+    const float* y1;                      // [M][256]
+    const float* res;                     // [M][N2]
+    const void* w2;                       // [N2][W2ROW]   pre-split expand weights + affine record
+    const void* w3;                       // [256][N2 / 32][3][32] bf16, k order permuted per 32-group
+    const float* scale3;                  // [256]
+    const float* shift3;
+    float* out;                           // [M][N2]
+    float* y0n;                           // [M][256]
+};
+
+// x = p0 + p1 + p2 exactly (round to nearest each time); element e of the three pieces
+__device__ __forceinline__ void split3(float x, unsigned short (&p)[3]) {
+    float r = x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)r);
+        p[q] = h;
+        r -= __builtin_bit_cast(float, (unsigned)h << 16);
+    }
+}
+
+// eight fp32 values -> three bf16x8 fragments
+__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8 (&f)[3]) {
+    unsigned short h[8][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { split3(lo[e], h[e]); split3(hi[e], h[4 + e]); }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        i32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (int)((unsigned)h[2 * i][q] | ((unsigned)h[2 * i + 1][q] << 16));
+        f[q] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+#define CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+__global__ __launch_bounds__(256) void chain_expand_reduce_kernel(ChainP p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * 64;
+    const long long m = m0 + wave * 16 + l16;                  // this lane's pixel
+    const int NS = p.N2 / 32;
+
+    // ---- buffer resources (wave-uniform)
+    auto rsrc_of = [](const void* base, size_t bytes) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+        i32x4 r;
+        r[0] = (int)__builtin_amdgcn_readfirstlane((unsigned)a);
+        r[1] = (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xFFFFu);
+        r[2] = (int)__builtin_amdgcn_readfirstlane((unsigned)(bytes < 0xFFFF0000ull ? bytes : 0xFFFF0000ull));
+        r[3] = 0x00020000;
+        return r;
+    };
+    // the block's 64 rows of res / out: offsets inside the block's slab stay far below 4 GB whatever M is
+    const i32x4 rsW2 = rsrc_of(p.w2, (size_t)p.N2 * W2ROW);
+    const i32x4 rsW3 = rsrc_of(p.w3, (size_t)KMID * p.N2 * 6);
+    const i32x4 rsRes = rsrc_of(p.res + (size_t)m0 * p.N2, (size_t)64 * p.N2 * 4);
+    const i32x4 rsOut = rsrc_of(p.out + (size_t)m0 * p.N2, (size_t)64 * p.N2 * 4);
+    const unsigned row_off = (unsigned)((wave * 16 + l16) * p.N2 + 4 * kg) * 4u;      // byte offset of (pixel, channel 4 kg) in those slabs
+
+    // ---- DMA roles: instruction i of this wave covers linear 16-byte segments L = (wave + 4 i) * 64 + lane of the tile image;
+    //      segment L -> (row L / 13, seg L % 13), seg 12 = the pad
+    unsigned offE[NDMA], offR[NDMA], ldsdst[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int ins = wave + 4 * i, L = ins * 64 + lane, prow = L / 13, seg = L % 13;
+        ldsdst[i] = (unsigned)ins * 1024u;
+        const int ks = prow >> 5, r = prow & 31;               // E tile: pseudo-row = (k-step, expand row within the stage)
+        offE[i] = (unsigned)(r * W2ROW + (seg < 12 ? ks * 192 + seg * 16 : KMID * 6));
+        offR[i] = (unsigned)((size_t)prow * p.N2 * 6 + (seg < 12 ? seg : 0) * 16);
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto dma_tile = [&](int t) {                               // tile t: even = E_{t/2}, odd = R_{t/2}; slot t % 3
+        const int s = t >> 1;
+        const unsigned slot = lds_base + (unsigned)(t % 3) * TILE_B;
+        if (t & 1) {
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 192);
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + ldsdst[i]);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(offR[i]), "s"(rsW3), "s"(soff) : "memory");
+            }
+        } else {
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 32 * W2ROW);
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + ldsdst[i]);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(offE[i]), "s"(rsW2), "s"(soff) : "memory");
+            }
+        }
+    };
+    auto res_load = [&](int s, f32x4 (&r)[2]) {                // residual of stage s: channels 32 s + 16 nt + 4 kg .. + 3 of this lane's pixel
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 128);
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[0]) : "v"(row_off), "s"(rsRes), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(r[1]) : "v"(row_off), "s"(rsRes), "s"(soff) : "memory");
+    };
+    auto out_store = [&](int s, const f32x4 (&v)[2]) {
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 128);
+        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v[0]), "v"(row_off), "s"(rsOut), "s"(soff) : "memory");
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:64\n\ts_nop 1" :: "v"(v[1]), "v"(row_off), "s"(rsOut), "s"(soff) : "memory");
+    };
+
+    // ---- prologue: three weight tiles in flight, then this wave's 16 x 256 activations straight into B-fragment registers
+    // residual registers ping-pong between two NAMED sets (stages are unrolled in pairs).  Their loads are inline assembly: the
+    // compiler takes the destination for written at once, so a copy it makes before the data lands copies garbage.  Every
+    // residual load is therefore issued BEFORE the weight tile of the same point of the loop -- the counted wait for that tile
+    // (operations retire in order) then covers it -- and the set is handed to the compiler ("claimed" by an empty asm behind a
+    // sched_barrier) only after that wait.
+    f32x4 rA[2], rB[2];
+    res_load(0, rA);
+    dma_tile(0);
+    dma_tile(1);
+    if (NS > 1) dma_tile(2);
+    bf16x8 yf[8][3];
+    {
+        const float* yrow = p.y1 + (size_t)m * KMID + kg * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(yrow + ks * 32), hi = *reinterpret_cast<const f32x4*>(yrow + ks * 32 + 4);
+            split8(lo, hi, yf[ks]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rA[0]), "+v"(rA[1]) :: "memory");          // everything issued so far has landed
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc3[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* arow = lds + l16 * ROWB + kg * 16;             // fragment address of row l16 of a tile, piece 0
+
+    auto stage = [&](const int s, f32x4 (&rcur)[2], f32x4 (&rnext)[2]) {
+        const bool last = s + 1 == NS;
+        // ================= expand stage s: tile 2 s
+        // vector-memory queue of this wave, oldest first, at this point (steady state):
+        //   R(s)x2 D(2s)x13 | S(s-1)x2  D(2s+1)x13     -> the residual of this stage and tile 2 s have landed once <= 15 younger
+        //                                                  operations are outstanding
+        if (s > 0) CHAIN_WAIT(15);
+        __syncthreads();                                       // every wave's part of tile 2 s is in LDS; reduce s - 1 has been read
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(rcur[0]), "+v"(rcur[1]));       // claim: from here on the compiler may touch the residual registers
+        res_load(s + 1, rnext);                                // (stage NS: past the block's slab for its last pixel row -> the range check returns zeros; never used)
+        if (s > 0 && 2 * s + 2 < 2 * NS) dma_tile(2 * s + 2);  // into the slot of tile 2 s - 1
+        const char* et = arow + ((2 * s) % 3) * TILE_B;
+        f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const char* a = et + (ks * 32 + nt * 16) * ROWB;
+                bf16x8 wf[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) wf[q] = *reinterpret_cast<const bf16x8*>(a + q * 64);
+#pragma unroll
+                for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                    for (int qa = 0; qa <= ord; ++qa)
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[qa], yf[ks][ord - qa], acc2[nt], 0, 0, 0);
+            }
+        // epilogue of the expand in registers: lane = pixel l16, channels 32 s + 16 nt + 4 kg + r; the affine record sits in the
+        // pad of row (k-step 0, channel) of the E tile
+        f32x4 v[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* aff = reinterpret_cast<const float*>(lds + ((2 * s) % 3) * TILE_B + (nt * 16 + 4 * kg + r) * ROWB + 192);
+                v[nt][r] = acc2[nt][r] * aff[0] + aff[1];
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = v[nt][r] + rcur[nt][r];
+                v[nt][r] = t > 0.f ? t : 0.f;
+            }
+        out_store(s, v);
+        bf16x8 of[3];                                          // B fragment of reduce k-step s: element j = channel 16 (j >> 2) + 4 kg + (j & 3)
+        split8(v[0], v[1], of);
+        // ================= reduce k-step s: tile 2 s + 1
+        //   D(2s+1)x13 | R(s+1)x2 D(2s+2)x13 S(s)x2   (last stage: no D(2s+2): wait for everything)
+        if (last) CHAIN_WAIT(0); else CHAIN_WAIT(17);
+        __syncthreads();                                       // tile 2 s + 1 is in LDS; every wave has read tile 2 s
+        if (2 * s + 3 < 2 * NS) dma_tile(2 * s + 3);           // into the slot of tile 2 s
+        const char* rt = arow + ((2 * s + 1) % 3) * TILE_B;
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) {
+            const char* a = rt + jt * 16 * ROWB;
+            bf16x8 wf[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wf[q] = *reinterpret_cast<const bf16x8*>(a + q * 64);
+#pragma unroll
+            for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                for (int qa = 0; qa <= ord; ++qa)
+                    acc3[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[qa], of[ord - qa], acc3[jt], 0, 0, 0);
+        }
+    };
+    for (int s = 0; s < NS; s += 2) {                          // NS is even (n2 % 64 == 0)
+        stage(s, rA, rB);
+        stage(s + 1, rB, rA);
+    }
+    CHAIN_WAIT(0);
+
+    // ---- epilogue of the reduce: y0n[m][16 jt + 4 kg + r] = relu(acc * scale3 + shift3), 16-byte stores
+    float* yo = p.y0n + (size_t)m * KMID + 4 * kg;
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale3 + jt * 16 + 4 * kg), sh = *reinterpret_cast<const f32x4*>(p.shift3 + jt * 16 + 4 * kg);
+        f32x4 o = acc3[jt] * sc + sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
+        *reinterpret_cast<f32x4*>(yo + jt * 16) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t codeps_chain1x1_w2_row_bytes(void) { return W2ROW; }
+
+extern "C" int codeps_chain1x1_expand_reduce(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
+                                             const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
+                                             codeps_stream_t stream) {
+    CODEPS_REQUIRE(y1 && residual && w2_rows && w3_split && scale3 && shift3 && out && y0_next, CODEPS_ERR_ARG, "chain1x1: null pointer argument");
+    CODEPS_REQUIRE(rows > 0 && rows % 64 == 0 && rows / 64 < (1ll << 31), CODEPS_ERR_ARG, "chain1x1: rows (%lld) must be a positive multiple of 64", rows);
+    CODEPS_REQUIRE(n2 >= 64 && n2 % 64 == 0 && n2 <= 4096, CODEPS_ERR_ARG, "chain1x1: expand channels (%d) must be a multiple of 64 in [64, 4096]", n2);
+    ChainP p;
+    p.M = rows; p.N2 = n2; p.y1 = y1; p.res = residual; p.w2 = w2_rows; p.w3 = w3_split; p.scale3 = scale3; p.shift3 = shift3;
+    p.out = out; p.y0n = y0_next;
+    codeps_allow_lds((const void*)chain_expand_reduce_kernel, 160 * 1024, "chain_expand_reduce_kernel");
+    hipLaunchKernelGGL(chain_expand_reduce_kernel, dim3((unsigned)(rows / 64)), dim3(256), 3 * TILE_B, (hipStream_t)stream, p);
+    CODEPS_CHECK_LAUNCH("chain_expand_reduce_kernel");
+    return CODEPS_OK;
+}

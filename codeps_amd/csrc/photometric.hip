@@ -11,12 +11,15 @@
 //         photo_fwd_kernel    per tile: warp + 4-tap gather + SSIM/L1 for 4 candidates, min, block sum,
 //                             writes the selected branch per pixel (u8) for the backward
 //         loss_reduce_kernel  fixed-order sum of per-block partials -> loss[0]
-//   bwd:  photo_bwd_kernel    per tile: recompute predictions (halo 2), SSIM adjoint coefficients
-//                             (halo 1), gather them at each pixel, back through the bilinear sample,
-//                             projection, pose and back-projection -> d depth_s, per-block d T partials
+//   bwd:  photo_bwd_kernel    per tile: the forward's SSIM adjoint coefficients of the selected branch (halo 1) and
+//                             its warped samples are READ BACK (round 3: the forward stores them, 60 B/px, instead of
+//                             the backward recomputing warp + sample on a halo-2 tile and the window sums on halo 1:
+//                             2.7x fewer VALU operations per pixel), gathered at each pixel, back through the
+//                             bilinear sample, projection, pose and back-projection -> d depth_s, per-block d T partials
 //         pose_reduce_kernel  fixed-order sum of d T partials per batch item
 //         depth_combine_kernel  transposed bilinear pyramid: d depth = g_0 + sum_s down_s^T(g_s)
-// HBM-bound: algorithmic traffic 40 B/px forward, 44 B/px backward; planes are NCHW so
+// HBM-bound: algorithmic traffic 40 B/px forward, 44 B/px backward + 60 B/px written and ~72 B/px read back
+// for the stored samples / coefficients; planes are NCHW so
 // every plane read is a unit-stride 256-B/wave stream; intermediates live in LDS tiles only.
 // No atomics anywhere -> results are bitwise reproducible run to run.
 #include "common.h"
@@ -43,7 +46,7 @@ constexpr int FTH = 8, FTW = 64;       // forward tile
 constexpr int BTH = 8, BTW = 32;       // backward tile
 
 struct WsLayout {
-    size_t pyr, sel, gds, loss_part, pose_part, total;
+    size_t pyr, sel, gds, loss_part, pose_part, pred, coef, total;
 };
 
 static Levels make_levels(const codeps_photometric_desc* d) {
@@ -81,6 +84,10 @@ static WsLayout make_layout(const Levels& L) {
     o.gds = off;       off = align_up(off + (size_t)L.map_total * 4, 256);
     o.loss_part = off; off = align_up(off + (size_t)L.fblk[L.num_scales] * 4, 256);
     o.pose_part = off; off = align_up(off + (size_t)L.bblk[L.num_scales] * 32 * 4, 256);
+    // forward results kept for the backward, per level [b][plane][h_s * w_s]: the warped samples of both source frames
+    // (6 planes) and the SSIM adjoint coefficients A, B, C per channel of the selected branch (9 planes, unscaled)
+    o.pred = off;      off = align_up(off + (size_t)L.map_total * 6 * 4, 256);
+    o.coef = off;      off = align_up(off + (size_t)L.map_total * 9 * 4, 256);
     o.total = off;
     return o;
 }
@@ -280,7 +287,8 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(Levels L, const float* _
                                                         uint64_t seed, const uint64_t* __restrict__ seed_ctr,
                                                         float alpha, float one_minus_alpha,
                                                         const float* __restrict__ pyr, uint8_t* __restrict__ sel,
-                                                        float* __restrict__ loss_part) {
+                                                        float* __restrict__ loss_part, float* __restrict__ pred_out,
+                                                        float* __restrict__ coef_out) {
     __shared__ float sm[15][FPN];         // tgt[3], im[3], ip[3], pred_m[3], pred_p[3]
     __shared__ float red[4];
     // device-side step counter (bumped once per step by codeps_step_counter_add): a replayed HIP graph draws fresh noise
@@ -323,6 +331,7 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(Levels L, const float* _
         const int gy = ty0 + oy, gx = tx0 + ox;
         if (gy >= hs || gx >= ws) continue;
         float ssim[4] = {0.f, 0.f, 0.f, 0.f}, l1[4] = {0.f, 0.f, 0.f, 0.f};
+        float wsum[3][8];                 // per channel: sy, syy and (sx, sxx, sxy) of the two WARPED candidates, for the adjoint
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float sy = 0.f, syy = 0.f;
@@ -346,6 +355,9 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(Levels L, const float* _
                 ssim[m] += ssim_val(sx[m], sy, sxx[m], syy, sxy[m]);
                 l1[m] += fabsf(xc[m] - yc);
             }
+            wsum[c][0] = sy; wsum[c][1] = syy;
+            wsum[c][2] = sx[0]; wsum[c][3] = sxx[0]; wsum[c][4] = sxy[0];
+            wsum[c][5] = sx[1]; wsum[c][6] = sxx[1]; wsum[c][7] = sxy[1];
         }
         float cand[4];
 #pragma unroll
@@ -360,6 +372,25 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(Levels L, const float* _
         for (int m = 1; m < 4; ++m) if (cand[m] < best) { best = cand[m]; bi = m; }
         sel[L.map_off[s] + ((long long)b * hs + gy) * ws + gx] = (uint8_t)bi;
         acc += best;
+        // kept for the backward: both warped samples at this pixel, and d SSIM / d window entry = A + B x + C y of the selected
+        // WARPED branch (identity branches carry no gradient: zeros)
+        {
+            const size_t hw = (size_t)hs * ws, o = (size_t)gy * ws + gx;
+            float* pr = pred_out + 6 * L.map_off[s] + (size_t)b * 6 * hw + o;
+            float* cf = coef_out + 9 * L.map_off[s] + (size_t)b * 9 * hw + o;
+            const int qc = (oy + 1) * FPW + ox + 1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pr[(size_t)c * hw] = sm[9 + c][qc];
+                pr[(size_t)(3 + c) * hw] = sm[12 + c][qc];
+                float A = 0.f, B = 0.f, C = 0.f;
+                if (bi < 2) {
+                    const bool p1 = bi == 1;
+                    ssim_grad(p1 ? wsum[c][5] : wsum[c][2], wsum[c][0], p1 ? wsum[c][6] : wsum[c][3], wsum[c][1], p1 ? wsum[c][7] : wsum[c][4], A, B, C);
+                }
+                cf[(size_t)c * hw] = A; cf[(size_t)(3 + c) * hw] = B; cf[(size_t)(6 + c) * hw] = C;
+            }
+        }
     }
     const float tot = block_sum<256>(acc, red);
     if (threadIdx.x == 0) loss_part[bid] = tot * L.pixw[s];
@@ -374,7 +405,6 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------- backward
-constexpr int BP2H = BTH + 4, BP2W = BTW + 4, BP2N = BP2H * BP2W;     // halo-2 tile: 12 x 36
 constexpr int BP1H = BTH + 2, BP1W = BTW + 2, BP1N = BP1H * BP1W;     // halo-1 tile: 10 x 34
 
 __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* __restrict__ img_t,
@@ -386,10 +416,10 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* _
                                                         const float* __restrict__ intr, float alpha,
                                                         float one_minus_alpha, const float* __restrict__ grad_loss,
                                                         const float* __restrict__ pyr, const uint8_t* __restrict__ sel,
+                                                        const float* __restrict__ pred_in, const float* __restrict__ coef_in,
                                                         float* __restrict__ gd0, float* __restrict__ gds,
                                                         float* __restrict__ pose_part) {
-    __shared__ float sv[9][BP2N];        // pred_m[3], pred_p[3], tgt[3] on the halo-2 tile
-    __shared__ float cf[9][BP1N];        // A[3], B[3], C[3] of the selected branch on the halo-1 tile
+    __shared__ float cf[9][BP1N];        // A[3], B[3], C[3] of the selected branch on the halo-1 tile (scaled by the loss weight)
     __shared__ int sk[BP1N];             // selected branch (0,1 = warped; >= 2 or -1 = no gradient)
     __shared__ float red[4][32];
     const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -406,29 +436,11 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* _
     const float* Tp = pose_p + b * 16;
     const float gout = grad_loss[0] * L.pixw[s];
     const float w_ssim = gout * alpha / 3.f, w_l1 = gout * one_minus_alpha / 3.f;
+    const size_t hw = (size_t)hs * ws;
+    const float* prd = pred_in + 6 * L.map_off[s] + (size_t)b * 6 * hw;
+    const float* cfi = coef_in + 9 * L.map_off[s] + (size_t)b * 9 * hw;
 
-    // phase 1: predictions + target on the halo-2 tile (reflected coordinates)
-    for (int i = threadIdx.x; i < BP2N; i += 256) {
-        const int py = i / BP2W, px = i % BP2W;
-        int gy = ty0 + py - 2, gx = tx0 + px - 2;
-        // two-step reflection: halo-2 positions are only ever read as reflect1 of halo-1 neighbours
-        gy = min(max(gy < 0 ? -gy : (gy >= hs ? 2 * (hs - 1) - gy : gy), 0), hs - 1);
-        gx = min(max(gx < 0 ? -gx : (gx >= ws ? 2 * (ws - 1) - gx : gx), 0), ws - 1);
-        const int o = gy * ws + gx;
-        const float d = P.dp[o];
-        const Warp wm = warp_point(k, Tm, gx, gy, d, ws, hs);
-        const Warp wp = warp_point(k, Tp, gx, gy, d, ws, hs);
-        const Taps tm = make_taps(wm.ix, wm.iy, ws, hs), tp = make_taps(wp.ix, wp.iy, ws, hs);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            sv[c][i] = sample(P.im + c * P.hw, tm);
-            sv[3 + c][i] = sample(P.ip + c * P.hw, tp);
-            sv[6 + c][i] = P.tg[c * P.hw + o];
-        }
-    }
-    __syncthreads();
-
-    // phase 2: SSIM adjoint coefficients of the selected branch at every p in the halo-1 tile
+    // phase 1: the forward's adjoint coefficients of the selected branch at every p of the halo-1 tile (unit-stride plane reads)
     for (int i = threadIdx.x; i < BP1N; i += 256) {
         const int py = i / BP1W, px = i % BP1W;
         const int gy = ty0 + py - 1, gx = tx0 + px - 1;
@@ -436,23 +448,9 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* _
         if (gy >= 0 && gy < hs && gx >= 0 && gx < ws) kk = sel[L.map_off[s] + ((long long)b * hs + gy) * ws + gx];
         sk[i] = kk;
         if (kk == 0 || kk == 1) {
+            const size_t o = (size_t)gy * ws + gx;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        // window entry = value at reflect1(p + delta); locate it inside the halo-2 tile
-                        const int ry = reflect1(gy + dy, hs), rx = reflect1(gx + dx, ws);
-                        const int q = (ry - ty0 + 2) * BP2W + (rx - tx0 + 2);
-                        const float x = sv[kk * 3 + c][q], y = sv[6 + c][q];
-                        sx += x; sy += y; sxx += x * x; syy += y * y; sxy += x * y;
-                    }
-                float A, B, C;
-                ssim_grad(sx, sy, sxx, syy, sxy, A, B, C);
-                cf[c][i] = A * w_ssim; cf[3 + c][i] = B * w_ssim; cf[6 + c][i] = C * w_ssim;
-            }
+            for (int c = 0; c < 9; ++c) cf[c][i] = cfi[(size_t)c * hw + o] * w_ssim;
         }
     }
     __syncthreads();
@@ -465,7 +463,14 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* _
         const int oy = threadIdx.x / BTW, ox = threadIdx.x % BTW;
         const int gy = ty0 + oy, gx = tx0 + ox;
         if (gy < hs && gx < ws) {
-            const int qi2 = (oy + 2) * BP2W + ox + 2;
+            const int o = gy * ws + gx;
+            float xq[2][3], yq[3];               // the forward's warped samples of both source frames and the target at q
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                xq[0][c] = prd[(size_t)c * hw + o];
+                xq[1][c] = prd[(size_t)(3 + c) * hw + o];
+                yq[c] = P.tg[c * P.hw + o];
+            }
             float g[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
             bool any[2] = {false, false};
 #pragma unroll
@@ -481,22 +486,25 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* _
                     const float my = 1.f + ((pyy == 0 && gy == 1) ? 1.f : 0.f) + ((pyy == hs - 1 && gy == hs - 2) ? 1.f : 0.f);
                     const float mx = 1.f + ((pxx == 0 && gx == 1) ? 1.f : 0.f) + ((pxx == ws - 1 && gx == ws - 2) ? 1.f : 0.f);
                     const float m = my * mx;
-                    any[kk] = true;
+                    // (compile-time indices only: a runtime-indexed register array would live in scratch memory)
+                    if (kk == 0) any[0] = true; else any[1] = true;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        g[kk][c] += m * (cf[c][pi] + cf[3 + c][pi] * sv[kk * 3 + c][qi2] + cf[6 + c][pi] * sv[6 + c][qi2]);
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = m * (cf[c][pi] + cf[3 + c][pi] * (kk == 0 ? xq[0][c] : xq[1][c]) + cf[6 + c][pi] * yq[c]);
+                        if (kk == 0) g[0][c] += v; else g[1][c] += v;
+                    }
                 }
             const int ks = sk[(oy + 1) * BP1W + ox + 1];
             if (ks == 0 || ks == 1) {
-                any[ks] = true;
+                if (ks == 0) any[0] = true; else any[1] = true;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float df = sv[ks * 3 + c][qi2] - sv[6 + c][qi2];
-                    g[ks][c] += w_l1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+                    const float df = (ks == 0 ? xq[0][c] : xq[1][c]) - yq[c];
+                    if (ks == 0) g[0][c] += w_l1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+                    else g[1][c] += w_l1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
                 }
             }
             float gdepth = 0.f;
-            const int o = gy * ws + gx;
             const float d = P.dp[o];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -535,13 +543,25 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(Levels L, const float* _
             else gds[L.map_off[s] + (long long)b * hs * ws + o] = gdepth;
         }
     }
-    // block reduction of the 2 x 16 pose gradient entries (fixed order)
+    // block reduction of the 2 x 16 pose gradient entries (fixed order).  Transposing butterfly: at step s the lanes whose bit s
+    // is set keep the upper half of the remaining entries and hand the lower half to their partner (and vice versa), so the 32
+    // entries cost 16 + 8 + 4 + 2 + 1 + 1 = 32 cross-lane moves per wave instead of 32 x 6 (one full butterfly per entry)
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const float v = wave_sum(dT[i]);
-        if (ln == 0) red[wv][i] = v;
+    int idx = 0;
+#define CODEPS_BFLY(HALF, BIT)                                                   \
+    {                                                                            \
+        const bool up = (ln & (BIT)) != 0;                                       \
+        idx += up ? (HALF) : 0;                                                  \
+        _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                     \
+            const float keep = up ? dT[i + (HALF)] : dT[i];                      \
+            const float give = up ? dT[i] : dT[i + (HALF)];                      \
+            dT[i] = keep + __shfl_xor(give, (BIT), 64);                          \
+        }                                                                        \
     }
+    CODEPS_BFLY(16, 1) CODEPS_BFLY(8, 2) CODEPS_BFLY(4, 4) CODEPS_BFLY(2, 8) CODEPS_BFLY(1, 16)
+#undef CODEPS_BFLY
+    dT[0] += __shfl_xor(dT[0], 32, 64);
+    if (ln < 32) red[wv][idx] = dT[0];
     __syncthreads();
     if (threadIdx.x < 32) pose_part[(size_t)bid * 32 + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
@@ -645,7 +665,8 @@ extern "C" int codeps_photometric_fwd(const codeps_photometric_desc* d, const fl
     const int nblk = L.fblk[L.num_scales];
     hipLaunchKernelGGL(photo_fwd_kernel, dim3(nblk), dim3(256), 0, st, L, img_t, img_m, img_p, depth, pose_m, pose_p, intr,
                        noise, (uint64_t)d->noise_seed, noise_counter, d->alpha, (float)(1.0 - (double)d->alpha),
-                       (const float*)(ws + W.pyr), (uint8_t*)(ws + W.sel), (float*)(ws + W.loss_part));
+                       (const float*)(ws + W.pyr), (uint8_t*)(ws + W.sel), (float*)(ws + W.loss_part), (float*)(ws + W.pred),
+                       (float*)(ws + W.coef));
     CODEPS_CHECK_LAUNCH("photo_fwd_kernel");
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)(ws + W.loss_part), nblk, loss);
     CODEPS_CHECK_LAUNCH("loss_reduce_kernel");
@@ -671,7 +692,8 @@ extern "C" int codeps_photometric_bwd(const codeps_photometric_desc* d, const fl
     const int nblk = L.bblk[L.num_scales];
     hipLaunchKernelGGL(photo_bwd_kernel, dim3(nblk), dim3(256), 0, st, L, img_t, img_m, img_p, depth, pose_m, pose_p, intr,
                        d->alpha, (float)(1.0 - (double)d->alpha), grad_loss, (const float*)(ws + W.pyr),
-                       (const uint8_t*)(ws + W.sel), grad_depth, (float*)(ws + W.gds), (float*)(ws + W.pose_part));
+                       (const uint8_t*)(ws + W.sel), (const float*)(ws + W.pred), (const float*)(ws + W.coef), grad_depth,
+                       (float*)(ws + W.gds), (float*)(ws + W.pose_part));
     CODEPS_CHECK_LAUNCH("photo_bwd_kernel");
     hipLaunchKernelGGL(pose_reduce_kernel, dim3(L.batch), dim3(1024), 0, st, L, (const float*)(ws + W.pose_part), grad_pose_m,
                        grad_pose_p);

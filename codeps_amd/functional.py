@@ -628,6 +628,80 @@ def stem_conv2d(x, weight, *, scale=None, shift=None, act=None):
                   macs_per_out=weight.shape[1] * 49)
 
 
+# ---------------------------------------------------------------------------------------- chained 1x1 pair (frozen bottlenecks)
+_chain_cache = {}
+_CHAIN = os.environ.get("CODEPS_CHAIN1X1", "1") != "0"       # A/B switch: 0 = the two layers as separate conv launches
+
+
+def _chain_perm(n2, device):
+    """k order of the reduce weights inside every 32-channel group: position 8 kg + j holds channel 16 (j >> 2) + 4 kg + (j & 3)
+    (the order in which an MFMA accumulator tile hands its channels over as the next MFMA's B operand, csrc/chain1x1.hip)."""
+    p = torch.arange(32, device=device)
+    inner = 16 * ((p & 7) >> 2) + 4 * (p >> 3) + (p & 3)
+    return (torch.arange(0, n2, 32, device=device).view(-1, 1) + inner.view(1, -1)).reshape(-1)
+
+
+def chain_weights(w_expand, scale2, shift2, w_reduce):
+    """Weight blobs of codeps_chain1x1_expand_reduce for FROZEN 1x1 weights (cached per parameter pair / version):
+    w2 rows = the pre-split expand pack row (8 x [3 pieces][32 bf16]) + 16 bytes (scale, shift, 0, 0); w3 = the pre-split pack
+    of the reduce weights with the permuted k order."""
+    key = (id(w_expand), id(w_reduce))
+    stamp = (w_expand._version, w_reduce._version, scale2._version, shift2._version, w_expand.data_ptr(), w_reduce.data_ptr(),
+             scale2.data_ptr())
+    hit = _chain_cache.get(key)
+    if hit is not None and hit[0] == stamp and hit[3]() is w_expand and hit[4]() is w_reduce:
+        return hit[1], hit[2]
+    n2, kmid = w_expand.shape[:2]
+    c3 = w_reduce.shape[0]
+    if kmid != 256 or c3 != 256 or w_reduce.shape[1] != n2 or n2 % 64 or tuple(w_expand.shape[2:]) != (1, 1) or tuple(w_reduce.shape[2:]) != (1, 1):
+        raise CodepsHipError("chain_weights: expects 1x1 weights [N2, 256, 1, 1] and [256, N2, 1, 1] with N2 % 64 == 0")
+    dev = w_expand.device
+    with torch.no_grad():
+        wf, _ = pack_weights(w_expand, n2, kmid, False)
+        split = wf.view(torch.uint8)[n2 * kmid * 4:][:n2 * kmid * 6].view(n2, kmid * 6)
+        aff = torch.zeros(n2, 4, dtype=torch.float32, device=dev)
+        aff[:, 0], aff[:, 1] = _f32c(scale2.detach()), _f32c(shift2.detach())
+        rowb = lib().codeps_chain1x1_w2_row_bytes()
+        w2 = torch.cat([split, aff.view(torch.uint8).view(n2, 16)], 1).contiguous()
+        assert w2.shape[1] == rowb
+        w3p = _f32c(w_reduce.detach())[:, _chain_perm(n2, dev)].contiguous()
+        wf3, _ = pack_weights(w3p, c3, n2, False)
+        w3 = wf3.view(torch.uint8)[c3 * n2 * 4:][:c3 * n2 * 6].clone()
+    _chain_cache[key] = (stamp, w2, w3, _weak(w_expand, _chain_cache, key), weakref.ref(w_reduce))
+    return w2, w3
+
+
+def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3, shift3):
+    """Inference-only fusion of two frozen 1x1 layers of consecutive ResNet bottlenecks (models/resnet_encoder.py:115-126):
+        out = relu(bn3(conv3(y1)) + residual)            [B,H,W,N2]
+        y0  = relu(bn1'(conv1'(out)))                    [B,H,W,256]    (the next bottleneck's first layer)
+    in ONE launch (C ABI: codeps_chain1x1_expand_reduce); the BatchNorms arrive folded as (scale, shift)."""
+    require_cuda(y1, residual, w_expand, w_reduce)
+    if torch.is_grad_enabled() and (y1.requires_grad or residual.requires_grad or w_expand.requires_grad or w_reduce.requires_grad):
+        raise CodepsHipError("chain_expand_reduce is an inference kernel (frozen encoder): no autograd support")
+    b, h, w_, kmid = y1.shape
+    n2 = w_expand.shape[0]
+    rows = b * h * w_
+    w2, w3 = chain_weights(w_expand, scale2, shift2, w_reduce)
+    y1, residual = y1.contiguous(), residual.contiguous()
+    out = torch.empty(b, h, w_, n2, dtype=torch.float32, device=y1.device)
+    y0 = torch.empty(b, h, w_, 256, dtype=torch.float32, device=y1.device)
+    flops = 2.0 * rows * (n2 * kmid + 256 * n2)
+    t0 = _prof_begin()
+    check(lib().codeps_chain1x1_expand_reduce(ptr(y1), ptr(residual), ptr(w2), ptr(w3), ptr(_f32c(scale3)), ptr(_f32c(shift3)), rows, n2,
+                                              ptr(out), ptr(y0), stream_ptr()), "codeps_chain1x1_expand_reduce")
+    if t0 is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _profile["events"].append(("conv_fwd_split", flops, t0, e, f"B{b} {h}x{w_} chain 256->{n2}->256 k1"))
+    return out, y0
+
+
+def chain_ok(y1, n2):
+    """Shapes the chained kernel takes: 256 mid channels, N2 % 64 == 0, pixel count a multiple of 64."""
+    return _CHAIN and y1.shape[-1] == 256 and n2 % 64 == 0 and (y1.numel() // 256) % 64 == 0
+
+
 # ---------------------------------------------------------------------------------------- BatchNorm
 def bn_fold(weight, bias, running_mean, running_var, eps):
     """Eval-mode BatchNorm as a per-channel affine (scale, shift) for the conv epilogue."""

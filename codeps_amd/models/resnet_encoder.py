@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
-from ._blocks import conv_bn, flush_bn_counters
+from ._blocks import conv_bn, flush_bn_counters, folded_bn
 
 _LAYERS = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]),
            101: ("bottleneck", [3, 4, 23, 3]), 152: ("bottleneck", [3, 8, 36, 3])}
@@ -51,6 +51,41 @@ class _Bottleneck(nn.Module):
         out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups)
         out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync, groups=groups)
         return conv_bn(out, self.conv3, self.bn3, "relu", residual=identity, sync=sync, groups=groups)
+
+
+def _frozen_eval(*mods):
+    """Eval-mode BatchNorm (foldable) and nothing that needs a gradient."""
+    if any(m.training for m in mods if isinstance(m, nn.modules.batchnorm._BatchNorm)):
+        return False
+    return not torch.is_grad_enabled() or not any(p.requires_grad for m in mods for p in m.parameters())
+
+
+def _run_layer(layer, x, sync, groups):
+    """One ResNet stage.  Frozen bottlenecks in eval mode whose mid width is 256 (ResNet-50 / 101 layer3: 22 of the 101's 33
+    bottlenecks) hand their last layer to the NEXT bottleneck's first one inside one launch (F.chain_expand_reduce: conv3 + bn3
+    + residual + ReLU, then conv1' + bn1' + ReLU, the 1024-channel tensor passing from one product to the other in
+    registers); every other block runs layer by layer."""
+    blocks = list(layer)
+    y0 = None                                                  # relu(bn1(conv1(x))) of the current block, when the previous launch made it
+    for i, blk in enumerate(blocks):
+        if not isinstance(blk, _Bottleneck):
+            x = blk.forward_nhwc(x, sync, groups)
+            continue
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        identity = x if blk.downsample is None else conv_bn(x, blk.downsample[0], blk.downsample[1], sync=sync, groups=groups)
+        if y0 is None:
+            y0 = conv_bn(x, blk.conv1, blk.bn1, "relu", sync=sync, groups=groups)
+        y1 = conv_bn(y0, blk.conv2, blk.bn2, "relu", sync=sync, groups=groups)
+        y0 = None
+        if (nxt is not None and nxt.downsample is None and nxt.conv1.out_channels == 256 and blk.conv3.in_channels == 256
+                and F.chain_ok(y1, blk.conv3.out_channels) and _frozen_eval(blk.bn3, blk.conv3, nxt.bn1, nxt.conv1)
+                and not (torch.is_grad_enabled() and (y1.requires_grad or identity.requires_grad))):
+            s2, t2 = folded_bn(blk.bn3)
+            s3, t3 = folded_bn(nxt.bn1)
+            x, y0 = F.chain_expand_reduce(y1, identity, blk.conv3.weight, s2, t2, nxt.conv1.weight, s3, t3)
+        else:
+            x = conv_bn(y1, blk.conv3, blk.bn3, "relu", residual=identity, sync=sync, groups=groups)
+    return x
 
 
 class _ResNet(nn.Module):
@@ -144,8 +179,7 @@ class ResnetEncoder(nn.Module):
         feats = [x]
         x = F.max_pool3x3s2(x)
         for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
-            for block in layer:
-                x = block.forward_nhwc(x, self.sync_bn, groups)
+            x = _run_layer(layer, x, self.sync_bn, groups)
             feats.append(x)
         flush_bn_counters()
         return [F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]

@@ -1,0 +1,130 @@
+"""The register-chained 1x1 pair of the frozen bottleneck stack (csrc/chain1x1.hip, F.chain_expand_reduce):
+    out = relu(bn3(conv3(y1)) + identity),  y0' = relu(bn1'(conv1'(out)))        (models/resnet_encoder.py:115-126)
+against float64, against the two layers run separately on the conv engine, launch-to-launch repeatability (the kernel counts
+its LDS-DMA / load / store completions by hand: a missed wait shows as a difference between launches), and through the
+ResNet trunk (chained vs layer-by-layer features)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+def _case(rows, n2, seed, kind="normal"):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "normal":
+        y1 = torch.relu(torch.randn(rows, 256, generator=g))
+        res = torch.relu(torch.randn(rows, n2, generator=g))
+        w2 = torch.randn(n2, 256, generator=g) * (2.0 / 256) ** 0.5
+        w3 = torch.randn(256, n2, generator=g) * (2.0 / n2) ** 0.5
+    else:                       # wide dynamic range
+        y1 = torch.randn(rows, 256, generator=g) * torch.exp2(torch.randint(-10, 11, (rows, 256), generator=g).float())
+        res = torch.randn(rows, n2, generator=g) * torch.exp2(torch.randint(-6, 7, (rows, n2), generator=g).float())
+        w2 = torch.randn(n2, 256, generator=g) * torch.exp2(torch.randint(-6, 7, (n2, 256), generator=g).float()) / 16
+        w3 = torch.randn(256, n2, generator=g) * torch.exp2(torch.randint(-6, 7, (256, n2), generator=g).float()) / 32
+    s2, t2 = 0.5 + torch.rand(n2, generator=g), 0.2 * torch.randn(n2, generator=g)
+    s3, t3 = 0.5 + torch.rand(256, generator=g), 0.2 * torch.randn(256, generator=g)
+    return y1, res, w2, w3, s2, t2, s3, t3
+
+
+def _ref(y1, res, w2, w3, s2, t2, s3, t3, dt):
+    y1, res, w2, w3, s2, t2, s3, t3 = (v.to(dt) for v in (y1, res, w2, w3, s2, t2, s3, t3))
+    out = torch.relu(y1 @ w2.t() * s2 + t2 + res)
+    return out, torch.relu(out @ w3.t() * s3 + t3)
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide"])
+@pytest.mark.parametrize("rows,n2", [(64, 64), (256, 1024), (16384, 1024), (4096, 512)])
+def test_chain_matches_float64_and_the_unfused_layers(rows, n2, kind):
+    from codeps_amd import functional as F
+    y1, res, w2, w3, s2, t2, s3, t3 = _case(rows, n2, 11 + rows % 97 + n2, kind)
+    o64, z64 = _ref(y1, res, w2, w3, s2, t2, s3, t3, torch.float64)
+    o32, z32 = _ref(y1, res, w2, w3, s2, t2, s3, t3, torch.float32)
+    d = lambda v: v.to(DEV)      # noqa: E731
+    h = 8 if rows % 8 == 0 else 1
+    y1d, resd = d(y1).view(1, h, rows // h, 256), d(res).view(1, h, rows // h, n2)
+    w2d, w3d = d(w2).view(n2, 256, 1, 1), d(w3).view(256, n2, 1, 1)
+    with torch.no_grad():
+        out, z = F.chain_expand_reduce(y1d, resd, w2d, d(s2), d(t2), w3d, d(s3), d(t3))
+        # the same two layers, one launch each, on the conv engine
+        uo = F.conv2d(y1d, w2d, scale=d(s2), shift=d(t2), residual=resd, act="relu")
+        uz = F.conv2d(uo, w3d, scale=d(s3), shift=d(t3), act="relu")
+    torch.cuda.synchronize()
+    out, z, uo, uz = out.view(rows, n2).cpu(), z.view(rows, 256).cpu(), uo.view(rows, n2).cpu(), uz.view(rows, 256).cpu()
+    e_o, e_z = _l2(out, o64), _l2(z, z64)
+    t_o, t_z = _l2(o32, o64), _l2(z32, z64)
+    u_o, u_z = _l2(uo, o64), _l2(uz, z64)
+    # within 3x torch's own fp32 error, or 1.5x the unfused engine's (same products, another summation order)
+    assert e_o <= max(3 * t_o, 1.5 * u_o) + 1e-9, f"expand: {e_o:.3e} vs torch fp32 {t_o:.3e}, unfused {u_o:.3e}"
+    assert e_z <= max(3 * t_z, 1.5 * u_z) + 1e-9, f"reduce: {e_z:.3e} vs torch fp32 {t_z:.3e}, unfused {u_z:.3e}"
+    # element-wise: no pixel / channel went to the wrong place (a permutation slip would be O(1) wrong somewhere)
+    scale = float(o64.abs().max())
+    assert float((out.double() - o64).abs().max()) <= 2e-5 * scale
+    assert float((z.double() - z64).abs().max()) <= 5e-5 * float(z64.abs().max())
+
+
+def test_chain_is_repeatable_launch_to_launch():
+    from codeps_amd import functional as F
+    y1, res, w2, w3, s2, t2, s3, t3 = _case(16384, 1024, 5)
+    d = lambda v: v.to(DEV)      # noqa: E731
+    y1d, resd = d(y1).view(8, 32, 64, 256), d(res).view(8, 32, 64, 1024)
+    w2d, w3d = d(w2).view(1024, 256, 1, 1), d(w3).view(256, 1024, 1, 1)
+    args = (y1d, resd, w2d, d(s2), d(t2), w3d, d(s3), d(t3))
+    with torch.no_grad():
+        o0, z0 = F.chain_expand_reduce(*args)
+        busy = torch.empty(64 << 20, device=DEV)
+        for i in range(200):
+            if i % 3 == 0:
+                busy.normal_()                       # unrelated traffic between launches: changes DMA / load timing
+            o, z = F.chain_expand_reduce(*args)
+            assert torch.equal(o, o0) and torch.equal(z, z0), f"launch {i} differs from launch 0"
+
+
+def test_chain_refuses_what_it_cannot_do():
+    from codeps_amd import functional as F
+    from codeps_amd._lib import CodepsHipError
+    y1 = torch.zeros(1, 4, 16, 256, device=DEV)
+    w2 = torch.zeros(1024, 256, 1, 1, device=DEV)
+    w3 = torch.zeros(256, 1024, 1, 1, device=DEV)
+    v = torch.zeros(1024, device=DEV)
+    v3 = torch.zeros(256, device=DEV)
+    with torch.no_grad():
+        F.chain_expand_reduce(y1, torch.zeros(1, 4, 16, 1024, device=DEV), w2, v, v, w3, v3, v3)
+        with pytest.raises(CodepsHipError):            # 60 pixels: not a multiple of 64
+            F.chain_expand_reduce(y1[:, :, :15].contiguous(), torch.zeros(1, 4, 15, 1024, device=DEV), w2, v, v, w3, v3, v3)
+    with pytest.raises(CodepsHipError):                # inference only
+        F.chain_expand_reduce(y1.requires_grad_(True), torch.zeros(1, 4, 16, 1024, device=DEV), w2, v, v, w3, v3, v3)
+
+
+@pytest.mark.parametrize("layers", [50, 101])
+def test_trunk_features_with_and_without_the_chain(layers):
+    """ResNet-50 / 101 in eval mode (the frozen encoder of the adaptation step): the features with layer3's 1x1 pairs chained
+    equal the layer-by-layer features to fp32 rounding (another summation order inside the 32-channel groups)."""
+    from codeps_amd import functional as F
+    from codeps_amd.models import ResnetEncoder
+    torch.manual_seed(3)
+    enc = ResnetEncoder(layers, False).to(DEV).eval()
+    for m in enc.modules():                          # non-trivial eval statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    x = torch.randn(2, 3, 128, 256, device=DEV)
+    prev = F._CHAIN
+    try:
+        with torch.no_grad():
+            F._CHAIN = True
+            a = [f.clone() for f in enc(x)]
+            F._CHAIN = False
+            b = [f.clone() for f in enc(x)]
+    finally:
+        F._CHAIN = prev
+    for i, (fa, fb) in enumerate(zip(a, b)):
+        assert fa.shape == fb.shape
+        assert _l2(fa, fb) < 5e-6, f"feature {i}: {_l2(fa, fb):.2e}"
+    assert not torch.equal(a[3], b[3]), "the chained path did not run (layer3 features are bit-identical)"
