@@ -78,7 +78,8 @@ SIGNATURES = {
     "codeps_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, I, I, I, P, c_size_t, P]),
     "codeps_chain1x1_w2_row_bytes": (c_size_t, []),
-    "codeps_chain1x1_expand_reduce": (c_int, [P, P, P, P, P, P, LL, I, P, P, P]),
+    "codeps_chain1x1_workspace_bytes": (c_size_t, [LL, I]),
+    "codeps_chain1x1_expand_reduce": (c_int, [P, P, P, P, P, P, LL, I, P, P, P, c_size_t, P]),
     "codeps_nchw_to_nhwc": (c_int, [P, I, I, I, I, P, I, I, I, P]),
     "codeps_nchw_to_nhwc_xpad": (c_int, [P, I, I, I, I, P, I, I, I, I, I, P]),
     "codeps_nhwc_to_nchw": (c_int, [P, I, I, I, I, I, P, P]),

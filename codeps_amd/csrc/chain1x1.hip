@@ -24,7 +24,14 @@
 //     row's folded BatchNorm (scale, shift): the affine of the expand reaches the epilogue through the same DMA.
 //   * every vector-memory operation of the main loop is issued through inline assembly and its completion is counted by hand
 //     (vmcnt: loads, stores and LDS DMA retire in issue order), so a tile has a full stage (two MFMA phases) to land.
-// One block = 64 pixels (M = 16384 at config 3: 256 blocks = one per CU), four waves x 16 pixels.
+// One block = 128 pixels x one K slice: eight waves x 16 pixels (two per SIMD), and the N2 / 32 stages are cut into `ksplit`
+// slices over blockIdx.y (M = 16384 at config 3: 128 pixel tiles x 2 slices = one block per CU).  The first version ran 64
+// pixels x all stages per CU: every CU then streams ALL 3 MB of weights for 64 pixels of work -- 52 KB per 1536 MFMA cycles
+// = the 66-73 GB/s a CU takes from L2 (MI355X_MICROARCH.md), measured 133 us, no faster than the separate layers.  With 128
+// pixels per tile a weight tile feeds twice the MFMAs (26 KB per 1536 cycles per SIMD pair) and the slices halve what a CU
+// streams; the price is the partial sums of the reduce (raw fp32 slabs + a fixed-order finish pass with the affine and ReLU).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -37,10 +44,14 @@ constexpr int KMID = 256;                 // channels of y1 (K of the expand) = 
 constexpr int ROWB = 208;                 // bytes per LDS row: [piece][32 bf16] + 16 pad
 constexpr int TILE_B = 256 * ROWB;        // one ring slot
 constexpr int W2ROW = KMID * 6 + 16;      // bytes per expand-weight row in HBM: 8 groups x [3 pieces][32 bf16] + (scale, shift, 0, 0)
-constexpr int NDMA = 13;                  // DMA instructions per wave and tile (4 waves x 13 x 64 lanes x 16 B = 256 x 208 B)
+constexpr int NWAVE = 8, BPIX = 16 * NWAVE;  // waves and pixels per block
+constexpr int NINS = 52;                  // 64-lane DMA instructions per tile (52 x 64 x 16 B = 256 x 208 B)
+constexpr int NDMA = 7;                   // per wave (8 x 7 = 56: the last four repeat instruction 51)
 
 struct ChainP {
-    long long M;                          // pixels (multiple of 64)
+    long long M;                          // pixels (multiple of 128)
+    int ksplit;                           // K slices of the reduce = slices of the expand's output channels (gridDim.y)
+    float* part;                          // [ksplit][M][256] raw partial sums of the reduce (ksplit > 1)
     int N2;                               // expand output channels (multiple of 32)
     const float* y1;                      // [M][256]
     const float* res;                     // [M][N2]
@@ -79,13 +90,14 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8 (&
 
 #define CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-__global__ __launch_bounds__(256) void chain_expand_reduce_kernel(ChainP p) {
+__global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long m0 = (long long)blockIdx.x * 64;
+    const long long m0 = (long long)blockIdx.x * BPIX;
     const long long m = m0 + wave * 16 + l16;                  // this lane's pixel
-    const int NS = p.N2 / 32;
+    const int NS = p.N2 / 32 / p.ksplit;                       // stages of this block (even), global stages [sbase, sbase + NS)
+    const int sbase = (int)blockIdx.y * NS;
 
     // ---- buffer resources (wave-uniform)
     auto rsrc_of = [](const void* base, size_t bytes) {
@@ -97,27 +109,27 @@ __global__ __launch_bounds__(256) void chain_expand_reduce_kernel(ChainP p) {
         r[3] = 0x00020000;
         return r;
     };
-    // the block's 64 rows of res / out: offsets inside the block's slab stay far below 4 GB whatever M is
+    // the block's 128 rows of res / out: offsets inside the block's slab stay far below 4 GB whatever M is
     const i32x4 rsW2 = rsrc_of(p.w2, (size_t)p.N2 * W2ROW);
     const i32x4 rsW3 = rsrc_of(p.w3, (size_t)KMID * p.N2 * 6);
-    const i32x4 rsRes = rsrc_of(p.res + (size_t)m0 * p.N2, (size_t)64 * p.N2 * 4);
-    const i32x4 rsOut = rsrc_of(p.out + (size_t)m0 * p.N2, (size_t)64 * p.N2 * 4);
+    const i32x4 rsRes = rsrc_of(p.res + (size_t)m0 * p.N2, (size_t)BPIX * p.N2 * 4);
+    const i32x4 rsOut = rsrc_of(p.out + (size_t)m0 * p.N2, (size_t)BPIX * p.N2 * 4);
     const unsigned row_off = (unsigned)((wave * 16 + l16) * p.N2 + 4 * kg) * 4u;      // byte offset of (pixel, channel 4 kg) in those slabs
 
-    // ---- DMA roles: instruction i of this wave covers linear 16-byte segments L = (wave + 4 i) * 64 + lane of the tile image;
+    // ---- DMA roles: instruction i of this wave covers linear 16-byte segments L = (wave + 8 i) * 64 + lane of the tile image;
     //      segment L -> (row L / 13, seg L % 13), seg 12 = the pad
     unsigned offE[NDMA], offR[NDMA], ldsdst[NDMA];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-        const int ins = wave + 4 * i, L = ins * 64 + lane, prow = L / 13, seg = L % 13;
+        const int ins = min(wave + NWAVE * i, NINS - 1), L = ins * 64 + lane, prow = L / 13, seg = L % 13;
         ldsdst[i] = (unsigned)ins * 1024u;
         const int ks = prow >> 5, r = prow & 31;               // E tile: pseudo-row = (k-step, expand row within the stage)
         offE[i] = (unsigned)(r * W2ROW + (seg < 12 ? ks * 192 + seg * 16 : KMID * 6));
         offR[i] = (unsigned)((size_t)prow * p.N2 * 6 + (seg < 12 ? seg : 0) * 16);
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    auto dma_tile = [&](int t) {                               // tile t: even = E_{t/2}, odd = R_{t/2}; slot t % 3
-        const int s = t >> 1;
+    auto dma_tile = [&](int t) {                               // local tile t: even = E, odd = R of local stage t / 2; slot t % 3
+        const int s = sbase + (t >> 1);
         const unsigned slot = lds_base + (unsigned)(t % 3) * TILE_B;
         if (t & 1) {
             const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 192);
@@ -137,13 +149,13 @@ __global__ __launch_bounds__(256) void chain_expand_reduce_kernel(ChainP p) {
             }
         }
     };
-    auto res_load = [&](int s, f32x4 (&r)[2]) {                // residual of stage s: channels 32 s + 16 nt + 4 kg .. + 3 of this lane's pixel
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 128);
+    auto res_load = [&](int sl, f32x4 (&r)[2]) {               // residual of local stage sl: channels 32 s + 16 nt + 4 kg .. + 3 of this lane's pixel
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((sbase + sl) * 128);
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[0]) : "v"(row_off), "s"(rsRes), "s"(soff) : "memory");
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(r[1]) : "v"(row_off), "s"(rsRes), "s"(soff) : "memory");
     };
-    auto out_store = [&](int s, const f32x4 (&v)[2]) {
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 128);
+    auto out_store = [&](int sl, const f32x4 (&v)[2]) {
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((sbase + sl) * 128);
         asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v[0]), "v"(row_off), "s"(rsOut), "s"(soff) : "memory");
         asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:64\n\ts_nop 1" :: "v"(v[1]), "v"(row_off), "s"(rsOut), "s"(soff) : "memory");
     };
@@ -181,13 +193,13 @@ __global__ __launch_bounds__(256) void chain_expand_reduce_kernel(ChainP p) {
         const bool last = s + 1 == NS;
         // ================= expand stage s: tile 2 s
         // vector-memory queue of this wave, oldest first, at this point (steady state):
-        //   R(s)x2 D(2s)x13 | S(s-1)x2  D(2s+1)x13     -> the residual of this stage and tile 2 s have landed once <= 15 younger
+        //   R(s)x2 D(2s)x7 | S(s-1)x2  D(2s+1)x7       -> the residual of this stage and tile 2 s have landed once <= 9 younger
         //                                                  operations are outstanding
-        if (s > 0) CHAIN_WAIT(15);
+        if (s > 0) CHAIN_WAIT(9);
         __syncthreads();                                       // every wave's part of tile 2 s is in LDS; reduce s - 1 has been read
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+v"(rcur[0]), "+v"(rcur[1]));       // claim: from here on the compiler may touch the residual registers
-        res_load(s + 1, rnext);                                // (stage NS: past the block's slab for its last pixel row -> the range check returns zeros; never used)
+        res_load(s + 1, rnext);                                // (one past the last stage: columns of the next slice or the next row, or past the slab -> zeros; never used)
         if (s > 0 && 2 * s + 2 < 2 * NS) dma_tile(2 * s + 2);  // into the slot of tile 2 s - 1
         const char* et = arow + ((2 * s) % 3) * TILE_B;
         f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -226,8 +238,8 @@ __global__ __launch_bounds__(256) void chain_expand_reduce_kernel(ChainP p) {
         bf16x8 of[3];                                          // B fragment of reduce k-step s: element j = channel 16 (j >> 2) + 4 kg + (j & 3)
         split8(v[0], v[1], of);
         // ================= reduce k-step s: tile 2 s + 1
-        //   D(2s+1)x13 | R(s+1)x2 D(2s+2)x13 S(s)x2   (last stage: no D(2s+2): wait for everything)
-        if (last) CHAIN_WAIT(0); else CHAIN_WAIT(17);
+        //   D(2s+1)x7 | R(s+1)x2 D(2s+2)x7 S(s)x2     (last stage: no D(2s+2): wait for everything)
+        if (last) CHAIN_WAIT(0); else CHAIN_WAIT(11);
         __syncthreads();                                       // tile 2 s + 1 is in LDS; every wave has read tile 2 s
         if (2 * s + 3 < 2 * NS) dma_tile(2 * s + 3);           // into the slot of tile 2 s
         const char* rt = arow + ((2 * s + 1) % 3) * TILE_B;
@@ -250,7 +262,14 @@ __global__ __launch_bounds__(256) void chain_expand_reduce_kernel(ChainP p) {
     }
     CHAIN_WAIT(0);
 
-    // ---- epilogue of the reduce: y0n[m][16 jt + 4 kg + r] = relu(acc * scale3 + shift3), 16-byte stores
+    // ---- epilogue of the reduce: y0n[m][16 jt + 4 kg + r] = relu(acc * scale3 + shift3), 16-byte stores; with K slices the raw
+    //      partial sums go to part[slice][m][256] and chain_finish_kernel adds them in slice order
+    if (p.ksplit > 1) {
+        float* po = p.part + ((size_t)blockIdx.y * p.M + m) * KMID + 4 * kg;
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) *reinterpret_cast<f32x4*>(po + jt * 16) = acc3[jt];
+        return;
+    }
     float* yo = p.y0n + (size_t)m * KMID + 4 * kg;
 #pragma unroll
     for (int jt = 0; jt < 16; ++jt) {
@@ -262,21 +281,62 @@ __global__ __launch_bounds__(256) void chain_expand_reduce_kernel(ChainP p) {
     }
 }
 
+// y0n = relu((sum_z part[z]) * scale3 + shift3), slices added in fixed order
+__global__ __launch_bounds__(256) void chain_finish_kernel(const float* __restrict__ part, int ksplit, long long MN, const float* __restrict__ scale3,
+                                                           const float* __restrict__ shift3, float* __restrict__ y0n) {
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (long long)gridDim.x * 1024) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
+        for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + (size_t)z * MN + i);
+        const int c = (int)(i % KMID);
+        v = v * *reinterpret_cast<const f32x4*>(scale3 + c) + *reinterpret_cast<const f32x4*>(shift3 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        *reinterpret_cast<f32x4*>(y0n + i) = v;
+    }
+}
+
+// K slices: as many as fill the 256 CUs with one block each, while every slice keeps an even number (>= 4) of stages
+static int chain_slices(long long rows, int n2) {
+    const long long tiles = rows / BPIX;
+    int ks = 1;
+    while (ks < 8 && tiles * ks * 2 <= 256 && (n2 / 32) % (ks * 4) == 0 && (n2 / 32) / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
+
 }  // namespace
 
 extern "C" size_t codeps_chain1x1_w2_row_bytes(void) { return W2ROW; }
 
+extern "C" size_t codeps_chain1x1_workspace_bytes(long long rows, int n2) {
+    if (rows <= 0 || rows % BPIX || n2 < 64 || n2 % 64) return 0;
+    const int ks = chain_slices(rows, n2);
+    return ks > 1 ? (size_t)ks * rows * KMID * sizeof(float) : 0;
+}
+
 extern "C" int codeps_chain1x1_expand_reduce(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
                                              const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
-                                             codeps_stream_t stream) {
+                                             void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     CODEPS_REQUIRE(y1 && residual && w2_rows && w3_split && scale3 && shift3 && out && y0_next, CODEPS_ERR_ARG, "chain1x1: null pointer argument");
-    CODEPS_REQUIRE(rows > 0 && rows % 64 == 0 && rows / 64 < (1ll << 31), CODEPS_ERR_ARG, "chain1x1: rows (%lld) must be a positive multiple of 64", rows);
+    CODEPS_REQUIRE(rows > 0 && rows % BPIX == 0 && rows / BPIX < (1ll << 31), CODEPS_ERR_ARG, "chain1x1: rows (%lld) must be a positive multiple of %d", rows, BPIX);
     CODEPS_REQUIRE(n2 >= 64 && n2 % 64 == 0 && n2 <= 4096, CODEPS_ERR_ARG, "chain1x1: expand channels (%d) must be a multiple of 64 in [64, 4096]", n2);
     ChainP p;
     p.M = rows; p.N2 = n2; p.y1 = y1; p.res = residual; p.w2 = w2_rows; p.w3 = w3_split; p.scale3 = scale3; p.shift3 = shift3;
     p.out = out; p.y0n = y0_next;
+    p.ksplit = chain_slices(rows, n2);
+    p.part = nullptr;
+    if (p.ksplit > 1) {
+        CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)p.ksplit * rows * KMID * sizeof(float), CODEPS_ERR_WORKSPACE,
+                       "chain1x1: workspace too small (codeps_chain1x1_workspace_bytes)");
+        p.part = static_cast<float*>(workspace);
+    }
+    hipStream_t st = (hipStream_t)stream;
     codeps_allow_lds((const void*)chain_expand_reduce_kernel, 160 * 1024, "chain_expand_reduce_kernel");
-    hipLaunchKernelGGL(chain_expand_reduce_kernel, dim3((unsigned)(rows / 64)), dim3(256), 3 * TILE_B, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(chain_expand_reduce_kernel, dim3((unsigned)(rows / BPIX), p.ksplit), dim3(64 * NWAVE), 3 * TILE_B, st, p);
+    if (p.ksplit > 1) {
+        const long long MN = rows * KMID;
+        hipLaunchKernelGGL(chain_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, (const float*)p.part, p.ksplit, MN,
+                           scale3, shift3, y0_next);
+    }
     CODEPS_CHECK_LAUNCH("chain_expand_reduce_kernel");
     return CODEPS_OK;
 }

@@ -688,8 +688,11 @@ def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3
     y0 = torch.empty(b, h, w_, 256, dtype=torch.float32, device=y1.device)
     flops = 2.0 * rows * (n2 * kmid + 256 * n2)
     t0 = _prof_begin()
+    wsb = lib().codeps_chain1x1_workspace_bytes(rows, n2)
+    ws = _workspace(wsb, y1.device, "chain1x1") if wsb else None
     check(lib().codeps_chain1x1_expand_reduce(ptr(y1), ptr(residual), ptr(w2), ptr(w3), ptr(_f32c(scale3)), ptr(_f32c(shift3)), rows, n2,
-                                              ptr(out), ptr(y0), stream_ptr()), "codeps_chain1x1_expand_reduce")
+                                              ptr(out), ptr(y0), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()),
+          "codeps_chain1x1_expand_reduce")
     if t0 is not None:
         e = torch.cuda.Event(enable_timing=True)
         e.record()
@@ -698,8 +701,8 @@ def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3
 
 
 def chain_ok(y1, n2):
-    """Shapes the chained kernel takes: 256 mid channels, N2 % 64 == 0, pixel count a multiple of 64."""
-    return _CHAIN and y1.shape[-1] == 256 and n2 % 64 == 0 and (y1.numel() // 256) % 64 == 0
+    """Shapes the chained kernel takes: 256 mid channels, N2 % 64 == 0, pixel count a multiple of 128."""
+    return _CHAIN and y1.shape[-1] == 256 and n2 % 64 == 0 and (y1.numel() // 256) % 128 == 0
 
 
 # ---------------------------------------------------------------------------------------- BatchNorm

@@ -134,14 +134,17 @@ int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, 
  * conv3 + bn3 + residual + ReLU of bottleneck i and conv1 + bn1 + ReLU of bottleneck i + 1, models/resnet_encoder.py:115-126):
  *     out[m][n2]  = relu(scale2 * (y1[m][:] . W2[n2][:]) + shift2 + residual[m][n2])     y1 [rows][256], out / residual [rows][n2]
  *     y0_next[m][c] = relu(scale3[c] * (out[m][:] . W3[c][:]) + shift3[c])               [rows][256]
- * `out` is handed from the first product to the second in registers (MFMA accumulator -> next MFMA operand).  rows % 64 == 0,
+ * `out` is handed from the first product to the second in registers (MFMA accumulator -> next MFMA operand).
  * n2 % 64 == 0.  w2_rows: n2 rows of codeps_chain1x1_w2_row_bytes() bytes = the pre-split pack row of W2 (256 x 6 bytes, the
  * layout behind codeps_conv2d_pack_weights' fp32 part) + (scale2, shift2, 0, 0) as four floats.  w3_split: the pre-split pack
  * of W3 [256][n2] whose k order inside every 32-channel group is p = 8 g + j -> channel 16 (j >> 2) + 4 g + (j & 3). */
 size_t codeps_chain1x1_w2_row_bytes(void);
+/* rows % 128 == 0.  Pixel tiles of 128 rows x K slices of the expand's channels fill the chip; with more than one slice the
+ * reduce's partial sums pass through `workspace` (codeps_chain1x1_workspace_bytes, 0 = not needed) and a fixed-order finish pass. */
+size_t codeps_chain1x1_workspace_bytes(long long rows, int n2);
 int codeps_chain1x1_expand_reduce(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
                                   const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
-                                  codeps_stream_t stream);
+                                  void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d);
 /* dw_oihw [out_c_real][in_c_real][kh][kw] (= or += when accumulate); split-K slabs + fixed-order reduce. */
 int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float* x1, const float* dz,

@@ -38,7 +38,7 @@ def _ref(y1, res, w2, w3, s2, t2, s3, t3, dt):
 
 
 @pytest.mark.parametrize("kind", ["normal", "wide"])
-@pytest.mark.parametrize("rows,n2", [(64, 64), (256, 1024), (16384, 1024), (4096, 512)])
+@pytest.mark.parametrize("rows,n2", [(128, 64), (256, 1024), (16384, 1024), (4096, 512), (8192, 1024), (1024, 256)])
 def test_chain_matches_float64_and_the_unfused_layers(rows, n2, kind):
     from codeps_amd import functional as F
     y1, res, w2, w3, s2, t2, s3, t3 = _case(rows, n2, 11 + rows % 97 + n2, kind)
@@ -87,17 +87,17 @@ def test_chain_is_repeatable_launch_to_launch():
 def test_chain_refuses_what_it_cannot_do():
     from codeps_amd import functional as F
     from codeps_amd._lib import CodepsHipError
-    y1 = torch.zeros(1, 4, 16, 256, device=DEV)
+    y1 = torch.zeros(1, 8, 16, 256, device=DEV)
     w2 = torch.zeros(1024, 256, 1, 1, device=DEV)
     w3 = torch.zeros(256, 1024, 1, 1, device=DEV)
     v = torch.zeros(1024, device=DEV)
     v3 = torch.zeros(256, device=DEV)
     with torch.no_grad():
-        F.chain_expand_reduce(y1, torch.zeros(1, 4, 16, 1024, device=DEV), w2, v, v, w3, v3, v3)
-        with pytest.raises(CodepsHipError):            # 60 pixels: not a multiple of 64
-            F.chain_expand_reduce(y1[:, :, :15].contiguous(), torch.zeros(1, 4, 15, 1024, device=DEV), w2, v, v, w3, v3, v3)
+        F.chain_expand_reduce(y1, torch.zeros(1, 8, 16, 1024, device=DEV), w2, v, v, w3, v3, v3)
+        with pytest.raises(CodepsHipError):            # 120 pixels: not a multiple of 128
+            F.chain_expand_reduce(y1[:, :, :15].contiguous(), torch.zeros(1, 8, 15, 1024, device=DEV), w2, v, v, w3, v3, v3)
     with pytest.raises(CodepsHipError):                # inference only
-        F.chain_expand_reduce(y1.requires_grad_(True), torch.zeros(1, 4, 16, 1024, device=DEV), w2, v, v, w3, v3, v3)
+        F.chain_expand_reduce(y1.requires_grad_(True), torch.zeros(1, 8, 16, 1024, device=DEV), w2, v, v, w3, v3, v3)
 
 
 @pytest.mark.parametrize("layers", [50, 101])

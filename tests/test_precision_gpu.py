@@ -54,12 +54,12 @@ class _arith:
         lib().codeps_conv2d_set_arith(self.prev)
 
 
-def _bound(err_torch, err_f32mfma, factor):
+def _bound(err_torch, err_f32mfma, factor, chain=1.5):
     """An fp32 convolution is allowed its summation order: the reference's (torch CPU: blocked / vectorised sums) and the matrix
     core's (one k-ordered fp32 chain per output, up to 2304 terms here) differ by up to ~4x in error against float64.  The split
     kernels must stay within `factor` x torch's own fp32 error, or -- on long chains -- within 1.5x of this library's f32-MFMA
     kernels, which multiply exactly and accumulate in the same order."""
-    return max(factor * err_torch, 1.5 * err_f32mfma) + 1e-9
+    return max(factor * err_torch, chain * err_f32mfma) + 1e-9
 
 
 def _inputs(kind, shape_x, shape_w, seed):
@@ -87,7 +87,7 @@ def _reference(x, w, gy, stride, pad, dtype):
 CASES = {
     # name: (B, H, W, Cin, Cout, k, expected forward kernel, expected dgrad kernel, expected wgrad kernel)
     "halo3_64": (4, 64, 128, 64, 64, 3, "conv_halo3_kernel", "conv_halo3_kernel", "wgrad_halo64s_kernel"),
-    "halo3_128": (2, 64, 128, 128, 128, 3, "conv_halo3_kernel", "conv_halo3_kernel", "wgrad_halo64s_kernel"),
+    "halo3_128": (2, 64, 128, 128, 128, 3, "conv_halo3r_kernel", "conv_halo3r_kernel", "wgrad_halo64s_kernel"),    # 128 blocks of 128 columns: the ring kernel on half the CUs
     "halo3r_256": (2, 64, 128, 128, 256, 3, "conv_halo3r_kernel", None, "wgrad_halo64s_kernel"),      # 128-column tiles: weights by LDS DMA
     "halo3r_dgrad": (2, 64, 128, 256, 256, 3, "conv_halo3r_kernel", "conv_halo3r_kernel", None),
     # grids below one block per CU: the ring kernel on >= 128 CUs without split, or with its channel chunks cut into K slices
@@ -128,10 +128,13 @@ def test_split_kernels_are_at_fp32_rounding_level(case, kind):
         assert "f32" in _last() or "16" in _last(), _last()
         fy.backward(nhwc(gy))
     m_fwd, m_dx, m_dw = l2(nchw(fy.detach(), co), y64), l2(nchw(fx.grad, ci), dx64), l2(fw.grad.cpu(), dw64)
+    # K-sliced variants: the f32-MFMA yardstick of these small-M shapes is itself cut into up to 16 K slices (shorter fp32 chains,
+    # smaller error) while the ring kernel uses 2-4 slices of 2304 terms -- same products, longer chains: 2x instead of 1.5x
+    ch = 2.0 if "splitk" in case else 1.5
     e_fwd, t_fwd = l2(nchw(y.detach(), co), y64), l2(y32, y64)
-    assert e_fwd <= _bound(t_fwd, m_fwd, 3), f"{case}/{kind} forward: {e_fwd:.3e} vs torch fp32 {t_fwd:.3e}, f32 MFMA {m_fwd:.3e}"
+    assert e_fwd <= _bound(t_fwd, m_fwd, 3, ch), f"{case}/{kind} forward: {e_fwd:.3e} vs torch fp32 {t_fwd:.3e}, f32 MFMA {m_fwd:.3e}"
     e_dx, t_dx = l2(nchw(dx.grad, ci), dx64), l2(dx32, dx64)
-    assert e_dx <= _bound(t_dx, m_dx, 3), f"{case}/{kind} data gradient: {e_dx:.3e} vs torch fp32 {t_dx:.3e}, f32 MFMA {m_dx:.3e}"
+    assert e_dx <= _bound(t_dx, m_dx, 3, ch), f"{case}/{kind} data gradient: {e_dx:.3e} vs torch fp32 {t_dx:.3e}, f32 MFMA {m_dx:.3e}"
     # weight gradient
     ww = wd.clone().requires_grad_(True)
     y2 = F.conv2d(nhwc(x), ww, pad=k // 2)
