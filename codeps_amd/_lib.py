@@ -154,6 +154,7 @@ SIGNATURES = {
     "codeps_color_jitter_u8": (c_int, [P, I, I, I, P, P, P, P, P, P, P]),
     "codeps_match_histograms_workspace_bytes": (c_size_t, [I]),
     "codeps_match_histograms_u8": (c_int, [P, P, I, I, I, I, I, P, P, c_size_t, P]),
+    "codeps_rgb_hsv_u8": (c_int, [P, LL, I, P, P]),
     "codeps_u8_to_tensor": (c_int, [P, I, I, I, P, P, ctypes.c_uint, P, P]),
     "codeps_cityscapes_labels_workspace_bytes": (c_size_t, []),
     "codeps_cityscapes_labels": (c_int, [P, P, I, I, I, I, P, ctypes.c_ulonglong, c_float, I, P, P, P, P, P, P, P, c_size_t, P]),

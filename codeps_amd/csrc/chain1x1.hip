@@ -45,8 +45,7 @@ constexpr int ROWB = 208;                 // bytes per LDS row: [piece][32 bf16]
 constexpr int TILE_B = 256 * ROWB;        // one ring slot
 constexpr int W2ROW = KMID * 6 + 16;      // bytes per expand-weight row in HBM: 8 groups x [3 pieces][32 bf16] + (scale, shift, 0, 0)
 constexpr int NWAVE = 8, BPIX = 16 * NWAVE;  // waves and pixels per block
-constexpr int NINS = 52;                  // 64-lane DMA instructions per tile (52 x 64 x 16 B = 256 x 208 B)
-constexpr int NDMA = 7;                   // per wave (8 x 7 = 56: the last four repeat instruction 51)
+constexpr int NDMA = 13;                  // DMA instructions per LOADER wave and tile (4 waves x 13 x 64 lanes x 16 B = 256 x 208 B)
 
 struct ChainP {
     long long M;                          // pixels (multiple of 128)
@@ -116,19 +115,25 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
     const i32x4 rsOut = rsrc_of(p.out + (size_t)m0 * p.N2, (size_t)BPIX * p.N2 * 4);
     const unsigned row_off = (unsigned)((wave * 16 + l16) * p.N2 + 4 * kg) * 4u;      // byte offset of (pixel, channel 4 kg) in those slabs
 
-    // ---- DMA roles: instruction i of this wave covers linear 16-byte segments L = (wave + 8 i) * 64 + lane of the tile image;
-    //      segment L -> (row L / 13, seg L % 13), seg 12 = the pad
+    // ---- DMA roles.  Only waves 4-7 (the second wave of every SIMD) issue the weight tiles: issuing an LDS-DMA instruction costs
+    //      its wave 60-185 cycles (MI355X_MICROARCH.md), and with all eight waves issuing right behind the barrier the matrix
+    //      pipes idled for that long twice per stage.  Now a SIMD's first wave starts its MFMAs at once while its partner
+    //      issues; the partner's MFMAs (and its epilogue VALU work) then run beside the first wave's next phase -- the two
+    //      waves of a SIMD stay half a phase apart.  Instruction i of loader wave w covers linear 16-byte segments
+    //      L = (w - 4 + 4 i) * 64 + lane of the tile image; segment L -> (row L / 13, seg L % 13), seg 12 = the pad
     unsigned offE[NDMA], offR[NDMA], ldsdst[NDMA];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-        const int ins = min(wave + NWAVE * i, NINS - 1), L = ins * 64 + lane, prow = L / 13, seg = L % 13;
+        const int ins = (wave & 3) + 4 * i, L = ins * 64 + lane, prow = L / 13, seg = L % 13;
         ldsdst[i] = (unsigned)ins * 1024u;
         const int ks = prow >> 5, r = prow & 31;               // E tile: pseudo-row = (k-step, expand row within the stage)
         offE[i] = (unsigned)(r * W2ROW + (seg < 12 ? ks * 192 + seg * 16 : KMID * 6));
         offR[i] = (unsigned)((size_t)prow * p.N2 * 6 + (seg < 12 ? seg : 0) * 16);
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const bool loader = wave >= 4;                             // wave-uniform (wave is an SGPR)
     auto dma_tile = [&](int t) {                               // local tile t: even = E, odd = R of local stage t / 2; slot t % 3
+        if (!loader) return;
         const int s = sbase + (t >> 1);
         const unsigned slot = lds_base + (unsigned)(t % 3) * TILE_B;
         if (t & 1) {
@@ -193,9 +198,9 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
         const bool last = s + 1 == NS;
         // ================= expand stage s: tile 2 s
         // vector-memory queue of this wave, oldest first, at this point (steady state):
-        //   R(s)x2 D(2s)x7 | S(s-1)x2  D(2s+1)x7       -> the residual of this stage and tile 2 s have landed once <= 9 younger
-        //                                                  operations are outstanding
-        if (s > 0) CHAIN_WAIT(9);
+        //   loader waves:  R(s)x2 D(2s)x13 | S(s-1)x2  D(2s+1)x13   -> residual of this stage + tile 2 s landed at <= 15 younger
+        //   the others:    R(s)x2          | S(s-1)x2                                                             at <= 2
+        if (s > 0) { if (loader) CHAIN_WAIT(15); else CHAIN_WAIT(2); }
         __syncthreads();                                       // every wave's part of tile 2 s is in LDS; reduce s - 1 has been read
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+v"(rcur[0]), "+v"(rcur[1]));       // claim: from here on the compiler may touch the residual registers
@@ -238,8 +243,8 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
         bf16x8 of[3];                                          // B fragment of reduce k-step s: element j = channel 16 (j >> 2) + 4 kg + (j & 3)
         split8(v[0], v[1], of);
         // ================= reduce k-step s: tile 2 s + 1
-        //   D(2s+1)x7 | R(s+1)x2 D(2s+2)x7 S(s)x2     (last stage: no D(2s+2): wait for everything)
-        if (last) CHAIN_WAIT(0); else CHAIN_WAIT(11);
+        //   loader waves: D(2s+1)x13 | R(s+1)x2 D(2s+2)x13 S(s)x2   (last stage: no D(2s+2): wait for everything)
+        if (loader) { if (last) CHAIN_WAIT(0); else CHAIN_WAIT(17); }
         __syncthreads();                                       // tile 2 s + 1 is in LDS; every wave has read tile 2 s
         if (2 * s + 3 < 2 * NS) dma_tile(2 * s + 3);           // into the slot of tile 2 s
         const char* rt = arow + ((2 * s + 1) % 3) * TILE_B;

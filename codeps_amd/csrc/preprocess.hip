@@ -456,6 +456,24 @@ extern "C" int codeps_match_histograms_u8(const uint8_t* img, const uint8_t* ref
     return CODEPS_OK;
 }
 
+// Pillow's Image.convert("HSV") / convert("RGB") on packed uint8 pixels (Convert.c rgb2hsv_row / hsv2rgb_row: the functions the
+// hue jitter uses), for transfer_histogram_style's "hsv" / "saturation" modes (datasets/preprocessing.py:64-71)
+__global__ __launch_bounds__(256) void hsv_convert_kernel(const uint8_t* __restrict__ src, long long n, int to_hsv, uint8_t* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int a = src[i * 3], b = src[i * 3 + 1], c = src[i * 3 + 2];
+        int x, y, z;
+        if (to_hsv) rgb2hsv(a, b, c, x, y, z); else hsv2rgb(a, b, c, x, y, z);
+        dst[i * 3] = (uint8_t)x; dst[i * 3 + 1] = (uint8_t)y; dst[i * 3 + 2] = (uint8_t)z;
+    }
+}
+
+extern "C" int codeps_rgb_hsv_u8(const uint8_t* src, long long pixels, int to_hsv, uint8_t* dst, codeps_stream_t stream) {
+    CODEPS_REQUIRE(src && dst && pixels > 0, CODEPS_ERR_ARG, "rgb_hsv_u8: bad arguments");
+    hipLaunchKernelGGL(hsv_convert_kernel, dim3(grid1(pixels)), dim3(256), 0, (hipStream_t)stream, src, pixels, to_hsv ? 1 : 0, dst);
+    CODEPS_CHECK_LAUNCH("hsv_convert_kernel");
+    return CODEPS_OK;
+}
+
 extern "C" size_t codeps_match_histograms_workspace_bytes(int batch) { return batch > 0 ? (size_t)batch * 768 * 9 : 0; }
 
 extern "C" int codeps_u8_to_tensor(const uint8_t* img, int batch, int h, int w, const float* mean, const float* std_, unsigned flip_mask,

@@ -183,25 +183,43 @@ def prepare_for_network(output: Dict[str, Any], cfg) -> None:
         output["rgb"][o] = t
 
 
-def transfer_histogram_style(img: torch.Tensor, reference_img: torch.Tensor, mode: Optional[str]) -> torch.Tensor:
-    """datasets/preprocessing.py:60-75.  mode "rgb": skimage match_histograms per channel, on the device; None: identity.
-    ("hsv" / "saturation" have no caller in the reference: datasets/replay_buffer.py:159,290 pass "rgb".)"""
-    if mode is None:
-        return img
-    if mode != "rgb":
-        if mode in ("hsv", "saturation"):
-            raise NotImplementedError(f"histogram transfer mode {mode!r} has no caller in the reference and is not built")
-        raise ValueError(f"Unknown histogram transfer mode: {mode}")
-    x, single = _batched(img.contiguous())
-    r, _ = _batched(reference_img.contiguous())
+def _convert_hsv(x: torch.Tensor, to_hsv: bool) -> torch.Tensor:
+    out = torch.empty_like(x)
+    check(lib().codeps_rgb_hsv_u8(ptr(x), x.numel() // 3, 1 if to_hsv else 0, ptr(out), stream_ptr()), "codeps_rgb_hsv_u8")
+    return out
+
+
+def _match(x: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
     b, h, w, _ = x.shape
-    if r.shape[0] != b:
-        raise _lib.CodepsHipError("transfer_histogram_style: one reference image per image")
     out = torch.empty_like(x)
     nbytes = lib().codeps_match_histograms_workspace_bytes(b)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     check(lib().codeps_match_histograms_u8(ptr(x), ptr(r), b, h, w, r.shape[1], r.shape[2], ptr(out), ptr(ws), nbytes, stream_ptr()),
           "codeps_match_histograms_u8")
+    return out
+
+
+def transfer_histogram_style(img: torch.Tensor, reference_img: torch.Tensor, mode: Optional[str]) -> torch.Tensor:
+    """datasets/preprocessing.py:60-75 on uint8 [B,H,W,3] / [H,W,3] device images.  "rgb": skimage match_histograms per channel;
+    "hsv": the same in Pillow's HSV space (Image.convert("HSV") -> match -> convert("RGB")); "saturation": only the S channel is
+    taken from the matched image; None: identity.  (The reference's callers pass "rgb": datasets/replay_buffer.py:159,290.)"""
+    if mode is None:
+        return img
+    if mode not in ("rgb", "hsv", "saturation"):
+        raise ValueError(f"Unknown histogram transfer mode: {mode}")
+    x, single = _batched(img.contiguous())
+    r, _ = _batched(reference_img.contiguous())
+    if r.shape[0] != x.shape[0]:
+        raise _lib.CodepsHipError("transfer_histogram_style: one reference image per image")
+    if mode == "rgb":
+        out = _match(x, r)
+    else:
+        x_hsv, r_hsv = _convert_hsv(x, True), _convert_hsv(r, True)
+        new = _match(x_hsv, r_hsv)
+        if mode == "saturation":
+            new[..., 0] = x_hsv[..., 0]
+            new[..., 2] = x_hsv[..., 2]
+        out = _convert_hsv(new.contiguous(), False)
     return out[0] if single else out
 
 

@@ -408,12 +408,13 @@ def _prof_begin():
     return e
 
 
-def _prof_end(start, kind, flops, desc=None, source=0):
+def _prof_end(start, kind, flops, desc=None, source=0, tag=None, kernel=None):
+    """kernel: name of the kernel for launches that do not go through the conv engine's dispatcher (tools/conv_layers.py asks the
+    library for the others)."""
     if start is None:
         return
     e = torch.cuda.Event(enable_timing=True)
     e.record()
-    tag = None
     if desc is not None:
         tag = (f"B{desc.batch} {desc.in_h}x{desc.in_w} {desc.c0}+{desc.c1}->{desc.out_c} k{desc.kh} s{desc.stride}"
                f"{' up' if desc.up0 else ''}")
@@ -693,10 +694,7 @@ def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3
     check(lib().codeps_chain1x1_expand_reduce(ptr(y1), ptr(residual), ptr(w2), ptr(w3), ptr(_f32c(scale3)), ptr(_f32c(shift3)), rows, n2,
                                               ptr(out), ptr(y0), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()),
           "codeps_chain1x1_expand_reduce")
-    if t0 is not None:
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        _profile["events"].append(("conv_fwd_split", flops, t0, e, f"B{b} {h}x{w_} chain 256->{n2}->256 k1"))
+    _prof_end(t0, "conv_fwd_split", flops, tag=f"B{b} {h}x{w_} 256->{n2}->256 k1 chain", kernel="chain_expand_reduce_kernel")
     return out, y0
 
 

@@ -366,6 +366,10 @@ int codeps_ssim_bwd(const float* x, const float* y, const float* grad_out, int p
  *   label_map256 = HOST table labelId -> train id (255 = ignore), thing ids as a bit mask, small-instance weights by area).
  * codeps_disparity_to_depth: Cityscapes 16-bit disparity -> depth [out_h][out_w] (baseline_times_fx = baseline * fx). */
 int codeps_lanczos_coeffs(int in_size, int out_size, int* bounds, int* coeffs);
+/* Pillow's Image.convert("HSV") (to_hsv != 0) / convert("RGB") of HSV pixels (to_hsv == 0) on packed uint8 [pixels][3]
+ * (Convert.c rgb2hsv_row / hsv2rgb_row, operation by operation): the "hsv" / "saturation" modes of transfer_histogram_style
+ * (datasets/preprocessing.py:64-71) are convert -> codeps_match_histograms_u8 -> convert back. */
+int codeps_rgb_hsv_u8(const uint8_t* src, long long pixels, int to_hsv, uint8_t* dst, codeps_stream_t stream);
 int codeps_resample_u8(const uint8_t* src, int batch, int h, int w, int axis, int out_size, const int* bounds,
                        const int* coeffs, int ksize, uint8_t* dst, codeps_stream_t stream);
 int codeps_color_jitter_u8(const uint8_t* src, int batch, int h, int w, const int* n_ops, const int* ops,

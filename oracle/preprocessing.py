@@ -219,6 +219,23 @@ def match_histograms_u8(image, reference):
     return out
 
 
+def transfer_histogram_style(img, reference, mode):
+    """datasets/preprocessing.py:60-75 on uint8 HWC arrays: "rgb" / "hsv" / "saturation" / None (Pillow's HSV space through
+    rgb_to_hsv / hsv_to_rgb above, which are pinned against Pillow itself)."""
+    if mode is None:
+        return img
+    if mode == "rgb":
+        return match_histograms_u8(img, reference)
+    if mode not in ("hsv", "saturation"):
+        raise ValueError(f"Unknown histogram transfer mode: {mode}")
+    img_hsv, ref_hsv = rgb_to_hsv(img), rgb_to_hsv(reference)
+    new = match_histograms_u8(img_hsv, ref_hsv)
+    if mode == "saturation":
+        new[:, :, 0] = img_hsv[:, :, 0]
+        new[:, :, 2] = img_hsv[:, :, 2]
+    return hsv_to_rgb(new)
+
+
 # ----------------------------------------------------------------------------------------------- label path
 def nearest_resize(a, out_h, out_w):
     """cv2.resize(..., interpolation=cv2.INTER_NEAREST) for a 2-D array: src = min(floor(dst * src / dst_size), src - 1)."""

@@ -67,6 +67,21 @@ def test_committed_fixtures():
     assert np.array_equal(op.to_tensor_normalize(z["jittered"], meta["mean"], meta["std"]), z["tensor"])
 
 
+def test_oracle_hsv_histogram_modes_against_pillow():
+    """oracle.transfer_histogram_style("hsv" / "saturation") with Pillow doing the colour-space conversions of the expected image."""
+    from PIL import Image
+    a, r = _img(48, 64, 13), (_img(40, 56, 14) * 0.7 + 40).astype(np.uint8)
+    a_hsv, r_hsv = np.array(Image.fromarray(a, "RGB").convert("HSV")), np.array(Image.fromarray(r, "RGB").convert("HSV"))
+    assert np.array_equal(op.rgb_to_hsv(a), a_hsv)
+    for mode in ("hsv", "saturation"):
+        new = op.match_histograms_u8(a_hsv, r_hsv)
+        if mode == "saturation":
+            new[:, :, 0], new[:, :, 2] = a_hsv[:, :, 0], a_hsv[:, :, 2]
+        want = np.array(Image.fromarray(new, "HSV").convert("RGB"))
+        assert np.array_equal(op.transfer_histogram_style(a, r, mode), want), mode
+    assert np.array_equal(op.transfer_histogram_style(a, r, "rgb"), op.match_histograms_u8(a, r)) and op.transfer_histogram_style(a, r, None) is a
+
+
 def test_histogram_matching_and_label_path_properties():
     a, r = _img(48, 64, 3), (_img(40, 56, 4) * 0.6 + 60).astype(np.uint8)
     m = op.match_histograms_u8(a, r)

@@ -126,6 +126,25 @@ def test_histogram_matching_against_oracle():
         P.transfer_histogram_style(_dev(a), _dev(r), "lab")
 
 
+@pytest.mark.parametrize("mode", ["hsv", "saturation"])
+def test_histogram_matching_in_hsv_space_against_pillow(mode):
+    """datasets/preprocessing.py:64-71: Image.convert("HSV") -> match_histograms -> (saturation: keep H and V) -> convert("RGB"),
+    with Pillow ITSELF doing both conversions of the expected image (the matching in between is the oracle's)."""
+    from PIL import Image
+    from codeps_amd.datasets import preprocessing as P
+    a, r = _img(96, 128, 13), (_img(80, 112, 14) * 0.7 + 40).astype(np.uint8)
+    a_hsv, r_hsv = np.array(Image.fromarray(a, "RGB").convert("HSV")), np.array(Image.fromarray(r, "RGB").convert("HSV"))
+    new = op.match_histograms_u8(a_hsv, r_hsv)
+    if mode == "saturation":
+        new[:, :, 0], new[:, :, 2] = a_hsv[:, :, 0], a_hsv[:, :, 2]
+    want = np.array(Image.fromarray(new, "HSV").convert("RGB"))
+    got = P.transfer_histogram_style(_dev(a), _dev(r), mode).cpu().numpy()
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} bytes differ from Pillow"
+    assert np.array_equal(op.transfer_histogram_style(a, r, mode), want)          # and the oracle's restatement of the same path
+    batch = P.transfer_histogram_style(_dev(np.stack([a, a])), _dev(np.stack([r, r])), mode).cpu().numpy()
+    assert np.array_equal(batch[0], want) and np.array_equal(batch[1], want)
+
+
 def test_cityscapes_label_path_against_oracle():
     from codeps_amd.datasets import preprocessing as P
     rng = np.random.default_rng(5)

@@ -43,12 +43,12 @@ def main():
     names = []
     orig_end = F._prof_end
 
-    def end(start, kind, flops, desc=None, source=0):
+    def end(start, kind, flops, desc=None, source=0, tag=None, kernel=None):
         n0 = len(F._profile["events"])
-        orig_end(start, kind, flops, desc, source)
+        orig_end(start, kind, flops, desc, source, tag, kernel)
         if len(F._profile["events"]) > n0:
             k = lib.codeps_conv2d_last_kernel()
-            names.append(k.decode() if k else "?")
+            names.append(kernel or (k.decode() if k else "?"))
     F._prof_end = end
     F._profile["events"].clear()
     F._profile["on"] = True
