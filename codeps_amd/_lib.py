@@ -33,7 +33,7 @@ class PhotometricDesc(Structure):
 
 class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("batch", "in_h", "in_w", "c0", "c1", "up0", "out_c", "out_h", "out_w", "kh", "kw",
-                                       "stride", "pad", "pad_mode", "act", "stride_w", "pad_w")]
+                                       "stride", "pad", "pad_mode", "act", "stride_w", "pad_w", "pix_pitch", "row_pitch")]
 
 
 def build(jobs=8, verbose=False):

@@ -46,6 +46,7 @@ struct ConvP {
     int Co, Ho, Wo;
     int KH, KW, stride, pad, pad_mode;   // stride / pad: vertical;  stride_w / pad_w: horizontal
     int stride_w, pad_w;
+    int pitch0, wrow0;    // forward, source 0 as overlapping pixels: floats between pixel starts / pixels per stored row (0 = dense)
     int act;
     int M, N;             // GEMM rows / cols of this launch
     int n_mt, n_nt;       // tile counts
@@ -156,6 +157,7 @@ __device__ __forceinline__ void build_gather(const ConvP& p, int m0, int ntap, u
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
                     v1 = (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(p.C1 * 4);
                     v0 = p.up0 ? (unsigned)((bb * H0 + (iy >> 1)) * W0 + (ix >> 1)) * (unsigned)(cs0 * 4)      // fused nearest x2 of source 0
+                       : p.pitch0 ? (unsigned)((bb * p.H + iy) * p.wrow0 + ix) * (unsigned)(p.pitch0 * 4)      // overlapping pixels
                                : (unsigned)((bb * p.H + iy) * p.W + ix) * (unsigned)(cs0 * 4);
                 }
             } else {
@@ -180,7 +182,7 @@ __device__ __forceinline__ void build_gather(const ConvP& p, int m0, int ntap, u
     }
     __syncthreads();
     const int Btot = p.M > 0 ? (p.M + HWm - 1) / HWm : 1;        // images addressed by the rows of this launch (= batch)
-    const size_t img0 = (size_t)H0 * W0 * cs0, img1 = (size_t)p.H * p.W * p.C1;
+    const size_t img0 = (MODE == MODE_FWD && p.pitch0) ? (size_t)p.H * p.wrow0 * p.pitch0 : (size_t)H0 * W0 * cs0, img1 = (size_t)p.H * p.W * p.C1;
     rs0 = make_rsrc(a0 + (size_t)b_first * img0, (size_t)(Btot - b_first) * img0 * 4);
     rs1 = two_src ? make_rsrc(a1 + (size_t)b_first * img1, (size_t)(Btot - b_first) * img1 * 4) : rs0;
 }
@@ -2413,6 +2415,13 @@ static int check_conv(const codeps_conv_desc* d, const char* who) {
     CODEPS_REQUIRE(ho == d->out_h && wo == d->out_w, CODEPS_ERR_ARG, "%s: output size %dx%d != expected %dx%d", who, d->out_h,
                    d->out_w, ho, wo);
     CODEPS_REQUIRE(d->pad_mode == 0 || (d->pad < d->in_h && d->pad < d->in_w), CODEPS_ERR_ARG, "%s: reflect pad too large", who);
+    if (d->pix_pitch != 0) {
+        CODEPS_REQUIRE(d->pix_pitch > 0 && d->pix_pitch % 4 == 0 && d->c0 >= d->pix_pitch && d->c1 == 0 && !d->up0 && d->kw == 1 && d->pad_w == 0 &&
+                           d->stride_w == 1 && d->pad_mode == 0 && d->out_c > 16 &&
+                           (long long)d->row_pitch * d->pix_pitch >= (long long)(d->in_w - 1) * d->pix_pitch + d->c0,
+                       CODEPS_ERR_ARG, "%s: overlapping-pixel form needs pix_pitch %% 4 == 0, c0 >= pix_pitch, one source, kw 1, no horizontal "
+                       "padding / stride, out_c > 16 and rows of >= (in_w - 1) * pix_pitch + c0 floats", who);
+    }
     return CODEPS_OK;
 }
 
@@ -2426,6 +2435,7 @@ static ConvP make_convp(const codeps_conv_desc* d) {
     p.Co = d->out_c; p.Ho = d->out_h; p.Wo = d->out_w; p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = d->pad;
     p.stride_w = d->stride_w; p.pad_w = d->pad_w;
     p.pad_mode = d->pad_mode; p.act = d->act;
+    p.pitch0 = d->pix_pitch; p.wrow0 = d->pix_pitch ? d->row_pitch : 0;
     return p;
 }
 
@@ -2805,6 +2815,7 @@ extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const 
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(dz && w_dgrad && dx && (source == 0 || (source == 1 && d->c1 > 0)), CODEPS_ERR_ARG, "conv2d_dgrad: bad arguments");
     CODEPS_REQUIRE(d->pad_mode == 0, CODEPS_ERR_ARG, "conv2d_dgrad: reflect padding has no dgrad path here");
+    CODEPS_REQUIRE(d->pix_pitch == 0, CODEPS_ERR_ARG, "conv2d_dgrad: the overlapping-pixel form is forward only");
     CODEPS_REQUIRE(d->stride_w == d->stride && d->pad_w == d->pad, CODEPS_ERR_ARG, "conv2d_dgrad: per-dimension stride / padding has no dgrad path");
     CODEPS_REQUIRE((d->out_c % 16) == 0, CODEPS_ERR_ARG, "conv2d_dgrad: out_c %d must be a multiple of 16", d->out_c);
     ConvP p = make_convp(d);
@@ -2890,6 +2901,7 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     CODEPS_REQUIRE(out_c_real > 0 && out_c_real <= d->out_c && in_c_real > 0 && in_c_real <= d->c0 + d->c1, CODEPS_ERR_ARG,
                    "conv2d_wgrad: real channel counts exceed the padded ones");
     CODEPS_REQUIRE((d->out_c % 4) == 0, CODEPS_ERR_ARG, "conv2d_wgrad: out_c %d must be a multiple of 4", d->out_c);
+    CODEPS_REQUIRE(d->pix_pitch == 0, CODEPS_ERR_ARG, "conv2d_wgrad: the overlapping-pixel form is forward only");
     int bm, bn, n_mt, n_nt, splits, pps;
     wgrad_plan(d, bm, bn, n_mt, n_nt, splits, pps);
     const SmallPlan sp = wgrad_small_plan(d);

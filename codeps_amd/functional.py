@@ -629,6 +629,60 @@ def stem_conv2d(x, weight, *, scale=None, shift=None, act=None):
                   macs_per_out=weight.shape[1] * 49)
 
 
+# ---------------------------------------------------------------------------------------- frozen 3-channel stem
+_STEM3 = os.environ.get("CODEPS_STEM3", "1") != "0"      # A/B switch: 0 = the double-pixel form for the frozen 3-channel stem too
+STEM3_XPAD = (3, 3)     # zero columns left / right of every row of 4-channel pixels in the frozen-stem layout (stem3_conv2d)
+_stem3_cache = {}
+
+
+def stem3_weight(weight):
+    """Frozen ResNet conv1 weight [co, 3, 7, 7] -> [co, 32, 7, 1]: W'[o][4 j + c][ky] = W[o][c][ky][j] (j < 7, c < 3, else 0) -- the
+    K layout of stem3_conv2d.  Cached per (tensor, version)."""
+    key = id(weight)
+    hit = _stem3_cache.get(key)
+    stamp = (weight.data_ptr(), weight._version)
+    if hit is not None and hit[0]() is weight and hit[1] == stamp:
+        return hit[2]
+    co, ci, kh, kw = weight.shape
+    if (ci, kh, kw) != (3, 7, 7):
+        raise _lib.CodepsHipError("stem3_weight: expects a [co, 3, 7, 7] weight")
+    with torch.no_grad():
+        w = _f32c(weight.detach())
+        out = torch.zeros(co, 8, 4, 7, dtype=torch.float32, device=w.device)          # [o][j][c][ky]
+        out[:, :7, :3, :] = w.permute(0, 3, 1, 2)                                        # W[o][c][ky][j] -> [o][j][c][ky]
+        out = out.reshape(co, 32, 7, 1).contiguous()
+    _stem3_cache[key] = (_weak(weight, _stem3_cache, key), stamp, out)
+    return out
+
+
+def stem3_conv2d(x4, weight, *, scale=None, shift=None, act=None):
+    """FROZEN ResNet conv1 on 3-channel images (7x7, stride 2, padding 3; models/resnet_encoder.py:115), inference only.
+    x4 [B, H, W + 6, 4]: the images as rows of 4-channel pixels with STEM3_XPAD zero columns (images_to_nhwc(..., 4, STEM3_XPAD)).
+    Output pixel x reads the 8 stored pixels 2 x .. 2 x + 7 of 7 rows = 32 contiguous floats per row: conv1 is a 7 x 1 convolution
+    over OVERLAPPING 32-float "pixels" that start every 8 floats (codeps_conv_desc.pix_pitch) -- K = 224 in 7 steps of 32
+    instead of the double-pixel form's K = 448 in 28 steps of 16 (stem_conv2d, which the 6-channel pose stem keeps)."""
+    require_cuda(x4, weight)
+    b, h, wp, c = x4.shape
+    w = wp - 6
+    if c != 4 or w % 2 or h % 2:
+        raise _lib.CodepsHipError("stem3_conv2d: expects [B, H, W + 6, 4] with even H and W")
+    if torch.is_grad_enabled() and (weight.requires_grad or x4.requires_grad):
+        raise _lib.CodepsHipError("stem3_conv2d is the frozen-encoder form (no gradients); use stem_conv2d")
+    w32 = stem3_weight(weight)
+    co = weight.shape[0]
+    cop = pad16(co)
+    wf, _ = pack_weights(w32, cop, 32, False)
+    desc = _lib.ConvDesc(b, h, w // 2, 32, 0, 0, cop, h // 2, w // 2, 7, 1, 2, 3, 0, ACT[act], 1, 0, 8, wp // 2)
+    sc, sh = _pad_vec(scale, cop), _pad_vec(shift, cop)
+    y = torch.empty(b, h // 2, w // 2, cop, dtype=torch.float32, device=x4.device)
+    flops = 2.0 * b * (h // 2) * (w // 2) * co * 147
+    t0 = _prof_begin()
+    check(lib().codeps_conv2d_fwd(ctypes.byref(desc), ptr(x4.contiguous()), None, ptr(wf), ptr(sc), ptr(sh), None, ptr(y), None, 0, stream_ptr()),
+          "codeps_conv2d_fwd (frozen stem)")
+    _prof_end(t0, "conv_fwd", flops, desc)
+    return y
+
+
 # ---------------------------------------------------------------------------------------- chained 1x1 pair (frozen bottlenecks)
 _chain_cache = {}
 _CHAIN = os.environ.get("CODEPS_CHAIN1X1", "1") != "0"       # A/B switch: 0 = the two layers as separate conv launches

@@ -45,6 +45,9 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
     train-mode BN uses batch statistics (`sync` = cross-rank sum reducer for SyncBatchNorm).
     stem=True: x is in the double-pixel stem layout and conv is ResNet's conv1 (F.stem_conv2d)."""
     stride, pad = conv.stride[0], conv.padding[0]
+    if stem == "s3":                   # frozen 3-channel stem (eval BN folded, no gradients): F.stem3_conv2d, K = 224
+        scale, shift = folded_bn(bn)
+        return F.stem3_conv2d(x, conv.weight, scale=scale, shift=shift, act=act)
     if stem:
         if bn.training or (torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad)):
             y = F.stem_conv2d(x, conv.weight)

@@ -160,6 +160,10 @@ class ResnetEncoder(nn.Module):
         # instead of 784 for the 16-channel padded form); anything else takes the generic 16-channel path
         stem = enc.conv1.in_channels <= 8 and first.shape[-1] % 2 == 0
         cp, xpad = (8, F.STEM_XPAD) if stem else (16, (0, 0))
+        # frozen 3-channel conv1 (the shared encoder of the adaptation step, inference passes): rows of 4-channel pixels and a
+        # 7 x 1 convolution over overlapping 8-pixel windows, K = 224 instead of the double-pixel form's 448 (F.stem3_conv2d)
+        if stem and F._STEM3 and enc.conv1.in_channels == 3 and first.shape[-2] % 2 == 0 and _frozen_eval(enc.conv1, enc.bn1):
+            stem, cp, xpad = "s3", 4, F.STEM3_XPAD
         if isinstance(input_image, _PairGroups):
             x = F.frame_pairs_to_nhwc(list(input_image), cp, xpad)
             groups, off = _Groups(), 0

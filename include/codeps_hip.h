@@ -85,6 +85,11 @@ typedef struct {
     int32_t act;                 /* 0 none, 1 ReLU, 2 ELU(alpha=1) */
     int32_t stride_w, pad_w;     /* horizontal stride / padding (= stride / pad for every nn.Conv2d of the reference; they
                                   * differ only for the double-pixel stem form, see codeps_nchw_to_nhwc_xpad) */
+    int32_t pix_pitch, row_pitch;/* forward only, 0 = dense: source 0 as OVERLAPPING pixels -- pixel (y, x) starts
+                                  * (y * row_pitch + x) * pix_pitch floats into the image and spans c0 >= pix_pitch floats
+                                  * (c1 = 0, no upsample, kw = 1, pad_w = 0).  The 3-channel frozen stem uses it: rows of
+                                  * 4-channel pixels, a "pixel" = the 8 neighbouring ones a 7-wide / stride-2 window reads
+                                  * (c0 = 32, pix_pitch = 8): conv1 as a 7 x 1 convolution with K = 224 instead of 448 */
 } codeps_conv_desc;
 
 /* OIHW [out_c][in_c][kh][kw] -> w_fwd [out_c_pad][kh*kw][in_c_pad] and/or w_dgrad [in_c_pad][kh*kw][out_c_pad] (fp32), each

@@ -59,4 +59,4 @@ def test_version_and_error_string():
 
 def test_structs_match_c_layout():
     assert ctypes.sizeof(_lib.PhotometricDesc) == 32 and _lib.PhotometricDesc.noise_seed.offset == 24
-    assert ctypes.sizeof(_lib.ConvDesc) == 17 * 4 and _lib.ConvDesc.stride_w.offset == 15 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 19 * 4 and _lib.ConvDesc.stride_w.offset == 15 * 4 and _lib.ConvDesc.row_pitch.offset == 18 * 4

@@ -128,3 +128,27 @@ def test_trunk_features_with_and_without_the_chain(layers):
         assert fa.shape == fb.shape
         assert _l2(fa, fb) < 5e-6, f"feature {i}: {_l2(fa, fb):.2e}"
     assert not torch.equal(a[3], b[3]), "the chained path did not run (layer3 features are bit-identical)"
+
+
+@pytest.mark.parametrize("b,h,w", [(2, 64, 128), (1, 96, 160), (3, 32, 64)])
+def test_frozen_three_channel_stem_against_float64_and_the_double_pixel_form(b, h, w):
+    """F.stem3_conv2d (conv1 as a 7 x 1 convolution over overlapping 8-pixel windows of 4-channel pixels, K = 224) against
+    torch's conv2d in float64 and against the double-pixel form (F.stem_conv2d, K = 448) on the same images."""
+    import torch.nn.functional as TF
+    from codeps_amd import functional as F
+    g = torch.Generator().manual_seed(b * 100 + h)
+    img = torch.randn(b, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    ref = torch.relu(TF.conv2d(img.double(), wt.double(), None, 2, 3) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    r32 = torch.relu(TF.conv2d(img, wt, None, 2, 3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    with torch.no_grad():
+        x4 = F.images_to_nhwc([img.to(DEV)], 4, F.STEM3_XPAD)
+        y3 = F.stem3_conv2d(x4, wt.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), act="relu")
+        x8 = F.images_to_nhwc([img.to(DEV)], 8, F.STEM_XPAD)
+        y8 = F.stem_conv2d(x8, wt.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), act="relu")
+    got3, got8 = y3[..., :64].permute(0, 3, 1, 2).cpu(), y8[..., :64].permute(0, 3, 1, 2).cpu()
+    assert got3.shape == ref.shape
+    e3, e8, e32 = _l2(got3, ref), _l2(got8, ref), _l2(r32, ref)
+    assert e3 <= max(3 * e32, 1.5 * e8) + 1e-9, f"stem3 {e3:.2e}, double-pixel {e8:.2e}, torch fp32 {e32:.2e}"
+    assert float((got3.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
