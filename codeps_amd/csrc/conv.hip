@@ -2350,18 +2350,27 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 }
 
 // All trainable weights of a step in ONE launch (instead of one pack + up to two split launches per layer and step): `items`
-// is a device table, one entry per (parameter, pack kind); a thread produces 8 consecutive k of one pack row -- the fp32 pack
-// (32 contiguous bytes) and, when the row takes the split-operand kernel, its three bf16 pieces (3 x 16 bytes) -- straight
-// from the OIHW parameter.  Blocks find their item by bisection over the items' first work-group index.
+// is a device table, one entry per (parameter, pack kind).  Blocks find their item by bisection over the items' first
+// work-group index.  A work group moves one SLAB through LDS so that both sides are coalesced (round 2 read the OIHW
+// parameter with a stride of `taps` floats per thread: 10x its bytes from HBM by the counters):
+//   forward pack  [co][tap][ci]: slab = one row co x up to `cbw` columns ci: ONE contiguous OIHW run of cbw * taps floats in,
+//                                taps runs of cbw floats out;
+//   dgrad pack    [ci][tap][co]: slab = `rb` rows ci x 64 columns co: per co one contiguous run of rb * taps floats in,
+//                                rb * taps runs of 64 floats out.
+// A thread then emits 8 consecutive k of a pack row -- the fp32 pack (32 bytes) and, when the row takes the split-operand
+// kernel, its three bf16 pieces (3 x 16 bytes) -- exactly the bytes codeps_conv2d_pack_weights writes.
+constexpr int PACK_SLAB = 4608;          // floats of LDS per work group (512 columns x 9 taps)
 struct PackItem {
     const float* w;              // OIHW parameter
     float* out;                  // fp32 pack [rows][taps * cols] (+ the split copy behind it when `split`)
     int co_real, ci_real, taps, rows, cols;      // rows x cols = padded (Co x Ci) for the forward pack, (Ci x Co) for the dgrad pack
     int dgrad, split;
-    long long first_group, groups;               // work in units of 256 threads x 8 k
+    int cbw, rb;                 // slab shape: columns per slab (forward: <= 512; dgrad: 64), rows per slab (forward: 1)
+    long long first_group, groups;               // work groups (slabs) of this item
 };
 
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem* __restrict__ items, int n_items) {
+    __shared__ float slab[PACK_SLAB];
     int lo = 0, hi = n_items - 1;
     const long long g = blockIdx.x;
     while (lo < hi) {
@@ -2370,29 +2379,49 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
     }
     const PackItem it = items[lo];
     const long long wrow = (long long)it.taps * it.cols;                   // k extent of a pack row
-    const long long chunk = (g - it.first_group) * 256 + threadIdx.x;      // 8 consecutive k
     const long long total = (long long)it.rows * wrow;
-    if (chunk * 8 >= total) return;
-    const int row = (int)(chunk * 8 / wrow);
-    const int k0 = (int)(chunk * 8 % wrow), tap = k0 / it.cols, c0 = k0 % it.cols;     // cols % 8 == 0: a chunk stays inside one tap
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int col = c0 + e;
-        const int co = it.dgrad ? col : row, ci = it.dgrad ? row : col;
-        v[e] = (co < it.co_real && ci < it.ci_real) ? it.w[((size_t)co * it.ci_real + ci) * it.taps + tap] : 0.f;
+    const int u = (int)(g - it.first_group);
+    const int ncb = (it.cols + it.cbw - 1) / it.cbw;
+    const int r0 = (u / ncb) * it.rb, c0 = (u % ncb) * it.cbw;
+    const int ncol = min(it.cbw, it.cols - c0), nrow = min(it.rb, it.rows - r0);
+    const int taps = it.taps;
+    // ---- in: slab[(col * nrow + row) * taps + tap] (forward: nrow = 1 -> [col][tap], the OIHW order of one co)
+    if (!it.dgrad) {
+        const int n = ncol * taps;
+        const int avail = (r0 < it.co_real) ? max(min(c0 + ncol, it.ci_real) - c0, 0) * taps : 0;
+        const float* src = it.w + ((size_t)r0 * it.ci_real + c0) * taps;
+        for (int i = threadIdx.x; i < n; i += 256) slab[i] = i < avail ? src[i] : 0.f;
+    } else {
+        const int run = nrow * taps, n = ncol * run;
+        const int avail = max(min(r0 + nrow, it.ci_real) - r0, 0) * taps;       // floats of a run that exist (rows = ci)
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int col = i / run, k = i - col * run;
+            const int co = c0 + col;
+            slab[i] = (co < it.co_real && k < avail) ? it.w[((size_t)co * it.ci_real + r0) * taps + k] : 0.f;
+        }
     }
-    const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-    float* dst = it.out + chunk * 8;
-    *reinterpret_cast<f32x4*>(dst) = a;
-    *reinterpret_cast<f32x4*>(dst + 4) = b;
-    if (it.split) {
-        u16x4 pl[3], ph[3];
-        split_bf16<3>(a, pl);
-        split_bf16<3>(b, ph);
-        unsigned short* sp = reinterpret_cast<unsigned short*>(it.out + total) + (chunk / 4) * 96 + (chunk % 4) * 8;
+    __syncthreads();
+    // ---- out: chunks of 8 consecutive columns of one (row, tap)
+    const int cpr = ncol / 8, nchunk = nrow * taps * cpr;
+    for (int q = threadIdx.x; q < nchunk; q += 256) {
+        const int jc = q % cpr, rt = q / cpr, tap = rt % taps, rr = rt / taps;
+        float v[8];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(sp + q * 32) = pack8(pl[q], ph[q]);
+        for (int e = 0; e < 8; ++e) v[e] = slab[((jc * 8 + e) * nrow + rr) * taps + tap];
+        const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        const long long k = (long long)(r0 + rr) * wrow + (long long)tap * it.cols + c0 + jc * 8;     // first of the 8 k of this chunk
+        const long long chunk = k / 8;
+        float* dst = it.out + k;
+        *reinterpret_cast<f32x4*>(dst) = a;
+        *reinterpret_cast<f32x4*>(dst + 4) = b;
+        if (it.split) {
+            u16x4 pl[3], ph[3];
+            split_bf16<3>(a, pl);
+            split_bf16<3>(b, ph);
+            unsigned short* sp = reinterpret_cast<unsigned short*>(it.out + total) + (chunk / 4) * 96 + (chunk % 4) * 8;
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) *reinterpret_cast<i32x4*>(sp + qq * 32) = pack8(pl[qq], ph[qq]);
+        }
     }
 }
 
@@ -2720,8 +2749,16 @@ extern "C" long long codeps_pack_item_fill(void* item, const float* w_oihw, floa
     it.rows = dgrad ? in_c_pad : out_c_pad; it.cols = dgrad ? out_c_pad : in_c_pad;
     it.split = split_tail_ok(it.cols, it.taps) ? 1 : 0;
     it.first_group = first_group;
-    const long long total = (long long)it.rows * it.cols * it.taps;
-    it.groups = (total / 8 + 255) / 256;
+    if (it.taps * 64 > PACK_SLAB) { codeps_set_error("pack_item_fill: %d taps exceed the slab", it.taps); return 0; }
+    if (!it.dgrad) {
+        it.rb = 1;
+        it.cbw = std::max(8, std::min(512, PACK_SLAB / it.taps / 8 * 8));
+        it.groups = (long long)it.rows * cdiv(it.cols, it.cbw);
+    } else {
+        it.cbw = 64;
+        it.rb = std::max(1, std::min(8, PACK_SLAB / (64 * it.taps)));
+        it.groups = (long long)cdiv(it.rows, it.rb) * cdiv(it.cols, it.cbw);
+    }
     memcpy(item, &it, sizeof(it));
     return it.groups;
 }
