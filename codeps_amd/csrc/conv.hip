@@ -1691,6 +1691,10 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
 // are built in registers from the neighbouring aligned groups (v_alignbit, 4 per fragment) -- no unaligned LDS access, no
 // second copy of the tile.  Every X row's fragments are read once per tile and used by the up to three (py, ky) pairs that
 // touch it: 66 fragment reads for 216 MFMAs (9 taps x 6 piece products x 4 k-chunks) per wave and tile.
+// CO32 (layers with <= 32 output channels: the decoders' 1/2-resolution stages): one 32-row co tile, so the waves that would hold
+// the second co tile split the PIXELS instead -- wave = (pixel half ph, ci tile): output rows 2 ph, 2 ph + 1 of every tile -- and
+// each pixel half writes its own partial slab (the slab reduction sums them like any other split).
+template <bool CO32>
 __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                             const float* __restrict__ x0, const float* __restrict__ x1,
                                                             const float* __restrict__ dz, float* __restrict__ part) {
@@ -1701,17 +1705,22 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     unsigned short* dZs = lds16;                       // [64][ZP]
     unsigned short* Xs = lds16 + 64 * ZP;              // [64][XP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
-    const int wco = wave & 1, wci = wave >> 1;
+    const int wco = CO32 ? 0 : (wave & 1), wci = wave >> 1;
+    const int ph = __builtin_amdgcn_readfirstlane(wave & 1);       // CO32: this wave's pixel half
     const int co_base = blockIdx.y * 64;
     const int chunk = blockIdx.x % ci_chunks, blk = blockIdx.x / ci_chunks;
     const int c_base = chunk * 64;
     const int total_tiles = p.B * tiles_y * tiles_x;
     const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
-    const bool s1 = c_base >= p.C0;
-    const float* src = s1 ? x1 : x0;
-    const int cs = s1 ? p.C1 : p.C0, c_src = s1 ? c_base - p.C0 : c_base;
-    const bool up = p.up0 && !s1;
-    const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
+    // source of a channel quad of this chunk (a 64-channel chunk may straddle the two concat sources: picked per quad)
+    auto src_of = [&](int c4, const float*& src, int& cs, int& c_src, bool& up) {
+        const int ch = c_base + c4 * 4;
+        const bool s1 = ch >= p.C0;
+        src = s1 ? x1 : x0;
+        cs = s1 ? p.C1 : p.C0;
+        c_src = s1 ? ch - p.C0 : ch;
+        up = p.up0 && !s1;
+    };
 
     f32x16 acc[9];
 #pragma unroll
@@ -1731,9 +1740,12 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     };
     // eight consecutive pixels (iy, ix0 .. ix0 + 7) of the X source, 4 channels from c4 * 4; zero outside the image
     auto x_row8 = [&](int b, int iy, int ix0, int c4, f32x4 (&dst)[8]) {
+        const float* src; int cs, c_src; bool up;
+        src_of(c4, src, cs, c_src, up);
+        const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
         if (p.pad_mode == 1) iy = reflect_idx(iy, p.H);
-        const bool rowok = iy >= 0 && iy < p.H && c_src + c4 * 4 < cs;
-        const float* rowp = src + ((size_t)b * Hs + (up ? iy >> 1 : iy)) * Ws * cs + c_src + c4 * 4;
+        const bool rowok = iy >= 0 && iy < p.H && c_src < cs;
+        const float* rowp = src + ((size_t)b * Hs + (up ? iy >> 1 : iy)) * Ws * cs + c_src;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int ix = ix0 + i;
@@ -1743,10 +1755,13 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
         }
     };
     auto x_pixel = [&](int b, int iy, int ix, int c4) -> f32x4 {
+        const float* src; int cs, c_src; bool up;
+        src_of(c4, src, cs, c_src, up);
+        const int Hs = up ? p.H / 2 : p.H, Ws = up ? p.W / 2 : p.W;
         if (p.pad_mode == 1) { iy = reflect_idx(iy, p.H); ix = reflect_idx(ix, p.W); }
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src < cs) {
             if (up) { iy >>= 1; ix >>= 1; }
-            return *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c_src + c4 * 4);
+            return *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c_src);
         }
         return f32x4{0.f, 0.f, 0.f, 0.f};
     };
@@ -1823,11 +1838,14 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
         if (tile + 1 < t_end) load_tile(tile + 1);
         bf16x8 zf[TH][3];
 #pragma unroll
-        for (int py = 0; py < TH; ++py)
+        for (int py = 0; py < TH; ++py) {
+            if (CO32 && (py >> 1) != ph) continue;                  // (wave-uniform)
 #pragma unroll
             for (int q = 0; q < 3; ++q) zf[py][q] = *reinterpret_cast<const bf16x8*>(zrow + q * PIX + py * TW);
+        }
 #pragma unroll
         for (int r = 0; r < XH; ++r) {
+            if (CO32 && (r < 2 * ph || r > 2 * ph + 3)) continue;   // X rows this wave's two output rows read
             bf16x8 xf[3][3];                                         // [kx][piece]
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -1849,6 +1867,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
             for (int ky = 0; ky < 3; ++ky) {
                 const int py = r - ky;
                 if (py < 0 || py >= TH) continue;
+                if (CO32 && (py >> 1) != ph) continue;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -1860,7 +1879,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
         }
     }
     // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 31, row (co) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float* dst = part + (size_t)blk * p.Co * 9 * p.Ct;
+    float* dst = part + (size_t)(CO32 ? blk * 2 + ph : blk) * p.Co * 9 * p.Ct;
     const int ci = c_base + wci * 32 + l32;
     if (ci < p.Ct) {
 #pragma unroll
@@ -2145,7 +2164,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64_kernel(WgradP p, int ci_chun
         }
 }
 
-struct SmallPlan { bool ok, stem, halo64; int mt, nt, ci_chunks, co_groups, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
+struct SmallPlan { bool ok, stem, halo64, co32; int mt, nt, ci_chunks, co_groups, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
 
 // Halo-tile weight gradient on the bf16 matrix cores with 3-piece operands (wgrad_halo64s_kernel); CODEPS_WGRAD_SPLIT=0 or
 // CODEPS_SPLIT != 3 selects the f32-MFMA kernel.
@@ -2194,8 +2213,12 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
         return s;
     }
     static const int halo_off = getenv("CODEPS_NO_HALO64") ? 1 : 0;                                    // tuning experiments only
-    if (!halo_off && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->stride_w == 1 && d->pad == 1 && d->pad_w == 1 && d->out_c >= 48 && Ct >= 48 &&
-        cdiv(Ct, 64) * cdiv(d->out_c, 64) >= halo_min_tiles() && (d->c1 == 0 || d->c0 % 64 == 0) && d->out_h == d->in_h && d->out_w == d->in_w) {
+    // <= 32 output channels (the decoders' half-resolution stages, f32 MFMA until round 3): the split kernel's CO32 form
+    static const int co32_on = getenv("CODEPS_WGRAD_CO32") ? atoi(getenv("CODEPS_WGRAD_CO32")) : 1;       // tuning experiments only
+    const bool co32 = co32_on && wgrad_split_on() && d->out_c > 16 && d->out_c <= 32;
+    if (!halo_off && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->stride_w == 1 && d->pad == 1 && d->pad_w == 1 && (d->out_c >= 48 || co32) && Ct >= 48 &&
+        (co32 || cdiv(Ct, 64) * cdiv(d->out_c, 64) >= halo_min_tiles()) && (d->c1 == 0 || d->c0 % 64 == 0 || wgrad_split_on()) &&
+        d->out_h == d->in_h && d->out_w == d->in_w) {
         // 64 x 64 channel tiles over 4x16-pixel tiles with halo (wgrad_halo64_kernel); a single-tile 64 -> 64 layer would need
         // ~768 pixel blocks = 768 partial slabs, where the per-tap kernel measures faster
         s.ok = s.halo64 = true;
@@ -2209,7 +2232,8 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
         const int want = std::max(1, halo_blocks / (s.ci_chunks * s.co_groups));
         s.tiles_per_block = std::max(2, cdiv(total, want));
         s.nblk = cdiv(total, s.tiles_per_block);
-        s.splits = s.nblk;
+        s.splits = co32 ? 2 * s.nblk : s.nblk;                   // CO32: one slab per pixel half
+        s.co32 = co32;
         return s;
     }
     s.ok = d->stride == 1 && d->stride_w == 1 && d->pad_w == d->pad && d->kh == d->kw && (d->kh == 1 || d->kh == 3) && d->out_c <= 32 &&
@@ -2964,9 +2988,16 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
             g_last_kernel = wgrad_split_on() ? "wgrad_halo64s_kernel" : "wgrad_halo64_kernel";
             if (wgrad_split_on()) {
                 constexpr size_t lds = (size_t)64 * ((3 * 64 + 8) + (3 * 6 * 32 + 8)) * 2;           // dZs + Xs (halfwords)
-                codeps_allow_lds((const void*)wgrad_halo64s_kernel, 160 * 1024, "wgrad_halo64s_kernel");
-                hipLaunchKernelGGL(wgrad_halo64s_kernel, dim3(g, sp.co_groups), dim3(256), lds, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
-                                   sp.tiles_per_block, x0, x1, dz, part);
+                if (sp.co32) {
+                    g_last_kernel = "wgrad_halo64s_kernel<co32>";
+                    codeps_allow_lds((const void*)wgrad_halo64s_kernel<true>, 160 * 1024, "wgrad_halo64s_kernel<co32>");
+                    hipLaunchKernelGGL(wgrad_halo64s_kernel<true>, dim3(g, sp.co_groups), dim3(256), lds, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
+                                       sp.tiles_per_block, x0, x1, dz, part);
+                } else {
+                    codeps_allow_lds((const void*)wgrad_halo64s_kernel<false>, 160 * 1024, "wgrad_halo64s_kernel");
+                    hipLaunchKernelGGL(wgrad_halo64s_kernel<false>, dim3(g, sp.co_groups), dim3(256), lds, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
+                                       sp.tiles_per_block, x0, x1, dz, part);
+                }
             } else
             hipLaunchKernelGGL(wgrad_halo64_kernel, dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
                                sp.tiles_per_block, x0, x1, dz, part);

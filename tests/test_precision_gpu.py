@@ -94,6 +94,7 @@ CASES = {
     "halo3r_small_grid": (6, 32, 64, 256, 256, 3, "conv_halo3r_kernel", "conv_halo3r_kernel", None),
     "halo3r_splitk": (4, 32, 64, 512, 256, 3, "conv_halo3r_kernel<splitk>", None, None),           # 128 blocks x 2 slices of 8 chunks
     "halo3r_splitk_dgrad": (4, 32, 64, 256, 512, 3, None, "conv_halo3r_kernel<splitk>", None),
+    "wgrad_co32": (4, 64, 128, 64, 32, 3, None, None, "wgrad_halo64s_kernel<co32>"),               # <= 32 output channels: pixel-split waves
     "ws_3x3_256": (7, 32, 48, 256, 256, 3, "conv_igemm_ws_kernel", "conv_igemm_ws_kernel", None),      # W % 32 != 0: not a halo-tile shape
     "ws_1x1_2048": (4, 32, 64, 2048, 512, 1, "conv_igemm_ws_kernel", None, None),
     "igemm_1x1": (8, 32, 64, 256, 1024, 1, "conv_igemm_kernel<split3>", "conv_igemm_ws_kernel", None),      # dgrad: K = 1024, one round of 128x128 blocks
@@ -202,3 +203,30 @@ def test_split_stem_forward_and_weight_gradient(in_ch, kind):
         mfma = run("conv_igemm_kernel<f32>", "wgrad_small_kernel")
     for name, e, t, m in zip(("forward", "d weight"), got, (l2(y32, y64), l2(dw32, dw64)), mfma):
         assert e <= _bound(t, m, 3), f"{kind} {name}: {e:.3e} vs torch fp32 {t:.3e}, f32 MFMA {m:.3e}"
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide"])
+def test_co32_weight_gradient_with_a_chunk_that_straddles_the_concat(kind):
+    """The decoders' half-resolution stage conv3x3(cat(nearest_x2(x0: 32 ch), x1: 64 ch)) -> 32 channels (models/depth_head.py:60-71):
+    its weight gradient on the split kernel's CO32 form; the first 64-channel chunk holds 32 up-sampled + 32 skip channels."""
+    F = _F()
+    b, h, w_, c0, c1, co = 3, 64, 128, 32, 64, 32
+    x0, wt, g = _inputs(kind, (b, c0, h // 2, w_ // 2), (co, c0 + c1, 3, 3), 77)
+    x1 = _inputs(kind, (b, c1, h, w_), (1, 1, 1, 1), 78)[0]
+    gy = torch.randn(b, co, h, w_, generator=g)
+    cat = torch.cat([TF.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1)
+    _y64, _dc64, dw64 = _reference(cat, wt, gy, 1, 1, torch.float64)
+    _y32, _dc32, dw32 = _reference(cat, wt, gy, 1, 1, torch.float32)
+
+    def run(expect):
+        ww = wt.to(DEV).requires_grad_(True)
+        y = F.conv2d(nhwc(x0), ww, x1=nhwc(x1), pad=1, up0=True)
+        y.backward(nhwc(gy))
+        assert expect in _last(), _last()
+        return l2(ww.grad.cpu(), dw64)
+
+    e = run("wgrad_halo64s_kernel<co32>")
+    with _arith(0):
+        m = run("wgrad")
+    t = l2(dw32, dw64)
+    assert e <= _bound(t, m, 3), f"{kind}: {e:.3e} vs torch fp32 {t:.3e}, f32 MFMA {m:.3e}"
