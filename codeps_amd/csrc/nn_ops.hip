@@ -9,6 +9,8 @@
 // (models/instance_head.py:38-46,90-98), F.interpolate bilinear (models/semantic_head.py:66-69,
 // models/instance_head.py:65-68,116-118), nn.Softmax(dim=1) (semantic_head.py:74, instance_head.py:146),
 // sigmoid + disp_to_depth (models/depth_head.py:48-54,71-74), ELU/ReLU backward.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -92,20 +94,34 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     f32x4 sc = {1.f, 1.f, 1.f, 1.f};
     if (scale && cok) sc = *reinterpret_cast<const f32x4*>(scale + tg * 4);
-    if (cok)
-#pragma unroll 4
-        for (long long r = r0 + tr; r < r1; r += TR) {
-            const size_t o = (size_t)r * C + tg * 4;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
-            f32x4 d = g;
-            if (act) {
-                const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+    // four rows per trip, every load issued before the first use; `act` / `dz` are launch-uniform: one copy of the loop each
+    auto body = [&](auto has_act, auto has_dz) {
+        for (long long r = r0 + tr; r < r1; r += 4 * TR) {
+            f32x4 g[4], yy[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = g[e] * act_grad(yy[e], act);
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = (size_t)min(r + (long long)u * TR, r1 - 1) * C + tg * 4;
+                g[u] = *reinterpret_cast<const f32x4*>(dy + o);
+                if constexpr (decltype(has_act)::value) yy[u] = *reinterpret_cast<const f32x4*>(y + o);
             }
-            acc += d;
-            if (dz) *reinterpret_cast<f32x4*>(dz + o) = d * sc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long rr = r + (long long)u * TR;
+                if (rr >= r1) break;
+                f32x4 d = g[u];
+                if constexpr (decltype(has_act)::value) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = g[u][e] * act_grad(yy[u][e], act);
+                }
+                acc += d;
+                if constexpr (decltype(has_dz)::value) *reinterpret_cast<f32x4*>(dz + (size_t)rr * C + tg * 4) = d * sc;
+            }
         }
+    };
+    if (cok && r0 < r1) {
+        if (act) { if (dz) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+        else { if (dz) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+    }
     if (!part) return;
     __shared__ f32x4 red[256];
     red[threadIdx.x] = acc;
@@ -273,12 +289,20 @@ __global__ __launch_bounds__(256) void bn_stats_mg_kernel(const float* __restric
     const long long r0 = gr.row0[g] + (long long)blockIdx.x * rpb;
     const long long r1 = min(r0 + rpb, gr.row0[g] + M);
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-    if (cok) {
+    if (cok && r0 < r1) {
         const f32x4 sh = *reinterpret_cast<const f32x4*>(x + (size_t)gr.row0[g] * C + tg * 4);
-#pragma unroll 4
-        for (long long r = r0 + tr; r < r1; r += TR) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + tg * 4) - sh;
-            s += v; q += v * v;
+        // four rows per trip, all loads issued before the first use, no branch in the body (rows past the range re-read the
+        // last row with weight 0): the loop as first written waited for every load before issuing the next
+        for (long long r = r0 + tr; r < r1; r += 4 * TR) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)min(r + (long long)u * TR, r1 - 1) * C + tg * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float wgt = (r + (long long)u * TR < r1) ? 1.f : 0.f;
+                const f32x4 d = (v[u] - sh) * wgt;
+                s += d; q += d * d;
+            }
         }
     }
     __shared__ f32x4 red[2][256];
@@ -432,18 +456,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __re
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + tg * 4), is = *reinterpret_cast<const f32x4*>(invstd + g * C + tg * 4);
         f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
         if (!y && act == 1) { ga = *reinterpret_cast<const f32x4*>(gamma + tg * 4); be = *reinterpret_cast<const f32x4*>(beta + tg * 4); }
-#pragma unroll 4
-        for (long long r = r0 + tr; r < r1; r += TR) {
-            const size_t o = (size_t)r * C + tg * 4;
-            f32x4 gg = *reinterpret_cast<const f32x4*>(dy + o);
-            const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
-            if (act == 1) {
-                const f32x4 yy = y ? *reinterpret_cast<const f32x4*>(y + o) : xh * ga + be;
+        // four rows per trip: every load of the trip is issued before the first use and the body has no branch (rows past the
+        // range re-read the last row with weight 0; `y` is block-uniform: two copies of the loop) -- as first written the loop
+        // waited for each pair of loads before issuing the next (2.8 TB/s)
+        auto body = [&](auto has_y) {
+            for (long long r = r0 + tr; r < r1; r += 4 * TR) {
+                f32x4 gv[4], xv[4], yv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gg[e] = yy[e] > 0.f ? gg[e] : 0.f;
+                for (int u = 0; u < 4; ++u) {
+                    const size_t o = (size_t)min(r + (long long)u * TR, r1 - 1) * C + tg * 4;
+                    gv[u] = *reinterpret_cast<const f32x4*>(dy + o);
+                    xv[u] = *reinterpret_cast<const f32x4*>(x + o);
+                    if constexpr (decltype(has_y)::value) yv[u] = *reinterpret_cast<const f32x4*>(y + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float wgt = (r + (long long)u * TR < r1) ? 1.f : 0.f;
+                    const f32x4 xh = (xv[u] - mu) * is;
+                    f32x4 yy;
+                    if constexpr (decltype(has_y)::value) yy = yv[u]; else yy = xh * ga + be;
+                    f32x4 gg = gv[u] * wgt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gg[e] = (act != 1 || yy[e] > 0.f) ? gg[e] : 0.f;
+                    s += gg; q += gg * xh;
+                }
             }
-            s += gg; q += gg * xh;
-        }
+        };
+        if (r0 < r1) { if (y) body(std::true_type{}); else body(std::false_type{}); }
     }
     __shared__ f32x4 red[2][256];
     red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
