@@ -1738,6 +1738,12 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
         c4 = (t & 3) | ((t / (4 * ngrp)) << 2);
         grp = (t >> 2) % ngrp;
     };
+    // X task index of this thread's two big tasks (u = 0: threads 128.., u = 1: threads 0..63).  Opaque to the compiler on
+    // purpose: with both written as bt - 128 it narrows the / 48 and % 12 to 16-bit multiplies of ONE register (tid - 128 and
+    // tid + 128 agree in the low byte), hoists that out of the tile loop and feeds the u = 1 lanes 0xff80 + tid -- wrong
+    // channel quads for a quarter of the X tile as soon as the per-quad source selection depends on them (ROCm 7.2 clang).
+    int xt0 = tid - 128, xt1 = tid + 128;
+    asm volatile("" : "+v"(xt0), "+v"(xt1));
     // eight consecutive pixels (iy, ix0 .. ix0 + 7) of the X source, 4 channels from c4 * 4; zero outside the image
     auto x_row8 = [&](int b, int iy, int ix0, int c4, f32x4 (&dst)[8]) {
         const float* src; int cs, c_src; bool up;
@@ -1782,7 +1788,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
                 for (int i = 0; i < 8; ++i)
                     bigr[u][i] = (rowok && gx0 + i < p.Wo) ? *reinterpret_cast<const f32x4*>(rowp + (size_t)i * p.Co) : f32x4{0.f, 0.f, 0.f, 0.f};
             } else {                                                 // X interior: grp = row r * 2 + group g (12 per tile)
-                task_of(bt - 128, 12, c4, grp);
+                task_of(u == 0 ? xt0 : xt1, 12, c4, grp);
                 x_row8(b, ty0 + (grp >> 1) - 1, tx0 + (grp & 1) * 8, c4, bigr[u]);
             }
         }
@@ -1802,7 +1808,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
                 task_of(bt, 8, c4, grp);
                 dst = dZs + (c4 * 4) * ZP + grp * 8; cstride = ZP; qstride = PIX;
             } else {
-                task_of(bt - 128, 12, c4, grp);
+                task_of(u == 0 ? xt0 : xt1, 12, c4, grp);
                 dst = Xs + (c4 * 4) * XP + (grp >> 1) * XROW + 8 + (grp & 1) * 8; cstride = XP; qstride = XQ;
             }
 #pragma unroll
