@@ -147,16 +147,16 @@ def pmc_traffic(default_workload):
     """HBM bytes per conv launch from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE passes of this same
     command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  Counters cannot be read from inside
     the process, so the value is the one measured when profiles/ was last refreshed -- None for other workloads."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
     if not default_workload or not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
-    return round(d["conv"]["hbm_mb_per_launch"] * 1e6), "profiles/r02_pmc_traffic.json (avg HBM bytes per conv launch)"
+    return round(d["conv"]["hbm_mb_per_launch"] * 1e6), "profiles/r03_pmc_traffic.json (avg HBM bytes per conv launch)"
 
 
 def photometric_pmc(default_workload):
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
     if not default_workload or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -232,7 +232,9 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
                      "algorithmic_mb_per_launch": round(pb / pn / 1e6, 2), "avg_launch_us": round(ps / pn * 1e6, 1),
                      "launches_per_step": pn // steps, "ms_per_step": round(ps / steps * 1e3, 3), "traffic": ptraffic,
                      "note": "84 B per pixel and batch item (40 forward + 44 backward, SURVEY.md 8d); VALU-bound in practice (~1.1 kFLOP of fp32 warp / SSIM "
-                             "arithmetic per pixel and scale), so the HBM fraction is low by construction; traffic = PMC HBM bytes per launch"}
+                             "arithmetic per pixel and scale), so the HBM fraction is low by construction; traffic = PMC HBM bytes per launch -- since "
+                             "round 3 it includes the warped samples and SSIM adjoint coefficients the forward keeps for the backward (60 B per pixel "
+                             "and scale, written once and read once) instead of recomputing them on a halo-2 tile"}
     # the vendor peak and the peak re-measured on this box (csrc/diag.hip: register-resident MFMA loop on operands
     # that change between consecutive MFMAs -- what the matrix pipe sustains under the power limit on real data -- and a stream
     # triad).  `peak` / `frac` stay on the vendor figure; the measured ones are reported beside them.

@@ -22,6 +22,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o r -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --graph 0 > /dev/null 2>&1
 python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps 3 > $OUT/${R}_pmc_traffic.json 2>/dev/null
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
+# 3b. matrix-pipe utilisation per kernel family (its own counter pass)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -o r -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --graph 0 > /dev/null 2>&1
+python3 tools/mfma_busy.py gpurun_out/pmc_mfma --steps 3 > $OUT/${R}_mfma_busy.json 2>/dev/null
+rm -rf gpurun_out/pmc_mfma
 # 4. the other configurations that fit one GPU, secondary rows
 python3 bench.py --mode train --no-cpu-baseline 2>/dev/null | line > $OUT/${R}_bench_n1_configs1_pretrain.json
 python3 bench.py --per-gpu-batch 4 --no-cpu-baseline 2>/dev/null | line > $OUT/${R}_bench_n1_configs3_slice.json
