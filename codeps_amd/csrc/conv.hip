@@ -2399,15 +2399,7 @@ struct PackItem {
     long long first_group, groups;               // work groups (slabs) of this item
 };
 
-__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem* __restrict__ items, int n_items) {
-    __shared__ float slab[PACK_SLAB];
-    int lo = 0, hi = n_items - 1;
-    const long long g = blockIdx.x;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[mid].first_group <= g) lo = mid; else hi = mid - 1;
-    }
-    const PackItem it = items[lo];
+__device__ __forceinline__ void pack_item_body(const PackItem& it, long long g, float* slab) {
     const long long wrow = (long long)it.taps * it.cols;                   // k extent of a pack row
     const long long total = (long long)it.rows * wrow;
     const int u = (int)(g - it.first_group);
@@ -2453,6 +2445,25 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
             for (int qq = 0; qq < 3; ++qq) *reinterpret_cast<i32x4*>(sp + qq * 32) = pack8(pl[qq], ph[qq]);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem* __restrict__ items, int n_items) {
+    __shared__ float slab[PACK_SLAB];
+    int lo = 0, hi = n_items - 1;
+    const long long g = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_group <= g) lo = mid; else hi = mid - 1;
+    }
+    const PackItem it = items[lo];
+    pack_item_body(it, g, slab);
+}
+
+// one parameter's forward and / or data-gradient pack (codeps_conv2d_pack_weights): the items travel as kernel arguments
+__global__ __launch_bounds__(256) void pack_weights_pair_kernel(PackItem a, PackItem b) {
+    __shared__ float slab[PACK_SLAB];
+    if ((long long)blockIdx.x < a.groups) pack_item_body(a, blockIdx.x, slab);
+    else pack_item_body(b, blockIdx.x, slab);
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -2744,12 +2755,46 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
 // chunks, or 16-channel chunks (the stem) as long as the row is a whole number of 32-element groups
 static bool split_tail_ok(int kc, int taps) { return kc % 32 == 0 || (kc == 16 && (taps * kc) % 32 == 0); }
 
+// table entry of one pack (slab shape, work groups); false when the shape does not fit the slab kernel
+static bool fill_pack_item(PackItem& it, const float* w_oihw, float* out, int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
+                           int dgrad, long long first_group) {
+    if ((out_c_pad % 8) != 0 || (in_c_pad % 8) != 0 || kh * kw * 64 > PACK_SLAB) return false;
+    it.w = w_oihw; it.out = out; it.co_real = out_c; it.ci_real = in_c; it.taps = kh * kw; it.dgrad = dgrad ? 1 : 0;
+    it.rows = dgrad ? in_c_pad : out_c_pad; it.cols = dgrad ? out_c_pad : in_c_pad;
+    it.split = split_tail_ok(it.cols, it.taps) ? 1 : 0;
+    it.first_group = first_group;
+    if (!it.dgrad) {
+        it.rb = 1;
+        it.cbw = std::max(8, std::min(512, PACK_SLAB / it.taps / 8 * 8));
+        it.groups = (long long)it.rows * cdiv(it.cols, it.cbw);
+    } else {
+        it.cbw = 64;
+        it.rb = std::max(1, std::min(8, PACK_SLAB / (64 * it.taps)));
+        it.groups = (long long)cdiv(it.rows, it.rb) * cdiv(it.cols, it.cbw);
+    }
+    return true;
+}
+
 extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, int out_c_pad, int in_c_pad,
                                           const float* w_oihw, float* w_fwd, float* w_dgrad, codeps_stream_t stream) {
     CODEPS_REQUIRE(out_c > 0 && in_c > 0 && kh > 0 && kw > 0 && out_c_pad >= out_c && in_c_pad >= in_c && w_oihw &&
                        (w_fwd || w_dgrad),
                    CODEPS_ERR_ARG, "conv2d_pack_weights: bad arguments");
     const long long total = (long long)out_c_pad * in_c_pad * kh * kw;
+    {   // one launch through the LDS slab (coalesced both ways, pack + split copy together); odd shapes keep the kernels below
+        PackItem a, b;
+        memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
+        bool ok = true;
+        long long groups = 0;
+        PackItem* slot = &a;
+        if (w_fwd) { ok = ok && fill_pack_item(*slot, w_oihw, w_fwd, out_c, in_c, kh, kw, out_c_pad, in_c_pad, 0, groups); groups += slot->groups; slot = &b; }
+        if (w_dgrad) { ok = ok && fill_pack_item(*slot, w_oihw, w_dgrad, out_c, in_c, kh, kw, out_c_pad, in_c_pad, 1, groups); groups += slot->groups; }
+        if (ok && groups > 0 && groups < (1ll << 31)) {
+            hipLaunchKernelGGL(pack_weights_pair_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a, b);
+            CODEPS_CHECK_LAUNCH("pack_weights_pair_kernel");
+            return CODEPS_OK;
+        }
+    }
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, out_c, in_c, kh * kw,
                        out_c_pad, in_c_pad, w_fwd, w_dgrad);
@@ -2775,19 +2820,10 @@ extern "C" long long codeps_pack_item_fill(void* item, const float* w_oihw, floa
         return 0;
     }
     PackItem it;
-    it.w = w_oihw; it.out = out; it.co_real = out_c; it.ci_real = in_c; it.taps = kh * kw; it.dgrad = dgrad ? 1 : 0;
-    it.rows = dgrad ? in_c_pad : out_c_pad; it.cols = dgrad ? out_c_pad : in_c_pad;
-    it.split = split_tail_ok(it.cols, it.taps) ? 1 : 0;
-    it.first_group = first_group;
-    if (it.taps * 64 > PACK_SLAB) { codeps_set_error("pack_item_fill: %d taps exceed the slab", it.taps); return 0; }
-    if (!it.dgrad) {
-        it.rb = 1;
-        it.cbw = std::max(8, std::min(512, PACK_SLAB / it.taps / 8 * 8));
-        it.groups = (long long)it.rows * cdiv(it.cols, it.cbw);
-    } else {
-        it.cbw = 64;
-        it.rb = std::max(1, std::min(8, PACK_SLAB / (64 * it.taps)));
-        it.groups = (long long)cdiv(it.rows, it.rb) * cdiv(it.cols, it.cbw);
+    memset(&it, 0, sizeof(it));
+    if (!fill_pack_item(it, w_oihw, out, out_c, in_c, kh, kw, out_c_pad, in_c_pad, dgrad, first_group)) {
+        codeps_set_error("pack_item_fill: %d taps exceed the slab", kh * kw);
+        return 0;
     }
     memcpy(item, &it, sizeof(it));
     return it.groups;

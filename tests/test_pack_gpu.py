@@ -1,6 +1,8 @@
 """The one-launch weight pack of a step (codeps_conv2d_pack_weights_multi, slabs through LDS) writes exactly the bytes of the
 one-by-one pack (codeps_conv2d_pack_weights): fp32 packs, data-gradient packs and the pre-split bf16 copies, for every kernel
-shape of the networks (1x1, 3x3, 4x4 up-dgrad weights, the 7x4 stem form, channel counts that need padding)."""
+shape of the networks (1x1, 3x3, 4x4 up-dgrad weights, the 7x4 stem form, channel counts that need padding).  Since both entry
+points run the same slab code, both are also compared with the layout written out in torch: [row][tap][col] fp32, then
+[row][K group of 32][piece][32] bf16 with the pieces of the exact 3-way split."""
 import pytest
 import torch
 
@@ -43,3 +45,41 @@ def test_multi_pack_equals_single_packs():
         assert not torch.equal(got_f, wf0), "the refresh did not see the new weights"
     F._pack_cache_train.clear()
     F._pack_table.update(dev=None, n=0, groups=0, entries=[], epoch=-1)
+
+
+def _reference_pack(w, rows_pad, cols_pad, dgrad):
+    """fp32 pack [rows_pad][taps][cols_pad] (+ split copy or None) of an OIHW tensor, in torch."""
+    co, ci, kh, kw = w.shape
+    t = w.reshape(co, ci, kh * kw)
+    t = t.permute(1, 2, 0) if dgrad else t.permute(0, 2, 1)                 # [row][tap][col]
+    out = torch.zeros(rows_pad, kh * kw, cols_pad, device=w.device)
+    out[:t.shape[0], :, :t.shape[2]] = t
+    flat = out.reshape(-1)
+    taps = kh * kw
+    if not (cols_pad % 32 == 0 or (cols_pad == 16 and (taps * cols_pad) % 32 == 0)):
+        return flat, None
+    p0 = flat.to(torch.bfloat16)
+    r1 = flat - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    pieces = torch.stack([p0, p1, p2], 0).view(3, -1, 32).permute(1, 0, 2).contiguous()      # [group of 32][piece][32]
+    return flat, pieces.view(torch.int16).reshape(-1)
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(32, 32, 7, 1)])
+def test_single_pack_matches_the_layout_written_out_in_torch(shape):
+    from codeps_amd import functional as F
+    torch.manual_seed(1)
+    co, ci = shape[:2]
+    p = torch.nn.Parameter(torch.randn(*shape, device=DEV) * torch.exp2(torch.randint(-8, 9, shape, device=DEV).float()))
+    cop, cip = F.pad16(co), F.pad16(ci)
+    wf, wd = F.pack_weights(p, cop, cip, True)
+    torch.cuda.synchronize()
+    for got, dgrad, rows, cols in ((wf, False, cop, cip), (wd, True, cip, cop)):
+        ref, pieces = _reference_pack(p.detach(), rows, cols, dgrad)
+        n = ref.numel()
+        assert torch.equal(got[:n].view(torch.int32), ref.view(torch.int32)), f"fp32 pack (dgrad={dgrad}) of {shape}"
+        if pieces is not None:
+            have = got[n:].view(torch.int16)[:pieces.numel()]
+            assert torch.equal(have, pieces), f"split copy (dgrad={dgrad}) of {shape}"
+    F._pack_cache_train.clear()
