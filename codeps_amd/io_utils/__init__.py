@@ -15,16 +15,11 @@ from ..config import CfgNode, get_cfg_defaults
 
 def make_modules_list(config) -> List[str]:
     """io_utils/io_utils.py:18-33: the modules a configuration instantiates (order is irrelevant: the reference returns list(set))."""
-    modules = []
-    if config.model.make_depth:
-        modules += ["backbone_po_depth", "backbone_pose_sflow", "depth_head", "pose_head"]
-        if config.model.make_sflow:
-            modules.append("flow_head")
-    if config.model.make_semantic:
-        modules += ["backbone_po_depth", "semantic_head"]
-    if config.model.make_instance:
-        modules += ["backbone_po_depth", "instance_head"]
-    return list(dict.fromkeys(modules))
+    m = config.model
+    wanted = (("backbone_po_depth", m.make_depth or m.make_semantic or m.make_instance),
+              ("backbone_pose_sflow", m.make_depth), ("depth_head", m.make_depth), ("pose_head", m.make_depth),
+              ("flow_head", m.make_depth and m.make_sflow), ("semantic_head", m.make_semantic), ("instance_head", m.make_instance))
+    return [name for name, on in wanted if on]
 
 
 def _plain(node):
@@ -47,34 +42,36 @@ def _load_pretraining_dict(model, state_dict):
     return model.load_state_dict(state_dict, False)
 
 
+def _module_state(ckpt, name):
+    """state_dict of one module inside a loaded checkpoint; a missing or None entry is the reference's KeyError."""
+    sd = ckpt["state_dict"].get(name)
+    if sd is None:
+        raise KeyError(f"The given checkpoint does not contain a state_dict for module {name}")
+    return sd
+
+
 def resume_from_checkpoint(model, checkpoint: str, modules: List[str]):
-    """io_utils/io_utils.py:36-49."""
-    checkpoint = torch.load(checkpoint, map_location="cpu")
-    state_dict = checkpoint["state_dict"]
-    for module in modules:
-        if module in state_dict and state_dict[module] is not None:
-            model_module = getattr(model, module)
-            if model_module is not None:
-                _load_pretraining_dict(model_module, state_dict[module])
-        else:
-            raise KeyError(f"The given checkpoint does not contain a state_dict for module {module}")
-    return checkpoint
+    """io_utils/io_utils.py:36-49: every listed module must be in the file; modules the model does not have are skipped."""
+    ckpt = torch.load(checkpoint, map_location="cpu")
+    for name in modules:
+        sd, target = _module_state(ckpt, name), getattr(model, name)
+        if target is not None:
+            _load_pretraining_dict(target, sd)
+    return ckpt
 
 
 def pretrained_from_checkpoints(model, checkpoints: List[str], modules: List[str], rank: int = 0):
-    """io_utils/io_utils.py:52-73: "module:path" entries load one module each from another checkpoint."""
+    """io_utils/io_utils.py:52-73: "module:path" entries load one module each from another checkpoint; a bare path is a
+    whole-body state dict."""
     for entry in checkpoints:
-        module, path = entry.split(":") if ":" in entry else (None, entry)
-        checkpoint = torch.load(path, map_location="cpu")
-        if module is None:
-            _load_pretraining_dict(getattr(model, "body"), checkpoint)
-            continue
-        if module not in modules:
-            raise ValueError(f"Unrecognized network module {module}")
-        state_dict = checkpoint["state_dict"]
-        if module not in state_dict or state_dict[module] is None:
-            raise KeyError(f"The given checkpoint does not contain a state_dict for module {module}")
-        _load_pretraining_dict(getattr(model, module), state_dict[module])
+        name, _, path = entry.rpartition(":")
+        ckpt = torch.load(path, map_location="cpu")
+        if not name:
+            _load_pretraining_dict(model.body, ckpt)
+        elif name in modules:
+            _load_pretraining_dict(getattr(model, name), _module_state(ckpt, name))
+        else:
+            raise ValueError(f"Unrecognized network module {name}")
 
 
 def gen_config(filename_config=None, adapt=False) -> CfgNode:
