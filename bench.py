@@ -167,6 +167,37 @@ def photometric_pmc(default_workload):
     return round(sum((r["read_mb_per_launch"] + r["write_mb_per_launch"]) * 1e6 for r in ks) / len(ks))
 
 
+def eval_pass_roofline(run_eval, steps=2):
+    """`--mode frame`: the conv engine inside the per-frame evaluation passes (scripts/adapt_codeps.py:166-199: EMA-teacher
+    evaluation of the target frame, teacher / student passes over the mix-up items; frozen weights, eval-mode BN folded into the
+    conv epilogues), measured like conv_roofline: HIP events around every conv launch, algorithmic FLOPs / event time."""
+    from codeps_amd import functional as F
+    F._profile["events"].clear()
+    F._profile["on"] = True
+    for _ in range(steps):
+        run_eval()
+    torch.cuda.synchronize()
+    F._profile["on"] = False
+    flops = secs = split_flops = split_secs = 0.0
+    n = 0
+    for kind, fl, a, b, _tag in F._profile["events"]:
+        if not kind.startswith("conv_"):
+            continue
+        t = a.elapsed_time(b) * 1e-3
+        flops += fl; secs += t; n += 1
+        if kind.endswith("_split"):
+            split_flops += fl; split_secs += t
+    F._profile["events"].clear()
+    if not n or split_secs == 0.0:
+        return None
+    peak = PEAK_BF16_MFMA_TFLOPS / 6
+    return {"bound": "mfma", "kernel": "conv engine inside the evaluation passes of a frame (forward only, frozen weights)",
+            "achieved": round(split_flops / split_secs / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(split_flops / split_secs / 1e12 / peak, 4), "launches_per_frame": n // steps,
+            "conv_ms_per_frame": round(secs / steps * 1e3, 3), "algorithmic_gflop_per_frame": round(flops / steps / 1e9, 1),
+            "all_conv_tflops": round(flops / secs / 1e12, 2)}
+
+
 def conv_roofline(runner, data, steps=2, default_workload=False):
     """Live measurement of the conv engine with HIP events on the launch stream: algorithmic (fp32-equivalent, unpadded) FLOPs
     of every launch / its event-timed duration, per kernel kind, each priced against the peak of the arithmetic it runs:
@@ -347,13 +378,17 @@ def main():
         replay = DiversityReplayBuffer(100000, 300, 0.95, device, feature_dim=int(net.backbone_po_depth.num_ch_enc[-1]))
         frame_no = [0]
 
+    def eval_passes():
+        sample = {k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items() if not k.endswith("mixup")}
+        sample["cut_mixup"] = dict(raw_mix)
+        pre_step(net, ema, ["semantic_head"], sample, [0, -1, 1], True)
+        return sample
+
     def one_step():
         if frame_mode:
             # per incoming frame: teacher / student evaluation passes (scripts/adapt_codeps.py:164-199), then the mix-up item
             # is built on the device (codeps/online_adap.py:331-335 -> Mixup.do_mixup) into the step's static input buffers
-            sample = {k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items() if not k.endswith("mixup")}
-            sample["cut_mixup"] = dict(raw_mix)
-            pre_step(net, ema, ["semantic_head"], sample, [0, -1, 1], True)
+            sample = eval_passes()
             mixed = Mixup.do_mixup("cut_mixup", sample["cut_mixup"], net.instance_algo, net.cfg_mixup)
             data["cut_mixup"]["rgb"][0].copy_(mixed["rgb"][0])
             data["cut_mixup"]["semantic"].copy_(mixed["semantic"])
@@ -390,6 +425,8 @@ def main():
         default_wl = (args.mode == "adapt" and (args.encoder in (None, 101)) and (args.height, args.width) == (512, 1024)
                       and args.per_gpu_batch in (None, 8) and not args.yaml_faithful)
         roof = conv_roofline(runner, data, default_workload=default_wl)
+        if frame_mode and roof is not None:
+            roof["eval_passes"] = eval_pass_roofline(eval_passes)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "adapt":
         cpu = cpu_baseline(net, args.height, args.width)
@@ -426,6 +463,9 @@ def main():
             line["roofline"] = roof
             if sec is not None:
                 line["roofline_hbm"] = sec           # the HBM-bound half of north_star: the photometric pipeline
+            ev = roof.pop("eval_passes", None)
+            if ev is not None:
+                line["roofline_eval_passes"] = ev    # --mode frame: the conv engine inside the per-frame evaluation passes
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -30,7 +30,7 @@ rm -rf gpurun_out/pmc_mfma
 python3 bench.py --mode train --no-cpu-baseline 2>/dev/null | line > $OUT/${R}_bench_n1_configs1_pretrain.json
 python3 bench.py --per-gpu-batch 4 --no-cpu-baseline 2>/dev/null | line > $OUT/${R}_bench_n1_configs3_slice.json
 python3 bench.py --mode train --encoder 101 --height 1024 --width 2048 --per-gpu-batch 2 --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | line > $OUT/${R}_bench_n1_configs4_slice.json
-python3 bench.py --mode frame --no-cpu-baseline --no-roofline 2>/dev/null | line > $OUT/${R}_bench_n1_frame.json
+python3 bench.py --mode frame --no-cpu-baseline 2>/dev/null | line > $OUT/${R}_bench_n1_frame.json
 python3 bench.py --yaml-faithful --no-cpu-baseline --no-roofline 2>/dev/null | line > $OUT/${R}_bench_n1_yaml_faithful.json
 python3 tools/peaks.py --json $OUT/${R}_peaks.json > /dev/null 2>&1
 python3 tools/conv_layers.py --json $OUT/${R}_conv_layers.json > $OUT/${R}_conv_layers.txt 2>/dev/null
