@@ -72,6 +72,59 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(int iters, int random, u
     out[tid] = s;
 }
 
+// What a SIMD does with vector ALU work next to a matrix-core stream (codeps_diag_mfma_valu): waves 0-3 issue 16
+// v_mfma_f32_32x32x16_bf16 per iteration on changing register operands; V v_fma_f32 per MFMA are issued EITHER by the same wave,
+// interleaved (OTHER = 0), OR by a second wave on the same SIMD (waves 4-7 of a 512-thread block, OTHER = 1) that runs nothing else.
+template <int V, int OTHER>
+__global__ __launch_bounds__(OTHER ? 512 : 256) void mfma_valu_kernel(int iters, unsigned seed, float* __restrict__ out) {
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    float x[8], ca = unit(mix(seed + tid)), cb = unit(mix(seed * 7 + tid));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = unit(mix(seed * 3 + tid * 8 + e));
+    if (OTHER && threadIdx.x >= 256) {                       // the vector-ALU wave: 16 * V fma per iteration, nothing else
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int v = 0; v < V; ++v) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[v & 7]) : "v"(ca), "v"(cb));
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += x[e];
+        out[tid] = s;
+        return;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[q][e] = (__bf16)unit(mix(seed + tid * 64 + q * 16 + e));
+            b[q][e] = (__bf16)unit(mix(seed * 3 + tid * 64 + q * 16 + e + 8));
+        }
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(u + (u >> 2)) & 3], b[(u >> 2) & 3], acc[u & 3], 0, 0, 0);
+            if (!OTHER) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[v & 7]) : "v"(ca), "v"(cb));
+            }
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += x[e];
+    out[tid] = s;
+}
+
 __global__ __launch_bounds__(256) void triad_kernel(const f32x4* __restrict__ b, const f32x4* __restrict__ c, float s, long long n4,
                                                     f32x4* __restrict__ a) {
     const long long stride = (long long)gridDim.x * 256;
@@ -220,6 +273,25 @@ extern "C" int codeps_diag_mfma_rate(int mode, int random_data, int blocks, int 
         else hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch);
     });
     CODEPS_CHECK_LAUNCH("mfma_rate_kernel");
+    return rc;
+}
+
+extern "C" int codeps_diag_mfma_valu(int valu_per_mfma, int other_wave, int blocks, int iters, int reps, float* scratch, float* ms_per_launch,
+                                     codeps_stream_t stream) {
+    CODEPS_REQUIRE((valu_per_mfma == 0 || valu_per_mfma == 2 || valu_per_mfma == 4 || valu_per_mfma == 8 || valu_per_mfma == 16) && blocks > 0 &&
+                       iters > 0 && reps > 0 && scratch && ms_per_launch,
+                   CODEPS_ERR_ARG, "codeps_diag_mfma_valu: bad argument (valu_per_mfma in {0, 2, 4, 8, 16})");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = timed(st, reps, ms_per_launch, [&]() {
+#define MV(V_, O_) hipLaunchKernelGGL((mfma_valu_kernel<V_, O_>), dim3(blocks), dim3(O_ ? 512 : 256), 0, st, iters, 0x9E3779B9u, scratch)
+        if (!other_wave) {
+            switch (valu_per_mfma) { case 0: MV(0, 0); break; case 2: MV(2, 0); break; case 4: MV(4, 0); break; case 8: MV(8, 0); break; default: MV(16, 0); }
+        } else {
+            switch (valu_per_mfma) { case 0: MV(0, 1); break; case 2: MV(2, 1); break; case 4: MV(4, 1); break; case 8: MV(8, 1); break; default: MV(16, 1); }
+        }
+#undef MV
+    });
+    CODEPS_CHECK_LAUNCH("mfma_valu_kernel");
     return rc;
 }
 

@@ -24,6 +24,12 @@ int codeps_diag_mfma_rate(int mode, int random_data, int blocks, int iters, int 
                           float* ms_per_launch, codeps_stream_t stream);
 int codeps_diag_stream_triad(float* a, const float* b, const float* c, long long n, int reps, float* ms_per_launch,
                              codeps_stream_t stream);
+/* codeps_diag_mfma_valu: vector-ALU work next to a matrix-core stream on one SIMD.  Waves 0-3 of every block issue 16 * iters
+ *   v_mfma_f32_32x32x16_bf16 on changing register operands; `valu_per_mfma` (0, 2, 4, 8 or 16) v_fma_f32 per MFMA are issued by
+ *   the same wave between the MFMAs (other_wave 0) or by a second wave of the same SIMD that does nothing else (other_wave 1:
+ *   512-thread blocks).  scratch: blocks * 512 floats.  Returns the time per launch. */
+int codeps_diag_mfma_valu(int valu_per_mfma, int other_wave, int blocks, int iters, int reps, float* scratch, float* ms_per_launch,
+                          codeps_stream_t stream);
 /* Pre-split activations and their first consumer (csrc/conv1x1s.hip; DESIGN.md 8: the measurement behind "activations kept in the
  * matrix cores' operand form between the frozen encoder's layers").
  * codeps_split_pack_rows: x fp32 [rows][row_stride] (first `channels` of every row, channels % 32 == 0) ->
