@@ -12,7 +12,9 @@ vendored and not installed here, so this file restates the *published* torchvisi
   - Bottleneck v1.5 (expansion 4): 1x1 BN ReLU 3x3(stride s) BN ReLU 1x1 BN (+identity) ReLU
   - downsample = conv1x1(stride s, no bias)+BN iff s != 1 or inplanes != planes*expansion
   - zero_init_residual=False
-PARITY UNPINNED against a reference run (no torchvision here); pinned by self-consistency tests only.
+PARITY UNPINNED against a reference run (no torchvision here); pinned by self-consistency tests and, as a second opinion,
+against transformers.ResNetModel (an independent implementation of the same architecture) loaded with these weights:
+tests/test_trunk_crosscheck_cpu.py.
 """
 from collections import OrderedDict
 
