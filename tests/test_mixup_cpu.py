@@ -108,3 +108,27 @@ def test_kornia_distance_transform_restatement_properties():
     ring = (cheb - 1) * 3 // 2
     assert ((d - ring)[m == 0] > 0).all() and ((d - ring)[m == 0] < 1.42).all()
     assert (om.kornia_distance_transform(np.zeros((6, 9), np.float32)) == 0).all()
+
+
+def test_restated_kornia_distance_transform_against_scipy():
+    """oracle.mixup.kornia_distance_transform restates kornia.contrib.distance_transform (kornia is absent: parity unpinned).
+    scipy IS installed and pins the structural claim the closed form of the device path relies on (csrc/mixup.hip:
+    codeps_conf_place): a background pixel is reached in iteration D - 1, D its CHEBYSHEV distance to the nearest object pixel,
+    and takes the value (D - 1) * 3 // 2 (kornia's `i * kernel_size // 2`: 0, 1, 3, 4, 6, ... -- not a Euclidean distance) plus a
+    soft-min correction in (0, 1.5]."""
+    import numpy as np
+    from scipy import ndimage
+    from oracle import mixup as M
+    rng = np.random.default_rng(3)
+    for case in range(4):
+        img = np.zeros((48, 80), np.float32)
+        for _ in range(3 + case):
+            y, x = rng.integers(2, 44), rng.integers(2, 76)
+            img[y:y + rng.integers(1, 6), x:x + rng.integers(1, 8)] = 1.0
+        got = M.kornia_distance_transform(img)
+        cheb = ndimage.distance_transform_cdt(img == 0, metric="chessboard")
+        bg = img == 0
+        assert np.all(got[~bg] == 0)
+        base = (cheb[bg] - 1) * 3 // 2
+        corr = got[bg] - base
+        assert corr.min() > 0 and corr.max() <= 1.5 + 1e-5, (corr.min(), corr.max())
