@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
 LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 6
+ABI_VERSION = 7
 DIAG_LIB_PATH = os.path.join(_HERE, "libcodeps_diag.so")
 
 _lib = None
@@ -167,7 +167,7 @@ SIGNATURES = {
     "codeps_depth_key_weights": (c_int, [P, P, P, I, I, P, I, c_float, c_float, I, P, I, P, P]),
     "codeps_weighted_sum_fwd": (c_int, [P, P, P, I, P, P, P]),
     "codeps_weighted_sum_bwd": (c_int, [P, P, P, I, P, P, P]),
-    "codeps_disp_head_fwd": (c_int, [P, P, P, I, I, I, I, c_float, c_float, P, P, P]),
+    "codeps_disp_head_fwd": (c_int, [P, P, P, I, I, I, I, c_float, c_float, P, P, P, P]),
     "codeps_disp_head_bwd_workspace_bytes": (c_size_t, [I, I, I]),
     "codeps_disp_head_bwd": (c_int, [P, P, P, P, P, I, I, I, I, c_float, c_float, P, P, P, I, P, c_size_t, P]),
     "codeps_upconv16_workspace_bytes": (c_size_t, []),
@@ -185,6 +185,8 @@ DIAG_SIGNATURES = {
     "codeps_diag_stream_triad": (c_int, [P, P, P, LL, I, P, P]),
     "codeps_diag_mfma_valu": (c_int, [I, I, I, I, I, P, P, P]),
     "codeps_diag_feed_rate": (c_int, [I, I, I, I, I, P, LL, P, P, P]),
+    "codeps_diag_mfma_rate_clock": (c_int, [I, I, I, I, I, P, P, P, P]),
+    "codeps_diag_mfma_valu_clock": (c_int, [I, I, I, I, I, P, P, P, P]),
     "codeps_split_pack_rows": (c_int, [P, LL, I, I, P, P]),
     "codeps_conv1x1_split_fwd": (c_int, [P, LL, I, I, P, P, P, P, I, P, P]),
 }

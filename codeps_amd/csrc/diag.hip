@@ -23,8 +23,20 @@ __device__ __forceinline__ unsigned mix(unsigned x) {
 // a value in [-1, 1) with a full 8-bit bf16 significand
 __device__ __forceinline__ float unit(unsigned h) { return (float)(int)(h & 0xFFFFu) * (1.f / 32768.f) - 1.f; }
 
+// In-kernel clock (MI355X_MICROARCH.md "DVFS give-back" item 6): s_memtime counts shader cycles, s_memrealtime a constant 100 MHz, so
+// (t1 - t0) / (r1 - r0) x 100 MHz is the clock the chip HELD around the loop and (t1 - t0) / #MFMA the cycles per MFMA -- neither
+// depends on an assumed frequency.  `stamps` (nullable; nothing else in the kernel reads it): per wave [4] = t0, r0, t1, r1.
+__device__ __forceinline__ void clock_stamp(unsigned long long* __restrict__ dst) {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): the stamps are back
+    __builtin_amdgcn_sched_barrier(0);
+    if ((threadIdx.x & 63) == 0) { dst[0] = t; dst[1] = r; }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(256) void mfma_rate_kernel(int iters, int random, unsigned seed, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void mfma_rate_kernel(int iters, int random, unsigned seed, float* __restrict__ out,
+                                                        unsigned long long* __restrict__ stamps = nullptr) {
     const unsigned tid = blockIdx.x * 256 + threadIdx.x;
     constexpr int POOL = 4;
     f32x16 acc32[4];
@@ -47,6 +59,7 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(int iters, int random, u
         fa[q] = random ? unit(mix(seed + tid * 8 + q)) : 0.f;
         fb[q] = random ? unit(mix(seed * 5 + tid * 8 + q + 4)) : 0.f;
     }
+    if (stamps) clock_stamp(stamps + (size_t)(tid >> 6) * 4);
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) {
 #pragma unroll
@@ -62,6 +75,8 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(int iters, int random, u
                 acc16[u & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(u + (u >> 2)) & 3], b[(u >> 2) & 3], acc16[u & 7], 0, 0, 0);
         }
     }
+    // (the closing stamp may precede the retirement of the last MFMA by its latency, <= 64 of the loop's ~10^6 cycles)
+    if (stamps) clock_stamp(stamps + (size_t)(tid >> 6) * 4 + 2);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -76,7 +91,8 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(int iters, int random, u
 // v_mfma_f32_32x32x16_bf16 per iteration on changing register operands; V v_fma_f32 per MFMA are issued EITHER by the same wave,
 // interleaved (OTHER = 0), OR by a second wave on the same SIMD (waves 4-7 of a 512-thread block, OTHER = 1) that runs nothing else.
 template <int V, int OTHER>
-__global__ __launch_bounds__(OTHER ? 512 : 256) void mfma_valu_kernel(int iters, unsigned seed, float* __restrict__ out) {
+__global__ __launch_bounds__(OTHER ? 512 : 256) void mfma_valu_kernel(int iters, unsigned seed, float* __restrict__ out,
+                                                                      unsigned long long* __restrict__ stamps = nullptr) {
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
     float x[8], ca = unit(mix(seed + tid)), cb = unit(mix(seed * 7 + tid));
 #pragma unroll
@@ -106,6 +122,8 @@ __global__ __launch_bounds__(OTHER ? 512 : 256) void mfma_valu_kernel(int iters,
             a[q][e] = (__bf16)unit(mix(seed + tid * 64 + q * 16 + e));
             b[q][e] = (__bf16)unit(mix(seed * 3 + tid * 64 + q * 16 + e + 8));
         }
+    // stamps: the MFMA waves only (wave w of block b -> slot 4 b + w)
+    if (stamps) clock_stamp(stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4);
     for (int it = 0; it < iters; ++it)
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -115,6 +133,7 @@ __global__ __launch_bounds__(OTHER ? 512 : 256) void mfma_valu_kernel(int iters,
                 for (int v = 0; v < V; ++v) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[v & 7]) : "v"(ca), "v"(cb));
             }
         }
+    if (stamps) clock_stamp(stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + 2);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -268,11 +287,44 @@ extern "C" int codeps_diag_mfma_rate(int mode, int random_data, int blocks, int 
     const double per_mfma = mode == 0 ? 2.0 * 32 * 32 * 16 : (mode == 1 ? 2.0 * 32 * 32 * 2 : 2.0 * 16 * 16 * 32);
     *flops_per_launch = per_mfma * 16.0 * iters * 4.0 * blocks;            // 16 MFMAs per iteration, 4 waves per block
     int rc = timed(st, reps, ms_per_launch, [&]() {
-        if (mode == 0) hipLaunchKernelGGL(mfma_rate_kernel<0>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch);
-        else if (mode == 1) hipLaunchKernelGGL(mfma_rate_kernel<1>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch);
-        else hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch);
+        if (mode == 0) hipLaunchKernelGGL(mfma_rate_kernel<0>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch, (unsigned long long*)nullptr);
+        else if (mode == 1) hipLaunchKernelGGL(mfma_rate_kernel<1>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch, (unsigned long long*)nullptr);
+        else hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch, (unsigned long long*)nullptr);
     });
     CODEPS_CHECK_LAUNCH("mfma_rate_kernel");
+    return rc;
+}
+
+extern "C" int codeps_diag_mfma_rate_clock(int mode, int random_data, int blocks, int iters, int reps, float* scratch, unsigned long long* stamps,
+                                           float* ms_per_launch, codeps_stream_t stream) {
+    CODEPS_REQUIRE(mode >= 0 && mode <= 2 && blocks > 0 && iters > 0 && reps > 0 && scratch && stamps && ms_per_launch, CODEPS_ERR_ARG,
+                   "codeps_diag_mfma_rate_clock: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = timed(st, reps, ms_per_launch, [&]() {
+        if (mode == 0) hipLaunchKernelGGL(mfma_rate_kernel<0>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch, stamps);
+        else if (mode == 1) hipLaunchKernelGGL(mfma_rate_kernel<1>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch, stamps);
+        else hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(blocks), dim3(256), 0, st, iters, random_data, 0x9E3779B9u, scratch, stamps);
+    });
+    CODEPS_CHECK_LAUNCH("mfma_rate_kernel (stamped)");
+    return rc;
+}
+
+extern "C" int codeps_diag_mfma_valu_clock(int valu_per_mfma, int other_wave, int blocks, int iters, int reps, float* scratch,
+                                           unsigned long long* stamps, float* ms_per_launch, codeps_stream_t stream) {
+    CODEPS_REQUIRE((valu_per_mfma == 0 || valu_per_mfma == 2 || valu_per_mfma == 4 || valu_per_mfma == 8 || valu_per_mfma == 16) && blocks > 0 &&
+                       iters > 0 && reps > 0 && scratch && stamps && ms_per_launch,
+                   CODEPS_ERR_ARG, "codeps_diag_mfma_valu_clock: bad argument (valu_per_mfma in {0, 2, 4, 8, 16})");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = timed(st, reps, ms_per_launch, [&]() {
+#define MV(V_, O_) hipLaunchKernelGGL((mfma_valu_kernel<V_, O_>), dim3(blocks), dim3(O_ ? 512 : 256), 0, st, iters, 0x9E3779B9u, scratch, stamps)
+        if (!other_wave) {
+            switch (valu_per_mfma) { case 0: MV(0, 0); break; case 2: MV(2, 0); break; case 4: MV(4, 0); break; case 8: MV(8, 0); break; default: MV(16, 0); }
+        } else {
+            switch (valu_per_mfma) { case 0: MV(0, 1); break; case 2: MV(2, 1); break; case 4: MV(4, 1); break; case 8: MV(8, 1); break; default: MV(16, 1); }
+        }
+#undef MV
+    });
+    CODEPS_CHECK_LAUNCH("mfma_valu_kernel (stamped)");
     return rc;
 }
 
@@ -283,7 +335,7 @@ extern "C" int codeps_diag_mfma_valu(int valu_per_mfma, int other_wave, int bloc
                    CODEPS_ERR_ARG, "codeps_diag_mfma_valu: bad argument (valu_per_mfma in {0, 2, 4, 8, 16})");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = timed(st, reps, ms_per_launch, [&]() {
-#define MV(V_, O_) hipLaunchKernelGGL((mfma_valu_kernel<V_, O_>), dim3(blocks), dim3(O_ ? 512 : 256), 0, st, iters, 0x9E3779B9u, scratch)
+#define MV(V_, O_) hipLaunchKernelGGL((mfma_valu_kernel<V_, O_>), dim3(blocks), dim3(O_ ? 512 : 256), 0, st, iters, 0x9E3779B9u, scratch, (unsigned long long*)nullptr)
         if (!other_wave) {
             switch (valu_per_mfma) { case 0: MV(0, 0); break; case 2: MV(2, 0); break; case 4: MV(4, 0); break; case 8: MV(8, 0); break; default: MV(16, 0); }
         } else {

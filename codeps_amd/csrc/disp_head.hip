@@ -46,7 +46,7 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ w, float*
 
 __global__ __launch_bounds__(256) void disp_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                             int H, int W, int tiles_x, float min_disp, float max_disp,
-                                                            float* __restrict__ disp, float* __restrict__ depth) {
+                                                            float* __restrict__ disp, float* __restrict__ depth, float* __restrict__ logit) {
     __shared__ f32x4 xs[HPIX * PITCH4];
     __shared__ __attribute__((aligned(16))) float ws[NW];
     const int b = blockIdx.y, y0 = (blockIdx.x / tiles_x) * TH, x0 = (blockIdx.x % tiles_x) * TW;
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void disp_head_fwd_kernel(const float* __restr
     }
     const size_t r = ((size_t)b * H + y) * W + xx;
     const float s = 1.f / (1.f + expf(-acc));
+    if (logit) logit[r] = acc;          // the pre-sigmoid value (models/depth_head.py:73), for parity checks in logit space
     disp[r] = s;
     depth[r] = 1.f / (min_disp + (max_disp - min_disp) * s);
 }
@@ -191,12 +192,12 @@ __global__ __launch_bounds__(256) void disp_head_dw_finish_kernel(const float* _
 }  // namespace
 
 extern "C" int codeps_disp_head_fwd(const float* x, const float* weight, const float* bias, int batch, int h, int w, int c, float min_depth,
-                                    float max_depth, float* disp, float* depth, codeps_stream_t stream) {
+                                    float max_depth, float* disp, float* depth, float* logit, codeps_stream_t stream) {
     CODEPS_REQUIRE(x && weight && disp && depth && batch > 0 && h >= 2 && w >= 2, CODEPS_ERR_ARG, "codeps_disp_head_fwd: bad arguments");
     CODEPS_REQUIRE(c == C, CODEPS_ERR_ARG, "codeps_disp_head_fwd: %d input channels (the decoder's last stage has %d)", c, C);
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     hipLaunchKernelGGL(disp_head_fwd_kernel, dim3(tiles_x * tiles_y, batch), dim3(256), 0, (hipStream_t)stream, x, weight, bias, h, w, tiles_x,
-                       (float)(1.0 / (double)max_depth), (float)(1.0 / (double)min_depth), disp, depth);
+                       (float)(1.0 / (double)max_depth), (float)(1.0 / (double)min_depth), disp, depth, logit);
     CODEPS_CHECK_LAUNCH("disp_head_fwd_kernel");
     return CODEPS_OK;
 }

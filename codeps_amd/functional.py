@@ -231,6 +231,12 @@ _pack_cache_train = {}     # trainable parameters: PERSISTENT pack buffers, re-f
 _weights_epoch = [0]       # bumped by every in-place optimizer update done through this library
 
 
+def _is_volatile(t):
+    """True for tensors whose VALUES may change without their torch version changing: trainable parameters (the fused optimizer
+    writes them through raw pointers), teacher views of the optimizer's buffers, and anything derived from those per epoch."""
+    return bool(t.requires_grad or getattr(t, "_codeps_volatile", False))
+
+
 def invalidate_weight_cache(everything=False):
     """Call after modifying parameters in place by means torch cannot see (raw-pointer kernels), and immediately BEFORE
     capturing a HIP graph of a step: the packs of trainable parameters keep their buffers (a captured graph reads those
@@ -640,7 +646,9 @@ def stem3_weight(weight):
     K layout of stem3_conv2d.  Cached per (tensor, version)."""
     key = id(weight)
     hit = _stem3_cache.get(key)
-    stamp = (weight.data_ptr(), weight._version)
+    # a trainable conv1 reaches this form during validation (eval mode under no_grad): the fused optimizer writes p.data through
+    # raw pointers, so only the weights epoch tells that the values changed
+    stamp = (weight.data_ptr(), weight._version, _weights_epoch[0] if _is_volatile(weight) else 0)
     if hit is not None and hit[0]() is weight and hit[1] == stamp:
         return hit[2]
     co, ci, kh, kw = weight.shape
@@ -701,10 +709,14 @@ def chain_weights(w_expand, scale2, shift2, w_reduce):
     w2 rows = the pre-split expand pack row (8 x [3 pieces][32 bf16]) + 16 bytes (scale, shift, 0, 0); w3 = the pre-split pack
     of the reduce weights with the permuted k order."""
     key = (id(w_expand), id(w_reduce))
+    # trainable (or teacher-view) weights are rewritten through raw pointers by the fused optimizer: their entry lives for one
+    # weights epoch.  The folded BatchNorm is identified by OBJECT (the entry keeps scale2 / shift2 alive, so their addresses
+    # cannot be handed to a newer fold while the entry exists)
+    volatile = _is_volatile(w_expand) or _is_volatile(w_reduce) or _is_volatile(scale2) or _is_volatile(shift2)
     stamp = (w_expand._version, w_reduce._version, scale2._version, shift2._version, w_expand.data_ptr(), w_reduce.data_ptr(),
-             scale2.data_ptr())
+             _weights_epoch[0] if volatile else 0)
     hit = _chain_cache.get(key)
-    if hit is not None and hit[0] == stamp and hit[3]() is w_expand and hit[4]() is w_reduce:
+    if hit is not None and hit[0] == stamp and hit[3]() is w_expand and hit[4]() is w_reduce and hit[5] is scale2 and hit[6] is shift2:
         return hit[1], hit[2]
     n2, kmid = w_expand.shape[:2]
     c3 = w_reduce.shape[0]
@@ -722,7 +734,7 @@ def chain_weights(w_expand, scale2, shift2, w_reduce):
         w3p = _f32c(w_reduce.detach())[:, _chain_perm(n2, dev)].contiguous()
         wf3, _ = pack_weights(w3p, c3, n2, False)
         w3 = wf3.view(torch.uint8)[c3 * n2 * 4:][:c3 * n2 * 6].clone()
-    _chain_cache[key] = (stamp, w2, w3, _weak(w_expand, _chain_cache, key), weakref.ref(w_reduce))
+    _chain_cache[key] = (stamp, w2, w3, _weak(w_expand, _chain_cache, key), weakref.ref(w_reduce), scale2, shift2)
     return w2, w3
 
 
@@ -1144,7 +1156,7 @@ _dw_cache = {}
 
 def _dw_pack(weight, c):
     """Depthwise weight [C,1,5,5] -> [25][Cp] tap-major pack; cached for frozen weights (identity + version checked)."""
-    frozen = not weight.requires_grad
+    frozen = not _is_volatile(weight)
     key = (id(weight), c)
     if frozen:
         hit = _dw_cache.get(key)
@@ -1342,7 +1354,7 @@ class _DispHead(torch.autograd.Function):
     """ReflectionPad2d(1) -> Conv2d(16, 1, 3) -> Sigmoid -> disp_to_depth in one kernel each way (C ABI: codeps_disp_head_*)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, min_depth, max_depth):
+    def forward(ctx, x, weight, bias, min_depth, max_depth, logit_out):
         require_cuda(x, weight)
         x = x.contiguous()
         b, h, w, c = x.shape
@@ -1350,8 +1362,10 @@ class _DispHead(torch.autograd.Function):
         bs = None if bias is None else _f32c(bias.detach())
         disp = torch.empty(b, 1, h, w, dtype=torch.float32, device=x.device)
         depth = torch.empty_like(disp)
-        check(lib().codeps_disp_head_fwd(ptr(x), ptr(wt), ptr(bs), b, h, w, c, min_depth, max_depth, ptr(disp), ptr(depth), stream_ptr()),
-              "codeps_disp_head_fwd")
+        if logit_out is not None and (tuple(logit_out.shape) != (b, 1, h, w) or logit_out.dtype != torch.float32 or not logit_out.is_contiguous()):
+            raise CodepsHipError("disp_head: logit_out must be a contiguous float32 [B,1,H,W] tensor")
+        check(lib().codeps_disp_head_fwd(ptr(x), ptr(wt), ptr(bs), b, h, w, c, min_depth, max_depth, ptr(disp), ptr(depth), ptr(logit_out),
+                                         stream_ptr()), "codeps_disp_head_fwd")
         ctx.save_for_backward(x, wt, disp)
         ctx.meta = (min_depth, max_depth, bias is not None)
         ctx.w_sink = grad_sink(weight) if weight.requires_grad else None
@@ -1383,14 +1397,14 @@ class _DispHead(torch.autograd.Function):
         elif ctx.w_sink is not None and dw is not None:
             ctx.w_sink.add_(dw.view_as(ctx.w_sink))
             dw = None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def disp_head(x, weight, bias, min_depth=0.1, max_depth=100.0):
+def disp_head(x, weight, bias, min_depth=0.1, max_depth=100.0, logit_out=None):
     """The depth decoder's output stage (models/depth_head.py:44-59,73-77) on NHWC features x [B,H,W,16]: reflection-padded
     3x3 convolution to one channel, sigmoid, disp_to_depth -> (depth, disp), both [B,1,H,W]; the 16-channel tensor is moved once
-    each way."""
-    return _DispHead.apply(x, weight, bias, float(min_depth), float(max_depth))
+    each way.  logit_out (optional, [B,1,H,W]): receives the pre-sigmoid convolution output (parity checks in logit space)."""
+    return _DispHead.apply(x, weight, bias, float(min_depth), float(max_depth), logit_out)
 
 
 # ---------------------------------------------------------------------------------------- pose

@@ -14,7 +14,12 @@ _fold_cache = {}
 _nbt_pending = []
 
 
+_stats_epoch = [0]
+
+
 def _count_batch(bn, n):
+    bn._codeps_stats_live = True          # its running statistics are written by kernels from now on (folded_bn)
+    _stats_epoch[0] += 1
     if bn.num_batches_tracked is not None:
         _nbt_pending.append((bn.num_batches_tracked, n))
 
@@ -29,13 +34,19 @@ def flush_bn_counters():
 def folded_bn(bn: nn.BatchNorm2d):
     """(scale, shift) of an eval-mode BatchNorm, cached while its tensors are unchanged."""
     key = id(bn)
+    # values that change behind torch's version counters: affine parameters the fused optimizer writes through raw pointers
+    # (trainable, or teacher views), running statistics a train-mode forward of this library has written (_count_batch marks the
+    # module).  Such a fold lives for one weights epoch; a frozen BatchNorm's fold lives as long as its tensors are unchanged.
+    volatile = (F._is_volatile(bn.weight) or F._is_volatile(bn.bias) or getattr(bn, "_codeps_stats_live", False))
     ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr())
+           bn.weight.data_ptr(), (F._weights_epoch[0], _stats_epoch[0]) if volatile else 0)
     hit = _fold_cache.get(key)
     if hit is not None and hit[0] == ver and hit[3]() is bn:
         return hit[1], hit[2]
     with torch.no_grad():
         scale, shift = F.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    if volatile:
+        scale._codeps_volatile = shift._codeps_volatile = True
     _fold_cache[key] = (ver, scale, shift, weakref.ref(bn, lambda _r, k=key: _fold_cache.pop(k, None)))
     return scale, shift
 

@@ -59,6 +59,9 @@ class DepthHead(nn.Module):
         for s in self.scales:       # scales 1..3 exist for state_dict compatibility; nothing reads them
             self.dispconvs[str(s)] = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(int(self.num_ch_dec[s]), 1, 3))
         self.sigmoid = nn.Sigmoid()
+        # parity instrumentation (off by default, not part of the reference's surface): a list here makes every forward append its
+        # pre-sigmoid disparity logits [B,1,H,W] (models/depth_head.py:73), written by the SAME kernel launch that produces depth
+        self.logit_log = None
 
     @staticmethod
     def disp_to_depth(disp: Tensor, min_depth: float = 0.1, max_depth: float = 100) -> Tensor:
@@ -70,10 +73,15 @@ class DepthHead(nn.Module):
         x, _ = _run_decoder(self, in_feats)
         conv = self.dispconvs["0"][1]
         if conv.in_channels == 16 and x.shape[-1] == 16:
-            depth_map, disp_map = F.disp_head(x, conv.weight, conv.bias)    # padded conv + sigmoid + disp_to_depth, one pass each way
+            tap = None if self.logit_log is None else x.new_empty(x.shape[0], 1, x.shape[1], x.shape[2])
+            depth_map, disp_map = F.disp_head(x, conv.weight, conv.bias, logit_out=tap)    # padded conv + sigmoid + disp_to_depth, one pass each way
+            if tap is not None:
+                self.logit_log.append(tap)
         else:
             logits = F.conv2d(x, conv.weight, conv.bias, pad=1, pad_mode="reflect")
             depth_map, disp_map = F.disp_depth(logits)      # sigmoid + disp_to_depth, one kernel
+            if self.logit_log is not None:
+                self.logit_log.append(F.to_nchw(logits.detach(), 1).clone())
         # detached: a module attribute that holds the autograd graph of the last call keeps its AccumulateGrad nodes (and
         # their streams) alive across iterations, which breaks HIP-graph capture of the next step
         self.outputs = {0: disp_map.detach()}

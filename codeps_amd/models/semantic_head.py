@@ -24,6 +24,9 @@ class SemanticHead(nn.Module):
         else:
             self.semconv = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(int(self.num_ch_dec[0]), num_classes, 3))
         self.softmax = nn.Softmax(dim=1)
+        # parity instrumentation (off by default): a list here makes every forward append its pre-softmax logits [B,C,H,W]
+        # (models/semantic_head.py:72-74, `sem_feat`)
+        self.logit_log = None
 
     def forward_nhwc(self, in_feats):
         """-> NHWC probabilities [B,H,W,pad16(num_classes)] (padding channels are 0)."""
@@ -38,6 +41,8 @@ class SemanticHead(nn.Module):
         else:
             conv = self.semconv[1]
             logits = F.conv2d(x, conv.weight, conv.bias, pad=1, pad_mode="reflect")
+        if self.logit_log is not None:
+            self.logit_log.append(F.to_nchw(logits.detach(), self.num_classes).clone())
         return F.channel_softmax(logits, self.num_classes)
 
     def forward(self, in_feats) -> Tensor:

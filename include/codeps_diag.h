@@ -30,6 +30,14 @@ int codeps_diag_stream_triad(float* a, const float* b, const float* c, long long
  *   512-thread blocks).  scratch: blocks * 512 floats.  Returns the time per launch. */
 int codeps_diag_mfma_valu(int valu_per_mfma, int other_wave, int blocks, int iters, int reps, float* scratch, float* ms_per_launch,
                           codeps_stream_t stream);
+/* The same two loops with IN-KERNEL CLOCK STAMPS (MI355X_MICROARCH.md "DVFS give-back" item 6): every MFMA wave stamps s_memtime (shader
+ *   cycles) and s_memrealtime (100 MHz) before and after its loop into stamps[wave][4] = t0, r0, t1, r1 (uint64; blocks * 4 waves; a
+ *   buffer nothing else reads).  cycles per MFMA = (t1 - t0) / (16 * iters); clock held = (t1 - t0) / (r1 - r0) x 100 MHz.  No assumed
+ *   frequency enters.  Run >= 2 s of back-to-back launches on random data before reading the stamps of the last one (tools/clock_cycles.py). */
+int codeps_diag_mfma_rate_clock(int mode, int random_data, int blocks, int iters, int reps, float* scratch, unsigned long long* stamps,
+                                float* ms_per_launch, codeps_stream_t stream);
+int codeps_diag_mfma_valu_clock(int valu_per_mfma, int other_wave, int blocks, int iters, int reps, float* scratch,
+                                unsigned long long* stamps, float* ms_per_launch, codeps_stream_t stream);
 /* Pre-split activations and their first consumer (csrc/conv1x1s.hip; DESIGN.md 8: the measurement behind "activations kept in the
  * matrix cores' operand form between the frozen encoder's layers").
  * codeps_split_pack_rows: x fp32 [rows][row_stride] (first `channels` of every row, channels % 32 == 0) ->

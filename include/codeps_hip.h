@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* codeps_stream_t;
 
-int codeps_version(void);                 /* ABI version (5), bumped on any signature / buffer-contract change */
+int codeps_version(void);                 /* ABI version (7), bumped on any signature / buffer-contract change */
 const char* codeps_last_error(void);      /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------------------------------------
@@ -579,10 +579,11 @@ int codeps_panoptic_stats(const int* pan_gt, const int* pan_pred, int batch, int
 /* ------------------------------------------------------------------------------------------------
  * The depth decoder's disparity output in one pass each way (csrc/disp_head.hip): dispconvs["0"] = ReflectionPad2d(1) ->
  * Conv2d(16, 1, 3), Sigmoid, DepthHead.disp_to_depth (models/depth_head.py:44-59,73-77).  x [B][h][w][16] NHWC fp32, weight
- * [1][16][3][3] (OIHW), bias [1] (nullable); disp / depth [B][1][h][w].  _bwd: ddisp / ddepth [B][1][h][w] (either nullable)
+ * [1][16][3][3] (OIHW), bias [1] (nullable); disp / depth [B][1][h][w]; logit (nullable) [B][1][h][w] receives the pre-sigmoid
+ * convolution output (models/depth_head.py:73: the quantity north_star's "logits within 1e-3" is stated on).  _bwd: ddisp / ddepth [B][1][h][w] (either nullable)
  * -> dx [B][h][w][16] (nullable), dweight [1][16][3][3], dbias [1] (nullable; += when accumulate); deterministic. */
 int codeps_disp_head_fwd(const float* x, const float* weight, const float* bias, int batch, int h, int w, int c, float min_depth,
-                         float max_depth, float* disp, float* depth, codeps_stream_t stream);
+                         float max_depth, float* disp, float* depth, float* logit, codeps_stream_t stream);
 size_t codeps_disp_head_bwd_workspace_bytes(int batch, int h, int w);
 int codeps_disp_head_bwd(const float* x, const float* weight, const float* disp, const float* ddisp, const float* ddepth, int batch,
                          int h, int w, int c, float min_depth, float max_depth, float* dx, float* dweight, float* dbias,

@@ -5,13 +5,14 @@ numpy restatement of the maximize_diversity branch of ReplayBuffer.add / load_st
 the first overflow, one row / column replaced per later insertion) -- the device kernel maintains the matrix incrementally, so
 the tests also check that the two formulations agree.
 
-PARITY UNPINNED: the algorithm's search runs inside faiss (requirements.txt: faiss-gpu==1.7.2), which is neither vendored
-under the reference nor installed here, so the reference's `add` cannot be executed to produce golden vectors.  What this
-file restates of faiss is its published behaviour for the three calls the reference makes:
+PINNED (round 4) by tests/golden/replay.npz: the reference's OWN ReplayBuffer.add / save_state / load_state run frame by frame
+(tests/golden/make_golden.py::golden_replay) -- threshold test, two-phase similarity-matrix bookkeeping, eviction rule,
+previous-domain ids -- on a brute-force stand-in for the faiss calls it makes (tests/golden/_ref_import.py; faiss-gpu==1.7.2
+of requirements.txt is neither vendored nor installed).  A flat inner-product index IS exact brute force, so what stays
+unpinned of faiss is only the fp32 summation order inside its dot products; its published behaviour as restated here:
   * faiss.normalize_L2(x): x *= 1 / sqrt(<x, x>) per row when the norm is positive (fvec_renorm_L2);
   * IndexIDMap(IndexFlatIP): exact inner products against every stored vector, results sorted by decreasing score;
     add_with_ids appends, remove_ids deletes and keeps the order of the rest, id_map / reconstruct_n read in stored order.
-Anchored on the reference's call sites only (no golden vectors exist for this path in the reference's repository).
 """
 import numpy as np
 
@@ -75,12 +76,8 @@ class DiversityBuffer:
         if self.buffer_indices["target"].sum() + extra > self.target_buffer_size:
             n = self.index.ntotal
             if self.distance_matrix is None:                                   # replay_buffer.py:415-423
-                dist, match = self.index.search(self.index.vecs, n)
-                pos = {int(i): k for k, i in enumerate(self.index.ids)}
-                mat = np.empty((n, n), np.float32)
-                for i in range(n):
-                    mat[i, [pos[int(m)] for m in match[i]]] = dist[i]
-                self.distance_matrix, self.distance_matrix_indices = mat, self.index.ids.copy()
+                self.distance_matrix = self._pairwise_by_id()
+                self.distance_matrix_indices = self.index.ids.copy()
             else:                                                              # replay_buffer.py:425-437
                 fill = int(np.argwhere(self.distance_matrix_indices < 0)[0, 0])
                 a, b = self.index.search(feats, n)
@@ -98,6 +95,34 @@ class DiversityBuffer:
             else:
                 self.buffer_indices["target"][removed] = 0
         return True, removed, float(similarity)
+
+    def _pairwise_by_id(self):
+        """replay_buffer.py:416-420 / 491-494: all pairwise similarities, the columns of every row put in ASCENDING-ID order
+        (`dist_mat[i, matching[i].argsort()]`) while the rows -- and distance_matrix_indices -- stay in stored order.  The two orders
+        coincide whenever ids were stored in increasing order (every run that starts empty, and a loaded FULL state); they do not
+        when a partially filled previous-domain state (ids 10000 + idx) is topped up with new frames before the first overflow."""
+        n = self.index.ntotal
+        dist, match = self.index.search(self.index.vecs, n)
+        mat = np.empty((n, n), np.float32)
+        for i in range(n):
+            mat[i, :] = dist[i, np.argsort(match[i], kind="stable")]
+        return mat
+
+    def ids_stored_in_increasing_order(self):
+        return bool(np.all(np.diff(self.index.ids) > 0)) if self.index is not None else True
+
+    def load_state(self, target_samples_indices, features):
+        """replay_buffer.py:475-499: the previous domain's samples enter a fresh index under id 10000 + idx, vectors as stored;
+        a FULL loaded state gets its similarity matrix right away -- float64, with one spare row / column of -1 for the next frame."""
+        self.buffer_indices["prev_target"] = [10000 + int(i) for i in target_samples_indices]
+        self.index = _FlatIP(int(np.asarray(features[0]).size))
+        for idx, f in zip(target_samples_indices, features):
+            self.index.add_with_ids(np.asarray(f, np.float32).reshape(1, -1), [10000 + int(idx)])
+        if self.index.ntotal == self.target_buffer_size:
+            n = self.index.ntotal
+            self.distance_matrix_indices = np.append(self.index.ids.copy(), [-1])
+            self.distance_matrix = -np.ones((n + 1, n + 1))
+            self.distance_matrix[:n, :n] = self._pairwise_by_id()
 
     def eviction_margin(self):
         """Gap between the two largest eviction scores of the current matrix (None before the first overflow): decisions

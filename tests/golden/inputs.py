@@ -189,3 +189,17 @@ def panoptic_maps(batch, h, w, seed, num_classes=14, things=(9, 10, 11, 12, 13),
     pred = np.where(flip & (pred >= 0), ((pred // 1000 + 1) % num_classes) * 1000 + np.where(pred % 1000 > 0, 7, 0), pred)
     pred = np.where((pred >= 0) & (pred // 1000 < things[0]), (pred // 1000) * 1000, pred)   # stuff classes carry no instance id
     return torch.from_numpy(gt.astype(np.int32)), torch.from_numpy(pred.astype(np.int32))
+
+
+def replay_features(n, c, h, w, seed, clusters=5):
+    """n post-ReLU-like encoder maps [1, c, h, w] around a few cluster centres: some frames are near-duplicates of an earlier one
+    (the replay buffer rejects them: cosine similarity above the threshold), some are new (stored; evictions once it is full)."""
+    g = _rng(seed)
+    centres = np.abs(g.standard_normal((clusters, c, 1, 1))).astype(np.float32)
+    out = []
+    for _ in range(n):
+        k = int(g.integers(clusters))
+        spread = float(g.choice([0.05, 0.5]))
+        f = centres[k] * (1 + spread * g.standard_normal((1, c, 1, 1))) + 0.3 * g.standard_normal((1, c, h, w))
+        out.append(torch.from_numpy(np.maximum(f, 0).astype(np.float32)))
+    return out

@@ -343,6 +343,43 @@ def _build_net(seed, use_thing_mask, w, h, adaptation=False, src_wh=None, depth_
     return net
 
 
+class _LogitTap:
+    """north_star states its tolerance on LOGITS: forward hooks on the reference's own modules record the pre-sigmoid disparity
+    (models/depth_head.py:71-74: `self.dispconvs["0"](x)`) and the pre-softmax semantic features (models/semantic_head.py:72-74:
+    `sem_feat`) of every head call; `depth_logit` / `semantic_logit` pick the call that produced a given result tensor."""
+
+    def __init__(self, net):
+        self.disp, self.sem, self._h = [], [], []
+        self._h.append(net.depth_head.dispconvs["0"].register_forward_hook(lambda m, i, o: self.disp.append(o.detach().clone())))
+        sh = getattr(net, "semantic_head", None)
+        if sh is not None:
+            conv = sh.semconv_guda if sh.use_guda_fusion else sh.semconv
+            self._h.append(conv.register_forward_hook(lambda m, i, o: self.sem.append(o.detach().clone())))
+
+    def close(self):
+        for h in self._h:
+            h.remove()
+
+    def depth_logit(self, depth):
+        for lg in self.disp:
+            if lg.shape == depth.shape and torch.equal(DepthHead.disp_to_depth(torch.sigmoid(lg)), depth.detach()):
+                return lg
+        for lg in self.disp:                                  # the result may be one item of a batched call
+            if lg.shape[1:] == depth.shape[1:]:
+                d = DepthHead.disp_to_depth(torch.sigmoid(lg))
+                for b0 in range(0, lg.shape[0] - depth.shape[0] + 1):
+                    if torch.equal(d[b0:b0 + depth.shape[0]], depth.detach()):
+                        return lg[b0:b0 + depth.shape[0]]
+        raise AssertionError("no recorded disparity logit reproduces the result's depth map")
+
+    def semantic_logit(self, semantic):
+        want = semantic.detach().long()
+        for lg in self.sem:
+            if lg.shape[0] == want.shape[0] and lg.shape[-2:] == want.shape[-2:] and torch.equal(torch.softmax(lg, 1).argmax(1), want.reshape(lg.shape[0], *lg.shape[-2:])):
+                return lg
+        raise AssertionError("no recorded semantic logit reproduces the result's label map")
+
+
 def _sample(b, h, w, seed, labels=True):
     f0, fm, fp = gi.triplet(b, h, w, seed)
     d = {"rgb": {0: f0, -1: fm, 1: fp}, "camera_model": gi.intrinsics(b, h, w, seed)}
@@ -360,7 +397,9 @@ def golden_network(seed=51):
     net = _build_net(seed, True, w, h)
     sample = _sample(b, h, w, seed)
     torch.manual_seed(2000 + seed)
+    tap = _LogitTap(net)
     losses, result, _stats = net(sample, "train", [0, -1, 1], do_panoptic_fusion=True)
+    tap.close()
     wts = dict(depth_recon=10.0, depth_smth=0.001, semantic=1.0, center=20.0, offset=0.1, thing_mask=0.5)
     total = sum(wts[k] * v for k, v in losses.items() if v is not None and k in wts)
     total.backward()
@@ -372,6 +411,7 @@ def golden_network(seed=51):
     res["total"] = total
     for k in ("depth", "semantic", "center", "offset", "panoptic", "instance", "thing_mask"):
         res["res_" + k] = result[k]
+    res["res_disp_logit"], res["res_sem_logit"] = tap.depth_logit(result["depth"]), tap.semantic_logit(result["semantic"])
     for name in ("depth_head", "pose_head", "semantic_head", "instance_head", "backbone_po_depth",
                  "backbone_pose_sflow"):
         res["pgrad_" + name] = grad_stats(getattr(net, name))
@@ -392,7 +432,9 @@ def golden_config0(seed=71):
     net.eval()
     sample = _sample(b, h, w, seed, labels=False)
     torch.manual_seed(3000 + seed)
+    tap = _LogitTap(net)
     losses, result, _stats = net(sample, "train", [0, -1, 1], do_panoptic_fusion=False)
+    tap.close()
     wts = dict(depth_recon=10.0, depth_smth=0.001)
     total = sum(wts[k] * v for k, v in losses.items() if v is not None and k in wts)
     total.backward()
@@ -402,6 +444,7 @@ def golden_config0(seed=71):
             res["loss_" + k] = v
     res["total"] = total
     res["res_depth"] = result["depth"]
+    res["res_disp_logit"] = tap.depth_logit(result["depth"])
     for name in ("depth_head", "pose_head", "backbone_po_depth", "backbone_pose_sflow"):
         res["pgrad_" + name] = grad_stats(getattr(net, name))
     save("config0", **res)
@@ -426,9 +469,11 @@ def golden_adapt(seed=61):
     sem_gt = {"target": None, "target_replay": None, "source": data["source"]["semantic"],
               "cut_mixup": mix["semantic"]}
     sem_w = {"source": data["source"]["semantic_weights"]}
+    tap = _LogitTap(net)
     sem_losses, _cm, sem_pred = net.semantic_algo.adaptation(feats, net.semantic_head, sem_gt, sem_w)
     dl, _fl, depth_pred, transf, _om, _ = net.depth_algo.adaptation(
         images, feats, cm, net.depth_head, net.backbone_pose_sflow, net.pose_head, None)
+    tap.close()
     wts = dict(depth_recon=10.0, depth_smth=0.001, semantic_source=1.0, semantic_cut_mixup=1.0)
     total = 10.0 * dl["recon"] + 0.001 * dl["smth"] + sem_losses["source"] + sem_losses["cut_mixup"]
     total.backward()
@@ -439,6 +484,7 @@ def golden_adapt(seed=61):
            "loss_depth_recon": dl["recon"], "loss_depth_smth": dl["smth"],
            "loss_semantic_source": sem_losses["source"], "loss_semantic_cut_mixup": sem_losses["cut_mixup"],
            "total": total, "res_depth": depth_pred, "res_semantic": sem_pred,
+           "res_disp_logit": tap.depth_logit(depth_pred), "res_sem_logit": tap.semantic_logit(sem_pred),
            "res_semantic_margin": top2[:, 0] - top2[:, 1], "res_T0": transf[0], "res_T1": transf[1]}
     for name in ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"):
         res["pgrad_" + name] = grad_stats(getattr(net, name))
@@ -458,7 +504,9 @@ def golden_adapt_real(seed=63):
             "cut_mixup": gi.mixup_item(2, hs, ws, ht, wt, seed + 3)}
     torch.manual_seed(3000 + seed)
     np.random.seed(seed)
+    tap = _LogitTap(net)
     losses, result, _stats, out_data = net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
+    tap.close()
     wts = dict(depth_recon=10.0, depth_smth=0.001, semantic_source=1.0, semantic_cut_mixup=1.0, center_source=20.0, offset_source=0.1)
     live = OrderedDict((k, v.mean()) for k, v in losses.items() if v is not None and v.requires_grad)
     total = sum(wts[k] * v for k, v in live.items())
@@ -473,6 +521,7 @@ def golden_adapt_real(seed=63):
             res["loss_" + k] = v
     for k in ("depth", "semantic", "center", "offset", "panoptic", "instance", "image_features"):
         res["res_" + k] = result[k]
+    res["res_disp_logit"], res["res_sem_logit"] = tap.depth_logit(result["depth"]), tap.semantic_logit(result["semantic"])
     res["mix_rgb"], res["mix_semantic"] = out_data["cut_mixup"]["rgb"][0], out_data["cut_mixup"]["semantic"]
     for name in ("depth_head", "pose_head", "semantic_head", "backbone_pose_sflow"):
         res["pgrad_" + name] = grad_stats(getattr(net, name))
@@ -497,8 +546,12 @@ def golden_eval_infer(seed=67):
     res = {"meta": json.dumps({"h": h, "w": w, "hs": hs, "ws": ws, "seed": seed, "teacher_scale": 0.97})}
     teacher.eval()
     with torch.no_grad():
+        tap_t, tap_s = _LogitTap(teacher), _LogitTap(net)
         _, r_eval, s_eval = teacher(target, "eval", [0, -1, 1], True, True)
         _, r_inf, s_inf = net.eval()(target, "infer", [0, -1, 1], True, False)
+        tap_t.close(), tap_s.close()
+        res["eval_disp_logit"], res["eval_sem_logit"] = tap_t.depth_logit(r_eval["depth"]), tap_t.semantic_logit(r_eval["semantic"])
+        res["infer_disp_logit"], res["infer_sem_logit"] = tap_s.depth_logit(r_inf["depth"]), tap_s.semantic_logit(r_inf["semantic"])
         assert s_inf["sem_conf"] is None
         mix = gi.mixup_item(2, hs, ws, h, w, seed + 3)
         for k in ("semantic_pred_tgt_ema", "center_pred_tgt_ema", "offset_pred_tgt_ema"):
@@ -682,8 +735,109 @@ def golden_metrics():
     save("metrics", **res)
 
 
+# ------------------------------------------------------------------------------------------ replay buffer
+REPLAY_CASES = {   # tag: (capacity, channels, h, w, threshold, frames, seed)
+    "small": (6, 64, 4, 8, 0.97, 60, 101),
+    "full": (16, 2048, 16, 32, 0.95, 40, 102),          # the shipped feature size: ResNet-101 layer4 of a 512x1024 frame
+    "keepall": (5, 48, 3, 5, 2.0, 25, 103),             # threshold never rejects: an eviction per frame once full
+}
+
+
+def _reference_replay_buffer(capacity, threshold, n_target):
+    """The reference's ReplayBuffer with the fields its `add` / `load_state` / `save_state` read, without the data-set half of its
+    constructor (files, samplers, multiprocessing arrays)."""
+    from datasets.replay_buffer import ReplayBuffer
+    rb = object.__new__(ReplayBuffer)
+    rb.maximize_diversity, rb.similarity_threshold, rb.target_buffer_size = True, threshold, capacity
+    rb.faiss_index = rb.distance_matrix = rb.distance_matrix_indices = None
+    rb.buffer_indices = {"target": torch.zeros(n_target, dtype=torch.int32)}
+    rb.target_data = None
+    return rb
+
+
+def _replay_run(rb, frames, first_index=0):
+    """ReplayBuffer.add frame by frame -> per-frame (stored, evicted id, top-1 similarity, eviction margin)."""
+    import contextlib
+    import io
+    stored, evicted, sims, margins = [], [], [], []
+    for i, f in enumerate(frames):
+        idx = first_index + i
+        idx_obj = rb.faiss_index
+        before_ids = [] if idx_obj is None else idx_obj._ids.tolist()
+        before_x = None if idx_obj is None else idx_obj.index._x.copy()
+        nlog = 0 if idx_obj is None else len(idx_obj.top1_log)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rb.add(idx, f)
+        after_ids = rb.faiss_index._ids.tolist()
+        was_stored = bool(rb.buffer_indices["target"][idx] == 1) or (idx in after_ids)
+        gone = [j for j in before_ids + ([idx] if was_stored else []) if j not in after_ids]
+        assert len(gone) <= 1
+        # stored-and-immediately-evicted frames: the reference clears buffer_indices["target"][idx] again
+        if not was_stored and idx_obj is not None and len(rb.faiss_index.top1_log) > nlog and rb.faiss_index.top1_log[-1] < rb.similarity_threshold:
+            was_stored, gone = True, [idx]
+        stored.append(was_stored)
+        evicted.append(gone[0] if gone else -1)
+        sims.append(0.0 if (idx_obj is None or len(before_ids) == 0) else rb.faiss_index.top1_log[-1])
+        margin = -1.0
+        if gone:                                                # gap between the two largest eviction scores, in float64
+            q = f.mean(-1).mean(-1).numpy().astype(np.float64)
+            q /= np.linalg.norm(q)
+            x = np.vstack([before_x.astype(np.float64), q])
+            m = x @ x.T
+            sc = np.sort(m.sum(0) - m.diagonal())
+            margin = float(sc[-1] - sc[-2])
+        margins.append(margin)
+    return dict(stored=np.array(stored, np.int8), evicted=np.array(evicted, np.int64), sim=np.array(sims, np.float32),
+                margin=np.array(margins, np.float64))
+
+
+def golden_replay():
+    """the reference's OWN ReplayBuffer.add / save_state / load_state (datasets/replay_buffer.py:387-499) over frame
+    sequences with rejections and evictions, on the brute-force faiss stand-in of _ref_import.py.  Inputs: inputs.replay_features
+    (seeds in the meta record); outputs: the decision per frame, the final index, the saved state, and a second-domain run that
+    starts from the loaded state (ids 10000 + idx, "hardcoded continual learning")."""
+    import tempfile
+    res, meta = {}, {"cases": {k: dict(zip(("capacity", "c", "h", "w", "threshold", "n", "seed"), v)) for k, v in REPLAY_CASES.items()}}
+    for tag, (cap, c, h, w, thr, n, seed) in REPLAY_CASES.items():
+        rb = _reference_replay_buffer(cap, thr, 1000)
+        out = _replay_run(rb, gi.replay_features(n, c, h, w, seed))
+        for k, v in out.items():
+            res[f"{tag}_{k}"] = v
+        res[f"{tag}_final_ids"] = rb.faiss_index._ids.copy()
+        res[f"{tag}_final_vecs"] = rb.faiss_index.index._x.copy()
+        res[f"{tag}_final_target"] = rb.buffer_indices["target"].numpy().copy()
+        print(f"replay {tag}: stored {int(out['stored'].sum())} / {n}, evictions {int((out['evicted'] >= 0).sum())}, "
+              f"smallest eviction margin {min([m for m in out['margin'] if m >= 0], default=-1):.2e}")
+    # second domain: save_state of the "small" run -> load_state into a fresh buffer -> 20 more frames
+    cap, c, h, w, thr, n, seed = REPLAY_CASES["small"]
+    rb = _reference_replay_buffer(cap, thr, 1000)
+    _replay_run(rb, gi.replay_features(n, c, h, w, seed))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            rb.save_state()
+            rb2 = _reference_replay_buffer(cap, thr, 1000)
+            rb2.load_state()
+        finally:
+            os.chdir(cwd)
+    res["domain2_loaded_ids"] = rb2.faiss_index._ids.copy()
+    res["domain2_prev_target"] = np.array(rb2.buffer_indices["prev_target"], np.int64)
+    meta["domain2"] = dict(from_case="small", n=20, seed=104)
+    out = _replay_run(rb2, gi.replay_features(20, c, h, w, 104))
+    for k, v in out.items():
+        res[f"domain2_{k}"] = v
+    res["domain2_final_ids"] = rb2.faiss_index._ids.copy()
+    res["domain2_final_prev_target"] = np.array(rb2.buffer_indices["prev_target"], np.int64)
+    res["domain2_final_target"] = rb2.buffer_indices["target"].numpy().copy()
+    print(f"replay domain2: stored {int(out['stored'].sum())} / 20, evictions {int((out['evicted'] >= 0).sum())}, of previous-domain "
+          f"samples {int((out['evicted'] >= 10000).sum())}")
+    res["meta"] = json.dumps(meta)
+    save("replay", **res)
+
+
 if __name__ == "__main__":
-    jobs = {"conf_mixup": golden_conf_mixup, "config0": golden_config0, "geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer, "preprocessing": golden_preprocessing,
+    jobs = {"replay": golden_replay, "conf_mixup": golden_conf_mixup, "config0": golden_config0, "geometry": golden_geometry, "geometry_grad": golden_geometry_grad, "network_adapt_real": golden_adapt_real, "eval_infer": golden_eval_infer, "preprocessing": golden_preprocessing,
             "heads_r18": lambda: golden_heads("r18", R18, 2, 32, 64, 3),
             "heads_r50": lambda: golden_heads("r50", R50, 1, 32, 64, 5, full=False),
             "recon_small": lambda: golden_recon("small", 2, 48, 80, 21),

@@ -1,14 +1,17 @@
-"""Every BASELINE.json configuration as a -m gpu test on ITS OWN workload (VERDICT r02 "configs_untested"):
+"""Every BASELINE.json configuration as a -m gpu test on ITS OWN workload (VERDICT r02 "configs_untested", r03 item 1a):
 
   configs[1]  ResNet-50 + four heads, 512x1024 pretrain step, B = 4            (scripts/train_codeps.py:97-108)
+  configs[2]  THE HEADLINE WORKLOAD: the online-adaptation step of cfg/adapt_cityscapes_kitti_360.yaml:21-24,34-35,51-52 at
+              B = 8 = 1 target + 3 replay + 2 source + 2 cut-mixup items, 512x1024, ResNet-101 frozen -- exactly what
+              `python bench.py` times                                            (scripts/adapt_codeps.py:260-299)
   configs[3]  the per-rank slice of the B = 32 / 8-GPU adaptation step: 1 target + 1 replay + 1 source + 1 mixup item,
               ResNet-101 frozen                                                  (scripts/adapt_codeps.py:260-299)
   configs[4]  the per-GPU slice of the 1024x2048 ResNet-101 pretrain step, B = 2 (HBM stress)
 
 built exactly as bench.py builds them (bench.build / bench.make_data), stepped twice eagerly and twice from a captured HIP
 graph from the same initial state: finite losses, graph == eager bit for bit (losses, parameters, Adam moments), every
-trainable parameter moved, peak HBM under a stated bound.  configs[0] and configs[2] have their own tests
-(tests/test_network_gpu.py::test_config0_*, tests/test_graph_gpu.py + bench.py); the 8-rank layout of configs[3] is
+trainable parameter moved, peak HBM under a stated bound.  configs[0] has its own test against the reference's golden
+(tests/test_network_gpu.py::test_config0_*); the 8-rank layout of configs[3] is
 tests/test_distributed_gpu.py::test_configs3_eight_rank_layout_equals_single_process_step.
 
 Plus the COMPOSITION check the pieces do not give: a reduced-size (64x128) ResNet-50 + four heads train-mode step -- batch-stat
@@ -28,6 +31,7 @@ DEV = "cuda:0"
 CONFIGS = {
     # name: (mode, encoder, height, width, per-GPU batch, peak-HBM bound in GB for TWO nets + one graph pool)
     "configs1_r50_4heads_b4": ("train", 50, 512, 1024, 4, 60.0),
+    "configs2_adapt_b8": ("adapt", 101, 512, 1024, 8, 60.0),
     "configs3_rank_slice_b4": ("adapt", 101, 512, 1024, 4, 40.0),
     "configs4_r101_1024x2048_b2": ("train", 101, 1024, 2048, 2, 110.0),
 }

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import inputs as gi
-from helpers import close, depth_bar, grad_stats, head_shapes, load, oracle_depth64, record_bar
+from helpers import close, depth_bar, depth_of_logit, grad_stats, head_shapes, load, logit_bar, oracle_depth64, record_bar
 from oracle import resnet as oresnet
 
 pytestmark = pytest.mark.gpu
@@ -45,6 +45,27 @@ def _sample(b, h, w, seed, labels=True):
     return d
 
 
+def _tap(*nets):
+    for n in nets:
+        n.depth_head.logit_log = []
+        if n.semantic_head is not None:
+            n.semantic_head.logit_log = []
+
+
+def _logit_bars(test, net, z, result, prefix="res_", depth_key="depth", sem_key="semantic"):
+    """north_star: depth / semantic logits within 1e-3 of the reference's (the goldens hold the reference's own pre-sigmoid /
+    pre-softmax tensors); the selected call must be the one that produced `result`."""
+    def same_depth(sel):
+        got = result[depth_key].detach().cpu().double()
+        assert float((depth_of_logit(sel) - got).abs().div(got).max()) < 1e-5, "the logged disparity logits are not those of the result"
+    logit_bar(test, "disparity", net.depth_head.logit_log, z[prefix + "disp_logit"], same_depth)
+    if net.semantic_head is not None and (prefix + "sem_logit") in z.files:
+        def same_labels(sel):
+            assert torch.equal(sel.argmax(1).to(torch.uint8), result[sem_key].detach().cpu().reshape(sel.shape[0], *sel.shape[-2:]).to(torch.uint8)), \
+                "the logged semantic logits are not those of the result"
+        logit_bar(test, "semantic", net.semantic_head.logit_log, z[prefix + "sem_logit"], same_labels)
+
+
 def _noise(seed, shapes):
     torch.manual_seed(seed)
     return [torch.cat([(torch.randn(b, 2, h >> s, w >> s) * .00001).reshape(-1) for s in range(5)]).to(DEV) for b, h, w in shapes]
@@ -71,9 +92,11 @@ def test_train_forward_backward_against_reference():
     b, h, w, seed = meta["b"], meta["h"], meta["w"], meta["seed"]
     net = _build(seed, True, w, h)
     net.depth_algo.reconstruction_loss.noise = _noise(meta["noise_seed"], [(b, h, w)])
+    _tap(net)
     losses, result, _ = net(_sample(b, h, w, seed), "train", [0, -1, 1], do_panoptic_fusion=True)
     total = sum(meta["weights"][k] * v for k, v in losses.items() if v is not None and k in meta["weights"])
     total.backward()
+    _logit_bars("network_train", net, z, result)
     for k, v in losses.items():
         if v is not None:
             close(v, z["loss_" + k], 1e-6, 5e-5, "loss " + k)
@@ -111,7 +134,9 @@ def test_config0_depth_only_train_step_against_reference():
         getattr(net, name).load_state_dict(gi.fill_state_dict(head_shapes(name), seed + 10 + i))
     net = net.to(DEV).eval()
     net.depth_algo.reconstruction_loss.noise = _noise(meta["noise_seed"], [(b, h, w)])
+    _tap(net)
     losses, result, _ = net(_sample(b, h, w, seed, labels=False), "train", [0, -1, 1], do_panoptic_fusion=False)
+    _logit_bars("config0", net, z, result)
     assert [k for k, v in losses.items() if v is not None] == ["depth_recon", "depth_smth"]
     total = sum(meta["weights"][k] * losses[k] for k in meta["weights"])
     total.backward()
@@ -137,7 +162,9 @@ def test_adaptation_step_against_reference():
     net.depth_algo.reconstruction_loss.noise = [n_tgt, n_rep]
     data = {"target": _sample(1, ht, wt, seed, False), "target_replay": _sample(2, ht, wt, seed + 1, False),
             "source": _sample(2, hs, ws, seed + 2), "cut_mixup": _sample(2, hs, ws, seed + 3)}
+    _tap(net)
     losses, result, _, _ = net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
+    _logit_bars("network_adapt", net, z, result)
     total = sum(meta["weights"][k] * losses[k] for k in meta["weights"])
     total.backward()
     for k in meta["weights"]:
@@ -171,7 +198,9 @@ def test_real_codepsnet_adapt_against_reference():
     data = {"target": _sample(1, ht, wt, seed, False), "target_replay": _sample(2, ht, wt, seed + 1, False),
             "source": _sample(2, hs, ws, seed + 2), "cut_mixup": raw}
     np.random.seed(meta["np_seed"])
+    _tap(net)
     losses, result, _, out_data = net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
+    _logit_bars("network_adapt_real", net, z, result)
     assert [k for k, v in losses.items() if v is not None] == meta["loss_keys"]
     live = [k for k, v in losses.items() if v is not None and v.requires_grad]
     assert live == meta["live"]
@@ -230,9 +259,13 @@ def test_eval_infer_modes_and_pre_step_against_reference():
         raw.pop(k)
     raw = {k: ({o: t_.to(DEV) for o, t_ in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in raw.items()}
     sample = {"target": target, "cut_mixup": raw}
+    _tap(net, teacher)
     r_eval, s_eval = pre_step(net, teacher, ["semantic_head"], sample, [0, -1, 1], True, do_class_wise_depth_stats=True)
+    _logit_bars("eval_infer_eval", teacher, z, r_eval, prefix="eval_")
+    _tap(net, teacher)
     with torch.no_grad():
         _, r_inf, s_inf = net(target, "infer", [0, -1, 1], True, False)
+    _logit_bars("eval_infer_infer", net, z, r_inf, prefix="infer_")
     assert s_inf["sem_conf"] is None
 
     def check(tag, r, margin):

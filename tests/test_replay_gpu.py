@@ -1,6 +1,7 @@
 """Device-side replay-buffer diversity sampler (codeps_replay_*, codeps_amd.datasets.DiversityReplayBuffer) against the
-oracle's restatement of ReplayBuffer.add (datasets/replay_buffer.py:387-455).  Parity is unpinned for this row (faiss is not
-available, see oracle/replay.py); decisions are compared exactly wherever the oracle's own margins exceed fp32 noise."""
+oracle's restatement of ReplayBuffer.add (datasets/replay_buffer.py:387-455) and, since round 4, against
+tests/golden/replay.npz: the reference's OWN add / save_state / load_state run frame by frame (faiss replaced by an exact
+brute-force stand-in, tests/golden/_ref_import.py).  Decisions are compared exactly wherever the margins exceed fp32 noise."""
 import numpy as np
 import pytest
 import torch
@@ -80,3 +81,86 @@ def test_load_state_and_continual_eviction():
         assert evicted not in second.buffer_indices["prev_target"] and int(second.buffer_indices["target"][5]) == 1
     with pytest.raises(ValueError):
         second.add(6, torch.zeros(2, c, 2, 3, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------ pinned against the REFERENCE (round 4)
+def _golden():
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "replay.npz"), allow_pickle=False)
+    return z, json.loads(str(z["meta"]))
+
+
+def _inputs():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import inputs as gi
+    return gi
+
+
+def _compare_log(z, tag, log, thr, first=0):
+    """Device decisions (call order) against the reference's ReplayBuffer.add; a difference is admissible only on a frame whose
+    margin in the reference is fp32 noise (<= 1e-5), after which the two buffers differ and the comparison stops."""
+    for i, (idx, stored, evicted, sim) in enumerate(log):
+        w_stored, w_evicted, w_sim, margin = bool(z[tag + "_stored"][i]), int(z[tag + "_evicted"][i]), float(z[tag + "_sim"][i]), float(z[tag + "_margin"][i])
+        assert idx == first + i and abs(sim - w_sim) < 2e-6, (tag, i, sim, w_sim)
+        if abs(w_sim - thr) <= 1e-5 and stored != w_stored:
+            return i
+        assert stored == w_stored, (tag, i)
+        if w_evicted >= 0 and margin <= 1e-5 and evicted != w_evicted:
+            return i
+        assert evicted == w_evicted, f"{tag}: frame {i}: device evicts {evicted}, the reference {w_evicted} (margin {margin:.2e})"
+    return len(log)
+
+
+@pytest.mark.parametrize("tag", ["small", "full", "keepall"])
+def test_add_matches_the_reference_frame_by_frame(tag):
+    """tests/golden/replay.npz = the reference's own ReplayBuffer.add (datasets/replay_buffer.py:387-455) over the same frames."""
+    from codeps_amd.datasets import DiversityReplayBuffer
+    gi = _inputs()
+    z, meta = _golden()
+    c = meta["cases"][tag]
+    buf = DiversityReplayBuffer(1000, c["capacity"], c["threshold"], DEV, feature_dim=c["c"])
+    for i, f in enumerate(gi.replay_features(c["n"], c["c"], c["h"], c["w"], c["seed"])):
+        buf.add(i, f.to(DEV))
+    buf.sync()
+    done = _compare_log(z, tag, buf.log, c["threshold"])
+    assert done >= min(c["n"], 30), f"{tag}: comparison stopped at frame {done} on a near-tie"
+    if done == c["n"]:
+        state = buf.state_dict()
+        assert sorted(state["target_samples_indices"]) == sorted(z[tag + "_final_ids"].tolist())
+        by_id = dict(zip(z[tag + "_final_ids"].tolist(), z[tag + "_final_vecs"]))
+        for i, v in zip(state["target_samples_indices"], state["faiss_features"]):
+            np.testing.assert_allclose(v, by_id[i], atol=2e-6)
+        assert np.array_equal(buf.buffer_indices["target"].numpy(), z[tag + "_final_target"])
+
+
+def test_second_domain_from_a_loaded_state_matches_the_reference():
+    """save_state -> load_state -> add (replay_buffer.py:462-499, 447-451): previous-domain samples under id 10000 + idx compete
+    with the new domain's frames for the same slots."""
+    from codeps_amd.datasets import DiversityReplayBuffer
+    gi = _inputs()
+    z, meta = _golden()
+    c = meta["cases"][meta["domain2"]["from_case"]]
+    first = DiversityReplayBuffer(1000, c["capacity"], c["threshold"], DEV, feature_dim=c["c"])
+    for i, f in enumerate(gi.replay_features(c["n"], c["c"], c["h"], c["w"], c["seed"])):
+        first.add(i, f.to(DEV))
+    first.sync()
+    assert _compare_log(z, "small", first.log, c["threshold"]) == c["n"]
+    state = first.state_dict()
+    order = np.argsort(state["target_samples_indices"])          # the reference saves in stored order = increasing id
+    state = {"target_samples_indices": [state["target_samples_indices"][k] for k in order],
+             "faiss_features": [state["faiss_features"][k] for k in order]}
+    second = DiversityReplayBuffer(1000, c["capacity"], c["threshold"], DEV, feature_dim=c["c"])
+    second.load_state_dict(state)
+    assert second.buffer_indices["prev_target"] == z["domain2_prev_target"].tolist()
+    second.log.clear()
+    n2 = meta["domain2"]["n"]
+    for i, f in enumerate(gi.replay_features(n2, c["c"], c["h"], c["w"], meta["domain2"]["seed"])):
+        second.add(i, f.to(DEV))
+    second.sync()
+    assert _compare_log(z, "domain2", second.log, c["threshold"]) == n2
+    assert sorted(second.buffer_indices["prev_target"]) == sorted(z["domain2_final_prev_target"].tolist())
+    assert np.array_equal(second.buffer_indices["target"].numpy(), z["domain2_final_target"])
+    assert sorted(second.state_dict()["target_samples_indices"]) == sorted(z["domain2_final_ids"].tolist())
