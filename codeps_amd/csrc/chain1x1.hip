@@ -89,8 +89,11 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8 (&
 
 #define CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+CODEPS_STAMP_DECL(chain)
+
 __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    CODEPS_STAMP_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long m0 = (long long)blockIdx.x * BPIX;
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
         float* po = p.part + ((size_t)blockIdx.y * p.M + m) * KMID + 4 * kg;
 #pragma unroll
         for (int jt = 0; jt < 16; ++jt) *reinterpret_cast<f32x4*>(po + jt * 16) = acc3[jt];
+        CODEPS_STAMP_END(chain);
         return;
     }
     float* yo = p.y0n + (size_t)m * KMID + 4 * kg;
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
         for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
         *reinterpret_cast<f32x4*>(yo + jt * 16) = o;
     }
+    CODEPS_STAMP_END(chain);
 }
 
 // y0n = relu((sum_z part[z]) * scale3 + shift3), slices added in fixed order
@@ -309,6 +314,9 @@ static int chain_slices(long long rows, int n2) {
 }
 
 }  // namespace
+
+CODEPS_STAMP_SETTER(chain)
+
 
 extern "C" size_t codeps_chain1x1_w2_row_bytes(void) { return W2ROW; }
 

@@ -40,6 +40,57 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 #ifdef __HIPCC__
+// ---- in-kernel clock stamps: ONLY in the diagnostic variant build (tools/build_variant.sh stamps -DCODEPS_CLOCK_STAMPS; in the
+// product library the macros are empty and no stamp executes).  MI355X_MICROARCH.md "DVFS give-back" item 6: s_memtime counts shader
+// cycles, s_memrealtime a constant 100 MHz; wave 0 of every block writes (cycles, 100 MHz ticks, phase A cycles, phase B cycles) of its
+// lifetime into a buffer of its own that no kernel reads (set per translation unit by codeps_stamp_buffer_*).
+#ifdef CODEPS_CLOCK_STAMPS
+#define CODEPS_STAMP_DECL(tag)                                                                                              \
+    __device__ unsigned long long* codeps_stamp_buf_##tag = nullptr;                                                        \
+    __device__ unsigned codeps_stamp_cap_##tag = 0;
+__device__ __forceinline__ unsigned long long codeps_memtime() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ __forceinline__ unsigned long long codeps_memrealtime() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define CODEPS_STAMP_BEGIN() unsigned long long st_pa_ = 0, st_pb_ = 0, st_ps_ = 0; (void)st_ps_; \
+    const unsigned long long st_r0_ = codeps_memrealtime(), st_t0_ = codeps_memtime()
+#define CODEPS_STAMP_PHASE_START() st_ps_ = codeps_memtime()
+#define CODEPS_STAMP_PHASE_A() st_pa_ += codeps_memtime() - st_ps_
+#define CODEPS_STAMP_PHASE_B() st_pb_ += codeps_memtime() - st_ps_
+#define CODEPS_STAMP_END(tag)                                                                                               \
+    do {                                                                                                                    \
+        const unsigned long long st_t1_ = codeps_memtime(), st_r1_ = codeps_memrealtime();                                  \
+        const unsigned st_slot_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                           \
+        if (threadIdx.x == 0 && codeps_stamp_buf_##tag && st_slot_ < codeps_stamp_cap_##tag) {                              \
+            unsigned long long* st_d_ = codeps_stamp_buf_##tag + (size_t)st_slot_ * 4;                                      \
+            st_d_[0] = st_t1_ - st_t0_; st_d_[1] = st_r1_ - st_r0_; st_d_[2] = st_pa_; st_d_[3] = st_pb_;                   \
+        }                                                                                                                   \
+    } while (0)
+#define CODEPS_STAMP_SETTER(tag)                                                                                            \
+    extern "C" int codeps_stamp_buffer_##tag(unsigned long long* buf, unsigned cap) {                                       \
+        if (hipMemcpyToSymbol(HIP_SYMBOL(codeps_stamp_buf_##tag), &buf, sizeof(buf)) != hipSuccess) return -1;              \
+        return hipMemcpyToSymbol(HIP_SYMBOL(codeps_stamp_cap_##tag), &cap, sizeof(cap)) == hipSuccess ? 0 : -1;             \
+    }
+#else
+#define CODEPS_STAMP_DECL(tag)
+#define CODEPS_STAMP_BEGIN() do {} while (0)
+#define CODEPS_STAMP_PHASE_START() do {} while (0)
+#define CODEPS_STAMP_PHASE_A() do {} while (0)
+#define CODEPS_STAMP_PHASE_B() do {} while (0)
+#define CODEPS_STAMP_END(tag) do {} while (0)
+#define CODEPS_STAMP_SETTER(tag)
+#endif
+
 // ---- wave / block reductions (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -93,6 +93,8 @@ __device__ __forceinline__ void split_bf16(const f32x4 v, u16x4 (&pc)[NP]) {
         }
 }
 
+CODEPS_STAMP_DECL(conv)
+
 // 16 zero floats in global memory: what a gathered load reads when its tap falls into the zero padding
 __device__ __attribute__((aligned(64))) float zero_page[16];
 
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     // load / store / barrier phases behind MFMAs).
     float* As = smem;                                 // [NBUF][BM][LDK]
     float* Bs = smem + NBUF * BM * LDK;               // [NBUF][BN][LDK]
+    CODEPS_STAMP_BEGIN();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -337,6 +340,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     const int lrow = lane & 31, lhalf = lane >> 5;
     for (int step = s_begin; step < s_end; ++step) {
         const int buf = NBUF == 2 ? ((step - s_begin) & 1) : 0;
+        CODEPS_STAMP_PHASE_START();
         if (step + 1 < s_end && CODEPS_ABLATE < 1) load_step(step + 1);           // global loads in flight during the MFMAs
         const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK;
         const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK;
@@ -392,9 +396,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #if CODEPS_ABLATE >= 2
         continue;
 #endif
+        CODEPS_STAMP_PHASE_A();                               // A: loads issued + fragment reads + MFMAs of this wave
+        CODEPS_STAMP_PHASE_START();
         if (NBUF == 1) __syncthreads();                       // every wave is done reading the single buffer
         if (step + 1 < s_end) store_step(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
+        CODEPS_STAMP_PHASE_B();                               // B: barrier + (wait for the loads) split + LDS stores + barrier
     }
 
     // ---- epilogue: accumulators -> LDS tile [BM][BN+4] -> coalesced float4 rows (512 B per 32 lanes at BN = 128),
@@ -462,6 +469,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
             }
         }
     }
+    CODEPS_STAMP_END(conv);
 }
 
 // ---------------------------------------------------------------------------------- wave-specialised variant (deep K)
@@ -863,6 +871,12 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 // back to back, -0.37 ms per step with the streams serialised, -0.13 ms with them overlapped (149 KB of LDS: nothing of
 // the pose stream shares the CU).  128 output columns only: with 64 (two chunks of nine taps per block, 96 KB) it loses
 // the second block per CU and measures 10 % slower than conv_halo3_kernel.  CODEPS_HALO_RING=0 selects conv_halo3_kernel.
+// Tuning aid (never set in the shipped build): -DCODEPS_ABLATE_RING=bits -- 1: no weight DMA after the first ring fill, 2: the
+// activation tile is written without the bf16 split, 4: the fragments of tap 0 serve every tap (no LDS fragment reads in the
+// tap loop).  Results are garbage; the timings bound what each stage costs.
+#ifndef CODEPS_ABLATE_RING
+#define CODEPS_ABLATE_RING 0
+#endif
 template <int MODE, int TN>
 __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
@@ -876,6 +890,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                  // [HPIX + 1][LDK]  (row HPIX: staging tasks past the tile)
     float* Bs = smem + (HPIX + 1) * LDK;               // [RING][BN][LDK]
+    CODEPS_STAMP_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
@@ -959,8 +974,16 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
         for (int i = 0; i < APASS; ++i) {
             const int pos = min((tid >> 2) + 64 * i, HPIX);
             u16x4 lo[NP], hi[NP];
+#if CODEPS_ABLATE_RING & 2
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                lo[q] = u16x4{(unsigned short)__builtin_bit_cast(unsigned, areg[i * 2][q]), 1, 2, 3};
+                hi[q] = u16x4{(unsigned short)__builtin_bit_cast(unsigned, areg[i * 2 + 1][q]), 1, 2, 3};
+            }
+#else
             split_bf16<NP>(areg[i * 2], lo);
             split_bf16<NP>(areg[i * 2 + 1], hi);
+#endif
             unsigned short* row = reinterpret_cast<unsigned short*>(As + pos * LDK);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + achunk * 8) = pack8(lo[q], hi[q]);
@@ -1028,9 +1051,14 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int g = g0 + tap;
+#if CODEPS_ABLATE_RING & 4
+            mfmas(fr[0]);
+            if (false) {
+#else
             if (tap < 8) read_frags(tap + 1, (g + 1) & 3, fr[(tap + 1) & 1]);   // tile g + 1 landed before the barrier that ended tap g - 1
             mfmas(fr[tap & 1]);
-            if (tap < 8) {                                         // one fragment read per four MFMAs (the scheduler would sink the reads)
+            if (tap < 8) {
+#endif                                         // one fragment read per four MFMAs (the scheduler would sink the reads)
 #pragma unroll
                 for (int k = 0; k < NA * NP + NB * NP; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -1056,7 +1084,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             }
             __syncthreads();
             // every wave has read tile g's fragments (during tap g - 1, or at the chunk's start): its slot takes tile g + 4
-            if (g + 4 < T) dma_b((tap + 4) % 9, chunk + (tap + 4) / 9, g & 3);
+            if (g + 4 < T && !(CODEPS_ABLATE_RING & 1)) dma_b((tap + 4) % 9, chunk + (tap + 4) / 9, g & 3);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1103,6 +1131,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             }
         }
     }
+    CODEPS_STAMP_END(conv);
 }
 
 // ---------------------------------------------------------------------------------- 16-column variant
@@ -1704,6 +1733,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
     unsigned short* dZs = lds16;                       // [64][ZP]
     unsigned short* Xs = lds16 + 64 * ZP;              // [64][XP]
+    CODEPS_STAMP_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int wco = CO32 ? 0 : (wave & 1), wci = wave >> 1;
     const int ph = __builtin_amdgcn_readfirstlane(wave & 1);       // CO32: this wave's pixel half
@@ -1838,9 +1868,12 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     const unsigned short* zrow = dZs + (wco * 32 + l32) * ZP + h * 8;
     const unsigned short* xrow = Xs + (wci * 32 + l32) * XP + h * 8;
     for (int tile = t_beg; tile < t_end; ++tile) {
+        CODEPS_STAMP_PHASE_START();
         __syncthreads();                                            // the previous tile's fragment reads are done
         store_tile();
         __syncthreads();
+        CODEPS_STAMP_PHASE_B();                                     // B: barrier + (wait for the loads) split + transpose + LDS stores + barrier
+        CODEPS_STAMP_PHASE_START();
         if (tile + 1 < t_end) load_tile(tile + 1);
         bf16x8 zf[TH][3];
 #pragma unroll
@@ -1883,6 +1916,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
                             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[py][qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
             }
         }
+        CODEPS_STAMP_PHASE_A();                                     // A: next tile's loads issued + fragment reads + 216 MFMAs of this wave
     }
     // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 31, row (co) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float* dst = part + (size_t)(CO32 ? blk * 2 + ph : blk) * p.Co * 9 * p.Ct;
@@ -1896,6 +1930,7 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
                 if (co < p.Co) dst[((size_t)co * 9 + t) * p.Ct + ci] = acc[t][r];
             }
     }
+    CODEPS_STAMP_END(conv);
 }
 
 // Weight gradient of the double-pixel stem (7 x 4 taps of 16 channels, stride (2, 1), 64 output channels) on the bf16 matrix
@@ -2750,6 +2785,9 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
 }
 
 }  // namespace
+
+CODEPS_STAMP_SETTER(conv)
+
 
 // a pack row ([tap][channel]) gets a pre-split copy when the kernel that reads it can be the split-operand one: 32-channel K
 // chunks, or 16-channel chunks (the stem) as long as the row is a whole number of 32-element groups
