@@ -71,6 +71,7 @@ SIGNATURES = {
     "codeps_conv2d_arith": (c_int, [POINTER(ConvDesc), I, I]),
     "codeps_conv2d_last_kernel": (c_char_p, []),
     "codeps_conv2d_set_arith": (c_int, [I]),
+    "codeps_conv2d_set_halo_ws": (c_int, [I]),
     "codeps_conv2d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_dgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc), I]),

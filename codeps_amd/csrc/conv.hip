@@ -1051,6 +1051,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int g = g0 + tap;
+            CODEPS_STAMP_PHASE_START();
 #if CODEPS_ABLATE_RING & 4
             mfmas(fr[0]);
             if (false) {
@@ -1071,6 +1072,8 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             // those loads, so tap 2's wait completes them -- told to the compiler there (an empty asm that "uses" the
             // registers), or it would count them against the DMA instructions in flight when store_a reads them.
             const bool t3 = g + 3 < T;
+            CODEPS_STAMP_PHASE_A();                                // A: fragment reads of tap + 1 issued, 96 MFMAs of tap issued
+            CODEPS_STAMP_PHASE_START();
             if (tap < 2 && more) {
                 if (t3) __builtin_amdgcn_s_waitcnt(0x0F70 | (BPW + NALOAD));
                 else __builtin_amdgcn_s_waitcnt(0x0F70 | NALOAD);
@@ -1085,6 +1088,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             __syncthreads();
             // every wave has read tile g's fragments (during tap g - 1, or at the chunk's start): its slot takes tile g + 4
             if (g + 4 < T && !(CODEPS_ABLATE_RING & 1)) dma_b((tap + 4) % 9, chunk + (tap + 4) / 9, g & 3);
+            CODEPS_STAMP_PHASE_B();                                // B: wait for tile g + 2, barrier, DMA of tile g + 4 issued
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1113,6 +1117,290 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
         __syncthreads();
         if (n < p.N) {
 #pragma unroll 4
+            for (int rr = r0; rr < WM * 32; rr += RPASS) {
+                const int pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
+                const size_t m = ((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
+                if (p.ksplit > 1) {                           // raw partial sum of this K slice; splitk_finish_kernel does the rest
+                    *reinterpret_cast<f32x4*>(p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
+                    continue;
+                }
+                if (MODE == MODE_FWD) {
+                    v = v * sc + sh;
+                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                *reinterpret_cast<f32x4*>(out + m * p.N + n) = v;
+            }
+        }
+    }
+    CODEPS_STAMP_END(conv);
+}
+
+// ---------------------------------------------------------------------------------- halo-tile ring kernel, producer / consumer waves
+// conv_halo3r_kernel with the staging taken out of the matrix waves' instruction streams.  In-kernel stamps of that kernel
+// (tools/clock_cycles.py, profiles/r04_clock_cycles.json; ResNet-101 layer3 3x3, 2.2-2.3 GHz in the kernel) put 57 % of a block's
+// lifetime into issuing MFMAs, 18 % into the wait + barrier + the seven LDS-DMA instructions every wave issues per tap, 8 % into the
+// bf16 split of the activation tile -- and a second wave on a SIMD that only issues vector / memory instructions does not cost the MFMA
+// wave a cycle (32.04 cycles per v_mfma_f32_32x32x16_bf16 with 0 .. 16 v_fma_f32 per MFMA in the partner wave).  So: 384 threads =
+// waves 0-3 CONSUMERS (the 2 x 2 wave grid: LDS fragment reads + MFMAs, nothing else in the tap loop) + waves 4-5 PRODUCERS (all
+// 26 LDS-DMA instructions of a weight tile, and load -> split -> store of the next chunk's activation tile while the consumers run
+// the chunk's last tap).  Same LDS image, same ring of four weight tiles, same arithmetic and summation order as conv_halo3r_kernel
+// (bit-identical results); one barrier per tap.  Six waves on four SIMDs leave 256 registers per wave, so the consumers keep ONE set
+// of A fragments and reload row tile i for the next tap right after its 24 MFMAs (the MFMAs run row tile by row tile), a second
+// set only for row tile 3, and two sets of B fragments.
+template <int MODE, int TN>
+__global__ __launch_bounds__(384) void conv_halo3p_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ residual, float* __restrict__ out) {
+    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = 3;
+    constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;
+    constexpr int BN = 32 * WN * TN;
+    constexpr int LDK = (NP * BK + 8) / 2;
+    constexpr int PT = 128;                                         // producer threads
+    constexpr int ATASK = (HPIX * 4 + PT - 1) / PT, NALOAD = ATASK * 2;      // (pixel, 8-channel group) tasks / 16-byte loads per producer thread
+    constexpr int BINS = BN * 13 / 64, BPW = BINS / 2;              // LDS-DMA instructions per weight tile / per producer wave
+    static_assert((BN * 13) % 128 == 0 && LDK * 4 == 13 * 16 && BPW + NALOAD < 64, "linear DMA layout; vmcnt immediates");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [HPIX + 1][LDK]  (row HPIX: staging tasks past the tile)
+    float* Bs = smem + (HPIX + 1) * LDK;               // [4][BN][LDK]
+    CODEPS_STAMP_BEGIN();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
+    const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
+    const int nt = logical % p.n_nt, mt = logical / p.n_nt;
+    const int n0 = nt * BN;
+    const int Hm = (MODE == MODE_FWD) ? p.Ho : p.H, Wm = (MODE == MODE_FWD) ? p.Wo : p.W;
+    const int tiles_x = Wm / TW, tiles_y = Hm / TH;
+    const int b = mt / (tiles_x * tiles_y), tr = mt % (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+    const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
+    const int cbase = p.ksplit > 1 ? (int)blockIdx.y * p.ksteps : 0;
+    const int nchunks = p.ksplit > 1 ? min(p.ksteps, Kc / BK - cbase) : Kc / BK;
+    const int T = 9 * nchunks;
+    constexpr int NA = 4, NB = 2 * TN;
+    const int l16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[NA][NB];
+
+    if (producer) {
+        // ============================================================ producers: weight tiles by LDS DMA, activation tiles
+        const int pw = wave - 4, ptid = tid - 256;
+        const bool up = MODE == MODE_FWD && p.up0;
+        const int H0 = up ? Hm / 2 : Hm, W0 = up ? Wm / 2 : Wm;
+        const int cs0 = (MODE == MODE_FWD) ? p.C0 : p.Co;
+        const float* img0 = a0 + (size_t)b * H0 * W0 * cs0;
+        const float* img1 = (MODE == MODE_FWD && p.C1 > 0) ? a1 + (size_t)b * Hm * Wm * p.C1 : nullptr;
+        const int achunk = ptid & 3;
+        const size_t wrow = (size_t)9 * Kc;
+        unsigned boff[BPW], bins[BPW];
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int ins = pw + 2 * i;
+            const int L = ins * 64 + lane, row = L / 13, seg = L % 13;
+            bins[i] = (unsigned)ins * 1024u;
+            boff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * 6 + (seg < 12 ? seg : 0) * 16);
+        }
+        auto rsrc_of = [](const void* base, size_t bytes) {
+            const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+            i32x4 r;
+            r[0] = (int)__builtin_amdgcn_readfirstlane((unsigned)a);
+            r[1] = (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xFFFFu);
+            r[2] = (int)__builtin_amdgcn_readfirstlane((unsigned)(bytes < (size_t)GATHER_OOB ? bytes : (size_t)GATHER_OOB));
+            r[3] = 0x00020000;
+            return r;
+        };
+        const i32x4 rsBv = rsrc_of(p.w3, (size_t)p.N * wrow * 6);
+        const i32x4 rsA0 = rsrc_of(img0, (size_t)H0 * W0 * cs0 * 4);
+        const i32x4 rsA1 = rsrc_of(img1 ? img1 : img0, img1 ? (size_t)Hm * Wm * p.C1 * 4 : 0);
+        const unsigned bs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(Bs);
+        auto dma_b = [&](int g) {                                   // weight tile g (global tap index of this block) -> slot g & 3
+            const int tap = g % 9, chunk = g / 9;
+            const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((tap * Kc + (cbase + chunk) * BK) * 6);
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(bs_lds + (g & 3) * BN * LDK * 4 + bins[i]);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(boff[i]), "s"(rsBv), "s"(koff) : "memory");
+            }
+        };
+        // The activation loads are inline assembly too: every vector-memory operation of these waves is then counted by hand (they
+        // retire in order), and the compiler -- which takes an asm destination for written at once -- gets the registers back only
+        // through the "claim" statement that carries the wait.
+        f32x4 areg[NALOAD];
+        auto load_a = [&](int chunk) {
+            const int cstep = (cbase + chunk) * BK;
+            const bool s1 = MODE == MODE_FWD && cstep >= p.C0;
+            const int cs = s1 ? p.C1 : cs0, ws = s1 ? Wm : W0, sh = (!s1 && up) ? 1 : 0;
+            const unsigned cbyte = (unsigned)((s1 ? cstep - p.C0 : cstep) + achunk * 8) * 4u;
+            const i32x4 rs = s1 ? rsA1 : rsA0;
+#pragma unroll
+            for (int i = 0; i < ATASK; ++i) {
+                const int pos = (ptid >> 2) + 32 * i;
+                const int iy = y0 + pos / HW - 1, ix = x0 + pos % HW - 1;
+                const bool ok = pos < HPIX && iy >= 0 && iy < Hm && ix >= 0 && ix < Wm;
+                const unsigned off = ok ? (unsigned)(((iy >> sh) * ws + (ix >> sh)) * cs) * 4u + cbyte : GATHER_OOB;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(areg[i * 2]) : "v"(off), "s"(rs) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(areg[i * 2 + 1]) : "v"(off), "s"(rs) : "memory");
+            }
+        };
+        auto store_a = [&]() {
+#pragma unroll
+            for (int i = 0; i < ATASK; ++i) {
+                const int pos = min((ptid >> 2) + 32 * i, HPIX);
+                u16x4 lo[NP], hi[NP];
+                split_bf16<NP>(areg[i * 2], lo);
+                split_bf16<NP>(areg[i * 2 + 1], hi);
+                unsigned short* row = reinterpret_cast<unsigned short*>(As + pos * LDK);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + achunk * 8) = pack8(lo[q], hi[q]);
+            }
+        };
+#define HALO3P_CLAIM(WAIT)                                                                                                       \
+    asm volatile(WAIT : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(areg[4]), "+v"(areg[5]), "+v"(areg[6]),   \
+                 "+v"(areg[7]), "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]), "+v"(areg[13]) :: "memory")
+        static_assert(NALOAD == 14, "HALO3P_CLAIM lists 14 registers");
+        // ---- prologue: first activation tile + four weight tiles; everything landed, tile written, next tile's loads in flight
+        load_a(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dma_b(g);                       // nchunks >= 1: taps 0 .. 3 exist
+        HALO3P_CLAIM("s_waitcnt vmcnt(0)");
+        __builtin_amdgcn_sched_barrier(0);
+        store_a();
+        if (nchunks > 1) load_a(1);
+        __syncthreads();                                            // S: tile 0 .. 3 and the first activation tile are visible
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int g0 = chunk * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int g = g0 + tap;
+                // (1) the slot of tile g - 1 is free (its fragments were read before barrier g - 1): tile g + 3 goes there
+                if (g >= 1 && g + 3 < T) dma_b(g + 3);
+                // (2) last tap of the chunk: the consumers read nothing of the activation tile any more (tap 8's A fragments were
+                //     read during tap 7): write the next chunk's tile, then start the loads of the one after it
+                if (tap == 8 && chunk + 1 < nchunks) {
+                    store_a();
+                    if (chunk + 2 < nchunks) load_a(chunk + 2);
+                }
+                // (3) tile g + 2 must have landed before barrier g (the consumers read its fragments during tap g + 1).  Younger
+                //     operations that may stay in flight: tile g + 3 (BPW instructions) and the activation loads issued in (2) of
+                //     this tap or of the tap before (tap 0: issued at the previous chunk's tap 8, or in the prologue).
+                const bool t3 = g >= 1 && g + 3 < T;
+                const bool al = (tap == 8 && chunk + 2 < nchunks) || (tap == 0 && chunk + 1 < nchunks);
+                if (t3 && al) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+                else if (t3) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                else if (al) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // tap 1's wait leaves at most tile g + 3 in flight: the activation loads (older) have landed -- claimed here,
+                // unconditionally (harmless when no loads were issued: the registers are then not read before the next load_a)
+                if (tap == 1) { HALO3P_CLAIM(""); }
+                static_assert(BPW == 13 && NALOAD == 14, "vmcnt immediates above");
+                __syncthreads();                                    // barrier g
+            }
+        }
+#undef HALO3P_CLAIM
+    } else {
+        // ============================================================ consumers: fragment reads + MFMAs
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned short* arow[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int pix = wm * 64 + i * 16 + l16;
+            arow[i] = reinterpret_cast<const unsigned short*>(As + ((pix / TW) * HW + pix % TW) * LDK) + kg * 8;
+        }
+        const unsigned short* brow = reinterpret_cast<const unsigned short*>(Bs + (wn * TN * 32 + l16) * LDK) + kg * 8;
+        auto toff_of = [](int tap) {                                // halfwords
+            const int ky = tap / 3, kx = tap % 3;
+            return ((MODE == MODE_FWD) ? ky * HW + kx : (2 - ky) * HW + (2 - kx)) * LDK * 2;
+        };
+        auto read_a = [&](int tap, int i, bf16x8 (&f)[NP]) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) f[q] = *reinterpret_cast<const bf16x8*>(arow[i] + toff_of(tap) + q * BK);
+        };
+        auto read_b = [&](int slot, bf16x8 (&f)[NB][NP]) {           // slot: wave-uniform
+            const unsigned short* bp = brow + slot * (BN * LDK * 2);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) f[j][q] = *reinterpret_cast<const bf16x8*>(bp + j * 16 * LDK * 2 + q * BK);
+        };
+        auto row_mfmas = [&](int i, const bf16x8 (&a)[NP], const bf16x8 (&bq)[NB][NP]) {
+#pragma unroll
+            for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+                for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa], bq[j][ord - qa], acc[i][j], 0, 0, 0);
+        };
+        bf16x8 af[3][NP], a3[2][NP], bq[2][NB][NP];
+        __syncthreads();                                            // S
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int g0 = chunk * 9;
+            // chunk start (behind barrier S or barrier g0 - 1): this chunk's activation tile and weight tile g0 are in LDS
+#pragma unroll
+            for (int i = 0; i < 3; ++i) read_a(0, i, af[i]);
+            read_a(0, 3, a3[0]);
+            read_b(g0 & 3, bq[0]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int g = g0 + tap;
+                CODEPS_STAMP_PHASE_START();
+                if (tap < 8) {                                      // the next tap's weight fragments and row tile 3: free registers
+                    read_b((g + 1) & 3, bq[(tap + 1) & 1]);
+                    read_a(tap + 1, 3, a3[(tap + 1) & 1]);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    row_mfmas(i, af[i], bq[tap & 1]);
+                    if (tap < 8) read_a(tap + 1, i, af[i]);         // reloaded in place once its 24 MFMAs have been issued
+                }
+                row_mfmas(3, a3[tap & 1], bq[tap & 1]);
+                if (tap < 8) {                                      // one fragment read per four MFMAs
+#pragma unroll
+                    for (int k = 0; k < NA * NP + NB * NP; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, (NA * NB * 6) / (NA * NP + NB * NP), 0);
+                    }
+                }
+                CODEPS_STAMP_PHASE_A();                             // A: fragment reads + 96 MFMAs issued
+                CODEPS_STAMP_PHASE_START();
+                __syncthreads();                                    // barrier g
+                CODEPS_STAMP_PHASE_B();                             // B: waiting at the barrier (the producers, the other consumers)
+            }
+        }
+    }
+
+    // ---- epilogue (as in conv_halo3r_kernel; the consumer waves hold the accumulators, all 384 threads move rows)
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;
+    constexpr int V4 = BN / 4, RPASS = 384 / V4;
+    const int c4 = tid % V4, r0 = tid / V4;
+    const int n = n0 + c4 * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_FWD && n < p.N) {
+        if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+        if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i > 0) __syncthreads();                               // (pass 0: the loop's last barrier already separates the fragment reads)
+        if (!producer) {
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cs[(wm * 32 + ih * 16 + 4 * kg + r) * LDC + (wn * NB + j) * 16 + l16] = acc[2 * i + ih][j][r];
+        }
+        __syncthreads();
+        if (n < p.N) {
             for (int rr = r0; rr < WM * 32; rr += RPASS) {
                 const int pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
                 const size_t m = ((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW;
@@ -2212,6 +2500,17 @@ struct SmallPlan { bool ok, stem, halo64, co32; int mt, nt, ci_chunks, co_groups
 // Operand arithmetic of the conv engine: 3 (default) = exact 3-way bf16 split on the bf16 MFMA, 0 = f32 MFMA, 2 = two pieces
 // (experiments only).  Initialised from CODEPS_SPLIT; codeps_conv2d_set_arith switches it at run time (A/B runs and the
 // precision tests, which compare the split kernels with the f32-MFMA kernels on the same tensors in one process).
+// Form of the halo-tile ring kernel: 0 (default) = the 256-thread kernel (conv_halo3r_kernel), 1 (CODEPS_HALO_WS=1) = producer /
+// consumer waves (conv_halo3p_kernel).  Bit-identical results; codeps_conv2d_set_halo_ws switches at run time (the tests compare the
+// two).  Round 4 measured the two within 1 % of each other on every layer and the step 0.4 % SLOWER with the producer form (33.78 vs
+// 33.64 ms, alternating runs on one box): the consumers' 20 % fewer cycles per tap come back as a lower clock (2.13 vs 2.32 GHz in
+// the kernel) -- DESIGN.md section 6c.
+static int g_halo_ws = -1;
+static int halo_ws_on() {
+    if (g_halo_ws < 0) g_halo_ws = getenv("CODEPS_HALO_WS") ? (atoi(getenv("CODEPS_HALO_WS")) != 0) : 0;
+    return g_halo_ws;
+}
+
 static int g_split_np = -1;
 static int split_pieces() {
     if (g_split_np < 0) g_split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
@@ -2626,14 +2925,17 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                 const int hks = halo_splitk_slices(p, p.n_mt * p.n_nt, nchunks_);
                 if (halo_ring || hks >= 2) {
                     constexpr size_t lds_r = (size_t)(205 + 4 * BN) * LDKf * sizeof(float);
-                    auto kr = conv_halo3r_kernel<MODE, TN>;
-                    codeps_allow_lds((const void*)kr, 160 * 1024, "conv_halo3r_kernel");
+                    // CODEPS_HALO_WS=1: the producer / consumer form of the ring kernel (bit-identical results); default 0: the 256-thread form
+                    const int halo_ws = halo_ws_on();
+                    auto kr = halo_ws ? conv_halo3p_kernel<MODE, TN> : conv_halo3r_kernel<MODE, TN>;
+                    codeps_allow_lds((const void*)kr, 160 * 1024, halo_ws ? "conv_halo3p_kernel" : "conv_halo3r_kernel");
                     p.ksplit = 1; p.ksteps = nchunks_;
                     // grids below one block per CU (the 1/16- and 1/32-resolution layers of the pose encoder and the decoders): cut the
                     // channel chunks into K slices so that the ring kernel (one block per CU) runs whole rounds of 256 blocks
                     if (hks >= 2) { p.ksteps = cdiv(nchunks_, hks); p.ksplit = cdiv(nchunks_, p.ksteps); }
-                    g_last_kernel = p.ksplit > 1 ? "conv_halo3r_kernel<splitk>" : "conv_halo3r_kernel";
-                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(256), lds_r, st, p, a0, a1, scale, shift, residual, out);
+                    g_last_kernel = halo_ws ? (p.ksplit > 1 ? "conv_halo3p_kernel<splitk>" : "conv_halo3p_kernel")
+                                            : (p.ksplit > 1 ? "conv_halo3r_kernel<splitk>" : "conv_halo3r_kernel");
+                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(halo_ws ? 384 : 256), lds_r, st, p, a0, a1, scale, shift, residual, out);
                     if (p.ksplit > 1) {
                         const long long MN = (long long)p.M * p.N;
                         hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
@@ -3026,6 +3328,12 @@ extern "C" size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d)
 }
 
 extern "C" const char* codeps_conv2d_last_kernel(void) { return g_last_kernel; }
+
+extern "C" int codeps_conv2d_set_halo_ws(int on) {
+    const int prev = halo_ws_on();
+    if (on == 0 || on == 1) g_halo_ws = on;
+    return prev;
+}
 
 extern "C" int codeps_conv2d_set_arith(int pieces) {
     const int prev = split_pieces();

@@ -71,8 +71,10 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(int iters, int random, u
                 acc32[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[(u + (u >> 2)) & 3], fb[(u >> 2) & 3], acc32[u & 3], 0, 0, 0);
         } else {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                acc16[u & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(u + (u >> 2)) & 3], b[(u >> 2) & 3], acc16[u & 7], 0, 0, 0);
+            for (int u = 0; u < 16; ++u)         // accumulate IN PLACE (inline asm pins D = C): through the builtin the register allocator
+                                                 // rotated the eight accumulators through overlapping windows (a[32:35] <- a[30:33] ...),
+                                                 // which the hardware serialises -- 31.5 instead of 16 cycles per MFMA, a codegen artefact
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[u & 7]) : "v"(a[(u + (u >> 2)) & 3]), "v"(b[(u >> 2) & 3]));
         }
     }
     // (the closing stamp may precede the retirement of the last MFMA by its latency, <= 64 of the loop's ~10^6 cycles)

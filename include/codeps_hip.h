@@ -122,6 +122,11 @@ const char* codeps_conv2d_last_kernel(void);
  * the bf16 MFMA, 0 = v_mfma_f32_32x32x2_f32, 2 = two pieces (experiments; outside the parity bar).  Returns the previous value;
  * any other argument only queries.  Weight packs made under one arithmetic stay valid under the others (they carry both forms). */
 int codeps_conv2d_set_arith(int pieces);
+/* Process-wide form of the 3x3 / stride-1 halo-tile ring kernel: 0 (default) = the 256-thread kernel in which every wave stages and
+ * multiplies, 1 (CODEPS_HALO_WS=1) = 384 threads, four consumer waves (fragment reads + MFMAs) + two producer waves (weight tiles by
+ * LDS DMA, activation tiles).  Same arithmetic and summation order: bit-identical results; measured within 1 % of each other (DESIGN.md
+ * 6c).  Returns the previous value; other arguments only query. */
+int codeps_conv2d_set_halo_ws(int on);
 /* workspace (optional, may be NULL): scratch for split-K partial sums; codeps_conv2d_fwd_workspace_bytes(d) is the size
  * that enables it for this shape (0 = never splits).  Small-M / deep-K launches (B = 1 inference, 1/32-resolution
  * layers) are cut into K slices + a fixed-order finish pass so that they still fill the 256 CUs. */

@@ -1,6 +1,8 @@
-"""conv_halo3r_kernel (weights by LDS DMA, hand-counted vmcnt waits, fragment reads under the MFMAs) against the kernel it replaces:
-the products of every accumulator are issued in the same order, so the two must agree BIT FOR BIT, and a missed wait would show up
-as a launch-to-launch difference -- 300 launches per shape must return the same bits."""
+"""The halo-tile ring kernels (weights by LDS DMA, hand-counted vmcnt waits, fragment reads under the MFMAs) -- conv_halo3p_kernel
+(default: four consumer waves + two producer waves) and conv_halo3r_kernel (every wave stages and multiplies; CODEPS_HALO_WS=0 /
+codeps_conv2d_set_halo_ws(0)) -- against the register-staged kernel they replace: the products of every accumulator are issued in the
+same order, so all three must agree BIT FOR BIT, and a missed wait would show up as a launch-to-launch difference -- 300 launches per
+shape must return the same bits."""
 import os
 import subprocess
 import sys
@@ -16,6 +18,8 @@ SHAPES = {                       # name: (B, H, W, C0, C1, Cout, up0)
     "layer3": (8, 32, 64, 256, 0, 256, False),
     "decoder": (4, 64, 128, 128, 128, 256, True),
     "wide": (2, 64, 128, 128, 0, 512, False),
+    "two_chunks_edge": (8, 36, 96, 32, 32, 128, False),        # both concat sources, tiles on every image border
+    "deep": (2, 32, 64, 1024, 256, 256, True),                 # 40 chunks, source switch in the middle, fused nearest x2
 }
 
 _CHILD = r"""
@@ -45,12 +49,60 @@ def run_case(name, launches):
     return outs[0], outs, lib.codeps_conv2d_last_kernel().decode()
 
 
+def _set_ws(on):
+    from codeps_amd import _lib
+    return _lib.lib().codeps_conv2d_set_halo_ws(on)
+
+
+@pytest.mark.parametrize("ws", [1, 0])
 @pytest.mark.parametrize("name", list(SHAPES))
-def test_ring_kernel_is_repeatable(name):
-    first, outs, kernel = run_case(name, 300)
-    assert kernel == "conv_halo3r_kernel", kernel
+def test_ring_kernel_is_repeatable(name, ws):
+    prev = _set_ws(ws)
+    try:
+        first, outs, kernel = run_case(name, 300)
+    finally:
+        _set_ws(prev)
+    assert kernel.replace("<splitk>", "") == ("conv_halo3p_kernel" if ws else "conv_halo3r_kernel"), kernel
     bad = [i for i, o in enumerate(outs) if not torch.equal(o, first)]
     assert not bad, f"{name}: launches {bad[:5]} differ from launch 0"
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_producer_consumer_form_equals_the_256_thread_form_bit_for_bit(name):
+    prev = _set_ws(1)
+    try:
+        a, _, ka = run_case(name, 1)
+        _set_ws(0)
+        b, _, kb = run_case(name, 1)
+    finally:
+        _set_ws(prev)
+    assert "halo3p" in ka and "halo3r" in kb, (ka, kb)
+    assert torch.equal(a, b), f"{name}: max |diff| {(a - b).abs().max().item():.3e}"
+
+
+def test_producer_consumer_data_gradient_equals_the_256_thread_form_bit_for_bit():
+    """The MODE_DGRAD instantiation (mirrored taps) and its K-sliced form."""
+    from codeps_amd import functional as F, _lib
+    import ctypes
+    lib = _lib.lib()
+    lib.codeps_conv2d_last_kernel.restype = ctypes.c_char_p
+    for b, h, w, ci, co in ((6, 32, 64, 256, 256), (4, 32, 64, 256, 512), (2, 64, 128, 256, 256)):
+        g = torch.Generator().manual_seed(b * 100 + co)
+        x = torch.randn(b, h, w, ci, generator=g).to(DEV)
+        wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).to(DEV)
+        gy = torch.randn(b, h, w, co, generator=g).to(DEV)
+        got = {}
+        for ws in (1, 0):
+            prev = _set_ws(ws)
+            try:
+                xx = x.clone().requires_grad_(True)
+                F.conv2d(xx, wt, pad=1).backward(gy)
+                torch.cuda.synchronize()
+                got[ws] = (xx.grad.clone(), lib.codeps_conv2d_last_kernel().decode())
+            finally:
+                _set_ws(prev)
+        assert "halo3p" in got[1][1] and "halo3r" in got[0][1], (got[1][1], got[0][1])
+        assert torch.equal(got[1][0], got[0][0]), f"B{b} {ci}->{co}: data gradients differ"
 
 
 def test_ring_kernel_equals_the_register_staged_kernel_bit_for_bit(tmp_path):
@@ -61,5 +113,5 @@ def test_ring_kernel_equals_the_register_staged_kernel_bit_for_bit(tmp_path):
     ref = torch.load(out)
     for name in SHAPES:
         got, _, kernel = run_case(name, 1)
-        assert kernel == "conv_halo3r_kernel", kernel
+        assert kernel.replace("<splitk>", "") in ("conv_halo3p_kernel", "conv_halo3r_kernel"), kernel
         assert torch.equal(got.cpu(), ref[name]), f"{name}: max |diff| {(got.cpu() - ref[name]).abs().max().item():.3e}"
