@@ -76,6 +76,7 @@ SIGNATURES = {
     "codeps_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_dgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc), I]),
     "codeps_conv2d_dgrad": (c_int, [POINTER(ConvDesc), I, P, P, P, P, c_size_t, P]),
+    "codeps_conv2d_dgrad_add": (c_int, [POINTER(ConvDesc), I, P, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, I, I, I, P, c_size_t, P]),
     "codeps_chain1x1_w2_row_bytes": (c_size_t, []),
@@ -123,7 +124,12 @@ SIGNATURES = {
     "codeps_up_dgrad_weight": (c_int, [P, I, I, I, P, P]),
     "codeps_reflect_pad_fold": (c_int, [P, I, I, I, I, I, P, P]),
     "codeps_panoptic_workspace_bytes": (c_size_t, [I, I, I]),
+    "codeps_channel_argmax": (c_int, [P, LL, I, I, P, P, P]),
+    "codeps_counters_add": (c_int, [P, P, I, P]),
+    "codeps_concat_f32": (c_int, [P, P, I, P, P]),
     "codeps_panoptic_fusion": (c_int, [P, P, P, I, I, I, ctypes.c_ulonglong, I, I, c_float, I, I, P, P, P, P, P, c_size_t, P]),
+    "codeps_panoptic_fusion_strided": (c_int, [P, P, LL, I, P, LL, LL, I, I, I, I, ctypes.c_ulonglong, I, I, c_float, I, I, P, P, P, P, P, P,
+                                               c_size_t, P]),
     "codeps_image_warp": (c_int, [P, P, P, P, P, I, I, I, I, I, P, P, P]),
     "codeps_image_warp_bwd_workspace_bytes": (c_size_t, [I]),
     "codeps_image_warp_bwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, c_size_t, P]),

@@ -49,14 +49,14 @@ class InstanceSegAlgo:
         offset_loss = self.offset_loss(offset_pred, offset, offset_weights)
         if thing_mask_logits is not None:
             thing_mask_loss = self.binary_mask_loss(thing_mask_logits, thing_mask.squeeze(1))
-            thing_mask_pred = torch.argmax(thing_mask_logits.detach(), dim=1).type(torch.uint8)
+            thing_mask_pred = F.channel_argmax(thing_mask_logits.detach(), torch.uint8)
         else:
             thing_mask_loss, thing_mask_pred = None, None
         return center_loss, offset_loss, center_pred, offset_pred, thing_mask_loss, thing_mask_pred
 
     def inference(self, feats, instance_head):
         center_pred, offset_pred, thing_mask_logits = instance_head(feats)
-        thing_mask_pred = None if thing_mask_logits is None else torch.argmax(thing_mask_logits, dim=1).type(torch.uint8)
+        thing_mask_pred = None if thing_mask_logits is None else F.channel_argmax(thing_mask_logits, torch.uint8)
         return center_pred, offset_pred, thing_mask_pred
 
     def evaluation(self):

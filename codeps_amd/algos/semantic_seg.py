@@ -60,16 +60,16 @@ class SemanticSegAlgo:
         if ignore_classes:
             masked = semantic_logits.detach().clone()
             masked[:, ignore_classes] = -float('inf')
-            semantic_pred = torch.argmax(masked, dim=1).type(torch.uint8)
+            semantic_pred = F.channel_argmax(masked, torch.uint8)
         else:
-            semantic_pred = torch.argmax(semantic_logits.detach(), dim=1).type(torch.uint8)
+            semantic_pred = F.channel_argmax(semantic_logits.detach(), torch.uint8)
         confusion_matrix = self._confusion(semantic_pred, semantic_gt_eval if semantic_gt_eval is not None else semantic_gt)
         semantic_loss = self.semantic_loss(semantic_logits, semantic_gt, semantic_weights)
         return semantic_loss, confusion_matrix, semantic_pred
 
     def inference(self, feats, semantic_head) -> Tuple[Tensor, Tensor]:
         semantic_logits = semantic_head(feats)
-        return torch.argmax(semantic_logits, dim=1).type(torch.uint8), semantic_logits
+        return F.channel_argmax(semantic_logits, torch.uint8), semantic_logits
 
     def evaluation(self, feats, semantic_head, semantic_gt: Tensor):
         semantic_pred, semantic_logits = self.inference(feats, semantic_head)
@@ -81,7 +81,7 @@ class SemanticSegAlgo:
             return None
         with torch.no_grad():           # the target prediction only feeds argmax / panoptic fusion
             target_probs = semantic_head(feats['target'][0])
-        return torch.argmax(target_probs, dim=1)
+        return F.channel_argmax(target_probs)
 
     def adaptation_supervised(self, feats, semantic_head, semantic_gt, semantic_weights, batched=None):
         """The supervised losses of the source and the mix-up keys (algos/semantic_seg.py:215-234)."""

@@ -464,6 +464,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     if (use_res) v += resv[u];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                } else if (residual) {                        // data gradient + the gradient that reached the same tensor by another path
+                    v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
                 }
                 *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
             }
@@ -655,6 +657,8 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
                     if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                } else if (residual) {
+                    v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
                 }
                 *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
             }
@@ -852,6 +856,8 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
                     if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                } else if (residual) {
+                    v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
                 }
                 *reinterpret_cast<f32x4*>(out + m * p.N + n) = v;
             }
@@ -1130,6 +1136,8 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
                     if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                } else if (residual) {
+                    v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
                 }
                 *reinterpret_cast<f32x4*>(out + m * p.N + n) = v;
             }
@@ -1414,6 +1422,8 @@ __global__ __launch_bounds__(384) void conv_halo3p_kernel(ConvP p, const float* 
                     if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                } else if (residual) {
+                    v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
                 }
                 *reinterpret_cast<f32x4*>(out + m * p.N + n) = v;
             }
@@ -1513,6 +1523,8 @@ __global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float*
                 if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+            } else if (residual) {
+                v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
             }
             *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
         }
@@ -1656,6 +1668,8 @@ __global__ __launch_bounds__(256) void conv_igemm16_lds_kernel(ConvP p, const fl
                 if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+            } else if (residual) {
+                v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
             }
             *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
         }
@@ -2939,7 +2953,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                     if (p.ksplit > 1) {
                         const long long MN = (long long)p.M * p.N;
                         hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
-                                           p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, MODE == MODE_FWD ? residual : nullptr,
+                                           p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
                                            MODE == MODE_FWD ? p.act : 0, out);
                     }
                     return;
@@ -2972,7 +2986,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             if (p.ksplit > 1) {
                 const long long MN = (long long)p.M * p.N;
                 hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
-                                   p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, MODE == MODE_FWD ? residual : nullptr,
+                                   p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
                                    MODE == MODE_FWD ? p.act : 0, out);
             }
             return;
@@ -2993,7 +3007,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     if (p.ksplit > 1) {
         const long long MN = (long long)p.M * p.N;
         hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
-                           p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, MODE == MODE_FWD ? residual : nullptr,
+                           p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
                            MODE == MODE_FWD ? p.act : 0, out);
     }
 }
@@ -3254,6 +3268,11 @@ extern "C" size_t codeps_conv2d_dgrad_workspace_bytes(const codeps_conv_desc* d,
 
 extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, float* dx,
                                    void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    return codeps_conv2d_dgrad_add(d, source, dz, w_dgrad, nullptr, dx, workspace, workspace_bytes, stream);
+}
+
+extern "C" int codeps_conv2d_dgrad_add(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, const float* add,
+                                       float* dx, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     int rc = check_conv(d, "conv2d_dgrad");
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(dz && w_dgrad && dx && (source == 0 || (source == 1 && d->c1 > 0)), CODEPS_ERR_ARG, "conv2d_dgrad: bad arguments");
@@ -3280,9 +3299,10 @@ extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const 
             const int ky0 = (py + d->pad) & 1, kx0 = (px + d->pad) & 1;
             if (ky0 >= d->kh || kx0 >= d->kw) need_zero = true;
         }
-        if (need_zero) {
-            hipError_t e = hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream);
-            CODEPS_REQUIRE(e == hipSuccess, CODEPS_ERR_LAUNCH, "conv2d_dgrad: memset failed: %s", hipGetErrorString(e));
+        if (need_zero) {                                        // classes no tap reaches: zero, or the incoming gradient alone
+            hipError_t e = add ? hipMemcpyAsync(dx, add, (size_t)p.M * p.N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream)
+                               : hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream);
+            CODEPS_REQUIRE(e == hipSuccess, CODEPS_ERR_LAUNCH, "conv2d_dgrad: memset / copy failed: %s", hipGetErrorString(e));
         }
         for (int c = 0; c < 4; ++c) {
             ConvP q = p;
@@ -3293,12 +3313,12 @@ extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const 
             q.Hc = (d->in_h - q.py + 1) / 2; q.Wc = (d->in_w - q.px + 1) / 2;
             if (q.Hc <= 0 || q.Wc <= 0) continue;
             q.M = d->batch * q.Hc * q.Wc;
-            dispatch_igemm<MODE_DGRAD>(q, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, nullptr, dx, (hipStream_t)stream);
+            dispatch_igemm<MODE_DGRAD>(q, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, add, dx, (hipStream_t)stream);
         }
         CODEPS_CHECK_LAUNCH("conv_igemm_kernel<dgrad, parity classes>");
         return CODEPS_OK;
     }
-    dispatch_igemm<MODE_DGRAD>(p, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, nullptr, dx, (hipStream_t)stream);
+    dispatch_igemm<MODE_DGRAD>(p, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, add, dx, (hipStream_t)stream);
     CODEPS_CHECK_LAUNCH("conv_igemm_kernel<dgrad>");
     return CODEPS_OK;
 }

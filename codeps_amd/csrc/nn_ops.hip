@@ -1519,6 +1519,77 @@ extern "C" int codeps_guda_gather_bwd(const float* grad_out, int batch, int h, i
     return CODEPS_OK;
 }
 
+// dst = src[0] ++ src[1] ++ ... (up to 8 contiguous fp32 sources, pointers and lengths by value): torch.cat along the leading dimension
+// and plain copies (the padded per-channel vectors, the pieces of a split batch's gradient) without a library kernel
+struct CatSet { const float* src[8]; long long end[8]; };       // end[i] = elements of sources 0 .. i
+__global__ __launch_bounds__(256) void concat_kernel(CatSet s, int n, float* __restrict__ dst) {
+    const long long total = s.end[n - 1];
+    const bool vec = (total & 3) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0;
+    bool al = vec;
+    for (int k = 0; k < n; ++k) al = al && (s.end[k] & 3) == 0 && (reinterpret_cast<size_t>(s.src[k]) & 15) == 0;
+    if (al) {
+        for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * 1024) {
+            int k = 0;
+            while (i >= s.end[k]) ++k;
+            const long long off = i - (k ? s.end[k - 1] : 0);
+            *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(s.src[k] + off);
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            int k = 0;
+            while (i >= s.end[k]) ++k;
+            dst[i] = s.src[k][i - (k ? s.end[k - 1] : 0)];
+        }
+    }
+}
+
+extern "C" int codeps_concat_f32(const float* const* sources, const long long* counts, int n, float* dst, codeps_stream_t stream) {
+    CODEPS_REQUIRE(sources && counts && dst && n >= 1 && n <= 8, CODEPS_ERR_ARG, "concat_f32: 1 .. 8 sources");
+    CatSet s;
+    long long total = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (i < n) { CODEPS_REQUIRE(sources[i] && counts[i] >= 0, CODEPS_ERR_ARG, "concat_f32: bad source %d", i); total += counts[i]; }
+        s.src[i] = i < n ? sources[i] : nullptr;
+        s.end[i] = total;
+    }
+    if (total == 0) return CODEPS_OK;
+    hipLaunchKernelGGL(concat_kernel, dim3(grid_for((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, n, dst);
+    CODEPS_CHECK_LAUNCH("concat_kernel");
+    return CODEPS_OK;
+}
+
+// arg-max over the first C channels of every NHWC row (torch.argmax semantics: first index of the maximum, a NaN is the maximum),
+// written as int64 and / or uint8 in one pass
+__global__ __launch_bounds__(256) void channel_argmax_kernel(const float* __restrict__ x, long long M, int C, int Cp, long long* __restrict__ o64,
+                                                             uint8_t* __restrict__ o8) {
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+        const float* row = x + (size_t)r * Cp;
+        float best = row[0];
+        int bi = 0;
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c0);          // Cp % 4 == 0: the padding lanes are never compared
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e;
+                if (c == 0 || c >= C) continue;
+                const float t = v[e];
+                if ((t > best || t != t) && best == best) { best = t; bi = c; }
+            }
+        }
+        if (o64) o64[r] = bi;
+        if (o8) o8[r] = (uint8_t)bi;
+    }
+}
+
+extern "C" int codeps_channel_argmax(const float* x, long long rows, int c, int c_pad, long long* out_i64, unsigned char* out_u8,
+                                     codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && (out_i64 || out_u8) && rows > 0 && c > 0 && c <= c_pad && (c_pad % 4) == 0 && (!out_u8 || c <= 256), CODEPS_ERR_ARG,
+                   "channel_argmax: bad arguments (c_pad %% 4 == 0; uint8 output: c <= 256)");
+    hipLaunchKernelGGL(channel_argmax_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, c, c_pad, out_i64, out_u8);
+    CODEPS_CHECK_LAUNCH("channel_argmax_kernel");
+    return CODEPS_OK;
+}
+
 extern "C" int codeps_softmax_fwd(const float* x, long long rows, int c, int c_pad, float* y, codeps_stream_t stream) {
     CODEPS_REQUIRE(x && y && rows > 0 && c > 0 && c <= 32 && c <= c_pad, CODEPS_ERR_ARG, "softmax_fwd: bad arguments (c <= 32)");
     if (c_pad == 16) hipLaunchKernelGGL(softmax16_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, c, y);

@@ -26,16 +26,53 @@ struct PanP {
     int H, W, top_k, nms, label_divisor, void_label;
     float threshold;
     unsigned long long thing_mask;   // bit c set <=> class c is a thing
+    // element strides of the centre heat map (batch, pixel) and of the offset field (batch, channel, pixel): the maps may be
+    // channel planes of NCHW tensors (pixel stride 1) or channels of NHWC tensors (pixel stride = padded channel count)
+    long long ctr_bs, off_bs, off_cs;
+    int ctr_ps, off_ps;
 };
 
 __device__ __forceinline__ float thr_val(float v, float thr) { return v > thr ? v : -1.f; }
 
+// 7x7 (<= 7x7) window maximum as a row pass and a column pass over a 32 x 32 tile with its halo in LDS (max is associative: the same
+// value as the direct 49-element maximum, 14 + 2 LDS reads per pixel instead of 49 global ones)
+constexpr int NT = 32, NR = 3;
+__global__ __launch_bounds__(256) void nms_flag_tile_kernel(PanP p, int tiles_x, const float* __restrict__ ctr, uint8_t* __restrict__ flag) {
+    __shared__ float t[NT + 2 * NR][NT + 2 * NR + 1];
+    __shared__ float rm[NT + 2 * NR][NT + 1];
+    const int HW = p.H * p.W, b = blockIdx.y, r = (p.nms - 1) / 2, E = NT + 2 * r;
+    const int y0 = (blockIdx.x / tiles_x) * NT, x0 = (blockIdx.x % tiles_x) * NT;
+    const float* c = ctr + (size_t)b * p.ctr_bs;
+    for (int i = threadIdx.x; i < E * E; i += 256) {
+        const int yy = i / E, xx = i % E, y = y0 - r + yy, x = x0 - r + xx;
+        t[yy][xx] = (y >= 0 && y < p.H && x >= 0 && x < p.W) ? thr_val(c[(size_t)(y * p.W + x) * p.ctr_ps], p.threshold) : -INFINITY;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < E * NT; i += 256) {
+        const int yy = i / NT, xx = i % NT;
+        float m = t[yy][xx];
+        for (int d = 1; d <= 2 * r; ++d) m = fmaxf(m, t[yy][xx + d]);
+        rm[yy][xx] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT * NT; i += 256) {
+        const int yy = i / NT, xx = i % NT, y = y0 + yy, x = x0 + xx;
+        if (y >= p.H || x >= p.W) continue;
+        float m = rm[yy][xx];
+        for (int d = 1; d <= 2 * r; ++d) m = fmaxf(m, rm[yy + d][xx]);
+        const float v = t[yy + r][xx + r];
+        flag[(size_t)b * HW + y * p.W + x] = (v == m && v > 0.f) ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void nms_flag_kernel(PanP p, const float* __restrict__ ctr, uint8_t* __restrict__ flag) {
     const int HW = p.H * p.W, b = blockIdx.y, r = (p.nms - 1) / 2;
-    const float* c = ctr + (size_t)b * HW;
+    const float* c0 = ctr + (size_t)b * p.ctr_bs;
+    const int ps = p.ctr_ps;
+    auto cat = [&](int i) { return c0[(size_t)i * ps]; };
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         const int y = i / p.W, x = i % p.W;
-        const float v = thr_val(c[i], p.threshold);
+        const float v = thr_val(cat(i), p.threshold);
         float m = -INFINITY;
         for (int dy = -r; dy <= r; ++dy) {
             const int yy = y + dy;
@@ -43,7 +80,7 @@ __global__ __launch_bounds__(256) void nms_flag_kernel(PanP p, const float* __re
             for (int dx = -r; dx <= r; ++dx) {
                 const int xx = x + dx;
                 if (xx < 0 || xx >= p.W) continue;
-                m = fmaxf(m, thr_val(c[yy * p.W + xx], p.threshold));
+                m = fmaxf(m, thr_val(cat(yy * p.W + xx), p.threshold));
             }
         }
         flag[(size_t)b * HW + i] = (v == m && v > 0.f) ? 1 : 0;
@@ -67,7 +104,8 @@ __global__ __launch_bounds__(1024) void select_kernel(PanP p, int nchunk, const 
     __shared__ int sh_k, sh_prefix, sh_rank, sh_cnt;
     __shared__ int scan[1024];
     const int b = blockIdx.x, HW = p.H * p.W, tid = threadIdx.x;
-    const float* c = ctr + (size_t)b * HW;
+    const float* c0 = ctr + (size_t)b * p.ctr_bs;
+    const int cps = p.ctr_ps;
     const uint8_t* f = flag + (size_t)b * HW;
     int* cnt = counts + b * nchunk;
     // total number of candidates
@@ -90,7 +128,7 @@ __global__ __launch_bounds__(1024) void select_kernel(PanP p, int nchunk, const 
             const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
             for (int i = tid; i < HW; i += 1024) {
                 if (!f[i]) continue;
-                const unsigned key = __float_as_uint(c[i]);
+                const unsigned key = __float_as_uint(c0[(size_t)i * cps]);
                 if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
             }
             __syncthreads();
@@ -111,7 +149,7 @@ __global__ __launch_bounds__(1024) void select_kernel(PanP p, int nchunk, const 
     for (int base = 0; base < HW; base += 1024) {
         if (cnt[base / CHUNK] == 0) continue;               // block-uniform: most chunks hold no candidate
         const int i = base + tid;
-        const int keep = (i < HW && f[i] && c[i] > tau) ? 1 : 0;
+        const int keep = (i < HW && f[i] && c0[(size_t)i * cps] > tau) ? 1 : 0;
         scan[tid] = keep;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {          // inclusive Hillis-Steele scan
@@ -143,19 +181,25 @@ __global__ __launch_bounds__(256) void group_kernel(PanP p, const uint8_t* __res
     for (int i = threadIdx.x; i < MAXC * NCLS; i += 256) lh[i] = 0;
     __syncthreads();
     const uint8_t* s = sem + (size_t)b * HW;
-    const float* oy = offs + (size_t)b * 2 * HW;
-    const float* ox = oy + HW;
+    const float* oy = offs + (size_t)b * p.off_bs;
+    const float* ox = oy + p.off_cs;
+    const int ops = p.off_ps;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         const int cls = s[i];
         int id = 0;
         if (Kc > 0 && cls < 64 && ((p.thing_mask >> cls) & 1ull)) {
-            const float yy = __fadd_rn((float)(i / p.W), oy[i]), xx = __fadd_rn((float)(i % p.W), ox[i]);
-            float best = INFINITY;
+            const float yy = __fadd_rn((float)(i / p.W), oy[(size_t)i * ops]), xx = __fadd_rn((float)(i % p.W), ox[(size_t)i * ops]);
+            // argmin_k sqrt(d2_k), first index on ties (the reference compares the ROOTS).  The correctly rounded root is monotone, so
+            // d2_k >= best d2 cannot give a strictly smaller root: only a smaller d2 takes the root (a handful of times per pixel)
+            float best = INFINITY, best2 = INFINITY;
             int bi = 0;
             for (int k = 0; k < Kc; ++k) {
                 const float dy = __fsub_rn(cy[k], yy), dx = __fsub_rn(cx[k], xx);
-                const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx)));
-                if (d < best) { best = d; bi = k; }
+                const float d2 = __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx));
+                if (d2 < best2) {
+                    const float d = __fsqrt_rn(d2);
+                    if (d < best) { best = d; bi = k; best2 = d2; }
+                }
             }
             id = bi + 1;
             if (cls < NCLS) atomicAdd(&lh[bi * NCLS + cls], 1);
@@ -188,7 +232,7 @@ __global__ void assign_kernel(PanP p, const int* __restrict__ state, const int* 
 }
 
 __global__ __launch_bounds__(256) void paste_kernel(PanP p, const uint8_t* __restrict__ sem, const uint8_t* __restrict__ ins,
-                                                    const int* __restrict__ idmap, int16_t* __restrict__ pan) {
+                                                    const int* __restrict__ idmap, int16_t* __restrict__ pan, long long* __restrict__ ins64) {
     const int b = blockIdx.y, HW = p.H * p.W;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         const size_t o = (size_t)b * HW + i;
@@ -198,6 +242,7 @@ __global__ __launch_bounds__(256) void paste_kernel(PanP p, const uint8_t* __res
         else if (cls == p.void_label || (cls < 64 && ((p.thing_mask >> cls) & 1ull))) v = -1;
         else v = cls * p.label_divisor;
         pan[o] = (int16_t)v;
+        if (ins64) ins64[o] = id;
     }
 }
 
@@ -219,6 +264,17 @@ extern "C" int codeps_panoptic_fusion(const uint8_t* semantic, const float* cent
                                       unsigned long long thing_class_mask, int label_divisor, int void_label, float threshold,
                                       int nms_kernel, int top_k, int16_t* panoptic, uint8_t* instance, int* centers, int* state,
                                       void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    return codeps_panoptic_fusion_strided(semantic, center, (long long)h * w, 1, offset, 2LL * h * w, (long long)h * w, 1, batch, h, w, thing_class_mask,
+                                          label_divisor, void_label, threshold, nms_kernel, top_k, panoptic, instance, nullptr, centers, state, workspace,
+                                          workspace_bytes, stream);
+}
+
+extern "C" int codeps_panoptic_fusion_strided(const uint8_t* semantic, const float* center, long long center_batch_stride, int center_pixel_stride,
+                                              const float* offset, long long offset_batch_stride, long long offset_channel_stride,
+                                              int offset_pixel_stride, int batch, int h, int w, unsigned long long thing_class_mask, int label_divisor,
+                                              int void_label, float threshold, int nms_kernel, int top_k, int16_t* panoptic, uint8_t* instance,
+                                              long long* instance_i64, int* centers, int* state, void* workspace, size_t workspace_bytes,
+                                              codeps_stream_t stream) {
     CODEPS_REQUIRE(semantic && center && offset && panoptic && instance && centers && state && workspace && batch > 0 && h > 0 && w > 0,
                    CODEPS_ERR_ARG, "panoptic_fusion: null pointer / bad shape");
     CODEPS_REQUIRE(top_k >= 1 && top_k <= MAXC && (nms_kernel % 2) == 1 && label_divisor > 0, CODEPS_ERR_ARG,
@@ -227,6 +283,9 @@ extern "C" int codeps_panoptic_fusion(const uint8_t* semantic, const float* cent
     PanP p;
     p.H = h; p.W = w; p.top_k = top_k; p.nms = nms_kernel; p.label_divisor = label_divisor; p.void_label = void_label;
     p.threshold = threshold; p.thing_mask = thing_class_mask;
+    CODEPS_REQUIRE(center_pixel_stride >= 1 && offset_pixel_stride >= 1, CODEPS_ERR_ARG, "panoptic_fusion: strides must be positive");
+    p.ctr_bs = center_batch_stride; p.ctr_ps = center_pixel_stride;
+    p.off_bs = offset_batch_stride; p.off_cs = offset_channel_stride; p.off_ps = offset_pixel_stride;
     const int HW = h * w, nchunk = cdiv(HW, CHUNK);
     char* ws = (char*)workspace;
     uint8_t* flag = (uint8_t*)ws; ws += align_up((size_t)batch * HW, 256);
@@ -235,14 +294,21 @@ extern "C" int codeps_panoptic_fusion(const uint8_t* semantic, const float* cent
     int* idmap = (int*)ws;
     hipStream_t st = (hipStream_t)stream;
     const int gx = std::min(cdiv(HW, 256), 1024);
+    // centre list: zero beyond the kept entries (callers read the whole [B,256,2] array)
+    CODEPS_REQUIRE(hipMemsetAsync(centers, 0, (size_t)batch * MAXC * 2 * sizeof(int), st) == hipSuccess, CODEPS_ERR_LAUNCH, "panoptic_fusion: memset failed");
     hipLaunchKernelGGL(zero_int_kernel, dim3(64), dim3(256), 0, st, hist, (long long)batch * MAXC * NCLS);
-    hipLaunchKernelGGL(nms_flag_kernel, dim3(gx, batch), dim3(256), 0, st, p, center, flag);
+    if (nms_kernel <= 2 * NR + 1) {
+        const int tiles_x = cdiv(w, NT), tiles_y = cdiv(h, NT);
+        hipLaunchKernelGGL(nms_flag_tile_kernel, dim3(tiles_x * tiles_y, batch), dim3(256), 0, st, p, tiles_x, center, flag);
+    } else {
+        hipLaunchKernelGGL(nms_flag_kernel, dim3(gx, batch), dim3(256), 0, st, p, center, flag);
+    }
     hipLaunchKernelGGL(block_count_kernel, dim3(nchunk, batch), dim3(256), 0, st, HW, nchunk, (const uint8_t*)flag, counts);
     hipLaunchKernelGGL(select_kernel, dim3(batch), dim3(1024), 0, st, p, nchunk, center, (const uint8_t*)flag, counts, state, centers);
     hipLaunchKernelGGL(group_kernel, dim3(std::min(gx, 256), batch), dim3(256), 0, st, p, semantic, offset, (const int*)state, (const int*)centers,
                        instance, hist);
     hipLaunchKernelGGL(assign_kernel, dim3(batch), dim3(64), 0, st, p, (const int*)state, (const int*)hist, idmap);
-    hipLaunchKernelGGL(paste_kernel, dim3(gx, batch), dim3(256), 0, st, p, semantic, (const uint8_t*)instance, (const int*)idmap, panoptic);
+    hipLaunchKernelGGL(paste_kernel, dim3(gx, batch), dim3(256), 0, st, p, semantic, (const uint8_t*)instance, (const int*)idmap, panoptic, instance_i64);
     CODEPS_CHECK_LAUNCH("panoptic kernels");
     return CODEPS_OK;
 }

@@ -91,7 +91,29 @@ __global__ void weighted_sum_bwd_kernel(SumArgs a, int n, const float* __restric
     }
 }
 
+// up to 64 int64 counters bumped by one launch: the pointers travel BY VALUE in the kernel arguments (no device table to fill)
+struct CounterSet { long long* p[64]; int inc[64]; };
+__global__ void counters_add_kernel(CounterSet s, int n) {
+    const int i = threadIdx.x;
+    if (i < n) *s.p[i] += s.inc[i];
+}
+
 }  // namespace
+
+extern "C" int codeps_counters_add(long long* const* counters, const int* increments, int n, codeps_stream_t stream) {
+    CODEPS_REQUIRE(counters && increments && n >= 0, CODEPS_ERR_ARG, "counters_add: bad arguments");
+    for (int base = 0; base < n; base += 64) {
+        CounterSet s;
+        const int m = n - base < 64 ? n - base : 64;
+        for (int i = 0; i < m; ++i) {
+            CODEPS_REQUIRE(counters[base + i] != nullptr, CODEPS_ERR_ARG, "counters_add: null counter");
+            s.p[i] = counters[base + i]; s.inc[i] = increments[base + i];
+        }
+        hipLaunchKernelGGL(counters_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s, m);
+    }
+    CODEPS_CHECK_LAUNCH("counters_add_kernel");
+    return CODEPS_OK;
+}
 
 extern "C" int codeps_step_counter_add(uint64_t* counter, uint64_t increment, codeps_stream_t stream) {
     CODEPS_REQUIRE(counter != nullptr, CODEPS_ERR_ARG, "step_counter_add: null counter");

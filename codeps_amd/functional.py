@@ -31,6 +31,43 @@ def step_counter_add(counter, increment=1):
     check(lib().codeps_step_counter_add(ptr(counter), int(increment), stream_ptr()), "codeps_step_counter_add")
 
 
+def counters_add(counters, increments):
+    """counters[i] += increments[i] for 0-dim / 1-element int64 device tensors, one launch (C ABI: codeps_counters_add)."""
+    n = len(counters)
+    if n == 0:
+        return
+    for t in counters:
+        require_cuda(t)
+        if t.dtype != torch.int64 or t.numel() != 1:
+            raise CodepsHipError("counters_add: int64 tensors with one element")
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in counters])
+    incs = (ctypes.c_int * n)(*[int(v) for v in increments])
+    check(lib().codeps_counters_add(ptrs, incs, n, stream_ptr()), "codeps_counters_add")
+
+
+def concat_rows(parts, out=None):
+    """torch.cat(parts, 0) for contiguous fp32 device tensors of equal trailing shape in one launch of this library (<= 8 parts per
+    launch; C ABI: codeps_concat_f32).  `out`: optional destination (flat length = the parts' total)."""
+    parts = [p_.contiguous() for p_ in parts]
+    for p_ in parts:
+        require_cuda(p_)
+        if p_.dtype != torch.float32:
+            raise CodepsHipError("concat_rows: fp32 tensors")
+    total = sum(p_.numel() for p_ in parts)
+    if out is None:
+        out = torch.empty((sum(p_.shape[0] for p_ in parts),) + tuple(parts[0].shape[1:]), dtype=torch.float32, device=parts[0].device)
+    flat, pos = out.view(-1), 0
+    if flat.numel() < total:
+        raise CodepsHipError("concat_rows: destination too small")
+    for i in range(0, len(parts), 8):
+        grp = parts[i:i + 8]
+        srcs = (ctypes.c_void_p * len(grp))(*[g.data_ptr() for g in grp])
+        cnts = (ctypes.c_longlong * len(grp))(*[g.numel() for g in grp])
+        check(lib().codeps_concat_f32(srcs, cnts, len(grp), ctypes.c_void_p(flat.data_ptr() + 4 * pos), stream_ptr()), "codeps_concat_f32")
+        pos += sum(g.numel() for g in grp)
+    return out
+
+
 def _f32c(t):
     """fp32 + contiguous without copying when already so."""
     if t.dtype != torch.float32:
@@ -352,7 +389,7 @@ def _pad_vec(v, n):
     if hit is not None and hit[4]() is src and hit[0] == stamp[0] and hit[3].device == v.device:
         _wait_written(hit[5])
         if (hit[1], hit[2]) != stamp[1:]:
-            hit[3][:v.numel()].copy_(v)
+            concat_rows([v.reshape(-1)], out=hit[3])               # (the padding lanes keep their zeros)
             hit[1], hit[2], hit[5] = stamp[1], stamp[2], _mark_written()
         return hit[3]
     out = torch.zeros(n, dtype=torch.float32, device=v.device)
@@ -441,7 +478,7 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv(cat(up(x0), x1), W) * scale + shift + residual) on NHWC tensors (C ABI conv2d)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, scale, shift, residual, stride, pad, pad_mode, act, up0, macs_per_out):
+    def forward(ctx, x0, x1, weight, bias, scale, shift, residual, stride, pad, pad_mode, act, up0, macs_per_out, fork=False):
         require_cuda(x0, x1, weight)
         co, ci, kh, kw = weight.shape
         cop = pad16(co)
@@ -471,12 +508,19 @@ class _Conv2d(torch.autograd.Function):
         ctx.weight_ref = weakref.ref(weight)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x0, x1, y if act else None, wd, sc)
+        ctx.fork = bool(fork)
+        if fork:
+            # second output = x0 itself (an alias): whatever else consumes the tensor (a residual connection, a down-sampling
+            # shortcut) takes THIS output, so its gradient arrives here with dy and the data-gradient kernel adds it in its
+            # epilogue -- instead of autograd summing two full-size tensors with a library kernel afterwards
+            return y, x0
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_fork=None):
         x0, x1, y, wd, sc = ctx.saved_tensors
         desc = ctx.desc
+        add = g_fork.contiguous() if (ctx.fork and g_fork is not None) else None
         dy = dy.contiguous()
         rows, cop = dy.numel() // dy.shape[-1], dy.shape[-1]
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
@@ -536,8 +580,9 @@ class _Conv2d(torch.autograd.Function):
             t0 = _prof_begin()
             wsb = lib().codeps_conv2d_dgrad_workspace_bytes(ctypes.byref(desc), 0)            # split-K scratch (small-M, deep-K shapes only)
             ws2 = _workspace(wsb, dy.device, "splitk") if wsb else None
-            check(lib().codeps_conv2d_dgrad(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(dx0), ptr(ws2), ws2.numel() if ws2 is not None else 0,
-                                            stream_ptr()), "codeps_conv2d_dgrad")
+            check(lib().codeps_conv2d_dgrad_add(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(add), ptr(dx0), ptr(ws2),
+                                                ws2.numel() if ws2 is not None else 0, stream_ptr()), "codeps_conv2d_dgrad_add")
+            add = None                                             # consumed by the kernel's epilogue
             _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci), desc)
         if x1 is not None and ctx.needs_input_grad[1]:
             dx1 = torch.empty_like(x1)
@@ -558,7 +603,9 @@ class _Conv2d(torch.autograd.Function):
             _prof_end(t0, "conv_wgrad", ctx.flops, desc)
             if sink is not None:
                 dw = None               # accumulated in place into the flat gradient buffer
-        return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None, None
+        if add is not None:                                        # (a data-gradient form without the fused add, or no data gradient)
+            dx0 = add if dx0 is None else dx0.add_(add)
+        return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None, None, None
 
 
 def _pair(v):
@@ -566,13 +613,14 @@ def _pair(v):
 
 
 def conv2d(x0, weight, bias=None, *, x1=None, scale=None, shift=None, residual=None, stride=1, pad=0, pad_mode="zeros",
-           act=None, up0=False, macs_per_out=None):
+           act=None, up0=False, macs_per_out=None, fork=False):
     """NHWC convolution.  x0 [B,H,W,C0p]; optional skip x1 concatenated along channels after an
     optional nearest-x2 upsample of x0; weight OIHW; stride / pad: int or (vertical, horizontal);
     returns [B,Ho,Wo,pad16(Cout)].  macs_per_out: algorithmic multiply-adds per output element for the profiler when
-    the weight tensor is a re-laid-out form of the reference's (stem_conv2d)."""
+    the weight tensor is a re-laid-out form of the reference's (stem_conv2d).  fork=True -> (y, x0'): x0' is x0 for every
+    other consumer of the tensor; the gradient they send back is added inside the data-gradient kernel (no separate sum)."""
     return _Conv2d.apply(x0, x1, weight, bias, scale, shift, residual, _pair(stride), _pair(pad),
-                         1 if pad_mode == "reflect" else 0, ACT[act], bool(up0), macs_per_out)
+                         1 if pad_mode == "reflect" else 0, ACT[act], bool(up0), macs_per_out, bool(fork))
 
 
 _stem_cache = {}
@@ -1240,6 +1288,28 @@ class _Softmax(torch.autograd.Function):
         return dx, None
 
 
+def channel_argmax(probs, dtype=torch.int64):
+    """torch.argmax(probs, dim=1) for an NCHW tensor that is (a view of) an NHWC tensor of this library -> labels [B,H,W] in
+    int64 (torch's dtype) or uint8.  An int64 result carries its uint8 form as `._codeps_u8` (what panoptic_fusion reads): one
+    pass, no conversion kernels (algos/semantic_seg.py:70-86)."""
+    require_cuda(probs)
+    b, c, h, w = probs.shape
+    probs = probs.detach()
+    st = probs.stride()
+    if probs.dtype == torch.float32 and st[1] == 1 and st[3] >= c and st[3] % 4 == 0 and st[2] == w * st[3] and st[0] == h * w * st[3]:
+        x = probs.as_strided((b, h, w, st[3]), (st[0], st[2], st[3], 1))      # a channel view of a padded NHWC tensor: read in place
+    else:
+        x = from_nchw(probs).contiguous()
+    cp = x.shape[-1]
+    o8 = torch.empty(b, h, w, dtype=torch.uint8, device=probs.device)
+    o64 = torch.empty(b, h, w, dtype=torch.int64, device=probs.device) if dtype == torch.int64 else None
+    check(lib().codeps_channel_argmax(ptr(x), b * h * w, c, cp, ptr(o64), ptr(o8), stream_ptr()), "codeps_channel_argmax")
+    if o64 is None:
+        return o8
+    o64._codeps_u8 = o8
+    return o64
+
+
 def channel_softmax(x, c):
     """Softmax over the first c channels of NHWC logits (padding channels -> 0)."""
     return _Softmax.apply(x, int(c))
@@ -1463,6 +1533,8 @@ class _SplitBatch(torch.autograd.Function):
             pos = b1
             parts.append(g if g is not None else torch.zeros((b1 - b0,) + ctx.shape[1:], dtype=like.dtype, device=like.device))
         if covered and pos == ctx.shape[0]:
+            if like.dtype == torch.float32 and len(parts) <= 8:
+                return concat_rows(parts), None
             return torch.cat(parts, 0), None
         out = torch.zeros(ctx.shape, dtype=like.dtype, device=like.device)       # overlapping / partial spans: accumulate
         for (b0, b1), g in zip(ctx.bounds, gs):
@@ -1732,23 +1804,38 @@ def panoptic_fusion(semantic, center, offset, thing_list, label_divisor=1000, vo
     centers int32 [B,256,2], state int32 [B,4] = (#candidates, #centres, ., .)).  No host sync."""
     require_cuda(semantic, center, offset)
     b, h, w = semantic.shape
-    sem8 = semantic if semantic.dtype == torch.uint8 else semantic.to(torch.uint8)
+    # the uint8 form of an int64 label map made by channel_argmax travels with it (no conversion pass)
+    sem8 = semantic if semantic.dtype == torch.uint8 else getattr(semantic, "_codeps_u8", None)
+    if sem8 is None or tuple(sem8.shape) != (b, h, w):
+        sem8 = semantic.to(torch.uint8)
     sem8 = sem8.contiguous()
-    center, offset = _f32c(center.detach()), _f32c(offset.detach())
+    center, offset = center.detach(), offset.detach()
+    if center.dtype != torch.float32 or offset.dtype != torch.float32:
+        center, offset = center.float(), offset.float()
+    # the maps are read in place through their strides (NCHW planes, or channels of the instance head's NHWC outputs)
+    cs, os_ = center.stride(), offset.stride()
+    if not (cs[2] == w * cs[3] and os_[2] == w * os_[3] and cs[3] >= 1 and os_[3] >= 1 and tuple(center.shape) == (b, 1, h, w)
+            and tuple(offset.shape) == (b, 2, h, w)):
+        center, offset = center.contiguous(), offset.contiguous()
+        cs, os_ = center.stride(), offset.stride()
     mask = 0
     for c in thing_list:
         mask |= 1 << int(c)
     dev = semantic.device
     pan = torch.empty(b, h, w, dtype=torch.int16, device=dev)
     inst = torch.empty(b, h, w, dtype=torch.uint8, device=dev)
-    centers = torch.zeros(b, 256, 2, dtype=torch.int32, device=dev)
+    inst64 = torch.empty(b, h, w, dtype=torch.int64, device=dev) if semantic.dtype == torch.int64 else None
+    centers = torch.empty(b, 256, 2, dtype=torch.int32, device=dev)
     state = torch.empty(b, 4, dtype=torch.int32, device=dev)
     nbytes = lib().codeps_panoptic_workspace_bytes(b, h, w)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(lib().codeps_panoptic_fusion(ptr(sem8), ptr(center), ptr(offset), b, h, w, mask, label_divisor, void_label, threshold,
-                                       nms_kernel, top_k, ptr(pan), ptr(inst), ptr(centers), ptr(state), ptr(ws), nbytes,
-                                       stream_ptr()), "codeps_panoptic_fusion")
-    if semantic.dtype != torch.uint8:
+    ws = _workspace(nbytes, dev, "panoptic")
+    check(lib().codeps_panoptic_fusion_strided(ptr(sem8), ptr(center), cs[0], cs[3], ptr(offset), os_[0], os_[1], os_[3], b, h, w, mask,
+                                               label_divisor, void_label, threshold, nms_kernel, top_k, ptr(pan), ptr(inst), ptr(inst64),
+                                               ptr(centers), ptr(state), ptr(ws), ws.numel(), stream_ptr()),
+          "codeps_panoptic_fusion_strided")
+    if inst64 is not None:
+        inst = inst64
+    elif semantic.dtype != torch.uint8:
         inst = inst.to(semantic.dtype)
     return pan, inst, centers, state
 

@@ -1,4 +1,5 @@
 """Shared helpers: conv + BatchNorm (+ReLU, +residual) on NHWC through the C ABI."""
+import os
 import weakref
 
 import torch
@@ -15,6 +16,7 @@ _nbt_pending = []
 
 
 _stats_epoch = [0]
+_FORK = os.environ.get("CODEPS_FORK", "1") != "0"      # A/B switch: 0 = autograd sums the gradients of a tensor with two consumers
 
 
 def _count_batch(bn, n):
@@ -26,8 +28,7 @@ def _count_batch(bn, n):
 
 def flush_bn_counters():
     if _nbt_pending:
-        with torch.no_grad():
-            torch._foreach_add_([t for t, _ in _nbt_pending], [n for _, n in _nbt_pending])
+        F.counters_add([t for t, _ in _nbt_pending], [n for _, n in _nbt_pending])
         _nbt_pending.clear()
 
 
@@ -51,10 +52,16 @@ def folded_bn(bn: nn.BatchNorm2d):
     return scale, shift
 
 
-def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None, groups=None, stem=False):
+def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None, groups=None, stem=False, fork=False):
     """act(BN(conv(x)) + residual).  Eval-mode BN is folded into the conv epilogue (one kernel);
     train-mode BN uses batch statistics (`sync` = cross-rank sum reducer for SyncBatchNorm).
-    stem=True: x is in the double-pixel stem layout and conv is ResNet's conv1 (F.stem_conv2d)."""
+    stem=True: x is in the double-pixel stem layout and conv is ResNet's conv1 (F.stem_conv2d).
+    fork=True -> (out, x'): x' is x for the block's other consumer of the tensor (identity / shortcut); when x needs a gradient the
+    convolution's data-gradient kernel then adds the gradient that comes back through x' in its epilogue (F.conv2d(fork=True))."""
+    if fork:
+        if not (_FORK and torch.is_grad_enabled() and x.requires_grad) or stem:
+            return conv_bn(x, conv, bn, act, residual, sync, groups, stem), x
+        return _conv_bn_fork(x, conv, bn, act, residual, sync, groups)
     stride, pad = conv.stride[0], conv.padding[0]
     if stem == "s3":                   # frozen 3-channel stem (eval BN folded, no gradients): F.stem3_conv2d, K = 224
         scale, shift = folded_bn(bn)
@@ -82,6 +89,23 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
         return F.batch_norm_eval(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual=residual, act=act)
     scale, shift = folded_bn(bn)
     return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act)
+
+
+def _conv_bn_fork(x, conv, bn, act, residual, sync, groups):
+    """conv_bn for an input that needs a gradient and has a second consumer (BN kept as its own op: x needs a gradient, so either BN is
+    in train mode or, with eval statistics, its output still has to carry the graph)."""
+    stride, pad = conv.stride[0], conv.padding[0]
+    if bn.training:
+        y, xa = F.conv2d(x, conv.weight, stride=stride, pad=pad, fork=True)
+        out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                 residual=residual, act=act, reduce_fn=sync, groups=groups)
+        _count_batch(bn, len(groups) if groups else 1)
+        return out, xa
+    if bn.weight.requires_grad or bn.bias.requires_grad:
+        y, xa = F.conv2d(x, conv.weight, stride=stride, pad=pad, fork=True)
+        return F.batch_norm_eval(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual=residual, act=act), xa
+    scale, shift = folded_bn(bn)
+    return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act, fork=True)
 
 
 def dwconv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, sync=None):

@@ -6,6 +6,7 @@ from typing import Tuple, Union
 import os
 
 import numpy as np
+import torch
 from numpy.typing import ArrayLike
 from torch import Tensor, nn
 
@@ -26,6 +27,7 @@ def _make_decoder(module, num_ch_enc, num_ch_dec, use_skips):
 
 
 _UPCONV16 = os.environ.get("CODEPS_UPCONV16", "1") != "0"      # A/B switch: 0 = the generic engine's fused-gather form
+_FORK = os.environ.get("CODEPS_FORK", "1") != "0"              # A/B switch: 0 = autograd sums the gradients of a tensor with two consumers
 
 
 def _run_decoder(module, in_feats, keep=()):
@@ -34,7 +36,12 @@ def _run_decoder(module, in_feats, keep=()):
     kept = {}
     for i in range(4, -1, -1):
         c0, c1 = module.upconvs_0[str(i)][0], module.upconvs_1[str(i)][0]
-        x = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu")
+        if (i + 1) in kept and _FORK and torch.is_grad_enabled() and x.requires_grad:
+            # the kept stage output has a second consumer (the GUDA fusion): it takes this convolution's alias of the tensor, so
+            # that the two gradients meet in the data-gradient kernel's epilogue instead of a separate full-size sum
+            x, kept[i + 1] = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu", fork=True)
+        else:
+            x = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu")
         skip = F.from_nchw(in_feats[i - 1]) if (module.use_skips and i > 0) else None
         if skip is None and c1.in_channels == 16 and c1.out_channels == 16 and x.shape[-1] == 16 and _UPCONV16:
             x = F.upconv16(x, c1.weight, c1.bias, act="elu")      # scale 0: four 2x2 convolutions of the half-resolution tensor

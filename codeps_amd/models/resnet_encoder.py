@@ -28,8 +28,10 @@ class _BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward_nhwc(self, x, sync, groups=None):
-        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
-        out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups)
+        # x has two consumers (conv1 and the identity / shortcut): the second one takes conv1's alias of it, so that the gradients
+        # meet inside conv1's data-gradient kernel
+        out, xa = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups, fork=True)
+        identity = xa if self.downsample is None else conv_bn(xa, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
         return conv_bn(out, self.conv2, self.bn2, "relu", residual=identity, sync=sync, groups=groups)
 
 
@@ -47,8 +49,8 @@ class _Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward_nhwc(self, x, sync, groups=None):
-        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
-        out = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups)
+        out, xa = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups, fork=True)
+        identity = xa if self.downsample is None else conv_bn(xa, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
         out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync, groups=groups)
         return conv_bn(out, self.conv3, self.bn3, "relu", residual=identity, sync=sync, groups=groups)
 
@@ -72,9 +74,10 @@ def _run_layer(layer, x, sync, groups):
             x = blk.forward_nhwc(x, sync, groups)
             continue
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-        identity = x if blk.downsample is None else conv_bn(x, blk.downsample[0], blk.downsample[1], sync=sync, groups=groups)
+        xa = x
         if y0 is None:
-            y0 = conv_bn(x, blk.conv1, blk.bn1, "relu", sync=sync, groups=groups)
+            y0, xa = conv_bn(x, blk.conv1, blk.bn1, "relu", sync=sync, groups=groups, fork=True)
+        identity = xa if blk.downsample is None else conv_bn(xa, blk.downsample[0], blk.downsample[1], sync=sync, groups=groups)
         y1 = conv_bn(y0, blk.conv2, blk.bn2, "relu", sync=sync, groups=groups)
         y0 = None
         if (nxt is not None and nxt.downsample is None and nxt.conv1.out_channels == 256 and blk.conv3.in_channels == 256

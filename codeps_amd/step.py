@@ -135,6 +135,7 @@ class StepRunner:
         self.net, self.cfg, self.mode, self.world, self.group = net, cfg, mode, world_size, group
         self.weights = dict(cfg.losses.weights)
         self.lr = float(cfg.train.optimizer.learning_rate if lr is None else lr)
+        self._one = None
         _mark_conv_biases(net)
         ema_mods = []
         if mode == "adapt":
@@ -234,7 +235,9 @@ class StepRunner:
             wts.append(float(w) * self.key_scale.get(k, 1.0))
         total = F.weighted_sum(terms, wts)
         self._touched = self._reached(tuple(k for k, v in losses.items() if any(v is t for t in terms)), total)
-        total.backward()
+        if self._one is None or self._one.device != total.device:
+            self._one = torch.ones((), dtype=total.dtype, device=total.device)
+        total.backward(self._one)                # (the default seed is an ATen ones_like launch per step)
         for side in (getattr(self.net, "pose_stream", None), getattr(self.net, "branch_stream", None)):
             if side is not None:      # the gradient sinks are written by kernels autograd does not track: join the side streams by hand
                 torch.cuda.current_stream().wait_stream(side)

@@ -140,6 +140,12 @@ int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, const float* x
 size_t codeps_conv2d_dgrad_workspace_bytes(const codeps_conv_desc* d, int source);
 int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad,
                         float* dx, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* The same with a second gradient of the same tensor added in the kernel's epilogue: dx = data gradient + add (add: dx's shape, may
+ * be NULL = codeps_conv2d_dgrad).  What autograd does with a tensor that has two consumers (a residual connection: the block's first
+ * convolution and the identity path, models/resnet_encoder.py via torchvision's BasicBlock / Bottleneck) without a separate
+ * full-size sum afterwards.  Stride-2 layers: pixels no tap reaches receive `add` alone. */
+int codeps_conv2d_dgrad_add(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, const float* add,
+                            float* dx, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 /* Two FROZEN 1x1 layers of consecutive ResNet bottlenecks in one launch (inference only; csrc/chain1x1.hip; replaces
  * conv3 + bn3 + residual + ReLU of bottleneck i and conv1 + bn1 + ReLU of bottleneck i + 1, models/resnet_encoder.py:115-126):
  *     out[m][n2]  = relu(scale2 * (y1[m][:] . W2[n2][:]) + shift2 + residual[m][n2])     y1 [rows][256], out / residual [rows][n2]
@@ -433,6 +439,10 @@ int codeps_lidar_depth(const float* points, int n, const double* lidar_to_rect, 
  *   may be NULL or hold NULL entries = 1; grads entries may be NULL), weights a HOST array, denom an
  *   optional DEVICE scalar (D <= 0 gives out = 0 and zero gradients).  n <= 16. */
 int codeps_step_counter_add(uint64_t* counter, uint64_t increment, codeps_stream_t stream);
+/* n int64 device counters bumped by increments[i] in ONE launch (host arrays of n pointers / n increments; the pointers are passed by
+ * value in the kernel arguments): BatchNorm's num_batches_tracked of every layer a forward ran in train mode
+ * (torch.nn.BatchNorm2d semantics, models/resnet_encoder.py via torchvision). */
+int codeps_counters_add(long long* const* counters, const int* increments, int n, codeps_stream_t stream);
 size_t codeps_depth_rule_state_floats(int length);
 int codeps_depth_key_weights(const float* pose_prev, const float* pose_next, float* rule_state, int length,
                              int n_keys, const float* key_counts, int target_index, float global_total,
@@ -458,6 +468,25 @@ int codeps_panoptic_fusion(const uint8_t* semantic, const float* center, const f
                            float threshold, int nms_kernel, int top_k, int16_t* panoptic, uint8_t* instance,
                            int* centers, int* state, void* workspace, size_t workspace_bytes,
                            codeps_stream_t stream);
+/* The same on maps that are channels of larger tensors (no repacking): element strides of the centre heat map (batch, pixel) and of
+ * the offset field (batch, channel dy -> dx, pixel) -- NCHW planes: (H W, 1) and (2 H W, H W, 1); channels of an NHWC tensor with Cp
+ * channels: (H W Cp, Cp) and (H W Cp, 1, Cp).  instance_i64 (nullable): the instance map once more as int64 (the reference returns it
+ * in the semantic map's dtype, algos/instance_seg.py:226-240).  centers is zero-filled beyond the kept entries by the call. */
+int codeps_panoptic_fusion_strided(const uint8_t* semantic, const float* center, long long center_batch_stride, int center_pixel_stride,
+                                   const float* offset, long long offset_batch_stride, long long offset_channel_stride,
+                                   int offset_pixel_stride, int batch, int h, int w, unsigned long long thing_class_mask,
+                                   int label_divisor, int void_label, float threshold, int nms_kernel, int top_k, int16_t* panoptic,
+                                   uint8_t* instance, long long* instance_i64, int* centers, int* state, void* workspace,
+                                   size_t workspace_bytes, codeps_stream_t stream);
+
+/* dst = sources[0] ++ ... ++ sources[n - 1] (1 <= n <= 8 contiguous fp32 arrays of counts[i] elements; host arrays): concatenation along
+ * the leading dimension and plain copies in one launch. */
+int codeps_concat_f32(const float* const* sources, const long long* counts, int n, float* dst, codeps_stream_t stream);
+
+/* torch.argmax(x, dim = channel) on NHWC rows x [rows][c_pad] (first c channels; first index of the maximum): the semantic label map
+ * of a probability tensor (algos/semantic_seg.py:70-86) as int64 and / or uint8 (either may be NULL) in one pass. */
+int codeps_channel_argmax(const float* x, long long rows, int c, int c_pad, long long* out_i64, unsigned char* out_u8,
+                          codeps_stream_t stream);
 
 /* ImageWarper / CoordinateWarper (misc/image_warper.py:92-184), the reference's public warping API
  * (the training path's warp is fused into codeps_photometric_*): src [B,c,H,W] NCHW, depth [B,1,H,W],

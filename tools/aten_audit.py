@@ -37,7 +37,7 @@ def main():
                  "zeros_like", "ones_like", "empty_like", "index_copy_", "index_select", "repeat", "expand", "permute")
     NOLAUNCH = ("empty", "empty_like", "empty_strided", "view", "_unsafe_view", "reshape", "permute", "expand", "slice", "select", "t",
                 "transpose", "as_strided", "detach", "alias", "unsqueeze", "squeeze", "_reshape_alias", "unbind", "split", "narrow",
-                "lift_fresh", "is_same_size", "sym_size", "stride", "size", "numel", "_local_scalar_dense", "item")
+                "lift_fresh", "is_same_size", "sym_size", "stride", "size", "numel", "_local_scalar_dense", "item", "record_stream")
 
     class Audit(TorchDispatchMode):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
