@@ -408,13 +408,37 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    red_before = (red.n_gather, red.n_reduce) if world > 1 else (0, 0)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step times (enqueue-only: no sync inside the timed region)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         one_step()
+    marks[args.steps].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    comm = None
+    if world > 1:
+        # what the collectives of this run were: proof that the backend saw `world` ranks, the flat gradient all-reduce timed on its
+        # own with HIP events (average of 5 after one warm-up; it sits between backward and Adam in the step), SyncBN traffic per step
+        buf = runner.grad_all
+        torch.distributed.all_reduce(buf.clone())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tmp = buf.clone()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            torch.distributed.all_reduce(tmp)
+        e1.record()
+        torch.cuda.synchronize()
+        comm = {"backend": torch.distributed.get_backend(), "ranks_seen": torch.distributed.get_world_size(),
+                "grad_allreduce_mb": round(buf.numel() * 4 / 1e6, 1), "grad_allreduce_ms": round(e0.elapsed_time(e1) / 5, 3),
+                "syncbn_allgathers_per_step": round((red.n_gather - red_before[0]) / args.steps, 1),
+                "syncbn_allreduces_per_step": round((red.n_reduce - red_before[1]) / args.steps, 1),
+                "launch": "eager (the SyncBN collectives sit inside forward / backward)"}
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -448,6 +472,9 @@ def main():
                       if args.mode == "adapt" else "pretrain-step images/sec",
             "value": round(total_images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # `value` is the mean over the timed region (the contract); the spread of the individual steps (HIP events, this rank):
+            "step_ms": {"median": round(per_step[len(per_step) // 2], 3), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
+                        "images_per_sec_at_median": round(n_images * world / (per_step[len(per_step) // 2] * 1e-3), 2)},
             "dtype": "f32", "data": "synthetic",
             "arithmetic": ("fp32 end to end; conv forward / data-gradient / halo-tile weight-gradient operands enter the matrix cores as "
                            "exact 3-way bf16 splits (six bf16 products per multiply, fp32 accumulate: product error ~6e-9 relative, below "
@@ -468,6 +495,8 @@ def main():
                 line["roofline_eval_passes"] = ev    # --mode frame: the conv engine inside the per-frame evaluation passes
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if comm is not None:
+            line["comm"] = comm
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

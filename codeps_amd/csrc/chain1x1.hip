@@ -130,8 +130,12 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
         const int ins = (wave & 3) + 4 * i, L = ins * 64 + lane, prow = L / 13, seg = L % 13;
         ldsdst[i] = (unsigned)ins * 1024u;
         const int ks = prow >> 5, r = prow & 31;               // E tile: pseudo-row = (k-step, expand row within the stage)
-        offE[i] = (unsigned)(r * W2ROW + (seg < 12 ? ks * 192 + seg * 16 : KMID * 6));
-        offR[i] = (unsigned)((size_t)prow * p.N2 * 6 + (seg < 12 ? seg : 0) * 16);
+        // fragment reads (lane = (row l16, k group kg)) are serviced in the lane groups {0-3, 12-15, 20-27}, ...: at a 208-byte pitch
+        // the kg = 0 and kg = 1 rows of a group share 16-byte slots (8 LDS cycles per read instead of 4) unless the k groups of rows
+        // 4 .. 11 (mod 16) are stored pairwise swapped -- the DMA picks the source segment per lane, the reader flips bit 0 of kg
+        const int swz = ((prow >> 2) ^ (prow >> 3)) & 1;
+        offE[i] = (unsigned)(r * W2ROW + (seg < 12 ? ks * 192 + (seg ^ swz) * 16 : KMID * 6));
+        offR[i] = (unsigned)((size_t)prow * p.N2 * 6 + (seg < 12 ? (seg ^ swz) : 0) * 16);
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const bool loader = wave >= 4;                             // wave-uniform (wave is an SGPR)
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const char* arow = lds + l16 * ROWB + kg * 16;             // fragment address of row l16 of a tile, piece 0
+    const char* arow = lds + l16 * ROWB + (kg ^ (((l16 >> 2) ^ (l16 >> 3)) & 1)) * 16;      // fragment address of row l16 of a tile, piece 0 (swizzle: see offE)
 
     auto stage = [&](const int s, f32x4 (&rcur)[2], f32x4 (&rnext)[2]) {
         const bool last = s + 1 == NS;

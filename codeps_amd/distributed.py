@@ -46,6 +46,8 @@ class SyncBatchNormReducer:
     def __init__(self, group=None):
         self.group = group
         self._counts = {}           # (device, counts) -> device tensor: the per-group element counts never change between steps
+        self._gather_out = {}       # (shape, dtype, device, stream) -> the all-gather's output buffer, reused by every step
+        self.n_gather = self.n_reduce = 0      # collectives issued so far (bench.py reports them per step)
 
     def _count_tensor(self, like, counts):
         """Device copy of the local element counts, made once: a fresh host->device copy per BatchNorm layer would
@@ -89,13 +91,20 @@ class SyncBatchNormReducer:
         tensor list, no stacking copy); the merge itself is the HIP kernel codeps_bn_sync_combine."""
         world = dist.get_world_size(self.group)
         packet = packet.contiguous()
-        buf = torch.empty((world,) + tuple(packet.shape), dtype=packet.dtype, device=packet.device)
+        # one output buffer per (packet shape, stream): layers of one stream are ordered by the stream, the two encoders run on two
+        # streams -- no allocation per layer and step
+        key = (tuple(packet.shape), packet.dtype, packet.device, torch.cuda.current_stream().cuda_stream if packet.is_cuda else 0, world)
+        buf = self._gather_out.get(key)
+        if buf is None:
+            buf = self._gather_out[key] = torch.empty((world,) + tuple(packet.shape), dtype=packet.dtype, device=packet.device)
+        self.n_gather += 1
         # concatenation along dim 0 is the output form both backends accept (gloo rejects a stacked [world, ...] output)
         dist.all_gather_into_tensor(buf.view((world * packet.shape[0],) + tuple(packet.shape[1:])), packet, group=self.group)
         return buf
 
     def sum(self, sums):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        self.n_reduce += 1
         return sums
 
 

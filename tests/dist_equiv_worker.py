@@ -58,9 +58,11 @@ def main():
     from codeps_amd.config import get_cfg_shipped
     from codeps_amd.distributed import SyncBatchNormReducer, init_from_env
     from codeps_amd.step import StepRunner
-    rank, _local, world = init_from_env("gloo")
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
+    # default: every rank on GPU 0, collectives over gloo (one-GPU boxes).  --rccl: one GPU per rank, backend "nccl" = RCCL
+    rccl = "--rccl" in sys.argv
+    rank, local, world = init_from_env("nccl" if rccl else "gloo")
+    dev = torch.device("cuda", local if rccl else 0)
+    torch.cuda.set_device(dev)
     torch.manual_seed(20)
     cfg = get_cfg_shipped(adapt=True)
     cfg.model.po_depth_net.params.nof_layers = 18

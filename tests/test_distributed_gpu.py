@@ -123,6 +123,30 @@ def test_sharded_step_equals_single_process_step(tmp_path, asym):
         assert float(((p - pr).abs() > 1e-7).float().mean()) < 0.05, "more than 5 % of the weights stepped differently"
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (dormant on the one-GPU boxes of this pool)")
+def test_sharded_step_over_rccl_equals_single_process_step(tmp_path):
+    """The same equivalence with backend "nccl" (= RCCL), one rank per device: the gradient all-reduce and the SyncBN collectives
+    over xGMI.  Skipped where a single GPU is visible; live on any box with two or more."""
+    single = str(tmp_path / "single.pt")
+    _run_worker(single, 1, ())
+    _run_worker(str(tmp_path / "shard.pt"), 2, ("--rccl",))
+    _compare(torch.load(single), [torch.load(str(tmp_path / f"shard_r{r}.pt")) for r in range(2)])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (dormant on the one-GPU boxes of this pool)")
+def test_bench_over_rccl_reports_the_collectives():
+    """`bench.py --gpus 2` as the driver launches it (RCCL): the line must prove that the backend saw both ranks and time the
+    flat gradient all-reduce."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--encoder", "18", "--height", "128", "--width", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["comm"]["backend"] == "nccl" and d["comm"]["ranks_seen"] == 2 and d["comm"]["grad_allreduce_ms"] > 0
+
+
 def test_two_ranks_on_one_gpu_complete_with_default_flags():
     env = dict(os.environ, CODEPS_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -135,3 +159,9 @@ def test_two_ranks_on_one_gpu_complete_with_default_flags():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["launch"] == "eager"
     assert d["value"] > 0 and d["value"] == d["value"]
     assert d["roofline"]["achieved"] > 0
+    # the collectives of the run, as the line reports them: both ranks seen, the flat gradient all-reduce timed, one all-gather and one
+    # all-reduce per train-mode BatchNorm layer of the pose encoder (ResNet-18: 20 layers) per step
+    c = d["comm"]
+    assert c["backend"] == "gloo" and c["ranks_seen"] == 2 and c["grad_allreduce_ms"] > 0
+    assert c["syncbn_allgathers_per_step"] == 20 and c["syncbn_allreduces_per_step"] == 20
+    assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
