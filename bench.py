@@ -143,21 +143,28 @@ def cpu_baseline(net, full_h, full_w, budget_s=24.0):
                       f"median of {len(single)} step(s) = {med1:.2f} s at 1 thread (no warm-up beyond the multi-thread steps)"}
 
 
+def _latest_profile(suffix):
+    """Newest profiles/rNN_<suffix> (the rocprofv3 summaries are refreshed per round by tools/refresh_profiles.sh)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_" + suffix)))
+    return hits[-1] if hits else None
+
+
 def pmc_traffic(default_workload):
     """HBM bytes per conv launch from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE passes of this same
     command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  Counters cannot be read from inside
     the process, so the value is the one measured when profiles/ was last refreshed -- None for other workloads."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
-    if not default_workload or not os.path.exists(path):
+    path = _latest_profile("pmc_traffic.json")
+    if not default_workload or path is None:
         return None, None
     with open(path) as f:
         d = json.load(f)
-    return round(d["conv"]["hbm_mb_per_launch"] * 1e6), "profiles/r03_pmc_traffic.json (avg HBM bytes per conv launch)"
+    return round(d["conv"]["hbm_mb_per_launch"] * 1e6), f"profiles/{os.path.basename(path)} (avg HBM bytes per conv launch)"
 
 
 def photometric_pmc(default_workload):
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
-    if not default_workload or not os.path.exists(path):
+    path = _latest_profile("pmc_traffic.json")
+    if not default_workload or path is None:
         return None
     with open(path) as f:
         rows = {r["kernel"]: r for r in json.load(f)["kernels"]}
@@ -165,6 +172,38 @@ def photometric_pmc(default_workload):
     if not ks:
         return None
     return round(sum((r["read_mb_per_launch"] + r["write_mb_per_launch"]) * 1e6 for r in ks) / len(ks))
+
+
+def photometric_shares():
+    """Where the wave cycles of the photometric kernels go, from the committed PMC pass (tools/pmc_kernels.py)."""
+    path = _latest_profile("pmc_kernels.json")
+    if path is None:
+        return None
+    with open(path) as f:
+        rows = {r["kernel"]: r for r in json.load(f)["kernels"]}
+    out = {"source": "profiles/" + os.path.basename(path)}
+    for k in ("photo_fwd_kernel", "photo_bwd_kernel"):
+        if k in rows:
+            out[k] = {"avg_us": rows[k]["avg_us"], "avg_waves_per_simd": rows[k]["avg_waves_per_simd"], **rows[k].get("share_of_wave_cycles", {})}
+    return out
+
+
+def clock_record():
+    """Cycles per MFMA and the clock the chip held, stamped in the kernels (tools/clock_cycles.py; committed per round)."""
+    out = {}
+    for key, suffix in (("bare_loops", "clock_cycles_bare.json"), ("kernels", "clock_cycles_kernels.json")):
+        path = _latest_profile(suffix)
+        if path is None:
+            continue
+        with open(path) as f:
+            d = json.load(f)
+        if key == "bare_loops":
+            out[key] = [{k: r[k] for k in ("loop", "operands", "cycles_per_mfma", "in_kernel_ghz", "tflops") if k in r}
+                        for r in d["bare"]["rows"] if r["loop"].startswith("bare")]
+        else:
+            out[key] = [{k: r[k] for k in ("layer", "kernel", "in_kernel_ghz", "mfma_cycles_needed_over_cycles_elapsed") if k in r} for r in d["kernels"]["rows"]]
+        out.setdefault("source", []).append("profiles/" + os.path.basename(path))
+    return out or None
 
 
 def eval_pass_roofline(run_eval, steps=2):
@@ -262,10 +301,14 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
                      "achieved": round(pb / ps / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(pb / ps / 1e9 / PEAK_HBM_GBS, 4),
                      "algorithmic_mb_per_launch": round(pb / pn / 1e6, 2), "avg_launch_us": round(ps / pn * 1e6, 1),
                      "launches_per_step": pn // steps, "ms_per_step": round(ps / steps * 1e3, 3), "traffic": ptraffic,
-                     "note": "84 B per pixel and batch item (40 forward + 44 backward, SURVEY.md 8d); VALU-bound in practice (~1.1 kFLOP of fp32 warp / SSIM "
-                             "arithmetic per pixel and scale), so the HBM fraction is low by construction; traffic = PMC HBM bytes per launch -- since "
-                             "round 3 it includes the warped samples and SSIM adjoint coefficients the forward keeps for the backward (60 B per pixel "
-                             "and scale, written once and read once) instead of recomputing them on a halo-2 tile"}
+                     "wave_cycle_shares": photometric_shares(),
+                     "note": "84 B per pixel and batch item (40 forward + 44 backward, SURVEY.md 8d).  Neither HBM- nor VALU-bound (PMC, round 4: "
+                             "`wave_cycle_shares`): the forward issues vector-ALU instructions in 40 % of its wave cycles at 1.7 waves per SIMD "
+                             "(a 8 x 64 tile + halo per block in LDS, 4-tap gathers with dependent address arithmetic), parked at waits / barriers "
+                             "30 %, issue-stalled 23 %; the backward (4.7 waves per SIMD) is parked or stalled 73 % of the time behind its gathers "
+                             "-- latency / occupancy-bound.  traffic = PMC HBM bytes per launch; since round 3 it includes the warped samples and "
+                             "SSIM adjoint coefficients the forward keeps for the backward (60 B per pixel and scale, written once and read "
+                             "once) instead of recomputing them on a halo-2 tile"}
     # the vendor peak and the peak re-measured on this box (csrc/diag.hip: register-resident MFMA loop on operands
     # that change between consecutive MFMAs -- what the matrix pipe sustains under the power limit on real data -- and a stream
     # triad).  `peak` / `frac` stay on the vendor figure; the measured ones are reported beside them.
@@ -278,8 +321,11 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
         measured = {"mfma_bf16_zeros_tflops": m["mfma_f32_32x32x16_bf16_zeros_tflops"], "mfma_bf16_random_tflops": m["mfma_f32_32x32x16_bf16_random_tflops"],
                     "mfma_f32_random_tflops": m["mfma_f32_32x32x2_f32_random_tflops"], "hbm_triad_gbs": m["hbm_triad_gbs"],
                     "peak_of_this_arithmetic": round(mpeak, 1), "frac": round(ach / mpeak, 4),
+                    "in_kernel_clock": clock_record(),
                     "note": "live micro-kernels on this GPU: no-memory MFMA loop (zeros = how vendor peaks are quoted; random = operands changing "
-                            "between consecutive MFMAs) and a[i] = b[i] + s c[i] over 3 x 1 GiB"}
+                            "between consecutive MFMAs) and a[i] = b[i] + s c[i] over 3 x 1 GiB.  The MFMA loop retires one "
+                            "v_mfma_f32_32x32x16_bf16 per 32.0 cycles on zeros AND on random operands; what falls on random data is the CLOCK the "
+                            "chip holds (in_kernel_clock: s_memtime / s_memrealtime stamps, 2.39 -> ~1.8 GHz; 16x16x32: 16.8 cycles, ~2.13 GHz)"}
     except Exception as e:                                  # noqa: BLE001  (diagnostics never fail the bench)
         print(f"[bench] measured peaks unavailable ({type(e).__name__}: {e})", file=sys.stderr)
     return {"bound": "mfma", "secondary": secondary, "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -1,0 +1,96 @@
+"""Round-4 entry points against torch / against the paths they replace: channel arg-max, row concatenation, multi-counter add, the
+data gradient with a second gradient added in its epilogue (conv2d fork output), panoptic fusion on strided maps."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _F():
+    from codeps_amd import functional as F
+    return F
+
+
+@pytest.mark.parametrize("c,layout", [(14, "nhwc_view"), (2, "nhwc_view"), (19, "nchw"), (14, "ties")])
+def test_channel_argmax_equals_torch(c, layout):
+    F = _F()
+    g = torch.Generator().manual_seed(c)
+    b, h, w = 2, 37, 53
+    if layout == "nchw":
+        x = torch.randn(b, c, h, w, generator=g).to(DEV)
+    else:
+        cp = (c + 15) // 16 * 16
+        base = torch.randn(b, h, w, cp, generator=g)
+        if layout == "ties":
+            base = torch.round(base * 2) / 2                       # many exact ties: the FIRST maximal index must win
+        base[..., c:] = 100.0                                      # padding lanes must never be compared
+        x = F.to_nchw(base.to(DEV), c)
+    want = torch.argmax(x, dim=1)
+    got = F.channel_argmax(x)
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+    assert torch.equal(got._codeps_u8, want.to(torch.uint8))
+    assert torch.equal(F.channel_argmax(x.detach(), torch.uint8), want.to(torch.uint8))
+
+
+@pytest.mark.parametrize("sizes", [[(3, 8, 16)], [(1, 5, 7), (2, 5, 7), (4, 5, 7)], [(2, 4)] * 8, [(1, 3)] * 11])
+def test_concat_rows_equals_torch_cat(sizes):
+    F = _F()
+    g = torch.Generator().manual_seed(len(sizes))
+    parts = [torch.randn(*s, generator=g).to(DEV) for s in sizes]
+    assert torch.equal(F.concat_rows(parts), torch.cat(parts, 0))
+
+
+def test_counters_add():
+    F = _F()
+    cs = [torch.full((), i, dtype=torch.int64, device=DEV) for i in range(70)]
+    F.counters_add(cs, [i % 5 + 1 for i in range(70)])
+    torch.cuda.synchronize()
+    assert [int(c) for c in cs] == [i + i % 5 + 1 for i in range(70)]
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 64, 64, 64, 3, 1), (2, 32, 64, 256, 256, 3, 1), (3, 32, 64, 64, 128, 3, 2), (3, 32, 64, 64, 128, 1, 2),
+                                   (2, 16, 32, 256, 64, 1, 1), (1, 32, 64, 32, 16, 3, 1)])
+def test_forked_conv_gradient_equals_autograd_sum(shape):
+    """y, x' = conv2d(x, fork=True); the gradient arriving through x' is added inside the data-gradient kernel: same bits as autograd's
+    own sum of the two gradients (one fp32 add per element either way), for the halo, generic, stride-2 parity-class and 16-column kernels."""
+    F = _F()
+    b, h, w, ci, co, k, st = shape
+    g = torch.Generator().manual_seed(ci + co + k)
+    x = torch.randn(b, h, w, ci, generator=g).to(DEV)
+    wt = (torch.randn(co, ci, k, k, generator=g) * 0.05).to(DEV)
+    other = torch.randn(b, h, w, ci, generator=g).to(DEV)             # d loss / d x through the second consumer
+    gy = None
+    grads = []
+    for fork in (True, False):
+        xx = x.clone().requires_grad_(True)
+        if fork:
+            y, xa = F.conv2d(xx, wt, stride=st, pad=k // 2, fork=True)
+        else:
+            y, xa = F.conv2d(xx, wt, stride=st, pad=k // 2), xx
+        if gy is None:
+            gy = torch.randn_like(y)
+        ((y * gy).sum() + (xa * other).sum()).backward()
+        grads.append(xx.grad.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(grads[0], grads[1]), f"max |diff| {(grads[0] - grads[1]).abs().max().item():.3e}"
+
+
+def test_panoptic_fusion_reads_strided_maps_in_place():
+    """Centre / offset maps as channels of padded NHWC tensors (what the instance head hands over) == the same maps as contiguous NCHW
+    planes, bit for bit; an int64 semantic map with its uint8 twin needs no conversion and returns an int64 instance map."""
+    F = _F()
+    g = torch.Generator().manual_seed(5)
+    b, h, w = 2, 96, 160
+    ctr_nhwc = torch.rand(b, h, w, 16, generator=g).to(DEV)
+    off_nhwc = (torch.randn(b, h, w, 16, generator=g) * 6).to(DEV)
+    center, offset = F.to_nchw(ctr_nhwc, 1), F.to_nchw(off_nhwc, 2)
+    probs = F.to_nchw(torch.rand(b, h, w, 16, generator=g).to(DEV), 14)
+    sem = F.channel_argmax(probs)
+    a = F.panoptic_fusion(sem, center, offset, [9, 10, 11, 12, 13], void_label=255)
+    c = F.panoptic_fusion(sem.to(torch.uint8), center.contiguous(), offset.contiguous(), [9, 10, 11, 12, 13], void_label=255)
+    torch.cuda.synchronize()
+    assert a[1].dtype == torch.int64 and c[1].dtype == torch.uint8
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1].to(torch.int64)) and torch.equal(a[2], c[2]) and torch.equal(a[3], c[3])
+    assert int(a[3][:, 1].min()) > 0, "the case must keep some centres"

@@ -33,5 +33,15 @@ python3 bench.py --mode train --encoder 101 --height 1024 --width 2048 --per-gpu
 python3 bench.py --mode frame --no-cpu-baseline 2>/dev/null | line > $OUT/${R}_bench_n1_frame.json
 python3 bench.py --yaml-faithful --no-cpu-baseline --no-roofline 2>/dev/null | line > $OUT/${R}_bench_n1_yaml_faithful.json
 python3 tools/peaks.py --json $OUT/${R}_peaks.json > /dev/null 2>&1
+# 5. clocks and cycles measured in the kernels (in-kernel stamps; the diagnostic variant of the library: tools/build_variant.sh stamps -DCODEPS_CLOCK_STAMPS)
+python3 tools/clock_cycles.py --bare --json $OUT/${R}_clock_cycles_bare.json > /dev/null 2>&1
+if [ -f codeps_amd/variants/libcodeps_hip_stamps.so ]; then
+  CODEPS_HIP_LIB=$PWD/codeps_amd/variants/libcodeps_hip_stamps.so python3 tools/clock_cycles.py --kernels --json $OUT/${R}_clock_cycles_kernels.json > /dev/null 2>&1
+fi
+# 6. where the wave cycles of the photometric / weight-gradient / ring / BatchNorm kernels go (one PMC pass)
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_k -o r -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --graph 0 > /dev/null 2>&1
+python3 tools/pmc_kernels.py gpurun_out/pmc_k photo_ pyramid wgrad_halo64s conv_halo3 conv_igemm chain_ bn_ > $OUT/${R}_pmc_kernels.json 2>/dev/null
+rm -rf gpurun_out/pmc_k
+python3 tools/aten_audit.py > $OUT/${R}_aten_audit.txt 2>/dev/null
 python3 tools/conv_layers.py --json $OUT/${R}_conv_layers.json > $OUT/${R}_conv_layers.txt 2>/dev/null
 ls -la $OUT
