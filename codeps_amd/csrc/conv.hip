@@ -37,6 +37,9 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 #ifndef CODEPS_ABLATE
 #define CODEPS_ABLATE 0
 #endif
+#ifndef CODEPS_IGEMM_SWZ
+#define CODEPS_IGEMM_SWZ 1       // A/B builds only: 0 = the padded 208-byte LDS rows of rounds 2-3 in conv_igemm_kernel<split3>
+#endif
 #ifndef CODEPS_HALO_SWZ
 #define CODEPS_HALO_SWZ 1        // A/B builds only: 0 = the 208-byte activation pitch and unswizzled weight tiles of rounds 2-3
 #endif
@@ -202,8 +205,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                                                          const float* __restrict__ residual, float* __restrict__ out) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     static_assert(NP == 0 || ((BK == 32 || (BK == 16 && NP == 3)) && NBUF == 1), "split-precision variant: BK = 32 (or 16 with pre-split weights), single LDS stage");
-    constexpr int LDK = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // padded LDS row (floats): conflict-free b128 fragment reads (an XOR-swizzled
-                                                      // unpadded layout was measured 1 % slower on the whole step)
+    // LDS row (floats).  f32 operands: BK + 4 (padded).  Split operands at BK = 32 (round 4): UNPADDED rows of 192 bytes = [piece][4 k
+    // groups of 16 bytes] with the k group stored at position kg ^ ((row >> 2) & 3).  With the 208-byte padded rows of rounds 2-3 the
+    // staging `ds_write_b128` (8 contiguous lanes = 2 rows x 4 chunks) hit one 16-byte slot twice per lane group: bank-conflict cycles
+    // = 10-13 % of these kernels' CU cycles (PMC, round 4).  At a 192-byte pitch two consecutive rows fill all eight slots, and the
+    // swizzle spreads the fragment reads (lane = row, 16 rows per ds_read_b128 lane group, 12 r mod 16 takes four values only) over
+    // all sixteen -- both conflict-free under the documented lane groups (MI355X_MICROARCH.md, LDS); 8 % less LDS per block.
+    constexpr bool SWZ = CODEPS_IGEMM_SWZ && NP > 0 && BK == 32;
+    constexpr int LDK = NP == 0 ? BK + 4 : (SWZ ? NP * BK / 2 : (NP * BK + 8) / 2);
     constexpr int KPT = NP > 0 ? 8 : 4;               // consecutive k values staged per thread and row (split kernel: 8, so that each bf16
                                                       // piece goes to LDS as one 16-B write)
     constexpr int SUB = KPT / 4;                      // 16-B global loads per staged chunk
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 
     // ---- per-thread staging roles: 16-B chunk `chunk` of rows rbase + RPP * i
     const int chunk = tid % CPR, rbase = tid / CPR;
+    const int wchunk = SWZ ? (chunk ^ ((rbase >> 2) & 3)) : chunk;       // where this thread's k group goes inside an LDS row (RPP % 16 == 0)
     constexpr bool AGUARD = (BM % RPP) != 0, BGUARD = (BN % RPP) != 0;
     // B rows (weights): row n = n0 + rbase + RPP*i, K-contiguous; rows past N are clamped (their columns are never stored)
     const size_t wrow = (MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct : (size_t)p.KH * p.KW * p.Co;     // floats per packed weight row
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     unsigned short* row = reinterpret_cast<unsigned short*>(Ab + (rbase + RPP * i) * LDK);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = pack8(lo[q], hi[q]);
+                        *reinterpret_cast<i32x4*>(row + q * BK + wchunk * 8) = pack8(lo[q], hi[q]);
                 }
             }
 #pragma unroll
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + RPP * i) * LDK);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = __builtin_bit_cast(i32x4, breg[i * BREGS + q]);
+                        *reinterpret_cast<i32x4*>(row + q * BK + wchunk * 8) = __builtin_bit_cast(i32x4, breg[i * BREGS + q]);
                 } else {
                     u16x4 lo[NP > 0 ? NP : 1], hi[NP > 0 ? NP : 1];
                     split_bf16<(NP > 0 ? NP : 1)>(breg[i * SUB], lo);
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + RPP * i) * LDK);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = pack8(lo[q], hi[q]);
+                        *reinterpret_cast<i32x4*>(row + q * BK + wchunk * 8) = pack8(lo[q], hi[q]);
                 }
             }
     };
@@ -372,7 +382,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #pragma unroll
             for (int kc = 0; kc < BK / 16; ++kc) {
                 bf16x8 af[TM][NP > 0 ? NP : 1], bf[TN][NP > 0 ? NP : 1];
-                const int ho = kc * 16 + lhalf * 8;               // halfword offset inside a piece
+                // halfword offset of this lane's k group inside a piece (swizzled layout: group (2 kc + half) ^ ((row >> 2) & 3))
+                const int ho = SWZ ? (((kc * 2 + lhalf) ^ ((lrow >> 2) & 3)) * 8) : kc * 16 + lhalf * 8;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -2939,7 +2950,8 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     // K-loop staging buffers + the gather table [sources][taps][BM] behind them; the epilogue tile reuses the front
     const int ntap = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
     const int nsrc = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
-    constexpr int LDKf = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // LDS row in floats (split precision: NP pieces x BK bf16 + pad)
+    constexpr int LDKp = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // LDS row in floats of the padded layouts (halo / ring / wave-specialised kernels)
+    constexpr int LDKf = (CODEPS_IGEMM_SWZ && NP > 0 && BK == 32) ? NP * BK / 2 : LDKp;      // ... of conv_igemm_kernel (unpadded + swizzled at BK = 32)
     const size_t lds = std::max(((size_t)NBUF * (BM + BN) * LDKf + (size_t)nsrc * ntap * BM) * sizeof(float),
                                 (size_t)WM * 32 * (BN + 4) * sizeof(float));
     if constexpr (NP == 3 && WM == 2 && WN == 2 && TM == 2 && BK == 32) {
@@ -2947,14 +2959,14 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         static const int halo3 = getenv("CODEPS_HALO3") ? atoi(getenv("CODEPS_HALO3")) : 2;          // x 128 blocks: smaller grids keep split-K / the 256-thread kernel
         if (halo3 && halo3_shape_ok<MODE>(p) &&
             ((long long)p.n_mt * p.n_nt >= halo3 * 128 || (TN == 2 && halo_splitk_slices(p, p.n_mt * p.n_nt, ((MODE == MODE_FWD) ? p.Ct : p.Co) / BK) >= 1))) {
-            constexpr size_t lds_h = std::max(((size_t)204 * (LDKf + (CODEPS_HALO_SWZ ? 4 : 0)) + (size_t)2 * BN * LDKf) * sizeof(float),
+            constexpr size_t lds_h = std::max(((size_t)204 * (LDKp + (CODEPS_HALO_SWZ ? 4 : 0)) + (size_t)2 * BN * LDKp) * sizeof(float),
                                               (size_t)WM * 32 * (BN + 4) * sizeof(float));
             static const int halo_ring = getenv("CODEPS_HALO_RING") ? atoi(getenv("CODEPS_HALO_RING")) : 1;
             if constexpr (TN == 2) {
                 const int nchunks_ = ((MODE == MODE_FWD) ? p.Ct : p.Co) / BK;
                 const int hks = halo_splitk_slices(p, p.n_mt * p.n_nt, nchunks_);
                 if (halo_ring || hks >= 2) {
-                    constexpr size_t lds_r = ((size_t)205 * (LDKf + (CODEPS_HALO_SWZ ? 4 : 0)) + (size_t)4 * BN * LDKf) * sizeof(float);
+                    constexpr size_t lds_r = ((size_t)205 * (LDKp + (CODEPS_HALO_SWZ ? 4 : 0)) + (size_t)4 * BN * LDKp) * sizeof(float);
                     // CODEPS_HALO_WS=1: the producer / consumer form of the ring kernel (bit-identical results); default 0: the 256-thread form
                     const int halo_ws = halo_ws_on();
                     auto kr = halo_ws ? conv_halo3p_kernel<MODE, TN> : conv_halo3r_kernel<MODE, TN>;
@@ -2990,7 +3002,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         static const int ws_blocks = getenv("CODEPS_WS_BLOCKS") ? atoi(getenv("CODEPS_WS_BLOCKS")) : 256;
         if (ws_min > 0 && nsteps_ >= ws_min && p.n_mt * p.n_nt <= ws_blocks) {
             const int nsrc_ = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
-            const size_t lds_ws = std::max(((size_t)2 * (BM + BN) * LDKf + (size_t)nsrc_ * ntap_ * BM) * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            const size_t lds_ws = std::max(((size_t)2 * (BM + BN) * LDKp + (size_t)nsrc_ * ntap_ * BM) * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
             auto kw = conv_igemm_ws_kernel<MODE, TN>;
             codeps_allow_lds((const void*)kw, 160 * 1024, "kw");
             const int blocks_ = p.n_mt * p.n_nt;
