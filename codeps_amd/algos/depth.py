@@ -64,6 +64,21 @@ class ReconstructionLoss:
         return F.photometric_loss(images, depth_map, poses, intr, self.num_scales, self.alpha, noise)
 
 
+class _SkipFlag:
+    """The sharded step's car-not-moving outcome: wraps the broadcast KEEP flag (device float, 1 = the target frame is used) and
+    reads as the reference's `is_car_moving` (1 / True = frame skipped) when somebody asks -- like the int32 device flag of the
+    unsharded path, without a conversion kernel per step."""
+
+    def __init__(self, keep):
+        self.keep = keep
+
+    def __int__(self):
+        return int(float(self.keep) < 0.5)
+
+    def __bool__(self):
+        return bool(int(self))
+
+
 class DepthAlgo:
     """algos/depth.py:332-595."""
 
@@ -265,7 +280,7 @@ class DepthAlgo:
             coef = F.depth_key_weights(counts, dev, ti, transformations.get("target") if shard["owner"] else None, self._rule_state,
                                        self.skip_rule_length, shard)
             if on_device:
-                self.adaptation_cache["is_car_moving"] = 1.0 - coef._codeps_keep    # device flag, 1 = skipped like the reference's `= skip_image` (read lazily)
+                self.adaptation_cache["is_car_moving"] = _SkipFlag(coef._codeps_keep)    # 1 = skipped like the reference's `= skip_image`; read lazily, no launch
         elif on_device:
             coef = F.depth_key_weights(counts, dev, live.index("target"), transformations["target"], self._rule_state,
                                        self.skip_rule_length)

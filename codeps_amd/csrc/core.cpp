@@ -33,8 +33,12 @@ static thread_local bool g_attr_failed = false;
 void codeps_allow_lds(const void* kernel, int bytes, const char* name) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    // fast path (hundreds of conv launches per eager step): this thread registered this (kernel, device) last time it asked
+    static thread_local const void* last_kernel = nullptr;
+    static thread_local int last_dev = -1;
+    if (kernel == last_kernel && dev == last_dev) return;
     std::lock_guard<std::mutex> lock(g_attr_mu);
-    if (g_attr_done.count({kernel, dev})) return;
+    if (g_attr_done.count({kernel, dev})) { last_kernel = kernel; last_dev = dev; return; }
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
         codeps_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s", name, bytes, dev, hipGetErrorString(e));
@@ -42,6 +46,7 @@ void codeps_allow_lds(const void* kernel, int bytes, const char* name) {
         return;
     }
     g_attr_done.insert({kernel, dev});
+    last_kernel = kernel; last_dev = dev;
 }
 
 bool codeps_take_attr_failure(void) {
