@@ -1707,6 +1707,7 @@ __global__ __launch_bounds__(256) void conv_igemm16_lds_kernel(ConvP p, const fl
 struct WgradP {
     int B, H, W, C0, C1, Ct, up0, Co, Ho, Wo, KH, KW, stride, pad, pad_mode, stride_w, pad_w;
     int n_mt, n_nt, splits, pix_per_split, P;     // P = B*Ho*Wo output pixels
+    int fast;                                     // wgrad_halo64s_kernel: the layer-wide conditions of its FAST address path hold
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -2051,14 +2052,19 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
 // CO32 (layers with <= 32 output channels: the decoders' 1/2-resolution stages): one 32-row co tile, so the waves that would hold
 // the second co tile split the PIXELS instead -- wave = (pixel half ph, ci tile): output rows 2 ph, 2 ph + 1 of every tile -- and
 // each pixel half writes its own partial slab (the slab reduction sums them like any other split).
-template <bool CO32>
-__global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
-                                                            const float* __restrict__ x0, const float* __restrict__ x1,
-                                                            const float* __restrict__ dz, float* __restrict__ part) {
+// FAST (picked per block, wave-uniform): zero padding, whole 4 x 16 tiles, and the block's 64-channel chunk inside ONE source that is
+// not up-sampled.  Then every address is (scalar tile origin) + (per-thread constant), padding is the range check of the buffer
+// resource (an offset past its end reads 0), and a tile's 17 loads are straight-line code: ~20 vector instructions per tile
+// instead of ~770 (per-pixel reflect / up-sample / bounds arithmetic and an exec-mask branch per load, whose joins also made the
+// compiler wait for each group of loads before the tile's MFMAs).  Stamped in the diagnostic build, that code was 22-25 % of a
+// block's lifetime -- one wave per SIMD, nothing else to issue while it runs.
+template <bool CO32, bool FAST>
+__device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
+                                                   const float* __restrict__ x0, const float* __restrict__ x1,
+                                                   const float* __restrict__ dz, float* __restrict__ part, unsigned short* lds16) {
     constexpr int TH = 4, TW = 16, XH = TH + 2, PIX = TH * TW, XROW = 32;
     constexpr int ZP = 3 * PIX + 8;                    // halfwords per dZ channel (pad: conflict-free 16-byte fragment reads)
     constexpr int XQ = XH * XROW, XP = 3 * XQ + 8;     // halfwords per X piece / per X channel
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
     unsigned short* dZs = lds16;                       // [64][ZP]
     unsigned short* Xs = lds16 + 64 * ZP;              // [64][XP]
     CODEPS_STAMP_BEGIN();
@@ -2129,7 +2135,74 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
         }
         return f32x4{0.f, 0.f, 0.f, 0.f};
     };
+    // FAST: per-thread constants of the three tasks -- byte offset from the tile origin (its pixel (ty0, tx0), channel 0 of the
+    // source), the X row the task reads (relative to ty0) and whether its channel quad exists
+    const bool s1 = c_base >= p.C0;                                  // (block-uniform)
+    const float* xsrc = s1 ? x1 : x0;
+    const int xcs = s1 ? p.C1 : p.C0, xc0 = s1 ? c_base - p.C0 : c_base;
+    int f_off[2] = {0, 0}, f_row[2] = {0, 0}, f_offs = 0, f_rows = 0;
+    bool f_ok[2] = {false, false}, f_oks = false, f_side = false;
+    if (FAST) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bt = tid + 256 * u;
+            int c4, grp;
+            if (bt < 128) {
+                task_of(bt, 8, c4, grp);
+                f_off[u] = (((grp >> 1) * p.Wo + (grp & 1) * 8) * p.Co + co_base + c4 * 4) * 4;
+                f_ok[u] = co_base + c4 * 4 < p.Co;
+            } else if (bt < 320) {
+                task_of(u == 0 ? xt0 : xt1, 12, c4, grp);
+                f_row[u] = (grp >> 1) - 1;
+                f_off[u] = ((f_row[u] * p.W + (grp & 1) * 8) * xcs + xc0 + c4 * 4) * 4;
+                f_ok[u] = xc0 + c4 * 4 < xcs;
+            }
+        }
+        if (tid >= 64) {
+            const int t = tid - 64, c4 = t & 15, rs = t >> 4, side = rs & 1;
+            f_rows = (rs >> 1) - 1;
+            f_side = side;
+            f_offs = ((f_rows * p.W + (side ? TW : -1)) * xcs + xc0 + c4 * 4) * 4;
+            f_oks = xc0 + c4 * 4 < xcs;
+        }
+    }
+    // the next tile's loads: fast_prep() = the scalar part (tile origin, buffer resources) and the three offsets; fast_issue(k) = load k of
+    // the 17 (0-7: big task 0 = dZ in waves 0, 1, X in waves 2, 3; 8-15: big task 1 = X rows, wave 0; 16: the halo pixels, waves 1-3).
+    // EVERY wave issues all 17: a lane without the task has f_ok = false and reads zeros through the range check (a wave-uniform branch
+    // made the compiler load into temporaries and copy them -- behind s_waitcnt vmcnt(0) -- in front of the MFMAs), and `valid` = false
+    // (no next tile) does the same for all lanes, so the tile loop has no branch around its loads.
+    __amdgpu_buffer_rsrc_t f_rs0, f_rsx;
+    unsigned f_vo0 = 0, f_vo1 = 0, f_vos = 0;
+    int f_pix0 = 0, f_pixx = 0;
+    auto fast_prep = [&](int tile, bool valid) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);             // (scalar)
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        const size_t zimg = (size_t)p.Ho * p.Wo * p.Co, ximg = (size_t)p.H * p.W * xcs;
+        const __amdgpu_buffer_rsrc_t rsz = make_rsrc(dz + (size_t)b * zimg, zimg * 4);
+        f_rsx = make_rsrc(xsrc + (size_t)b * ximg, ximg * 4);
+        const int zorg = (ty0 * p.Wo + tx0) * p.Co * 4, xorg = (ty0 * p.W + tx0) * xcs * 4;
+        const bool isz = __builtin_amdgcn_readfirstlane(wave) < 2;
+        f_rs0 = isz ? rsz : f_rsx;
+        f_pixx = xcs * 4;
+        f_pix0 = isz ? p.Co * 4 : f_pixx;
+        const int org0 = isz ? zorg : xorg;
+        f_vo0 = (valid && f_ok[0] && (unsigned)(ty0 + f_row[0]) < (unsigned)p.H) ? (unsigned)(org0 + f_off[0]) : GATHER_OOB;
+        f_vo1 = (valid && f_ok[1] && (unsigned)(ty0 + f_row[1]) < (unsigned)p.H) ? (unsigned)(xorg + f_off[1]) : GATHER_OOB;
+        const bool oks = valid && f_oks && (unsigned)(ty0 + f_rows) < (unsigned)p.H && (f_side ? tx0 + TW < p.W : tx0 > 0);
+        f_vos = oks ? (unsigned)(xorg + f_offs) : GATHER_OOB;
+    };
+    auto fast_issue = [&](int k) {
+        if (k < 8) bigr[0][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rs0, f_vo0, k * f_pix0, 0));
+        else if (k < 16) bigr[1][k - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsx, f_vo1, (k - 8) * f_pixx, 0));
+        else smallr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsx, f_vos, 0, 0));
+    };
+    auto load_tile_fast = [&](int tile) {
+        fast_prep(tile, true);
+#pragma unroll
+        for (int k = 0; k < 17; ++k) fast_issue(k);
+    };
     auto load_tile = [&](int tile) {
+        if (FAST) { load_tile_fast(tile); return; }
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
 #pragma unroll
@@ -2202,7 +2275,16 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
         __syncthreads();
         CODEPS_STAMP_PHASE_B();                                     // B: barrier + (wait for the loads) split + transpose + LDS stores + barrier
         CODEPS_STAMP_PHASE_START();
-        if (tile + 1 < t_end) load_tile(tile + 1);
+#ifdef CODEPS_WG_NOSPREAD                                            // (variant builds: the A/B of the spread form)
+        constexpr bool SPREAD = false;
+#else
+        constexpr bool SPREAD = FAST && !CO32;                      // the next tile's loads and the next row's fragment reads ride under the MFMAs
+#endif
+        if (SPREAD) fast_prep(min(tile + 1, t_end - 1), tile + 1 < t_end);
+        else if (tile + 1 < t_end) load_tile(tile + 1);
+#ifdef CODEPS_WG_STAMP_LOADS                                         // diagnostic split of phase A: A = issuing the next tile's loads only
+        CODEPS_STAMP_PHASE_A();
+#endif
         bf16x8 zf[TH][3];
 #pragma unroll
         for (int py = 0; py < TH; ++py) {
@@ -2210,15 +2292,33 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
 #pragma unroll
             for (int q = 0; q < 3; ++q) zf[py][q] = *reinterpret_cast<const bf16x8*>(zrow + q * PIX + py * TW);
         }
-#pragma unroll
-        for (int r = 0; r < XH; ++r) {
-            if (CO32 && (r < 2 * ph || r > 2 * ph + 3)) continue;   // X rows this wave's two output rows read
-            bf16x8 xf[3][3];                                         // [kx][piece]
+        i32x4 xraw[2][3][3];                                        // [row parity][piece][prev | cur | next]: 16-byte groups of one X row
+        auto read_row = [&](int r) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const unsigned short* g0 = xrow + q * XQ + r * XROW;
-                const i32x4 prev = *reinterpret_cast<const i32x4*>(g0), cur = *reinterpret_cast<const i32x4*>(g0 + 8),
-                            next = *reinterpret_cast<const i32x4*>(g0 + 16);
+                xraw[r & 1][q][0] = *reinterpret_cast<const i32x4*>(g0);
+                xraw[r & 1][q][1] = *reinterpret_cast<const i32x4*>(g0 + 8);
+                xraw[r & 1][q][2] = *reinterpret_cast<const i32x4*>(g0 + 16);
+            }
+        };
+        if (SPREAD) read_row(0);
+#pragma unroll
+        for (int r = 0; r < XH; ++r) {
+            if (CO32 && (r < 2 * ph || r > 2 * ph + 3)) continue;   // X rows this wave's two output rows read
+            if (SPREAD) {
+                // a 16-byte buffer load occupies the CU's address path for ~16 cycles per wave: seventeen of them issued in one burst by
+                // all four waves stalled each wave for 1.5-1.9 k cycles per tile (stamped); three per X row disappear under that row's MFMAs
+                if (r + 1 < XH) read_row(r + 1);
+#pragma unroll
+                for (int k = 3 * r; k < min(3 * r + 3, 17); ++k) fast_issue(k);
+                __builtin_amdgcn_sched_barrier(0);                  // (left alone, the scheduler sinks the reads to the end of the region)
+            } else
+                read_row(r);
+            bf16x8 xf[3][3];                                         // [kx][piece]
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const i32x4 prev = xraw[r & 1][q][0], cur = xraw[r & 1][q][1], next = xraw[r & 1][q][2];
                 i32x4 left, right;
                 left[0] = (int)__builtin_amdgcn_alignbit((unsigned)cur[0], (unsigned)prev[3], 16);
                 right[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)cur[3], 16);
@@ -2243,8 +2343,11 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
                         for (int qa = 0; qa <= ord; ++qa)
                             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[py][qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
             }
+            if (SPREAD) __builtin_amdgcn_sched_barrier(0);          // keep the row regions apart: loads and reads of a region lead its MFMAs
         }
+#ifndef CODEPS_WG_STAMP_LOADS
         CODEPS_STAMP_PHASE_A();                                     // A: next tile's loads issued + fragment reads + 216 MFMAs of this wave
+#endif
     }
     // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 31, row (co) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float* dst = part + (size_t)(CO32 ? blk * 2 + ph : blk) * p.Co * 9 * p.Ct;
@@ -2259,6 +2362,18 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
             }
     }
     CODEPS_STAMP_END(conv);
+}
+
+template <bool CO32>
+__global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
+                                                            const float* __restrict__ x0, const float* __restrict__ x1,
+                                                            const float* __restrict__ dz, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    const int c_base = (blockIdx.x % ci_chunks) * 64;
+    // p.fast: the layer-wide conditions (host); per block: the chunk lies in one source, and that source is not up-sampled
+    const bool fast = p.fast && (c_base >= p.C0 || (!p.up0 && (p.C1 == 0 || c_base + 64 <= p.C0)));
+    if (fast) wgrad_halo64s_body<CO32, true>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+    else wgrad_halo64s_body<CO32, false>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
 }
 
 // Weight gradient of the double-pixel stem (7 x 4 taps of 16 channels, stride (2, 1), 64 output channels) on the bf16 matrix
@@ -3412,6 +3527,9 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     p.stride_w = d->stride_w; p.pad_w = d->pad_w;
     p.pad_mode = d->pad_mode; p.n_mt = n_mt; p.n_nt = n_nt; p.splits = splits; p.pix_per_split = pps;
     p.P = d->batch * d->out_h * d->out_w;
+    static const int wg_fast = getenv("CODEPS_WGRAD_FAST") ? atoi(getenv("CODEPS_WGRAD_FAST")) : 1;                 // tuning experiments only
+    p.fast = wg_fast && d->pad_mode == 0 && d->out_h % 4 == 0 && d->out_w % 16 == 0 && (d->c0 % 4) == 0 && (d->c1 % 4) == 0 &&
+             (size_t)d->in_h * d->in_w * std::max(std::max(d->c0, d->c1), d->out_c) * 4 < ((size_t)1 << 31);
     const int grid = n_mt * n_nt * d->kh * d->kw * splits;
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
