@@ -76,6 +76,16 @@ __device__ __forceinline__ unsigned long long codeps_memrealtime() {
             st_d_[0] = st_t1_ - st_t0_; st_d_[1] = st_r1_ - st_r0_; st_d_[2] = st_pa_; st_d_[3] = st_pb_;                   \
         }                                                                                                                   \
     } while (0)
+// one record per WAVE (slot = 4 * block + wave): which wave of a block is the late one at its barriers
+#define CODEPS_STAMP_END_WAVES(tag)                                                                                         \
+    do {                                                                                                                    \
+        const unsigned long long st_t1_ = codeps_memtime(), st_r1_ = codeps_memrealtime();                                  \
+        const unsigned st_slot_ = 4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + (threadIdx.x >> 6);  \
+        if ((threadIdx.x & 63) == 0 && codeps_stamp_buf_##tag && st_slot_ < codeps_stamp_cap_##tag) {                       \
+            unsigned long long* st_d_ = codeps_stamp_buf_##tag + (size_t)st_slot_ * 4;                                      \
+            st_d_[0] = st_t1_ - st_t0_; st_d_[1] = st_r1_ - st_r0_; st_d_[2] = st_pa_; st_d_[3] = st_pb_;                   \
+        }                                                                                                                   \
+    } while (0)
 #define CODEPS_STAMP_SETTER(tag)                                                                                            \
     extern "C" int codeps_stamp_buffer_##tag(unsigned long long* buf, unsigned cap) {                                       \
         if (hipMemcpyToSymbol(HIP_SYMBOL(codeps_stamp_buf_##tag), &buf, sizeof(buf)) != hipSuccess) return -1;              \
@@ -88,6 +98,7 @@ __device__ __forceinline__ unsigned long long codeps_memrealtime() {
 #define CODEPS_STAMP_PHASE_A() do {} while (0)
 #define CODEPS_STAMP_PHASE_B() do {} while (0)
 #define CODEPS_STAMP_END(tag) do {} while (0)
+#define CODEPS_STAMP_END_WAVES(tag) do {} while (0)
 #define CODEPS_STAMP_SETTER(tag)
 #endif
 

@@ -2364,6 +2364,287 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
     CODEPS_STAMP_END(conv);
 }
 
+// The FAST blocks of the 64-row form, double-buffered (wgrad_halo64s_body spends a quarter of a block's lifetime staging -- split,
+// transpose, LDS stores between two barriers -- with the matrix pipe idle: one wave per SIMD, nothing else to issue).  Here a 4 x 16
+// tile is two 2 x 16 sub-tiles and LDS holds two of them (2 x 66 KB): while the waves run the 108 MFMAs of sub-tile j from one
+// buffer, the same waves split and store sub-tile j + 1 into the other between those MFMAs (vector slots the MFMAs leave free) and
+// issue the loads of sub-tile j + 2 into the second register set -- one barrier per sub-tile, no staging phase.  The price is the halo
+// rows staged twice (4 X rows per 2 output rows instead of 6 per 4); the work is hidden, the extra reads hit L2.
+// Tasks per sub-tile: 64 dZ (8 pixels x 4 channels; wave 0), 128 X interior (waves 1, 2), 128 halo pixels (two per lane; wave 3).
+// The sub-tile loop exists three times, once per role: a wave runs its own staging instructions between its MFMAs, in one basic block
+// (one shared instruction stream with the other roles' stores sent to a scrap area measured SLOWER than the single-buffered body: the
+// LDS pipe was then busy longer than the matrix pipe).
+__device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
+                                                   const float* __restrict__ x0, const float* __restrict__ x1,
+                                                   const float* __restrict__ dz, float* __restrict__ part, unsigned short* lds16) {
+    constexpr int TH = 2, TW = 16, XH = TH + 2, PIX = TH * TW, XROW = 32;
+    constexpr int ZP = 3 * PIX + 8;                    // halfwords per dZ channel (104: 52 dwords, conflict-free 16-byte fragment reads)
+    constexpr int XQ = XH * XROW, XP = 3 * XQ + 8;     // halfwords per X piece / per X channel (392: 196 dwords)
+    constexpr int XS0 = 64 * ZP;                       // X rows start behind the dZ rows
+    constexpr int BUF = 64 * (ZP + XP);               // halfwords per buffer: [64][ZP] dZ, [64][XP] X
+#ifndef WG_FILL
+#define WG_FILL 4
+#endif
+    CODEPS_STAMP_BEGIN();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+    const int role = __builtin_amdgcn_readfirstlane(wave);            // 0: dZ, 1 / 2: X interior, 3: halo pixels
+    const int co_base = blockIdx.y * 64;
+    const int chunk = blockIdx.x % ci_chunks, blk = blockIdx.x / ci_chunks;
+    const int c_base = chunk * 64;
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    const int NJ = 2 * (t_end - t_beg);                               // sub-tiles of this block (even)
+    const bool s1 = c_base >= p.C0;                                   // (block-uniform)
+    const float* xsrc = s1 ? x1 : x0;
+    const int xcs = s1 ? p.C1 : p.C0, xc0 = s1 ? c_base - p.C0 : c_base;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-thread constants.  Big task (quad's low two bits over four consecutive lanes, then the pixel group, then the quad's high
+    // bits: see wgrad_halo64s_body): global byte offset from the sub-tile origin, the X row it reads, LDS halfword of its first store
+    int b_off = 0, b_row = 0, b_dst = 0;
+    bool b_ok = false;
+    if (role == 0) {
+        const int c4 = (lane & 3) | ((lane >> 4) << 2), grp = (lane >> 2) & 3;
+        b_off = (((grp >> 1) * p.Wo + (grp & 1) * 8) * p.Co + co_base + c4 * 4) * 4;
+        b_ok = co_base + c4 * 4 < p.Co;
+        b_dst = (c4 * 4) * ZP + grp * 8;
+    } else if (role < 3) {
+        const int t = tid - 64, c4 = (t & 3) | ((t >> 5) << 2), grp = (t >> 2) & 7;
+        b_row = (grp >> 1) - 1;
+        b_off = ((b_row * p.W + (grp & 1) * 8) * xcs + xc0 + c4 * 4) * 4;
+        b_ok = xc0 + c4 * 4 < xcs;
+        b_dst = XS0 + (c4 * 4) * XP + (grp >> 1) * XROW + 8 + (grp & 1) * 8;
+    }
+    int s_off[2] = {0, 0}, s_row[2] = {0, 0}, s_dst[2] = {0, 0}, s_dstk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    unsigned s_selk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    bool s_ok[2] = {false, false}, s_side[2] = {false, false};
+    if (role == 3) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = lane + 64 * u, c4 = t & 15, rs = t >> 4;
+            s_side[u] = rs & 1;
+            s_row[u] = (rs >> 1) - 1;
+            s_off[u] = ((s_row[u] * p.W + (s_side[u] ? TW : -1)) * xcs + xc0 + c4 * 4) * 4;
+            s_ok[u] = xc0 + c4 * 4 < xcs;
+            s_dst[u] = XS0 + (c4 * 4) * XP + (rs >> 1) * XROW + (s_side[u] ? 24 : 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = (k + (c4 >> 1)) & 3;
+                s_dstk[u][k] = s_dst[u] + e * XP;
+                s_selk[u][k] = 0x0c0c0000u | (e == 0 ? 0x0504u : e == 1 ? 0x0706u : e == 2 ? 0x0100u : 0x0302u);
+            }
+        }
+    }
+    const size_t zimg = (size_t)p.Ho * p.Wo * p.Co, ximg = (size_t)p.H * p.W * xcs;
+    // the loads of sub-tile j for a wave of role ROLE (0: dZ, 1: X interior -- eight 16-byte loads; 3: two halo pixels); all lanes read
+    // zeros when !valid (the sub-tile behind the last one), so the tile loop has no branch around its loads
+    auto issue_loads = [&](auto role_c, int j, bool valid, f32x4 (&raw)[8], unsigned tok = 0) {
+        constexpr int ROLE = decltype(role_c)::value;
+        const int tile = t_beg + (j >> 1);                                                     // (all scalar)
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * 4 + (j & 1) * TH, tx0 = (tr % tiles_x) * TW;
+        if (ROLE == 0) {
+            const __amdgpu_buffer_rsrc_t rsz = make_rsrc(dz + (size_t)b * zimg, zimg * 4);
+            const int zorg = (ty0 * p.Wo + tx0) * p.Co * 4, zpix = p.Co * 4;
+            const unsigned vo = (valid && b_ok) ? (unsigned)(zorg + b_off) : GATHER_OOB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsz, vo, i * zpix, 0));
+        } else {
+            const __amdgpu_buffer_rsrc_t rsx = make_rsrc(xsrc + (size_t)b * ximg, ximg * 4);
+            const int xorg = (ty0 * p.W + tx0) * xcs * 4, xpix = xcs * 4;
+            if (ROLE == 1) {
+                const unsigned vo = (valid && b_ok && (unsigned)(ty0 + b_row) < (unsigned)p.H) ? (unsigned)(xorg + b_off) : GATHER_OOB;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, i * xpix, 0));
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bool ok = valid && s_ok[u] && (unsigned)(ty0 + s_row[u]) < (unsigned)p.H && (s_side[u] ? tx0 + TW < p.W : tx0 > 0);
+                    raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (ok ? (unsigned)(xorg + s_off[u]) : GATHER_OOB) + tok, 0, 0));
+                }
+            }
+        }
+    };
+    // channel e of the big task: 8 pixels -> three 16-byte rows (one per piece)
+    auto store_big = [&](auto role_c, const f32x4 (&raw)[8], int e, unsigned short* buf) {
+        constexpr int ROLE = decltype(role_c)::value;
+        constexpr int cs = ROLE == 0 ? ZP : XP, qs = ROLE == 0 ? PIX : XQ;
+        const f32x4 lo4 = {raw[0][e], raw[1][e], raw[2][e], raw[3][e]};
+        const f32x4 hi4 = {raw[4][e], raw[5][e], raw[6][e], raw[7][e]};
+        u16x4 lo[3], hi[3];
+        split_bf16<3>(lo4, lo);
+        split_bf16<3>(hi4, hi);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(buf + b_dst + e * cs + q * qs) = pack8(lo[q], hi[q]);
+    };
+    // a halo pixel's 2-byte stores: a channel's row starts 196 dwords behind its neighbour's (= 4 mod 32: what the 16-byte fragment reads
+    // want), so the halo slots of all rows and channels fall on 16 of the 32 write banks -- 4-way at best.  With all lanes storing the
+    // SAME channel of their quad the 64 addresses fell on four to eight banks (the wave with these stores was 1.1 k cycles per sub-tile
+    // behind the others, stamped per wave); so lane's k-th store takes channel (k + (quad >> 1)) & 3 of its quad: 4 lanes per bank.
+    struct SmallPc { unsigned lo[3], hi[3]; };                      // a halo pixel's 4 channels x 3 pieces, two halfwords per dword
+    auto split_small = [&](const f32x4 v) {
+        u16x4 pc[3];
+        split_bf16<3>(v, pc);
+        SmallPc o;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            o.lo[q] = (unsigned)pc[q][0] | ((unsigned)pc[q][1] << 16);
+            o.hi[q] = (unsigned)pc[q][2] | ((unsigned)pc[q][3] << 16);
+        }
+        return o;
+    };
+    auto store_small = [&](const SmallPc& pc, int u, unsigned short* buf) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)                              // v_perm_b32: bytes 0-3 = hi, 4-7 = lo (selector = byte numbers of the wanted halfword)
+                buf[s_dstk[u][k] + q * XQ] = (unsigned short)__builtin_amdgcn_perm(pc.lo[q], pc.hi[q], s_selk[u][k]);
+    };
+    auto store_all = [&](auto role_c, const f32x4 (&raw)[8], unsigned short* buf) {
+        constexpr int ROLE = decltype(role_c)::value;
+        if (ROLE == 3) { store_small(split_small(raw[0]), 0, buf); store_small(split_small(raw[1]), 1, buf); }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_big(role_c, raw, e, buf);
+        }
+    };
+
+    const int zoff = (wco * 32 + l32) * ZP + h * 8, xoff = XS0 + (wci * 32 + l32) * XP + h * 8;
+    // one sub-tile: its 108 MFMAs out of `cur`, the staging of the next one (registers rs, loaded a phase ago) into `nxt`, the loads
+    // of the one after that into rl.  One copy of this code per role: a wave runs ITS staging instructions between the MFMAs and
+    // nothing else, in one basic block
+    auto phase = [&](auto role_c, int j, const f32x4 (&rs)[8], f32x4 (&rl)[8], const unsigned short* cur, unsigned short* nxt) {
+        constexpr int ROLE = decltype(role_c)::value;
+        // (halo role: split BEFORE the next loads are issued -- with the two old and the two new loads in flight together the compiler's
+        //  wait in front of the split, vmcnt(1), also waited for the first NEW load: a memory latency per sub-tile, stamped per wave)
+        SmallPc pc0 = {}, pc1 = {};
+        unsigned tok = 0;                                           // (zero; makes the loads' offsets depend on the split's results: program order alone did not hold)
+        if (ROLE == 3) {
+            pc0 = split_small(rs[0]);
+            pc1 = split_small(rs[1]);
+            asm volatile("" : "+v"(tok) : "v"(pc0.lo[0]), "v"(pc0.lo[1]), "v"(pc0.lo[2]), "v"(pc0.hi[0]), "v"(pc0.hi[1]), "v"(pc0.hi[2]),
+                                          "v"(pc1.lo[0]), "v"(pc1.lo[1]), "v"(pc1.lo[2]), "v"(pc1.hi[0]), "v"(pc1.hi[1]), "v"(pc1.hi[2]));
+        }
+        issue_loads(role_c, min(j + 2, NJ - 1), j + 2 < NJ, rl, tok);
+        const unsigned short* zrow = cur + zoff;
+        const unsigned short* xrow = cur + xoff;
+        bf16x8 zf[TH][3];
+#pragma unroll
+        for (int py = 0; py < TH; ++py)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) zf[py][q] = *reinterpret_cast<const bf16x8*>(zrow + q * PIX + py * TW);
+        i32x4 xraw[2][3][3];                                        // [row parity][piece][prev | cur | next]
+        auto read_row = [&](int r) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned short* g0 = xrow + q * XQ + r * XROW;
+                xraw[r & 1][q][0] = *reinterpret_cast<const i32x4*>(g0);
+                xraw[r & 1][q][1] = *reinterpret_cast<const i32x4*>(g0 + 8);
+                xraw[r & 1][q][2] = *reinterpret_cast<const i32x4*>(g0 + 16);
+            }
+        };
+        read_row(0);
+#pragma unroll
+        for (int r = 0; r < XH; ++r) {
+            if (r + 1 < XH) read_row(r + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // staging of the next sub-tile under the 36 MFMAs of each of the two middle rows
+            if (ROLE == 3) {
+                if (r == 1) store_small(pc0, 0, nxt);
+                if (r == 2) store_small(pc1, 1, nxt);
+            } else {
+                if (r == 1) { store_big(role_c, rs, 0, nxt); store_big(role_c, rs, 1, nxt); }
+                if (r == 2) { store_big(role_c, rs, 2, nxt); store_big(role_c, rs, 3, nxt); }
+            }
+            bf16x8 xf[3][3];                                         // [kx][piece]
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const i32x4 prev = xraw[r & 1][q][0], curv = xraw[r & 1][q][1], next = xraw[r & 1][q][2];
+                i32x4 left, right;
+                left[0] = (int)__builtin_amdgcn_alignbit((unsigned)curv[0], (unsigned)prev[3], 16);
+                right[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)curv[3], 16);
+#pragma unroll
+                for (int i = 1; i < 4; ++i) left[i] = (int)__builtin_amdgcn_alignbit((unsigned)curv[i], (unsigned)curv[i - 1], 16);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) right[i] = (int)__builtin_amdgcn_alignbit((unsigned)curv[i + 1], (unsigned)curv[i], 16);
+                xf[0][q] = __builtin_bit_cast(bf16x8, left);
+                xf[1][q] = __builtin_bit_cast(bf16x8, curv);
+                xf[2][q] = __builtin_bit_cast(bf16x8, right);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int py = r - ky;
+                if (py < 0 || py >= TH) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                        for (int qa = 0; qa <= ord; ++qa)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[py][qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
+            }
+            // one MFMA, then up to four of the staging's vector / LDS-store instructions in the cycles it leaves free
+#pragma unroll
+            for (int i = 0; i < (r == 0 || r == 3 ? 18 : 36); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x202, WG_FILL, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto run = [&](auto role_c) {
+        f32x4 ra[8], rb[8];
+        unsigned short* buf0 = lds16;
+        unsigned short* buf1 = lds16 + BUF;
+        issue_loads(role_c, 0, true, ra);
+        issue_loads(role_c, 1, true, rb);
+        store_all(role_c, ra, buf0);
+        __syncthreads();
+        for (int j = 0; j < NJ; j += 2) {
+            CODEPS_STAMP_PHASE_START();
+            phase(role_c, j, rb, ra, buf0, buf1);
+            CODEPS_STAMP_PHASE_A();                                 // A: the sub-tile's MFMAs with the staging between them
+            CODEPS_STAMP_PHASE_START();
+            __syncthreads();                                        // buf0 is read, buf1 is written
+            CODEPS_STAMP_PHASE_B();                                 // B: waiting at the barrier
+            CODEPS_STAMP_PHASE_START();
+            phase(role_c, j + 1, ra, rb, buf1, buf0);
+            CODEPS_STAMP_PHASE_A();
+            CODEPS_STAMP_PHASE_START();
+            __syncthreads();
+            CODEPS_STAMP_PHASE_B();
+        }
+    };
+    if (NJ > 0) {
+        if (role == 0) run(std::integral_constant<int, 0>{});
+        else if (role == 3) run(std::integral_constant<int, 3>{});
+        else run(std::integral_constant<int, 1>{});
+    }
+    // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 31, row (co) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* dst = part + (size_t)blk * p.Co * 9 * p.Ct;
+    const int ci = c_base + wci * 32 + l32;
+    if (ci < p.Ct) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Co) dst[((size_t)co * 9 + t) * p.Ct + ci] = acc[t][r];
+            }
+    }
+#ifdef CODEPS_WG_STAMP_WAVES
+    CODEPS_STAMP_END_WAVES(conv);
+#else
+    CODEPS_STAMP_END(conv);
+#endif
+}
+
 template <bool CO32>
 __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                             const float* __restrict__ x0, const float* __restrict__ x1,
@@ -2372,6 +2653,10 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     const int c_base = (blockIdx.x % ci_chunks) * 64;
     // p.fast: the layer-wide conditions (host); per block: the chunk lies in one source, and that source is not up-sampled
     const bool fast = p.fast && (c_base >= p.C0 || (!p.up0 && (p.C1 == 0 || c_base + 64 <= p.C0)));
+#ifndef CODEPS_WG_NODBUF                                             // (variant builds: the A/B of the double-buffered body)
+    if (fast && !CO32) wgrad_halo64d_body(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+    else
+#endif
     if (fast) wgrad_halo64s_body<CO32, true>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
     else wgrad_halo64s_body<CO32, false>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
 }
@@ -3541,7 +3826,9 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
         if (sp.halo64) {
             g_last_kernel = wgrad_split_on() ? "wgrad_halo64s_kernel" : "wgrad_halo64_kernel";
             if (wgrad_split_on()) {
-                constexpr size_t lds = (size_t)64 * ((3 * 64 + 8) + (3 * 6 * 32 + 8)) * 2;           // dZs + Xs (halfwords)
+                // 4 x 16 tiles: dZs + Xs (halfwords); the double-buffered body: two 2 x 16 sub-tiles
+                constexpr size_t lds_s = (size_t)64 * ((3 * 64 + 8) + (3 * 6 * 32 + 8)) * 2, lds_d = (size_t)2 * (64 * ((3 * 32 + 8) + (3 * 4 * 32 + 8))) * 2;
+                const size_t lds = sp.co32 ? lds_s : std::max(lds_s, lds_d);
                 if (sp.co32) {
                     g_last_kernel = "wgrad_halo64s_kernel<co32>";
                     codeps_allow_lds((const void*)wgrad_halo64s_kernel<true>, 160 * 1024, "wgrad_halo64s_kernel<co32>");
