@@ -2374,6 +2374,9 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
 // The sub-tile loop exists three times, once per role: a wave runs its own staging instructions between its MFMAs, in one basic block
 // (one shared instruction stream with the other roles' stores sent to a scrap area measured SLOWER than the single-buffered body: the
 // LDS pipe was then busy longer than the matrix pipe).
+// UP: the block's chunk comes from the up-sampled source (nearest, x 2): source pixel (y >> 1, x >> 1) -- a big task loads four
+// pixels and uses each twice, every offset is still (scaled tile origin) + (per-thread constant).
+template <bool UP>
 __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                    const float* __restrict__ x0, const float* __restrict__ x1,
                                                    const float* __restrict__ dz, float* __restrict__ part, unsigned short* lds16) {
@@ -2417,7 +2420,7 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
     } else if (role < 3) {
         const int t = tid - 64, c4 = (t & 3) | ((t >> 5) << 2), grp = (t >> 2) & 7;
         b_row = (grp >> 1) - 1;
-        b_off = ((b_row * p.W + (grp & 1) * 8) * xcs + xc0 + c4 * 4) * 4;
+        b_off = UP ? (((b_row >> 1) * (p.W / 2) + (grp & 1) * 4) * xcs + xc0 + c4 * 4) * 4 : ((b_row * p.W + (grp & 1) * 8) * xcs + xc0 + c4 * 4) * 4;
         b_ok = xc0 + c4 * 4 < xcs;
         b_dst = XS0 + (c4 * 4) * XP + (grp >> 1) * XROW + 8 + (grp & 1) * 8;
     }
@@ -2430,7 +2433,8 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
             const int t = lane + 64 * u, c4 = t & 15, rs = t >> 4;
             s_side[u] = rs & 1;
             s_row[u] = (rs >> 1) - 1;
-            s_off[u] = ((s_row[u] * p.W + (s_side[u] ? TW : -1)) * xcs + xc0 + c4 * 4) * 4;
+            s_off[u] = UP ? (((s_row[u] >> 1) * (p.W / 2) + (s_side[u] ? TW / 2 : -1)) * xcs + xc0 + c4 * 4) * 4
+                          : ((s_row[u] * p.W + (s_side[u] ? TW : -1)) * xcs + xc0 + c4 * 4) * 4;
             s_ok[u] = xc0 + c4 * 4 < xcs;
             s_dst[u] = XS0 + (c4 * 4) * XP + (rs >> 1) * XROW + (s_side[u] ? 24 : 7);
 #pragma unroll
@@ -2441,7 +2445,7 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
             }
         }
     }
-    const size_t zimg = (size_t)p.Ho * p.Wo * p.Co, ximg = (size_t)p.H * p.W * xcs;
+    const size_t zimg = (size_t)p.Ho * p.Wo * p.Co, ximg = UP ? (size_t)(p.H / 2) * (p.W / 2) * xcs : (size_t)p.H * p.W * xcs;
     // the loads of sub-tile j for a wave of role ROLE (0: dZ, 1: X interior -- eight 16-byte loads; 3: two halo pixels); all lanes read
     // zeros when !valid (the sub-tile behind the last one), so the tile loop has no branch around its loads
     auto issue_loads = [&](auto role_c, int j, bool valid, f32x4 (&raw)[8], unsigned tok = 0) {
@@ -2457,11 +2461,11 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
             for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsz, vo, i * zpix, 0));
         } else {
             const __amdgpu_buffer_rsrc_t rsx = make_rsrc(xsrc + (size_t)b * ximg, ximg * 4);
-            const int xorg = (ty0 * p.W + tx0) * xcs * 4, xpix = xcs * 4;
+            const int xorg = UP ? ((ty0 / 2) * (p.W / 2) + tx0 / 2) * xcs * 4 : (ty0 * p.W + tx0) * xcs * 4, xpix = xcs * 4;
             if (ROLE == 1) {
                 const unsigned vo = (valid && b_ok && (unsigned)(ty0 + b_row) < (unsigned)p.H) ? (unsigned)(xorg + b_off) : GATHER_OOB;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, i * xpix, 0));
+                for (int i = 0; i < (UP ? 4 : 8); ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, i * xpix, 0));
             } else {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -2475,6 +2479,16 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
     auto store_big = [&](auto role_c, const f32x4 (&raw)[8], int e, unsigned short* buf) {
         constexpr int ROLE = decltype(role_c)::value;
         constexpr int cs = ROLE == 0 ? ZP : XP, qs = ROLE == 0 ? PIX : XQ;
+        if (UP && ROLE == 1) {                                      // four source pixels, each twice
+            const f32x4 v4 = {raw[0][e], raw[1][e], raw[2][e], raw[3][e]};
+            u16x4 pc[3];
+            split_bf16<3>(v4, pc);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<i32x4*>(buf + b_dst + e * cs + q * qs) =
+                    pack8(u16x4{pc[q][0], pc[q][0], pc[q][1], pc[q][1]}, u16x4{pc[q][2], pc[q][2], pc[q][3], pc[q][3]});
+            return;
+        }
         const f32x4 lo4 = {raw[0][e], raw[1][e], raw[2][e], raw[3][e]};
         const f32x4 hi4 = {raw[4][e], raw[5][e], raw[6][e], raw[7][e]};
         u16x4 lo[3], hi[3];
@@ -2652,10 +2666,13 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
     const int c_base = (blockIdx.x % ci_chunks) * 64;
     // p.fast: the layer-wide conditions (host); per block: the chunk lies in one source, and that source is not up-sampled
-    const bool fast = p.fast && (c_base >= p.C0 || (!p.up0 && (p.C1 == 0 || c_base + 64 <= p.C0)));
+    const bool one_src = c_base >= p.C0 || p.C1 == 0 || c_base + 64 <= p.C0, up = p.up0 && c_base < p.C0;
+    const bool fast = p.fast && one_src && !up;
 #ifndef CODEPS_WG_NODBUF                                             // (variant builds: the A/B of the double-buffered body)
-    if (fast && !CO32) wgrad_halo64d_body(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
-    else
+    if (!CO32 && p.fast && one_src) {
+        if (up) wgrad_halo64d_body<true>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+        else wgrad_halo64d_body<false>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+    } else
 #endif
     if (fast) wgrad_halo64s_body<CO32, true>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
     else wgrad_halo64s_body<CO32, false>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);

@@ -94,3 +94,50 @@ def test_panoptic_fusion_reads_strided_maps_in_place():
     assert a[1].dtype == torch.int64 and c[1].dtype == torch.uint8
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1].to(torch.int64)) and torch.equal(a[2], c[2]) and torch.equal(a[3], c[3])
     assert int(a[3][:, 1].min()) > 0, "the case must keep some centres"
+
+
+@pytest.mark.parametrize("case", [
+    # (batch, H, W, c0, c1, up0, co): 4 x 16-divisible maps -> the double-buffered FAST body of wgrad_halo64s_kernel
+    (2, 16, 32, 64, 0, False, 64),        # one chunk, one 64-row co tile
+    (1, 32, 48, 128, 0, False, 128),      # 2 x 2 tiles of channels
+    (2, 16, 32, 80, 0, False, 64),        # second chunk holds 16 of 64 channels (the rest reads zeros through the range check)
+    (1, 32, 64, 64, 64, True, 64),        # chunk 0 from the up-sampled source (each source pixel twice), chunk 1 from the skip
+    (1, 16, 32, 64, 48, False, 96),       # concat without up-sampling, ragged skip width, co 96 (second co tile half empty)
+    (1, 18, 32, 64, 0, False, 64),        # H % 4 != 0 -> the generic body (same kernel name, same bound)
+])
+def test_weight_gradient_fast_bodies_against_float64(case):
+    """wgrad_halo64s_kernel picks its body per block (FAST: buffer loads with constant per-thread offsets, double-buffered 2 x 16
+    sub-tiles; UP form for an up-sampled chunk; generic otherwise): every form against a float64 convolution gradient
+    (reference arithmetic: fp32 convs, models/resnet_encoder.py:115-126), and bit-identical from launch to launch."""
+    import torch.nn.functional as TF
+    from codeps_amd import functional as F
+    from codeps_amd._lib import lib
+    b, h, w, c0, c1, up0, co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x0 = torch.relu(torch.randn(b, c0, h // 2 if up0 else h, w // 2 if up0 else w, generator=g))
+    x1 = torch.relu(torch.randn(b, c1, h, w, generator=g)) if c1 else None
+    wt = torch.randn(co, c0 + c1, 3, 3, generator=g) * (2.0 / (9 * (c0 + c1))) ** 0.5
+    gy = torch.randn(b, co, h, w, generator=g)
+    full = TF.interpolate(x0, scale_factor=2, mode="nearest") if up0 else x0
+    if c1:
+        full = torch.cat([full, x1], 1)
+
+    def ref(dtype):
+        ww = wt.to(dtype).requires_grad_(True)
+        TF.conv2d(full.to(dtype), ww, padding=1).backward(gy.to(dtype))
+        return ww.grad
+
+    dw64, dw32 = ref(torch.float64), ref(torch.float32)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)       # noqa: E731
+    lib().codeps_conv2d_last_kernel.restype = __import__("ctypes").c_char_p
+    outs = []
+    for _ in range(3):
+        ww = wt.to(DEV).detach().requires_grad_(True)
+        y = F.conv2d(nhwc(x0), ww, x1=nhwc(x1) if c1 else None, pad=1, up0=up0)
+        y.backward(nhwc(gy) if y.shape[-1] == co else torch.nn.functional.pad(nhwc(gy), (0, y.shape[-1] - co)))
+        assert lib().codeps_conv2d_last_kernel().decode().startswith("wgrad_halo64s_kernel")
+        outs.append(ww.grad.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
+    e, t = l2(outs[0], dw64), l2(dw32, dw64)
+    assert e <= 3 * t + 1e-9, f"{case}: {e:.3e} vs torch fp32 {t:.3e}"
