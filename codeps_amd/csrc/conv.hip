@@ -2368,7 +2368,8 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
 // transpose, LDS stores between two barriers -- with the matrix pipe idle: one wave per SIMD, nothing else to issue).  Here a 4 x 16
 // tile is two 2 x 16 sub-tiles and LDS holds two of them (2 x 66 KB): while the waves run the 108 MFMAs of sub-tile j from one
 // buffer, the same waves split and store sub-tile j + 1 into the other between those MFMAs (vector slots the MFMAs leave free) and
-// issue the loads of sub-tile j + 2 into the second register set -- one barrier per sub-tile, no staging phase.  The price is the halo
+// issue the loads of sub-tile j + 2 into the second register set -- one barrier per sub-tile (in front of its last 18 MFMAs, which
+// need registers only: the first fragment reads of the next sub-tile ride under them), no staging phase.  The price is the halo
 // rows staged twice (4 X rows per 2 output rows instead of 6 per 4); the work is hidden, the extra reads hit L2.
 // Tasks per sub-tile: 64 dZ (8 pixels x 4 channels; wave 0), 128 X interior (waves 1, 2), 128 halo pixels (two per lane; wave 3).
 // The sub-tile loop exists three times, once per role: a wave runs its own staging instructions between its MFMAs, in one basic block
@@ -2533,7 +2534,26 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
     // one sub-tile: its 108 MFMAs out of `cur`, the staging of the next one (registers rs, loaded a phase ago) into `nxt`, the loads
     // of the one after that into rl.  One copy of this code per role: a wave runs ITS staging instructions between the MFMAs and
     // nothing else, in one basic block
-    auto phase = [&](auto role_c, int j, const f32x4 (&rs)[8], f32x4 (&rl)[8], const unsigned short* cur, unsigned short* nxt) {
+    // fragments a phase starts with: dZ rows 0, 1 and X row 0 of its buffer.  They are read by the PREVIOUS phase, right behind the
+    // barrier that phase places in front of its last 18 MFMAs (row 3: registers only) -- the LDS latency at the start of a sub-tile
+    // disappears under those MFMAs
+    struct Frag { bf16x8 zf[TH][3]; i32x4 x0[3][3]; };
+    auto prefetch = [&](const unsigned short* buf, Frag& f) {
+        const unsigned short* zrow = buf + zoff;
+        const unsigned short* xrow = buf + xoff;
+#pragma unroll
+        for (int py = 0; py < TH; ++py)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) f.zf[py][q] = *reinterpret_cast<const bf16x8*>(zrow + q * PIX + py * TW);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const unsigned short* g0 = xrow + q * XQ;
+            f.x0[q][0] = *reinterpret_cast<const i32x4*>(g0);
+            f.x0[q][1] = *reinterpret_cast<const i32x4*>(g0 + 8);
+            f.x0[q][2] = *reinterpret_cast<const i32x4*>(g0 + 16);
+        }
+    };
+    auto phase = [&](auto role_c, int j, const f32x4 (&rs)[8], f32x4 (&rl)[8], const unsigned short* cur, unsigned short* nxt, Frag& fr) {
         constexpr int ROLE = decltype(role_c)::value;
         // (halo role: split BEFORE the next loads are issued -- with the two old and the two new loads in flight together the compiler's
         //  wait in front of the split, vmcnt(1), also waited for the first NEW load: a memory latency per sub-tile, stamped per wave)
@@ -2546,14 +2566,16 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
                                           "v"(pc1.lo[0]), "v"(pc1.lo[1]), "v"(pc1.lo[2]), "v"(pc1.hi[0]), "v"(pc1.hi[1]), "v"(pc1.hi[2]));
         }
         issue_loads(role_c, min(j + 2, NJ - 1), j + 2 < NJ, rl, tok);
-        const unsigned short* zrow = cur + zoff;
         const unsigned short* xrow = cur + xoff;
         bf16x8 zf[TH][3];
-#pragma unroll
-        for (int py = 0; py < TH; ++py)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) zf[py][q] = *reinterpret_cast<const bf16x8*>(zrow + q * PIX + py * TW);
         i32x4 xraw[2][3][3];                                        // [row parity][piece][prev | cur | next]
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int py = 0; py < TH; ++py) zf[py][q] = fr.zf[py][q];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xraw[0][q][i] = fr.x0[q][i];
+        }
         auto read_row = [&](int r) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -2563,10 +2585,13 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
                 xraw[r & 1][q][2] = *reinterpret_cast<const i32x4*>(g0 + 16);
             }
         };
-        read_row(0);
 #pragma unroll
         for (int r = 0; r < XH; ++r) {
             if (r + 1 < XH) read_row(r + 1);
+            else {
+                __syncthreads();                                    // every wave has read `cur` (row 3 is in registers) and written its part of `nxt`
+                prefetch(nxt, fr);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // staging of the next sub-tile under the 36 MFMAs of each of the two middle rows
             if (ROLE == 3) {
@@ -2620,19 +2645,11 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
         issue_loads(role_c, 1, true, rb);
         store_all(role_c, ra, buf0);
         __syncthreads();
+        Frag fr;
+        prefetch(buf0, fr);
         for (int j = 0; j < NJ; j += 2) {
-            CODEPS_STAMP_PHASE_START();
-            phase(role_c, j, rb, ra, buf0, buf1);
-            CODEPS_STAMP_PHASE_A();                                 // A: the sub-tile's MFMAs with the staging between them
-            CODEPS_STAMP_PHASE_START();
-            __syncthreads();                                        // buf0 is read, buf1 is written
-            CODEPS_STAMP_PHASE_B();                                 // B: waiting at the barrier
-            CODEPS_STAMP_PHASE_START();
-            phase(role_c, j + 1, ra, rb, buf1, buf0);
-            CODEPS_STAMP_PHASE_A();
-            CODEPS_STAMP_PHASE_START();
-            __syncthreads();
-            CODEPS_STAMP_PHASE_B();
+            phase(role_c, j, rb, ra, buf0, buf1, fr);
+            phase(role_c, j + 1, ra, rb, buf1, buf0, fr);
         }
     };
     if (NJ > 0) {
