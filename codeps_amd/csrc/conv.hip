@@ -2375,9 +2375,14 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
 // The sub-tile loop exists three times, once per role: a wave runs its own staging instructions between its MFMAs, in one basic block
 // (one shared instruction stream with the other roles' stores sent to a scrap area measured SLOWER than the single-buffered body: the
 // LDS pipe was then busy longer than the matrix pipe).
-// UP: the block's chunk comes from the up-sampled source (nearest, x 2): source pixel (y >> 1, x >> 1) -- a big task loads four
-// pixels and uses each twice, every offset is still (scaled tile origin) + (per-thread constant).
-template <bool UP>
+// Sources: a chunk's 64 channels are two halves of 32 (quads 0-7, 8-15); each half lies in ONE source (host + kernel wrapper check:
+// the concat boundary is at a multiple of 32 inside the chunk), which may be the up-sampled one (nearest, x 2: source pixel
+// (y >> 1, x >> 1) -- a big task loads four pixels and uses each twice, every offset is still (scaled tile origin) + (per-thread
+// constant)).  X interior: wave 1 stages half 0, wave 2 half 1; halo pixels: a lane's task 0 is in half 0, task 1 in half 1 -- so the
+// source of every load instruction is wave-uniform and its up-sampling a compile-time property of the wave's code copy.
+// CO32 (<= 32 output channels): one 32-row co tile; the waves that would hold the second one split the sub-tile's two output rows
+// instead (wave = (row ph, ci tile), 54 MFMAs per sub-tile) and each row writes its own partial slab, as in wgrad_halo64s_body.
+template <bool CO32>
 __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                    const float* __restrict__ x0, const float* __restrict__ x1,
                                                    const float* __restrict__ dz, float* __restrict__ part, unsigned short* lds16) {
@@ -2391,7 +2396,7 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
 #endif
     CODEPS_STAMP_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
-    const int wco = wave & 1, wci = wave >> 1;
+    const int wco = CO32 ? 0 : (wave & 1), wci = wave >> 1;
     const int role = __builtin_amdgcn_readfirstlane(wave);            // 0: dZ, 1 / 2: X interior, 3: halo pixels
     const int co_base = blockIdx.y * 64;
     const int chunk = blockIdx.x % ci_chunks, blk = blockIdx.x / ci_chunks;
@@ -2399,9 +2404,17 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
     const int total_tiles = p.B * tiles_y * tiles_x;
     const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
     const int NJ = 2 * (t_end - t_beg);                               // sub-tiles of this block (even)
-    const bool s1 = c_base >= p.C0;                                   // (block-uniform)
-    const float* xsrc = s1 ? x1 : x0;
-    const int xcs = s1 ? p.C1 : p.C0, xc0 = s1 ? c_base - p.C0 : c_base;
+    // X source of a half of the chunk (block-uniform)
+    struct XSrc { const float* ptr; int cs, c0; bool up; size_t img; };
+    auto xsrc_of = [&](int half) {
+        const int ch = c_base + 32 * half;
+        const bool s1 = ch >= p.C0;
+        XSrc o;
+        o.ptr = s1 ? x1 : x0; o.cs = s1 ? p.C1 : p.C0; o.c0 = s1 ? ch - p.C0 : ch; o.up = p.up0 && !s1;
+        o.img = o.up ? (size_t)(p.H / 2) * (p.W / 2) * o.cs : (size_t)p.H * p.W * o.cs;
+        return o;
+    };
+    const XSrc xs[2] = {xsrc_of(0), xsrc_of(1)};
 
     f32x16 acc[9];
 #pragma unroll
@@ -2419,38 +2432,45 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
         b_ok = co_base + c4 * 4 < p.Co;
         b_dst = (c4 * 4) * ZP + grp * 8;
     } else if (role < 3) {
-        const int t = tid - 64, c4 = (t & 3) | ((t >> 5) << 2), grp = (t >> 2) & 7;
+        const XSrc& sx = xs[role - 1];
+        const int t = tid - 64, c4 = (t & 3) | ((t >> 5) << 2), c4l = c4 & 7, grp = (t >> 2) & 7;      // wave 1: quads 0-7, wave 2: 8-15
         b_row = (grp >> 1) - 1;
-        b_off = UP ? (((b_row >> 1) * (p.W / 2) + (grp & 1) * 4) * xcs + xc0 + c4 * 4) * 4 : ((b_row * p.W + (grp & 1) * 8) * xcs + xc0 + c4 * 4) * 4;
-        b_ok = xc0 + c4 * 4 < xcs;
+        b_off = sx.up ? (((b_row >> 1) * (p.W / 2) + (grp & 1) * 4) * sx.cs + sx.c0 + c4l * 4) * 4
+                      : ((b_row * p.W + (grp & 1) * 8) * sx.cs + sx.c0 + c4l * 4) * 4;
+        b_ok = sx.c0 + c4l * 4 < sx.cs;
         b_dst = XS0 + (c4 * 4) * XP + (grp >> 1) * XROW + 8 + (grp & 1) * 8;
     }
-    int s_off[2] = {0, 0}, s_row[2] = {0, 0}, s_dst[2] = {0, 0}, s_dstk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    unsigned s_selk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    bool s_ok[2] = {false, false}, s_side[2] = {false, false};
+    int s_off[2] = {0, 0}, s_row = 0, s_dstk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    unsigned s_selk[4] = {0, 0, 0, 0};
+    bool s_ok[2] = {false, false}, s_side = false;
     if (role == 3) {
+        const int c4l = lane & 7, rs = lane >> 3;                    // task u: quad c4l + 8 u, (row, side) rs
+        s_side = rs & 1;
+        s_row = (rs >> 1) - 1;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int t = lane + 64 * u, c4 = t & 15, rs = t >> 4;
-            s_side[u] = rs & 1;
-            s_row[u] = (rs >> 1) - 1;
-            s_off[u] = UP ? (((s_row[u] >> 1) * (p.W / 2) + (s_side[u] ? TW / 2 : -1)) * xcs + xc0 + c4 * 4) * 4
-                          : ((s_row[u] * p.W + (s_side[u] ? TW : -1)) * xcs + xc0 + c4 * 4) * 4;
-            s_ok[u] = xc0 + c4 * 4 < xcs;
-            s_dst[u] = XS0 + (c4 * 4) * XP + (rs >> 1) * XROW + (s_side[u] ? 24 : 7);
+            const XSrc& sx = xs[u];
+            s_off[u] = sx.up ? (((s_row >> 1) * (p.W / 2) + (s_side ? TW / 2 : -1)) * sx.cs + sx.c0 + c4l * 4) * 4
+                             : ((s_row * p.W + (s_side ? TW : -1)) * sx.cs + sx.c0 + c4l * 4) * 4;
+            s_ok[u] = sx.c0 + c4l * 4 < sx.cs;
+            const int dst = XS0 + ((c4l + 8 * u) * 4) * XP + (rs >> 1) * XROW + (s_side ? 24 : 7);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = (k + (c4 >> 1)) & 3;
-                s_dstk[u][k] = s_dst[u] + e * XP;
-                s_selk[u][k] = 0x0c0c0000u | (e == 0 ? 0x0504u : e == 1 ? 0x0706u : e == 2 ? 0x0100u : 0x0302u);
-            }
+            for (int k = 0; k < 4; ++k) s_dstk[u][k] = dst + ((k + (c4l >> 1)) & 3) * XP;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (k + (c4l >> 1)) & 3;
+            s_selk[k] = 0x0c0c0000u | (e == 0 ? 0x0504u : e == 1 ? 0x0706u : e == 2 ? 0x0100u : 0x0302u);
         }
     }
-    const size_t zimg = (size_t)p.Ho * p.Wo * p.Co, ximg = UP ? (size_t)(p.H / 2) * (p.W / 2) * xcs : (size_t)p.H * p.W * xcs;
-    // the loads of sub-tile j for a wave of role ROLE (0: dZ, 1: X interior -- eight 16-byte loads; 3: two halo pixels); all lanes read
+    const size_t zimg = (size_t)p.Ho * p.Wo * p.Co;
+    // cfg of a wave's code copy: bits 0-1 role (0: dZ, 1: X interior, 3: halo pixels), bit 2: the wave's source (role 1) / the source of
+    // half 0 (role 3) is up-sampled, bit 3: role 3, the source of half 1 is up-sampled, bit 4: CO32, the wave's output row
+    // the loads of sub-tile j (role 0, 1: eight 16-byte loads, four from an up-sampled source; 3: two halo pixels); all lanes read
     // zeros when !valid (the sub-tile behind the last one), so the tile loop has no branch around its loads
-    auto issue_loads = [&](auto role_c, int j, bool valid, f32x4 (&raw)[8], unsigned tok = 0) {
-        constexpr int ROLE = decltype(role_c)::value;
+    auto issue_loads = [&](auto cfg_c, int j, bool valid, f32x4 (&raw)[8], unsigned tok = 0) {
+        constexpr int CFG = decltype(cfg_c)::value, ROLE = CFG & 3;
+        constexpr bool UPA = (CFG >> 2) & 1, UPB = (CFG >> 3) & 1;
         const int tile = t_beg + (j >> 1);                                                     // (all scalar)
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int ty0 = (tr / tiles_x) * 4 + (j & 1) * TH, tx0 = (tr % tiles_x) * TW;
@@ -2460,27 +2480,31 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
             const unsigned vo = (valid && b_ok) ? (unsigned)(zorg + b_off) : GATHER_OOB;
 #pragma unroll
             for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsz, vo, i * zpix, 0));
+        } else if (ROLE == 1) {
+            const XSrc& sx = xs[role - 1];
+            const __amdgpu_buffer_rsrc_t rsx = make_rsrc(sx.ptr + (size_t)b * sx.img, sx.img * 4);
+            const int xorg = UPA ? ((ty0 / 2) * (p.W / 2) + tx0 / 2) * sx.cs * 4 : (ty0 * p.W + tx0) * sx.cs * 4, xpix = sx.cs * 4;
+            const unsigned vo = (valid && b_ok && (unsigned)(ty0 + b_row) < (unsigned)p.H) ? (unsigned)(xorg + b_off) : GATHER_OOB;
+#pragma unroll
+            for (int i = 0; i < (UPA ? 4 : 8); ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, i * xpix, 0));
         } else {
-            const __amdgpu_buffer_rsrc_t rsx = make_rsrc(xsrc + (size_t)b * ximg, ximg * 4);
-            const int xorg = UP ? ((ty0 / 2) * (p.W / 2) + tx0 / 2) * xcs * 4 : (ty0 * p.W + tx0) * xcs * 4, xpix = xcs * 4;
-            if (ROLE == 1) {
-                const unsigned vo = (valid && b_ok && (unsigned)(ty0 + b_row) < (unsigned)p.H) ? (unsigned)(xorg + b_off) : GATHER_OOB;
+            const bool okp = valid && (unsigned)(ty0 + s_row) < (unsigned)p.H && (s_side ? tx0 + TW < p.W : tx0 > 0);
 #pragma unroll
-                for (int i = 0; i < (UP ? 4 : 8); ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, i * xpix, 0));
-            } else {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const bool ok = valid && s_ok[u] && (unsigned)(ty0 + s_row[u]) < (unsigned)p.H && (s_side[u] ? tx0 + TW < p.W : tx0 > 0);
-                    raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (ok ? (unsigned)(xorg + s_off[u]) : GATHER_OOB) + tok, 0, 0));
-                }
+            for (int u = 0; u < 2; ++u) {
+                const XSrc& sx = xs[u];
+                const bool up = u == 0 ? UPA : UPB;
+                const __amdgpu_buffer_rsrc_t rsx = make_rsrc(sx.ptr + (size_t)b * sx.img, sx.img * 4);
+                const int xorg = up ? ((ty0 / 2) * (p.W / 2) + tx0 / 2) * sx.cs * 4 : (ty0 * p.W + tx0) * sx.cs * 4;
+                raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, ((okp && s_ok[u]) ? (unsigned)(xorg + s_off[u]) : GATHER_OOB) + tok, 0, 0));
             }
         }
     };
     // channel e of the big task: 8 pixels -> three 16-byte rows (one per piece)
-    auto store_big = [&](auto role_c, const f32x4 (&raw)[8], int e, unsigned short* buf) {
-        constexpr int ROLE = decltype(role_c)::value;
+    auto store_big = [&](auto cfg_c, const f32x4 (&raw)[8], int e, unsigned short* buf) {
+        constexpr int CFG = decltype(cfg_c)::value, ROLE = CFG & 3;
+        constexpr bool UPA = (CFG >> 2) & 1;
         constexpr int cs = ROLE == 0 ? ZP : XP, qs = ROLE == 0 ? PIX : XQ;
-        if (UP && ROLE == 1) {                                      // four source pixels, each twice
+        if (UPA && ROLE == 1) {                                     // four source pixels, each twice
             const f32x4 v4 = {raw[0][e], raw[1][e], raw[2][e], raw[3][e]};
             u16x4 pc[3];
             split_bf16<3>(v4, pc);
@@ -2500,8 +2524,8 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
     };
     // a halo pixel's 2-byte stores: a channel's row starts 196 dwords behind its neighbour's (= 4 mod 32: what the 16-byte fragment reads
     // want), so the halo slots of all rows and channels fall on 16 of the 32 write banks -- 4-way at best.  With all lanes storing the
-    // SAME channel of their quad the 64 addresses fell on four to eight banks (the wave with these stores was 1.1 k cycles per sub-tile
-    // behind the others, stamped per wave); so lane's k-th store takes channel (k + (quad >> 1)) & 3 of its quad: 4 lanes per bank.
+    // SAME channel of their quad the 64 addresses would fall on four to eight banks; so lane's k-th store takes channel
+    // (k + (quad >> 1)) & 3 of its quad: 4 lanes per bank.
     struct SmallPc { unsigned lo[3], hi[3]; };                      // a halo pixel's 4 channels x 3 pieces, two halfwords per dword
     auto split_small = [&](const f32x4 v) {
         u16x4 pc[3];
@@ -2519,23 +2543,20 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int k = 0; k < 4; ++k)                              // v_perm_b32: bytes 0-3 = hi, 4-7 = lo (selector = byte numbers of the wanted halfword)
-                buf[s_dstk[u][k] + q * XQ] = (unsigned short)__builtin_amdgcn_perm(pc.lo[q], pc.hi[q], s_selk[u][k]);
+                buf[s_dstk[u][k] + q * XQ] = (unsigned short)__builtin_amdgcn_perm(pc.lo[q], pc.hi[q], s_selk[k]);
     };
-    auto store_all = [&](auto role_c, const f32x4 (&raw)[8], unsigned short* buf) {
-        constexpr int ROLE = decltype(role_c)::value;
+    auto store_all = [&](auto cfg_c, const f32x4 (&raw)[8], unsigned short* buf) {
+        constexpr int ROLE = decltype(cfg_c)::value & 3;
         if (ROLE == 3) { store_small(split_small(raw[0]), 0, buf); store_small(split_small(raw[1]), 1, buf); }
         else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) store_big(role_c, raw, e, buf);
+            for (int e = 0; e < 4; ++e) store_big(cfg_c, raw, e, buf);
         }
     };
 
     const int zoff = (wco * 32 + l32) * ZP + h * 8, xoff = XS0 + (wci * 32 + l32) * XP + h * 8;
-    // one sub-tile: its 108 MFMAs out of `cur`, the staging of the next one (registers rs, loaded a phase ago) into `nxt`, the loads
-    // of the one after that into rl.  One copy of this code per role: a wave runs ITS staging instructions between the MFMAs and
-    // nothing else, in one basic block
-    // fragments a phase starts with: dZ rows 0, 1 and X row 0 of its buffer.  They are read by the PREVIOUS phase, right behind the
-    // barrier that phase places in front of its last 18 MFMAs (row 3: registers only) -- the LDS latency at the start of a sub-tile
+    // fragments a phase starts with: the dZ rows and X row 0 of its buffer.  They are read by the PREVIOUS phase, right behind the
+    // barrier that phase places in front of its last row's MFMAs (row 3: registers only) -- the LDS latency at the start of a sub-tile
     // disappears under those MFMAs
     struct Frag { bf16x8 zf[TH][3]; i32x4 x0[3][3]; };
     auto prefetch = [&](const unsigned short* buf, Frag& f) {
@@ -2553,8 +2574,11 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
             f.x0[q][2] = *reinterpret_cast<const i32x4*>(g0 + 16);
         }
     };
-    auto phase = [&](auto role_c, int j, const f32x4 (&rs)[8], f32x4 (&rl)[8], const unsigned short* cur, unsigned short* nxt, Frag& fr) {
-        constexpr int ROLE = decltype(role_c)::value;
+    // one sub-tile: its MFMAs out of `cur`, the staging of the next one (registers rs, loaded a phase ago) into `nxt`, the loads of the
+    // one after that into rl.  One copy of this code per cfg: a wave runs ITS staging instructions between the MFMAs and nothing else,
+    // in one basic block
+    auto phase = [&](auto cfg_c, int j, const f32x4 (&rs)[8], f32x4 (&rl)[8], const unsigned short* cur, unsigned short* nxt, Frag& fr) {
+        constexpr int CFG = decltype(cfg_c)::value, ROLE = CFG & 3, PH = (CFG >> 4) & 1;
         // (halo role: split BEFORE the next loads are issued -- with the two old and the two new loads in flight together the compiler's
         //  wait in front of the split, vmcnt(1), also waited for the first NEW load: a memory latency per sub-tile, stamped per wave)
         SmallPc pc0 = {}, pc1 = {};
@@ -2565,7 +2589,7 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
             asm volatile("" : "+v"(tok) : "v"(pc0.lo[0]), "v"(pc0.lo[1]), "v"(pc0.lo[2]), "v"(pc0.hi[0]), "v"(pc0.hi[1]), "v"(pc0.hi[2]),
                                           "v"(pc1.lo[0]), "v"(pc1.lo[1]), "v"(pc1.lo[2]), "v"(pc1.hi[0]), "v"(pc1.hi[1]), "v"(pc1.hi[2]));
         }
-        issue_loads(role_c, min(j + 2, NJ - 1), j + 2 < NJ, rl, tok);
+        issue_loads(cfg_c, min(j + 2, NJ - 1), j + 2 < NJ, rl, tok);
         const unsigned short* xrow = cur + xoff;
         bf16x8 zf[TH][3];
         i32x4 xraw[2][3][3];                                        // [row parity][piece][prev | cur | next]
@@ -2593,13 +2617,13 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
                 prefetch(nxt, fr);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // staging of the next sub-tile under the 36 MFMAs of each of the two middle rows
+            // staging of the next sub-tile under the MFMAs of the two middle rows
             if (ROLE == 3) {
                 if (r == 1) store_small(pc0, 0, nxt);
                 if (r == 2) store_small(pc1, 1, nxt);
             } else {
-                if (r == 1) { store_big(role_c, rs, 0, nxt); store_big(role_c, rs, 1, nxt); }
-                if (r == 2) { store_big(role_c, rs, 2, nxt); store_big(role_c, rs, 3, nxt); }
+                if (r == 1) { store_big(cfg_c, rs, 0, nxt); store_big(cfg_c, rs, 1, nxt); }
+                if (r == 2) { store_big(cfg_c, rs, 2, nxt); store_big(cfg_c, rs, 3, nxt); }
             }
             bf16x8 xf[3][3];                                         // [kx][piece]
 #pragma unroll
@@ -2616,10 +2640,13 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
                 xf[1][q] = __builtin_bit_cast(bf16x8, curv);
                 xf[2][q] = __builtin_bit_cast(bf16x8, right);
             }
+            int n_mfma = 0;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int py = r - ky;
                 if (py < 0 || py >= TH) continue;
+                if (CO32 && py != PH) continue;
+                n_mfma += 18;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -2628,37 +2655,44 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
                         for (int qa = 0; qa <= ord; ++qa)
                             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[py][qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
             }
-            // one MFMA, then up to four of the staging's vector / LDS-store instructions in the cycles it leaves free
+            // one MFMA, then up to WG_FILL of the staging's vector / LDS-store instructions in the cycles it leaves free
 #pragma unroll
-            for (int i = 0; i < (r == 0 || r == 3 ? 18 : 36); ++i) {
+            for (int i = 0; i < n_mfma; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x202, WG_FILL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x202, CO32 ? WG_FILL + 2 : WG_FILL, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto run = [&](auto role_c) {
+    auto run = [&](auto cfg_c) {
         f32x4 ra[8], rb[8];
         unsigned short* buf0 = lds16;
         unsigned short* buf1 = lds16 + BUF;
-        issue_loads(role_c, 0, true, ra);
-        issue_loads(role_c, 1, true, rb);
-        store_all(role_c, ra, buf0);
+        issue_loads(cfg_c, 0, true, ra);
+        issue_loads(cfg_c, 1, true, rb);
+        store_all(cfg_c, ra, buf0);
         __syncthreads();
         Frag fr;
         prefetch(buf0, fr);
         for (int j = 0; j < NJ; j += 2) {
-            phase(role_c, j, rb, ra, buf0, buf1, fr);
-            phase(role_c, j + 1, ra, rb, buf1, buf0, fr);
+            phase(cfg_c, j, rb, ra, buf0, buf1, fr);
+            phase(cfg_c, j + 1, ra, rb, buf1, buf0, fr);
         }
     };
     if (NJ > 0) {
-        if (role == 0) run(std::integral_constant<int, 0>{});
-        else if (role == 3) run(std::integral_constant<int, 3>{});
-        else run(std::integral_constant<int, 1>{});
+        // the wave's code copy.  CO32: output row ph = wave & 1
+#define WG_RUN(CFG) run(std::integral_constant<int, (CFG)>{})
+        constexpr int P1 = CO32 ? 16 : 0;                           // cfg bit 4 of the odd waves
+        if (role == 0) WG_RUN(0);
+        else if (role == 1) { if (xs[0].up) WG_RUN(1 | 4 | P1); else WG_RUN(1 | P1); }
+        else if (role == 2) { if (xs[1].up) WG_RUN(1 | 4); else WG_RUN(1); }
+        else if (xs[1].up) WG_RUN(3 | 4 | 8 | P1);
+        else if (xs[0].up) WG_RUN(3 | 4 | P1);
+        else WG_RUN(3 | P1);
+#undef WG_RUN
     }
     // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 31, row (co) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float* dst = part + (size_t)blk * p.Co * 9 * p.Ct;
+    float* dst = part + (size_t)(CO32 ? blk * 2 + (wave & 1) : blk) * p.Co * 9 * p.Ct;
     const int ci = c_base + wci * 32 + l32;
     if (ci < p.Ct) {
 #pragma unroll
@@ -2686,10 +2720,8 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     const bool one_src = c_base >= p.C0 || p.C1 == 0 || c_base + 64 <= p.C0, up = p.up0 && c_base < p.C0;
     const bool fast = p.fast && one_src && !up;
 #ifndef CODEPS_WG_NODBUF                                             // (variant builds: the A/B of the double-buffered body)
-    if (!CO32 && p.fast && one_src) {
-        if (up) wgrad_halo64d_body<true>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
-        else wgrad_halo64d_body<false>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
-    } else
+    // double-buffered body: each 32-channel half of the chunk in one source
+    if (p.fast && (one_src || c_base + 32 == p.C0)) { wgrad_halo64d_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16); return; }
 #endif
     if (fast) wgrad_halo64s_body<CO32, true>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
     else wgrad_halo64s_body<CO32, false>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
@@ -3862,7 +3894,7 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
             if (wgrad_split_on()) {
                 // 4 x 16 tiles: dZs + Xs (halfwords); the double-buffered body: two 2 x 16 sub-tiles
                 constexpr size_t lds_s = (size_t)64 * ((3 * 64 + 8) + (3 * 6 * 32 + 8)) * 2, lds_d = (size_t)2 * (64 * ((3 * 32 + 8) + (3 * 4 * 32 + 8))) * 2;
-                const size_t lds = sp.co32 ? lds_s : std::max(lds_s, lds_d);
+                const size_t lds = std::max(lds_s, lds_d);
                 if (sp.co32) {
                     g_last_kernel = "wgrad_halo64s_kernel<co32>";
                     codeps_allow_lds((const void*)wgrad_halo64s_kernel<true>, 160 * 1024, "wgrad_halo64s_kernel<co32>");

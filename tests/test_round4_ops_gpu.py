@@ -104,6 +104,9 @@ def test_panoptic_fusion_reads_strided_maps_in_place():
     (1, 32, 64, 64, 64, True, 64),        # chunk 0 from the up-sampled source (each source pixel twice), chunk 1 from the skip
     (1, 16, 32, 64, 48, False, 96),       # concat without up-sampling, ragged skip width, co 96 (second co tile half empty)
     (1, 18, 32, 64, 0, False, 64),        # H % 4 != 0 -> the generic body (same kernel name, same bound)
+    (1, 16, 32, 32, 32, True, 64),        # ONE chunk: half 0 from the up-sampled source, half 1 from the skip (per-wave sources)
+    (2, 16, 32, 64, 0, False, 32),        # <= 32 output channels: the CO32 form of the double-buffered body (waves split the rows)
+    (1, 32, 32, 32, 64, True, 32),        # CO32 + a chunk split at 32 (the decoders' half-resolution stage) + a half-empty chunk
 ])
 def test_weight_gradient_fast_bodies_against_float64(case):
     """wgrad_halo64s_kernel picks its body per block (FAST: buffer loads with constant per-thread offsets, double-buffered 2 x 16
