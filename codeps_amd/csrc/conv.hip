@@ -2878,6 +2878,219 @@ __global__ __launch_bounds__(256) void wgrad_stem74s_kernel(WgradP p, int tiles_
     }
 }
 
+// wgrad_stem74s_kernel, double-buffered like wgrad_halo64d_body (maps of whole 4 x 16 tiles, no x padding -- the double-pixel stem
+// layout carries its zero columns): LDS holds two tiles (2 x 55 KB); while a wave runs the MFMAs of tile t it splits and stores tile
+// t + 1 between them and then issues the loads of tile t + 2; addresses are (scalar tile origin) + (per-thread constant), row padding
+// is the range check of the buffer resource.  Roles: waves 0, 1 stage dZ (128 tasks of 8 pixels x 4 channels), wave 2 the first 64 of
+// the 156 X tasks; wave 3 -- tap row 6 only, half the MFMAs -- the other 92 (two per lane).  One code copy per role.
+__global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_x, int tiles_y, int tiles_per_block,
+                                                            const float* __restrict__ x0, const float* __restrict__ dz, float* __restrict__ part) {
+    constexpr int TH = 4, TW = 16, KH = 7, KW = 4, XH = (TH - 1) * 2 + KH, PIX = TH * TW, XROW = 24;
+    constexpr int ZP = 3 * PIX + 8;                    // halfwords per dZ channel
+    constexpr int XQ = XH * XROW, XP = 3 * XQ;         // halfwords per X piece / channel (468 dwords: odd multiple of 4 -> conflict-free)
+    constexpr int XS0 = 64 * ZP, BUF = XS0 + 16 * XP;  // halfwords per buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = blockIdx.x;
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    const int NT = t_end - t_beg;
+
+    f32x4 acc[4][2][KW];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < KW; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-thread constants of the (up to two) tasks: byte offset from the tile origin, the X row (relative to 2 ty0 - pad), LDS halfword
+    int k_off[2] = {0, 0}, k_row[2] = {0, 0}, k_dst[2] = {0, 0};
+    bool k_ok[2] = {false, false};
+    if (wave < 2) {
+        const int bt = tid, c4 = (bt & 3) | ((bt >> 5) << 2), grp = (bt >> 2) & 7;
+        k_off[0] = (((grp >> 1) * p.Wo + (grp & 1) * 8) * p.Co + c4 * 4) * 4;
+        k_ok[0] = true;
+        k_dst[0] = (c4 * 4) * ZP + grp * 8;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = (wave == 2 ? 0 : 64) + lane + 64 * u;
+            if ((wave == 2 && u == 1) || t >= 156) continue;
+            const int c4 = t & 3, grp = t >> 2, row = grp / 3, g = grp % 3;
+            k_row[u] = row;
+            k_off[u] = ((row * p.W + g * 8) * 16 + c4 * 4) * 4;
+            k_ok[u] = true;
+            k_dst[u] = XS0 + (c4 * 4) * XP + row * XROW + g * 8;
+        }
+        if (!k_ok[1]) k_dst[1] = k_dst[0];                          // (no second task: its zeros go where the first task's data follows)
+    }
+    const size_t zimg = (size_t)p.Ho * p.Wo * p.Co, ximg = (size_t)p.H * p.W * 16;
+    // ROLE 0: dZ task, 1: one X task, 2: two X tasks (wave 3)
+    auto issue_loads = [&](auto role_c, int u, int t, bool valid, f32x4 (&raw)[8]) {
+        constexpr int ROLE = decltype(role_c)::value;
+        const int tile = t_beg + t;                                                            // (all scalar)
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        if (ROLE == 0) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(dz + (size_t)b * zimg, zimg * 4);
+            const unsigned vo = valid ? (unsigned)((ty0 * p.Wo + tx0) * p.Co * 4 + k_off[0]) : GATHER_OOB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, i * p.Co * 4, 0));
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(x0 + (size_t)b * ximg, ximg * 4);
+            const int iy0 = ty0 * 2 - p.pad;                        // rows above / below the image: zeros (the columns carry their own padding)
+            const unsigned vo = (valid && k_ok[u] && (unsigned)(iy0 + k_row[u]) < (unsigned)p.H) ? (unsigned)((iy0 * p.W + tx0) * 64 + k_off[u]) : GATHER_OOB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, i * 64, 0));
+        }
+    };
+    auto store_big = [&](auto role_c, int u, const f32x4 (&raw)[8], int e, unsigned short* buf) {
+        constexpr int ROLE = decltype(role_c)::value;
+        constexpr int cs = ROLE == 0 ? ZP : XP, qs = ROLE == 0 ? PIX : XQ;
+        const f32x4 lo4 = {raw[0][e], raw[1][e], raw[2][e], raw[3][e]};
+        const f32x4 hi4 = {raw[4][e], raw[5][e], raw[6][e], raw[7][e]};
+        u16x4 lo[3], hi[3];
+        split_bf16<3>(lo4, lo);
+        split_bf16<3>(hi4, hi);
+        // (lanes 28-63 of wave 3's second task have no task: they hold zeros and store them where the first task of the same lane
+        //  stores -- before it, in program order -- so the slot ends with the real data)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(buf + k_dst[u] + e * cs + q * qs) = pack8(lo[q], hi[q]);
+    };
+    const int ky0 = wave * 2;
+    // one tile: its MFMAs out of `cur`; between them the staging of the next tile (registers r0 / r1, loaded a phase ago) into `nxt`,
+    // then the loads of the tile after that
+    auto phase = [&](auto role_c, int t, f32x4 (&r0)[8], f32x4 (&r1)[8], const unsigned short* cur, unsigned short* nxt) {
+        constexpr int ROLE = decltype(role_c)::value, NKYL = ROLE == 2 ? 1 : 2;
+        const unsigned short* dZs = cur;
+        const unsigned short* Xs = cur + XS0;
+        i32x4 xraw[2][3][2];                                        // [region parity][piece][cur | next]
+        auto read_x = [&](int ks, int kyl, int par) {
+            const int r = 2 * (2 * ks + (kg >> 1)) + ky0 + kyl;     // input row of this lane's 8 pixels through tap row ky
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned short* g0 = Xs + l16 * XP + q * XQ + r * XROW + (kg & 1) * 8;
+                xraw[par][q][0] = *reinterpret_cast<const i32x4*>(g0);
+                xraw[par][q][1] = *reinterpret_cast<const i32x4*>(g0 + 8);
+            }
+        };
+        read_x(0, 0, 0);
+        int region = 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                           // K-step = 32 output pixels = tile rows 2 ks, 2 ks + 1
+            bf16x8 zf[4][3];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    zf[a][q] = *reinterpret_cast<const bf16x8*>(dZs + (a * 16 + l16) * ZP + q * PIX + ks * 32 + kg * 8);
+#pragma unroll
+            for (int kyl = 0; kyl < NKYL; ++kyl, ++region) {
+                const int par = region & 1;
+                // the next region's X fragments, one region ahead
+                if (kyl + 1 < NKYL) read_x(ks, kyl + 1, par ^ 1);
+                else if (ks == 0) read_x(1, 0, par ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // staging: regions 0, 1 (wave 3: its two regions) split and store; the loads of the tile after the next follow the last split
+                if (ROLE == 2) {
+                    if (region == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) store_big(role_c, 1, r1, e, nxt);      // (second task first: see store_big)
+                    } else {
+                        issue_loads(role_c, 1, min(t + 2, NT - 1), t + 2 < NT, r1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) store_big(role_c, 0, r0, e, nxt);
+                    }
+                } else {
+                    if (region == 0) { store_big(role_c, 0, r0, 0, nxt); store_big(role_c, 0, r0, 1, nxt); }
+                    if (region == 1) { store_big(role_c, 0, r0, 2, nxt); store_big(role_c, 0, r0, 3, nxt); }
+                    if (region == 2) issue_loads(role_c, 0, min(t + 2, NT - 1), t + 2 < NT, r0);
+                }
+                bf16x8 xf[KW][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const i32x4 cur4 = xraw[par][q][0], next = xraw[par][q][1];
+                    i32x4 s1, s2, s3;
+                    s2[0] = cur4[1]; s2[1] = cur4[2]; s2[2] = cur4[3]; s2[3] = next[0];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) s1[i] = (int)__builtin_amdgcn_alignbit((unsigned)cur4[i + 1], (unsigned)cur4[i], 16);
+                    s1[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)cur4[3], 16);
+                    s3[0] = (int)__builtin_amdgcn_alignbit((unsigned)cur4[2], (unsigned)cur4[1], 16);
+                    s3[1] = (int)__builtin_amdgcn_alignbit((unsigned)cur4[3], (unsigned)cur4[2], 16);
+                    s3[2] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)cur4[3], 16);
+                    s3[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[1], (unsigned)next[0], 16);
+                    xf[0][q] = __builtin_bit_cast(bf16x8, cur4);
+                    xf[1][q] = __builtin_bit_cast(bf16x8, s1);
+                    xf[2][q] = __builtin_bit_cast(bf16x8, s2);
+                    xf[3][q] = __builtin_bit_cast(bf16x8, s3);
+                }
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                    for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                        for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+                                acc[a][kyl][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[a][qa], xf[kx][ord - qa], acc[a][kyl][kx], 0, 0, 0);
+                // 96 MFMAs of 16 cycles: two of them, then up to three of the staging's vector / LDS-store instructions
+#pragma unroll
+                for (int i = 0; i < 48; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x202, ROLE == 2 ? 5 : 3, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ROLE == 2) issue_loads(role_c, 0, min(t + 2, NT - 1), t + 2 < NT, r0);
+        __syncthreads();                                            // `cur` is read, `nxt` is written
+    };
+    auto run = [&](auto role_c) {
+        constexpr int ROLE = decltype(role_c)::value;
+        f32x4 r0[8], r1[8];
+        unsigned short* buf0 = lds16;
+        unsigned short* buf1 = lds16 + BUF;
+        issue_loads(role_c, 0, 0, true, r0);
+        if (ROLE == 2) issue_loads(role_c, 1, 0, true, r1);
+        if (ROLE == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_big(role_c, 1, r1, e, buf0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_big(role_c, 0, r0, e, buf0);
+        issue_loads(role_c, 0, min(1, NT - 1), 1 < NT, r0);
+        if (ROLE == 2) issue_loads(role_c, 1, min(1, NT - 1), 1 < NT, r1);
+        __syncthreads();
+        for (int t = 0; t < NT; t += 2) {
+            phase(role_c, t, r0, r1, buf0, buf1);
+            if (t + 1 < NT) phase(role_c, t + 1, r0, r1, buf1, buf0);
+        }
+    };
+    if (NT > 0) {
+        if (wave < 2) run(std::integral_constant<int, 0>{});
+        else if (wave == 2) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+    }
+    // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + reg
+    float* dst = part + (size_t)blk * p.Co * (KH * KW) * p.Ct;
+#pragma unroll
+    for (int kyl = 0; kyl < 2; ++kyl) {
+        const int ky = wave * 2 + kyl;
+        if (ky >= KH) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = a * 16 + kg * 4 + r;
+                    dst[((size_t)co * (KH * KW) + ky * KW + kx) * p.Ct + l16] = acc[a][kyl][kx][r];
+                }
+    }
+}
+
 // ---------------------------------------------------------------------------------- halo-tile wgrad, 64 x 64 channel tiles
 // 3x3 / stride 1 weight gradient for layers with >= 48 channels on both sides.  A block owns a (64 output channels) x
 // (64 input channels) tile of dW for all 9 taps and walks 4x16-pixel output tiles: the dZ tile and the X tile WITH its
@@ -3914,6 +4127,12 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
                                    sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
             else if (sp.co_groups == 1) {              // ... on the bf16 matrix cores (3-piece operands)
                 g_last_kernel = "wgrad_stem74s_kernel";
+                static const int stem_dbuf = getenv("CODEPS_STEM_DBUF") ? atoi(getenv("CODEPS_STEM_DBUF")) : 1;        // tuning experiments only
+                if (stem_dbuf && p.fast && d->pad_w == 0 && d->in_h == 2 * d->out_h) {          // whole tiles, rows padded by the range check
+                    constexpr size_t lds = (size_t)2 * (64 * (3 * 64 + 8) + 16 * 3 * 13 * 24) * 2;
+                    codeps_allow_lds((const void*)wgrad_stem74d_kernel, 160 * 1024, "wgrad_stem74d_kernel");
+                    hipLaunchKernelGGL(wgrad_stem74d_kernel, dim3(g), dim3(256), lds, st, p, sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, dz, part);
+                } else
                 hipLaunchKernelGGL(wgrad_stem74s_kernel, dim3(g), dim3(256), 0, st, p, sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, dz, part);
             } else                                       // double-pixel stem: 7 x 4 taps of 16 (2 pixels x 8 channels), stride (2, 1)
                 hipLaunchKernelGGL((wgrad_small_kernel<1, 1, 7, 4, 2, 1, 4, 16>), dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks,

@@ -144,3 +144,35 @@ def test_weight_gradient_fast_bodies_against_float64(case):
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
     e, t = l2(outs[0], dw64), l2(dw32, dw64)
     assert e <= 3 * t + 1e-9, f"{case}: {e:.3e} vs torch fp32 {t:.3e}"
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 256), (1, 72, 96), (2, 8, 32)])
+def test_stem_weight_gradient_double_buffered_against_float64(shape):
+    """ResNet conv1 (7x7 / 2 / 3; models/resnet_encoder.py:115) in the double-pixel layout: the double-buffered weight gradient
+    (`wgrad_stem74d_kernel`, whole 4 x 16 tiles) against float64; block tile counts even, odd (72 x 96: 27 tiles in blocks of 8) and
+    one (8 x 32); bit-identical from launch to launch."""
+    import torch.nn.functional as TF
+    from codeps_amd import functional as F
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(b, 6, h, w, generator=g)
+    wt = torch.randn(64, 6, 7, 7, generator=g) * (2.0 / (49 * 6)) ** 0.5
+    gy = torch.randn(b, 64, h // 2, w // 2, generator=g)
+
+    def ref(dtype):
+        ww = wt.to(dtype).requires_grad_(True)
+        TF.conv2d(x.to(dtype), ww, stride=2, padding=3).backward(gy.to(dtype))
+        return ww.grad
+
+    dw64, dw32 = ref(torch.float64), ref(torch.float32)
+    frames = [x[:, i:i + 3].contiguous().to(DEV) for i in (0, 3)]
+    outs = []
+    for _ in range(3):
+        ww = wt.to(DEV).detach().requires_grad_(True)
+        y = F.stem_conv2d(F.images_to_nhwc(frames, 8, F.STEM_XPAD), ww)
+        y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+        outs.append(ww.grad.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
+    e, t = l2(outs[0], dw64), l2(dw32, dw64)
+    assert e <= 3 * t + 1e-9, f"{shape}: {e:.3e} vs torch fp32 {t:.3e}"
