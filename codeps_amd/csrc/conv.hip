@@ -1465,6 +1465,138 @@ __global__ __launch_bounds__(384) void conv_halo3p_kernel(ConvP p, const float* 
 // both operands go global -> VGPR directly (lane (l&15, q=l>>4) loads 16 B = k 4q..4q+3 of its own pixel row / weight
 // row for each 16-deep k group; 4 lanes cover one 64-B run), software-pipelined one K-step ahead in registers.
 // No LDS and no barrier in the main loop; waves run independently (64 rows = 4 row tiles per wave).
+// Forward of the double-pixel stem (ResNet conv1 as 7 x 4 taps of 16 channels, stride (2, 1), padding (3, 0), 64 output channels:
+// codeps_amd.functional.stem_conv2d) as a halo-tile kernel.  The generic kernel runs it in 28 K-steps of one tap each and stages
+// a 128-row operand tile for every one of them -- 100 TFLOP/s; here an 8 x 32 output tile's input (21 rows x 35 double pixels) is
+// split and stored in LDS ONCE, as [row][double pixel][piece][16 ch] at a 112-byte pitch (28 dwords: conflict-free 16-byte fragment
+// reads), and every tap reads its fragments from that image at a shifted address.  The pre-split weights of one tap row (4 taps x 64
+// channels, 25 KB) ride in a two-slot ring filled through registers one tap row ahead.  Eight waves, two per SIMD (one hides the
+// other's fragment-read and barrier latencies: with four waves of two rows each the kernel measured 490 us, 50 % of its MFMA time);
+// wave w owns output row w of the tile (one 32-pixel MFMA row tile x two 32-channel column tiles): 48 MFMAs per tap row against
+// 12 + 24 fragment reads.  Blocks walk `tiles_per_block` tiles; the next tile's loads are issued under the last tap rows of the
+// current one.
+__global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x, int tiles_y, int tiles_per_block, const float* __restrict__ x,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ y) {
+    constexpr int TH = 8, TW = 32, KH = 7, KW = 4, XH = 2 * TH + KH - 2, XW = TW + KW - 1, PIT = 56;      // PIT: halfwords per double pixel
+    constexpr int WROW = 200;                          // halfwords per output channel and tap row: [2 groups][3 pieces][32] + pad (100 dwords)
+    constexpr int NT = 512, NTASK = XH * XW * 4, NRAW = (NTASK + NT - 1) / NT, NWSEG = 64 * 24 / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    unsigned short* Xs = lds16;                        // [XH][XW][PIT]
+    unsigned short* Ws = lds16 + XH * XW * PIT;        // [2][64][WROW]
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blockIdx.x * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    const size_t ximg = (size_t)p.H * p.W * 16;
+    const char* w3 = static_cast<const char*>(p.w3);
+
+    // input tasks: (row r, double pixel c, channel quad c4); thread tid owns tasks tid + 512 k
+    int t_off[NRAW], t_row[NRAW], t_dst[NRAW];
+#pragma unroll
+    for (int k = 0; k < NRAW; ++k) {
+        const int t = tid + NT * k, c4 = t & 3, pc = t >> 2, c = pc % XW, r = pc / XW;
+        t_row[k] = t < NTASK ? r : 1 << 20;            // (a row no image has)
+        t_off[k] = ((r * p.W + c) * 16 + c4 * 4) * 4;
+        t_dst[k] = (r * XW + c) * PIT + c4 * 4;
+    }
+    f32x4 raw[NRAW];
+    auto load_x = [&](int tile, bool valid) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);             // (scalar)
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(x + (size_t)b * ximg, ximg * 4);
+        const int iy0 = 2 * ty0 - p.pad, org = (iy0 * p.W + tx0) * 64;
+#pragma unroll
+        for (int k = 0; k < NRAW; ++k) {
+            const unsigned vo = (valid && (unsigned)(iy0 + t_row[k]) < (unsigned)p.H) ? (unsigned)(org + t_off[k]) : GATHER_OOB;
+            raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int k = 0; k < NRAW; ++k) {
+            if (tid + NT * k >= NTASK) continue;
+            u16x4 pc[3];
+            split_bf16<3>(raw[k], pc);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u16x4*>(Xs + t_dst[k] + q * 16) = pc[q];
+        }
+    };
+    // weights of tap row ky: per output channel 384 contiguous bytes of the pre-split pack ([co][14 groups][3 pieces][32 bf16], groups 2 ky, 2 ky + 1)
+    i32x4 wreg[NWSEG];
+    auto load_w = [&](int ky) {
+#pragma unroll
+        for (int i = 0; i < NWSEG; ++i) {
+            const int seg = tid + NT * i, co = seg / 24, s16 = seg % 24;
+            wreg[i] = *reinterpret_cast<const i32x4*>(w3 + ((size_t)co * 14 + 2 * ky) * 192 + s16 * 16);
+        }
+    };
+    auto store_w = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < NWSEG; ++i) {
+            const int seg = tid + NT * i, co = seg / 24, s16 = seg % 24;
+            *reinterpret_cast<i32x4*>(Ws + (slot * 64 + co) * WROW + s16 * 8) = wreg[i];
+        }
+    };
+
+    if (t_beg < t_end) load_x(t_beg, true);
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        load_w(0);
+        __syncthreads();                                            // the previous tile's fragment reads are done
+        store_x();
+        store_w(0);
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            if (ky + 1 < KH) load_w(ky + 1);
+            if (ky == KH - 3) load_x(min(tile + 1, t_end - 1), tile + 1 < t_end);       // (lands under the last tap rows)
+            const unsigned short* W = Ws + (ky & 1) * 64 * WROW;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                bf16x8 bw[2][3];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        bw[nt][q] = *reinterpret_cast<const bf16x8*>(W + (nt * 32 + l32) * WROW + ((kx >> 1) * 3 + q) * 32 + (kx & 1) * 16 + h * 8);
+                const int row = 2 * wave + ky;
+                bf16x8 a[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(Xs + (row * XW + l32 + kx) * PIT + q * 16 + h * 8);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                        for (int qa = 0; qa <= ord; ++qa)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[qa], bw[nt][ord - qa], acc[nt], 0, 0, 0);
+            }
+            if (ky + 1 < KH) {
+                store_w((ky + 1) & 1);                              // the slot tap row ky - 1 was read from: every wave is past the barrier behind it
+                __syncthreads();
+            }
+        }
+        // epilogue: C layout of the 32 x 32 tile: column (channel) = lane & 31, row (pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = nt * 32 + l32;
+            const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+            float* orow = y + (((size_t)b * p.Ho + ty0 + wave) * p.Wo + tx0) * 64 + co;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+                orow[(size_t)m * 64] = apply_act(acc[nt][e] * sc + sh, p.act);
+            }
+        }
+    }
+}
+
 template <int MODE, int BK>
 __global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                            const float* __restrict__ wq, const float* __restrict__ scale,
@@ -3956,6 +4088,20 @@ extern "C" int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, con
     if (workspace && codeps_conv2d_fwd_workspace_bytes(d) > 0) { p.part = (float*)workspace; p.part_bytes = workspace_bytes; }
     p.w3 = w_fwd + (size_t)d->out_c * d->kh * d->kw * (d->c0 + d->c1);         // behind the fp32 pack (codeps_conv2d_packed_weight_floats)
     const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
+    static const int stem_halo = getenv("CODEPS_STEM_HALO") ? atoi(getenv("CODEPS_STEM_HALO")) : 1;                  // tuning experiments only
+    if (stem_halo && d->kh == 7 && d->kw == 4 && d->stride == 2 && d->stride_w == 1 && d->pad == 3 && d->pad_w == 0 && d->c0 == 16 && d->c1 == 0 &&
+        !d->up0 && d->out_c == 64 && d->pix_pitch == 0 && d->pad_mode == 0 && !residual && split_pieces() == 3 && d->out_h % 8 == 0 &&
+        d->out_w % 32 == 0 && d->in_h == 2 * d->out_h && d->in_w >= d->out_w + 3 && (size_t)d->in_h * d->in_w * 64 < ((size_t)1 << 31)) {
+        // the double-pixel stem (functional.stem_conv2d) on whole 8 x 32 tiles: the halo-tile kernel
+        const int tiles_x = d->out_w / 32, tiles_y = d->out_h / 8, total = d->batch * tiles_x * tiles_y;
+        const int tpb = std::max(1, cdiv(total, 256 * std::max(1, total / (256 * 12))));     // one block per CU and round, <= ~12 tiles each
+        constexpr size_t lds = ((size_t)21 * 35 * 56 + 2 * 64 * 200) * 2;
+        g_last_kernel = "conv_stem74f_kernel";
+        codeps_allow_lds((const void*)conv_stem74f_kernel, 160 * 1024, "conv_stem74f_kernel");
+        hipLaunchKernelGGL(conv_stem74f_kernel, dim3(cdiv(total, tpb)), dim3(512), lds, (hipStream_t)stream, p, tiles_x, tiles_y, tpb, x0, scale, shift, y);
+        CODEPS_CHECK_LAUNCH("conv_stem74f_kernel");
+        return CODEPS_OK;
+    }
     dispatch_igemm<MODE_FWD>(p, gran, x0, x1, w_fwd, scale, shift, residual, y, (hipStream_t)stream);
     CODEPS_CHECK_LAUNCH("conv_igemm_kernel<fwd>");
     return CODEPS_OK;

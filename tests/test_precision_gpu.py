@@ -180,7 +180,8 @@ def test_halo3_with_fused_upsample_and_concat(kind, co, kernel):
 @pytest.mark.parametrize("kind", ["normal", "wide", "cancel"])
 @pytest.mark.parametrize("in_ch", [3, 6])
 def test_split_stem_forward_and_weight_gradient(in_ch, kind):
-    """ResNet conv1 (7x7 / 2 / 3) in its double-pixel form: split forward with 16-channel K-steps and `wgrad_stem74s_kernel`."""
+    """ResNet conv1 (7x7 / 2 / 3) in its double-pixel form: the halo-tile forward (`conv_stem74f_kernel`, whole 8 x 32 tiles) and the
+    weight gradient `wgrad_stem74s_kernel` (whole 4 x 16 tiles: its double-buffered form)."""
     F = _F()
     b, h, w_ = 4, 128, 256
     x, wt, g = _inputs(kind, (b, in_ch, h, w_), (64, in_ch, 7, 7), 91 + in_ch)
@@ -198,7 +199,7 @@ def test_split_stem_forward_and_weight_gradient(in_ch, kind):
         assert _last() == k_wg, _last()
         return l2(nchw(y.detach(), 64), y64), l2(ww.grad.cpu(), dw64)
 
-    got = run("conv_igemm_kernel<split3,bk16>", "wgrad_stem74s_kernel")
+    got = run("conv_stem74f_kernel", "wgrad_stem74s_kernel")
     with _arith(0):
         mfma = run("conv_igemm_kernel<f32>", "wgrad_small_kernel")
     for name, e, t, m in zip(("forward", "d weight"), got, (l2(y32, y64), l2(dw32, dw64)), mfma):
