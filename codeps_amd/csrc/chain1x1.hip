@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
             for (int i = 0; i < NDMA; ++i) {
                 const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + ldsdst[i]);
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(offR[i]), "s"(rsW3), "s"(soff) : "memory", "m0");
+                             :: "s"(dst), "v"(offR[i]), "s"(rsW3), "s"(soff) : "memory");
             }
         } else {
             const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 32 * W2ROW);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
             for (int i = 0; i < NDMA; ++i) {
                 const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + ldsdst[i]);
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(offE[i]), "s"(rsW2), "s"(soff) : "memory", "m0");
+                             :: "s"(dst), "v"(offE[i]), "s"(rsW2), "s"(soff) : "memory");
             }
         }
     };

@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
         for (int i = 0; i < BPW; ++i) {
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(bs_lds + slot * BN * LDK * 4 + bins[i]);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(dst), "v"(boff[i]), "s"(rsBv), "s"(koff) : "memory", "m0");
+                         :: "s"(dst), "v"(boff[i]), "s"(rsBv), "s"(koff) : "memory");
         }
     };
 
@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(384) void conv_halo3p_kernel(ConvP p, const float* 
             for (int i = 0; i < BPW; ++i) {
                 const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(bs_lds + (g & 3) * BN * LDK * 4 + bins[i]);
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(boff[i]), "s"(rsBv), "s"(koff) : "memory", "m0");
+                             :: "s"(dst), "v"(boff[i]), "s"(rsBv), "s"(koff) : "memory");
             }
         };
         // The activation loads are inline assembly too: every vector-memory operation of these waves is then counted by hand (they

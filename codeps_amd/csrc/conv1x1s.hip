@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void conv1x1s_kernel(C1P p, const unsigned sho
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds_base + slot * STAGE + ins * 1024);
             const i32x4 rs = ins >= AINS ? rsB : rsA;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(dst), "v"(goff[i]), "s"(rs), "s"(koff) : "memory", "m0");
+                         :: "s"(dst), "v"(goff[i]), "s"(rs), "s"(koff) : "memory");
         }
     };
 

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void feed_kernel(const char* __restrict__ src,
                 if (i < nl) {
                     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(lds_base + buf * span + (i * 4 + wave) * 1024);
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                                 :: "s"(dst), "v"((unsigned)(lane * 16)), "s"(rs), "s"(g0 + (i * 4 + wave) * 1024) : "memory", "m0");
+                                 :: "s"(dst), "v"((unsigned)(lane * 16)), "s"(rs), "s"(g0 + (i * 4 + wave) * 1024) : "memory");
                 }
         }
         pos = (pos + span * 13u) % (window_bytes - span);
