@@ -3223,6 +3223,224 @@ __global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_
     }
 }
 
+// 3 x 3 / STRIDE 2 weight gradient (the first convolution of ResNet-18/34 stages 2-4: models/resnet_encoder.py:115-126 ->
+// torchvision BasicBlock) on the bf16 matrix cores, double-buffered like wgrad_halo64d_body.  Through tap (ky, kx) output pixel
+// (oy, ox) meets input pixel (2 oy + ky - 1, 2 ox + kx - 1): consecutive output pixels read every SECOND input column, so the input
+// columns are de-interleaved by parity while they are staged -- an X row in LDS is [E: 16 even columns | O: halo, 16 odd columns] --
+// and the 8-pixel fragment of tap kx is a contiguous 16-byte read again: kx = 1 reads E, kx = 2 reads O, kx = 0 reads O one slot to
+// the left (v_alignbit with the preceding group, as in the stride-1 kernels).  A 2 x 16 output sub-tile needs 5 input rows of 33
+// columns: with 64 input channels that is 79 KB per buffer, so a block takes 32 input channels x 64 output channels (two buffers of
+// 52 KB) and its four waves are (co tile) x (output row of the sub-tile): 54 MFMAs per wave and sub-tile.  Staging roles: wave 0 dZ (64
+// tasks of 8 pixels x 4 channels), waves 1-3 the 160 X tasks (8 input pixels x 4 channels: four even + four odd, two 8-byte stores per
+// channel and piece), wave 3 also the 40 halo pixels (column -1).  Until this kernel these layers ran on the f32 MFMA at 84 TFLOP/s.
+__global__ __launch_bounds__(256) void wgrad_s2_halo_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
+                                                            const float* __restrict__ x0, const float* __restrict__ dz, float* __restrict__ part) {
+    constexpr int TH = 2, TW = 16, XR = 5, PIX = TH * TW, XROW = 40;
+    constexpr int ZP = 3 * PIX + 8;                    // halfwords per dZ channel (104)
+    constexpr int XQ = XR * XROW, XP = 3 * XQ + 16;    // halfwords per X piece / per X channel (616: 308 dwords = 4 x 77, conflict-free 16-byte reads)
+    constexpr int XS0 = 64 * ZP, BUF = XS0 + 32 * XP;  // halfwords per buffer: [64][ZP] dZ, [32][XP] X
+    constexpr int OOFF = 16;                           // the O plane of a row starts here: slot OOFF + 7 = column -1, OOFF + 8 + i = column 2 i + 1
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave & 1, ph = wave >> 1;          // this wave's 32-row co tile and output row of a sub-tile
+    const int co_base = blockIdx.y * 64;
+    const int chunk = blockIdx.x % ci_chunks, blk = blockIdx.x / ci_chunks;
+    const int c_base = chunk * 32;
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    const int NJ = 2 * (t_end - t_beg);
+    const int xcs = p.C0;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-thread constants of the big task (dZ: wave 0; X: waves 1-3, task t = 64 (wave - 1) + lane < 160) and of wave 3's halo task
+    int b_off = 0, b_row = 0, b_dst = 0;
+    bool b_ok = false;
+    if (wave == 0) {
+        const int c4 = (lane & 3) | ((lane >> 4) << 2), grp = (lane >> 2) & 3;
+        b_off = (((grp >> 1) * p.Wo + (grp & 1) * 8) * p.Co + co_base + c4 * 4) * 4;
+        b_ok = co_base + c4 * 4 < p.Co;
+        b_dst = (c4 * 4) * ZP + grp * 8;
+    } else {
+        // (wave 3 holds tasks 128-159 only: its upper 32 lanes repeat the lower ones -- same loads, same stores, same data)
+        const int t = wave == 3 ? 128 + (lane & 31) : 64 * (wave - 1) + lane, c4 = t & 7, g = (t >> 3) & 3, r = t >> 5;   // quad fastest: 128 contiguous bytes per pixel
+        b_row = r - 1;
+        b_off = ((b_row * p.W + g * 8) * xcs + c_base + c4 * 4) * 4;
+        b_ok = c_base + c4 * 4 < xcs;
+        b_dst = XS0 + (c4 * 4) * XP + r * XROW + g * 4;                                        // E slot of its four even pixels; O: + OOFF + 8
+    }
+    int s_off = 0, s_row = 0, s_dst = 0;
+    bool s_ok = false;
+    if (wave == 3) {
+        const int sl = lane % 40, c4 = sl & 7, r = sl >> 3;          // 40 halo tasks; lanes 40-63 repeat lanes 0-23
+        s_row = r - 1;
+        s_off = ((s_row * p.W - 1) * xcs + c_base + c4 * 4) * 4;
+        s_ok = c_base + c4 * 4 < xcs;
+        s_dst = XS0 + (c4 * 4) * XP + r * XROW + OOFF + 7;
+    }
+    const size_t zimg = (size_t)p.Ho * p.Wo * p.Co, ximg = (size_t)p.H * p.W * xcs;
+    // ROLE 0: dZ task; 1: X task; 3: X task + halo pixel (raw[8])
+    auto issue_loads = [&](auto role_c, int j, bool valid, f32x4 (&raw)[9]) {
+        constexpr int ROLE = decltype(role_c)::value;
+        const int tile = t_beg + (j >> 1);                                                     // (all scalar)
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int oy0 = (tr / tiles_x) * 4 + (j & 1) * TH, ox0 = (tr % tiles_x) * TW;
+        if (ROLE == 0) {
+            const __amdgpu_buffer_rsrc_t rsz = make_rsrc(dz + (size_t)b * zimg, zimg * 4);
+            const unsigned vo = (valid && b_ok) ? (unsigned)((oy0 * p.Wo + ox0) * p.Co * 4 + b_off) : GATHER_OOB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsz, vo, i * p.Co * 4, 0));
+        } else {
+            const __amdgpu_buffer_rsrc_t rsx = make_rsrc(x0 + (size_t)b * ximg, ximg * 4);
+            const int xorg = (2 * oy0 * p.W + 2 * ox0) * xcs * 4;
+            const unsigned vo = (valid && b_ok && (unsigned)(2 * oy0 + b_row) < (unsigned)p.H) ? (unsigned)(xorg + b_off) : GATHER_OOB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, i * xcs * 4, 0));
+            if (ROLE == 3) {
+                const bool ok = valid && s_ok && (unsigned)(2 * oy0 + s_row) < (unsigned)p.H && ox0 > 0;
+                raw[8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? (unsigned)(xorg + s_off) : GATHER_OOB, 0, 0));
+            }
+        }
+    };
+    // channel e of the big task.  dZ: 8 pixels -> one 16-byte row per piece.  X: pixels 0, 2, 4, 6 -> E, 1, 3, 5, 7 -> O, 8 bytes each
+    auto store_big = [&](auto role_c, const f32x4 (&raw)[9], int e, unsigned short* buf) {
+        constexpr int ROLE = decltype(role_c)::value;
+        u16x4 lo[3], hi[3];
+        if (ROLE == 0) {
+            split_bf16<3>(f32x4{raw[0][e], raw[1][e], raw[2][e], raw[3][e]}, lo);
+            split_bf16<3>(f32x4{raw[4][e], raw[5][e], raw[6][e], raw[7][e]}, hi);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(buf + b_dst + e * ZP + q * PIX) = pack8(lo[q], hi[q]);
+        } else {
+            split_bf16<3>(f32x4{raw[0][e], raw[2][e], raw[4][e], raw[6][e]}, lo);      // even columns
+            split_bf16<3>(f32x4{raw[1][e], raw[3][e], raw[5][e], raw[7][e]}, hi);      // odd columns
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                *reinterpret_cast<u16x4*>(buf + b_dst + e * XP + q * XQ) = lo[q];
+                *reinterpret_cast<u16x4*>(buf + b_dst + e * XP + q * XQ + OOFF + 8) = hi[q];
+            }
+        }
+    };
+    auto store_small = [&](const f32x4 v, unsigned short* buf) {
+        u16x4 pc[3];
+        split_bf16<3>(v, pc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) buf[s_dst + e * XP + q * XQ] = pc[q][e];
+    };
+    auto store_all = [&](auto role_c, const f32x4 (&raw)[9], unsigned short* buf) {
+        constexpr int ROLE = decltype(role_c)::value;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_big(role_c, raw, e, buf);
+        if (ROLE == 3) store_small(raw[8], buf);
+    };
+
+    const int zoff = (wco * 32 + l32) * ZP + ph * TW + h * 8, xoff = XS0 + l32 * XP + (2 * ph) * XROW + h * 8;
+    // fragments a phase starts with (read by the previous phase behind its barrier): this wave's dZ row and its first X row
+    struct Frag { bf16x8 zf[3]; i32x4 x0[3][3]; };                  // x0[piece][E | O | O's preceding group]
+    auto read_row = [&](const unsigned short* xrow, int ky, i32x4 (&dst)[3][3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const unsigned short* g0 = xrow + q * XQ + ky * XROW;
+            dst[q][0] = *reinterpret_cast<const i32x4*>(g0);
+            dst[q][1] = *reinterpret_cast<const i32x4*>(g0 + OOFF + 8);
+            dst[q][2] = *reinterpret_cast<const i32x4*>(g0 + OOFF);
+        }
+    };
+    auto prefetch = [&](const unsigned short* buf, Frag& f) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f.zf[q] = *reinterpret_cast<const bf16x8*>(buf + zoff + q * PIX);
+        read_row(buf + xoff, 0, f.x0);
+    };
+    auto phase = [&](auto role_c, int j, const f32x4 (&rs)[9], f32x4 (&rl)[9], const unsigned short* cur, unsigned short* nxt, Frag& fr) {
+        constexpr int ROLE = decltype(role_c)::value;
+        issue_loads(role_c, min(j + 2, NJ - 1), j + 2 < NJ, rl);
+        const unsigned short* xrow = cur + xoff;
+        bf16x8 zf[3];
+        i32x4 xraw[2][3][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            zf[q] = fr.zf[q];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xraw[0][q][i] = fr.x0[q][i];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            if (ky + 1 < 3) read_row(xrow, ky + 1, xraw[(ky + 1) & 1]);
+            else {
+                __syncthreads();                                    // every wave has read `cur` (its last row is in registers) and written its part of `nxt`
+                prefetch(nxt, fr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ky == 0) { store_big(role_c, rs, 0, nxt); store_big(role_c, rs, 1, nxt); }
+            if (ky == 1) { store_big(role_c, rs, 2, nxt); store_big(role_c, rs, 3, nxt); if (ROLE == 3) store_small(rs[8], nxt); }
+            bf16x8 xf[3][3];                                         // [kx][piece]
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const i32x4 ev = xraw[ky & 1][q][0], od = xraw[ky & 1][q][1], pv = xraw[ky & 1][q][2];
+                i32x4 left;
+                left[0] = (int)__builtin_amdgcn_alignbit((unsigned)od[0], (unsigned)pv[3], 16);
+#pragma unroll
+                for (int i = 1; i < 4; ++i) left[i] = (int)__builtin_amdgcn_alignbit((unsigned)od[i], (unsigned)od[i - 1], 16);
+                xf[0][q] = __builtin_bit_cast(bf16x8, left);
+                xf[1][q] = __builtin_bit_cast(bf16x8, ev);
+                xf[2][q] = __builtin_bit_cast(bf16x8, od);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                    for (int qa = 0; qa <= ord; ++qa)
+                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x202, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto run = [&](auto role_c) {
+        f32x4 ra[9], rb[9];
+        unsigned short* buf0 = lds16;
+        unsigned short* buf1 = lds16 + BUF;
+        issue_loads(role_c, 0, true, ra);
+        issue_loads(role_c, 1, true, rb);
+        store_all(role_c, ra, buf0);
+        __syncthreads();
+        Frag fr;
+        prefetch(buf0, fr);
+        for (int j = 0; j < NJ; j += 2) {
+            phase(role_c, j, rb, ra, buf0, buf1, fr);
+            phase(role_c, j + 1, ra, rb, buf1, buf0, fr);
+        }
+    };
+    if (NJ > 0) {
+        if (wave == 0) run(std::integral_constant<int, 0>{});
+        else if (wave == 3) run(std::integral_constant<int, 3>{});
+        else run(std::integral_constant<int, 1>{});
+    }
+    // one partial slab per (block, output row of the sub-tiles): [2 blk + ph][co][tap][ci]
+    float* dst = part + (size_t)(blk * 2 + ph) * p.Co * 9 * p.Ct;
+    const int ci = c_base + l32;
+    if (ci < p.Ct) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Co) dst[((size_t)co * 9 + t) * p.Ct + ci] = acc[t][r];
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------- halo-tile wgrad, 64 x 64 channel tiles
 // 3x3 / stride 1 weight gradient for layers with >= 48 channels on both sides.  A block owns a (64 output channels) x
 // (64 input channels) tile of dW for all 9 taps and walks 4x16-pixel output tiles: the dZ tile and the X tile WITH its
@@ -4042,6 +4260,27 @@ extern "C" size_t codeps_conv2d_packed_weight_floats(int out_c_pad, int in_c_pad
 // kernel, K chunks of 32 channels), 0 = f32 MFMA (16-column kernels, 16-channel K chunks, CODEPS_SPLIT=0).  mode 0 = forward,
 // 1 = data gradient w.r.t. `source`, 2 = weight gradient (3 for the halo-tile layers, else 0).  Used by bench.py to price each launch
 // against the right peak.
+// 3 x 3 / stride 2 weight gradient on wgrad_s2_halo_kernel: whole 4 x 16 output tiles, one source, 32-channel input chunks
+struct S2Plan { bool ok; int ci_chunks, co_groups, tiles_x, tiles_y, nblk, tiles_per_block, splits; };
+static S2Plan wgrad_s2_plan(const codeps_conv_desc* d) {
+    S2Plan s;
+    memset(&s, 0, sizeof(s));
+    static const int s2_on = getenv("CODEPS_WGRAD_S2") ? atoi(getenv("CODEPS_WGRAD_S2")) : 1;                     // tuning experiments only
+    s.ok = s2_on && wgrad_split_on() && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->stride_w == 2 && d->pad == 1 && d->pad_w == 1 &&
+           d->c1 == 0 && !d->up0 && d->pad_mode == 0 && d->pix_pitch == 0 && d->c0 >= 32 && d->c0 % 32 == 0 && d->out_c >= 48 && d->out_c % 4 == 0 &&
+           d->in_h == 2 * d->out_h && d->in_w == 2 * d->out_w && d->out_h % 4 == 0 && d->out_w % 16 == 0 &&
+           (size_t)d->in_h * d->in_w * std::max(d->c0, d->out_c) * 4 < ((size_t)1 << 31);
+    if (!s.ok) return s;
+    s.ci_chunks = d->c0 / 32; s.co_groups = cdiv(d->out_c, 64);
+    s.tiles_x = d->out_w / 16; s.tiles_y = d->out_h / 4;
+    const int total = d->batch * s.tiles_x * s.tiles_y;
+    const int want = std::max(1, 256 / (s.ci_chunks * s.co_groups));      // one block per CU and round
+    s.tiles_per_block = std::max(2, cdiv(total, want));
+    s.nblk = cdiv(total, s.tiles_per_block);
+    s.splits = 2 * s.nblk;                                                 // one slab per (block, output row of the sub-tiles)
+    return s;
+}
+
 static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
     const int split_np = split_pieces();
     static const int force_bk = getenv("CODEPS_FORCE_BK") ? atoi(getenv("CODEPS_FORCE_BK")) : 0;
@@ -4055,6 +4294,7 @@ static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
     }
     if (mode == 2) {
         if (split_np != 3 || !wgrad_split_on()) return 0;
+        if (wgrad_s2_plan(d).ok) return 3;                                             // stride-2 halo-tile kernel
         const SmallPlan sp = wgrad_small_plan(d);
         return (sp.ok && (sp.halo64 || (sp.stem && sp.co_groups == 1))) ? 3 : 0;       // halo-tile kernel / split stem kernel
     }
@@ -4193,6 +4433,8 @@ static void wgrad_plan(const codeps_conv_desc* d, int& bm, int& bn, int& n_mt, i
 
 extern "C" size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d) {
     if (check_conv(d, "conv2d_wgrad_workspace_bytes") != CODEPS_OK) return 0;
+    const S2Plan s2 = wgrad_s2_plan(d);
+    if (s2.ok) return (size_t)s2.splits * d->out_c * d->c0 * 9 * sizeof(float);
     const SmallPlan sp = wgrad_small_plan(d);
     if (sp.ok) return (size_t)sp.splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
     int bm, bn, n_mt, n_nt, splits, pps;
@@ -4228,6 +4470,8 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     wgrad_plan(d, bm, bn, n_mt, n_nt, splits, pps);
     const SmallPlan sp = wgrad_small_plan(d);
     if (sp.ok) splits = sp.splits;
+    const S2Plan s2 = wgrad_s2_plan(d);
+    if (s2.ok) splits = s2.splits;
     const size_t need = (size_t)splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
     CODEPS_REQUIRE(workspace_bytes >= need, CODEPS_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
     WgradP p;
@@ -4243,6 +4487,17 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     const int grid = n_mt * n_nt * d->kh * d->kw * splits;
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
+    if (s2.ok) {
+        constexpr size_t lds = (size_t)2 * (64 * (3 * 32 + 8) + 32 * (3 * 5 * 40 + 16)) * 2;
+        g_last_kernel = "wgrad_s2_halo_kernel";
+        codeps_allow_lds((const void*)wgrad_s2_halo_kernel, 160 * 1024, "wgrad_s2_halo_kernel");
+        hipLaunchKernelGGL(wgrad_s2_halo_kernel, dim3(s2.nblk * s2.ci_chunks, s2.co_groups), dim3(256), lds, st, p, s2.ci_chunks, s2.tiles_x, s2.tiles_y,
+                           s2.tiles_per_block, x0, dz, part);
+        CODEPS_CHECK_LAUNCH("wgrad_s2_halo_kernel");
+        launch_wgrad_reduce(part, splits, d->out_c, d->c0, 9, out_c_real, in_c_real, dw_oihw, accumulate, st);
+        CODEPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+        return CODEPS_OK;
+    }
     if (sp.ok) {
         const int g = sp.nblk * sp.ci_chunks;
 #define WS_LAUNCH(MT, NT, KS) hipLaunchKernelGGL((wgrad_small_kernel<MT, NT, KS, KS, 1, 1, 8, 32>), dim3(g), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, \

@@ -176,3 +176,45 @@ def test_stem_weight_gradient_double_buffered_against_float64(shape):
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
     e, t = l2(outs[0], dw64), l2(dw32, dw64)
     assert e <= 3 * t + 1e-9, f"{shape}: {e:.3e} vs torch fp32 {t:.3e}"
+
+
+@pytest.mark.parametrize("case", [
+    # (batch, H, W, ci, co): 3 x 3 / stride 2 / pad 1 on maps whose OUTPUT is whole 4 x 16 tiles -> wgrad_s2_halo_kernel
+    (2, 32, 64, 64, 128),        # ResNet-18 layer2.0.conv1 at a small size
+    (1, 8, 32, 32, 64),          # one tile, one 32-channel chunk
+    (3, 16, 32, 128, 256),       # 4 chunks x 4 co groups, odd tile count per block
+    (1, 24, 32, 96, 80),         # co 80: second co group a quarter full; 3 output tile rows
+])
+def test_stride2_weight_gradient_against_float64(case):
+    """The first convolution of ResNet-18/34 stages 2-4 (3 x 3, stride 2; models/resnet_encoder.py:115-126 -> torchvision BasicBlock):
+    its weight gradient on the bf16 matrix cores (input columns de-interleaved by parity in LDS, double-buffered sub-tiles) against a
+    float64 gradient, and bit-identical from launch to launch."""
+    import ctypes
+    import torch.nn.functional as TF
+    from codeps_amd import functional as F
+    from codeps_amd._lib import lib
+    b, h, w, ci, co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.relu(torch.randn(b, ci, h, w, generator=g))
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5
+    gy = torch.randn(b, co, h // 2, w // 2, generator=g)
+
+    def ref(dtype):
+        ww = wt.to(dtype).requires_grad_(True)
+        TF.conv2d(x.to(dtype), ww, stride=2, padding=1).backward(gy.to(dtype))
+        return ww.grad
+
+    dw64, dw32 = ref(torch.float64), ref(torch.float32)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)       # noqa: E731
+    lib().codeps_conv2d_last_kernel.restype = ctypes.c_char_p
+    outs = []
+    for _ in range(3):
+        ww = wt.to(DEV).detach().requires_grad_(True)
+        y = F.conv2d(nhwc(x), ww, stride=2, pad=1)
+        y.backward(nhwc(gy))
+        assert lib().codeps_conv2d_last_kernel().decode() == "wgrad_s2_halo_kernel"
+        outs.append(ww.grad.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
+    e, t = l2(outs[0], dw64), l2(dw32, dw64)
+    assert e <= 3 * t + 1e-9, f"{case}: {e:.3e} vs torch fp32 {t:.3e}"
