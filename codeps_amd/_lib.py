@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
 LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 7
+ABI_VERSION = 8
 DIAG_LIB_PATH = os.path.join(_HERE, "libcodeps_diag.so")
 
 _lib = None
@@ -95,6 +95,8 @@ SIGNATURES = {
     "codeps_bn_fwd_mg": (c_int, [P, I, P, P, I, I, P, P, P, I, c_float, c_float, P, P, P, P, P, P, I, I, P, c_size_t, P]),
     "codeps_bn_sync_combine": (c_int, [P, I, I, P, P, I, I, c_float, c_float, P, P, P, P, P, P]),
     "codeps_bn_bwd_mg": (c_int, [P, P, P, I, P, P, I, I, P, P, P, P, P, I, P, P, P, I, P, P, I, I, P, c_size_t, P]),
+    "codeps_bn_relu_pool_fwd": (c_int, [P, I, P, P, I, I, I, I, P, P, P, P, P, P, P]),
+    "codeps_bn_relu_pool_bwd": (c_int, [P, P, P, I, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, P, c_size_t, P]),
     "codeps_maxpool3x3s2_fwd": (c_int, [P, I, I, I, I, P, P, P]),
     "codeps_maxpool3x3s2_bwd": (c_int, [P, P, I, I, I, I, P, P]),
     "codeps_dwconv5x5": (c_int, [P, P, P, P, I, I, I, I, I, I, P, P]),

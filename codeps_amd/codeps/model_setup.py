@@ -24,6 +24,7 @@ def _geometry_part(cfg, device, enc_channels, adaptation: bool, label_mode, eval
     pose_cfg = cfg.model.pose_sflow_net.params
     pose_encoder = models.ResnetEncoder(pose_cfg.nof_layers, pose_cfg.weights_init == "pretrained", num_input_images=2,
                                         num_channels_input=3)
+    pose_encoder.only_last_feature = True          # PoseHead reads features[-1] only (models/pose_head.py:30)
     ssim = algos.SSIMLoss()
     sizes = {"target": cfg.dataset.feed_img_size, "source": cfg.adapt.source_dataset.feed_img_size if adaptation else None}
     recon = {k: (algos.ReconstructionLoss(hw[1], hw[0], ssim, cfg.depth.num_recon_scales, device) if hw is not None else None)

@@ -435,14 +435,61 @@ __global__ __launch_bounds__(256) void bn_apply_mg_kernel(const float* __restric
     }
 }
 
+// Gradient source "through a 3 x 3 / stride-2 / pad-1 max-pool" (the stem: bn1 -> relu -> maxpool, models/resnet_encoder.py:118-121): the
+// BatchNorm backward kernels then gather dy of a pixel from the pooled gradient and the arg-max bytes of the (up to four) windows
+// that contain it -- exactly maxpool_bwd_kernel's sum, in its order -- instead of reading a materialised full-resolution dy.
+struct PoolSrc { const float* dp; const uint8_t* arg; int H, W, Ho, Wo; float inv_hw, inv_w; };
+// n / d for 0 <= n < 2^24 * d-ish through a float reciprocal + one correction step (the kernels below divide per element; the
+// hardware has no integer divide: ~35 instructions each)
+__device__ __forceinline__ int fast_div(long long n, long long d, float inv_d) {
+    if (n >> 23) return (int)(n / d);                             // (beyond the float's exact integers: the plain divide)
+    int q = (int)((float)n * inv_d);
+    long long r = n - (long long)q * d;
+    q += r >= d ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return q;
+}
+// branch-free: the (up to) 2 x 2 windows that contain pixel (iy, ix) -- an even coordinate lies in one window (tap 1), an odd one in
+// two (taps 2 and 0) -- are all loaded (clamped addresses), masked afterwards, and added in maxpool_bwd_kernel's order (oy, then ox)
+__device__ __forceinline__ f32x4 pool_grad(const PoolSrc& ps, long long row, int C, int g4) {
+    const long long hw = (long long)ps.H * ps.W;
+    const int b = fast_div(row, hw, ps.inv_hw);
+    const int rem = (int)(row - (long long)b * hw), iy = fast_div(rem, ps.W, ps.inv_w), ix = rem - iy * ps.W;
+    const int oy0 = iy >> 1, ox0 = ix >> 1;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    uint32_t pk[2][2];
+    f32x4 gd[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int oy = min(oy0 + dy, ps.Ho - 1), ox = min(ox0 + dx, ps.Wo - 1);
+            const size_t o = (((size_t)b * ps.Ho + oy) * ps.Wo + ox) * C + g4 * 4;
+            pk[dy][dx] = *reinterpret_cast<const uint32_t*>(ps.arg + o);
+            gd[dy][dx] = *reinterpret_cast<const f32x4*>(ps.dp + o);
+        }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const bool in = (dy == 0 || ((iy & 1) && oy0 + 1 < ps.Ho)) && (dx == 0 || ((ix & 1) && ox0 + 1 < ps.Wo));
+            const uint32_t me = (uint32_t)((iy - ((oy0 + dy) * 2 - 1)) * 3 + ix - ((ox0 + dx) * 2 - 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (in && ((pk[dy][dx] >> (8 * e)) & 0xFF) == me) a[e] += gd[dy][dx][e];
+        }
+    return a;
+}
+
 // backward partials per group: (sum g, sum g*xhat) with g = dy * relu'(y): part[g][blk][2][C]
 // y == nullptr with act == 1: the ReLU mask is recomputed as (x - mean) * invstd * gamma + beta > 0 (the forward expression;
 // only valid without a residual) instead of reading the saved output -- one tensor less per pass
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int act, int C, int nblk,
-                                                               float* __restrict__ part) {
+                                                               float* __restrict__ part, PoolSrc ps) {
     const int g = blockIdx.z;
     const int Gall = C / 4, G = Gall < 256 ? Gall : 256;
     const int tl = threadIdx.x % G, tr = threadIdx.x / G, TR = 256 / G;
@@ -464,8 +511,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_mg_kernel(const float* __re
                 f32x4 gv[4], xv[4], yv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const size_t o = (size_t)min(r + (long long)u * TR, r1 - 1) * C + tg * 4;
-                    gv[u] = *reinterpret_cast<const f32x4*>(dy + o);
+                    const long long ru = min(r + (long long)u * TR, r1 - 1);
+                    const size_t o = (size_t)ru * C + tg * 4;
+                    gv[u] = POOL ? pool_grad(ps, ru, C, tg) : *reinterpret_cast<const f32x4*>(dy + o);
                     xv[u] = *reinterpret_cast<const f32x4*>(x + o);
                     if constexpr (decltype(has_y)::value) yv[u] = *reinterpret_cast<const f32x4*>(y + o);
                 }
@@ -521,11 +569,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_mg_kernel(const float* __re
     }
 }
 
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_mg_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ sums, int act,
-                                                              long long M, int C, float* __restrict__ dx, float* __restrict__ dres) {
+                                                              long long M, int C, float* __restrict__ dx, float* __restrict__ dres, PoolSrc ps) {
     const int G = C / 4;
     const long long total = M * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -533,7 +582,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_mg_kernel(const float* __res
         const long long row = i / G;
         const int grp = bn_group_of(gr, row);
         const size_t o = (size_t)row * C + g4 * 4;
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        f32x4 g = POOL ? pool_grad(ps, row, C, g4) : *reinterpret_cast<const f32x4*>(dy + o);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + grp * C + g4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + grp * C + g4 * 4);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g4 * 4);
         const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
@@ -547,6 +596,65 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_mg_kernel(const float* __res
         const f32x4 sgx = *reinterpret_cast<const f32x4*>(sums + (size_t)grp * 2 * C + C + g4 * 4);
         const float ic = gr.inv_count[grp];
         *reinterpret_cast<f32x4*>(dx + o) = ga * is * (g - sg * ic - xh * sgx * ic);
+    }
+}
+
+// bn_bwd_apply_mg_kernel<POOL = true> for even H and W: one thread per 2 x 2 block of pixels and channel quad.  The block's four
+// windows (rows k, k + 1; columns j, j + 1 of the pooled map) are loaded ONCE and serve its four pixels (3 loads per pixel instead of 9);
+// every pixel's gradient is summed in pool_grad's order, so the result is bit-identical.
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool2x2_kernel(const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const float* __restrict__ sums, int B, int C,
+                                                                   float* __restrict__ dx, PoolSrc ps) {
+    const int G = C / 4, H2 = ps.H / 2, W2 = ps.W / 2;
+    const long long total = (long long)B * H2 * W2 * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g4 = (int)(i % G);
+        long long t = i / G;
+        const int j = (int)(t % W2); t /= W2;
+        const int k = (int)(t % H2);
+        const int b = (int)(t / H2);
+        const int grp = bn_group_of(gr, (long long)b * ps.H * ps.W);
+        uint32_t pk[2][2];
+        f32x4 gd[2][2], xv[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dxx = 0; dxx < 2; ++dxx) {
+                const int oy = min(k + dy, ps.Ho - 1), ox = min(j + dxx, ps.Wo - 1);
+                const size_t o = (((size_t)b * ps.Ho + oy) * ps.Wo + ox) * C + g4 * 4;
+                pk[dy][dxx] = *reinterpret_cast<const uint32_t*>(ps.arg + o);
+                gd[dy][dxx] = *reinterpret_cast<const f32x4*>(ps.dp + o);
+                xv[dy][dxx] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * ps.H + 2 * k + dy) * ps.W + 2 * j + dxx) * C + g4 * 4);
+            }
+        const bool oky = k + 1 < ps.Ho, okx = j + 1 < ps.Wo;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + grp * C + g4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + grp * C + g4 * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g4 * 4), be = *reinterpret_cast<const f32x4*>(beta + g4 * 4);
+        const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + (size_t)grp * 2 * C + g4 * 4);
+        const f32x4 sgx = *reinterpret_cast<const f32x4*>(sums + (size_t)grp * 2 * C + C + g4 * 4);
+        const float ic = gr.inv_count[grp];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                // pixel (2 k + py, 2 j + px): windows (k + dy, j + dx) with dy <= py, dx <= px; its tap there = (py + 1 - 2 dy, px + 1 - 2 dx)
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dy = 0; dy <= py; ++dy)
+#pragma unroll
+                    for (int dxx = 0; dxx <= px; ++dxx) {
+                        const bool in = (dy == 0 || oky) && (dxx == 0 || okx);
+                        const uint32_t me = (uint32_t)((py + 1 - 2 * dy) * 3 + px + 1 - 2 * dxx);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (in && ((pk[dy][dxx] >> (8 * e)) & 0xFF) == me) g[e] += gd[dy][dxx][e];
+                    }
+                const f32x4 xh = (xv[py][px] - mu) * is;
+                const f32x4 yy = xh * ga + be;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+                *reinterpret_cast<f32x4*>(dx + (((size_t)b * ps.H + 2 * k + py) * ps.W + 2 * j + px) * C + g4 * 4) = ga * is * (g - sg * ic - xh * sgx * ic);
+            }
     }
 }
 
@@ -577,6 +685,44 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * C + g * 4;
         *reinterpret_cast<f32x4*>(y + o) = best;
         if (arg) *reinterpret_cast<uint32_t*>(arg + o) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    }
+}
+
+// relu(batch-norm(z)) and the 3 x 3 / stride-2 / pad-1 max-pool over it in one pass (the stem in train mode): the full-resolution
+// activation is never written.  Same expression as bn_apply_mg_kernel, same comparison and tie rule as maxpool_fwd_kernel.
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ z, BnGroups gr, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int B, int H, int W, int C, int Ho, int Wo,
+                                                               float* __restrict__ y, uint8_t* __restrict__ arg) {
+    const int G = C / 4;
+    const long long total = (long long)B * Ho * Wo * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        long long pix = i / G;
+        const int ox = (int)(pix % Wo); pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        const int grp = bn_group_of(gr, (long long)b * H * W);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + grp * C + g * 4), is = *reinterpret_cast<const f32x4*>(invstd + grp * C + g * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4), be = *reinterpret_cast<const f32x4*>(beta + g * 4);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                f32x4 v = (*reinterpret_cast<const f32x4*>(z + (((size_t)b * H + iy) * W + ix) * C + g * 4) - mu) * is * ga + be;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    if (v[e] > best[e] || (v[e] != v[e])) { best[e] = v[e]; bi[e] = ky * 3 + kx; }
+                }
+            }
+        const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * C + g * 4;
+        *reinterpret_cast<f32x4*>(y + o) = best;
+        *reinterpret_cast<uint32_t*>(arg + o) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
 }
 
@@ -1377,8 +1523,8 @@ extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x,
     if (!apply_only) {
         CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)n_groups * nblk * 2 * c * 4 && dgamma && dbeta, CODEPS_ERR_WORKSPACE,
                        "bn_bwd_mg: workspace too small / null grads");
-        hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, beta, act, c, nblk,
-                           (float*)workspace);
+        hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel<false>, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, beta, act, c, nblk,
+                           (float*)workspace, PoolSrc{});
         hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 4)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma,
                            dbeta, accumulate);
         CODEPS_CHECK_LAUNCH("bn_bwd_reduce_mg_kernel");
@@ -1386,10 +1532,63 @@ extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x,
     if (!reduce_only) {
         CODEPS_REQUIRE(gamma && inv_count && dx, CODEPS_ERR_ARG, "bn_bwd_mg: null gamma / inv_count / dx");
         for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = inv_count[i];
-        hipLaunchKernelGGL(bn_bwd_apply_mg_kernel, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, beta, (const float*)sums,
-                           act, M, c, dx, dres);
+        hipLaunchKernelGGL(bn_bwd_apply_mg_kernel<false>, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, beta, (const float*)sums,
+                           act, M, c, dx, dres, PoolSrc{});
         CODEPS_CHECK_LAUNCH("bn_bwd_apply_mg_kernel");
     }
+    return CODEPS_OK;
+}
+
+// Stem in train mode, fused (models/resnet_encoder.py:118-121: bn1 -> relu -> maxpool): forward = relu(BN(z)) max-pooled in one pass, the
+// statistics come from codeps_bn_fwd_mg(stats_only = 1); backward = BatchNorm's two passes reading the POOLED gradient + arg-max bytes.
+// Groups are whole images (row0 / rows in pixels, multiples of h * w).  Bit-identical to bn_fwd_mg + maxpool3x3s2_fwd resp.
+// maxpool3x3s2_bwd + bn_bwd_mg: same expressions, same orders of summation.
+extern "C" int codeps_bn_relu_pool_fwd(const float* z, int n_groups, const long long* row0, const long long* rows, int batch, int h, int w, int c,
+                                       const float* mean, const float* invstd, const float* gamma, const float* beta, float* pooled,
+                                       uint8_t* argmax, codeps_stream_t stream) {
+    BnGroups gr;
+    long long M;
+    int rc = make_groups(n_groups, row0, rows, gr, M, "bn_relu_pool_fwd");
+    if (rc) return rc;
+    CODEPS_REQUIRE(z && mean && invstd && gamma && beta && pooled && argmax && batch > 0 && h > 0 && w > 0 && (c % 4) == 0 &&
+                   M == (long long)batch * h * w, CODEPS_ERR_ARG, "bn_relu_pool_fwd: bad arguments (groups must cover batch * h * w rows)");
+    for (int i = 0; i < n_groups; ++i)
+        CODEPS_REQUIRE(row0[i] % ((long long)h * w) == 0 && rows[i] % ((long long)h * w) == 0, CODEPS_ERR_ARG, "bn_relu_pool_fwd: groups are whole images");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(grid_for((long long)batch * ho * wo * (c / 4))), dim3(256), 0, (hipStream_t)stream, z, gr, mean, invstd,
+                       gamma, beta, batch, h, w, c, ho, wo, pooled, argmax);
+    CODEPS_CHECK_LAUNCH("bn_relu_pool_fwd_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_relu_pool_bwd(const float* dpooled, const uint8_t* argmax, const float* z, int n_groups, const long long* row0,
+                                       const long long* rows, int batch, int h, int w, int c, int c_real, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, const float* inv_count, float* sums, float* dgamma, float* dbeta,
+                                       int accumulate, float* dz, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    BnGroups gr;
+    long long M;
+    int rc = make_groups(n_groups, row0, rows, gr, M, "bn_relu_pool_bwd");
+    if (rc) return rc;
+    CODEPS_REQUIRE(dpooled && argmax && z && mean && invstd && gamma && beta && inv_count && sums && dgamma && dbeta && dz && (c % 4) == 0 &&
+                   M == (long long)batch * h * w, CODEPS_ERR_ARG, "bn_relu_pool_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = mg_blocks(gr);
+    CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)n_groups * nblk * 2 * c * 4, CODEPS_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
+    PoolSrc ps;
+    ps.dp = dpooled; ps.arg = argmax; ps.H = h; ps.W = w; ps.Ho = (h + 2 - 3) / 2 + 1; ps.Wo = (w + 2 - 3) / 2 + 1;
+    ps.inv_hw = 1.f / ((float)h * (float)w); ps.inv_w = 1.f / (float)w;
+    hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel<true>, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, (const float*)nullptr, (const float*)nullptr, z, gr,
+                       mean, invstd, gamma, beta, 1, c, nblk, (float*)workspace, ps);
+    hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 4)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma, dbeta,
+                       accumulate);
+    for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = inv_count[i];
+    if (h % 2 == 0 && w % 2 == 0)
+        hipLaunchKernelGGL(bn_bwd_apply_pool2x2_kernel, dim3(grid_for(M / 4 * (c / 4))), dim3(256), 0, st, z, gr, mean, invstd, gamma, beta, (const float*)sums,
+                           batch, c, dz, ps);
+    else
+    hipLaunchKernelGGL(bn_bwd_apply_mg_kernel<true>, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, (const float*)nullptr, (const float*)nullptr, z, gr, mean,
+                       invstd, gamma, beta, (const float*)sums, 1, M, c, dz, (float*)nullptr, ps);
+    CODEPS_CHECK_LAUNCH("bn_relu_pool_bwd");
     return CODEPS_OK;
 }
 

@@ -1033,6 +1033,71 @@ def max_pool3x3s2(x):
     return _MaxPool.apply(x)
 
 
+_BNPOOL = os.environ.get("CODEPS_BNPOOL", "1") != "0"      # A/B switch: 0 = train-mode stem as separate BatchNorm and max-pool ops
+
+
+class _BnReluPoolTrain(torch.autograd.Function):
+    """maxpool3x3s2(relu(batch_norm_train(z))) of the stem (models/resnet_encoder.py:118-121) without the full-resolution activation
+    or its gradient (C ABI: codeps_bn_fwd_mg(stats_only) + codeps_bn_relu_pool_{fwd,bwd}); `groups` as in _BatchNormTrain.  Bit-identical
+    to the two separate ops.  Local statistics only (no SyncBatchNorm reducer)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, groups):
+        require_cuda(z, gamma, beta)
+        z = z.contiguous()
+        bsz, h, w, cp = z.shape
+        c = gamma.numel()
+        per_item = h * w
+        groups = [(0, bsz)] if not groups else list(groups)
+        ng, row0, rows = _group_arrays(groups, per_item)
+        g, b_ = _pad_vec(gamma, cp), _pad_vec(beta, cp)
+        dev = z.device
+        mean = torch.empty(ng, cp, dtype=torch.float32, device=dev)
+        var, invstd = torch.empty_like(mean), torch.empty_like(mean)
+        ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
+        rm = running_mean if (running_mean is not None and running_mean.numel() == c) else None
+        check(lib().codeps_bn_fwd_mg(ptr(z), ng, row0, rows, cp, c, None, None, None, 1, eps, momentum, ptr(rm),
+                                     ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), None, 1, 0,
+                                     ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg (statistics)")
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty(bsz, ho, wo, cp, dtype=torch.float32, device=dev)
+        arg = torch.empty(bsz, ho, wo, cp, dtype=torch.uint8, device=dev)
+        check(lib().codeps_bn_relu_pool_fwd(ptr(z), ng, row0, rows, bsz, h, w, cp, ptr(mean), ptr(invstd), ptr(g), ptr(b_), ptr(y), ptr(arg),
+                                            stream_ptr()), "codeps_bn_relu_pool_fwd")
+        ctx.inv_count = [1.0 / ((b1 - b0) * per_item) for b0, b1 in groups]
+        ctx.save_for_backward(z, arg, g, b_, mean, invstd)
+        ctx.c, ctx.groups, ctx.geom = c, groups, (bsz, h, w, cp)
+        gs, bs = grad_sink(gamma), grad_sink(beta)
+        ctx.sinks = (gs, bs) if (gs is not None and bs is not None and gamma.requires_grad and beta.requires_grad) else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, arg, g, b_, mean, invstd = ctx.saved_tensors
+        bsz, h, w, cp = ctx.geom
+        ng, row0, rows = _group_arrays(ctx.groups, h * w)
+        inv_count = (ctypes.c_float * ng)(*ctx.inv_count)
+        dev = z.device
+        sums = torch.empty(ng, 2, cp, dtype=torch.float32, device=dev)
+        if ctx.sinks is not None:
+            dgamma, dbeta, acc = ctx.sinks[0], ctx.sinks[1], 1
+        else:
+            dgamma = torch.empty(ctx.c, dtype=torch.float32, device=dev)
+            dbeta, acc = torch.empty_like(dgamma), 0
+        dz = torch.empty_like(z)
+        ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
+        check(lib().codeps_bn_relu_pool_bwd(ptr(dy.contiguous()), ptr(arg), ptr(z), ng, row0, rows, bsz, h, w, cp, ctx.c, ptr(mean), ptr(invstd),
+                                            ptr(g), ptr(b_), inv_count, ptr(sums), ptr(dgamma), ptr(dbeta), acc, ptr(dz), ptr(ws), ws.numel(),
+                                            stream_ptr()), "codeps_bn_relu_pool_bwd")
+        if ctx.sinks is not None:
+            dgamma = dbeta = None
+        return dz, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_relu_maxpool_train(z, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, groups=None):
+    return _BnReluPoolTrain.apply(z, gamma, beta, running_mean, running_var, momentum, eps, groups)
+
+
 class _Bilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, out_h, out_w, align, out, c_off):

@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
-from ._blocks import conv_bn, flush_bn_counters, folded_bn
+from ._blocks import _count_batch, conv_bn, flush_bn_counters, folded_bn
 
 _LAYERS = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]),
            101: ("bottleneck", [3, 4, 23, 3]), 152: ("bottleneck", [3, 8, 36, 3])}
@@ -149,6 +149,9 @@ class ResnetEncoder(nn.Module):
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
         self.sync_bn = None            # set by codeps_amd.distributed for SyncBatchNorm semantics
+        # True = the caller reads the LAST feature map only (the pose net: models/pose_head.py:30): forward() then returns None in
+        # place of the stride-2 map and, in train mode, runs bn1 -> relu -> maxpool as one pass each way (F.bn_relu_maxpool_train)
+        self.only_last_feature = False
 
     accepts_frame_tuple = True
 
@@ -182,14 +185,23 @@ class ResnetEncoder(nn.Module):
             x = F.images_to_nhwc([input_image], cp, xpad)
         else:
             x = F.from_nchw(input_image, 16)
-        x = conv_bn(x, enc.conv1, enc.bn1, "relu", sync=self.sync_bn, groups=groups, stem=stem)
-        feats = [x]
-        x = F.max_pool3x3s2(x)
+        if self.only_last_feature and F._BNPOOL and enc.bn1.training and self.sync_bn is None and stem != "s3":
+            # train-mode stem whose ReLU output nobody reads: statistics, then relu(bn(z)) max-pooled straight from z (and the backward
+            # from the pooled gradient) -- 2.5 GB of the stem's 4.4 GB of BatchNorm / pooling traffic per step are not moved
+            z = F.stem_conv2d(x, enc.conv1.weight) if stem else F.conv2d(x, enc.conv1.weight, stride=enc.conv1.stride[0], pad=enc.conv1.padding[0])
+            x = F.bn_relu_maxpool_train(z, enc.bn1.weight, enc.bn1.bias, enc.bn1.running_mean, enc.bn1.running_var, enc.bn1.momentum,
+                                        enc.bn1.eps, groups)
+            _count_batch(enc.bn1, len(groups) if groups else 1)
+            feats = [None]
+        else:
+            x = conv_bn(x, enc.conv1, enc.bn1, "relu", sync=self.sync_bn, groups=groups, stem=stem)
+            feats = [x]
+            x = F.max_pool3x3s2(x)
         for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
             x = _run_layer(layer, x, self.sync_bn, groups)
             feats.append(x)
         flush_bn_counters()
-        return [F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]
+        return [None if f is None else F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]
 
     def forward_pair_groups(self, pairs, plan=None):
         """pairs = [(frame_a, frame_b), ...]: every pair is what the reference feeds to ONE call of this encoder

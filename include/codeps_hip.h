@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* codeps_stream_t;
 
-int codeps_version(void);                 /* ABI version (7), bumped on any signature / buffer-contract change */
+int codeps_version(void);                 /* ABI version (8), bumped on any signature / buffer-contract change */
 const char* codeps_last_error(void);      /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------------------------------------
@@ -238,6 +238,20 @@ int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x, int n_grou
                      int apply_only, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 /* codeps_bn_bwd_mg: y may be NULL when act == 1 and the forward had no residual: the ReLU mask is then recomputed from
  * x, mean, invstd, gamma, beta (one tensor less to keep and to read per backward pass). */
+/* The stem in train mode, fused (models/resnet_encoder.py:118-121: bn1 -> relu -> maxpool; torchvision ResNet._forward_impl):
+ * fwd = relu(batch-norm(z)) max-pooled (3 x 3 / 2 / 1) in ONE pass over z -- the full-resolution activation is never written;
+ * statistics (mean, invstd per group) come from codeps_bn_fwd_mg(stats_only = 1).  bwd = BatchNorm's two passes (sums, then dz)
+ * reading the POOLED gradient + arg-max bytes: no full-resolution gradient of the ReLU output either.  Groups are whole images
+ * (row0 / rows in pixels, multiples of h * w).  Bit-identical to codeps_bn_fwd_mg + codeps_maxpool3x3s2_fwd resp.
+ * codeps_maxpool3x3s2_bwd + codeps_bn_bwd_mg (same expressions, same orders of summation).  workspace: codeps_bn_mg_workspace_bytes. */
+int codeps_bn_relu_pool_fwd(const float* z, int n_groups, const long long* row0, const long long* rows, int batch, int h,
+                            int w, int c, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            float* pooled, uint8_t* argmax, codeps_stream_t stream);
+int codeps_bn_relu_pool_bwd(const float* dpooled, const uint8_t* argmax, const float* z, int n_groups, const long long* row0,
+                            const long long* rows, int batch, int h, int w, int c, int c_real, const float* mean,
+                            const float* invstd, const float* gamma, const float* beta, const float* inv_count, float* sums,
+                            float* dgamma, float* dbeta, int accumulate, float* dz, void* workspace, size_t workspace_bytes,
+                            codeps_stream_t stream);
 /* nn.MaxPool2d(3, 2, 1) (models/resnet_encoder.py:31); argmax = window tap 0..8 per element (u8). */
 int codeps_maxpool3x3s2_fwd(const float* x, int batch, int h, int w, int c, float* y, uint8_t* argmax,
                             codeps_stream_t stream);

@@ -218,3 +218,38 @@ def test_stride2_weight_gradient_against_float64(case):
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
     e, t = l2(outs[0], dw64), l2(dw32, dw64)
     assert e <= 3 * t + 1e-9, f"{case}: {e:.3e} vs torch fp32 {t:.3e}"
+
+
+@pytest.mark.parametrize("groups,hw", [(False, (64, 96)), (True, (64, 96)), (False, (36, 52))])
+def test_fused_stem_bn_relu_pool_is_bit_identical(groups, hw):
+    """Train-mode stem of the pose encoder (models/resnet_encoder.py:118-121: bn1 -> relu -> maxpool) as one pass each way
+    (`ResnetEncoder.only_last_feature`, C ABI codeps_bn_relu_pool_{fwd,bwd}) against the separate BatchNorm and max-pool ops: last
+    feature map, running statistics and every parameter gradient bit for bit; with and without per-pair statistic groups."""
+    import copy
+    from codeps_amd import models
+    torch.manual_seed(3)
+    enc = models.ResnetEncoder(18, False, num_input_images=2).to(DEV).train()
+    ref = copy.deepcopy(enc)
+    enc.only_last_feature = True
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.rand(2, 3, hw[0], hw[1], generator=g).to(DEV) for _ in range(4)]        # (36 x 52: stem output 18 x 26; 2 x 2 form too)
+    gy = None
+    outs = []
+    for net in (ref, enc):
+        if groups:
+            feats = net.forward_pair_groups([(frames[0], frames[1]), (frames[2], frames[3])])
+        else:
+            feats = net((frames[0], frames[1]))
+        last = feats[-1]
+        if gy is None:
+            gy = torch.randn(last.shape, generator=torch.Generator().manual_seed(9)).to(DEV)
+        last.backward(gy)
+        outs.append((last.detach().clone(), [None if p.grad is None else p.grad.clone() for p in net.parameters()],
+                     net.encoder.bn1.running_mean.clone(), net.encoder.bn1.running_var.clone(), int(net.encoder.bn1.num_batches_tracked)))
+    assert enc((frames[0], frames[1]))[0] is None and ref((frames[0], frames[1]))[0] is not None
+    a, b = outs
+    assert torch.equal(a[0], b[0])
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and a[4] == b[4]
+    assert sum(ga is not None for ga in a[1]) >= 60
+    for ga, gb in zip(a[1], b[1]):
+        assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb))
