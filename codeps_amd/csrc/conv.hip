@@ -687,12 +687,14 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
 // of it (a tap is a row offset in the [pixel][piece][32] layout: aligned, no gather table).  Only the pre-split weights of
 // (tap, chunk) move per K-step, through a double buffer: one barrier per tap.  Same arithmetic, same epilogue.
 // MODE_DGRAD (stride 1): input pixel p sums dZ(p + (1 - ky, 1 - kx)) x W[ci][tap][co]: the same kernel with mirrored taps.
-template <int MODE, int TN>
+// WM x WN waves: 2 x 2 = 4 x 32 output pixels x (64 TN) columns (two blocks per CU at TN = 1); 4 x 1 (round 4) = 8 x 32 pixels x 32
+// columns for the layers with <= 32 output channels (the decoders' half-resolution stage), which the generic kernel ran at 84-119 TFLOP/s.
+template <int MODE, int TN, int WM = 2, int WN = 2>
 __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ residual, float* __restrict__ out) {
-    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = 3;
-    constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;      // 128 outputs, 204 halo pixels
+    constexpr int TM = 2, BK = 32, NP = 3;
+    constexpr int TH = 2 * WM, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;  // WM = 2: 128 outputs, 204 halo pixels; WM = 4: 256 / 340
     constexpr int BN = 32 * WN * TN;
     constexpr int LDK = (NP * BK + 8) / 2;                                        // floats per LDS row
     constexpr int LDKA = CODEPS_HALO_SWZ ? LDK + 4 : LDK;                         // activation rows: 224 bytes (conv_halo3r_kernel explains)
@@ -723,13 +725,13 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
     // B staging roles: a (tap, chunk) row of the pre-split pack is 192 contiguous bytes = 12 16-byte segments, and so is its LDS
     // row ([piece][32]): task t = tid + 256 i copies segment t % 12 of row t / 12 -- twelve neighbouring lanes move one row, so
     // both the global read and the LDS write are contiguous (the 4-lanes-per-row mapping left the writes on a 2-way bank conflict)
-    constexpr int BTASK = BN * 12 / 256;
+    constexpr int BTASK = (BN * 12 + 255) / 256;                                   // (BN = 32: 384 segments, the second pass half empty)
     const size_t wrow = (size_t)9 * Kc;
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const float*>(p.w3), (size_t)p.N * wrow * 6);
     unsigned boff[BTASK], bdst[BTASK];
 #pragma unroll
     for (int i = 0; i < BTASK; ++i) {
-        const int t = tid + 256 * i, row = t / 12, seg = t % 12;
+        const int t = min(tid + 256 * i, BN * 12 - 1), row = t / 12, seg = t % 12;        // (surplus lanes repeat the last segment: same data, same slot)
         boff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * 6 + seg * 16);
         bdst[i] = (unsigned)(row * LDK * 4 + (seg ^ (CODEPS_HALO_SWZ ? (((row >> 2) ^ (row >> 3)) & 1) : 0)) * 16);    // k groups of rows 4 .. 11 swapped pairwise
     }
@@ -4046,6 +4048,21 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                                    p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
                                    MODE == MODE_FWD ? p.act : 0, out);
             }
+            return;
+        }
+    }
+    if constexpr (NP == 3 && WM == 4 && WN == 1 && TM == 2 && TN == 1 && BK == 32) {
+        // <= 32 output columns, 3x3 / stride 1 / zero padding on whole 8 x 32 tiles: the halo-tile kernel in its 4 x 1 wave form
+        static const int halo32 = getenv("CODEPS_HALO32") ? atoi(getenv("CODEPS_HALO32")) : 1;      // tuning experiments only
+        const int Hm_ = (MODE == MODE_FWD) ? p.Ho : p.H;
+        if (halo32 && halo3_shape_ok<MODE>(p) && Hm_ % 8 == 0 && (long long)p.n_mt * p.n_nt >= 256) {
+            constexpr size_t lds_h = std::max(((size_t)340 * (LDKp + (CODEPS_HALO_SWZ ? 4 : 0)) + (size_t)2 * BN * LDKp) * sizeof(float),
+                                              (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            auto kh = conv_halo3_kernel<MODE, 1, 4, 1>;
+            codeps_allow_lds((const void*)kh, 160 * 1024, "conv_halo3_kernel<4x1>");
+            p.ksplit = 1;
+            g_last_kernel = "conv_halo3_kernel<32 columns>";
+            hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
             return;
         }
     }

@@ -253,3 +253,40 @@ def test_fused_stem_bn_relu_pool_is_bit_identical(groups, hw):
     assert sum(ga is not None for ga in a[1]) >= 60
     for ga, gb in zip(a[1], b[1]):
         assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb))
+
+
+@pytest.mark.parametrize("case", [
+    # (batch, H, W, c0, c1, up0, co): <= 32 output channels on whole 8 x 32 tiles, >= 256 tiles -> conv_halo3_kernel in its 4 x 1 wave form
+    (4, 128, 128, 64, 0, False, 32),
+    (4, 128, 128, 32, 64, True, 32),       # the decoders' half-resolution stage: nearest x2 of 32 channels ++ 64 skip channels
+    (2, 128, 256, 96, 0, False, 24),       # 24 real output channels (padded to 32)
+])
+def test_halo_kernel_with_32_output_columns_against_float64(case):
+    """3 x 3 convolutions with <= 32 output channels (models/depth_head.py:60-71 at the half-resolution stage) on the halo-tile kernel:
+    forward against float64 within 3 x torch's own fp32 error, launch-to-launch identical."""
+    import ctypes
+    import torch.nn.functional as TF
+    from codeps_amd import functional as F
+    from codeps_amd._lib import lib
+    b, h, w, c0, c1, up0, co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x0 = torch.relu(torch.randn(b, c0, h // 2 if up0 else h, w // 2 if up0 else w, generator=g))
+    x1 = torch.relu(torch.randn(b, c1, h, w, generator=g)) if c1 else None
+    wt = torch.randn(co, c0 + c1, 3, 3, generator=g) * (2.0 / (9 * (c0 + c1))) ** 0.5
+    bias = torch.randn(co, generator=g) * 0.1
+    full = TF.interpolate(x0, scale_factor=2, mode="nearest") if up0 else x0
+    if c1:
+        full = torch.cat([full, x1], 1)
+    y64 = TF.elu(TF.conv2d(full.double(), wt.double(), bias.double(), padding=1))
+    y32 = TF.elu(TF.conv2d(full, wt, bias, padding=1))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)       # noqa: E731
+    lib().codeps_conv2d_last_kernel.restype = ctypes.c_char_p
+    outs = []
+    for _ in range(2):
+        y = F.conv2d(nhwc(x0), wt.to(DEV), bias.to(DEV), x1=nhwc(x1) if c1 else None, pad=1, up0=up0, act="elu")
+        assert lib().codeps_conv2d_last_kernel().decode() == "conv_halo3_kernel<32 columns>"
+        outs.append(y[..., :co].permute(0, 3, 1, 2).cpu())
+    assert torch.equal(outs[0], outs[1])
+    l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
+    e, t = l2(outs[0], y64), l2(y32, y64)
+    assert e <= 3 * t + 1e-9, f"{case}: {e:.3e} vs torch fp32 {t:.3e}"
