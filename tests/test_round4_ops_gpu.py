@@ -290,3 +290,59 @@ def test_halo_kernel_with_32_output_columns_against_float64(case):
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
     e, t = l2(outs[0], y64), l2(y32, y64)
     assert e <= 3 * t + 1e-9, f"{case}: {e:.3e} vs torch fp32 {t:.3e}"
+
+
+@pytest.mark.parametrize("case", [
+    # the pose encoder's layers at the size of BASELINE configs[2] (12 frame pairs): (kind, batch, H, W, ci, co)
+    ("s1", 12, 128, 256, 64, 64),          # layer1: wgrad_halo64s_kernel, double-buffered body
+    ("s1", 12, 32, 64, 256, 256),          # layer3
+    ("s2", 12, 128, 256, 64, 128),         # layer2.0.conv1: wgrad_s2_halo_kernel
+    ("stem", 12, 512, 1024, 6, 64),        # conv1: conv_stem74f_kernel + wgrad_stem74d_kernel
+])
+def test_full_size_weight_gradients_agree_with_the_f32_mfma_kernels(case):
+    """At the headline workload's own sizes the split-operand weight-gradient kernels of this round against this library's f32-MFMA
+    kernels on the same tensors (exact fp32 products, the yardstick of tests/test_precision_gpu.py): relative L2 difference at the
+    level of fp32 summation order, and linear in the incoming gradient."""
+    import ctypes
+    from codeps_amd import functional as F
+    from codeps_amd._lib import lib
+    kind, b, h, w, ci, co = case
+    g = torch.Generator().manual_seed(h + ci)
+    lib().codeps_conv2d_last_kernel.restype = ctypes.c_char_p
+    if kind == "stem":
+        frames = [torch.rand(b, 3, h, w, generator=g).to(DEV) for _ in range(2)]
+        wt = (torch.randn(co, ci, 7, 7, generator=g) * 0.05).to(DEV)
+        gy = torch.randn(b, h // 2, w // 2, co, generator=g).to(DEV)
+
+        def run(wgt, grad):
+            ww = wgt.detach().requires_grad_(True)
+            y = F.stem_conv2d(F.images_to_nhwc(frames, 8, F.STEM_XPAD), ww)
+            y.backward(grad)
+            return y.detach(), ww.grad
+        expect = "wgrad_stem74s_kernel"
+    else:
+        x = torch.relu(torch.randn(b, h, w, ci, generator=g)).to(DEV)
+        wt = (torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5).to(DEV)
+        st = 2 if kind == "s2" else 1
+        gy = torch.randn(b, h // st, w // st, co, generator=g).to(DEV)
+
+        def run(wgt, grad):
+            ww = wgt.detach().requires_grad_(True)
+            y = F.conv2d(x, ww, stride=st, pad=1)
+            y.backward(grad)
+            return y.detach(), ww.grad
+        expect = "wgrad_s2_halo_kernel" if kind == "s2" else "wgrad_halo64s_kernel"
+    y3, dw3 = run(wt, gy)
+    assert lib().codeps_conv2d_last_kernel().decode() == expect
+    _y, dw3b = run(wt, 0.5 * gy)
+    assert torch.equal(dw3b, 0.5 * dw3)                               # scaling by a power of two is exact in every product and sum
+    prev = lib().codeps_conv2d_set_arith(0)
+    try:
+        y0, dw0 = run(wt, gy)
+        assert "split" not in lib().codeps_conv2d_last_kernel().decode() and lib().codeps_conv2d_last_kernel().decode() != expect
+    finally:
+        lib().codeps_conv2d_set_arith(prev)
+    l2 = lambda a, r: float((a.double() - r.double()).norm() / r.double().norm())       # noqa: E731
+    assert l2(y3, y0) <= 2e-6, l2(y3, y0)
+    # (the stem sums 1.57 M pixels per weight: the two kernels' slab / summation orders differ by 5e-6 there, measured)
+    assert l2(dw3, dw0) <= (2e-5 if kind == "stem" else 2e-6), l2(dw3, dw0)
