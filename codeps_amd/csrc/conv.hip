@@ -2186,13 +2186,11 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
 // CO32 (layers with <= 32 output channels: the decoders' 1/2-resolution stages): one 32-row co tile, so the waves that would hold
 // the second co tile split the PIXELS instead -- wave = (pixel half ph, ci tile): output rows 2 ph, 2 ph + 1 of every tile -- and
 // each pixel half writes its own partial slab (the slab reduction sums them like any other split).
-// FAST (picked per block, wave-uniform): zero padding, whole 4 x 16 tiles, and the block's 64-channel chunk inside ONE source that is
-// not up-sampled.  Then every address is (scalar tile origin) + (per-thread constant), padding is the range check of the buffer
-// resource (an offset past its end reads 0), and a tile's 17 loads are straight-line code: ~20 vector instructions per tile
-// instead of ~770 (per-pixel reflect / up-sample / bounds arithmetic and an exec-mask branch per load, whose joins also made the
-// compiler wait for each group of loads before the tile's MFMAs).  Stamped in the diagnostic build, that code was 22-25 % of a
-// block's lifetime -- one wave per SIMD, nothing else to issue while it runs.
-template <bool CO32, bool FAST>
+// This is the GENERIC body (reflect padding, ragged maps, a chunk split between the sources elsewhere than at 32): per-pixel address
+// arithmetic behind exec-mask branches -- stamped in the diagnostic build (-DCODEPS_WG_STAMP_LOADS), issuing a tile's 17 loads that way
+// is 22-25 % of a block's lifetime, the split + store phase another 20 %.  Every block of the shipped configurations takes
+// wgrad_halo64d_body below instead.
+template <bool CO32>
 __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                    const float* __restrict__ x0, const float* __restrict__ x1,
                                                    const float* __restrict__ dz, float* __restrict__ part, unsigned short* lds16) {
@@ -2269,74 +2267,7 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
         }
         return f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // FAST: per-thread constants of the three tasks -- byte offset from the tile origin (its pixel (ty0, tx0), channel 0 of the
-    // source), the X row the task reads (relative to ty0) and whether its channel quad exists
-    const bool s1 = c_base >= p.C0;                                  // (block-uniform)
-    const float* xsrc = s1 ? x1 : x0;
-    const int xcs = s1 ? p.C1 : p.C0, xc0 = s1 ? c_base - p.C0 : c_base;
-    int f_off[2] = {0, 0}, f_row[2] = {0, 0}, f_offs = 0, f_rows = 0;
-    bool f_ok[2] = {false, false}, f_oks = false, f_side = false;
-    if (FAST) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int bt = tid + 256 * u;
-            int c4, grp;
-            if (bt < 128) {
-                task_of(bt, 8, c4, grp);
-                f_off[u] = (((grp >> 1) * p.Wo + (grp & 1) * 8) * p.Co + co_base + c4 * 4) * 4;
-                f_ok[u] = co_base + c4 * 4 < p.Co;
-            } else if (bt < 320) {
-                task_of(u == 0 ? xt0 : xt1, 12, c4, grp);
-                f_row[u] = (grp >> 1) - 1;
-                f_off[u] = ((f_row[u] * p.W + (grp & 1) * 8) * xcs + xc0 + c4 * 4) * 4;
-                f_ok[u] = xc0 + c4 * 4 < xcs;
-            }
-        }
-        if (tid >= 64) {
-            const int t = tid - 64, c4 = t & 15, rs = t >> 4, side = rs & 1;
-            f_rows = (rs >> 1) - 1;
-            f_side = side;
-            f_offs = ((f_rows * p.W + (side ? TW : -1)) * xcs + xc0 + c4 * 4) * 4;
-            f_oks = xc0 + c4 * 4 < xcs;
-        }
-    }
-    // the next tile's loads: fast_prep() = the scalar part (tile origin, buffer resources) and the three offsets; fast_issue(k) = load k of
-    // the 17 (0-7: big task 0 = dZ in waves 0, 1, X in waves 2, 3; 8-15: big task 1 = X rows, wave 0; 16: the halo pixels, waves 1-3).
-    // EVERY wave issues all 17: a lane without the task has f_ok = false and reads zeros through the range check (a wave-uniform branch
-    // made the compiler load into temporaries and copy them -- behind s_waitcnt vmcnt(0) -- in front of the MFMAs), and `valid` = false
-    // (no next tile) does the same for all lanes, so the tile loop has no branch around its loads.
-    __amdgpu_buffer_rsrc_t f_rs0, f_rsx;
-    unsigned f_vo0 = 0, f_vo1 = 0, f_vos = 0;
-    int f_pix0 = 0, f_pixx = 0;
-    auto fast_prep = [&](int tile, bool valid) {
-        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);             // (scalar)
-        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
-        const size_t zimg = (size_t)p.Ho * p.Wo * p.Co, ximg = (size_t)p.H * p.W * xcs;
-        const __amdgpu_buffer_rsrc_t rsz = make_rsrc(dz + (size_t)b * zimg, zimg * 4);
-        f_rsx = make_rsrc(xsrc + (size_t)b * ximg, ximg * 4);
-        const int zorg = (ty0 * p.Wo + tx0) * p.Co * 4, xorg = (ty0 * p.W + tx0) * xcs * 4;
-        const bool isz = __builtin_amdgcn_readfirstlane(wave) < 2;
-        f_rs0 = isz ? rsz : f_rsx;
-        f_pixx = xcs * 4;
-        f_pix0 = isz ? p.Co * 4 : f_pixx;
-        const int org0 = isz ? zorg : xorg;
-        f_vo0 = (valid && f_ok[0] && (unsigned)(ty0 + f_row[0]) < (unsigned)p.H) ? (unsigned)(org0 + f_off[0]) : GATHER_OOB;
-        f_vo1 = (valid && f_ok[1] && (unsigned)(ty0 + f_row[1]) < (unsigned)p.H) ? (unsigned)(xorg + f_off[1]) : GATHER_OOB;
-        const bool oks = valid && f_oks && (unsigned)(ty0 + f_rows) < (unsigned)p.H && (f_side ? tx0 + TW < p.W : tx0 > 0);
-        f_vos = oks ? (unsigned)(xorg + f_offs) : GATHER_OOB;
-    };
-    auto fast_issue = [&](int k) {
-        if (k < 8) bigr[0][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rs0, f_vo0, k * f_pix0, 0));
-        else if (k < 16) bigr[1][k - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsx, f_vo1, (k - 8) * f_pixx, 0));
-        else smallr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsx, f_vos, 0, 0));
-    };
-    auto load_tile_fast = [&](int tile) {
-        fast_prep(tile, true);
-#pragma unroll
-        for (int k = 0; k < 17; ++k) fast_issue(k);
-    };
     auto load_tile = [&](int tile) {
-        if (FAST) { load_tile_fast(tile); return; }
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
 #pragma unroll
@@ -2409,13 +2340,7 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
         __syncthreads();
         CODEPS_STAMP_PHASE_B();                                     // B: barrier + (wait for the loads) split + transpose + LDS stores + barrier
         CODEPS_STAMP_PHASE_START();
-#ifdef CODEPS_WG_NOSPREAD                                            // (variant builds: the A/B of the spread form)
-        constexpr bool SPREAD = false;
-#else
-        constexpr bool SPREAD = FAST && !CO32;                      // the next tile's loads and the next row's fragment reads ride under the MFMAs
-#endif
-        if (SPREAD) fast_prep(min(tile + 1, t_end - 1), tile + 1 < t_end);
-        else if (tile + 1 < t_end) load_tile(tile + 1);
+        if (tile + 1 < t_end) load_tile(tile + 1);
 #ifdef CODEPS_WG_STAMP_LOADS                                         // diagnostic split of phase A: A = issuing the next tile's loads only
         CODEPS_STAMP_PHASE_A();
 #endif
@@ -2426,33 +2351,15 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
 #pragma unroll
             for (int q = 0; q < 3; ++q) zf[py][q] = *reinterpret_cast<const bf16x8*>(zrow + q * PIX + py * TW);
         }
-        i32x4 xraw[2][3][3];                                        // [row parity][piece][prev | cur | next]: 16-byte groups of one X row
-        auto read_row = [&](int r) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const unsigned short* g0 = xrow + q * XQ + r * XROW;
-                xraw[r & 1][q][0] = *reinterpret_cast<const i32x4*>(g0);
-                xraw[r & 1][q][1] = *reinterpret_cast<const i32x4*>(g0 + 8);
-                xraw[r & 1][q][2] = *reinterpret_cast<const i32x4*>(g0 + 16);
-            }
-        };
-        if (SPREAD) read_row(0);
 #pragma unroll
         for (int r = 0; r < XH; ++r) {
             if (CO32 && (r < 2 * ph || r > 2 * ph + 3)) continue;   // X rows this wave's two output rows read
-            if (SPREAD) {
-                // a 16-byte buffer load occupies the CU's address path for ~16 cycles per wave: seventeen of them issued in one burst by
-                // all four waves stalled each wave for 1.5-1.9 k cycles per tile (stamped); three per X row disappear under that row's MFMAs
-                if (r + 1 < XH) read_row(r + 1);
-#pragma unroll
-                for (int k = 3 * r; k < min(3 * r + 3, 17); ++k) fast_issue(k);
-                __builtin_amdgcn_sched_barrier(0);                  // (left alone, the scheduler sinks the reads to the end of the region)
-            } else
-                read_row(r);
             bf16x8 xf[3][3];                                         // [kx][piece]
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const i32x4 prev = xraw[r & 1][q][0], cur = xraw[r & 1][q][1], next = xraw[r & 1][q][2];
+                const unsigned short* g0 = xrow + q * XQ + r * XROW;
+                const i32x4 prev = *reinterpret_cast<const i32x4*>(g0), cur = *reinterpret_cast<const i32x4*>(g0 + 8),
+                            next = *reinterpret_cast<const i32x4*>(g0 + 16);
                 i32x4 left, right;
                 left[0] = (int)__builtin_amdgcn_alignbit((unsigned)cur[0], (unsigned)prev[3], 16);
                 right[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)cur[3], 16);
@@ -2477,7 +2384,6 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
                         for (int qa = 0; qa <= ord; ++qa)
                             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[py][qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
             }
-            if (SPREAD) __builtin_amdgcn_sched_barrier(0);          // keep the row regions apart: loads and reads of a region lead its MFMAs
         }
 #ifndef CODEPS_WG_STAMP_LOADS
         CODEPS_STAMP_PHASE_A();                                     // A: next tile's loads issued + fragment reads + 216 MFMAs of this wave
@@ -2498,8 +2404,14 @@ __device__ __forceinline__ void wgrad_halo64s_body(const WgradP& p, int ci_chunk
     CODEPS_STAMP_END(conv);
 }
 
-// The FAST blocks of the 64-row form, double-buffered (wgrad_halo64s_body spends a quarter of a block's lifetime staging -- split,
-// transpose, LDS stores between two barriers -- with the matrix pipe idle: one wave per SIMD, nothing else to issue).  Here a 4 x 16
+#ifndef WG_FILL
+#define WG_FILL 4                                       // staging instructions offered to the scheduler per MFMA (A/B builds: 3 and 5 measured slower)
+#endif
+
+// The blocks with constant-offset addressing (p.fast, see the kernel wrapper), double-buffered (wgrad_halo64s_body spends a quarter
+// of a block's lifetime staging -- split, transpose, LDS stores between two barriers -- and as much issuing its loads, with the
+// matrix pipe idle: one wave per SIMD, nothing else to issue).  Every address here is (scalar tile origin) + (per-thread constant),
+// padding is the range check of the buffer resource (an offset past its end reads 0).  A 4 x 16
 // tile is two 2 x 16 sub-tiles and LDS holds two of them (2 x 66 KB): while the waves run the 108 MFMAs of sub-tile j from one
 // buffer, the same waves split and store sub-tile j + 1 into the other between those MFMAs (vector slots the MFMAs leave free) and
 // issue the loads of sub-tile j + 2 into the second register set -- one barrier per sub-tile (in front of its last 18 MFMAs, which
@@ -2525,9 +2437,6 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
     constexpr int XQ = XH * XROW, XP = 3 * XQ + 8;     // halfwords per X piece / per X channel (392: 196 dwords)
     constexpr int XS0 = 64 * ZP;                       // X rows start behind the dZ rows
     constexpr int BUF = 64 * (ZP + XP);               // halfwords per buffer: [64][ZP] dZ, [64][XP] X
-#ifndef WG_FILL
-#define WG_FILL 4
-#endif
     CODEPS_STAMP_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int wco = CO32 ? 0 : (wave & 1), wci = wave >> 1;
@@ -2850,15 +2759,10 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
                                                             const float* __restrict__ dz, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
     const int c_base = (blockIdx.x % ci_chunks) * 64;
-    // p.fast: the layer-wide conditions (host); per block: the chunk lies in one source, and that source is not up-sampled
-    const bool one_src = c_base >= p.C0 || p.C1 == 0 || c_base + 64 <= p.C0, up = p.up0 && c_base < p.C0;
-    const bool fast = p.fast && one_src && !up;
-#ifndef CODEPS_WG_NODBUF                                             // (variant builds: the A/B of the double-buffered body)
-    // double-buffered body: each 32-channel half of the chunk in one source
-    if (p.fast && (one_src || c_base + 32 == p.C0)) { wgrad_halo64d_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16); return; }
-#endif
-    if (fast) wgrad_halo64s_body<CO32, true>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
-    else wgrad_halo64s_body<CO32, false>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+    const bool one_src = c_base >= p.C0 || p.C1 == 0 || c_base + 64 <= p.C0;
+    // p.fast: the layer-wide conditions (host); per block: each 32-channel half of the chunk in one source -> the double-buffered body
+    if (p.fast && (one_src || c_base + 32 == p.C0)) wgrad_halo64d_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+    else wgrad_halo64s_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
 }
 
 // Weight gradient of the double-pixel stem (7 x 4 taps of 16 channels, stride (2, 1), 64 output channels) on the bf16 matrix
