@@ -214,6 +214,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
         res_load(s + 1, rnext);                                // (one past the last stage: columns of the next slice or the next row, or past the slab -> zeros; never used)
         if (s > 0 && 2 * s + 2 < 2 * NS) dma_tile(2 * s + 2);  // into the slot of tile 2 s - 1
         const char* et = arow + ((2 * s) % 3) * TILE_B;
+        CODEPS_STAMP_PHASE_START();
         f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
                     for (int qa = 0; qa <= ord; ++qa)
                         acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[qa], yf[ks][ord - qa], acc2[nt], 0, 0, 0);
             }
+        CODEPS_STAMP_PHASE_A();                                // A: fragment reads + the 96 MFMAs of the expand stage
         // epilogue of the expand in registers: lane = pixel l16, channels 32 s + 16 nt + 4 kg + r; the affine record sits in the
         // pad of row (k-step 0, channel) of the E tile
         f32x4 v[2];
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
         __syncthreads();                                       // tile 2 s + 1 is in LDS; every wave has read tile 2 s
         if (2 * s + 3 < 2 * NS) dma_tile(2 * s + 3);           // into the slot of tile 2 s
         const char* rt = arow + ((2 * s + 1) % 3) * TILE_B;
+        CODEPS_STAMP_PHASE_START();
 #pragma unroll
         for (int jt = 0; jt < 16; ++jt) {
             const char* a = rt + jt * 16 * ROWB;
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
                 for (int qa = 0; qa <= ord; ++qa)
                     acc3[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[qa], of[ord - qa], acc3[jt], 0, 0, 0);
         }
+        CODEPS_STAMP_PHASE_B();                                // B: fragment reads + the 96 MFMAs of the reduce k-step
     };
     for (int s = 0; s < NS; s += 2) {                          // NS is even (n2 % 64 == 0)
         stage(s, rA, rB);
