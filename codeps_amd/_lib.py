@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
 LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 8
+ABI_VERSION = 9
 DIAG_LIB_PATH = os.path.join(_HERE, "libcodeps_diag.so")
 
 _lib = None
@@ -29,6 +29,15 @@ class CodepsHipError(RuntimeError):
 class PhotometricDesc(Structure):
     _fields_ = [("batch", c_int32), ("height", c_int32), ("width", c_int32), ("num_scales", c_int32),
                 ("alpha", c_float), ("noise_seed", c_uint64)]
+
+
+class ConvEpilogue(Structure):
+    """codeps_conv_epilogue (include/codeps_hip.h): gate + per-tile statistics of a forward / data-gradient launch's epilogue."""
+    _fields_ = [("gate", c_void_p), ("gate_act", c_int32), ("stat_mode", c_int32), ("stat_part", c_void_p), ("stat_part_bytes", c_size_t),
+                ("bn_x", c_void_p), ("bn_mean", c_void_p), ("bn_invstd", c_void_p), ("bn_gamma", c_void_p), ("bn_beta", c_void_p),
+                ("bn_relu", c_int32), ("bn_groups", c_int32), ("bn_group_b0", c_int32 * 8),
+                ("applied", c_int32), ("n_seg", c_int32), ("seg_tile0", c_int32 * 4), ("seg_tiles_per_image", c_int32 * 4),
+                ("seg_tile_rows", c_int32 * 4), ("seg_tiles", c_int32 * 4)]
 
 
 class ConvDesc(Structure):
@@ -77,6 +86,9 @@ SIGNATURES = {
     "codeps_conv2d_dgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc), I]),
     "codeps_conv2d_dgrad": (c_int, [POINTER(ConvDesc), I, P, P, P, P, c_size_t, P]),
     "codeps_conv2d_dgrad_add": (c_int, [POINTER(ConvDesc), I, P, P, P, P, P, c_size_t, P]),
+    "codeps_conv2d_epilogue_part_bytes": (c_size_t, [LL, I, I]),
+    "codeps_conv2d_fwd_ex": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, POINTER(ConvEpilogue), P]),
+    "codeps_conv2d_dgrad_ex": (c_int, [POINTER(ConvDesc), I, P, P, P, P, P, c_size_t, POINTER(ConvEpilogue), P]),
     "codeps_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, I, I, I, P, c_size_t, P]),
     "codeps_chain1x1_w2_row_bytes": (c_size_t, []),
@@ -95,8 +107,11 @@ SIGNATURES = {
     "codeps_bn_fwd_mg": (c_int, [P, I, P, P, I, I, P, P, P, I, c_float, c_float, P, P, P, P, P, P, I, I, P, c_size_t, P]),
     "codeps_bn_sync_combine": (c_int, [P, I, I, P, P, I, I, c_float, c_float, P, P, P, P, P, P]),
     "codeps_bn_bwd_mg": (c_int, [P, P, P, I, P, P, I, I, P, P, P, P, P, I, P, P, P, I, P, P, I, I, P, c_size_t, P]),
+    "codeps_colsum_finish": (c_int, [P, I, I, P, I, I, P]),
+    "codeps_bn_finalize_tiles": (c_int, [P, I, I, I, I, P, P, I, c_float, P, P, P, P]),
+    "codeps_bn_bwd_tiles": (c_int, [P, I, P, P, P, I, P, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, P, I, P]),
     "codeps_bn_relu_pool_fwd": (c_int, [P, I, P, P, I, I, I, I, P, P, P, P, P, P, P]),
-    "codeps_bn_relu_pool_bwd": (c_int, [P, P, P, I, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, P, c_size_t, P]),
+    "codeps_bn_relu_pool_bwd": (c_int, [P, P, P, I, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, P, c_size_t, I, P]),
     "codeps_maxpool3x3s2_fwd": (c_int, [P, I, I, I, I, P, P, P]),
     "codeps_maxpool3x3s2_bwd": (c_int, [P, P, I, I, I, I, P, P]),
     "codeps_dwconv5x5": (c_int, [P, P, P, P, I, I, I, I, I, I, P, P]),

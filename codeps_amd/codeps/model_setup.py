@@ -30,8 +30,10 @@ def _geometry_part(cfg, device, enc_channels, adaptation: bool, label_mode, eval
     recon = {k: (algos.ReconstructionLoss(hw[1], hw[0], ssim, cfg.depth.num_recon_scales, device) if hw is not None else None)
              for k, hw in sizes.items()}
     algo = algos.DepthAlgo(recon["target"], algos.EdgeAwareSmoothnessLoss(), evaluator, None, None, recon["source"], label_mode)
-    return (pose_encoder, models.DepthHead(enc_channels, use_skips=True),
-            models.PoseHead(pose_encoder.num_ch_enc, num_input_features=1, num_frames_to_predict_for=2), algo)
+    depth_head = models.DepthHead(enc_channels, use_skips=True)         # (construction order = the reference's: same random initialisation)
+    pose_head = models.PoseHead(pose_encoder.num_ch_enc, num_input_features=1, num_frames_to_predict_for=2)
+    pose_head.owns_input = True                    # ... and is that map's only reader (algos/depth.py:408-420)
+    return pose_encoder, depth_head, pose_head, algo
 
 
 def _semantic_part(cfg, device, enc_channels, n_classes: int, ignore: List[int], evaluator) -> Tuple[Any, Any]:

@@ -69,6 +69,18 @@ struct ConvP {
     // weights of this launch pre-split into three bf16 pieces ([row][K group of 32][piece][32], written by the weight pack
     // behind its fp32 part); the 3-piece kernel stages its B operand from here with plain copies
     const void* w3;
+    // epilogue extras (codeps_conv_epilogue; all optional, applied to the value the epilogue is about to store, after the residual /
+    // second-gradient add):  a GATE  v *= g'  and per-M-tile COLUMN STATISTICS of the gated v
+    const float* ex_gate;       // gate 1 / 2: the activation's output [M][N];  gate 3: the block output when a residual fed the ReLU (else null)
+    int ex_gate_act;            // 0 none, 1 ReLU' (gate > 0), 2 ELU' (gate > 0 ? 1 : gate + 1), 3 train-mode BatchNorm (+ ReLU) backward
+    int ex_stat;                // 0 none, 1 (shift, sum (v - shift), sum (v - shift)^2), 2 sum v, 3 (sum v, sum v * xhat)
+    float* ex_part;             // [tile][rows of the mode][N]
+    int ex_tile0;               // tile index of this launch's first M tile (the stride-2 parity classes are four launches)
+    int ex_img_rows;            // gate 3 / stat 1 with the generic kernels: GEMM rows per image (a multiple of the tile's rows)
+    const float* ex_bn_x;       // gate 3: BatchNorm's input z [M][N], mean / invstd [groups][N], gamma / beta [N]
+    const float* ex_bn_mean; const float* ex_bn_invstd; const float* ex_bn_gamma; const float* ex_bn_beta;
+    int ex_bn_relu, ex_bn_ng;
+    int ex_bn_b0[8];            // first image of every statistic group
 };
 
 
@@ -127,6 +139,79 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return v > 0.f ? v : 0.f;
     if (act == 2) return v > 0.f ? v : expm1f(v);
     return v;
+}
+
+// ---- epilogue extras (ConvP.ex_*).  Per thread: the column quad n .. n + 3 of some rows of ONE M tile whose rows lie in one image.
+struct EpiCtx { f32x4 sh, s1, s2, mu, is, ga, be; };
+
+// img: image of the tile (block-uniform); n: first column of this thread's quad (n < p.N)
+__device__ __forceinline__ void epi_begin(const ConvP& p, EpiCtx& ec, int img, int n) {
+    ec.sh = ec.s1 = ec.s2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    ec.mu = ec.be = f32x4{0.f, 0.f, 0.f, 0.f};
+    ec.is = ec.ga = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (p.ex_gate_act == 3 && n < p.N) {
+        int g = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) g += (i < p.ex_bn_ng && img >= p.ex_bn_b0[i]) ? 1 : 0;
+        ec.mu = *reinterpret_cast<const f32x4*>(p.ex_bn_mean + (size_t)g * p.N + n);
+        ec.is = *reinterpret_cast<const f32x4*>(p.ex_bn_invstd + (size_t)g * p.N + n);
+        if (p.ex_bn_relu && !p.ex_gate) {
+            ec.ga = *reinterpret_cast<const f32x4*>(p.ex_bn_gamma + n);
+            ec.be = *reinterpret_cast<const f32x4*>(p.ex_bn_beta + n);
+        }
+    }
+}
+
+// v = the value about to be stored at out[idx]: gate it, account for it in the tile's statistics
+__device__ __forceinline__ f32x4 epi_apply(const ConvP& p, EpiCtx& ec, f32x4 v, size_t idx) {
+    if (p.ex_gate_act == 1 || p.ex_gate_act == 2) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.ex_gate + idx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= g[e] > 0.f ? 1.f : (p.ex_gate_act == 2 ? g[e] + 1.f : 0.f);      // = act_bwd_kernel's product
+    }
+    if (p.ex_gate_act == 3) {
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(p.ex_bn_x + idx) - ec.mu) * ec.is;
+        if (p.ex_bn_relu) {
+            const f32x4 yy = p.ex_gate ? *reinterpret_cast<const f32x4*>(p.ex_gate + idx) : xh * ec.ga + ec.be;    // bn_bwd_reduce_mg_kernel's mask
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = yy[e] > 0.f ? v[e] : 0.f;
+        }
+        if (p.ex_stat == 3) { ec.s1 += v; ec.s2 += v * xh; }
+    }
+    if (p.ex_stat == 1) { const f32x4 d = v - ec.sh; ec.s1 += d; ec.s2 += d * d; }
+    if (p.ex_stat == 2) ec.s1 += v;
+    return v;
+}
+
+// After the last store: the tile's statistics -> p.ex_part[tile][rows][N].  Threads tid = k * V4 + c4 (k < RPASS) hold column quad c4;
+// `red` = 2 * (threads of the block) f32x4 of LDS nobody reads any more (a barrier is taken first).  Fixed summation order.
+__device__ __forceinline__ void epi_flush(const ConvP& p, const EpiCtx& ec, float* red, int tid, int V4, int RPASS, int tile, int n) {
+    if (!p.ex_stat) return;
+    const int NT = V4 * RPASS;                                     // threads of the block (256, or 512 in the wave-specialised kernel)
+    __syncthreads();
+    f32x4* r = reinterpret_cast<f32x4*>(red);
+    r[tid] = ec.s1; r[NT + tid] = ec.s2;
+    __syncthreads();
+    if (tid < V4 && n < p.N) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < RPASS; ++k) { a += r[k * V4 + tid]; b += r[NT + k * V4 + tid]; }
+        const int rows = p.ex_stat == 1 ? 3 : (p.ex_stat == 2 ? 1 : 2);
+        float* dst = p.ex_part + ((size_t)(p.ex_tile0 + tile) * rows) * p.N + n;
+        if (p.ex_stat == 1) {
+            *reinterpret_cast<f32x4*>(dst) = ec.sh; *reinterpret_cast<f32x4*>(dst + p.N) = a; *reinterpret_cast<f32x4*>(dst + 2 * (size_t)p.N) = b;
+        } else {
+            *reinterpret_cast<f32x4*>(dst) = a;
+            if (p.ex_stat == 3) *reinterpret_cast<f32x4*>(dst + p.N) = b;
+        }
+    }
+}
+
+// The extras are compiled into the EX = true instantiation of a kernel only: with them in every instantiation the epilogue, not the
+// K loop, set the register count (conv_igemm_kernel 128 x 128: 166 -> 176 registers, 3 -> 2 waves per SIMD).
+template <bool EX>
+__device__ __forceinline__ f32x4 epi_apply_t(const ConvP& p, EpiCtx& ec, f32x4 v, size_t idx) {
+    if constexpr (EX) return epi_apply(p, ec, v, idx);
+    else return v;
 }
 
 // XCD-aware bijective block remap (guide T1): blocks with equal blockIdx % 8 share an XCD.
@@ -197,7 +282,7 @@ __device__ __forceinline__ void build_gather(const ConvP& p, int m0, int ntap, u
 
 // One implicit-GEMM kernel for forward and dgrad.
 //   A rows: pixels.  B rows: GEMM columns n (weights packed [n][tap][c], c contiguous).
-template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF, int NP = 0>
+template <int MODE, int WM, int WN, int TM, int TN, int BK, int NBUF, int NP = 0, bool EX = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* __restrict__ a0,
                                                          const float* __restrict__ a1, const float* __restrict__ wq,
                                                          const float* __restrict__ scale,
@@ -433,6 +518,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
         if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
     }
+    EpiCtx ec;
+    if constexpr (EX) epi_begin(p, ec, p.ex_img_rows ? m0 / p.ex_img_rows : 0, n);
     // one pass per row-tile index i: staging holds WM*32 rows (keeps the LDS footprint at <= 34 KB so that the
     // K-loop buffers, not the epilogue, decide how many blocks fit on a CU)
 #pragma unroll
@@ -457,6 +544,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
             }
         }
         __syncthreads();
+        if constexpr (EX) if (i == 0 && p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + c4 * 4) * sc + sh;     // the tile's first row = the statistics' shift
         if (n < p.N) {
 #pragma unroll
             for (int u = 0; u < NRES; ++u) {
@@ -481,10 +569,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                 } else if (residual) {                        // data gradient + the gradient that reached the same tensor by another path
                     v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
                 }
-                *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+                *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = epi_apply_t<EX>(p, ec, v, (size_t)m * p.N + n);
             }
         }
     }
+    if constexpr (EX) epi_flush(p, ec, smem, tid, V4, RPASS, mt, n);
     CODEPS_STAMP_END(conv);
 }
 
@@ -495,7 +584,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 // buffered, ONE barrier per K-step.  In the 256-thread kernel every wave runs load -> convert -> write -> barrier -> read ->
 // MFMA -> barrier in sequence and the matrix pipe idles ~63 % of the time (PMC); here a SIMD's producer wave
 // converts and writes K-step s + 1 while its consumer wave multiplies K-step s.
-template <int MODE, int TN>
+template <int MODE, int TN, bool EX = false>
 __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ residual, float* __restrict__ out) {
@@ -641,6 +730,8 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
         if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
         if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
     }
+    EpiCtx ec;
+    if constexpr (EX) epi_begin(p, ec, p.ex_img_rows ? m0 / p.ex_img_rows : 0, n);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if (i > 0) __syncthreads();
@@ -652,6 +743,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
                     Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
         }
         __syncthreads();
+        if constexpr (EX) if (i == 0 && p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + c4 * 4) * sc + sh;
         if (n < p.N) {
 #pragma unroll 2
             for (int rr = r0; rr < WM * 32; rr += RPASS) {
@@ -674,10 +766,11 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
                 } else if (residual) {
                     v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
                 }
-                *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+                *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = epi_apply_t<EX>(p, ec, v, (size_t)m * p.N + n);
             }
         }
     }
+    if constexpr (EX) epi_flush(p, ec, smem, tid, V4, RPASS, mt, n);
 }
 
 // ---------------------------------------------------------------------------------- halo-tile variant (3x3, stride 1)
@@ -689,7 +782,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
 // MODE_DGRAD (stride 1): input pixel p sums dZ(p + (1 - ky, 1 - kx)) x W[ci][tap][co]: the same kernel with mirrored taps.
 // WM x WN waves: 2 x 2 = 4 x 32 output pixels x (64 TN) columns (two blocks per CU at TN = 1); 4 x 1 (round 4) = 8 x 32 pixels x 32
 // columns for the layers with <= 32 output channels (the decoders' half-resolution stage), which the generic kernel ran at 84-119 TFLOP/s.
-template <int MODE, int TN, int WM = 2, int WN = 2>
+template <int MODE, int TN, int WM = 2, int WN = 2, bool EX = false>
 __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ residual, float* __restrict__ out) {
@@ -851,6 +944,8 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
         if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
         if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
     }
+    EpiCtx ec;
+    if constexpr (EX) epi_begin(p, ec, b, n);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if (i > 0) __syncthreads();
@@ -863,6 +958,7 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
                 for (int r = 0; r < 4; ++r)
                     Cs[(wm * 32 + ih * 16 + 4 * kg + r) * LDC + (wn * NB + j) * 16 + l16] = acc[2 * i + ih][j][r];
         __syncthreads();
+        if constexpr (EX) if (i == 0 && p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + c4 * 4) * sc + sh;     // the tile's first row = the statistics' shift
         if (n < p.N) {
 #pragma unroll 4
             for (int rr = r0; rr < WM * 32; rr += RPASS) {
@@ -877,10 +973,11 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
                 } else if (residual) {
                     v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
                 }
-                *reinterpret_cast<f32x4*>(out + m * p.N + n) = v;
+                *reinterpret_cast<f32x4*>(out + m * p.N + n) = epi_apply_t<EX>(p, ec, v, m * p.N + n);
             }
         }
     }
+    if constexpr (EX) epi_flush(p, ec, smem, tid, V4, RPASS, mt, n);
 }
 
 // ---------------------------------------------------------------------------------- halo-tile variant, weights by LDS DMA
@@ -902,7 +999,7 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 #define CODEPS_ABLATE_RING 0
 #endif
 
-template <int MODE, int TN>
+template <int MODE, int TN, bool EX = false>
 __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ residual, float* __restrict__ out) {
@@ -1138,6 +1235,8 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
         if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
         if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
     }
+    EpiCtx ec;
+    if constexpr (EX) epi_begin(p, ec, b, n);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         __syncthreads();
@@ -1149,6 +1248,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
                 for (int r = 0; r < 4; ++r)
                     Cs[(wm * 32 + ih * 16 + 4 * kg + r) * LDC + (wn * NB + j) * 16 + l16] = acc[2 * i + ih][j][r];
         __syncthreads();
+        if constexpr (EX) if (i == 0 && p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + c4 * 4) * sc + sh;     // the tile's first row = the statistics' shift
         if (n < p.N) {
 #pragma unroll 4
             for (int rr = r0; rr < WM * 32; rr += RPASS) {
@@ -1167,10 +1267,11 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
                 } else if (residual) {
                     v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
                 }
-                *reinterpret_cast<f32x4*>(out + m * p.N + n) = v;
+                *reinterpret_cast<f32x4*>(out + m * p.N + n) = epi_apply_t<EX>(p, ec, v, m * p.N + n);
             }
         }
     }
+    if constexpr (EX) if (p.ksplit <= 1) epi_flush(p, ec, smem, tid, V4, RPASS, mt, n);
     CODEPS_STAMP_END(conv);
 }
 
@@ -1599,7 +1700,7 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
     }
 }
 
-template <int MODE, int BK>
+template <int MODE, int BK, bool EX = false>
 __global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                            const float* __restrict__ wq, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ residual,
@@ -1667,12 +1768,15 @@ __global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float*
     __syncthreads();
     const int c4 = tid & 3, r0 = tid >> 2;                   // 4 float4 per row, 64 rows per pass
     const int n = c4 * 4;
+    EpiCtx ec;
+    if constexpr (EX) epi_begin(p, ec, p.ex_img_rows ? m0 / p.ex_img_rows : 0, n);
     if (n < p.N) {
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (MODE == MODE_FWD) {
             if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
             if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
         }
+        if constexpr (EX) if (p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + n) * sc + sh;
 #pragma unroll
         for (int rr = r0; rr < BM; rr += 64) {
             const int m = m0 + rr;
@@ -1686,15 +1790,16 @@ __global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float*
             } else if (residual) {
                 v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
             }
-            *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+            *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = epi_apply_t<EX>(p, ec, v, (size_t)m * p.N + n);
         }
     }
+    if constexpr (EX) epi_flush(p, ec, Cs, tid, 4, 64, blockIdx.x, n);
 }
 
 // LDS-staged flavour of the 16-column kernel for deep K (e.g. the 240-channel GUDA conv): full 128-B row segments are
 // fetched once per K-step by 8 adjacent lanes and re-read from LDS as fragments, which keeps the texture path off the
 // critical path when K per tap is large; the register-direct flavour above wins for the K = 144 decoder tail.
-template <int MODE, int BK>
+template <int MODE, int BK, bool EX = false>
 __global__ __launch_bounds__(256) void conv_igemm16_lds_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                                const float* __restrict__ wq, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ residual,
@@ -1812,12 +1917,15 @@ __global__ __launch_bounds__(256) void conv_igemm16_lds_kernel(ConvP p, const fl
     __syncthreads();
     const int c4 = tid & 3, r0 = tid >> 2;
     const int n = c4 * 4;
+    EpiCtx ec;
+    if constexpr (EX) epi_begin(p, ec, p.ex_img_rows ? m0 / p.ex_img_rows : 0, n);
     if (n < p.N) {
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (MODE == MODE_FWD) {
             if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
             if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
         }
+        if constexpr (EX) if (p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + n) * sc + sh;
 #pragma unroll
         for (int rr = r0; rr < BM; rr += 64) {
             const int m = m0 + rr;
@@ -1831,9 +1939,10 @@ __global__ __launch_bounds__(256) void conv_igemm16_lds_kernel(ConvP p, const fl
             } else if (residual) {
                 v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
             }
-            *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+            *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = epi_apply_t<EX>(p, ec, v, (size_t)m * p.N + n);
         }
     }
+    if constexpr (EX) epi_flush(p, ec, Cs, tid, 4, 64, blockIdx.x, n);
 }
 
 // ---------------------------------------------------------------------------------- wgrad
@@ -3818,11 +3927,38 @@ static ConvP make_convp(const codeps_conv_desc* d) {
     return p;
 }
 
+// What the launches of the current entry-point call did with the requested epilogue extras (codeps_conv_epilogue's out fields)
+struct EpiOut { int applied, n_seg, tile0[4], tpi[4], rows[4], tiles[4]; };
+static thread_local EpiOut g_epi;
+
+// Called by every launch site once the tile shape and the K split are known.  Statistics and the BatchNorm gate need every M tile
+// inside one image and no K slices; when that fails they are dropped together (the caller then runs the separate kernels on an
+// UNGATED result: applied bit 0 stays clear).  Plain activation gates (1 / 2) survive split-K (splitk_finish_kernel applies them).
+static bool epi_plan(ConvP& p, int tile_rows, bool supported = true) {
+    if (!p.ex_gate_act && !p.ex_stat) return false;
+    if (!supported) { p.ex_gate = nullptr; p.ex_gate_act = 0; p.ex_stat = 0; return false; }     // (a kernel form without the EX instantiation)
+    const bool bn = p.ex_gate_act == 3;
+    bool ok = p.ksplit <= 1;
+    if (ok && (bn || p.ex_stat == 1) && (p.ex_img_rows <= 0 || p.ex_img_rows % tile_rows != 0)) ok = false;
+    if (!ok) {
+        if (bn) { p.ex_gate = nullptr; p.ex_gate_act = 0; }
+        p.ex_stat = 0;
+    }
+    if (p.ex_gate_act) g_epi.applied |= 1;
+    if (p.ex_stat && g_epi.n_seg < 4) {
+        g_epi.applied |= 2;
+        const int k = g_epi.n_seg++;
+        g_epi.tile0[k] = p.ex_tile0; g_epi.rows[k] = tile_rows; g_epi.tiles[k] = p.n_mt;
+        g_epi.tpi[k] = p.ex_img_rows > 0 ? p.ex_img_rows / tile_rows : 0;
+    }
+    return p.ksplit <= 1 && (p.ex_gate_act || p.ex_stat);          // true: launch the kernel's EX instantiation (K slices: the finish pass gates)
+}
+
 // K slices a launch of `blocks` tiles with `nsteps` K-steps is cut into (1 = no split-K); shared by the cost model and the launcher
 static int splitk_slices(const ConvP& p, int blocks, int nsteps) {
     static const int sk_blocks = getenv("CODEPS_SPLITK_BLOCKS") ? atoi(getenv("CODEPS_SPLITK_BLOCKS")) : 192;   // env: tuning experiments only
     static const int sk_target = getenv("CODEPS_SPLITK_TARGET") ? atoi(getenv("CODEPS_SPLITK_TARGET")) : 512;
-    if (!p.part || blocks >= sk_blocks || nsteps < 16) return 1;
+    if (!p.part || p.par || blocks >= sk_blocks || nsteps < 16) return 1;      // (the parity-class rows are not the output's rows: no K slices there)
     int ks = std::min(std::min(sk_target / blocks, nsteps / 8), 16);
     while (ks >= 2 && (size_t)ks * p.M * p.N * sizeof(float) > p.part_bytes) --ks;
     return std::max(ks, 1);
@@ -3851,7 +3987,8 @@ static int halo_splitk_slices(const ConvP& p, int blocks, int nchunks) {
 // split-K finish: out = act((sum_z part[z]) * scale + shift + residual), fixed summation order
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, long long MN, int N,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            const float* __restrict__ residual, int act, float* __restrict__ out) {
+                                                            const float* __restrict__ residual, int act, float* __restrict__ out,
+                                                            const float* __restrict__ gate, int gate_act) {
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (long long)gridDim.x * 1024) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
         for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + (size_t)z * MN + i);
@@ -3861,6 +3998,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        if (gate) {                                               // ConvP.ex_gate_act 1 / 2 (epi_apply's product)
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gate + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= g[e] > 0.f ? 1.f : (gate_act == 2 ? g[e] + 1.f : 0.f);
+        }
         *reinterpret_cast<f32x4*>(out + i) = v;
     }
 }
@@ -3910,6 +4052,8 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                     // grids below one block per CU (the 1/16- and 1/32-resolution layers of the pose encoder and the decoders): cut the
                     // channel chunks into K slices so that the ring kernel (one block per CU) runs whole rounds of 256 blocks
                     if (hks >= 2) { p.ksteps = cdiv(nchunks_, hks); p.ksplit = cdiv(nchunks_, p.ksteps); }
+                    const bool ex = epi_plan(p, 128, !halo_ws);
+                    if (ex) { kr = conv_halo3r_kernel<MODE, TN, true>; codeps_allow_lds((const void*)kr, 160 * 1024, "conv_halo3r_kernel<ex>"); }
                     g_last_kernel = halo_ws ? (p.ksplit > 1 ? "conv_halo3p_kernel<splitk>" : "conv_halo3p_kernel")
                                             : (p.ksplit > 1 ? "conv_halo3r_kernel<splitk>" : "conv_halo3r_kernel");
                     hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(halo_ws ? 384 : 256), lds_r, st, p, a0, a1, scale, shift, residual, out);
@@ -3917,14 +4061,14 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                         const long long MN = (long long)p.M * p.N;
                         hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
                                            p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
-                                           MODE == MODE_FWD ? p.act : 0, out);
+                                           MODE == MODE_FWD ? p.act : 0, out, p.ex_gate, p.ex_gate_act);
                     }
                     return;
                 }
             }
-            auto kh = conv_halo3_kernel<MODE, TN>;
-            codeps_allow_lds((const void*)kh, 160 * 1024, "kh");
             p.ksplit = 1;
+            auto kh = epi_plan(p, 128) ? conv_halo3_kernel<MODE, TN, 2, 2, true> : conv_halo3_kernel<MODE, TN>;
+            codeps_allow_lds((const void*)kh, 160 * 1024, "kh");
             g_last_kernel = "conv_halo3_kernel";
             hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
             return;
@@ -3938,19 +4082,19 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         if (ws_min > 0 && nsteps_ >= ws_min && p.n_mt * p.n_nt <= ws_blocks) {
             const int nsrc_ = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
             const size_t lds_ws = std::max(((size_t)2 * (BM + BN) * LDKp + (size_t)nsrc_ * ntap_ * BM) * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
-            auto kw = conv_igemm_ws_kernel<MODE, TN>;
-            codeps_allow_lds((const void*)kw, 160 * 1024, "kw");
             const int blocks_ = p.n_mt * p.n_nt;
             p.ksplit = 1; p.ksteps = nsteps_;
             const int ks_ = splitk_slices(p, blocks_, nsteps_);
             if (ks_ >= 2) { p.ksteps = cdiv(nsteps_, ks_); p.ksplit = cdiv(nsteps_, p.ksteps); }
+            auto kw = epi_plan(p, BM) ? conv_igemm_ws_kernel<MODE, TN, true> : conv_igemm_ws_kernel<MODE, TN>;
+            codeps_allow_lds((const void*)kw, 160 * 1024, "kw");
             g_last_kernel = "conv_igemm_ws_kernel";
             hipLaunchKernelGGL(kw, dim3(blocks_, p.ksplit), dim3(512), lds_ws, st, p, a0, a1, scale, shift, residual, out);
             if (p.ksplit > 1) {
                 const long long MN = (long long)p.M * p.N;
                 hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
                                    p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
-                                   MODE == MODE_FWD ? p.act : 0, out);
+                                   MODE == MODE_FWD ? p.act : 0, out, p.ex_gate, p.ex_gate_act);
             }
             return;
         }
@@ -3962,16 +4106,15 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         if (halo32 && halo3_shape_ok<MODE>(p) && Hm_ % 8 == 0 && (long long)p.n_mt * p.n_nt >= 256) {
             constexpr size_t lds_h = std::max(((size_t)340 * (LDKp + (CODEPS_HALO_SWZ ? 4 : 0)) + (size_t)2 * BN * LDKp) * sizeof(float),
                                               (size_t)WM * 32 * (BN + 4) * sizeof(float));
-            auto kh = conv_halo3_kernel<MODE, 1, 4, 1>;
-            codeps_allow_lds((const void*)kh, 160 * 1024, "conv_halo3_kernel<4x1>");
             p.ksplit = 1;
+            auto kh = epi_plan(p, 256) ? conv_halo3_kernel<MODE, 1, 4, 1, true> : conv_halo3_kernel<MODE, 1, 4, 1>;
+            codeps_allow_lds((const void*)kh, 160 * 1024, "conv_halo3_kernel<4x1>");
             g_last_kernel = "conv_halo3_kernel<32 columns>";
             hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
             return;
         }
     }
     auto k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, NP>;
-    codeps_allow_lds((const void*)k, 160 * 1024, "k");
     // split-K when the tile grid cannot fill the chip and K is deep (B = 1 target inference, 1/32-resolution decoder inputs)
     const int blocks = p.n_mt * p.n_nt, Kc = (MODE == MODE_FWD) ? p.Ct : p.Co, nsteps = ntap * (Kc / BK);
     p.ksplit = 1; p.ksteps = nsteps;
@@ -3980,13 +4123,18 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         p.ksteps = cdiv(nsteps, ks);
         p.ksplit = cdiv(nsteps, p.ksteps);
     }
+    // (the extras exist in the default arithmetic's instantiations -- three bf16 pieces at 32-channel K steps -- and the f32 form the <= 64-column tiles fall back to)
+    constexpr bool EXOK = (NP == 3 && BK == 32 && NBUF == 1) || (NP == 0 && BK == 16 && NBUF == 2);
+    if constexpr (EXOK) { if (epi_plan(p, BM)) k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, NP, true>; }
+    else epi_plan(p, BM, false);
+    codeps_allow_lds((const void*)k, 160 * 1024, "k");
     g_last_kernel = NP == 3 ? (BK == 16 ? "conv_igemm_kernel<split3,bk16>" : "conv_igemm_kernel<split3>") : (NP == 2 ? "conv_igemm_kernel<split2>" : "conv_igemm_kernel<f32>");
     hipLaunchKernelGGL(k, dim3(blocks, p.ksplit), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
     if (p.ksplit > 1) {
         const long long MN = (long long)p.M * p.N;
         hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
                            p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
-                           MODE == MODE_FWD ? p.act : 0, out);
+                           MODE == MODE_FWD ? p.act : 0, out, p.ex_gate, p.ex_gate_act);
     }
 }
 
@@ -4013,20 +4161,21 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
     const bool bk32 = (kc_gran % 32) == 0 && force_bk != 16;
     if (p.N <= 16) {
         p.n_mt = cdiv(p.M, 256); p.n_nt = 1;
+        p.ksplit = 1;
+        const bool ex = epi_plan(p, 256);
         const int kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
-        const bool single = (MODE != MODE_FWD) || p.C1 == 0;
-        (void)single;
         g_last_kernel = kc >= 96 ? "conv_igemm16_lds_kernel" : "conv_igemm16_kernel";
         if (kc >= 96) {                        // deep K per tap (GUDA 240 channels): LDS-staged flavour
-            if (bk32) hipLaunchKernelGGL((conv_igemm16_lds_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
-            else      hipLaunchKernelGGL((conv_igemm16_lds_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
+            auto k16 = bk32 ? (ex ? conv_igemm16_lds_kernel<MODE, 32, true> : conv_igemm16_lds_kernel<MODE, 32>)
+                            : (ex ? conv_igemm16_lds_kernel<MODE, 16, true> : conv_igemm16_lds_kernel<MODE, 16>);
+            hipLaunchKernelGGL(k16, dim3(p.n_mt), dim3(256), 0, st, p, a0, a1, wq, scale, shift, residual, out);
         } else {
             const int ntap = (MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW;
             const size_t lds = (size_t)((MODE == MODE_FWD && p.C1 > 0) ? 2 : 1) * ntap * 256 * sizeof(unsigned);
-            codeps_allow_lds((const void*)conv_igemm16_kernel<MODE, 32>, 120 * 1024, "conv_igemm16_kernel<32>");
-            codeps_allow_lds((const void*)conv_igemm16_kernel<MODE, 16>, 120 * 1024, "conv_igemm16_kernel<16>");
-            if (bk32) hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 32>), dim3(p.n_mt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
-            else      hipLaunchKernelGGL((conv_igemm16_kernel<MODE, 16>), dim3(p.n_mt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
+            auto k16 = bk32 ? (ex ? conv_igemm16_kernel<MODE, 32, true> : conv_igemm16_kernel<MODE, 32>)
+                            : (ex ? conv_igemm16_kernel<MODE, 16, true> : conv_igemm16_kernel<MODE, 16>);
+            codeps_allow_lds((const void*)k16, 120 * 1024, "conv_igemm16_kernel");
+            hipLaunchKernelGGL(k16, dim3(p.n_mt), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
         }
         return;
     }
@@ -4238,14 +4387,55 @@ extern "C" size_t codeps_conv2d_fwd_workspace_bytes(const codeps_conv_desc* d) {
     return (size_t)16 * M * d->out_c * sizeof(float);
 }
 
+static_assert(sizeof(codeps_conv_epilogue) == 184, "codeps_conv_epilogue: layout shared with the ctypes binding (_lib.ConvEpilogue)");
+// codeps_conv_epilogue -> ConvP.ex_* (the request) and back (what the launches did)
+static int epi_load(ConvP& p, const codeps_conv_epilogue* e, long long rows, const char* who) {
+    memset(&g_epi, 0, sizeof(g_epi));
+    if (!e) return CODEPS_OK;
+    CODEPS_REQUIRE(e->gate_act >= 0 && e->gate_act <= 3 && e->stat_mode >= 0 && e->stat_mode <= 3, CODEPS_ERR_ARG, "%s: bad epilogue modes", who);
+    CODEPS_REQUIRE((e->gate_act != 1 && e->gate_act != 2) || e->gate, CODEPS_ERR_ARG, "%s: activation gate without its tensor", who);
+    CODEPS_REQUIRE(e->gate_act != 3 || (e->bn_x && e->bn_mean && e->bn_invstd && e->bn_groups >= 1 && e->bn_groups <= 8 &&
+                                        (!e->bn_relu || e->gate || (e->bn_gamma && e->bn_beta))), CODEPS_ERR_ARG, "%s: BatchNorm gate: missing tensors / 1..8 groups", who);
+    CODEPS_REQUIRE(e->stat_mode != 3 || e->gate_act == 3, CODEPS_ERR_ARG, "%s: statistics mode 3 belongs to the BatchNorm gate", who);
+    const int srows = e->stat_mode == 1 ? 3 : (e->stat_mode == 2 ? 1 : 2);
+    CODEPS_REQUIRE(!e->stat_mode || (e->stat_part && e->stat_part_bytes >= (size_t)(rows / 64 + 16) * srows * p.N * sizeof(float)),
+                   CODEPS_ERR_WORKSPACE, "%s: statistics buffer too small (codeps_conv2d_epilogue_part_bytes)", who);
+    p.ex_gate = e->gate; p.ex_gate_act = e->gate_act; p.ex_stat = e->stat_mode; p.ex_part = e->stat_part;
+    p.ex_bn_x = e->bn_x; p.ex_bn_mean = e->bn_mean; p.ex_bn_invstd = e->bn_invstd; p.ex_bn_gamma = e->bn_gamma; p.ex_bn_beta = e->bn_beta;
+    p.ex_bn_relu = e->bn_relu; p.ex_bn_ng = e->bn_groups;
+    for (int i = 0; i < 8; ++i) p.ex_bn_b0[i] = i < e->bn_groups ? e->bn_group_b0[i] : 0;
+    return CODEPS_OK;
+}
+static void epi_store(codeps_conv_epilogue* e) {
+    if (!e) return;
+    e->applied = g_epi.applied; e->n_seg = g_epi.n_seg;
+    for (int i = 0; i < 4; ++i) {
+        e->seg_tile0[i] = g_epi.tile0[i]; e->seg_tiles_per_image[i] = g_epi.tpi[i]; e->seg_tile_rows[i] = g_epi.rows[i]; e->seg_tiles[i] = g_epi.tiles[i];
+    }
+}
+
+extern "C" size_t codeps_conv2d_epilogue_part_bytes(long long gemm_rows, int cols, int stat_mode) {
+    const int srows = stat_mode == 1 ? 3 : (stat_mode == 2 ? 1 : 2);
+    return (size_t)(gemm_rows / 64 + 16) * srows * cols * sizeof(float);
+}
+
 extern "C" int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, const float* x1, const float* w_fwd,
                                  const float* scale, const float* shift, const float* residual, float* y, void* workspace,
                                  size_t workspace_bytes, codeps_stream_t stream) {
+    return codeps_conv2d_fwd_ex(d, x0, x1, w_fwd, scale, shift, residual, y, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int codeps_conv2d_fwd_ex(const codeps_conv_desc* d, const float* x0, const float* x1, const float* w_fwd,
+                                    const float* scale, const float* shift, const float* residual, float* y, void* workspace,
+                                    size_t workspace_bytes, codeps_conv_epilogue* epilogue, codeps_stream_t stream) {
     int rc = check_conv(d, "conv2d_fwd");
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(x0 && w_fwd && y && (d->c1 == 0 || x1), CODEPS_ERR_ARG, "conv2d_fwd: null pointer");
     ConvP p = make_convp(d);
     p.M = d->batch * d->out_h * d->out_w; p.N = d->out_c;
+    rc = epi_load(p, epilogue, p.M, "conv2d_fwd");
+    if (rc != CODEPS_OK) return rc;
+    p.ex_img_rows = d->out_h * d->out_w;
     if (workspace && codeps_conv2d_fwd_workspace_bytes(d) > 0) { p.part = (float*)workspace; p.part_bytes = workspace_bytes; }
     p.w3 = w_fwd + (size_t)d->out_c * d->kh * d->kw * (d->c0 + d->c1);         // behind the fp32 pack (codeps_conv2d_packed_weight_floats)
     const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
@@ -4261,10 +4451,12 @@ extern "C" int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, con
         codeps_allow_lds((const void*)conv_stem74f_kernel, 160 * 1024, "conv_stem74f_kernel");
         hipLaunchKernelGGL(conv_stem74f_kernel, dim3(cdiv(total, tpb)), dim3(512), lds, (hipStream_t)stream, p, tiles_x, tiles_y, tpb, x0, scale, shift, y);
         CODEPS_CHECK_LAUNCH("conv_stem74f_kernel");
+        epi_store(epilogue);                                   // (this kernel has no epilogue extras: applied = 0)
         return CODEPS_OK;
     }
     dispatch_igemm<MODE_FWD>(p, gran, x0, x1, w_fwd, scale, shift, residual, y, (hipStream_t)stream);
     CODEPS_CHECK_LAUNCH("conv_igemm_kernel<fwd>");
+    epi_store(epilogue);
     return CODEPS_OK;
 }
 
@@ -4287,6 +4479,12 @@ extern "C" int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const 
 
 extern "C" int codeps_conv2d_dgrad_add(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, const float* add,
                                        float* dx, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    return codeps_conv2d_dgrad_ex(d, source, dz, w_dgrad, add, dx, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int codeps_conv2d_dgrad_ex(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, const float* add,
+                                      float* dx, void* workspace, size_t workspace_bytes, codeps_conv_epilogue* epilogue,
+                                      codeps_stream_t stream) {
     int rc = check_conv(d, "conv2d_dgrad");
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(dz && w_dgrad && dx && (source == 0 || (source == 1 && d->c1 > 0)), CODEPS_ERR_ARG, "conv2d_dgrad: bad arguments");
@@ -4301,6 +4499,9 @@ extern "C" int codeps_conv2d_dgrad_add(const codeps_conv_desc* d, int source, co
     const bool up = d->up0 && source == 0;
     p.M = d->batch * (up ? (d->in_h / 2) * (d->in_w / 2) : d->in_h * d->in_w);
     p.N = p.Cs;
+    rc = epi_load(p, epilogue, p.M, "conv2d_dgrad");
+    if (rc != CODEPS_OK) return rc;
+    p.ex_img_rows = up ? (d->in_h / 2) * (d->in_w / 2) : d->in_h * d->in_w;
     if (workspace && codeps_conv2d_dgrad_workspace_bytes(d, source) > 0) { p.part = (float*)workspace; p.part_bytes = workspace_bytes; }
     // weights of this source: rows [c_off, c_off + Cs) of the [ci][tap][co] pack
     const float* wsrc = w_dgrad + (size_t)p.c_off * d->kh * d->kw * d->out_c;
@@ -4313,11 +4514,15 @@ extern "C" int codeps_conv2d_dgrad_add(const codeps_conv_desc* d, int source, co
             const int ky0 = (py + d->pad) & 1, kx0 = (px + d->pad) & 1;
             if (ky0 >= d->kh || kx0 >= d->kw) need_zero = true;
         }
+        // epilogue extras over the four class launches: all or nothing -- even sizes only (every class then has the same rows and the
+        // same tile plan), and no class without taps (its pixels are a copy, not an epilogue)
+        if (need_zero || (d->in_h & 1) || (d->in_w & 1)) { p.ex_gate = nullptr; p.ex_gate_act = 0; p.ex_stat = 0; }
         if (need_zero) {                                        // classes no tap reaches: zero, or the incoming gradient alone
             hipError_t e = add ? hipMemcpyAsync(dx, add, (size_t)p.M * p.N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream)
                                : hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream);
             CODEPS_REQUIRE(e == hipSuccess, CODEPS_ERR_LAUNCH, "conv2d_dgrad: memset / copy failed: %s", hipGetErrorString(e));
         }
+        int tile0 = 0;
         for (int c = 0; c < 4; ++c) {
             ConvP q = p;
             q.par = 1; q.py = c >> 1; q.px = c & 1;
@@ -4327,13 +4532,19 @@ extern "C" int codeps_conv2d_dgrad_add(const codeps_conv_desc* d, int source, co
             q.Hc = (d->in_h - q.py + 1) / 2; q.Wc = (d->in_w - q.px + 1) / 2;
             if (q.Hc <= 0 || q.Wc <= 0) continue;
             q.M = d->batch * q.Hc * q.Wc;
+            q.ex_img_rows = q.Hc * q.Wc;
+            q.ex_tile0 = tile0;
+            const int seg_before = g_epi.n_seg;
             dispatch_igemm<MODE_DGRAD>(q, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, add, dx, (hipStream_t)stream);
+            if (g_epi.n_seg > seg_before) tile0 += g_epi.tiles[seg_before];        // the classes' tiles follow one another without gaps
         }
         CODEPS_CHECK_LAUNCH("conv_igemm_kernel<dgrad, parity classes>");
+        epi_store(epilogue);
         return CODEPS_OK;
     }
     dispatch_igemm<MODE_DGRAD>(p, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, add, dx, (hipStream_t)stream);
     CODEPS_CHECK_LAUNCH("conv_igemm_kernel<dgrad>");
+    epi_store(epilogue);
     return CODEPS_OK;
 }
 

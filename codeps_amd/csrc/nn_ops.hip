@@ -404,6 +404,79 @@ __global__ __launch_bounds__(256) void bn_sync_combine_kernel(const float* __res
     if (upd) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
+// ---- BatchNorm statistics from the producing / consuming convolution's epilogue (ConvP.ex_stat, conv.hip): per M TILE partials
+// instead of a pass over the tensor.  A tile lies inside one image; group g = images [b0, b1); segment k (the stride-2 data gradient is
+// four launches) holds tiles tile0[k] + image * tpi[k] + (0 .. tpi[k]), rows[k] rows each.
+struct TileSegs { int n; int tile0[4]; int tpi[4]; int rows[4]; };
+struct ImgGroups { int n; int b0[8]; int b1[8]; };
+
+// One block per (64 channels, statistic group), 1024 threads = 16 waves: wave w walks tiles w, w + 16, ... with its lanes on 64
+// CONSECUTIVE channels (256-byte rows of the partials), the 16 waves meet in LDS in a fixed order.  (First form, round 5: one wave per
+// channel with the lanes on different tiles -- 4-byte reads 768 bytes apart -- and a last-arrival ticket (__threadfence() + an integer
+// atomic per block, right behind a convolution that had filled the L2) for the cross-group part: 45 us per launch against 6.5 us for
+// this form.  The parts that need every group -- running statistics, dgamma / dbeta -- ride in the apply kernels, which run after this
+// one anyway.)
+// forward: part[tile][3][C] = (shift, sum (z - shift), sum (z - shift)^2) -> mean / biased var / invstd of group blockIdx.y
+// (bn_finalize_mg_kernel's arithmetic on sums re-based to the group's first tile's shift)
+__global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(const float* __restrict__ part, TileSegs sg, ImgGroups ig, int C, float eps,
+                                                                 float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd) {
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const bool cin = c < C;
+    const int t0 = sg.tile0[0] + ig.b0[g] * sg.tpi[0], nt = (ig.b1[g] - ig.b0[g]) * sg.tpi[0];
+    const float rows = (float)sg.rows[0];
+    float s1 = 0.f, s2 = 0.f, sh0 = 0.f;
+    if (cin) {
+        sh0 = part[(size_t)t0 * 3 * C + c];
+#pragma unroll 4
+        for (int t = w; t < nt; t += 16) {
+            const float* q = part + (size_t)(t0 + t) * 3 * C + c;
+            const float d = q[0] - sh0, a = q[C], b = q[2 * (size_t)C];
+            s1 += a + rows * d;
+            s2 += b + 2.f * d * a + rows * d * d;
+        }
+    }
+    __shared__ float red[2][16][64];
+    red[0][w][threadIdx.x & 63] = s1; red[1][w][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (w == 0 && cin) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += red[0][k][threadIdx.x]; b += red[1][k][threadIdx.x]; }
+        const float n = rows * (float)nt;
+        const float d = a / n;
+        const float v = fmaxf(b / n - d * d, 0.f);
+        mean[g * C + c] = sh0 + d; var[g * C + c] = v; invstd[g * C + c] = rsqrtf(v + eps);
+    }
+}
+
+// backward: part[tile][2][C] = (sum g, sum g * xhat) over every segment's tiles of group blockIdx.y -> sums[g][2][C]
+__global__ __launch_bounds__(1024) void bn_bwd_finish_tiles_kernel(const float* __restrict__ part, TileSegs sg, ImgGroups ig, int C,
+                                                                   float* __restrict__ sums) {
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const bool cin = c < C;
+    float s1 = 0.f, s2 = 0.f;
+    if (cin)
+        for (int k = 0; k < sg.n; ++k) {
+            const int t0 = sg.tile0[k] + ig.b0[g] * sg.tpi[k], nt = (ig.b1[g] - ig.b0[g]) * sg.tpi[k];
+#pragma unroll 4
+            for (int t = w; t < nt; t += 16) {
+                const float* q = part + (size_t)(t0 + t) * 2 * C + c;
+                s1 += q[0]; s2 += q[C];
+            }
+        }
+    __shared__ float red[2][16][64];
+    red[0][w][threadIdx.x & 63] = s1; red[1][w][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (w == 0 && cin) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += red[0][k][threadIdx.x]; b += red[1][k][threadIdx.x]; }
+        sums[(size_t)g * 2 * C + c] = a; sums[(size_t)g * 2 * C + C + c] = b;
+    }
+}
+
 __device__ __forceinline__ int bn_group_of(const BnGroups& gr, long long row) {
     int g = 0;
 #pragma unroll
@@ -411,10 +484,24 @@ __device__ __forceinline__ int bn_group_of(const BnGroups& gr, long long row) {
     return g;
 }
 
+// running statistics of a launch whose per-group (mean, biased var) come from codeps_bn_finalize_tiles: the momentum updates, group
+// after group (bn_finalize_mg_kernel's expressions), by the first block of the apply pass
+struct BnRunning { float* mean; float* var; const float* batch_var; float momentum; int c_real; };
+
 __global__ __launch_bounds__(256) void bn_apply_mg_kernel(const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ residual, int act,
-                                                          long long M, int C, float* __restrict__ y) {
+                                                          long long M, int C, float* __restrict__ y, BnRunning run) {
+    if (run.mean && blockIdx.x == 0)
+        for (int c = threadIdx.x; c < run.c_real; c += 256) {
+            float rm = run.mean[c], rv = run.var[c];
+            for (int g = 0; g < gr.n; ++g) {
+                const float n = (float)gr.rows[g];
+                rm = rm * (1.f - run.momentum) + run.momentum * mean[g * C + c];
+                rv = rv * (1.f - run.momentum) + run.momentum * (run.batch_var[g * C + c] * (n / fmaxf(n - 1.f, 1.f)));
+            }
+            run.mean[c] = rm; run.var[c] = rv;
+        }
     const int G = C / 4;
     const long long total = M * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -569,12 +656,23 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_mg_kernel(const float* __re
     }
 }
 
+// affine gradients of a backward whose per-group sums come from codeps_bn_bwd_finish_tiles (local_sums: THIS rank's, before any all-reduce)
+struct BnAffineGrad { float* dgamma; float* dbeta; const float* local_sums; int accumulate, c_real; };
+
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_mg_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ x, BnGroups gr, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ sums, int act,
-                                                              long long M, int C, float* __restrict__ dx, float* __restrict__ dres, PoolSrc ps) {
+                                                              long long M, int C, float* __restrict__ dx, float* __restrict__ dres, PoolSrc ps,
+                                                              BnAffineGrad ag) {
+    if (ag.dgamma && blockIdx.x == 0)                             // dgamma / dbeta from this rank's per-group sums, in group order (bn_bwd_finish_mg_kernel)
+        for (int c = threadIdx.x; c < ag.c_real; c += 256) {
+            float tb = 0.f, tg = 0.f;
+            for (int g = 0; g < gr.n; ++g) { tb += ag.local_sums[(size_t)g * 2 * C + c]; tg += ag.local_sums[(size_t)g * 2 * C + C + c]; }
+            ag.dgamma[c] = ag.accumulate ? ag.dgamma[c] + tg : tg;
+            ag.dbeta[c] = ag.accumulate ? ag.dbeta[c] + tb : tb;
+        }
     const int G = C / 4;
     const long long total = M * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1404,6 +1502,14 @@ extern "C" int codeps_bn_apply(const float* x, const float* mean, const float* i
     return CODEPS_OK;
 }
 
+// bias gradient from the per-tile column sums a data-gradient launch left (codeps_conv_epilogue stat_mode 2): part [tiles][c]
+extern "C" int codeps_colsum_finish(const float* part, int tiles, int c, float* out, int c_real, int accumulate, codeps_stream_t stream) {
+    CODEPS_REQUIRE(part && out && tiles > 0 && c > 0 && c_real > 0 && c_real <= c, CODEPS_ERR_ARG, "colsum_finish: bad arguments");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(c, 4)), dim3(256), 0, (hipStream_t)stream, part, tiles, 1, c, out, c_real, accumulate);
+    CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
+    return CODEPS_OK;
+}
+
 extern "C" int codeps_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd, int act,
                                     long long rows, int c, float* sums /*[2][c]*/, void* workspace, size_t workspace_bytes,
                                     codeps_stream_t stream) {
@@ -1476,9 +1582,69 @@ extern "C" int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* r
     }
     if (!stats_only) {
         CODEPS_REQUIRE(gamma && beta && y, CODEPS_ERR_ARG, "bn_fwd_mg: null affine / output");
+        // apply_only with running statistics: the batch statistics came from codeps_bn_finalize_tiles -- the momentum updates ride here
+        BnRunning run{apply_only ? running_mean : nullptr, running_var, var, momentum, c_real};
         hipLaunchKernelGGL(bn_apply_mg_kernel, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, x, gr, (const float*)mean, (const float*)invstd,
-                           gamma, beta, residual, act, M, c, y);
+                           gamma, beta, residual, act, M, c, y, run);
         CODEPS_CHECK_LAUNCH("bn_apply_mg_kernel");
+    }
+    return CODEPS_OK;
+}
+
+static int make_tile_args(int n_seg, const int* seg_tile0, const int* seg_tiles_per_image, const int* seg_tile_rows, int n_groups,
+                          const int* group_b0, const int* group_b1, TileSegs& sg, ImgGroups& ig, const char* who) {
+    CODEPS_REQUIRE(n_seg >= 1 && n_seg <= 4 && seg_tile0 && seg_tiles_per_image && seg_tile_rows && n_groups >= 1 && n_groups <= 8 && group_b0 &&
+                   group_b1, CODEPS_ERR_ARG, "%s: 1..4 tile segments, 1..8 groups", who);
+    memset(&sg, 0, sizeof(sg)); memset(&ig, 0, sizeof(ig));
+    sg.n = n_seg; ig.n = n_groups;
+    for (int k = 0; k < n_seg; ++k) {
+        CODEPS_REQUIRE(seg_tile0[k] >= 0 && seg_tiles_per_image[k] > 0 && seg_tile_rows[k] > 0, CODEPS_ERR_ARG, "%s: bad tile segment %d", who, k);
+        sg.tile0[k] = seg_tile0[k]; sg.tpi[k] = seg_tiles_per_image[k]; sg.rows[k] = seg_tile_rows[k];
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        CODEPS_REQUIRE(group_b1[g] > group_b0[g] && group_b0[g] >= 0, CODEPS_ERR_ARG, "%s: empty statistic group %d", who, g);
+        ig.b0[g] = group_b0[g]; ig.b1[g] = group_b1[g];
+    }
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_finalize_tiles(const float* part, int tile0, int tiles_per_image, int tile_rows, int n_groups, const int* group_b0,
+                                        const int* group_b1, int c, float eps, float* mean, float* var, float* invstd, codeps_stream_t stream) {
+    TileSegs sg; ImgGroups ig;
+    int rc = make_tile_args(1, &tile0, &tiles_per_image, &tile_rows, n_groups, group_b0, group_b1, sg, ig, "bn_finalize_tiles");
+    if (rc) return rc;
+    CODEPS_REQUIRE(part && mean && var && invstd && c > 0, CODEPS_ERR_ARG, "bn_finalize_tiles: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(c, 64), n_groups), dim3(1024), 0, (hipStream_t)stream, part, sg, ig, c, eps, mean, var, invstd);
+    CODEPS_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_bn_bwd_tiles(const float* part, int n_seg, const int* seg_tile0, const int* seg_tiles_per_image, const int* seg_tile_rows,
+                                   int n_groups, const long long* row0, const long long* rows, const int* group_b0, const int* group_b1,
+                                   const float* g, const float* x, int c, int c_real, const float* mean, const float* invstd, const float* gamma,
+                                   const float* inv_count, float* local_sums, const float* sums, float* dgamma, float* dbeta, int accumulate,
+                                   float* dx, int phase, codeps_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (phase == 0 || phase == 1) {
+        TileSegs sg; ImgGroups ig;
+        int rc = make_tile_args(n_seg, seg_tile0, seg_tiles_per_image, seg_tile_rows, n_groups, group_b0, group_b1, sg, ig, "bn_bwd_tiles");
+        if (rc) return rc;
+        CODEPS_REQUIRE(part && local_sums && c > 0, CODEPS_ERR_ARG, "bn_bwd_tiles: bad arguments");
+        hipLaunchKernelGGL(bn_bwd_finish_tiles_kernel, dim3(cdiv(c, 64), n_groups), dim3(1024), 0, st, part, sg, ig, c, local_sums);
+        CODEPS_CHECK_LAUNCH("bn_bwd_finish_tiles_kernel");
+    }
+    if (phase == 0 || phase == 2) {
+        BnGroups gr;
+        long long M;
+        int rc = make_groups(n_groups, row0, rows, gr, M, "bn_bwd_tiles");
+        if (rc) return rc;
+        CODEPS_REQUIRE(g && x && mean && invstd && gamma && inv_count && local_sums && dgamma && dbeta && dx && (c % 4) == 0 && c_real <= c,
+                       CODEPS_ERR_ARG, "bn_bwd_tiles: bad arguments");
+        for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = inv_count[i];
+        hipLaunchKernelGGL(bn_bwd_apply_mg_kernel<false>, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, g, (const float*)nullptr, x, gr, mean, invstd, gamma,
+                           (const float*)nullptr, sums ? sums : (const float*)local_sums, 0, M, c, dx, (float*)nullptr, PoolSrc{},
+                           BnAffineGrad{dgamma, dbeta, local_sums, accumulate, c_real});
+        CODEPS_CHECK_LAUNCH("bn_bwd_apply_mg_kernel");
     }
     return CODEPS_OK;
 }
@@ -1533,7 +1699,7 @@ extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x,
         CODEPS_REQUIRE(gamma && inv_count && dx, CODEPS_ERR_ARG, "bn_bwd_mg: null gamma / inv_count / dx");
         for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = inv_count[i];
         hipLaunchKernelGGL(bn_bwd_apply_mg_kernel<false>, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, dy, y, x, gr, mean, invstd, gamma, beta, (const float*)sums,
-                           act, M, c, dx, dres, PoolSrc{});
+                           act, M, c, dx, dres, PoolSrc{}, BnAffineGrad{});
         CODEPS_CHECK_LAUNCH("bn_bwd_apply_mg_kernel");
     }
     return CODEPS_OK;
@@ -1564,30 +1730,35 @@ extern "C" int codeps_bn_relu_pool_fwd(const float* z, int n_groups, const long 
 extern "C" int codeps_bn_relu_pool_bwd(const float* dpooled, const uint8_t* argmax, const float* z, int n_groups, const long long* row0,
                                        const long long* rows, int batch, int h, int w, int c, int c_real, const float* mean, const float* invstd,
                                        const float* gamma, const float* beta, const float* inv_count, float* sums, float* dgamma, float* dbeta,
-                                       int accumulate, float* dz, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+                                       int accumulate, float* dz, void* workspace, size_t workspace_bytes, int phase, codeps_stream_t stream) {
     BnGroups gr;
     long long M;
     int rc = make_groups(n_groups, row0, rows, gr, M, "bn_relu_pool_bwd");
     if (rc) return rc;
     CODEPS_REQUIRE(dpooled && argmax && z && mean && invstd && gamma && beta && inv_count && sums && dgamma && dbeta && dz && (c % 4) == 0 &&
-                   M == (long long)batch * h * w, CODEPS_ERR_ARG, "bn_relu_pool_bwd: bad arguments");
+                   M == (long long)batch * h * w && phase >= 0 && phase <= 2, CODEPS_ERR_ARG, "bn_relu_pool_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = mg_blocks(gr);
     CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)n_groups * nblk * 2 * c * 4, CODEPS_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
     PoolSrc ps;
     ps.dp = dpooled; ps.arg = argmax; ps.H = h; ps.W = w; ps.Ho = (h + 2 - 3) / 2 + 1; ps.Wo = (w + 2 - 3) / 2 + 1;
     ps.inv_hw = 1.f / ((float)h * (float)w); ps.inv_w = 1.f / (float)w;
-    hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel<true>, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, (const float*)nullptr, (const float*)nullptr, z, gr,
-                       mean, invstd, gamma, beta, 1, c, nblk, (float*)workspace, ps);
-    hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 4)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma, dbeta,
-                       accumulate);
+    // phase 0: everything; 1: the sums (+ dgamma / dbeta, from THIS rank's sums) only; 2: dz from `sums` only -- SyncBatchNorm all-reduces
+    // the sums in between (misc/train_utils.py:50-51)
+    if (phase != 2) {
+        hipLaunchKernelGGL(bn_bwd_reduce_mg_kernel<true>, dim3(nblk, col_tiles(c), n_groups), dim3(256), 0, st, (const float*)nullptr, (const float*)nullptr, z, gr,
+                           mean, invstd, gamma, beta, 1, c, nblk, (float*)workspace, ps);
+        hipLaunchKernelGGL(bn_bwd_finish_mg_kernel, dim3(cdiv(c, 4)), dim3(256), 0, st, (const float*)workspace, gr, c, c_real, nblk, sums, dgamma, dbeta,
+                           accumulate);
+    }
+    if (phase == 1) { CODEPS_CHECK_LAUNCH("bn_relu_pool_bwd"); return CODEPS_OK; }
     for (int i = 0; i < n_groups; ++i) gr.inv_count[i] = inv_count[i];
     if (h % 2 == 0 && w % 2 == 0)
         hipLaunchKernelGGL(bn_bwd_apply_pool2x2_kernel, dim3(grid_for(M / 4 * (c / 4))), dim3(256), 0, st, z, gr, mean, invstd, gamma, beta, (const float*)sums,
                            batch, c, dz, ps);
     else
     hipLaunchKernelGGL(bn_bwd_apply_mg_kernel<true>, dim3(grid_for(M * (c / 4))), dim3(256), 0, st, (const float*)nullptr, (const float*)nullptr, z, gr, mean,
-                       invstd, gamma, beta, (const float*)sums, 1, M, c, dz, (float*)nullptr, ps);
+                       invstd, gamma, beta, (const float*)sums, 1, M, c, dz, (float*)nullptr, ps, BnAffineGrad{});
     CODEPS_CHECK_LAUNCH("bn_relu_pool_bwd");
     return CODEPS_OK;
 }

@@ -474,11 +474,86 @@ def _prof_end(start, kind, flops, desc=None, source=0, tag=None, kernel=None):
 _UP_DGRAD16 = os.environ.get("CODEPS_UP_DGRAD16", "1") != "0"     # A/B switch: 0 = the 36-pair gather form of the data-gradient kernel
 
 
+_EPI = os.environ.get("CODEPS_EPILOGUE", "1") != "0"       # A/B switch: 0 = activation / BatchNorm backward and statistics as separate passes
+# ... and one by one: BatchNorm statistics from the forward epilogue / activation gates / the BatchNorm gate of the data gradient
+_EPI_PARTS = {k: os.environ.get("CODEPS_EPI_" + k.upper(), "1") != "0" for k in ("stats", "act", "bn")}
+
+
+class _Gate:
+    """Travels as `._codeps_gate` on the OUTPUT of an activation -- conv + ELU / ReLU (`kind` "act") or train-mode BatchNorm + ReLU
+    ("bn") -- and tells a convolution that consumes the tensor EXCLUSIVELY (`conv2d(..., exclusive=True)`: it, plus whoever takes its
+    fork alias, are the tensor's only consumers) how to apply that activation's backward in its own data-gradient epilogue
+    (codeps_conv_epilogue).  The consumer's backward leaves a hand-off record; the producer's backward, which autograd runs next with
+    exactly that gradient tensor, finds its incoming gradient already gated (and its bias / BatchNorm sums as per-tile partials)."""
+    __slots__ = ("kind", "act", "want_colsum", "has_res", "x", "mean", "invstd", "gamma", "beta", "groups", "handoff")
+
+    def __init__(self, kind, act):
+        # (the gated tensor itself is not kept here -- the consumer has it as its x0 -- so that the tensor, which carries this object,
+        # and its grad_fn's context, which also does, form no reference cycle)
+        self.kind, self.act = kind, act
+        self.want_colsum = self.has_res = False
+        self.x = self.mean = self.invstd = self.gamma = self.beta = self.groups = None
+        self.handoff = None
+
+    def take(self, dy):
+        """The hand-off of this backward pass, if the consumer gated the gradient: checked against the tensor that arrived."""
+        h, self.handoff = self.handoff, None
+        if h is None:
+            return None
+        if h["ptr"] != dy.data_ptr() or h["version"] != dy._version or h["shape"] != tuple(dy.shape):
+            raise _lib.CodepsHipError("a gradient gated in a convolution's epilogue reached its producer modified: the tensor passed with "
+                                      "exclusive=True has another consumer (autograd summed a second gradient into it)")
+        return h
+
+
+class _ConvOpts:
+    """Non-tensor options / results of one conv2d call: in -- in_gate (the gate of x0, consumed exclusively), bn_stats (the output feeds a
+    train-mode BatchNorm: leave its batch statistics as per-tile partials); out -- gate (of the output, when it has an activation),
+    stats (the partials record, None when the launch plan could not produce them)."""
+    __slots__ = ("in_gate", "bn_stats", "gate", "stats")
+
+    def __init__(self, in_gate=None, bn_stats=False):
+        self.in_gate, self.bn_stats, self.gate, self.stats = in_gate, bn_stats, None, None
+
+
+def _epilogue_for(gate, x0, rows, cols, device):
+    """codeps_conv_epilogue for a data-gradient launch whose result is the gradient of x0, the tensor `gate` came with."""
+    e = _lib.ConvEpilogue()
+    if gate.kind == "act":
+        e.gate, e.gate_act = x0.data_ptr(), gate.act
+        e.stat_mode = 2 if gate.want_colsum else 0
+    else:
+        e.gate = x0.data_ptr() if gate.has_res else None         # a residual fed the ReLU: the mask is (block output > 0)
+        e.gate_act, e.stat_mode = 3, 3
+        e.bn_x, e.bn_mean, e.bn_invstd = gate.x.data_ptr(), gate.mean.data_ptr(), gate.invstd.data_ptr()
+        e.bn_gamma, e.bn_beta = gate.gamma.data_ptr(), gate.beta.data_ptr()
+        e.bn_relu, e.bn_groups = 1, len(gate.groups)
+        for i, (b0, _b1) in enumerate(gate.groups):
+            e.bn_group_b0[i] = b0
+    part = None
+    if e.stat_mode:
+        nbytes = lib().codeps_conv2d_epilogue_part_bytes(rows, cols, e.stat_mode)
+        part = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        e.stat_part, e.stat_part_bytes = part.data_ptr(), nbytes
+    return e, part
+
+
+def _handoff(gate, e, part, dx):
+    """Record what the launch did (gate applied: bit 0; statistics written: bit 1) for the producer's backward."""
+    if not (e.applied & 1):
+        return
+    h = {"ptr": dx.data_ptr(), "version": dx._version, "shape": tuple(dx.shape), "part": None}
+    if e.applied & 2:
+        h["part"] = part
+        h["segs"] = [(e.seg_tile0[k], e.seg_tiles_per_image[k], e.seg_tile_rows[k], e.seg_tiles[k]) for k in range(e.n_seg)]
+    gate.handoff = h
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv(cat(up(x0), x1), W) * scale + shift + residual) on NHWC tensors (C ABI conv2d)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, scale, shift, residual, stride, pad, pad_mode, act, up0, macs_per_out, fork=False):
+    def forward(ctx, x0, x1, weight, bias, scale, shift, residual, stride, pad, pad_mode, act, up0, macs_per_out, fork=False, opts=None):
         require_cuda(x0, x1, weight)
         co, ci, kh, kw = weight.shape
         cop = pad16(co)
@@ -497,9 +572,31 @@ class _Conv2d(torch.autograd.Function):
         t0 = _prof_begin()
         wsb = lib().codeps_conv2d_fwd_workspace_bytes(ctypes.byref(desc))          # split-K scratch (small-M, deep-K shapes only)
         ws = _workspace(wsb, x0.device, "splitk") if wsb else None
-        check(lib().codeps_conv2d_fwd(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
-                                      ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()), "codeps_conv2d_fwd")
+        epi = spart = None
+        if opts is not None and opts.bn_stats and _EPI and _EPI_PARTS["stats"] and not act and sc is None and sh is None and residual is None:
+            # the output feeds a train-mode BatchNorm: (shift, sum, sum of squares) per M tile from the epilogue instead of a pass over y
+            epi = _lib.ConvEpilogue()
+            epi.stat_mode = 1
+            nbytes = lib().codeps_conv2d_epilogue_part_bytes(desc.batch * desc.out_h * desc.out_w, cop, 1)
+            spart = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
+            epi.stat_part, epi.stat_part_bytes = spart.data_ptr(), nbytes
+        check(lib().codeps_conv2d_fwd_ex(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
+                                         ptr(ws), ws.numel() if ws is not None else 0, ctypes.byref(epi) if epi is not None else None,
+                                         stream_ptr()), "codeps_conv2d_fwd")
         _prof_end(t0, "conv_fwd", flops, desc)
+        if epi is not None and (epi.applied & 2):
+            opts.stats = {"part": spart, "tile0": epi.seg_tile0[0], "tpi": epi.seg_tiles_per_image[0], "rows": epi.seg_tile_rows[0]}
+        # the gate of x0 (its producer's activation backward, applied in this launch's data-gradient epilogue) and the gate this
+        # convolution's own activation offers to ITS exclusive consumer
+        ctx.in_gate = opts.in_gate if (opts is not None and _EPI and ctx.needs_input_grad[0] and opts.in_gate is not None and
+                                       _EPI_PARTS[opts.in_gate.kind]) else None
+        ctx.out_gate = None
+        # (grad mode is off inside forward(): needs_input_grad is what says whether a backward will run)
+        if opts is not None and _EPI and act and scale is None and residual is None and \
+                (ctx.needs_input_grad[0] or ctx.needs_input_grad[2] or (x1 is not None and ctx.needs_input_grad[1])):
+            g = _Gate("act", act)
+            g.want_colsum = bias is not None and ctx.needs_input_grad[3]
+            ctx.out_gate = opts.gate = g
         ctx.desc, ctx.co, ctx.ci, ctx.has_bias = desc, co, ci, bias is not None
         ctx.flops = flops
         ctx.w_sink = grad_sink(weight) if weight.requires_grad else None
@@ -521,6 +618,7 @@ class _Conv2d(torch.autograd.Function):
         x0, x1, y, wd, sc = ctx.saved_tensors
         desc = ctx.desc
         add = g_fork.contiguous() if (ctx.fork and g_fork is not None) else None
+        gated = ctx.out_gate.take(dy) if ctx.out_gate is not None else None
         dy = dy.contiguous()
         rows, cop = dy.numel() // dy.shape[-1], dy.shape[-1]
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
@@ -529,7 +627,22 @@ class _Conv2d(torch.autograd.Function):
             dbias = ctx.b_sink if ctx.b_sink is not None else torch.empty(ctx.co, dtype=torch.float32, device=dy.device)
         b_acc = 1 if ctx.b_sink is not None else 0
         dres = None
-        if desc.act or sc is not None or need_b:
+        if gated is not None:
+            # dy IS dz: the consumer's data-gradient epilogue multiplied by act'(y); the bias gradient from its per-tile column sums
+            dz = dy
+            if need_b:
+                if gated["part"] is not None:
+                    tiles = sum(sg[3] for sg in gated["segs"])
+                    check(lib().codeps_colsum_finish(ptr(gated["part"]), tiles, cop, ptr(dbias), ctx.co, b_acc, stream_ptr()),
+                          "codeps_colsum_finish")
+                else:
+                    wsb = lib().codeps_colsum_workspace_bytes(rows, cop, 1)
+                    ws = _workspace(wsb, dy.device, "colsum")
+                    check(lib().codeps_act_bwd(ptr(dy), None, None, 0, rows, cop, None, ptr(dbias), ctx.co, b_acc, ptr(ws), ws.numel(),
+                                               stream_ptr()), "codeps_act_bwd (bias gradient)")
+                if ctx.b_sink is not None:
+                    dbias = None
+        elif desc.act or sc is not None or need_b:
             wsb = lib().codeps_colsum_workspace_bytes(rows, cop, 1)
             ws = _workspace(wsb, dy.device, "colsum")
             if ctx.has_res and ctx.needs_input_grad[6] and sc is not None:
@@ -572,17 +685,31 @@ class _Conv2d(torch.autograd.Function):
             t0 = _prof_begin()
             wsb = lib().codeps_conv2d_fwd_workspace_bytes(ctypes.byref(d2))
             ws2 = _workspace(wsb, dy.device, "splitk") if wsb else None
-            check(lib().codeps_conv2d_fwd(ctypes.byref(d2), ptr(dz), None, ptr(wf2), None, None, None, ptr(dx0), ptr(ws2),
-                                          ws2.numel() if ws2 is not None else 0, stream_ptr()), "codeps_conv2d_fwd (up-conv data gradient)")
+            e2 = p2 = None
+            if ctx.in_gate is not None:
+                e2, p2 = _epilogue_for(ctx.in_gate, x0, dx0.numel() // c0p, c0p, dy.device)
+            # (the second gradient of a forked input rides as the forward kernel's residual: added before the gate)
+            check(lib().codeps_conv2d_fwd_ex(ctypes.byref(d2), ptr(dz), None, ptr(wf2), None, None, ptr(add), ptr(dx0), ptr(ws2),
+                                             ws2.numel() if ws2 is not None else 0, ctypes.byref(e2) if e2 is not None else None,
+                                             stream_ptr()), "codeps_conv2d_fwd (up-conv data gradient)")
+            add = None
+            if e2 is not None:
+                _handoff(ctx.in_gate, e2, p2, dx0)
             _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci) * (16.0 / 36.0), d2)      # the FLOPs this form performs
         elif ctx.needs_input_grad[0]:
             dx0 = torch.empty_like(x0)
             t0 = _prof_begin()
             wsb = lib().codeps_conv2d_dgrad_workspace_bytes(ctypes.byref(desc), 0)            # split-K scratch (small-M, deep-K shapes only)
             ws2 = _workspace(wsb, dy.device, "splitk") if wsb else None
-            check(lib().codeps_conv2d_dgrad_add(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(add), ptr(dx0), ptr(ws2),
-                                                ws2.numel() if ws2 is not None else 0, stream_ptr()), "codeps_conv2d_dgrad_add")
+            e2 = p2 = None
+            if ctx.in_gate is not None:
+                e2, p2 = _epilogue_for(ctx.in_gate, x0, dx0.numel() // dx0.shape[-1], dx0.shape[-1], dy.device)
+            check(lib().codeps_conv2d_dgrad_ex(ctypes.byref(desc), 0, ptr(dz), ptr(wd), ptr(add), ptr(dx0), ptr(ws2),
+                                               ws2.numel() if ws2 is not None else 0, ctypes.byref(e2) if e2 is not None else None,
+                                               stream_ptr()), "codeps_conv2d_dgrad_ex")
             add = None                                             # consumed by the kernel's epilogue
+            if e2 is not None:
+                _handoff(ctx.in_gate, e2, p2, dx0)
             _prof_end(t0, "conv_dgrad", ctx.flops * (ctx.c0_real / ctx.ci), desc)
         if x1 is not None and ctx.needs_input_grad[1]:
             dx1 = torch.empty_like(x1)
@@ -605,7 +732,7 @@ class _Conv2d(torch.autograd.Function):
                 dw = None               # accumulated in place into the flat gradient buffer
         if add is not None:                                        # (a data-gradient form without the fused add, or no data gradient)
             dx0 = add if dx0 is None else dx0.add_(add)
-        return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None, None, None, None
 
 
 def _pair(v):
@@ -613,14 +740,25 @@ def _pair(v):
 
 
 def conv2d(x0, weight, bias=None, *, x1=None, scale=None, shift=None, residual=None, stride=1, pad=0, pad_mode="zeros",
-           act=None, up0=False, macs_per_out=None, fork=False):
+           act=None, up0=False, macs_per_out=None, fork=False, exclusive=False, bn_stats=False):
     """NHWC convolution.  x0 [B,H,W,C0p]; optional skip x1 concatenated along channels after an
     optional nearest-x2 upsample of x0; weight OIHW; stride / pad: int or (vertical, horizontal);
     returns [B,Ho,Wo,pad16(Cout)].  macs_per_out: algorithmic multiply-adds per output element for the profiler when
     the weight tensor is a re-laid-out form of the reference's (stem_conv2d).  fork=True -> (y, x0'): x0' is x0 for every
-    other consumer of the tensor; the gradient they send back is added inside the data-gradient kernel (no separate sum)."""
-    return _Conv2d.apply(x0, x1, weight, bias, scale, shift, residual, _pair(stride), _pair(pad),
-                         1 if pad_mode == "reflect" else 0, ACT[act], bool(up0), macs_per_out, bool(fork))
+    other consumer of the tensor; the gradient they send back is added inside the data-gradient kernel (no separate sum).
+    exclusive=True: this call (and the taker of its fork alias) is the ONLY consumer of x0 -- when x0 came out of a conv + activation or
+    a train-mode BatchNorm + ReLU of this library, that producer's activation backward (and its bias / BatchNorm sums) then happens in
+    this convolution's data-gradient epilogue (`_Gate`).  bn_stats=True: the result feeds a train-mode BatchNorm; `y._codeps_stats`
+    then carries its batch statistics as per-tile partials (None when the launch plan cannot produce them)."""
+    opts = _ConvOpts(getattr(x0, "_codeps_gate", None) if exclusive else None, bn_stats)
+    out = _Conv2d.apply(x0, x1, weight, bias, scale, shift, residual, _pair(stride), _pair(pad),
+                        1 if pad_mode == "reflect" else 0, ACT[act], bool(up0), macs_per_out, bool(fork), opts)
+    y = out[0] if fork else out
+    if opts.gate is not None:
+        y._codeps_gate = opts.gate
+    if opts.stats is not None:
+        y._codeps_stats = opts.stats
+    return out
 
 
 _stem_cache = {}
@@ -830,6 +968,12 @@ def _group_arrays(groups, per_item):
     return n, arr(*[g[0] * per_item for g in groups]), arr(*[(g[1] - g[0]) * per_item for g in groups])
 
 
+def _img_groups(groups):
+    n = len(groups)
+    arr = ctypes.c_int * n
+    return n, arr(*[g[0] for g in groups]), arr(*[g[1] for g in groups])
+
+
 class _BatchNormTrain(torch.autograd.Function):
     """Train-mode BatchNorm (+ residual, + ReLU) on NHWC with batch statistics (C ABI: codeps_bn_{fwd,bwd}_mg);
     statistics pass through `reduce_fn` (cross-rank combination for SyncBN; None = local).
@@ -840,7 +984,7 @@ class _BatchNormTrain(torch.autograd.Function):
     All groups are handled by one launch per phase."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, reduce_fn, groups):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, reduce_fn, groups, opts=None):
         require_cuda(x, gamma, beta)
         x = x.contiguous()
         cp = x.shape[-1]
@@ -860,7 +1004,25 @@ class _BatchNormTrain(torch.autograd.Function):
         ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
         counts = [float((b1 - b0) * per_item) for b0, b1 in groups]
         rm = running_mean if (running_mean is not None and running_mean.numel() == c) else None
-        if reduce_fn is None:
+        tiles = opts.stats if (opts is not None and _EPI) else None       # statistics partials the producing convolution's epilogue left
+
+        def local_stats(mean_o, var_o, invstd_o):
+            """per-group (mean, biased var, invstd) of THIS rank's rows"""
+            if tiles is not None:
+                ngi, gb0, gb1 = _img_groups(groups)
+                check(lib().codeps_bn_finalize_tiles(ptr(tiles["part"]), tiles["tile0"], tiles["tpi"], tiles["rows"], ngi, gb0, gb1, cp, eps,
+                                                     ptr(mean_o), ptr(var_o), ptr(invstd_o), stream_ptr()), "codeps_bn_finalize_tiles")
+            else:
+                check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(mean_o),
+                                             ptr(var_o), ptr(invstd_o), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+
+        if reduce_fn is None and tiles is not None:
+            local_stats(mean, var, invstd)
+            # (apply_only with the running statistics: their momentum updates ride in the apply pass)
+            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, ptr(rm),
+                                         ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1,
+                                         ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+        elif reduce_fn is None:
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, ptr(rm),
                                          ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 0,
                                          ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
@@ -870,8 +1032,7 @@ class _BatchNormTrain(torch.autograd.Function):
             # kernel weighs every rank's slot with its element count (0 = ignored)
             G, l2g = plan["n_global"], plan["index"](dev)
             pk_local = torch.empty(2, ng, cp, dtype=torch.float32, device=dev)
-            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(pk_local[0]),
-                                         ptr(pk_local[1]), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+            local_stats(pk_local[0], pk_local[1], invstd)
             pk = torch.zeros(2, G, cp, dtype=torch.float32, device=dev)
             pk.index_copy_(1, l2g, pk_local)
             gathered = reduce_fn.gather(pk)                                     # [world, 2, G, cp]
@@ -890,8 +1051,7 @@ class _BatchNormTrain(torch.autograd.Function):
                   "codeps_bn_fwd_mg")
         else:       # SyncBN: local statistics -> all-gather -> one combine kernel (merge + running stats + invstd) -> apply
             pk = torch.empty(2, ng, cp, dtype=torch.float32, device=dev)        # [mean | var] = the all-gather packet, no packing pass
-            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(pk[0]),
-                                         ptr(pk[1]), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+            local_stats(pk[0], pk[1], invstd)
             gathered = reduce_fn.gather(pk)                                     # [world, 2, ng, cp], ONE collective per layer
             world = gathered.shape[0]
             counts = [n * world for n in counts]                                # equal shards on every rank by construction
@@ -907,6 +1067,13 @@ class _BatchNormTrain(torch.autograd.Function):
         ctx.save_for_backward(x, y if (act and residual is not None) else None, g, b_, mean, invstd)
         ctx.act, ctx.c, ctx.reduce_fn, ctx.has_res, ctx.groups, ctx.per_item = act, c, reduce_fn, residual is not None, groups, per_item
         ctx.plan = plan
+        # BatchNorm + ReLU: what an exclusive consumer needs to run the mask and the backward sums in its data-gradient epilogue
+        ctx.out_gate = None
+        if opts is not None and _EPI and act == 1 and ctx.needs_input_grad[0]:
+            gt = _Gate("bn", 3)
+            gt.has_res = residual is not None
+            gt.x, gt.mean, gt.invstd, gt.gamma, gt.beta, gt.groups = x, mean, invstd, g, b_, groups
+            ctx.out_gate = opts.gate = gt
         # flat-gradient sinks of the affine parameters (codeps_amd.step): the backward accumulates dgamma / dbeta in place
         gs, bs = grad_sink(gamma), grad_sink(beta)
         ctx.sinks = (gs, bs) if (gs is not None and bs is not None and gamma.requires_grad and beta.requires_grad) else None
@@ -915,6 +1082,7 @@ class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, g, b_, mean, invstd = ctx.saved_tensors
+        gated = ctx.out_gate.take(dy) if ctx.out_gate is not None else None
         dy = dy.contiguous()
         cp = x.shape[-1]
         ng, row0, rows = _group_arrays(ctx.groups, ctx.per_item)
@@ -927,8 +1095,36 @@ class _BatchNormTrain(torch.autograd.Function):
             dgamma = torch.empty(ctx.c, dtype=torch.float32, device=dev)
             dbeta, acc = torch.empty_like(dgamma), 0
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
+        if gated is not None:
+            # dy arrived masked (relu') from the consumer's data-gradient epilogue, with (sum g, sum g * xhat) per tile: the reduce pass
+            # is a finish over the partials, the apply pass reads dy without a mask, and the residual's gradient IS dy
+            segs = gated["segs"]
+            ns = len(segs)
+            iarr = ctypes.c_int * ns
+            ngi, gb0, gb1 = _img_groups(ctx.groups)
+            t0s, tpis, trs = iarr(*[sg[0] for sg in segs]), iarr(*[sg[1] for sg in segs]), iarr(*[sg[2] for sg in segs])
+
+            def tiles_pass(phase, global_sums):
+                check(lib().codeps_bn_bwd_tiles(ptr(gated["part"]), ns, t0s, tpis, trs, ng, row0, rows, gb0, gb1, ptr(dy), ptr(x), cp, ctx.c,
+                                                ptr(mean), ptr(invstd), ptr(g), inv_count, ptr(sums), ptr(global_sums), ptr(dgamma), ptr(dbeta),
+                                                acc, ptr(dx), phase, stream_ptr()), "codeps_bn_bwd_tiles")
+            if ctx.reduce_fn is None:
+                tiles_pass(0, None)
+            else:
+                tiles_pass(1, None)
+                if ctx.plan is not None:
+                    l2g = ctx.plan["index"](dev)
+                    sums_g = torch.zeros(ctx.plan["n_global"], 2, cp, dtype=torch.float32, device=dev)
+                    sums_g.index_copy_(0, l2g, sums)
+                    gsums = ctx.reduce_fn.sum(sums_g).index_select(0, l2g)
+                else:
+                    gsums = ctx.reduce_fn.sum(sums.clone())          # (the local sums stay: dgamma / dbeta are this rank's)
+                tiles_pass(2, gsums)
+            if ctx.sinks is not None:
+                dgamma = dbeta = None
+            return dx, dgamma, dbeta, (dy if (ctx.has_res and ctx.needs_input_grad[3]) else None), None, None, None, None, None, None, None, None
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         if ctx.reduce_fn is None:
             check(lib().codeps_bn_bwd_mg(ptr(dy), ptr(y), ptr(x), ng, row0, rows, cp, ctx.c, ptr(mean), ptr(invstd), ptr(g), ptr(b_), inv_count,
                                          ctx.act, ptr(sums), ptr(dgamma), ptr(dbeta), acc, ptr(dx), ptr(dres), 0, 0, ptr(ws), ws.numel(),
@@ -949,7 +1145,7 @@ class _BatchNormTrain(torch.autograd.Function):
                                          stream_ptr()), "codeps_bn_bwd_mg")
         if ctx.sinks is not None:
             dgamma = dbeta = None           # already accumulated into the flat gradient buffer
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
 class _BatchNormEval(torch.autograd.Function):
@@ -998,10 +1194,23 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, residua
     return _BatchNormEval.apply(x, gamma, beta, residual, running_mean, running_var, float(eps), ACT[act])
 
 
+class _BnOpts:
+    __slots__ = ("stats", "gate")
+
+    def __init__(self, stats=None):
+        self.stats, self.gate = stats, None
+
+
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None, act=None,
                      reduce_fn=None, groups=None):
-    return _BatchNormTrain.apply(x, gamma, beta, residual, running_mean, running_var, float(momentum), float(eps), ACT[act],
-                                 reduce_fn, groups)
+    """x may carry `._codeps_stats` (conv2d(..., bn_stats=True)): the statistics pass then is a finish over per-tile partials.  A ReLU
+    output carries `._codeps_gate` for a convolution that consumes it exclusively (conv2d(..., exclusive=True))."""
+    opts = _BnOpts(getattr(x, "_codeps_stats", None))
+    y = _BatchNormTrain.apply(x, gamma, beta, residual, running_mean, running_var, float(momentum), float(eps), ACT[act],
+                              reduce_fn, groups, opts)
+    if opts.gate is not None:
+        y._codeps_gate = opts.gate
+    return y
 
 
 # ---------------------------------------------------------------------------------------- pooling / resize
@@ -1039,15 +1248,18 @@ _BNPOOL = os.environ.get("CODEPS_BNPOOL", "1") != "0"      # A/B switch: 0 = tra
 class _BnReluPoolTrain(torch.autograd.Function):
     """maxpool3x3s2(relu(batch_norm_train(z))) of the stem (models/resnet_encoder.py:118-121) without the full-resolution activation
     or its gradient (C ABI: codeps_bn_fwd_mg(stats_only) + codeps_bn_relu_pool_{fwd,bwd}); `groups` as in _BatchNormTrain.  Bit-identical
-    to the two separate ops.  Local statistics only (no SyncBatchNorm reducer)."""
+    to the two separate ops.  `reduce_fn` (round 5): SyncBatchNorm -- statistics pass, all-gather + codeps_bn_sync_combine (equal or
+    unequal shards, exactly as _BatchNormTrain), pooled pass; backward: this rank's sums, all-reduce, dz pass
+    (misc/train_utils.py:50-51)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, groups):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, groups, reduce_fn=None):
         require_cuda(z, gamma, beta)
         z = z.contiguous()
         bsz, h, w, cp = z.shape
         c = gamma.numel()
         per_item = h * w
+        plan = getattr(groups, "plan", None) if reduce_fn is not None else None
         groups = [(0, bsz)] if not groups else list(groups)
         ng, row0, rows = _group_arrays(groups, per_item)
         g, b_ = _pad_vec(gamma, cp), _pad_vec(beta, cp)
@@ -1056,17 +1268,47 @@ class _BnReluPoolTrain(torch.autograd.Function):
         var, invstd = torch.empty_like(mean), torch.empty_like(mean)
         ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
         rm = running_mean if (running_mean is not None and running_mean.numel() == c) else None
-        check(lib().codeps_bn_fwd_mg(ptr(z), ng, row0, rows, cp, c, None, None, None, 1, eps, momentum, ptr(rm),
-                                     ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), None, 1, 0,
-                                     ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg (statistics)")
+        rv = running_var if rm is not None else None
+        counts = [float((b1 - b0) * per_item) for b0, b1 in groups]
+
+        def local_stats(mean_o, var_o, rm_, rv_):
+            check(lib().codeps_bn_fwd_mg(ptr(z), ng, row0, rows, cp, c, None, None, None, 1, eps, momentum, ptr(rm_), ptr(rv_), ptr(mean_o),
+                                         ptr(var_o), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg (statistics)")
+        if reduce_fn is None:
+            local_stats(mean, var, rm, rv)
+        elif plan is not None:          # unequal shards: one packet slot per GLOBAL statistic group (see _BatchNormTrain)
+            G, l2g = plan["n_global"], plan["index"](dev)
+            pk_local = torch.empty(2, ng, cp, dtype=torch.float32, device=dev)
+            local_stats(pk_local[0], pk_local[1], None, None)
+            pk = torch.zeros(2, G, cp, dtype=torch.float32, device=dev)
+            pk.index_copy_(1, l2g, pk_local)
+            gathered = reduce_fn.gather(pk)
+            world = gathered.shape[0]
+            rank_counts = [plan["items"][r][gg] * per_item for r in range(world) for gg in range(G)]
+            gcounts = [sum(plan["items"][r][gg] for r in range(world)) * per_item for gg in range(G)]
+            mean_g = torch.empty(G, cp, dtype=torch.float32, device=dev)
+            var_g, invstd_g = torch.empty_like(mean_g), torch.empty_like(mean_g)
+            check(lib().codeps_bn_sync_combine(ptr(gathered), world, G, (ctypes.c_float * G)(*gcounts), (ctypes.c_float * (world * G))(*rank_counts),
+                                               cp, c, eps, momentum, ptr(rm), ptr(rv), ptr(mean_g), ptr(var_g), ptr(invstd_g), stream_ptr()),
+                  "codeps_bn_sync_combine")
+            mean, var, invstd = mean_g.index_select(0, l2g), var_g.index_select(0, l2g), invstd_g.index_select(0, l2g)
+            counts = [gcounts[gg] for gg in plan["local_to_global"]]
+        else:
+            pk = torch.empty(2, ng, cp, dtype=torch.float32, device=dev)
+            local_stats(pk[0], pk[1], None, None)
+            gathered = reduce_fn.gather(pk)
+            world = gathered.shape[0]
+            counts = [n * world for n in counts]
+            check(lib().codeps_bn_sync_combine(ptr(gathered), world, ng, (ctypes.c_float * ng)(*counts), None, cp, c, eps, momentum, ptr(rm), ptr(rv),
+                                               ptr(mean), ptr(var), ptr(invstd), stream_ptr()), "codeps_bn_sync_combine")
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = torch.empty(bsz, ho, wo, cp, dtype=torch.float32, device=dev)
         arg = torch.empty(bsz, ho, wo, cp, dtype=torch.uint8, device=dev)
         check(lib().codeps_bn_relu_pool_fwd(ptr(z), ng, row0, rows, bsz, h, w, cp, ptr(mean), ptr(invstd), ptr(g), ptr(b_), ptr(y), ptr(arg),
                                             stream_ptr()), "codeps_bn_relu_pool_fwd")
-        ctx.inv_count = [1.0 / ((b1 - b0) * per_item) for b0, b1 in groups]
+        ctx.inv_count = [1.0 / n for n in counts]
         ctx.save_for_backward(z, arg, g, b_, mean, invstd)
-        ctx.c, ctx.groups, ctx.geom = c, groups, (bsz, h, w, cp)
+        ctx.c, ctx.groups, ctx.geom, ctx.reduce_fn, ctx.plan = c, groups, (bsz, h, w, cp), reduce_fn, plan
         gs, bs = grad_sink(gamma), grad_sink(beta)
         ctx.sinks = (gs, bs) if (gs is not None and bs is not None and gamma.requires_grad and beta.requires_grad) else None
         return y
@@ -1086,16 +1328,31 @@ class _BnReluPoolTrain(torch.autograd.Function):
             dbeta, acc = torch.empty_like(dgamma), 0
         dz = torch.empty_like(z)
         ws = _workspace(lib().codeps_bn_mg_workspace_bytes(ng, cp), dev, "bn")
-        check(lib().codeps_bn_relu_pool_bwd(ptr(dy.contiguous()), ptr(arg), ptr(z), ng, row0, rows, bsz, h, w, cp, ctx.c, ptr(mean), ptr(invstd),
-                                            ptr(g), ptr(b_), inv_count, ptr(sums), ptr(dgamma), ptr(dbeta), acc, ptr(dz), ptr(ws), ws.numel(),
-                                            stream_ptr()), "codeps_bn_relu_pool_bwd")
+        dyc = dy.contiguous()
+
+        def run(phase, s_):
+            check(lib().codeps_bn_relu_pool_bwd(ptr(dyc), ptr(arg), ptr(z), ng, row0, rows, bsz, h, w, cp, ctx.c, ptr(mean), ptr(invstd),
+                                                ptr(g), ptr(b_), inv_count, ptr(s_), ptr(dgamma), ptr(dbeta), acc, ptr(dz), ptr(ws), ws.numel(),
+                                                phase, stream_ptr()), "codeps_bn_relu_pool_bwd")
+        if ctx.reduce_fn is None:
+            run(0, sums)
+        else:
+            run(1, sums)                                   # this rank's sums (+ its dgamma / dbeta: DDP adds the ranks' later)
+            if ctx.plan is not None:
+                l2g = ctx.plan["index"](dev)
+                sums_g = torch.zeros(ctx.plan["n_global"], 2, cp, dtype=torch.float32, device=dev)
+                sums_g.index_copy_(0, l2g, sums)
+                sums = ctx.reduce_fn.sum(sums_g).index_select(0, l2g).contiguous()
+            else:
+                sums = ctx.reduce_fn.sum(sums)
+            run(2, sums)
         if ctx.sinks is not None:
             dgamma = dbeta = None
-        return dz, dgamma, dbeta, None, None, None, None, None
+        return dz, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_relu_maxpool_train(z, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, groups=None):
-    return _BnReluPoolTrain.apply(z, gamma, beta, running_mean, running_var, momentum, eps, groups)
+def bn_relu_maxpool_train(z, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, groups=None, reduce_fn=None):
+    return _BnReluPoolTrain.apply(z, gamma, beta, running_mean, running_var, momentum, eps, groups, reduce_fn)
 
 
 class _Bilinear(torch.autograd.Function):
@@ -1361,7 +1618,10 @@ def channel_argmax(probs, dtype=torch.int64):
     b, c, h, w = probs.shape
     probs = probs.detach()
     st = probs.stride()
-    if probs.dtype == torch.float32 and st[1] == 1 and st[3] >= c and st[3] % 4 == 0 and st[2] == w * st[3] and st[0] == h * w * st[3]:
+    # in place only for a view that starts at channel 0 of a 16-byte aligned pixel (the kernel issues f32x4 loads and the widened view
+    # must stay inside the storage): anything else goes through a contiguous copy
+    if (probs.dtype == torch.float32 and st[1] == 1 and st[3] >= c and st[3] % 4 == 0 and st[2] == w * st[3] and st[0] == h * w * st[3]
+            and probs.storage_offset() % st[3] == 0 and probs.data_ptr() % 16 == 0):
         x = probs.as_strided((b, h, w, st[3]), (st[0], st[2], st[3], 1))      # a channel view of a padded NHWC tensor: read in place
     else:
         x = from_nchw(probs).contiguous()
@@ -1371,7 +1631,7 @@ def channel_argmax(probs, dtype=torch.int64):
     check(lib().codeps_channel_argmax(ptr(x), b * h * w, c, cp, ptr(o64), ptr(o8), stream_ptr()), "codeps_channel_argmax")
     if o64 is None:
         return o8
-    o64._codeps_u8 = o8
+    o64._codeps_u8 = (o8, o64._version)        # valid while the int64 map is unmodified (panoptic_fusion checks the version)
     return o64
 
 
@@ -1870,9 +2130,11 @@ def panoptic_fusion(semantic, center, offset, thing_list, label_divisor=1000, vo
     require_cuda(semantic, center, offset)
     b, h, w = semantic.shape
     # the uint8 form of an int64 label map made by channel_argmax travels with it (no conversion pass)
-    sem8 = semantic if semantic.dtype == torch.uint8 else getattr(semantic, "_codeps_u8", None)
-    if sem8 is None or tuple(sem8.shape) != (b, h, w):
-        sem8 = semantic.to(torch.uint8)
+    sem8 = semantic
+    if semantic.dtype != torch.uint8:
+        twin = getattr(semantic, "_codeps_u8", None)
+        # an in-place edit of the int64 map after channel_argmax (e.g. masking labels) bumps its version: the twin is stale then
+        sem8 = twin[0] if (twin is not None and twin[1] == semantic._version and tuple(twin[0].shape) == (b, h, w)) else semantic.to(torch.uint8)
     sem8 = sem8.contiguous()
     center, offset = center.detach(), offset.detach()
     if center.dtype != torch.float32 or offset.dtype != torch.float32:

@@ -52,16 +52,21 @@ def folded_bn(bn: nn.BatchNorm2d):
     return scale, shift
 
 
-def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None, groups=None, stem=False, fork=False):
+def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None, groups=None, stem=False, fork=False,
+            exclusive=False):
     """act(BN(conv(x)) + residual).  Eval-mode BN is folded into the conv epilogue (one kernel);
     train-mode BN uses batch statistics (`sync` = cross-rank sum reducer for SyncBatchNorm).
     stem=True: x is in the double-pixel stem layout and conv is ResNet's conv1 (F.stem_conv2d).
     fork=True -> (out, x'): x' is x for the block's other consumer of the tensor (identity / shortcut); when x needs a gradient the
-    convolution's data-gradient kernel then adds the gradient that comes back through x' in its epilogue (F.conv2d(fork=True))."""
+    convolution's data-gradient kernel then adds the gradient that comes back through x' in its epilogue (F.conv2d(fork=True)).
+    exclusive=True: this call (with the taker of its fork alias) is x's only consumer, so the backward of the activation that produced
+    x may run in this convolution's data-gradient epilogue (F.conv2d(exclusive=True)).  Train-mode BatchNorm takes its batch statistics
+    from the convolution's epilogue (F.conv2d(bn_stats=True)) where the launch plan allows."""
     if fork:
         if not (_FORK and torch.is_grad_enabled() and x.requires_grad) or stem:
+            # (without the fork the alias is x itself: a second consumer autograd sums separately -> not exclusive)
             return conv_bn(x, conv, bn, act, residual, sync, groups, stem), x
-        return _conv_bn_fork(x, conv, bn, act, residual, sync, groups)
+        return _conv_bn_fork(x, conv, bn, act, residual, sync, groups, exclusive)
     stride, pad = conv.stride[0], conv.padding[0]
     if stem == "s3":                   # frozen 3-channel stem (eval BN folded, no gradients): F.stem3_conv2d, K = 224
         scale, shift = folded_bn(bn)
@@ -78,34 +83,35 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
         scale, shift = folded_bn(bn)
         return F.stem_conv2d(x, conv.weight, scale=scale, shift=shift, act=act)
     if bn.training:
-        y = F.conv2d(x, conv.weight, stride=stride, pad=pad)
+        y = F.conv2d(x, conv.weight, stride=stride, pad=pad, exclusive=exclusive, bn_stats=True)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                  residual=residual, act=act, reduce_fn=sync, groups=groups)
         _count_batch(bn, len(groups) if groups else 1)
         return out
     if torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad):
         # eval statistics but trainable affine parameters: keep BN as its own op so gamma/beta get gradients
-        y = F.conv2d(x, conv.weight, stride=stride, pad=pad)
+        y = F.conv2d(x, conv.weight, stride=stride, pad=pad, exclusive=exclusive)
         return F.batch_norm_eval(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual=residual, act=act)
     scale, shift = folded_bn(bn)
-    return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act)
+    return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act, exclusive=exclusive)
 
 
-def _conv_bn_fork(x, conv, bn, act, residual, sync, groups):
+def _conv_bn_fork(x, conv, bn, act, residual, sync, groups, exclusive=False):
     """conv_bn for an input that needs a gradient and has a second consumer (BN kept as its own op: x needs a gradient, so either BN is
     in train mode or, with eval statistics, its output still has to carry the graph)."""
     stride, pad = conv.stride[0], conv.padding[0]
     if bn.training:
-        y, xa = F.conv2d(x, conv.weight, stride=stride, pad=pad, fork=True)
+        y, xa = F.conv2d(x, conv.weight, stride=stride, pad=pad, fork=True, exclusive=exclusive, bn_stats=True)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                  residual=residual, act=act, reduce_fn=sync, groups=groups)
         _count_batch(bn, len(groups) if groups else 1)
         return out, xa
     if bn.weight.requires_grad or bn.bias.requires_grad:
-        y, xa = F.conv2d(x, conv.weight, stride=stride, pad=pad, fork=True)
+        y, xa = F.conv2d(x, conv.weight, stride=stride, pad=pad, fork=True, exclusive=exclusive)
         return F.batch_norm_eval(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual=residual, act=act), xa
     scale, shift = folded_bn(bn)
-    return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act, fork=True)
+    return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act, fork=True,
+                    exclusive=exclusive)
 
 
 def dwconv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, sync=None):

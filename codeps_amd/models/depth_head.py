@@ -36,17 +36,20 @@ def _run_decoder(module, in_feats, keep=()):
     kept = {}
     for i in range(4, -1, -1):
         c0, c1 = module.upconvs_0[str(i)][0], module.upconvs_1[str(i)][0]
+        # exclusive: the previous stage's output (i < 4; the encoder map of stage 4 has other readers) is read by this convolution alone,
+        # or by it and the taker of its fork alias -- its ELU backward and bias gradient then come out of this convolution's
+        # data-gradient epilogue (F.conv2d(exclusive=True)); likewise for the stage's own two convolutions
         if (i + 1) in kept and _FORK and torch.is_grad_enabled() and x.requires_grad:
             # the kept stage output has a second consumer (the GUDA fusion): it takes this convolution's alias of the tensor, so
             # that the two gradients meet in the data-gradient kernel's epilogue instead of a separate full-size sum
-            x, kept[i + 1] = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu", fork=True)
+            x, kept[i + 1] = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu", fork=True, exclusive=True)
         else:
-            x = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu")
+            x = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu", exclusive=i < 4 and (i + 1) not in kept)
         skip = F.from_nchw(in_feats[i - 1]) if (module.use_skips and i > 0) else None
         if skip is None and c1.in_channels == 16 and c1.out_channels == 16 and x.shape[-1] == 16 and _UPCONV16:
             x = F.upconv16(x, c1.weight, c1.bias, act="elu")      # scale 0: four 2x2 convolutions of the half-resolution tensor
         else:
-            x = F.conv2d(x, c1.weight, c1.bias, x1=skip, pad=1, act="elu", up0=True)
+            x = F.conv2d(x, c1.weight, c1.bias, x1=skip, pad=1, act="elu", up0=True, exclusive=True)
         if i in keep:
             kept[i] = x
     return x, kept

@@ -25,14 +25,17 @@ class PoseHead(nn.Module):
         self.convs[("pose", 2)] = nn.Conv2d(256, 6 * num_frames_to_predict_for, 1)
         self.relu = nn.ReLU()
         self.net = nn.ModuleList(list(self.convs.values()))
+        # True = this head is the ONLY reader of input_features[-1] (set with ResnetEncoder.only_last_feature by codeps.model_setup):
+        # the backward of the encoder's last BatchNorm + ReLU then runs in the squeeze convolution's data-gradient epilogue
+        self.owns_input = False
 
     def _features(self, input_features):
         x = F.from_nchw(input_features[-1])
         sq, p0, p1, p2 = self.net
-        x = F.conv2d(x, sq.weight, sq.bias, act="relu")
-        x = F.conv2d(x, p0.weight, p0.bias, stride=self.stride, pad=1, act="relu")
-        x = F.conv2d(x, p1.weight, p1.bias, stride=self.stride, pad=1, act="relu")
-        return F.conv2d(x, p2.weight, p2.bias)
+        x = F.conv2d(x, sq.weight, sq.bias, act="relu", exclusive=self.owns_input)
+        x = F.conv2d(x, p0.weight, p0.bias, stride=self.stride, pad=1, act="relu", exclusive=True)
+        x = F.conv2d(x, p1.weight, p1.bias, stride=self.stride, pad=1, act="relu", exclusive=True)
+        return F.conv2d(x, p2.weight, p2.bias, exclusive=True)
 
     def forward(self, input_features: List[Tensor], invert_pose: bool = False) -> Tensor:
         # spatial mean, *0.01, frame 0 of num_frames_to_predict_for, Rodrigues, (inverse) composition: one kernel

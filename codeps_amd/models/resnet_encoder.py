@@ -27,12 +27,13 @@ class _BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
-    def forward_nhwc(self, x, sync, groups=None):
+    def forward_nhwc(self, x, sync, groups=None, own_input=False):
         # x has two consumers (conv1 and the identity / shortcut): the second one takes conv1's alias of it, so that the gradients
-        # meet inside conv1's data-gradient kernel
-        out, xa = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups, fork=True)
+        # meet inside conv1's data-gradient kernel.  own_input: this block is x's only reader (true between the blocks of a stage), so
+        # the ReLU / BatchNorm backward of the block that made x runs in conv1's data-gradient epilogue; `out` is conv2's alone.
+        out, xa = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups, fork=True, exclusive=own_input)
         identity = xa if self.downsample is None else conv_bn(xa, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
-        return conv_bn(out, self.conv2, self.bn2, "relu", residual=identity, sync=sync, groups=groups)
+        return conv_bn(out, self.conv2, self.bn2, "relu", residual=identity, sync=sync, groups=groups, exclusive=True)
 
 
 class _Bottleneck(nn.Module):
@@ -48,11 +49,11 @@ class _Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.downsample = downsample
 
-    def forward_nhwc(self, x, sync, groups=None):
-        out, xa = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups, fork=True)
+    def forward_nhwc(self, x, sync, groups=None, own_input=False):
+        out, xa = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups, fork=True, exclusive=own_input)
         identity = xa if self.downsample is None else conv_bn(xa, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
-        out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync, groups=groups)
-        return conv_bn(out, self.conv3, self.bn3, "relu", residual=identity, sync=sync, groups=groups)
+        out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync, groups=groups, exclusive=True)
+        return conv_bn(out, self.conv3, self.bn3, "relu", residual=identity, sync=sync, groups=groups, exclusive=True)
 
 
 def _frozen_eval(*mods):
@@ -62,23 +63,26 @@ def _frozen_eval(*mods):
     return not torch.is_grad_enabled() or not any(p.requires_grad for m in mods for p in m.parameters())
 
 
-def _run_layer(layer, x, sync, groups):
+def _run_layer(layer, x, sync, groups, own_input=False):
     """One ResNet stage.  Frozen bottlenecks in eval mode whose mid width is 256 (ResNet-50 / 101 layer3: 22 of the 101's 33
     bottlenecks) hand their last layer to the NEXT bottleneck's first one inside one launch (F.chain_expand_reduce: conv3 + bn3
     + residual + ReLU, then conv1' + bn1' + ReLU, the 1024-channel tensor passing from one product to the other in
-    registers); every other block runs layer by layer."""
+    registers); every other block runs layer by layer.
+    own_input: the stage is the only reader of x (the caller keeps no other use of the previous stage's map); between the blocks of a
+    stage that is always so -- see _BasicBlock.forward_nhwc."""
     blocks = list(layer)
     y0 = None                                                  # relu(bn1(conv1(x))) of the current block, when the previous launch made it
     for i, blk in enumerate(blocks):
+        own = own_input if i == 0 else True
         if not isinstance(blk, _Bottleneck):
-            x = blk.forward_nhwc(x, sync, groups)
+            x = blk.forward_nhwc(x, sync, groups, own)
             continue
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
         xa = x
         if y0 is None:
-            y0, xa = conv_bn(x, blk.conv1, blk.bn1, "relu", sync=sync, groups=groups, fork=True)
+            y0, xa = conv_bn(x, blk.conv1, blk.bn1, "relu", sync=sync, groups=groups, fork=True, exclusive=own)
         identity = xa if blk.downsample is None else conv_bn(xa, blk.downsample[0], blk.downsample[1], sync=sync, groups=groups)
-        y1 = conv_bn(y0, blk.conv2, blk.bn2, "relu", sync=sync, groups=groups)
+        y1 = conv_bn(y0, blk.conv2, blk.bn2, "relu", sync=sync, groups=groups, exclusive=True)
         y0 = None
         if (nxt is not None and nxt.downsample is None and nxt.conv1.out_channels == 256 and blk.conv3.in_channels == 256
                 and F.chain_ok(y1, blk.conv3.out_channels) and _frozen_eval(blk.bn3, blk.conv3, nxt.bn1, nxt.conv1)
@@ -87,7 +91,7 @@ def _run_layer(layer, x, sync, groups):
             s3, t3 = folded_bn(nxt.bn1)
             x, y0 = F.chain_expand_reduce(y1, identity, blk.conv3.weight, s2, t2, nxt.conv1.weight, s3, t3)
         else:
-            x = conv_bn(y1, blk.conv3, blk.bn3, "relu", residual=identity, sync=sync, groups=groups)
+            x = conv_bn(y1, blk.conv3, blk.bn3, "relu", residual=identity, sync=sync, groups=groups, exclusive=True)
     return x
 
 
@@ -185,12 +189,12 @@ class ResnetEncoder(nn.Module):
             x = F.images_to_nhwc([input_image], cp, xpad)
         else:
             x = F.from_nchw(input_image, 16)
-        if self.only_last_feature and F._BNPOOL and enc.bn1.training and self.sync_bn is None and stem != "s3":
+        if self.only_last_feature and F._BNPOOL and enc.bn1.training and stem != "s3":
             # train-mode stem whose ReLU output nobody reads: statistics, then relu(bn(z)) max-pooled straight from z (and the backward
             # from the pooled gradient) -- 2.5 GB of the stem's 4.4 GB of BatchNorm / pooling traffic per step are not moved
             z = F.stem_conv2d(x, enc.conv1.weight) if stem else F.conv2d(x, enc.conv1.weight, stride=enc.conv1.stride[0], pad=enc.conv1.padding[0])
             x = F.bn_relu_maxpool_train(z, enc.bn1.weight, enc.bn1.bias, enc.bn1.running_mean, enc.bn1.running_var, enc.bn1.momentum,
-                                        enc.bn1.eps, groups)
+                                        enc.bn1.eps, groups, reduce_fn=self.sync_bn)        # (SyncBatchNorm too, since round 5)
             _count_batch(enc.bn1, len(groups) if groups else 1)
             feats = [None]
         else:
@@ -198,7 +202,8 @@ class ResnetEncoder(nn.Module):
             feats = [x]
             x = F.max_pool3x3s2(x)
         for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
-            x = _run_layer(layer, x, self.sync_bn, groups)
+            # only_last_feature: nobody but the next stage reads a stage's map
+            x = _run_layer(layer, x, self.sync_bn, groups, own_input=self.only_last_feature)
             feats.append(x)
         flush_bn_counters()
         return [None if f is None else F.to_nchw(f, int(c)) for f, c in zip(feats, self.num_ch_enc)]

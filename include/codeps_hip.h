@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* codeps_stream_t;
 
-int codeps_version(void);                 /* ABI version (8), bumped on any signature / buffer-contract change */
+int codeps_version(void);                 /* ABI version (9), bumped on any signature / buffer-contract change */
 const char* codeps_last_error(void);      /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------------------------------------
@@ -146,6 +146,38 @@ int codeps_conv2d_dgrad(const codeps_conv_desc* d, int source, const float* dz, 
  * full-size sum afterwards.  Stride-2 layers: pixels no tap reaches receive `add` alone. */
 int codeps_conv2d_dgrad_add(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, const float* add,
                             float* dx, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* Epilogue extras of a forward / data-gradient launch (round 5): work that used to be separate full-size passes right after the
+ * convolution, done on the value the epilogue is about to store (after the residual / second-gradient add).
+ *   gate_act 1 / 2: v *= ReLU' / ELU'(gate)  -- `gate` = the OUTPUT of the activation that produced the tensor whose gradient this
+ *                   launch computes (its own input x0): the producer's activation backward (models/depth_head.py:63-71, the decoders'
+ *                   conv + ELU chain; models/pose_head.py:36-44) needs no pass of its own.
+ *   gate_act 3:     train-mode BatchNorm (+ ReLU) backward, first half (torchvision BasicBlock / Bottleneck behind
+ *                   models/resnet_encoder.py:115-126): xhat = (bn_x - mean[g]) * invstd[g], g = statistic group of the row's image;
+ *                   v is masked with (gate > 0) when `gate` (the block output, a residual fed the ReLU) is given, else with
+ *                   (xhat * gamma + beta > 0) when bn_relu; stat_mode 3 sums (v, v * xhat) per tile: BatchNorm's backward reduce pass.
+ *   stat_mode 1:    per M tile (shift = the tile's first row, sum (v - shift), sum (v - shift)^2) of a FORWARD launch: the batch
+ *                   statistics of the train-mode BatchNorm that follows, without reading the tensor again.
+ *   stat_mode 2:    per M tile column sums (the bias gradient of the gated tensor's producer).
+ * stat_part: [tiles][3 | 1 | 2][cols] floats, codeps_conv2d_epilogue_part_bytes(GEMM rows of the launch, cols, stat_mode) bytes.
+ * Out fields: `applied` bit 0 = the gate was applied, bit 1 = the statistics were written.  Statistics and the BatchNorm gate need
+ * every M tile inside one image and a launch without K slices; when the tile plan of the shape cannot give that, they are dropped
+ * TOGETHER (bits clear, result ungated) and the caller runs the separate kernels.  Tiles of segment k (the stride-2 data gradient is
+ * four launches = up to four segments) are seg_tile0[k] .. + seg_tiles[k], seg_tile_rows[k] rows each, seg_tiles_per_image[k] per image. */
+typedef struct {
+    const float* gate; int32_t gate_act; int32_t stat_mode;
+    float* stat_part; size_t stat_part_bytes;
+    const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;
+    int32_t bn_relu, bn_groups; int32_t bn_group_b0[8];
+    int32_t applied, n_seg; int32_t seg_tile0[4], seg_tiles_per_image[4], seg_tile_rows[4], seg_tiles[4];
+} codeps_conv_epilogue;
+size_t codeps_conv2d_epilogue_part_bytes(long long gemm_rows, int cols, int stat_mode);
+/* codeps_conv2d_fwd / codeps_conv2d_dgrad_add with epilogue extras (epilogue may be NULL = the plain call). */
+int codeps_conv2d_fwd_ex(const codeps_conv_desc* d, const float* x0, const float* x1, const float* w_fwd,
+                         const float* scale, const float* shift, const float* residual, float* y,
+                         void* workspace, size_t workspace_bytes, codeps_conv_epilogue* epilogue, codeps_stream_t stream);
+int codeps_conv2d_dgrad_ex(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, const float* add,
+                           float* dx, void* workspace, size_t workspace_bytes, codeps_conv_epilogue* epilogue,
+                           codeps_stream_t stream);
 /* Two FROZEN 1x1 layers of consecutive ResNet bottlenecks in one launch (inference only; csrc/chain1x1.hip; replaces
  * conv3 + bn3 + residual + ReLU of bottleneck i and conv1 + bn1 + ReLU of bottleneck i + 1, models/resnet_encoder.py:115-126):
  *     out[m][n2]  = relu(scale2 * (y1[m][:] . W2[n2][:]) + shift2 + residual[m][n2])     y1 [rows][256], out / residual [rows][n2]
@@ -191,6 +223,10 @@ size_t codeps_colsum_workspace_bytes(long long rows, int c, int k);
 int codeps_act_bwd(const float* dy, const float* y, const float* scale, int act, long long rows, int c,
                    float* dz, float* dbias, int c_real, int accumulate, void* workspace,
                    size_t workspace_bytes, codeps_stream_t stream);
+/* out[c_real] (= / +=) sum over tiles of part[tiles][c]: the bias gradient from the column sums a data-gradient launch left per M tile
+ * (codeps_conv_epilogue stat_mode 2), fixed order.  With the gate of that launch it replaces codeps_act_bwd for a conv + activation
+ * whose output feeds one convolution (models/depth_head.py:63-71). */
+int codeps_colsum_finish(const float* part, int tiles, int c, float* out, int c_real, int accumulate, codeps_stream_t stream);
 /* Train-mode BatchNorm (nn.BatchNorm2d / SyncBatchNorm, misc/train_utils.py:50-51): statistics leave
  * the library as raw sums so the caller can all-reduce them over ranks before normalising.
  *   bn_stats:       sums[0][c] = sum (x - s_c), sums[1][c] = sum (x - s_c)^2 with the shift s_c = x[0][c]
@@ -236,6 +272,22 @@ int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x, int n_grou
                      const float* gamma, const float* beta, const float* inv_count, int act, float* sums,
                      float* dgamma, float* dbeta, int accumulate, float* dx, float* dres, int reduce_only,
                      int apply_only, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* Train-mode BatchNorm statistics from convolution epilogues (codeps_conv_epilogue, round 5) instead of passes over the tensor
+ * (torchvision BatchNorm2d behind models/resnet_encoder.py:115-126; SyncBatchNorm: misc/train_utils.py:50-51).  Group g = images
+ * [group_b0[g], group_b1[g]).
+ * codeps_bn_finalize_tiles: stat_mode-1 partials of the producing forward launch -> mean / biased var / invstd [groups][c]; then
+ *   codeps_bn_fwd_mg(apply_only = 1), which -- given running_mean / running_var there -- also applies the momentum updates group after
+ *   group (SyncBatchNorm: mean / var go into the all-gather packet instead, codeps_bn_sync_combine updates the running statistics).
+ * codeps_bn_bwd_tiles: stat_mode-3 partials of the data-gradient launch that produced AND masked BatchNorm's incoming gradient g.
+ *   phase 1: partials -> local_sums [groups][2][c];  phase 2: dx = gamma * invstd * (g - sum g / n - xhat * sum (g xhat) / n) with `sums`
+ *   (NULL = local_sums; SyncBatchNorm: the all-reduced copy) and dgamma / dbeta (= / +=) from local_sums;  phase 0: both. */
+int codeps_bn_finalize_tiles(const float* part, int tile0, int tiles_per_image, int tile_rows, int n_groups, const int* group_b0,
+                             const int* group_b1, int c, float eps, float* mean, float* var, float* invstd, codeps_stream_t stream);
+int codeps_bn_bwd_tiles(const float* part, int n_seg, const int* seg_tile0, const int* seg_tiles_per_image, const int* seg_tile_rows,
+                        int n_groups, const long long* row0, const long long* rows, const int* group_b0, const int* group_b1,
+                        const float* g, const float* x, int c, int c_real, const float* mean, const float* invstd,
+                        const float* gamma, const float* inv_count, float* local_sums, const float* sums, float* dgamma,
+                        float* dbeta, int accumulate, float* dx, int phase, codeps_stream_t stream);
 /* codeps_bn_bwd_mg: y may be NULL when act == 1 and the forward had no residual: the ReLU mask is then recomputed from
  * x, mean, invstd, gamma, beta (one tensor less to keep and to read per backward pass). */
 /* The stem in train mode, fused (models/resnet_encoder.py:118-121: bn1 -> relu -> maxpool; torchvision ResNet._forward_impl):
@@ -251,7 +303,8 @@ int codeps_bn_relu_pool_bwd(const float* dpooled, const uint8_t* argmax, const f
                             const long long* rows, int batch, int h, int w, int c, int c_real, const float* mean,
                             const float* invstd, const float* gamma, const float* beta, const float* inv_count, float* sums,
                             float* dgamma, float* dbeta, int accumulate, float* dz, void* workspace, size_t workspace_bytes,
-                            codeps_stream_t stream);
+                            int phase, codeps_stream_t stream);
+/* (phase 0: everything; 1: sums + dgamma / dbeta only; 2: dz from `sums` only -- SyncBatchNorm all-reduces the sums in between) */
 /* nn.MaxPool2d(3, 2, 1) (models/resnet_encoder.py:31); argmax = window tap 0..8 per element (u8). */
 int codeps_maxpool3x3s2_fwd(const float* x, int batch, int h, int w, int c, float* y, uint8_t* argmax,
                             codeps_stream_t stream);

@@ -60,3 +60,6 @@ def test_version_and_error_string():
 def test_structs_match_c_layout():
     assert ctypes.sizeof(_lib.PhotometricDesc) == 32 and _lib.PhotometricDesc.noise_seed.offset == 24
     assert ctypes.sizeof(_lib.ConvDesc) == 19 * 4 and _lib.ConvDesc.stride_w.offset == 15 * 4 and _lib.ConvDesc.row_pitch.offset == 18 * 4
+    # codeps_conv_epilogue: 2 pointers-with-ints up front, 5 pointers, 2 + 8 ints, 2 + 16 ints
+    assert ctypes.sizeof(_lib.ConvEpilogue) == 184 and _lib.ConvEpilogue.stat_part.offset == 16 and _lib.ConvEpilogue.bn_x.offset == 32
+    assert _lib.ConvEpilogue.bn_group_b0.offset == 80 and _lib.ConvEpilogue.applied.offset == 112 and _lib.ConvEpilogue.seg_tiles.offset == 168

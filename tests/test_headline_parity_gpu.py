@@ -1,0 +1,93 @@
+"""The composed network at the HEADLINE size against the oracle (missing item 3): one 512 x 1024 image through the frozen
+ResNet-101 encoder (eval-mode BatchNorm folded into the conv epilogues, the layer3 chain kernel, the kernel variants the cost model
+picks at this size), DepthHead and SemanticHead (GUDA fusion), compared with `oracle.network` / `oracle.heads` on the same weights in
+fp32 -- north_star's bar: depth / semantic LOGITS within 1e-3 -- and in float64 (how much of the difference is the fp32 reference's own
+rounding).  models/resnet_encoder.py:115-126, models/depth_head.py:56-78, models/semantic_head.py:46-76."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+from helpers import record_bar
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_r101_depth_and_semantic_logits_at_512x1024_against_oracle():
+    from codeps_amd.models import DepthHead, ResnetEncoder, SemanticHead
+    from oracle import heads as oheads
+    from oracle import resnet as oresnet
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 8 else 32))
+    layers, h, w, ncls = 101, 512, 1024, 14
+    sd = gi.fill_state_dict(gi.shapes_of(oresnet.make_state_dict(layers, 3, 0)), 77 + layers)
+    enc = ResnetEncoder(layers, False, 1, 3)
+    enc.load_state_dict({"encoder." + k: v for k, v in sd.items()})
+    enc.to(DEV)
+    x = gi.smooth_image(1, h, w, 5, 3)
+    # 101 layers of random weights with unit running statistics blow the activations up to 1e8: calibrate the running statistics
+    # with ONE train-mode pass (momentum 1: running = batch statistics of this image), as a trained checkpoint's would be -- the
+    # weights under test are whatever that leaves in the state dict, which the oracle then receives
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    enc.train()
+    with torch.no_grad():
+        enc(x.to(DEV))
+    enc.eval()
+    sd = {k[len("encoder."):]: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+    ch = enc.num_ch_enc
+    depth, sem = DepthHead(ch, True), SemanticHead(ch, ncls, True, True)
+    dsd = gi.fill_state_dict(gi.shapes_of(depth.state_dict()), 401)
+    ssd = gi.fill_state_dict(gi.shapes_of(sem.state_dict()), 402)
+    depth.load_state_dict(dsd)
+    sem.load_state_dict(ssd)
+    depth.to(DEV).eval()
+    sem.to(DEV).eval()
+    depth.logit_log, sem.logit_log = [], []
+    with torch.no_grad():
+        feats = enc(x.to(DEV))
+        d_hip = depth(feats)
+        p_hip = sem(feats)
+    torch.cuda.synchronize()
+    dl_hip, sl_hip = depth.logit_log[0].cpu(), sem.logit_log[0].cpu()
+
+    def oracle(dt):
+        cast = lambda t: t.to(dt) if t.is_floating_point() else t      # noqa: E731
+        with torch.no_grad():
+            of = oresnet.features({k: cast(v) for k, v in sd.items()}, x.to(dt), layers, training=False)
+            dl, sl = [], []
+            od, _ = oheads.depth_head({k: cast(v) for k, v in dsd.items()}, of, logits=dl)
+            op = oheads.semantic_head({k: cast(v) for k, v in ssd.items()}, of, True, logits_out=sl)
+        return of, dl[0], sl[0], od, op
+
+    of32, dl32, sl32, od32, op32 = oracle(torch.float32)
+    rec = {}
+    # encoder features first: a logit difference is only meaningful on equal features
+    for i, (a, b) in enumerate(zip(feats, of32)):
+        rec[f"feat{i}_max_abs_err_rel"] = float((a.cpu() - b).abs().max() / b.abs().max())
+        assert rec[f"feat{i}_max_abs_err_rel"] <= 2e-4, f"encoder feature {i}: {rec[f'feat{i}_max_abs_err_rel']:.2e} of its range"
+    e_d = float((dl_hip - dl32).abs().max())
+    e_s = float((sl_hip - sl32).abs().max())
+    rec.update(depth_logit_max_abs_err=e_d, depth_logit_max_abs=float(dl32.abs().max()), semantic_logit_max_abs_err=e_s,
+               semantic_logit_max_abs=float(sl32.abs().max()), logit_bar="1e-3 absolute vs the fp32 oracle (north_star)")
+    # float64 yardstick: how far the fp32 oracle itself is from the exact network
+    _of64, dl64, sl64, _od64, op64 = oracle(torch.float64)
+    rec.update(depth_logit_err_vs_fp64=float((dl_hip.double() - dl64).abs().max()),
+               oracle_fp32_depth_logit_err_vs_fp64=float((dl32.double() - dl64).abs().max()),
+               semantic_logit_err_vs_fp64=float((sl_hip.double() - sl64).abs().max()),
+               oracle_fp32_semantic_logit_err_vs_fp64=float((sl32.double() - sl64).abs().max()))
+    arg_hip, arg32 = p_hip.argmax(1).cpu(), op32.argmax(1)
+    rec["semantic_argmax_differing_pixels"] = int((arg_hip != arg32).sum())
+    rec["depth_max_abs_err_m"] = float((d_hip.cpu() - od32).abs().max())
+    rec["depth_max_m"] = float(od32.max())
+    record_bar("headline_512x1024_r101_depth_semantic", **rec)
+    assert e_d <= 1e-3, f"disparity logits differ by {e_d:.3e} (north_star: 1e-3; they reach {rec['depth_logit_max_abs']:.1f})"
+    assert e_s <= 1e-3, f"semantic logits differ by {e_s:.3e} (north_star: 1e-3; they reach {rec['semantic_logit_max_abs']:.1f})"
+    # arg-max: equal wherever the fp32 oracle's own top-2 margin exceeds twice the logit error
+    top2 = sl32.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * max(e_s, 1e-6)
+    assert bool((arg_hip == arg32)[safe].all()), "semantic arg-max differs at a pixel whose margin exceeds the logit error"
+    # metres: 1e-3 absolute, or the conditioning of disp_to_depth (d depth / d logit ~ depth at the far end)
+    cap = float(((d_hip.cpu() - od32).abs() - 1e-4 * od32.abs()).max())
+    assert cap <= 1e-3, f"depth differs by {rec['depth_max_abs_err_m']:.3e} m: beyond 1e-3 + 1e-4 |depth|"

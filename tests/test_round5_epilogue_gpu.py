@@ -1,0 +1,255 @@
+"""Round-5 epilogue extras of the conv engine (codeps_conv_epilogue) against the separate passes they replace: activation backward +
+bias gradient in the consumer's data-gradient epilogue (bit-identical), train-mode BatchNorm statistics from the producing
+convolution's epilogue and BatchNorm's backward reduce from the consuming convolution's (same values up to summation order; checked
+against float64), the misuse guard of `exclusive=True`."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _F():
+    from codeps_amd import functional as F
+    return F
+
+
+def _nhwc(g, b, h, w, c, scale=1.0):
+    return (torch.randn(b, h, w, c, generator=g) * scale).to(DEV)
+
+
+def _conv_chain(F, x, ws, bs, acts, strides, exclusive, up=None, skip=None):
+    """conv + act chain on NHWC; layer i > 0 reads layer i - 1 exclusively when asked to"""
+    y = x
+    for i, (w, b, a, st) in enumerate(zip(ws, bs, acts, strides)):
+        k = w.shape[-1]
+        kw = dict(stride=st, pad=k // 2, act=a, exclusive=exclusive and i > 0)
+        if up is not None and i == up:
+            y = F.conv2d(y, w, b, x1=skip, up0=True, **kw)
+        else:
+            y = F.conv2d(y, w, b, **kw)
+    return y
+
+
+@pytest.mark.parametrize("case", [
+    # (b, h, w, channels per layer, kernel sizes, activations, strides)
+    (2, 32, 64, [64, 64, 64, 32], [3, 3, 3], ["elu", "elu", None], [1, 1, 1]),            # halo kernels, 64 and 32 columns
+    (2, 16, 32, [128, 128, 128], [3, 3], ["relu", "relu"], [1, 1]),                       # ring kernel (maybe K slices: the finish pass gates)
+    (1, 16, 32, [512, 256, 256, 16], [1, 3, 1], ["relu", "relu", None], [1, 1, 1]),       # pose head: 1x1 -> 3x3 -> 1x1 to 16 columns
+    (3, 32, 64, [32, 16, 16], [3, 3], ["elu", "elu"], [1, 1]),                            # 16-column kernels
+    (2, 32, 64, [64, 64, 128], [3, 3], ["relu", None], [1, 2]),                           # stride-2 consumer: four parity-class launches
+    (2, 8, 16, [256, 256, 256], [3, 3], ["elu", "elu"], [1, 1]),                          # small maps
+])
+def test_activation_backward_in_the_consumer_epilogue_is_bit_identical(case):
+    F = _F()
+    b, h, w, chans, ks, acts, strides = case
+    g = torch.Generator().manual_seed(sum(chans) + h)
+    x = _nhwc(g, b, h, w, chans[0])
+    ws = [(torch.randn(chans[i + 1], chans[i], ks[i], ks[i], generator=g) / (chans[i] * ks[i] * ks[i]) ** 0.5).to(DEV).requires_grad_() for i in range(len(ks))]
+    bs = [(torch.randn(chans[i + 1], generator=g) * 0.1).to(DEV).requires_grad_() for i in range(len(ks))]
+    res = {}
+    for excl in (False, True):
+        xi = x.clone().requires_grad_()
+        y = _conv_chain(F, xi, ws, bs, acts, strides, excl)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        grads = torch.autograd.grad(y, [xi] + ws + bs, gy)
+        res[excl] = [y] + list(grads)
+    _same(res, len(bs))
+
+
+def _same(res, n_bias):
+    """everything bit for bit, except the bias gradients: their column sums come from per-tile partials of the consumer's launch
+    instead of act_bwd_kernel's row blocks -- another (fixed) order of the same additions"""
+    n = len(res[False])
+    for i, (a, c) in enumerate(zip(res[False], res[True])):
+        if i >= n - n_bias:
+            assert float((a - c).abs().max()) <= 2e-6 * (float(a.abs().max()) + float(a.abs().sum()) / a.numel() * 100), (i, float((a - c).abs().max()))
+        else:
+            assert torch.equal(a, c), (i, float((a - c).abs().max()))
+
+
+def test_gate_through_the_upsampling_decoder_stage_is_bit_identical():
+    """conv(i, 0) + ELU -> [nearest x2 + concat skip] conv(i, 1) + ELU -> conv(i - 1, 0): the gradient of the half-resolution tensor
+    comes out of a FORWARD launch (the 4 x 4 / stride-2 form of the up-convolution's data gradient), gated in its epilogue"""
+    F = _F()
+    g = torch.Generator().manual_seed(3)
+    b, h, w = 2, 16, 32
+    x = _nhwc(g, b, h, w, 128)
+    skip = _nhwc(g, b, 2 * h, 2 * w, 64)
+    mk = lambda co, ci: (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).to(DEV).requires_grad_()     # noqa: E731
+    ws = [mk(64, 128), mk(64, 128), mk(32, 64)]
+    bs = [(torch.randn(c, generator=g) * 0.1).to(DEV).requires_grad_() for c in (64, 64, 32)]
+    res = {}
+    for excl in (False, True):
+        xi = x.clone().requires_grad_()
+        y = _conv_chain(F, xi, ws, bs, ["elu", "elu", "elu"], [1, 1, 1], excl, up=1, skip=skip)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        res[excl] = [y] + list(torch.autograd.grad(y, [xi] + ws + bs, gy))
+    _same(res, len(bs))
+
+
+def test_forked_consumer_gates_the_sum_of_both_gradients():
+    """y = elu(conv(x)); z, y' = conv2d(y, fork=True, exclusive=True); loss reads z and y': (dgrad + gradient through y') * elu'(y)"""
+    F = _F()
+    g = torch.Generator().manual_seed(11)
+    x = _nhwc(g, 2, 32, 64, 64)
+    w0 = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV).requires_grad_()
+    b0 = torch.zeros(64, device=DEV).requires_grad_()
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV).requires_grad_()
+    res = {}
+    for excl in (False, True):
+        xi = x.clone().requires_grad_()
+        y = F.conv2d(xi, w0, b0, pad=1, act="elu")
+        z, ya = F.conv2d(y, w1, None, pad=1, fork=True, exclusive=excl)
+        loss = (z * z).sum() + (ya * 0.5).sum()
+        res[excl] = torch.autograd.grad(loss, [xi, w0, w1, b0])
+    _same(res, 1)
+
+
+def test_exclusive_with_a_second_consumer_raises():
+    F = _F()
+    from codeps_amd._lib import CodepsHipError
+    g = torch.Generator().manual_seed(12)
+    x = _nhwc(g, 1, 32, 64, 64).requires_grad_()
+    w0 = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV).requires_grad_()
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV).requires_grad_()
+    y = F.conv2d(x, w0, torch.zeros(64, device=DEV).requires_grad_(), pad=1, act="elu")
+    z = F.conv2d(y, w1, None, pad=1, exclusive=True)               # a lie: y is also read below
+    loss = z.sum() + (y * y).sum()
+    with pytest.raises((CodepsHipError, RuntimeError)):
+        loss.backward()
+        torch.cuda.synchronize()
+
+
+def _bn_modules(c_in, c, n_blocks, stride, seed):
+    from codeps_amd.models.resnet_encoder import _BasicBlock
+    from torch import nn
+    torch.manual_seed(seed)
+    blocks = []
+    for i in range(n_blocks):
+        ds = None
+        if i == 0 and (stride != 1 or c_in != c):
+            ds = nn.Sequential(nn.Conv2d(c_in, c, 1, stride, bias=False), nn.BatchNorm2d(c))
+        blocks.append(_BasicBlock(c_in if i == 0 else c, c, stride if i == 0 else 1, ds))
+    m = nn.Sequential(*blocks).to(DEV).train()
+    for p in m.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(0.5, 1.5)
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.bias.data.normal_(0, 0.3)
+    return m
+
+
+def _run_blocks(F, m, x, groups, own):
+    from codeps_amd.models.resnet_encoder import _run_layer
+    return _run_layer(m, x, None, groups, own_input=own)
+
+
+def _ref_blocks_f64(m, x_nhwc, groups):
+    """float64 torch reference of the BasicBlock stack with per-group batch statistics"""
+    import torch.nn.functional as tf
+    x = x_nhwc.permute(0, 3, 1, 2).double()
+
+    def bn(z, mod):
+        out = torch.empty_like(z)
+        for b0, b1 in groups:
+            zz = z[b0:b1]
+            mu = zz.mean((0, 2, 3), keepdim=True)
+            var = zz.var((0, 2, 3), unbiased=False, keepdim=True)
+            out[b0:b1] = (zz - mu) / torch.sqrt(var + mod.eps) * mod.weight.double().view(1, -1, 1, 1) + mod.bias.double().view(1, -1, 1, 1)
+        return out
+    for blk in m:
+        idn = x
+        out = torch.relu(bn(tf.conv2d(x, blk.conv1.weight.double(), None, blk.conv1.stride, 1), blk.bn1))
+        out = bn(tf.conv2d(out, blk.conv2.weight.double(), None, 1, 1), blk.bn2)
+        if blk.downsample is not None:
+            idn = bn(tf.conv2d(x, blk.downsample[0].weight.double(), None, blk.downsample[0].stride), blk.downsample[1])
+        x = torch.relu(out + idn)
+    return x.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("case", [(6, 64, 128, 64, 64, 2, 1, 3), (4, 64, 128, 64, 128, 2, 2, 2), (8, 32, 64, 256, 256, 2, 1, 1), (6, 32, 64, 256, 512, 2, 2, 2),
+                                  (6, 32, 64, 64, 64, 2, 1, 3), (2, 16, 32, 256, 512, 2, 2, 2)])
+def test_train_mode_batchnorm_through_the_conv_epilogues_against_float64(case):
+    """ResNet-18 stages in train mode: statistics from the producing convolution's epilogue, ReLU mask + (sum g, sum g xhat) in the
+    consuming convolution's data-gradient epilogue -- same results as the separate passes up to summation order: both compared with a
+    float64 evaluation of the same stack (outputs, input gradient, every parameter gradient, running statistics)"""
+    F = _F()
+    b, h, w, c_in, c, n_blocks, stride, ngroups = case
+    per = b // ngroups
+    groups = [(i * per, (i + 1) * per) for i in range(ngroups)]
+    g = torch.Generator().manual_seed(c + h)
+    x = _nhwc(g, b, h, w, c_in)
+    out = {}
+    for mode in ("separate", "fused"):
+        m = _bn_modules(c_in, c, n_blocks, stride, seed=7)
+        F._EPI = mode == "fused"
+        try:
+            xi = x.clone().requires_grad_()
+            y = _run_blocks(F, m, xi, groups if ngroups > 1 else None, True)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+            params = [p for p in m.parameters()]
+            grads = torch.autograd.grad(y, [xi] + params, gy)
+            stats = [t.clone() for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d) for t in (mod.running_mean, mod.running_var)]
+            out[mode] = (y.detach(), grads, stats, m)
+        finally:
+            F._EPI = True
+    # float64 yardstick
+    m64 = out["fused"][3]
+    x64 = x.clone().double().requires_grad_()
+    p64 = [p for p in m64.parameters()]
+    y64 = _ref_blocks_f64(m64, x64, groups)
+    g64 = torch.autograd.grad(y64, [x64] + p64, gy.double(), allow_unused=True)
+
+    # relative L2: a ReLU whose pre-activation is ~1e-7 may fall on the other side of zero under another summation order of the batch
+    # statistics, which moves single gradient elements by their full size (max-norm errors of 1e-3 .. 1e-2 against float64 in EITHER
+    # path, as in tests/test_modules_gpu.py) but not the norm
+    def err(a, ref):
+        return float((a.double() - ref).norm() / (ref.norm() + 1e-30))
+    e_sep, e_fus = err(out["separate"][0], y64), err(out["fused"][0], y64)
+    print(f"BN case {case}: output rel-L2 error vs float64: separate {e_sep:.2e}, fused {e_fus:.2e}")
+    assert e_fus <= max(2e-6, 3 * e_sep), (e_fus, e_sep)
+    for i, r in enumerate(g64):
+        if r is None:
+            continue
+        es, ef = err(out["separate"][1][i], r.double()), err(out["fused"][1][i], r.double())
+        assert ef <= max(5e-3, 3 * es), (i, ef, es)            # (a flipped ReLU moves the norm by ~ 1 / sqrt(elements))
+    for s_, f_ in zip(out["separate"][2], out["fused"][2]):
+        assert float((s_ - f_).abs().max()) <= 1e-5 * (1 + float(s_.abs().max()))
+
+
+def test_epilogue_kernels_really_ran():
+    """the fused path is the one that runs: after a fused BasicBlock step no bn_stats / bn_bwd_reduce launch is needed -- checked through
+    the hand-off records (a consumer that gated leaves one; the producer clears it)"""
+    F = _F()
+    g = torch.Generator().manual_seed(2)
+    x = _nhwc(g, 4, 64, 128, 64)
+    w0 = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV).requires_grad_()
+    y = F.conv2d(x, w0, None, pad=1, bn_stats=True)
+    assert getattr(y, "_codeps_stats", None) is not None and y._codeps_stats["rows"] in (128, 256)
+    gamma, beta = torch.ones(64, device=DEV).requires_grad_(), torch.zeros(64, device=DEV).requires_grad_()
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    z = F.batch_norm_train(y, gamma, beta, rm, rv, act="relu")
+    gate = getattr(z, "_codeps_gate", None)
+    assert gate is not None and gate.kind == "bn"
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV).requires_grad_()
+    o = F.conv2d(z, w1, None, pad=1, exclusive=True)
+    seen = {}
+    orig = F._Gate.take
+
+    def spy(self, dy):
+        if self is gate:
+            seen["handoff"] = self.handoff is not None and self.handoff["part"] is not None
+        return orig(self, dy)
+    F._Gate.take = spy
+    try:
+        o.sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        F._Gate.take = orig
+    assert seen.get("handoff") is True
+    # batch statistics from the tiles == the tensor's
+    yy = y.detach().double()
+    assert torch.allclose(rm.double(), 0.1 * yy.mean((0, 1, 2)), atol=1e-6)
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * yy.reshape(-1, 64).var(0, unbiased=True), rtol=1e-5)
