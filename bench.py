@@ -302,13 +302,11 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
                      "algorithmic_mb_per_launch": round(pb / pn / 1e6, 2), "avg_launch_us": round(ps / pn * 1e6, 1),
                      "launches_per_step": pn // steps, "ms_per_step": round(ps / steps * 1e3, 3), "traffic": ptraffic,
                      "wave_cycle_shares": photometric_shares(),
-                     "note": "84 B per pixel and batch item (40 forward + 44 backward, SURVEY.md 8d).  Neither HBM- nor VALU-bound (PMC, round 4: "
-                             "`wave_cycle_shares`): the forward issues vector-ALU instructions in 40 % of its wave cycles at 1.7 waves per SIMD "
-                             "(a 8 x 64 tile + halo per block in LDS, 4-tap gathers with dependent address arithmetic), parked at waits / barriers "
-                             "30 %, issue-stalled 23 %; the backward (4.7 waves per SIMD) is parked or stalled 73 % of the time behind its gathers "
-                             "-- latency / occupancy-bound.  traffic = PMC HBM bytes per launch; since round 3 it includes the warped samples and "
-                             "SSIM adjoint coefficients the forward keeps for the backward (60 B per pixel and scale, written once and read "
-                             "once) instead of recomputing them on a halo-2 tile"}
+                     "note": "84 B per pixel and batch item (40 forward + 44 backward, SURVEY.md 8d): achieved / frac are LIVE (HIP events of this "
+                             "run).  `wave_cycle_shares` and `traffic` are read from the newest committed profiles/rNN_* file (a separate rocprofv3 "
+                             "--pmc run of the same command, named in their `source` fields), not measured by this run; traffic = PMC HBM bytes per "
+                             "launch incl. the warped samples and SSIM adjoint coefficients the forward keeps for the backward (60 B per pixel and "
+                             "scale, written once and read once)"}
     # the vendor peak and the peak re-measured on this box (csrc/diag.hip: register-resident MFMA loop on operands
     # that change between consecutive MFMAs -- what the matrix pipe sustains under the power limit on real data -- and a stream
     # triad).  `peak` / `frac` stay on the vendor figure; the measured ones are reported beside them.
@@ -322,10 +320,10 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
                     "mfma_f32_random_tflops": m["mfma_f32_32x32x2_f32_random_tflops"], "hbm_triad_gbs": m["hbm_triad_gbs"],
                     "peak_of_this_arithmetic": round(mpeak, 1), "frac": round(ach / mpeak, 4),
                     "in_kernel_clock": clock_record(),
-                    "note": "live micro-kernels on this GPU: no-memory MFMA loop (zeros = how vendor peaks are quoted; random = operands changing "
-                            "between consecutive MFMAs) and a[i] = b[i] + s c[i] over 3 x 1 GiB.  The MFMA loop retires one "
-                            "v_mfma_f32_32x32x16_bf16 per 32.0 cycles on zeros AND on random operands; what falls on random data is the CLOCK the "
-                            "chip holds (in_kernel_clock: s_memtime / s_memrealtime stamps, 2.39 -> ~1.8 GHz; 16x16x32: 16.8 cycles, ~2.13 GHz)"}
+                    "note": "mfma_* / hbm_triad_gbs: LIVE micro-kernels on this GPU (no-memory MFMA loop; zeros = how vendor peaks are quoted, "
+                            "random = operands changing between consecutive MFMAs; a[i] = b[i] + s c[i] over 3 x 1 GiB).  in_kernel_clock: cycles "
+                            "per MFMA and the clock held, from the committed s_memtime / s_memrealtime stamp files named in its `source` (a "
+                            "diagnostic build; not measured by this run)"}
     except Exception as e:                                  # noqa: BLE001  (diagnostics never fail the bench)
         print(f"[bench] measured peaks unavailable ({type(e).__name__}: {e})", file=sys.stderr)
     return {"bound": "mfma", "secondary": secondary, "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -335,6 +333,38 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
                          "algorithmic_gflop_per_step": round(flops / steps / 1e9, 1)},
             "conv_ms_per_step": round(secs / steps * 1e3, 3), "algorithmic_gflop_per_step": round(flops / steps / 1e9, 1),
             "by_kind": detail}
+
+
+SECONDARY = (("configs1_pretrain", ["--mode", "train"]),
+             ("configs3_slice", ["--per-gpu-batch", "4"]),
+             ("configs4_slice", ["--mode", "train", "--encoder", "101", "--height", "1024", "--width", "2048", "--per-gpu-batch", "2", "--steps", "5",
+                                 "--warmup", "2"]),
+             ("frame", ["--mode", "frame"]))
+
+
+def secondary_rows():
+    """The other configurations BASELINE.json names that fit one GPU (configs[1], the per-GPU slices of configs[3] / configs[4]) and the
+    frame mode, each measured by a CHILD process of this bench (a fresh GPU context each; never an exec from a process that has touched
+    the GPU) with its own warm-up, graph capture, timed steps and conv roofline pass.  -> {name: {images/s, ms/step, roofline.frac, ...}}"""
+    import subprocess
+    out = {}
+    for name, flags in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), *flags, "--no-cpu-baseline", "--no-secondary"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+            d = json.loads(lines[-1])
+            roof = d.get("roofline") or {}
+            out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                         "step_ms_median": d["step_ms"]["median"], "steps": d["steps"], "workload": d["config"]["workload"],
+                         "launch": d["config"]["launch"], "peak_hbm_gb": d["config"]["peak_hbm_gb"],
+                         "roofline_frac": roof.get("frac"), "roofline_tflops": roof.get("achieved"),
+                         "conv_ms_per_step": roof.get("conv_ms_per_step"), "algorithmic_gflop_per_step": roof.get("algorithmic_gflop_per_step"),
+                         "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:                              # noqa: BLE001  (a secondary row never fails the headline measurement)
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def main():
@@ -358,7 +388,14 @@ def main():
                          "512x1024, B = 7) instead of the all-512x1024 B = 8 batch the BASELINE metric is quoted on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary rows (the other BASELINE configurations that fit one GPU + the frame mode), which the default "
+                         "single-GPU run measures in child processes BEFORE its own step and reports under `secondary`")
     args = ap.parse_args()
+    secondary = None
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_secondary and args.mode == "adapt" and args.encoder is None
+            and args.per_gpu_batch is None and (args.height, args.width) == (512, 1024) and not args.yaml_faithful and args.graph):
+        secondary = secondary_rows()        # before this process touches the GPU: one context at a time
 
     from codeps_amd import _lib
     from codeps_amd.distributed import init_from_env
@@ -484,7 +521,14 @@ def main():
                 "grad_allreduce_mb": round(buf.numel() * 4 / 1e6, 1), "grad_allreduce_ms": round(e0.elapsed_time(e1) / 5, 3),
                 "syncbn_allgathers_per_step": round((red.n_gather - red_before[0]) / args.steps, 1),
                 "syncbn_allreduces_per_step": round((red.n_reduce - red_before[1]) / args.steps, 1),
-                "launch": "eager (the SyncBN collectives sit inside forward / backward)"}
+                "launch": "eager (the SyncBN collectives sit inside forward / backward)",
+                # the gradient collective as the step issues it (codeps_amd.step): the heads' front of the flat buffer from inside the
+                # backward pass on its own stream, the encoders' back after it -- or one collective (CODEPS_AR_OVERLAP=0, unequal shards)
+                "grad_allreduce_segments": {"front_mb": round(runner._early_end * 4 / 1e6, 1),
+                                            "back_mb": round((buf.numel() - runner._early_end) * 4 / 1e6, 1),
+                                            "steps_with_the_front_overlapped": runner.ar_overlap_steps,
+                                            "overlap": "front segment all-reduced on a second stream while the encoders' backward pass runs"
+                                                       if runner._early_end else "none (single collective between backward and Adam)"}}
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -543,6 +587,8 @@ def main():
             line["cpu_baseline"] = cpu
         if comm is not None:
             line["comm"] = comm
+        if secondary is not None:
+            line["secondary"] = secondary
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -45,46 +45,8 @@ class SyncBatchNormReducer:
 
     def __init__(self, group=None):
         self.group = group
-        self._counts = {}           # (device, counts) -> device tensor: the per-group element counts never change between steps
         self._gather_out = {}       # (shape, dtype, device, stream) -> the all-gather's output buffer, reused by every step
         self.n_gather = self.n_reduce = 0      # collectives issued so far (bench.py reports them per step)
-
-    def _count_tensor(self, like, counts):
-        """Device copy of the local element counts, made once: a fresh host->device copy per BatchNorm layer would
-        synchronise the host with the stream 40 times per step and stop it from running ahead of the GPU."""
-        key = (like.device, tuple(float(n) for n in counts))
-        t = self._counts.get(key)
-        if t is None:
-            t = torch.tensor(key[1], dtype=like.dtype, device=like.device)
-            self._counts[key] = t
-        return t
-
-    def __call__(self, mean, var, count):
-        world = dist.get_world_size(self.group)
-        c = mean.numel()
-        packed = torch.cat([mean, var, self._count_tensor(mean, [count])])
-        g = self.gather(packed)                        # [world, 2c+1]
-        means, vars_, counts = g[:, :c], g[:, c:2 * c], g[:, 2 * c:]
-        total = counts.sum()
-        mean_all = (means * counts).sum(0) / total
-        var_all = ((vars_ + (means - mean_all) ** 2) * counts).sum(0) / total
-        # counts are equal on all ranks by construction (equal shards) -> no device->host read-back
-        return mean_all, var_all, float(count) * world
-
-    def combine_groups(self, mean, var, counts):
-        """All statistic groups of one BatchNorm layer in ONE all-gather: mean / var [G, C], counts = G floats."""
-        world = dist.get_world_size(self.group)
-        g, c = mean.shape
-        packed = torch.cat([mean.reshape(-1), var.reshape(-1), self._count_tensor(mean, counts)])
-        allp = self.gather(packed)                                    # [world, 2*G*C + G]
-        means = allp[:, :g * c].view(world, g, c)
-        vars_ = allp[:, g * c:2 * g * c].view(world, g, c)
-        cnts = allp[:, 2 * g * c:].view(world, g, 1)
-        total = cnts.sum(0)                                           # [G, 1]
-        mean_all = (means * cnts).sum(0) / total
-        var_all = ((vars_ + (means - mean_all) ** 2) * cnts).sum(0) / total
-        # counts are equal on all ranks by construction (equal shards) -> no host sync needed to read them back
-        return mean_all, var_all, [float(n) * world for n in counts]
 
     def gather(self, packet):
         """All-gather of one contiguous statistics packet -> [world, *packet.shape]: ONE all_gather_into_tensor (no per-rank
@@ -106,6 +68,20 @@ class SyncBatchNormReducer:
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
         self.n_reduce += 1
         return sums
+
+
+def combine_host(gathered, rank_counts=None):
+    """Host mirror of codeps_bn_sync_combine's merge (csrc/nn_ops.hip bn_sync_combine_kernel) for tests: gathered [world, 2, G, C] =
+    every rank's (mean, biased var) per statistic group -> (mean [G, C], var [G, C]) of the union by the parallel-variance formula;
+    rank_counts [world][G] = element counts (None: equal on all ranks, 0: the rank holds nothing of that group)."""
+    world, _, g, c = gathered.shape
+    w = torch.ones(world, g, 1, dtype=gathered.dtype) if rank_counts is None else torch.as_tensor(rank_counts, dtype=gathered.dtype).view(world, g, 1)
+    w = w.to(gathered.device)
+    means, vars_ = gathered[:, 0], gathered[:, 1]
+    tot = w.sum(0)
+    mean = (means * w).sum(0) / tot
+    var = ((vars_ + (means - mean) ** 2) * w).sum(0) / tot
+    return mean, var
 
 
 def shard_items(n_items, rank, world):

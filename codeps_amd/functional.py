@@ -732,6 +732,10 @@ class _Conv2d(torch.autograd.Function):
                 dw = None               # accumulated in place into the flat gradient buffer
         if add is not None:                                        # (a data-gradient form without the fused add, or no data gradient)
             dx0 = add if dx0 is None else dx0.add_(add)
+        wref = ctx.weight_ref()
+        done = getattr(wref, "_codeps_grad_done", None) if wref is not None else None
+        if done is not None:        # codeps_amd.step: this node is the last one of its module's backward (segmented gradient all-reduce)
+            done()
         return dx0, dx1, dw, dbias, None, None, dres, None, None, None, None, None, None, None, None
 
 

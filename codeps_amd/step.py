@@ -150,13 +150,19 @@ class StepRunner:
         def live(name):
             return not (".fc." in name or name.startswith("fc.") or any(f"dispconvs.{i}." in name for i in (1, 2, 3)))
         ema_params, other = [], []
-        for attr in ADAPT_MODULES.values():
+        # heads first, encoders last: the backward pass finishes the heads' gradients long before the encoders' (the pose encoder's
+        # stem weight gradient is the step's last kernel), so the flat buffer's front can be all-reduced while the back is still being
+        # written (world > 1: _segment_ready)
+        n_heads = 0
+        for attr in sorted(ADAPT_MODULES.values(), key=lambda a: a.startswith("backbone")):
             mod = getattr(net, attr, None)
             if mod is None:
                 continue
             for name, p in mod.named_parameters():
                 if p.requires_grad and live(name):
                     (ema_params if attr in ema_mods else other).append(p)
+                    if not attr.startswith("backbone") and attr not in ema_mods:
+                        n_heads += p.numel()
         # ONE flat gradient buffer for the whole step (north_star: "a single RCCL all-reduce of gradients"); the EMA'd modules'
         # parameters are its first range, so the two FlatStates (they differ only in whether an EMA copy is kept) are views of it
         sets = [(ps, with_ema) for ps, with_ema in ((ema_params, True), (other, False)) if ps]
@@ -168,6 +174,31 @@ class StepRunner:
             self.groups.append(FlatState(ps, with_ema, self.grad_all[off:off + n]))
             off += n
         self.step_count = 0
+        # ---- world > 1: the gradient all-reduce in two segments.  Segment A = the EMA'd modules + the other heads (the flat buffer's
+        # front), launched on its own stream from inside the backward pass as soon as the last kernel that writes it has been issued
+        # (the data-gradient / weight-gradient node of every head's FIRST convolution is that head's last backward node: it calls
+        # _segment_ready through functional's `_codeps_grad_done` hook); segment B = the encoders, after the backward pass.  The
+        # collectives stay SUMs of the same buffer: results are those of the single all-reduce.  CODEPS_AR_OVERLAP=0: one collective.
+        import os
+        self._seg, self._seg_marks, self._early_end, self.comm_stream = None, [], 0, None
+        self.ar_overlap_steps = 0
+        n_front = sum(p.numel() for p in ema_params) + n_heads
+        if world_size > 1 and os.environ.get("CODEPS_AR_OVERLAP", "1") != "0" and 0 < n_front < total and self.grad_all.is_cuda:
+            for attr in ("depth_head", "semantic_head", "pose_head"):
+                mod = getattr(net, attr, None)
+                if mod is None or attr in self.frozen:
+                    continue
+                first = mod.net[0] if attr == "pose_head" else mod.upconvs_0["4"][0]
+                if first.weight.requires_grad:
+                    self._seg_marks.append(first.weight)
+            trainable_heads = [a for a in ADAPT_MODULES.values() if not a.startswith("backbone") and getattr(net, a, None) is not None
+                               and any(p.requires_grad for p in getattr(net, a).parameters())]
+            # (a trainable head without a mark -- the instance head of the pre-training step -- keeps the single collective)
+            if self._seg_marks and len(self._seg_marks) == len(trainable_heads):
+                self._early_end = n_front
+                self.comm_stream = torch.cuda.Stream()
+                for w in self._seg_marks:
+                    w._codeps_grad_done = self._segment_ready
         # device step counter mixed into the photometric tie-break noise (bumped on the stream at the start of every step, so a
         # replayed HIP graph draws new noise) + this runner's host seed base for the calls within one step
         self.noise_counter = torch.zeros(1, dtype=torch.int64, device=self.groups[0].flat.device)
@@ -184,6 +215,7 @@ class StepRunner:
                 net.branch_stream = torch.cuda.Stream()
         self.key_scale = {}             # per-loss re-weighting of a batch-sharded step with unequal shards (set_key_counts)
         self._reach_cache = {}          # active losses -> per group, which parameters the backward pass reaches
+        self._found_ids = frozenset()
         self._unequal_shards = False
         self._touched = None
 
@@ -235,6 +267,11 @@ class StepRunner:
             wts.append(float(w) * self.key_scale.get(k, 1.0))
         total = F.weighted_sum(terms, wts)
         self._touched = self._reached(tuple(k for k, v in losses.items() if any(v is t for t in terms)), total)
+        self._seg = None
+        if self._early_end and not torch.cuda.is_current_stream_capturing():
+            need = sum(1 for w in self._seg_marks if id(w) in self._found_ids)
+            if need:
+                self._seg = {"need": need, "events": [], "work": None}
         if self._one is None or self._one.device != total.device:
             self._one = torch.ones((), dtype=total.dtype, device=total.device)
         total.backward(self._one)                # (the default seed is an ATen ones_like launch per step)
@@ -266,15 +303,46 @@ class StepRunner:
                     found.add(id(var))
                 stack.extend(nf for nf, _ in fn.next_functions)
             masks = [[id(p) in found for p in g.params] for g in self.groups]
-            hit = self._reach_cache[active] = (None if all(all(m) for m in masks) else masks,)
+            hit = self._reach_cache[active] = (None if all(all(m) for m in masks) else masks, frozenset(found))
+        self._found_ids = hit[1]
         return hit[0]
+
+    def _segment_ready(self):
+        """Called (on autograd's thread) right after the last backward kernels of one head have been issued.  When every head the
+        step's losses reach has reported, the flat buffer's front is complete on the device once the recorded events have passed: its
+        all-reduce starts on the communication stream, next to the encoders' backward pass."""
+        seg = self._seg
+        if seg is None or seg["work"] is not None:
+            return
+        ev = torch.cuda.Event()
+        ev.record()                                          # this node's stream: everything the head's backward issued precedes it
+        seg["events"].append(ev)
+        if len(seg["events"]) < seg["need"]:
+            return
+        import torch.distributed as dist
+        with torch.cuda.stream(self.comm_stream):
+            for e in seg["events"]:
+                self.comm_stream.wait_event(e)
+            seg["work"] = dist.all_reduce(self.grad_all[:self._early_end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def allreduce_gradients(self):
+        """The step's gradient collective after forward_backward: the whole flat buffer, or -- when the backward pass has already
+        started the front segment's all-reduce on the communication stream (_segment_ready) -- the back segment, then the join."""
+        seg, self._seg = self._seg, None
+        if seg is not None and seg["work"] is not None:
+            allreduce_flat_gradients(self.grad_all[self._early_end:], self.group)        # segment B: the encoders
+            seg["work"].wait()                                                            # segment A has been under way since the heads finished
+            self.ar_overlap_steps += 1
+        else:
+            allreduce_flat_gradients(self.grad_all, self.group)
+        return self.grad_all
 
     def optimizer_step(self, apply_ema=True):
         """ONE all-reduce of the step's flat gradient buffer, then the fused Adam kernel per flat group (EMA'd modules / the
         rest).  apply_ema False leaves the EMA copy alone: the reference filters the teacher once per FRAME, after its
         `nof_adaptation_steps` optimizer steps (scripts/adapt_codeps.py:266-299)."""
         self.step_count += 1
-        allreduce_flat_gradients(self.grad_all, self.group)
+        self.allreduce_gradients()
         for i, g in enumerate(self.groups):
             g.adam(None if self._touched is None else self._touched[i], self.lr, 1.0 / self.world, self.ema_alpha, apply_ema)
 

@@ -99,8 +99,8 @@ def main():
         if asym:
             runner.set_key_counts(counts, rank)
     total, losses, _ = runner.forward_backward(data)
-    from codeps_amd.distributed import allreduce_flat_gradients
-    allreduce_flat_gradients(runner.grad_all, runner.group)          # the step's ONE gradient collective
+    runner.allreduce_gradients()                                     # the step's gradient collective (the heads' front segment has been under
+                                                                     # way since the backward pass issued the last kernel that writes it)
     grads = [(g.grad / world).cpu() for g in runner.groups]
     runner.step_count += 1
     from codeps_amd import functional as F

@@ -24,20 +24,24 @@ def _worker(rank, world, port, out):
     x = torch.randn(6, 5, 4, 3)                      # [items, H, W, C] (NHWC like the product)
     lo, hi = shard_items(x.shape[0], rank, world)
     xs = x[lo:hi].reshape(-1, 3)
-    # ---- SyncBN forward statistics == single-process statistics of the whole batch
+    # ---- SyncBN forward statistics == single-process statistics of the whole batch: the product's path -- ONE all-gather of the
+    # [mean | var] packet of all statistic groups (SyncBatchNormReducer.gather), merged by codeps_bn_sync_combine, here by its host mirror
+    from codeps_amd.distributed import combine_host
     red = SyncBatchNormReducer()
-    mean, var, count = red(xs.mean(0), xs.var(0, unbiased=False), float(xs.shape[0]))
-    full = x.reshape(-1, 3)
-    ok_stats = torch.allclose(mean, full.mean(0), atol=1e-6) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-6) \
-        and count == full.shape[0]
-    # ---- all groups of a layer in one collective
     xa, xb = x[lo:hi, :2].reshape(-1, 3), x[lo:hi, 2:].reshape(-1, 3)       # two statistic groups (row blocks)
-    mg, vg, cg = red.combine_groups(torch.stack([xa.mean(0), xb.mean(0)]),
-                                    torch.stack([xa.var(0, unbiased=False), xb.var(0, unbiased=False)]),
-                                    [float(xa.shape[0]), float(xb.shape[0])])
+    pk = torch.stack([torch.stack([xa.mean(0), xb.mean(0)]), torch.stack([xa.var(0, unbiased=False), xb.var(0, unbiased=False)])])   # [2, G, C]
+    gathered = red.gather(pk)                                                # [world, 2, G, C]
+    mg, vg = combine_host(gathered)
     fa, fb = x[:, :2].reshape(-1, 3), x[:, 2:].reshape(-1, 3)
-    ok_stats = ok_stats and torch.allclose(mg[0], fa.mean(0), atol=1e-6) and torch.allclose(vg[1], fb.var(0, unbiased=False), atol=1e-6) \
-        and cg == [float(fa.shape[0]), float(fb.shape[0])]
+    ok_stats = tuple(gathered.shape) == (world, 2, 2, 3) and torch.allclose(mg[0], fa.mean(0), atol=1e-6) and \
+        torch.allclose(mg[1], fb.mean(0), atol=1e-6) and torch.allclose(vg[0], fa.var(0, unbiased=False), atol=1e-6) and \
+        torch.allclose(vg[1], fb.var(0, unbiased=False), atol=1e-6)
+    # unequal element counts (BASELINE configs[3]: ranks hold different numbers of items of a key): rank r brings r + 1 items of group 0
+    xu = x[: rank + 1].reshape(-1, 3)
+    pku = torch.stack([xu.mean(0, keepdim=True), xu.var(0, unbiased=False, keepdim=True)])       # [2, 1, C]
+    mu, vu = combine_host(red.gather(pku), [[float((r + 1) * 20)] for r in range(world)])
+    both = torch.cat([x[: r + 1].reshape(-1, 3) for r in range(world)])
+    ok_stats = ok_stats and torch.allclose(mu[0], both.mean(0), atol=1e-6) and torch.allclose(vu[0], both.var(0, unbiased=False), atol=1e-6)
     # ---- SyncBN backward sums
     g = torch.arange(6.0).view(2, 3) * (rank + 1)
     tot = red.sum(g.clone())
@@ -48,7 +52,7 @@ def _worker(rank, world, port, out):
     loss.backward()
     flat = wgt.grad.clone()
     allreduce_flat_gradients(flat)
-    ref = full.mean(0)                              # d/dw of the global mean
+    ref = x.reshape(-1, 3).mean(0)                  # d/dw of the global mean
     ok_grad = torch.allclose(flat / world, ref, atol=1e-6)
     out.put((rank, ok_stats, ok_sums, ok_grad))
     dist.barrier()

@@ -201,3 +201,8 @@ def test_two_ranks_on_one_gpu_complete_with_default_flags():
     assert c["backend"] == "gloo" and c["ranks_seen"] == 2 and c["grad_allreduce_ms"] > 0
     assert c["syncbn_allgathers_per_step"] == 20 and c["syncbn_allreduces_per_step"] == 20
     assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
+    # the gradient collective ran in two segments in every timed step (round 5): the heads' front of the flat buffer from inside the
+    # backward pass, the pose encoder's back after it
+    sg = c["grad_allreduce_segments"]
+    assert sg["front_mb"] > 0 and sg["back_mb"] > 0 and abs(sg["front_mb"] + sg["back_mb"] - c["grad_allreduce_mb"]) < 0.2
+    assert sg["steps_with_the_front_overlapped"] >= d["steps"]
