@@ -194,9 +194,13 @@ SIGNATURES = {
     "codeps_disp_head_fwd": (c_int, [P, P, P, I, I, I, I, c_float, c_float, P, P, P, P]),
     "codeps_disp_head_bwd_workspace_bytes": (c_size_t, [I, I, I]),
     "codeps_disp_head_bwd": (c_int, [P, P, P, P, P, I, I, I, I, c_float, c_float, P, P, P, I, P, c_size_t, P]),
+    "codeps_disp_head_dx_blocks": (c_int, [I, I, I]),
+    "codeps_disp_head_bwd_gated": (c_int, [P, P, P, P, P, I, I, I, I, c_float, c_float, P, P, P, I, I, P, P, c_size_t, P]),
     "codeps_upconv16_workspace_bytes": (c_size_t, []),
     "codeps_upconv16_fwd": (c_int, [P, P, P, I, I, I, I, P, P, c_size_t, P]),
     "codeps_upconv16_dgrad": (c_int, [P, P, I, I, I, P, P, c_size_t, P]),
+    "codeps_upconv16_dgrad_blocks": (c_int, [I, I, I]),
+    "codeps_upconv16_dgrad_gated": (c_int, [P, P, I, I, I, P, P, I, P, P, c_size_t, P]),
     "codeps_upconv16_wgrad_workspace_bytes": (c_size_t, []),
     "codeps_upconv16_wgrad": (c_int, [P, P, I, I, I, P, I, P, c_size_t, P]),
 }

@@ -62,6 +62,10 @@ struct ConvP {
     // stride-2 dgrad by input-parity class: rows enumerate the pixels (2y'+py, 2x'+px) only and the K loop walks just the
     // taps whose parity can reach them (3x3: 1, 2, 2 or 4 taps instead of 9 mostly-zero ones)
     int par, py, px, ky0, kx0, nky, nkx, Hc, Wc;
+    // par == 2 (round 5): ALL parity classes in one launch -- blockIdx.z = class, its (py, px, ky0, kx0, nky, nkx) in pcls; Hc / Wc / M
+    // are the same for every class (even H and W).  Four launches of 96-192 blocks each left 25-60 % of the CUs idle.
+    int pcls[4][6];
+    int grid_mult;        // launches that repeat the tile grid (4 parity classes): what the tile cost model multiplies the blocks by
     // split-K (small-M launches): gridDim.y slices of `ksteps` K-steps each write raw partial sums to part[slice][M][N]
     int ksplit, ksteps;
     float* part;
@@ -220,6 +224,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// par == 2: this block's parity class (blockIdx.z) becomes the launch's (p is the kernel's own copy of the parameters)
+__device__ __forceinline__ void select_parity_class(ConvP& p) {
+    if (p.par == 2) {
+        const int c = blockIdx.z;
+        p.py = p.pcls[c][0]; p.px = p.pcls[c][1]; p.ky0 = p.pcls[c][2]; p.kx0 = p.pcls[c][3]; p.nky = p.pcls[c][4]; p.nkx = p.pcls[c][5];
+        p.ex_tile0 += c * p.n_mt;
+    }
+}
+
 // Gather table of one block of BM rows (see conv_igemm_kernel): tab[source][tap][row] = byte offset of the pixel that row
 // reads through that tap, relative to the first image the block touches (GATHER_OOB = zero padding / row past M), plus
 // the buffer resources of the source(s) rebased to that image.  Ends with a barrier.
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     float* As = smem;                                 // [NBUF][BM][LDK]
     float* Bs = smem + NBUF * BM * LDK;               // [NBUF][BN][LDK]
     CODEPS_STAMP_BEGIN();
+    if constexpr (MODE == MODE_DGRAD) select_parity_class(p);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -597,6 +611,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
     float* As = smem;                                 // [2][BM][LDK]
     float* Bs = smem + 2 * BM * LDK;                  // [2][BN][LDK]
     unsigned* tab = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * LDK);
+    if constexpr (MODE == MODE_DGRAD) select_parity_class(p);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
@@ -3945,11 +3960,13 @@ static bool epi_plan(ConvP& p, int tile_rows, bool supported = true) {
         p.ex_stat = 0;
     }
     if (p.ex_gate_act) g_epi.applied |= 1;
-    if (p.ex_stat && g_epi.n_seg < 4) {
+    if (p.ex_stat) {
         g_epi.applied |= 2;
-        const int k = g_epi.n_seg++;
-        g_epi.tile0[k] = p.ex_tile0; g_epi.rows[k] = tile_rows; g_epi.tiles[k] = p.n_mt;
-        g_epi.tpi[k] = p.ex_img_rows > 0 ? p.ex_img_rows / tile_rows : 0;
+        for (int c = 0; c < (p.par == 2 ? 4 : 1) && g_epi.n_seg < 4; ++c) {          // (all parity classes in one launch: one segment each)
+            const int k = g_epi.n_seg++;
+            g_epi.tile0[k] = p.ex_tile0 + c * p.n_mt; g_epi.rows[k] = tile_rows; g_epi.tiles[k] = p.n_mt;
+            g_epi.tpi[k] = p.ex_img_rows > 0 ? p.ex_img_rows / tile_rows : 0;
+        }
     }
     return p.ksplit <= 1 && (p.ex_gate_act || p.ex_stat);          // true: launch the kernel's EX instantiation (K slices: the finish pass gates)
 }
@@ -4079,7 +4096,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         // ... and whose grid is a single round of one block per CU: the block owns the CU (111 KB of LDS), so a second round
         // would run without the co-resident blocks that hide the 256-thread kernel's prologue / epilogue
         static const int ws_blocks = getenv("CODEPS_WS_BLOCKS") ? atoi(getenv("CODEPS_WS_BLOCKS")) : 256;
-        if (ws_min > 0 && nsteps_ >= ws_min && p.n_mt * p.n_nt <= ws_blocks) {
+        if (ws_min > 0 && nsteps_ >= ws_min && p.n_mt * p.n_nt * std::max(p.grid_mult, 1) <= ws_blocks) {
             const int nsrc_ = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
             const size_t lds_ws = std::max(((size_t)2 * (BM + BN) * LDKp + (size_t)nsrc_ * ntap_ * BM) * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
             const int blocks_ = p.n_mt * p.n_nt;
@@ -4089,7 +4106,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             auto kw = epi_plan(p, BM) ? conv_igemm_ws_kernel<MODE, TN, true> : conv_igemm_ws_kernel<MODE, TN>;
             codeps_allow_lds((const void*)kw, 160 * 1024, "kw");
             g_last_kernel = "conv_igemm_ws_kernel";
-            hipLaunchKernelGGL(kw, dim3(blocks_, p.ksplit), dim3(512), lds_ws, st, p, a0, a1, scale, shift, residual, out);
+            hipLaunchKernelGGL(kw, dim3(blocks_, p.ksplit, p.par == 2 ? 4 : 1), dim3(512), lds_ws, st, p, a0, a1, scale, shift, residual, out);
             if (p.ksplit > 1) {
                 const long long MN = (long long)p.M * p.N;
                 hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
@@ -4129,7 +4146,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     else epi_plan(p, BM, false);
     codeps_allow_lds((const void*)k, 160 * 1024, "k");
     g_last_kernel = NP == 3 ? (BK == 16 ? "conv_igemm_kernel<split3,bk16>" : "conv_igemm_kernel<split3>") : (NP == 2 ? "conv_igemm_kernel<split2>" : "conv_igemm_kernel<f32>");
-    hipLaunchKernelGGL(k, dim3(blocks, p.ksplit), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
+    hipLaunchKernelGGL(k, dim3(blocks, p.ksplit, p.par == 2 ? 4 : 1), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
     if (p.ksplit > 1) {
         const long long MN = (long long)p.M * p.N;
         hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
@@ -4146,7 +4163,7 @@ static int pick_tile(const ConvP& p, const TileOpt* opts, int n, int nsteps) {
     int best = 0;
     double best_t = 1e300;
     for (int i = 0; i < n; ++i) {
-        const long long blocks = (long long)cdiv(p.M, opts[i].bm) * cdiv(p.N, opts[i].bn);
+        const long long blocks = (long long)cdiv(p.M, opts[i].bm) * cdiv(p.N, opts[i].bn) * std::max(p.grid_mult, 1);
         const int ks = splitk_slices(p, (int)blocks, nsteps);
         const double t = (double)((blocks * ks + 255) / 256) * opts[i].bm * opts[i].bn / ks * opts[i].penalty * (ks > 1 ? 1.08 : 1.0);
         if (t < best_t) { best_t = t; best = i; }
@@ -4521,6 +4538,27 @@ extern "C" int codeps_conv2d_dgrad_ex(const codeps_conv_desc* d, int source, con
             hipError_t e = add ? hipMemcpyAsync(dx, add, (size_t)p.M * p.N * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream)
                                : hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream);
             CODEPS_REQUIRE(e == hipSuccess, CODEPS_ERR_LAUNCH, "conv2d_dgrad: memset / copy failed: %s", hipGetErrorString(e));
+        }
+        static const int par_merge = getenv("CODEPS_PARITY_MERGE") ? atoi(getenv("CODEPS_PARITY_MERGE")) : 1;         // A/B: 0 = one launch per class
+        if (par_merge && !need_zero && !(d->in_h & 1) && !(d->in_w & 1) && p.N > 16) {
+            // every class has taps and the same rows: ONE launch, blockIdx.z = class (the K loop of a block walks its class's 1-4 taps)
+            ConvP q = p;
+            q.par = 2; q.grid_mult = 4;
+            q.Hc = d->in_h / 2; q.Wc = d->in_w / 2;
+            q.M = d->batch * q.Hc * q.Wc;
+            q.ex_img_rows = q.Hc * q.Wc;
+            q.nky = q.nkx = 0;
+            for (int c = 0; c < 4; ++c) {
+                const int py = c >> 1, px = c & 1, ky0 = (py + d->pad) & 1, kx0 = (px + d->pad) & 1;
+                const int nky = (d->kh - ky0 + 1) / 2, nkx = (d->kw - kx0 + 1) / 2;
+                q.pcls[c][0] = py; q.pcls[c][1] = px; q.pcls[c][2] = ky0; q.pcls[c][3] = kx0; q.pcls[c][4] = nky; q.pcls[c][5] = nkx;
+                q.nky = std::max(q.nky, nky); q.nkx = std::max(q.nkx, nkx);          // (the host sizes the gather table for the largest class)
+            }
+            q.py = q.px = 0; q.ky0 = q.pcls[0][2]; q.kx0 = q.pcls[0][3];
+            dispatch_igemm<MODE_DGRAD>(q, d->out_c, dz, nullptr, wsrc, nullptr, nullptr, add, dx, (hipStream_t)stream);
+            CODEPS_CHECK_LAUNCH("conv_igemm_kernel<dgrad, parity classes in one launch>");
+            epi_store(epilogue);
+            return CODEPS_OK;
         }
         int tile0 = 0;
         for (int c = 0; c < 4; ++c) {

@@ -87,11 +87,19 @@ __global__ __launch_bounds__(256) void disp_head_g_kernel(const float* __restric
 }
 
 // dx[q][c] = sum over padded positions u that reflect onto q and taps t with p = u - t inside the image of g[p] w[t][c]
+// x_act != 0 (round 5): x is the OUTPUT of an activation (the decoder's last ELU, models/depth_head.py:63-71) read by this head alone: dx is
+// multiplied by act'(x) here -- the producer's activation backward needs no pass over the full-resolution tensor -- and the block's column
+// sums of the gated dx (the producer's bias gradient) go to col_part[block][16]
 __global__ __launch_bounds__(256) void disp_head_dx_kernel(const float* __restrict__ g, const float* __restrict__ w, int B, int H, int W,
-                                                           float* __restrict__ dx) {
+                                                           float* __restrict__ dx, const float* __restrict__ x, int x_act,
+                                                           float* __restrict__ col_part) {
     __shared__ __attribute__((aligned(16))) float ws[NW];
+    __shared__ float cred[4][C];
     load_weights(w, ws);
     __syncthreads();
+    f32x4 csum[C4];
+#pragma unroll
+    for (int q = 0; q < C4; ++q) csum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long n = (long long)B * H * W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int xq = (int)(i % W), yq = (int)((i / W) % H);
@@ -122,9 +130,30 @@ __global__ __launch_bounds__(256) void disp_head_dx_kernel(const float* __restri
             }
         }
         f32x4* o = reinterpret_cast<f32x4*>(dx + i * C);
+        if (x_act) {
+            const f32x4* xv = reinterpret_cast<const f32x4*>(x + i * C);
+#pragma unroll
+            for (int q = 0; q < C4; ++q) {
+                const f32x4 y = xv[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q][e] *= y[e] > 0.f ? 1.f : (x_act == 2 ? y[e] + 1.f : 0.f);       // = act_bwd_kernel's product
+                csum[q] += acc[q];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < C4; ++q) o[q] = acc[q];
     }
+    if (!col_part) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < C4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = wave_sum(csum[q][e]);
+            if (lane == 0) cred[wave][q * 4 + e] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < C) col_part[(size_t)blockIdx.x * C + threadIdx.x] = (cred[0][threadIdx.x] + cred[1][threadIdx.x]) + (cred[2][threadIdx.x] + cred[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void disp_head_dw_kernel(const float* __restrict__ x, const float* __restrict__ g, int B, int H, int W,
@@ -206,9 +235,22 @@ extern "C" size_t codeps_disp_head_bwd_workspace_bytes(int batch, int h, int w) 
     return batch > 0 ? align_up((size_t)batch * h * w * sizeof(float), 256) + (size_t)512 * (NW + 1) * sizeof(float) : 0;
 }
 
+extern "C" int codeps_disp_head_dx_blocks(int batch, int h, int w) {
+    return (int)std::min<long long>(((long long)batch * h * w + 255) / 256, 4096);
+}
+
 extern "C" int codeps_disp_head_bwd(const float* x, const float* weight, const float* disp, const float* ddisp, const float* ddepth, int batch,
                                     int h, int w, int c, float min_depth, float max_depth, float* dx, float* dweight, float* dbias,
                                     int accumulate, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    return codeps_disp_head_bwd_gated(x, weight, disp, ddisp, ddepth, batch, h, w, c, min_depth, max_depth, dx, dweight, dbias, accumulate, 0, nullptr,
+                                      workspace, workspace_bytes, stream);
+}
+
+extern "C" int codeps_disp_head_bwd_gated(const float* x, const float* weight, const float* disp, const float* ddisp, const float* ddepth, int batch,
+                                          int h, int w, int c, float min_depth, float max_depth, float* dx, float* dweight, float* dbias,
+                                          int accumulate, int x_act, float* x_colsum_part, void* workspace, size_t workspace_bytes,
+                                          codeps_stream_t stream) {
+    CODEPS_REQUIRE(x_act >= 0 && x_act <= 2 && (!x_colsum_part || (x_act && dx)), CODEPS_ERR_ARG, "codeps_disp_head_bwd: bad gate arguments");
     CODEPS_REQUIRE(x && weight && disp && (ddisp || ddepth) && workspace && batch > 0 && h >= 2 && w >= 2, CODEPS_ERR_ARG,
                    "codeps_disp_head_bwd: bad arguments");
     CODEPS_REQUIRE(c == C, CODEPS_ERR_ARG, "codeps_disp_head_bwd: %d input channels (the decoder's last stage has %d)", c, C);
@@ -220,7 +262,7 @@ extern "C" int codeps_disp_head_bwd(const float* x, const float* weight, const f
     const float mind = (float)(1.0 / (double)max_depth), maxd = (float)(1.0 / (double)min_depth);
     const int grid = (int)std::min<long long>((M + 255) / 256, 4096);
     hipLaunchKernelGGL(disp_head_g_kernel, dim3(grid), dim3(256), 0, st, ddisp, ddepth, disp, M, mind, maxd, g);
-    if (dx) hipLaunchKernelGGL(disp_head_dx_kernel, dim3(grid), dim3(256), 0, st, (const float*)g, weight, batch, h, w, dx);
+    if (dx) hipLaunchKernelGGL(disp_head_dx_kernel, dim3(grid), dim3(256), 0, st, (const float*)g, weight, batch, h, w, dx, x, x_act, x_colsum_part);
     if (dweight || dbias) {
         const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
         const int nblk = std::min(batch * tiles_x * tiles_y, 512);

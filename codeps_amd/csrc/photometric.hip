@@ -277,7 +277,11 @@ __device__ __forceinline__ void ssim_grad(float sx, float sy, float sxx, float s
 // ---------------------------------------------------------------------------------- forward
 constexpr int FPH = FTH + 2, FPW = FTW + 2, FPN = FPH * FPW;     // halo-1 tile: 10 x 66
 
-__global__ __launch_bounds__(256) void photo_fwd_kernel(Levels L, const float* __restrict__ img_t,
+#ifndef CODEPS_PHOTO_WAVES
+#define CODEPS_PHOTO_WAVES 3                  // waves per SIMD the register allocation leaves room for: 3 = 168 registers + 36 bytes of scratch, measured
+                                              // 120 us per launch against 129 at 2 (177 registers) and 136 at 4 (128 registers, 200 bytes of scratch)
+#endif
+__global__ __launch_bounds__(256, CODEPS_PHOTO_WAVES) void photo_fwd_kernel(Levels L, const float* __restrict__ img_t,
                                                         const float* __restrict__ img_m,
                                                         const float* __restrict__ img_p,
                                                         const float* __restrict__ depth,

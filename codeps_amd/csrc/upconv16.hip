@@ -115,8 +115,11 @@ __global__ __launch_bounds__(256) void upconv16_fwd_kernel(const float* __restri
 // source neighbourhood (20 x 36 output pixels) sits in LDS; two source rows per wave, 16 (class, tap) x 4 MFMAs per row
 constexpr int ZH = 2 * XH, ZW = 2 * XW, ZPIX = ZH * ZW;
 
+// x_act != 0 (round 5): the source tensor x is the output of an activation read by this layer alone: dx *= act'(x) in the output stage and
+// the block's column sums of the gated dx go to col_part[block][16] (the producer's activation backward and bias gradient)
 __global__ __launch_bounds__(256) void upconv16_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wc, int Hs, int Ws, int tiles_x,
-                                                             float* __restrict__ dx) {
+                                                             float* __restrict__ dx, const float* __restrict__ x, int x_act,
+                                                             float* __restrict__ col_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* zs = reinterpret_cast<f32x4*>(smem);        // [ZPIX][P4]
     float* os = smem + ZPIX * P4 * 4;                  // [SH x SW source pixels][P4 * 4] output staging
@@ -155,11 +158,31 @@ __global__ __launch_bounds__(256) void upconv16_dgrad_kernel(const float* __rest
         for (int e = 0; e < 4; ++e) os[(r * SW + 4 * i + e) * (P4 * 4) + m] = acc[e];
     }
     __syncthreads();
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};                  // (a thread keeps its channel quad q = idx & 3 over the two passes: 256 % 4 == 0)
     for (int idx = threadIdx.x; idx < SH * SW * 4; idx += 256) {
         const int p = idx >> 2, q = idx & 3;
         const int sy = sy0 + p / SW, sx = sx0 + p % SW;
-        if (sy < Hs && sx < Ws)
-            *reinterpret_cast<f32x4*>(dx + (((size_t)b * Hs + sy) * Ws + sx) * C + q * 4) = *reinterpret_cast<const f32x4*>(os + p * (P4 * 4) + q * 4);
+        if (sy < Hs && sx < Ws) {
+            const size_t o = (((size_t)b * Hs + sy) * Ws + sx) * C + q * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(os + p * (P4 * 4) + q * 4);
+            if (x_act) {
+                const f32x4 y = *reinterpret_cast<const f32x4*>(x + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= y[e] > 0.f ? 1.f : (x_act == 2 ? y[e] + 1.f : 0.f);
+                csum += v;
+            }
+            *reinterpret_cast<f32x4*>(dx + o) = v;
+        }
+    }
+    if (!col_part) return;
+    __syncthreads();                                    // `os` is free again: the 64 threads of a channel quad meet there in a fixed order
+    f32x4* red = reinterpret_cast<f32x4*>(os);
+    red[threadIdx.x] = csum;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 64; ++k) a += red[k * 4 + threadIdx.x];
+        *reinterpret_cast<f32x4*>(col_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C + threadIdx.x * 4) = a;
     }
 }
 
@@ -262,8 +285,16 @@ extern "C" int codeps_upconv16_fwd(const float* x, const float* weight, const fl
     return CODEPS_OK;
 }
 
+extern "C" int codeps_upconv16_dgrad_blocks(int batch, int hs, int ws) { return batch * cdiv(ws, SW) * cdiv(hs, SH); }
+
 extern "C" int codeps_upconv16_dgrad(const float* dz, const float* weight, int batch, int hs, int ws, float* dx, void* workspace,
                                      size_t workspace_bytes, codeps_stream_t stream) {
+    return codeps_upconv16_dgrad_gated(dz, weight, batch, hs, ws, dx, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int codeps_upconv16_dgrad_gated(const float* dz, const float* weight, int batch, int hs, int ws, float* dx, const float* x, int x_act,
+                                           float* x_colsum_part, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x_act >= 0 && x_act <= 2 && (!x_act || x) && (!x_colsum_part || x_act), CODEPS_ERR_ARG, "codeps_upconv16_dgrad: bad gate arguments");
     CODEPS_REQUIRE(dz && weight && dx && workspace && batch > 0 && hs > 0 && ws > 0, CODEPS_ERR_ARG, "codeps_upconv16_dgrad: bad arguments");
     CODEPS_REQUIRE(workspace_bytes >= codeps_upconv16_workspace_bytes(), CODEPS_ERR_WORKSPACE, "codeps_upconv16_dgrad: workspace too small");
     const int tiles_x = cdiv(ws, SW), tiles_y = cdiv(hs, SH);
@@ -272,7 +303,8 @@ extern "C" int codeps_upconv16_dgrad(const float* dz, const float* weight, int b
     hipStream_t st = (hipStream_t)stream;
     float* wc = static_cast<float*>(workspace);
     hipLaunchKernelGGL(upconv16_collapse_kernel, dim3(16), dim3(256), 0, st, weight, wc);
-    hipLaunchKernelGGL(upconv16_dgrad_kernel, dim3(tiles_x * tiles_y, batch), dim3(256), lds, st, dz, (const float*)wc, hs, ws, tiles_x, dx);
+    hipLaunchKernelGGL(upconv16_dgrad_kernel, dim3(tiles_x * tiles_y, batch), dim3(256), lds, st, dz, (const float*)wc, hs, ws, tiles_x, dx, x, x_act,
+                       x_colsum_part);
     CODEPS_CHECK_LAUNCH("upconv16_dgrad_kernel");
     return CODEPS_OK;
 }

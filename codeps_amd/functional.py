@@ -549,6 +549,18 @@ def _handoff(gate, e, part, dx):
     gate.handoff = h
 
 
+def _handoff_blocks(gate, dx, part, blocks):
+    """Hand-off of a gate applied by a kernel outside the conv engine (upconv16 / disp_head data gradients): dx is gated; part
+    [blocks][cols] = its column sums per block (None: the producer sums dx itself)."""
+    gate.handoff = {"ptr": dx.data_ptr(), "version": dx._version, "shape": tuple(dx.shape), "part": part, "segs": [(0, 0, 0, blocks)]}
+
+
+def _act_gate_of(x, exclusive):
+    """The activation gate x carries, if the caller is x's only reader and the activation gates are switched on."""
+    g = getattr(x, "_codeps_gate", None) if exclusive else None
+    return g if (g is not None and g.kind == "act" and _EPI and _EPI_PARTS["act"]) else None
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv(cat(up(x0), x1), W) * scale + shift + residual) on NHWC tensors (C ABI conv2d)."""
 
@@ -1681,7 +1693,7 @@ class _UpConv16(torch.autograd.Function):
     (C ABI: codeps_upconv16_*)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, opts=None):
         require_cuda(x, weight)
         x = x.contiguous()
         b, hs, ws_, c = x.shape
@@ -1698,11 +1710,20 @@ class _UpConv16(torch.autograd.Function):
         ctx.w_sink = grad_sink(weight) if weight.requires_grad else None
         ctx.b_sink = grad_sink(bias) if (bias is not None and bias.requires_grad) else None
         ctx.save_for_backward(x, wt, y if act else None)
+        # gates (see _Gate): the one x came with (its producer's activation backward runs in this layer's data-gradient kernel) and the
+        # one this layer's own activation offers to its exclusive reader (disp_head)
+        ctx.in_gate = opts.in_gate if (opts is not None and ctx.needs_input_grad[0]) else None
+        ctx.out_gate = None
+        if opts is not None and _EPI and _EPI_PARTS["act"] and act and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            g = _Gate("act", act)
+            g.want_colsum = bias is not None and ctx.needs_input_grad[2]
+            ctx.out_gate = opts.gate = g
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wt, y = ctx.saved_tensors
+        gated = ctx.out_gate.take(dy) if ctx.out_gate is not None else None
         dy = dy.contiguous()
         b, hs, ws_, c = x.shape
         rows = dy.numel() // 16
@@ -1712,7 +1733,18 @@ class _UpConv16(torch.autograd.Function):
         if need_b:
             dbias = ctx.b_sink if ctx.b_sink is not None else torch.empty(16, dtype=torch.float32, device=dev)
         dz = dy
-        if ctx.act or need_b:
+        if gated is not None:                   # dy arrived multiplied by act'(y), with its column sums per block
+            if need_b:
+                if gated["part"] is not None:
+                    check(lib().codeps_colsum_finish(ptr(gated["part"]), gated["segs"][0][3], 16, ptr(dbias), 16, 1 if ctx.b_sink is not None else 0,
+                                                     stream_ptr()), "codeps_colsum_finish")
+                else:
+                    ws = _workspace(lib().codeps_colsum_workspace_bytes(rows, 16, 1), dev, "colsum")
+                    check(lib().codeps_act_bwd(ptr(dy), None, None, 0, rows, 16, None, ptr(dbias), 16, 1 if ctx.b_sink is not None else 0, ptr(ws),
+                                               ws.numel(), stream_ptr()), "codeps_act_bwd (bias gradient)")
+                if ctx.b_sink is not None:
+                    dbias = None
+        elif ctx.act or need_b:
             wsb = lib().codeps_colsum_workspace_bytes(rows, 16, 1)
             ws = _workspace(wsb, dev, "colsum")
             dz = torch.empty_like(dy) if ctx.act else dy
@@ -1726,7 +1758,15 @@ class _UpConv16(torch.autograd.Function):
             t0 = _prof_begin()
             nb = lib().codeps_upconv16_workspace_bytes()
             wsp = _workspace(nb, dev, "upconv16_w")
-            check(lib().codeps_upconv16_dgrad(ptr(dz), ptr(wt), b, hs, ws_, ptr(dx), ptr(wsp), nb, stream_ptr()), "codeps_upconv16_dgrad")
+            gt = ctx.in_gate
+            if gt is not None:
+                blocks = lib().codeps_upconv16_dgrad_blocks(b, hs, ws_)
+                part = torch.empty(blocks, 16, dtype=torch.float32, device=dev) if gt.want_colsum else None
+                check(lib().codeps_upconv16_dgrad_gated(ptr(dz), ptr(wt), b, hs, ws_, ptr(dx), ptr(x), gt.act, ptr(part), ptr(wsp), nb, stream_ptr()),
+                      "codeps_upconv16_dgrad_gated")
+                _handoff_blocks(gt, dx, part, blocks)
+            else:
+                check(lib().codeps_upconv16_dgrad(ptr(dz), ptr(wt), b, hs, ws_, ptr(dx), ptr(wsp), nb, stream_ptr()), "codeps_upconv16_dgrad")
             _prof_end(t0, "conv_dgrad", ctx.flops)
         if ctx.needs_input_grad[1]:
             sink = ctx.w_sink
@@ -1739,21 +1779,26 @@ class _UpConv16(torch.autograd.Function):
             _prof_end(t0, "conv_wgrad", ctx.flops)
             if sink is not None:
                 dw = None
-        return dx, dw, dbias, None
+        return dx, dw, dbias, None, None
 
 
-def upconv16(x, weight, bias=None, act=None):
+def upconv16(x, weight, bias=None, act=None, exclusive=False):
     """act(conv3x3(nearest_x2(x), weight) + bias) for 16 -> 16 channels without a skip tensor (the decoders' last stage,
     models/depth_head.py:60-71): x [B,hs,ws,16] NHWC -> [B,2hs,2ws,16].  Same values as conv2d(..., up0=True) to fp32 rounding
-    (the taps that read one source pixel are summed in the weights first)."""
-    return _UpConv16.apply(x, weight, bias, ACT[act])
+    (the taps that read one source pixel are summed in the weights first).  exclusive: as in conv2d -- x's producer's activation backward
+    then runs in this layer's data-gradient kernel; the result offers its own gate to ITS exclusive reader."""
+    opts = _ConvOpts(_act_gate_of(x, exclusive))
+    y = _UpConv16.apply(x, weight, bias, ACT[act], opts)
+    if opts.gate is not None:
+        y._codeps_gate = opts.gate
+    return y
 
 
 class _DispHead(torch.autograd.Function):
     """ReflectionPad2d(1) -> Conv2d(16, 1, 3) -> Sigmoid -> disp_to_depth in one kernel each way (C ABI: codeps_disp_head_*)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, min_depth, max_depth, logit_out):
+    def forward(ctx, x, weight, bias, min_depth, max_depth, logit_out, in_gate=None):
         require_cuda(x, weight)
         x = x.contiguous()
         b, h, w, c = x.shape
@@ -1766,6 +1811,7 @@ class _DispHead(torch.autograd.Function):
         check(lib().codeps_disp_head_fwd(ptr(x), ptr(wt), ptr(bs), b, h, w, c, min_depth, max_depth, ptr(disp), ptr(depth), ptr(logit_out),
                                          stream_ptr()), "codeps_disp_head_fwd")
         ctx.save_for_backward(x, wt, disp)
+        ctx.in_gate = in_gate if ctx.needs_input_grad[0] else None
         ctx.meta = (min_depth, max_depth, bias is not None)
         ctx.w_sink = grad_sink(weight) if weight.requires_grad else None
         ctx.b_sink = grad_sink(bias) if (bias is not None and bias.requires_grad) else None
@@ -1788,22 +1834,28 @@ class _DispHead(torch.autograd.Function):
             db = ctx.b_sink if sinks else torch.empty(1, dtype=torch.float32, device=dev)
         nbytes = lib().codeps_disp_head_bwd_workspace_bytes(b, h, w)
         ws = _workspace(nbytes, dev, "disp_head")
-        check(lib().codeps_disp_head_bwd(ptr(x), ptr(wt), ptr(disp), ptr(None if ddisp is None else ddisp.contiguous()),
-                                         ptr(None if ddepth is None else ddepth.contiguous()), b, h, w, c, mn, mx, ptr(dx), ptr(dw), ptr(db),
-                                         1 if sinks else 0, ptr(ws), nbytes, stream_ptr()), "codeps_disp_head_bwd")
+        gt = ctx.in_gate if dx is not None else None
+        blocks = lib().codeps_disp_head_dx_blocks(b, h, w) if gt is not None else 0
+        part = torch.empty(blocks, 16, dtype=torch.float32, device=dev) if (gt is not None and gt.want_colsum) else None
+        check(lib().codeps_disp_head_bwd_gated(ptr(x), ptr(wt), ptr(disp), ptr(None if ddisp is None else ddisp.contiguous()),
+                                               ptr(None if ddepth is None else ddepth.contiguous()), b, h, w, c, mn, mx, ptr(dx), ptr(dw), ptr(db),
+                                               1 if sinks else 0, gt.act if gt is not None else 0, ptr(part), ptr(ws), nbytes, stream_ptr()),
+              "codeps_disp_head_bwd")
+        if gt is not None:
+            _handoff_blocks(gt, dx, part, blocks)
         if sinks:
             dw = db = None              # accumulated in place into the flat gradient buffer
         elif ctx.w_sink is not None and dw is not None:
             ctx.w_sink.add_(dw.view_as(ctx.w_sink))
             dw = None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def disp_head(x, weight, bias, min_depth=0.1, max_depth=100.0, logit_out=None):
+def disp_head(x, weight, bias, min_depth=0.1, max_depth=100.0, logit_out=None, exclusive=False):
     """The depth decoder's output stage (models/depth_head.py:44-59,73-77) on NHWC features x [B,H,W,16]: reflection-padded
     3x3 convolution to one channel, sigmoid, disp_to_depth -> (depth, disp), both [B,1,H,W]; the 16-channel tensor is moved once
     each way.  logit_out (optional, [B,1,H,W]): receives the pre-sigmoid convolution output (parity checks in logit space)."""
-    return _DispHead.apply(x, weight, bias, float(min_depth), float(max_depth), logit_out)
+    return _DispHead.apply(x, weight, bias, float(min_depth), float(max_depth), logit_out, _act_gate_of(x, exclusive))
 
 
 # ---------------------------------------------------------------------------------------- pose

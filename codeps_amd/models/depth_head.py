@@ -47,7 +47,7 @@ def _run_decoder(module, in_feats, keep=()):
             x = F.conv2d(x, c0.weight, c0.bias, pad=1, act="elu", exclusive=i < 4 and (i + 1) not in kept)
         skip = F.from_nchw(in_feats[i - 1]) if (module.use_skips and i > 0) else None
         if skip is None and c1.in_channels == 16 and c1.out_channels == 16 and x.shape[-1] == 16 and _UPCONV16:
-            x = F.upconv16(x, c1.weight, c1.bias, act="elu")      # scale 0: four 2x2 convolutions of the half-resolution tensor
+            x = F.upconv16(x, c1.weight, c1.bias, act="elu", exclusive=True)      # scale 0: four 2x2 convolutions of the half-resolution tensor
         else:
             x = F.conv2d(x, c1.weight, c1.bias, x1=skip, pad=1, act="elu", up0=True, exclusive=True)
         if i in keep:
@@ -84,7 +84,8 @@ class DepthHead(nn.Module):
         conv = self.dispconvs["0"][1]
         if conv.in_channels == 16 and x.shape[-1] == 16:
             tap = None if self.logit_log is None else x.new_empty(x.shape[0], 1, x.shape[1], x.shape[2])
-            depth_map, disp_map = F.disp_head(x, conv.weight, conv.bias, logit_out=tap)    # padded conv + sigmoid + disp_to_depth, one pass each way
+            # (the decoder's output is read by this stage alone: its ELU backward rides in the stage's data-gradient kernel)
+            depth_map, disp_map = F.disp_head(x, conv.weight, conv.bias, logit_out=tap, exclusive=True)    # padded conv + sigmoid + disp_to_depth, one pass each way
             if tap is not None:
                 self.logit_log.append(tap)
         else:

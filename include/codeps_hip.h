@@ -689,6 +689,15 @@ size_t codeps_disp_head_bwd_workspace_bytes(int batch, int h, int w);
 int codeps_disp_head_bwd(const float* x, const float* weight, const float* disp, const float* ddisp, const float* ddepth, int batch,
                          int h, int w, int c, float min_depth, float max_depth, float* dx, float* dweight, float* dbias,
                          int accumulate, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* The same for an input x that is the OUTPUT of an activation read by this head alone (round 5; models/depth_head.py:63-71, the
+ * decoder's last ELU): x_act 1 / 2 = ReLU / ELU: dx is multiplied by act'(x) in the kernel that produces it, and
+ * x_colsum_part [codeps_disp_head_dx_blocks(batch, h, w)][16] (optional) receives the per-block column sums of the gated dx -- the
+ * producer's activation backward and bias gradient without a pass over the full-resolution tensor. */
+int codeps_disp_head_dx_blocks(int batch, int h, int w);
+int codeps_disp_head_bwd_gated(const float* x, const float* weight, const float* disp, const float* ddisp, const float* ddepth,
+                               int batch, int h, int w, int c, float min_depth, float max_depth, float* dx, float* dweight,
+                               float* dbias, int accumulate, int x_act, float* x_colsum_part, void* workspace,
+                               size_t workspace_bytes, codeps_stream_t stream);
 
 /* The decoders' last up-convolution (csrc/upconv16.hip): nearest x2 -> Conv2d(16, 16, 3, padding 1) (+ bias, act 0 none / 1 ReLU /
  * 2 ELU) with no skip tensor (models/depth_head.py:60-71 at scale 0) as four 2 x 2 convolutions of the half-resolution tensor
@@ -701,6 +710,12 @@ int codeps_upconv16_fwd(const float* x, const float* weight, const float* bias, 
                         void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 int codeps_upconv16_dgrad(const float* dz, const float* weight, int batch, int hs, int ws, float* dx, void* workspace,
                           size_t workspace_bytes, codeps_stream_t stream);
+/* ... with the gate of its source tensor (x = the activation output this layer alone reads; see codeps_disp_head_bwd_gated):
+ * x_colsum_part [codeps_upconv16_dgrad_blocks(batch, hs, ws)][16]. */
+int codeps_upconv16_dgrad_blocks(int batch, int hs, int ws);
+int codeps_upconv16_dgrad_gated(const float* dz, const float* weight, int batch, int hs, int ws, float* dx, const float* x,
+                                int x_act, float* x_colsum_part, void* workspace, size_t workspace_bytes,
+                                codeps_stream_t stream);
 size_t codeps_upconv16_wgrad_workspace_bytes(void);
 int codeps_upconv16_wgrad(const float* x, const float* dz, int batch, int hs, int ws, float* dweight, int accumulate, void* workspace,
                           size_t workspace_bytes, codeps_stream_t stream);

@@ -253,3 +253,25 @@ def test_epilogue_kernels_really_ran():
     yy = y.detach().double()
     assert torch.allclose(rm.double(), 0.1 * yy.mean((0, 1, 2)), atol=1e-6)
     assert torch.allclose(rv.double(), 0.9 + 0.1 * yy.reshape(-1, 64).var(0, unbiased=True), rtol=1e-5)
+
+
+def test_decoder_tail_gates_are_bit_identical():
+    """conv3x3(32 -> 16) + ELU -> upconv16 + ELU -> disp_head (models/depth_head.py:60-77): the two ELU backward passes ride in
+    upconv16's and disp_head's data-gradient kernels; everything but the bias gradients (another order of the same column sums) bit for bit"""
+    F = _F()
+    g = torch.Generator().manual_seed(21)
+    x = _nhwc(g, 2, 32, 64, 32)
+    w0 = (torch.randn(16, 32, 3, 3, generator=g) / 17).to(DEV).requires_grad_()
+    w1 = (torch.randn(16, 16, 3, 3, generator=g) / 12).to(DEV).requires_grad_()
+    wd = (torch.randn(1, 16, 3, 3, generator=g) / 12).to(DEV).requires_grad_()
+    b0, b1 = (torch.randn(16, generator=g) * 0.1).to(DEV).requires_grad_(), (torch.randn(16, generator=g) * 0.1).to(DEV).requires_grad_()
+    bd = torch.zeros(1, device=DEV).requires_grad_()
+    res = {}
+    for excl in (False, True):
+        xi = x.clone().requires_grad_()
+        y0 = F.conv2d(xi, w0, b0, pad=1, act="elu")
+        y1 = F.upconv16(y0, w1, b1, act="elu", exclusive=excl)
+        depth, disp = F.disp_head(y1, wd, bd, exclusive=excl)
+        gy = torch.randn(depth.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        res[excl] = [depth.detach()] + list(torch.autograd.grad((depth * gy).sum() + disp.sum(), [xi, w0, w1, wd, bd, b0, b1]))
+    _same(res, 2)
