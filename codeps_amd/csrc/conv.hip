@@ -224,13 +224,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// par == 2: this block's parity class (blockIdx.z) becomes the launch's (p is the kernel's own copy of the parameters)
-__device__ __forceinline__ void select_parity_class(ConvP& p) {
+// The parity class of this block: the launch's (par == 1: one launch per class) or blockIdx.z's (par == 2).  Read-only on purpose:
+// WRITING the selected class back into the kernel's by-value ConvP made the compiler keep the whole struct in scratch (400 bytes per
+// lane in every data-gradient instantiation, every data-gradient launch 30-50 % slower -- measured on the pre-training configurations).
+struct ParSel { int py, px, ky0, kx0, nky, nkx, tile_off; };
+__device__ __forceinline__ ParSel parity_class(const ConvP& p) {
+    ParSel s{p.py, p.px, p.ky0, p.kx0, p.nky, p.nkx, 0};
     if (p.par == 2) {
         const int c = blockIdx.z;
-        p.py = p.pcls[c][0]; p.px = p.pcls[c][1]; p.ky0 = p.pcls[c][2]; p.kx0 = p.pcls[c][3]; p.nky = p.pcls[c][4]; p.nkx = p.pcls[c][5];
-        p.ex_tile0 += c * p.n_mt;
+#define PCLS(k) (c == 0 ? p.pcls[0][k] : c == 1 ? p.pcls[1][k] : c == 2 ? p.pcls[2][k] : p.pcls[3][k])
+        s.py = PCLS(0); s.px = PCLS(1); s.ky0 = PCLS(2); s.kx0 = PCLS(3); s.nky = PCLS(4); s.nkx = PCLS(5);
+#undef PCLS
+        s.tile_off = c * p.n_mt;
     }
+    return s;
 }
 
 // Gather table of one block of BM rows (see conv_igemm_kernel): tab[source][tap][row] = byte offset of the pixel that row
@@ -238,7 +245,7 @@ __device__ __forceinline__ void select_parity_class(ConvP& p) {
 // the buffer resources of the source(s) rebased to that image.  Ends with a barrier.
 template <int MODE, int BM>
 __device__ __forceinline__ void build_gather(const ConvP& p, int m0, int ntap, unsigned* tab, const float* a0, const float* a1,
-                                             __amdgpu_buffer_rsrc_t& rs0, __amdgpu_buffer_rsrc_t& rs1) {
+                                             __amdgpu_buffer_rsrc_t& rs0, __amdgpu_buffer_rsrc_t& rs1, const ParSel pc) {
     const int tid = threadIdx.x;
     const bool two_src = MODE == MODE_FWD && p.C1 > 0;
     const bool parc = MODE == MODE_DGRAD && p.par;
@@ -269,13 +276,13 @@ __device__ __forceinline__ void build_gather(const ConvP& p, int m0, int ntap, u
             } else {
                 // dgrad: the output pixel (ty, tx) that read this input pixel through tap (ky, kx)
                 int ky, kx, qy = 0, qx = 0;
-                if (parc) { ky = p.ky0 + 2 * (tap / p.nkx); kx = p.kx0 + 2 * (tap % p.nkx); }
+                if (parc) { ky = pc.ky0 + 2 * (tap / pc.nkx); kx = pc.kx0 + 2 * (tap % pc.nkx); }
                 else if (upd) {
                     const int q = tap / (p.KH * p.KW), t2 = tap % (p.KH * p.KW);
                     qy = q >> 1; qx = q & 1; ky = t2 / p.KW; kx = t2 % p.KW;
                 } else { ky = tap / p.KW; kx = tap % p.KW; }
                 int iy = y, ix = x;
-                if (parc) { iy = 2 * iy + p.py; ix = 2 * ix + p.px; }
+                if (parc) { iy = 2 * iy + pc.py; ix = 2 * ix + pc.px; }
                 if (upd) { iy = 2 * iy + qy; ix = 2 * ix + qx; }
                 int ty = iy + p.pad - ky, tx = ix + p.pad - kx;
                 bool ok = ty >= 0 && tx >= 0;
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     float* As = smem;                                 // [NBUF][BM][LDK]
     float* Bs = smem + NBUF * BM * LDK;               // [NBUF][BN][LDK]
     CODEPS_STAMP_BEGIN();
-    if constexpr (MODE == MODE_DGRAD) select_parity_class(p);
+    const ParSel pc = parity_class(p);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- K-step enumeration: (tap, source segment, channel chunk)
-    const int ntap = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx
+    const int ntap = (MODE == MODE_DGRAD && p.par) ? pc.nky * pc.nkx
                    : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
     const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;          // channels per tap in the packed weights
     const int steps_per_tap = Kc / BK;
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     //      the loop the MFMA pipe idled 20-45 % of the time behind VALU work).
     unsigned* tab = reinterpret_cast<unsigned*>(smem + NBUF * (BM + BN) * LDK);
     __amdgpu_buffer_rsrc_t rs0, rs1;
-    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1);
+    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1, pc);
 
     // ---- per-thread staging roles: 16-B chunk `chunk` of rows rbase + RPP * i
     const int chunk = tid % CPR, rbase = tid / CPR;
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         }
         // ---- B operand (packed weights, K contiguous)
         int koff;
-        if (MODE == MODE_DGRAD && p.par) koff = ((p.ky0 + 2 * (tap / p.nkx)) * p.KW + p.kx0 + 2 * (tap % p.nkx)) * Kc + cstep;
+        if (MODE == MODE_DGRAD && p.par) koff = ((pc.ky0 + 2 * (tap / pc.nkx)) * p.KW + pc.kx0 + 2 * (tap % pc.nkx)) * Kc + cstep;
         else if (MODE == MODE_DGRAD && p.up0 && p.src == 0) koff = ((tap % (p.KH * p.KW)) * Kc) + cstep;
         else koff = tap * Kc + cstep;
 #pragma unroll
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                 if (m >= p.M) continue;
                 if (MODE == MODE_DGRAD && p.par) {            // class row -> pixel of the full-resolution gradient
                     const int bb = m / (p.Hc * p.Wc), rem = m % (p.Hc * p.Wc);
-                    m = (bb * p.H + 2 * (rem / p.Wc) + p.py) * p.W + 2 * (rem % p.Wc) + p.px;
+                    m = (bb * p.H + 2 * (rem / p.Wc) + pc.py) * p.W + 2 * (rem % p.Wc) + pc.px;
                 }
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
                 if (p.ksplit > 1) {                           // raw partial sum of this K slice; splitk_finish_kernel does the rest
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
             }
         }
     }
-    if constexpr (EX) epi_flush(p, ec, smem, tid, V4, RPASS, mt, n);
+    if constexpr (EX) epi_flush(p, ec, smem, tid, V4, RPASS, mt + pc.tile_off, n);
     CODEPS_STAMP_END(conv);
 }
 
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
     float* As = smem;                                 // [2][BM][LDK]
     float* Bs = smem + 2 * BM * LDK;                  // [2][BN][LDK]
     unsigned* tab = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * LDK);
-    if constexpr (MODE == MODE_DGRAD) select_parity_class(p);
+    const ParSel pc = parity_class(p);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
@@ -619,13 +626,13 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
     const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
     const int nt = logical % p.n_nt, mt = logical / p.n_nt;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int ntap = (MODE == MODE_DGRAD && p.par) ? p.nky * p.nkx
+    const int ntap = (MODE == MODE_DGRAD && p.par) ? pc.nky * pc.nkx
                    : ((MODE == MODE_DGRAD && p.up0 && p.src == 0) ? 4 * p.KH * p.KW : p.KH * p.KW);
     const int Kc = (MODE == MODE_FWD) ? p.Ct : p.Co;
     const int steps_per_tap = Kc / BK;
     const int nsteps = ntap * steps_per_tap;
     __amdgpu_buffer_rsrc_t rs0, rs1;
-    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1);
+    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1, pc);
 
     const int s_begin = p.ksplit > 1 ? (int)blockIdx.y * p.ksteps : 0;
     const int s_end = p.ksplit > 1 ? min(nsteps, s_begin + p.ksteps) : nsteps;
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
                     areg[i * 2 + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + coff + 16 * u, 0, 0));
             }
             int koff;
-            if (MODE == MODE_DGRAD && p.par) koff = ((p.ky0 + 2 * (tap / p.nkx)) * p.KW + p.kx0 + 2 * (tap % p.nkx)) * Kc + cstep;
+            if (MODE == MODE_DGRAD && p.par) koff = ((pc.ky0 + 2 * (tap / pc.nkx)) * p.KW + pc.kx0 + 2 * (tap % pc.nkx)) * Kc + cstep;
             else if (MODE == MODE_DGRAD && p.up0 && p.src == 0) koff = ((tap % (p.KH * p.KW)) * Kc) + cstep;
             else koff = tap * Kc + cstep;
 #pragma unroll
@@ -766,7 +773,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
                 if (m >= p.M) continue;
                 if (MODE == MODE_DGRAD && p.par) {
                     const int bb = m / (p.Hc * p.Wc), rem = m % (p.Hc * p.Wc);
-                    m = (bb * p.H + 2 * (rem / p.Wc) + p.py) * p.W + 2 * (rem % p.Wc) + p.px;
+                    m = (bb * p.H + 2 * (rem / p.Wc) + pc.py) * p.W + 2 * (rem % p.Wc) + pc.px;
                 }
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
                 if (p.ksplit > 1) {
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
             }
         }
     }
-    if constexpr (EX) epi_flush(p, ec, smem, tid, V4, RPASS, mt, n);
+    if constexpr (EX) epi_flush(p, ec, smem, tid, V4, RPASS, mt + pc.tile_off, n);
 }
 
 // ---------------------------------------------------------------------------------- halo-tile variant (3x3, stride 1)
@@ -1731,7 +1738,7 @@ __global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float*
     const int steps_per_tap = Kc / BK, nsteps = ntap * steps_per_tap;
     unsigned* tab = reinterpret_cast<unsigned*>(smem);
     __amdgpu_buffer_rsrc_t rs0, rs1;
-    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1);
+    build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1, parity_class(p));
     // weight row of this lane's column; columns past N read row N - 1 (their results are never stored)
     const float* brow = wq + (size_t)min(l16, p.N - 1) * p.KH * p.KW * Kc + q * 4;
     const int rrow = wave * 64 + l16;                            // this lane's row in tile i: rrow + 16 * i

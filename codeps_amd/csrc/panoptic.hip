@@ -21,6 +21,7 @@ namespace {
 constexpr int MAXC = 256;        // centre capacity (reference keeps < top_k = 200)
 constexpr int NCLS = 32;         // class histogram stride (semantic ids < 32; 255 = void)
 constexpr int CHUNK = 1024;
+constexpr int CAND_CAP = 16384;  // compact candidate list per image (more candidates than that: the selection walks the pixels as before)
 
 struct PanP {
     int H, W, top_k, nms, label_divisor, void_label;
@@ -97,11 +98,50 @@ __global__ __launch_bounds__(256) void block_count_kernel(int HW, int nchunk, co
     if (threadIdx.x == 0) counts[b * nchunk + ch] = (int)t;
 }
 
+// Candidates of chunk `ch` (1024 pixels) in row-major order -> cand[b][rank] = pixel index, rank = candidates in earlier chunks + rank
+// inside the chunk (round 5: the selection below then walks K candidates instead of H * W pixels four times over).  One block per
+// chunk that holds a candidate; a block sums the counts of the chunks in front of it (<= 512 ints).
+__global__ __launch_bounds__(256) void compact_kernel(int HW, int nchunk, const uint8_t* __restrict__ flag, const int* __restrict__ counts,
+                                                      int* __restrict__ cand, int cap) {
+    __shared__ int sh[256];
+    __shared__ int base;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int* cnt = counts + b * nchunk;
+    if (cnt[ch] == 0) return;                                     // block-uniform
+    int a = 0;
+    for (int i = threadIdx.x; i < ch; i += 256) a += cnt[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) base = sh[0];
+    __syncthreads();
+    // four consecutive pixels per thread: rank inside the chunk by an exclusive scan of the per-thread counts
+    const uint8_t* f = flag + (size_t)b * HW;
+    const int p0 = ch * CHUNK + threadIdx.x * 4;
+    int k[4], n = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { k[e] = (p0 + e < HW && f[p0 + e]) ? 1 : 0; n += k[e]; }
+    __syncthreads();
+    sh[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = base + sh[threadIdx.x] - n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (k[e]) { if (pos < cap) cand[(size_t)b * cap + pos] = p0 + e; ++pos; }
+}
+
 // state per image: [0] K candidates, [1] Kc kept centres, [2] tau bits
 __global__ __launch_bounds__(1024) void select_kernel(PanP p, int nchunk, const float* __restrict__ ctr, const uint8_t* __restrict__ flag,
-                                                      int* __restrict__ counts, int* __restrict__ state, int* __restrict__ centers) {
+                                                      int* __restrict__ counts, int* __restrict__ state, int* __restrict__ centers,
+                                                      const int* __restrict__ cand, int cap) {
     __shared__ unsigned hist[256];
-    __shared__ int sh_k, sh_prefix, sh_rank, sh_cnt;
+    __shared__ int sh_prefix, sh_rank, sh_cnt;
     __shared__ int scan[1024];
     const int b = blockIdx.x, HW = p.H * p.W, tid = threadIdx.x;
     const float* c0 = ctr + (size_t)b * p.ctr_bs;
@@ -116,9 +156,34 @@ __global__ __launch_bounds__(1024) void select_kernel(PanP p, int nchunk, const 
     for (int s = 512; s > 0; s >>= 1) { if (tid < s) scan[tid] += scan[tid + s]; __syncthreads(); }
     const int K = scan[0];
     __syncthreads();
+    const int* cl = cand + (size_t)b * cap;
+    const bool listed = K <= cap;                                // the compact list holds every candidate (else: the pixel walk below)
     // 200-th largest candidate score (keys: float bits of positive scores, monotone as uint32)
     float tau = -INFINITY;
-    if (K >= p.top_k) {
+    if (K >= p.top_k && listed) {
+        if (tid == 0) { sh_prefix = 0; sh_rank = p.top_k; }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = (unsigned)sh_prefix;
+            const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int j = tid; j < K; j += 1024) {
+                const unsigned key = __float_as_uint(c0[(size_t)cl[j] * cps]);
+                if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned k = (unsigned)sh_rank, above = 0;
+                int bin = 255;
+                for (; bin > 0; --bin) { if (above + hist[bin] >= k) break; above += hist[bin]; }
+                sh_prefix = (int)(prefix | ((unsigned)bin << shift));
+                sh_rank = (int)(k - above);
+            }
+            __syncthreads();
+        }
+        tau = __uint_as_float((unsigned)sh_prefix);
+    } else if (K >= p.top_k) {
         if (tid == 0) { sh_prefix = 0; sh_rank = p.top_k; }
         __syncthreads();
         for (int shift = 24; shift >= 0; shift -= 8) {
@@ -146,6 +211,26 @@ __global__ __launch_bounds__(1024) void select_kernel(PanP p, int nchunk, const 
     // ordered list of kept centres (row-major order), at most MAXC
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
+    if (listed) {                                                 // the candidates in order, 1024 at a time
+        for (int base = 0; base < K; base += 1024) {
+            const int j = base + tid;
+            const int i = j < K ? cl[j] : 0;
+            const int keep = (j < K && c0[(size_t)i * cps] > tau) ? 1 : 0;
+            scan[tid] = keep;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                const int v = tid >= off ? scan[tid - off] : 0;
+                __syncthreads();
+                scan[tid] += v;
+                __syncthreads();
+            }
+            const int pos = sh_cnt + scan[tid] - keep;
+            if (keep && pos < MAXC) { centers[(b * MAXC + pos) * 2] = i / p.W; centers[(b * MAXC + pos) * 2 + 1] = i % p.W; }
+            __syncthreads();
+            if (tid == 1023) sh_cnt += scan[1023];
+            __syncthreads();
+        }
+    } else
     for (int base = 0; base < HW; base += 1024) {
         if (cnt[base / CHUNK] == 0) continue;               // block-uniform: most chunks hold no candidate
         const int i = base + tid;
@@ -211,23 +296,29 @@ __global__ __launch_bounds__(256) void group_kernel(PanP p, const uint8_t* __res
         if (lh[i]) atomicAdd(&hist[(size_t)b * MAXC * NCLS + i], lh[i]);
 }
 
-__global__ void assign_kernel(PanP p, const int* __restrict__ state, const int* __restrict__ hist, int* __restrict__ idmap) {
-    // one thread per image: serial over <= MAXC instances, ascending id (reference loop order)
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(256) void assign_kernel(PanP p, const int* __restrict__ state, const int* __restrict__ hist, int* __restrict__ idmap) {
+    // majority class per instance in parallel (thread k = instance k; round 4 walked 256 x 32 bins in ONE thread: 140 us of serial loads),
+    // then the running per-class counters in ascending instance order (the reference's loop order) by one thread over LDS
+    __shared__ int best[MAXC];
+    const int b = blockIdx.x, k = threadIdx.x;
     const int Kc = state[b * 4 + 1];
+    int bestc = -1;
+    if (k < Kc) {
+        const int* h = hist + ((size_t)b * MAXC + k) * NCLS;
+        int bestn = 0;
+        for (int c = 0; c < NCLS; ++c)
+            if (h[c] > bestn) { bestn = h[c]; bestc = c; }              // first max = smallest label (torch.mode)
+    }
+    best[k] = bestc;
+    __syncthreads();
+    if (k != 0) return;
     int counter[NCLS];
     for (int c = 0; c < NCLS; ++c) counter[c] = 0;
-    for (int k = 0; k < MAXC; ++k) {
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = best[i];
         int val = -1;
-        if (k < Kc) {
-            const int* h = hist + ((size_t)b * MAXC + k) * NCLS;
-            int bestc = -1, bestn = 0;
-            for (int c = 0; c < NCLS; ++c)
-                if (h[c] > bestn) { bestn = h[c]; bestc = c; }          // first max = smallest label (torch.mode)
-            if (bestc >= 0) { counter[bestc] += 1; val = bestc * p.label_divisor + counter[bestc]; }
-        }
-        idmap[b * MAXC + k] = val;
+        if (c >= 0) { counter[c] += 1; val = c * p.label_divisor + counter[c]; }
+        idmap[b * MAXC + i] = val;
     }
 }
 
@@ -257,7 +348,8 @@ extern "C" size_t codeps_panoptic_workspace_bytes(int batch, int h, int w) {
     return align_up((size_t)batch * HW, 256)                      // flags
            + align_up((size_t)batch * nchunk * 4, 256)            // chunk counts
            + align_up((size_t)batch * MAXC * NCLS * 4, 256)       // histograms
-           + align_up((size_t)batch * MAXC * 4, 256);             // id map
+           + align_up((size_t)batch * MAXC * 4, 256)              // id map
+           + align_up((size_t)batch * CAND_CAP * 4, 256);         // compact candidate list
 }
 
 extern "C" int codeps_panoptic_fusion(const uint8_t* semantic, const float* center, const float* offset, int batch, int h, int w,
@@ -291,7 +383,8 @@ extern "C" int codeps_panoptic_fusion_strided(const uint8_t* semantic, const flo
     uint8_t* flag = (uint8_t*)ws; ws += align_up((size_t)batch * HW, 256);
     int* counts = (int*)ws;       ws += align_up((size_t)batch * nchunk * 4, 256);
     int* hist = (int*)ws;         ws += align_up((size_t)batch * MAXC * NCLS * 4, 256);
-    int* idmap = (int*)ws;
+    int* idmap = (int*)ws;        ws += align_up((size_t)batch * MAXC * 4, 256);
+    int* cand = (int*)ws;
     hipStream_t st = (hipStream_t)stream;
     const int gx = std::min(cdiv(HW, 256), 1024);
     // centre list: zero beyond the kept entries (callers read the whole [B,256,2] array)
@@ -304,10 +397,12 @@ extern "C" int codeps_panoptic_fusion_strided(const uint8_t* semantic, const flo
         hipLaunchKernelGGL(nms_flag_kernel, dim3(gx, batch), dim3(256), 0, st, p, center, flag);
     }
     hipLaunchKernelGGL(block_count_kernel, dim3(nchunk, batch), dim3(256), 0, st, HW, nchunk, (const uint8_t*)flag, counts);
-    hipLaunchKernelGGL(select_kernel, dim3(batch), dim3(1024), 0, st, p, nchunk, center, (const uint8_t*)flag, counts, state, centers);
+    hipLaunchKernelGGL(compact_kernel, dim3(nchunk, batch), dim3(256), 0, st, HW, nchunk, (const uint8_t*)flag, (const int*)counts, cand, CAND_CAP);
+    hipLaunchKernelGGL(select_kernel, dim3(batch), dim3(1024), 0, st, p, nchunk, center, (const uint8_t*)flag, counts, state, centers, (const int*)cand,
+                       CAND_CAP);
     hipLaunchKernelGGL(group_kernel, dim3(std::min(gx, 256), batch), dim3(256), 0, st, p, semantic, offset, (const int*)state, (const int*)centers,
                        instance, hist);
-    hipLaunchKernelGGL(assign_kernel, dim3(batch), dim3(64), 0, st, p, (const int*)state, (const int*)hist, idmap);
+    hipLaunchKernelGGL(assign_kernel, dim3(batch), dim3(MAXC), 0, st, p, (const int*)state, (const int*)hist, idmap);
     hipLaunchKernelGGL(paste_kernel, dim3(gx, batch), dim3(256), 0, st, p, semantic, (const uint8_t*)instance, (const int*)idmap, panoptic, instance_i64);
     CODEPS_CHECK_LAUNCH("panoptic kernels");
     return CODEPS_OK;

@@ -275,3 +275,22 @@ def test_decoder_tail_gates_are_bit_identical():
         gy = torch.randn(depth.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
         res[excl] = [depth.detach()] + list(torch.autograd.grad((depth * gy).sum() + disp.sum(), [xi, w0, w1, wd, bd, b0, b1]))
     _same(res, 2)
+
+
+@pytest.mark.parametrize("h,w,nms", [(512, 1024, 7), (512, 512, 3), (64, 96, 7)])
+def test_panoptic_centre_selection_on_dense_candidates(h, w, nms):
+    """misc/post_processing_panoptic.py:31-92 on a heat map of white noise: ~H W / nms^2 local maxima, i.e. 10 k candidates through the
+    compact candidate list (round 5) at 512 x 1024 / 7, 29 k -- more than the list holds: the pixel-walk selection -- at 512 x 512 / 3.
+    The 200 kept centres, in row-major order, bit for bit against the oracle."""
+    import numpy as np
+    F = _F()
+    from oracle import panoptic
+    g = torch.Generator().manual_seed(h + nms)
+    ctr = torch.rand(1, 1, h, w, generator=g) * 0.8 + 0.15
+    sem = torch.full((1, h, w), 11, dtype=torch.uint8)
+    off = torch.zeros(1, 2, h, w)
+    pan, inst, centers, state = F.panoptic_fusion(sem.to(DEV), ctr.to(DEV), off.to(DEV), [9, 10, 11, 12, 13], nms_kernel=nms)
+    pts = panoptic.find_centers(ctr[0, 0].numpy(), 0.1, nms, 200)
+    k = int(state[0, 1])
+    assert k == len(pts) and (int(state[0, 0]) > 200 or h * w < 49 * 200)
+    assert np.array_equal(centers[0, :k].cpu().numpy(), np.asarray(pts))
