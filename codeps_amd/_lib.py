@@ -110,7 +110,7 @@ SIGNATURES = {
     "codeps_colsum_finish": (c_int, [P, I, I, P, I, I, P]),
     "codeps_bn_finalize_tiles": (c_int, [P, I, I, I, I, P, P, I, c_float, P, P, P, P]),
     "codeps_bn_bwd_tiles": (c_int, [P, I, P, P, P, I, P, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, P, I, P]),
-    "codeps_bn_relu_pool_fwd": (c_int, [P, I, P, P, I, I, I, I, P, P, P, P, P, P, P]),
+    "codeps_bn_relu_pool_fwd": (c_int, [P, I, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, c_float, I, P]),
     "codeps_bn_relu_pool_bwd": (c_int, [P, P, P, I, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, P, c_size_t, I, P]),
     "codeps_maxpool3x3s2_fwd": (c_int, [P, I, I, I, I, P, P, P]),
     "codeps_maxpool3x3s2_bwd": (c_int, [P, P, I, I, I, I, P, P]),

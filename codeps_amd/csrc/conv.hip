@@ -1719,6 +1719,32 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
                 orow[(size_t)m * 64] = apply_act(acc[nt][e] * sc + sh, p.act);
             }
         }
+        if (p.ex_stat == 1) {
+            // the tile's statistics for the train-mode BatchNorm behind the stem (ConvP.ex_stat 1: shift = the tile's first pixel, sum (z - shift),
+            // sum (z - shift)^2 per channel; no scale / shift in that configuration): 16 values per lane, the other half-wave by a shuffle,
+            // the eight waves (= output rows of the tile) in LDS in a fixed order -- instead of a 400 MB pass over the stem's output
+            float* st_sh = reinterpret_cast<float*>(lds16 + XH * XW * PIT + 2 * 64 * WROW);      // [64] shift, then [8 waves][2][64] partial sums
+            float* st_part = st_sh + 64;
+            if (wave == 0 && h == 0) { st_sh[l32] = acc[0][0]; st_sh[32 + l32] = acc[1][0]; }
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float s0 = st_sh[nt * 32 + l32];
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float d = acc[nt][e] - s0; a += d; q += d * d; }
+                a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+                if (h == 0) { st_part[(wave * 2 + 0) * 64 + nt * 32 + l32] = a; st_part[(wave * 2 + 1) * 64 + nt * 32 + l32] = q; }
+            }
+            __syncthreads();
+            if (tid < 64) {
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) { a += st_part[(w8 * 2 + 0) * 64 + tid]; q += st_part[(w8 * 2 + 1) * 64 + tid]; }
+                float* dst = p.ex_part + (size_t)tile * 3 * 64 + tid;
+                dst[0] = st_sh[tid]; dst[64] = a; dst[128] = q;
+            }
+        }
     }
 }
 
@@ -4470,12 +4496,20 @@ extern "C" int codeps_conv2d_fwd_ex(const codeps_conv_desc* d, const float* x0, 
         // the double-pixel stem (functional.stem_conv2d) on whole 8 x 32 tiles: the halo-tile kernel
         const int tiles_x = d->out_w / 32, tiles_y = d->out_h / 8, total = d->batch * tiles_x * tiles_y;
         const int tpb = std::max(1, cdiv(total, 256 * std::max(1, total / (256 * 12))));     // one block per CU and round, <= ~12 tiles each
-        constexpr size_t lds = ((size_t)21 * 35 * 56 + 2 * 64 * 200) * 2;
+        constexpr size_t lds = ((size_t)21 * 35 * 56 + 2 * 64 * 200) * 2 + (64 + 8 * 2 * 64) * sizeof(float);
         g_last_kernel = "conv_stem74f_kernel";
         codeps_allow_lds((const void*)conv_stem74f_kernel, 160 * 1024, "conv_stem74f_kernel");
+        // epilogue extras of this kernel: the forward statistics only (its 8 x 32 tiles lie inside one image by construction)
+        const bool stem_stats = p.ex_stat == 1 && !p.ex_gate_act && !scale && !shift && d->act == 0;
+        p.ex_gate = nullptr; p.ex_gate_act = 0;
+        if (!stem_stats) p.ex_stat = 0;
         hipLaunchKernelGGL(conv_stem74f_kernel, dim3(cdiv(total, tpb)), dim3(512), lds, (hipStream_t)stream, p, tiles_x, tiles_y, tpb, x0, scale, shift, y);
         CODEPS_CHECK_LAUNCH("conv_stem74f_kernel");
-        epi_store(epilogue);                                   // (this kernel has no epilogue extras: applied = 0)
+        if (stem_stats) {
+            g_epi.applied = 2; g_epi.n_seg = 1;
+            g_epi.tile0[0] = 0; g_epi.tpi[0] = tiles_x * tiles_y; g_epi.rows[0] = 256; g_epi.tiles[0] = total;
+        }
+        epi_store(epilogue);
         return CODEPS_OK;
     }
     dispatch_igemm<MODE_FWD>(p, gran, x0, x1, w_fwd, scale, shift, residual, y, (hipStream_t)stream);

@@ -791,7 +791,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ z, BnGroups gr, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int B, int H, int W, int C, int Ho, int Wo,
-                                                               float* __restrict__ y, uint8_t* __restrict__ arg) {
+                                                               float* __restrict__ y, uint8_t* __restrict__ arg, BnRunning run) {
+    if (run.mean && blockIdx.x == 0)            // batch statistics from codeps_bn_finalize_tiles: the momentum updates ride here (as in bn_apply_mg_kernel)
+        for (int c = threadIdx.x; c < run.c_real; c += 256) {
+            float rm = run.mean[c], rv = run.var[c];
+            for (int g = 0; g < gr.n; ++g) {
+                const float n = (float)gr.rows[g];
+                rm = rm * (1.f - run.momentum) + run.momentum * mean[g * C + c];
+                rv = rv * (1.f - run.momentum) + run.momentum * (run.batch_var[g * C + c] * (n / fmaxf(n - 1.f, 1.f)));
+            }
+            run.mean[c] = rm; run.var[c] = rv;
+        }
     const int G = C / 4;
     const long long total = (long long)B * Ho * Wo * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1711,7 +1721,8 @@ extern "C" int codeps_bn_bwd_mg(const float* dy, const float* y, const float* x,
 // maxpool3x3s2_bwd + bn_bwd_mg: same expressions, same orders of summation.
 extern "C" int codeps_bn_relu_pool_fwd(const float* z, int n_groups, const long long* row0, const long long* rows, int batch, int h, int w, int c,
                                        const float* mean, const float* invstd, const float* gamma, const float* beta, float* pooled,
-                                       uint8_t* argmax, codeps_stream_t stream) {
+                                       uint8_t* argmax, float* running_mean, float* running_var, const float* batch_var, float momentum,
+                                       int c_real, codeps_stream_t stream) {
     BnGroups gr;
     long long M;
     int rc = make_groups(n_groups, row0, rows, gr, M, "bn_relu_pool_fwd");
@@ -1721,8 +1732,11 @@ extern "C" int codeps_bn_relu_pool_fwd(const float* z, int n_groups, const long 
     for (int i = 0; i < n_groups; ++i)
         CODEPS_REQUIRE(row0[i] % ((long long)h * w) == 0 && rows[i] % ((long long)h * w) == 0, CODEPS_ERR_ARG, "bn_relu_pool_fwd: groups are whole images");
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    CODEPS_REQUIRE(!running_mean || (running_var && batch_var && c_real > 0 && c_real <= c), CODEPS_ERR_ARG,
+                   "bn_relu_pool_fwd: running statistics need running_var, the batch variances and c_real");
+    BnRunning run{running_mean, running_var, batch_var, momentum, c_real};
     hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(grid_for((long long)batch * ho * wo * (c / 4))), dim3(256), 0, (hipStream_t)stream, z, gr, mean, invstd,
-                       gamma, beta, batch, h, w, c, ho, wo, pooled, argmax);
+                       gamma, beta, batch, h, w, c, ho, wo, pooled, argmax, run);
     CODEPS_CHECK_LAUNCH("bn_relu_pool_fwd_kernel");
     return CODEPS_OK;
 }

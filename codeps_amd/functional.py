@@ -476,6 +476,7 @@ _UP_DGRAD16 = os.environ.get("CODEPS_UP_DGRAD16", "1") != "0"     # A/B switch: 
 
 _EPI = os.environ.get("CODEPS_EPILOGUE", "1") != "0"       # A/B switch: 0 = activation / BatchNorm backward and statistics as separate passes
 # ... and one by one: BatchNorm statistics from the forward epilogue / activation gates / the BatchNorm gate of the data gradient
+_STEM_STATS = os.environ.get("CODEPS_STEM_STATS", "1") != "0"      # A/B switch: the stem convolution's statistics epilogue
 _EPI_PARTS = {k: os.environ.get("CODEPS_EPI_" + k.upper(), "1") != "0" for k in ("stats", "act", "bn")}
 
 
@@ -825,7 +826,7 @@ def stem_weight(weight):
     return _StemWeight.apply(weight)
 
 
-def stem_conv2d(x, weight, *, scale=None, shift=None, act=None):
+def stem_conv2d(x, weight, *, scale=None, shift=None, act=None, bn_stats=False):
     """ResNet conv1 (7x7, stride 2, padding 3, <= 8 input channels; models/resnet_encoder.py:115) on the double-pixel
     stem layout: x [B, H, W + 6, 8] = images with STEM_XPAD zero columns (images_to_nhwc(..., 8, STEM_XPAD)).
     Two neighbouring pixels are one 16-channel pixel of a [B, H, (W + 6) / 2, 16] view and conv1 is a 7x4 convolution
@@ -834,7 +835,7 @@ def stem_conv2d(x, weight, *, scale=None, shift=None, act=None):
     if c != 8 or wp % 2:
         raise _lib.CodepsHipError("stem_conv2d: expects [B, H, W + 6, 8] with even W")
     return conv2d(x.view(b, h, wp // 2, 16), stem_weight(weight), scale=scale, shift=shift, stride=(2, 1), pad=(3, 0), act=act,
-                  macs_per_out=weight.shape[1] * 49)
+                  macs_per_out=weight.shape[1] * 49, bn_stats=bn_stats and _STEM_STATS)
 
 
 # ---------------------------------------------------------------------------------------- frozen 3-channel stem
@@ -1287,7 +1288,14 @@ class _BnReluPoolTrain(torch.autograd.Function):
         rv = running_var if rm is not None else None
         counts = [float((b1 - b0) * per_item) for b0, b1 in groups]
 
+        tiles = getattr(z, "_codeps_stats", None) if (_EPI and _EPI_PARTS["stats"]) else None     # partials from the stem convolution's epilogue
+
         def local_stats(mean_o, var_o, rm_, rv_):
+            if tiles is not None:
+                ngi, gb0, gb1 = _img_groups(groups)
+                check(lib().codeps_bn_finalize_tiles(ptr(tiles["part"]), tiles["tile0"], tiles["tpi"], tiles["rows"], ngi, gb0, gb1, cp, eps,
+                                                     ptr(mean_o), ptr(var_o), ptr(invstd), stream_ptr()), "codeps_bn_finalize_tiles")
+                return                      # (the running statistics' momentum updates ride in the pooled pass below)
             check(lib().codeps_bn_fwd_mg(ptr(z), ng, row0, rows, cp, c, None, None, None, 1, eps, momentum, ptr(rm_), ptr(rv_), ptr(mean_o),
                                          ptr(var_o), ptr(invstd), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg (statistics)")
         if reduce_fn is None:
@@ -1320,7 +1328,9 @@ class _BnReluPoolTrain(torch.autograd.Function):
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = torch.empty(bsz, ho, wo, cp, dtype=torch.float32, device=dev)
         arg = torch.empty(bsz, ho, wo, cp, dtype=torch.uint8, device=dev)
+        run = tiles is not None and reduce_fn is None and rm is not None
         check(lib().codeps_bn_relu_pool_fwd(ptr(z), ng, row0, rows, bsz, h, w, cp, ptr(mean), ptr(invstd), ptr(g), ptr(b_), ptr(y), ptr(arg),
+                                            ptr(rm) if run else None, ptr(rv) if run else None, ptr(var) if run else None, momentum, c,
                                             stream_ptr()), "codeps_bn_relu_pool_fwd")
         ctx.inv_count = [1.0 / n for n in counts]
         ctx.save_for_backward(z, arg, g, b_, mean, invstd)
@@ -1368,6 +1378,8 @@ class _BnReluPoolTrain(torch.autograd.Function):
 
 
 def bn_relu_maxpool_train(z, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, groups=None, reduce_fn=None):
+    """z may carry `._codeps_stats` (stem_conv2d(..., bn_stats=True)): the statistics pass over the stem's output is then a finish over
+    per-tile partials."""
     return _BnReluPoolTrain.apply(z, gamma, beta, running_mean, running_var, momentum, eps, groups, reduce_fn)
 
 

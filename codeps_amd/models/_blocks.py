@@ -73,7 +73,7 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
         return F.stem3_conv2d(x, conv.weight, scale=scale, shift=shift, act=act)
     if stem:
         if bn.training or (torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad)):
-            y = F.stem_conv2d(x, conv.weight)
+            y = F.stem_conv2d(x, conv.weight, bn_stats=bn.training)
             if bn.training:
                 out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                          residual=residual, act=act, reduce_fn=sync, groups=groups)

@@ -192,7 +192,8 @@ class ResnetEncoder(nn.Module):
         if self.only_last_feature and F._BNPOOL and enc.bn1.training and stem != "s3":
             # train-mode stem whose ReLU output nobody reads: statistics, then relu(bn(z)) max-pooled straight from z (and the backward
             # from the pooled gradient) -- 2.5 GB of the stem's 4.4 GB of BatchNorm / pooling traffic per step are not moved
-            z = F.stem_conv2d(x, enc.conv1.weight) if stem else F.conv2d(x, enc.conv1.weight, stride=enc.conv1.stride[0], pad=enc.conv1.padding[0])
+            z = F.stem_conv2d(x, enc.conv1.weight, bn_stats=True) if stem else \
+                F.conv2d(x, enc.conv1.weight, stride=enc.conv1.stride[0], pad=enc.conv1.padding[0], bn_stats=True)
             x = F.bn_relu_maxpool_train(z, enc.bn1.weight, enc.bn1.bias, enc.bn1.running_mean, enc.bn1.running_var, enc.bn1.momentum,
                                         enc.bn1.eps, groups, reduce_fn=self.sync_bn)        # (SyncBatchNorm too, since round 5)
             _count_batch(enc.bn1, len(groups) if groups else 1)

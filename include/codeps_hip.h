@@ -295,10 +295,14 @@ int codeps_bn_bwd_tiles(const float* part, int n_seg, const int* seg_tile0, cons
  * statistics (mean, invstd per group) come from codeps_bn_fwd_mg(stats_only = 1).  bwd = BatchNorm's two passes (sums, then dz)
  * reading the POOLED gradient + arg-max bytes: no full-resolution gradient of the ReLU output either.  Groups are whole images
  * (row0 / rows in pixels, multiples of h * w).  Bit-identical to codeps_bn_fwd_mg + codeps_maxpool3x3s2_fwd resp.
- * codeps_maxpool3x3s2_bwd + codeps_bn_bwd_mg (same expressions, same orders of summation).  workspace: codeps_bn_mg_workspace_bytes. */
+ * codeps_maxpool3x3s2_bwd + codeps_bn_bwd_mg (same expressions, same orders of summation).  workspace: codeps_bn_mg_workspace_bytes.
+ * running_mean != NULL (round 5): the batch statistics came from codeps_bn_finalize_tiles (partials of the stem convolution's
+ * epilogue) -- the momentum updates of running_mean / running_var [c_real] from mean / batch_var [n_groups, c], group after group,
+ * ride in this launch. */
 int codeps_bn_relu_pool_fwd(const float* z, int n_groups, const long long* row0, const long long* rows, int batch, int h,
                             int w, int c, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                            float* pooled, uint8_t* argmax, codeps_stream_t stream);
+                            float* pooled, uint8_t* argmax, float* running_mean, float* running_var, const float* batch_var,
+                            float momentum, int c_real, codeps_stream_t stream);
 int codeps_bn_relu_pool_bwd(const float* dpooled, const uint8_t* argmax, const float* z, int n_groups, const long long* row0,
                             const long long* rows, int batch, int h, int w, int c, int c_real, const float* mean,
                             const float* invstd, const float* gamma, const float* beta, const float* inv_count, float* sums,

@@ -294,3 +294,71 @@ def test_panoptic_centre_selection_on_dense_candidates(h, w, nms):
     k = int(state[0, 1])
     assert k == len(pts) and (int(state[0, 0]) > 200 or h * w < 49 * 200)
     assert np.array_equal(centers[0, :k].cpu().numpy(), np.asarray(pts))
+
+
+@pytest.mark.parametrize("groups", [False, True])
+def test_stem_statistics_from_the_halo_kernel_epilogue(groups):
+    """Train-mode stem of the pose encoder (models/resnet_encoder.py:118-121): conv_stem74f_kernel leaves (shift, sum, sum of squares)
+    per 8 x 32 tile and codeps_bn_finalize_tiles + the pooled pass (running statistics riding in it) replace the statistics pass over
+    the stem's output.  Against the classical statistics pass (CODEPS_EPI_STATS=0's path): same batch statistics up to fp32 summation
+    order -> running statistics within 1e-6, last feature map / parameter gradients within 2e-3 / 5e-3 relative L2 (every BatchNorm
+    of the reference run takes the classical pass; a ReLU may flip for a few elements at zero); the tile statistics themselves against
+    float64 statistics of the stem's output."""
+    import copy
+    import ctypes
+    from codeps_amd import models
+    from codeps_amd._lib import lib
+    F = _F()
+    torch.manual_seed(11)
+    enc = models.ResnetEncoder(18, False, num_input_images=2).to(DEV).train()
+    enc.only_last_feature = True
+    ref = copy.deepcopy(enc)
+    g = torch.Generator().manual_seed(6)
+    frames = [torch.rand(2, 3, 128, 256, generator=g).to(DEV) for _ in range(4)]          # stem output 64 x 128: whole 8 x 32 tiles
+    lib().codeps_conv2d_last_kernel.restype = ctypes.c_char_p
+    outs, gy = [], None
+    seen = {}
+    orig = F.stem_conv2d
+
+    def spy(*a, **k):
+        z = orig(*a, **k)
+        seen["kernel"] = lib().codeps_conv2d_last_kernel().decode()
+        seen["stats"] = getattr(z, "_codeps_stats", None)
+        return z
+    keep = F._EPI_PARTS["stats"]
+    try:
+        for net, on in ((ref, False), (enc, True)):
+            F._EPI_PARTS["stats"] = on and keep
+            F.stem_conv2d = spy if on else orig
+            last = (net.forward_pair_groups([(frames[0], frames[1]), (frames[2], frames[3])]) if groups else net((frames[0], frames[1])))[-1]
+            if gy is None:
+                gy = torch.randn(last.shape, generator=torch.Generator().manual_seed(9)).to(DEV)
+            last.backward(gy)
+            outs.append((last.detach().clone(), [p.grad.clone() for p in net.parameters() if p.grad is not None],
+                         net.encoder.bn1.running_mean.clone(), net.encoder.bn1.running_var.clone()))
+    finally:
+        F._EPI_PARTS["stats"] = keep
+        F.stem_conv2d = orig
+    if not keep:
+        pytest.skip("CODEPS_EPI_STATS=0")
+    assert seen["kernel"] == "conv_stem74f_kernel" and seen["stats"] is not None and seen["stats"]["rows"] == 256
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))        # noqa: E731
+    a, b = outs
+    assert rel(b[0], a[0]) <= 2e-3
+    assert rel(b[2], a[2]) <= 1e-6 and rel(b[3], a[3]) <= 1e-6
+    assert len(a[1]) == len(b[1]) >= 60
+    worst = max(rel(gb, ga) for ga, gb in zip(a[1], b[1]))
+    assert worst <= 5e-3, worst
+    # and against float64 statistics of the stem's output itself
+    with torch.no_grad():
+        x = F.frame_pairs_to_nhwc([(frames[0], frames[1])], 8, F.STEM_XPAD)
+        z = orig(x, enc.encoder.conv1.weight, bn_stats=True)
+        st = z._codeps_stats
+        mean = torch.empty(1, 64, device=DEV)
+        var, inv = torch.empty_like(mean), torch.empty_like(mean)
+        ngi, gb0, gb1 = F._img_groups([(0, 2)])
+        F.check(lib().codeps_bn_finalize_tiles(F.ptr(st["part"]), st["tile0"], st["tpi"], st["rows"], ngi, gb0, gb1, 64, 1e-5, F.ptr(mean), F.ptr(var),
+                                               F.ptr(inv), F.stream_ptr()), "finalize")
+        zz = z.double().reshape(-1, 64)
+        assert torch.allclose(mean[0].double(), zz.mean(0), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(var[0].double(), zz.var(0, unbiased=False), rtol=1e-5)
