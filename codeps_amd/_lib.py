@@ -79,6 +79,7 @@ SIGNATURES = {
     "codeps_conv2d_pack_weights_multi": (c_int, [P, I, LL, P]),
     "codeps_conv2d_arith": (c_int, [POINTER(ConvDesc), I, I]),
     "codeps_conv2d_last_kernel": (c_char_p, []),
+    "codeps_conv2d_last_finish_kernel": (c_char_p, []),
     "codeps_conv2d_set_arith": (c_int, [I]),
     "codeps_conv2d_set_halo_ws": (c_int, [I]),
     "codeps_conv2d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),

@@ -81,6 +81,7 @@ struct ConvP {
     float* ex_part;             // [tile][rows of the mode][N]
     int ex_tile0;               // tile index of this launch's first M tile (the stride-2 parity classes are four launches)
     int ex_img_rows;            // gate 3 / stat 1 with the generic kernels: GEMM rows per image (a multiple of the tile's rows)
+    int ex_fin;                 // K slices: the extras run in splitk_finish_ex_kernel (64-row tiles) instead of the GEMM kernel's epilogue
     const float* ex_bn_x;       // gate 3: BatchNorm's input z [M][N], mean / invstd [groups][N], gamma / beta [N]
     const float* ex_bn_mean; const float* ex_bn_invstd; const float* ex_bn_gamma; const float* ex_bn_beta;
     int ex_bn_relu, ex_bn_ng;
@@ -2198,6 +2199,136 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------- wgrad of 1x1 convolutions, split arithmetic
+// dW[co][ci] = sum over pixels dZ[pix][co] X[pix'][ci] (pix' = pix, or the stride-2 sample of a down-sampling shortcut): a GEMM whose K
+// is the pixel axis, the SLOW axis of both NHWC operands.  conv_wgrad_kernel runs it on v_mfma_f32_32x32x2f32 (1/16 of the bf16 rate:
+// 50-60 us per bottleneck convolution of the pre-training configurations, 2.6 ms per step).  Here, as in wgrad_halo64s_kernel: a task
+// is 8 consecutive pixels x 4 channels (eight 16-byte loads, 64 contiguous bytes per pixel over four lanes), split into the three bf16
+// pieces in registers and written TRANSPOSED -- per channel and piece the 8 pixels as one 16-byte LDS store -- so that the fragments
+// of v_mfma_f32_32x32x16_bf16 (8 consecutive k per lane) are aligned 16-byte reads.  Block = 256 channels of the wider operand (A) x
+// 128 (TB = 2) or 64 (TB = 1) of the other (B) x K-steps of 32 pixels; wave = 128 x (TB x 32).  The tile is that large because every
+// block streams its A and B rows over ALL its pixels: a 128 x 64 tile (the first form of this kernel) moved ~200 MB per layer through
+// the memory system whatever the layer and ran at the f32 kernel's speed (60-70 us, ~3.3 TB/s).  The next K-step's loads are in flight
+// under the MFMAs.  SWAP: A = X, B = dZ (Ci > Co).  One partial slab [co][ci] per block, summed in a fixed order by wgrad_reduce_kernel.
+template <bool SWAP, int TB>
+__global__ __launch_bounds__(256, TB == 1 ? 2 : 1) void wgrad_1x1s_kernel(WgradP p, const float* __restrict__ x, const float* __restrict__ dz,
+                                                                          float* __restrict__ part) {
+    constexpr int KP = 32, ZP = 3 * KP + 8;                  // pixels per K-step; halfwords per channel row (pad: conflict-free fragment reads)
+    constexpr int TA = 4, BA = 2 * TA * 32, BB = 2 * TB * 32;
+    constexpr int NBT = BB / 4 * (KP / 8);                   // B tasks per K-step (A: 256)
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    unsigned short* As = lds16;                             // [BA][ZP]
+    unsigned short* Bs = lds16 + BA * ZP;                   // [BB][ZP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int wa = wave >> 1, wb = wave & 1;                // wave tile: A channels wa * 128 .., B channels wb * TB * 32 ..
+    const int CA = SWAP ? p.Ct : p.Co, CB = SWAP ? p.Co : p.Ct;
+    const int n_bt = (CB + BB - 1) / BB;
+    const int a0 = (blockIdx.y / n_bt) * BA, b0 = (blockIdx.y % n_bt) * BB;
+    const int split = blockIdx.x;
+    const int pbeg = split * p.pix_per_split, pend = min(pbeg + p.pix_per_split, p.P);
+    const bool strided = p.stride != 1 || p.stride_w != 1;
+
+    // Loads without branches: buffer loads whose byte offset is GATHER_OOB (-> zeros from the hardware range check) for pixels behind
+    // the slab's end and channels behind the operand's last -- sixteen `if (ok) load` made sixteen exec-mask regions per K-step, and the
+    // first form of this kernel spent its time there (434 v_mul_lo_u32 and 187 s_cbranch_execz in 4300 instructions, 60 TF/s).
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (size_t)p.B * p.H * p.W * p.Ct * 4), rs_z = make_rsrc(dz, (size_t)p.P * p.Co * 4);
+    const __amdgpu_buffer_rsrc_t rs_a = SWAP ? rs_x : rs_z, rs_b = SWAP ? rs_z : rs_x;
+    // tasks: A 64 quads x 4 pixel groups = 256 (thread tid), B (BB / 4) x 4 = 128 / 64 (the first threads).  Task -> (quad, group): the
+    // quad's low two bits over four consecutive lanes (64 contiguous bytes per pixel), then the pixel group, then the quad's high bits
+    const int t_c4 = (tid & 3) | ((tid >> 4) << 2), t_g = (tid >> 2) & 3;
+    const bool b_on = tid < NBT;
+    const int ca = a0 + t_c4 * 4, cb = b0 + t_c4 * 4;
+    const bool a_ok = ca < CA, b_ok = b_on && cb < CB;
+    // element offset of output pixel q in X (dZ: q * Co)
+    auto x_pix = [&](int q) -> unsigned {
+        if (!strided) return (unsigned)q * (unsigned)p.Ct;
+        const int b = q / (p.Ho * p.Wo), rem = q % (p.Ho * p.Wo);
+        return (unsigned)(((b * p.H + (rem / p.Wo) * p.stride) * p.W + (rem % p.Wo) * p.stride_w)) * (unsigned)p.Ct;
+    };
+    f32x4 ra[8], rb[8];
+    auto load_step = [&](int q0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int qa = q0 + t_g * 8 + i;
+            const bool ok = qa < pend;
+            const unsigned ox = x_pix(qa), oz = (unsigned)qa * (unsigned)p.Co;
+            const unsigned va = (ok && a_ok) ? ((SWAP ? ox : oz) + ca) * 4u : GATHER_OOB;
+            const unsigned vb = (ok && b_ok) ? ((SWAP ? oz : ox) + cb) * 4u : GATHER_OOB;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, va, 0, 0));
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, vb, 0, 0));     // (threads without a B task: out of range, no traffic)
+        }
+    };
+    auto store_task = [&](const f32x4 (&r)[8], unsigned short* dst) {      // dst = row of the quad's first channel, at this pixel group
+        u16x4 pc[8][3];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split_bf16<3>(r[i], pc[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const u16x4 lo = {pc[0][q][e], pc[1][q][e], pc[2][q][e], pc[3][q][e]}, hi = {pc[4][q][e], pc[5][q][e], pc[6][q][e], pc[7][q][e]};
+                *reinterpret_cast<i32x4*>(dst + e * ZP + q * KP) = pack8(lo, hi);
+            }
+    };
+
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nsteps = (pend - pbeg + KP - 1) / KP;
+    if (nsteps > 0) load_step(pbeg);
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();                                     // the previous K-step's fragment reads are done
+        store_task(ra, As + (t_c4 * 4) * ZP + t_g * 8);
+        if (b_on) store_task(rb, Bs + (t_c4 * 4) * ZP + t_g * 8);
+        __syncthreads();
+        if (step + 1 < nsteps) load_step(pbeg + (step + 1) * KP);
+#pragma unroll
+        for (int ks = 0; ks < KP / 16; ++ks) {
+            bf16x8 fb[TB][3];
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    fb[j][q] = *reinterpret_cast<const bf16x8*>(Bs + ((wb * TB + j) * 32 + l32) * ZP + q * KP + ks * 16 + h * 8);
+#pragma unroll
+            for (int i = 0; i < TA; ++i) {
+                bf16x8 fa[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bf16x8*>(As + ((wa * TA + i) * 32 + l32) * ZP + q * KP + ks * 16 + h * 8);
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+#pragma unroll
+                    for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                        for (int qa = 0; qa <= ord; ++qa)
+                            // (the lanes of the result run along the SECOND operand: always the input channels, the slab's fast axis)
+                            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ord - qa], fa[qa], acc[i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa], fb[j][ord - qa], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // partial slab [split][co][ci]; C layout: column = lane & 31 (ci), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (co)
+    float* dst = part + (size_t)split * p.Co * p.Ct;
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+            const int ta = a0 + (wa * TA + i) * 32, tb = b0 + (wb * TB + j) * 32;          // first A / B channel of this 32 x 32 tile
+            const int ci = (SWAP ? ta : tb) + l32;
+            if (ci >= p.Ct) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (SWAP ? tb : ta) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Co) dst[(size_t)co * p.Ct + ci] = acc[i][j][r];
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------- wgrad, small channel counts
 // Weight gradient of stride-1 1x1 / 3x3 convs with <= 32 output channels (the full-resolution decoder tail, the
 // disparity / class convs, the 240-channel GUDA conv): K (= pixels) is huge and the output is tiny, so the generic
@@ -3725,6 +3856,29 @@ static SmallPlan wgrad_small_plan(const codeps_conv_desc* d) {
     return s;
 }
 
+// 1 x 1 convolutions (any stride, no padding, one source) with >= 48 channels on both sides: wgrad_1x1s_kernel
+struct W1Plan { bool ok, swap; int tb, tiles, splits, pps; };
+static W1Plan wgrad_1x1_plan(const codeps_conv_desc* d) {
+    W1Plan w;
+    memset(&w, 0, sizeof(w));
+    static const int on = getenv("CODEPS_WGRAD_1X1S") ? atoi(getenv("CODEPS_WGRAD_1X1S")) : 1;       // A/B switch
+    const int P = d->batch * d->out_h * d->out_w;
+    w.ok = on && wgrad_split_on() && d->kh == 1 && d->kw == 1 && d->pad == 0 && d->pad_w == 0 && d->c1 == 0 && !d->up0 && d->pad_mode == 0 &&
+           d->pix_pitch == 0 && d->out_c >= 48 && d->c0 >= 48 && (d->out_c % 4) == 0 && (d->c0 % 4) == 0 && P >= 512 &&
+           (d->out_h - 1) * d->stride < d->in_h && (d->out_w - 1) * d->stride_w < d->in_w &&
+           (size_t)d->batch * d->in_h * d->in_w * d->c0 * 4 < (size_t)GATHER_OOB && (size_t)P * d->out_c * 4 < (size_t)GATHER_OOB;     // 32-bit byte offsets
+    if (!w.ok) return w;
+    w.swap = d->c0 > d->out_c;                                     // the wider operand takes the 256-channel side of the tile
+    const int CA = w.swap ? d->c0 : d->out_c, CB = w.swap ? d->out_c : d->c0;
+    w.tb = CB > 64 ? 2 : 1;                                        // B side: 128 channels, or 64 (two blocks per CU)
+    w.tiles = cdiv(CA, 256) * cdiv(CB, 64 * w.tb);
+    // one balanced round: ~256 blocks (512 for the 64-channel form), >= 4 K-steps of 32 pixels each
+    const int s = std::max(1, std::min((w.tb == 1 ? 512 : 256) / w.tiles, P / 128));
+    w.pps = (int)align_up((size_t)cdiv(P, s), 32);
+    w.splits = cdiv(P, w.pps);
+    return w;
+}
+
 // sum the split slabs and scatter into the OIHW gradient: dw[co][ci][ky][kx] (+= if accumulate).
 // The slabs are [split][co][tap][ci] with ci padded to a multiple of 16: a thread owns four neighbouring ci of one (co, tap) and
 // every SG-th slab (16-byte loads, four in flight), the SG partial sums of a column meet in LDS in a fixed order -- the layers
@@ -3963,6 +4117,7 @@ static int check_conv(const codeps_conv_desc* d, const char* who) {
 
 // name of the kernel variant the last conv entry point launched (tests select variants by shape and check it)
 static const char* volatile g_last_kernel = "";      // process-wide on purpose: autograd runs backward launches on its own thread
+static const char* volatile g_last_finish = "";      // the finish pass of the last launch that was cut into K slices
 
 static ConvP make_convp(const codeps_conv_desc* d) {
     ConvP p;
@@ -3980,24 +4135,39 @@ struct EpiOut { int applied, n_seg, tile0[4], tpi[4], rows[4], tiles[4]; };
 static thread_local EpiOut g_epi;
 
 // Called by every launch site once the tile shape and the K split are known.  Statistics and the BatchNorm gate need every M tile
-// inside one image and no K slices; when that fails they are dropped together (the caller then runs the separate kernels on an
-// UNGATED result: applied bit 0 stays clear).  Plain activation gates (1 / 2) survive split-K (splitk_finish_kernel applies them).
+// inside one image; when that fails they are dropped together (the caller then runs the separate kernels on an UNGATED result:
+// applied bit 0 stays clear).  With K slices the extras move into the finish pass (splitk_finish_ex_kernel; plain activation gates
+// without statistics: splitk_finish_kernel).
+constexpr int FIN_ROWS = 64;
 static bool epi_plan(ConvP& p, int tile_rows, bool supported = true) {
+    p.ex_fin = 0;
     if (!p.ex_gate_act && !p.ex_stat) return false;
-    if (!supported) { p.ex_gate = nullptr; p.ex_gate_act = 0; p.ex_stat = 0; return false; }     // (a kernel form without the EX instantiation)
     const bool bn = p.ex_gate_act == 3;
-    bool ok = p.ksplit <= 1;
-    if (ok && (bn || p.ex_stat == 1) && (p.ex_img_rows <= 0 || p.ex_img_rows % tile_rows != 0)) ok = false;
-    if (!ok) {
-        if (bn) { p.ex_gate = nullptr; p.ex_gate_act = 0; }
-        p.ex_stat = 0;
+    int n_tiles = p.n_mt;
+    if (p.ksplit > 1) {
+        // K slices: the finish pass owns the epilogue.  Its extras form (splitk_finish_ex_kernel) works on 64-row tiles of the output
+        // whatever GEMM kernel wrote the slices; plain activation gates without statistics stay on the simple finish kernel
+        static const int fin_on = getenv("CODEPS_EPI_FINISH") ? atoi(getenv("CODEPS_EPI_FINISH")) : 1;      // A/B switch
+        tile_rows = FIN_ROWS; n_tiles = cdiv(p.M, FIN_ROWS);
+        const bool ok = fin_on && !p.par && p.N % 64 == 0 && (!(bn || p.ex_stat == 1) || (p.ex_img_rows > 0 && p.ex_img_rows % FIN_ROWS == 0));
+        if (!ok) {
+            if (bn) { p.ex_gate = nullptr; p.ex_gate_act = 0; }
+            p.ex_stat = 0;
+        }
+        p.ex_fin = (bn || p.ex_stat) ? 1 : 0;
+    } else {
+        if (!supported) { p.ex_gate = nullptr; p.ex_gate_act = 0; p.ex_stat = 0; return false; }     // (a kernel form without the EX instantiation)
+        if ((bn || p.ex_stat == 1) && (p.ex_img_rows <= 0 || p.ex_img_rows % tile_rows != 0)) {
+            if (bn) { p.ex_gate = nullptr; p.ex_gate_act = 0; }
+            p.ex_stat = 0;
+        }
     }
     if (p.ex_gate_act) g_epi.applied |= 1;
     if (p.ex_stat) {
         g_epi.applied |= 2;
         for (int c = 0; c < (p.par == 2 ? 4 : 1) && g_epi.n_seg < 4; ++c) {          // (all parity classes in one launch: one segment each)
             const int k = g_epi.n_seg++;
-            g_epi.tile0[k] = p.ex_tile0 + c * p.n_mt; g_epi.rows[k] = tile_rows; g_epi.tiles[k] = p.n_mt;
+            g_epi.tile0[k] = p.ex_tile0 + c * n_tiles; g_epi.rows[k] = tile_rows; g_epi.tiles[k] = n_tiles;
             g_epi.tpi[k] = p.ex_img_rows > 0 ? p.ex_img_rows / tile_rows : 0;
         }
     }
@@ -4057,6 +4227,72 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     }
 }
 
+// The same finish with the epilogue extras (ConvP.ex_*: gates 1-3, statistics 1-3): block = 64 rows x 64 columns of the output (small-M
+// layers: M / 64 x N / 64 blocks fill the chip where 256-column blocks left half of it idle -- 28 us per launch against 9), a thread
+// owns one column quad and every 16th row (epi_begin / epi_apply / epi_flush as in the GEMM kernels' epilogues), so the per-tile
+// partial statistics come out in the layout codeps_bn_finalize_tiles / codeps_bn_bwd_tiles / codeps_colsum_finish read.
+constexpr int FIN_COLS = 64;
+__global__ __launch_bounds__(256) void splitk_finish_ex_kernel(ConvP p, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ residual, int act, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float red[2 * 256 * 4];
+    constexpr int V4 = FIN_COLS / 4, RPASS = 256 / V4, NR = FIN_ROWS / RPASS;
+    const int tid = threadIdx.x, c4 = tid % V4, k = tid / V4;
+    const int tile = blockIdx.x, n = blockIdx.y * FIN_COLS + c4 * 4;          // (N is a multiple of 64: epi_plan)
+    const long long MN = (long long)p.M * p.N;
+    const int m0 = tile * FIN_ROWS;
+    EpiCtx ec;
+    epi_begin(p, ec, p.ex_img_rows ? m0 / p.ex_img_rows : 0, n);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+    f32x4 v[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int m = m0 + k + u * RPASS;
+        v[u] = m < p.M ? *reinterpret_cast<const f32x4*>(p.part + (size_t)m * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int z = 1; z < p.ksplit; ++z)
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int m = m0 + k + u * RPASS;
+            if (m < p.M) v[u] += *reinterpret_cast<const f32x4*>(p.part + (size_t)z * MN + (size_t)m * p.N + n);
+        }
+    if (p.ex_stat == 1) {                                  // the tile's first row = the statistics' shift
+        const size_t i0 = (size_t)m0 * p.N + n;
+        f32x4 f = *reinterpret_cast<const f32x4*>(p.part + i0);
+        for (int z = 1; z < p.ksplit; ++z) f += *reinterpret_cast<const f32x4*>(p.part + (size_t)z * MN + i0);
+        ec.sh = f * sc + sh;
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int m = m0 + k + u * RPASS;
+        if (m >= p.M) continue;
+        const size_t i = (size_t)m * p.N + n;
+        f32x4 r = v[u];
+        if (scale) r = r * sc;
+        if (shift) r += sh;
+        if (residual) r += *reinterpret_cast<const f32x4*>(residual + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = apply_act(r[e], act);
+        *reinterpret_cast<f32x4*>(out + i) = epi_apply(p, ec, r, i);
+    }
+    epi_flush(p, ec, red, tid, V4, RPASS, tile, n);
+}
+
+template <int MODE>
+static void launch_splitk_finish(const ConvP& p, hipStream_t st, const float* scale, const float* shift, const float* residual, float* out) {
+    const long long MN = (long long)p.M * p.N;
+    const float* sc = MODE == MODE_FWD ? scale : nullptr;
+    const float* sh = MODE == MODE_FWD ? shift : nullptr;
+    const int act = MODE == MODE_FWD ? p.act : 0;
+    g_last_finish = p.ex_fin ? "splitk_finish_ex_kernel" : "splitk_finish_kernel";
+    if (p.ex_fin)
+        hipLaunchKernelGGL(splitk_finish_ex_kernel, dim3(cdiv(p.M, FIN_ROWS), p.N / FIN_COLS), dim3(256), 0, st, p, sc, sh, residual, act, out);
+    else
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
+                           p.N, sc, sh, residual, act, out, p.ex_gate, p.ex_gate_act);
+}
+
 // 3x3 / stride 1 / zero padding layers the halo-tile kernels take (forward: also the decoder's concat + fused nearest-x2 input)
 template <int MODE>
 static bool halo3_shape_ok(const ConvP& p) {
@@ -4107,12 +4343,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                     g_last_kernel = halo_ws ? (p.ksplit > 1 ? "conv_halo3p_kernel<splitk>" : "conv_halo3p_kernel")
                                             : (p.ksplit > 1 ? "conv_halo3r_kernel<splitk>" : "conv_halo3r_kernel");
                     hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(halo_ws ? 384 : 256), lds_r, st, p, a0, a1, scale, shift, residual, out);
-                    if (p.ksplit > 1) {
-                        const long long MN = (long long)p.M * p.N;
-                        hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
-                                           p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
-                                           MODE == MODE_FWD ? p.act : 0, out, p.ex_gate, p.ex_gate_act);
-                    }
+                    if (p.ksplit > 1) launch_splitk_finish<MODE>(p, st, scale, shift, residual, out);
                     return;
                 }
             }
@@ -4140,12 +4371,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             codeps_allow_lds((const void*)kw, 160 * 1024, "kw");
             g_last_kernel = "conv_igemm_ws_kernel";
             hipLaunchKernelGGL(kw, dim3(blocks_, p.ksplit, p.par == 2 ? 4 : 1), dim3(512), lds_ws, st, p, a0, a1, scale, shift, residual, out);
-            if (p.ksplit > 1) {
-                const long long MN = (long long)p.M * p.N;
-                hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
-                                   p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
-                                   MODE == MODE_FWD ? p.act : 0, out, p.ex_gate, p.ex_gate_act);
-            }
+            if (p.ksplit > 1) launch_splitk_finish<MODE>(p, st, scale, shift, residual, out);
             return;
         }
     }
@@ -4180,12 +4406,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     codeps_allow_lds((const void*)k, 160 * 1024, "k");
     g_last_kernel = NP == 3 ? (BK == 16 ? "conv_igemm_kernel<split3,bk16>" : "conv_igemm_kernel<split3>") : (NP == 2 ? "conv_igemm_kernel<split2>" : "conv_igemm_kernel<f32>");
     hipLaunchKernelGGL(k, dim3(blocks, p.ksplit, p.par == 2 ? 4 : 1), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
-    if (p.ksplit > 1) {
-        const long long MN = (long long)p.M * p.N;
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, p.part, p.ksplit, MN,
-                           p.N, MODE == MODE_FWD ? scale : nullptr, MODE == MODE_FWD ? shift : nullptr, residual,
-                           MODE == MODE_FWD ? p.act : 0, out, p.ex_gate, p.ex_gate_act);
-    }
+    if (p.ksplit > 1) launch_splitk_finish<MODE>(p, st, scale, shift, residual, out);
 }
 
 // Tile choice: estimated time ~ waves of blocks over the 256 CUs x tile area x a small-tile inefficiency factor.
@@ -4416,6 +4637,7 @@ static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
         if (split_np != 3 || !wgrad_split_on()) return 0;
         if (wgrad_s2_plan(d).ok) return 3;                                             // stride-2 halo-tile kernel
         const SmallPlan sp = wgrad_small_plan(d);
+        if (!sp.ok && wgrad_1x1_plan(d).ok) return 3;                                  // 1 x 1: wgrad_1x1s_kernel
         return (sp.ok && (sp.halo64 || (sp.stem && sp.co_groups == 1))) ? 3 : 0;       // halo-tile kernel / split stem kernel
     }
     const int n = source ? d->c1 : d->c0;
@@ -4648,12 +4870,15 @@ extern "C" size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d)
     if (s2.ok) return (size_t)s2.splits * d->out_c * d->c0 * 9 * sizeof(float);
     const SmallPlan sp = wgrad_small_plan(d);
     if (sp.ok) return (size_t)sp.splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
+    const W1Plan w1 = wgrad_1x1_plan(d);
+    if (w1.ok) return (size_t)w1.splits * d->out_c * d->c0 * sizeof(float);
     int bm, bn, n_mt, n_nt, splits, pps;
     wgrad_plan(d, bm, bn, n_mt, n_nt, splits, pps);
     return (size_t)splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
 }
 
 extern "C" const char* codeps_conv2d_last_kernel(void) { return g_last_kernel; }
+extern "C" const char* codeps_conv2d_last_finish_kernel(void) { return g_last_finish; }
 
 extern "C" int codeps_conv2d_set_halo_ws(int on) {
     const int prev = halo_ws_on();
@@ -4683,6 +4908,8 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     if (sp.ok) splits = sp.splits;
     const S2Plan s2 = wgrad_s2_plan(d);
     if (s2.ok) splits = s2.splits;
+    const W1Plan w1 = (sp.ok || s2.ok) ? W1Plan{} : wgrad_1x1_plan(d);
+    if (w1.ok) { splits = w1.splits; pps = w1.pps; }
     const size_t need = (size_t)splits * d->out_c * (d->c0 + d->c1) * d->kh * d->kw * sizeof(float);
     CODEPS_REQUIRE(workspace_bytes >= need, CODEPS_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", workspace_bytes, need);
     WgradP p;
@@ -4761,6 +4988,18 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
         const long long total = (long long)d->out_c * (d->c0 + d->c1) * d->kh * d->kw;
         (void)total;
         launch_wgrad_reduce(part, splits, d->out_c, d->c0 + d->c1, d->kh * d->kw, out_c_real, in_c_real, dw_oihw, accumulate, st);
+        CODEPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+        return CODEPS_OK;
+    }
+    if (w1.ok) {
+        const size_t lds = (size_t)(256 + 64 * w1.tb) * (3 * 32 + 8) * 2;
+        g_last_kernel = "wgrad_1x1s_kernel";
+        auto k1 = w1.tb == 2 ? (w1.swap ? wgrad_1x1s_kernel<true, 2> : wgrad_1x1s_kernel<false, 2>)
+                             : (w1.swap ? wgrad_1x1s_kernel<true, 1> : wgrad_1x1s_kernel<false, 1>);
+        codeps_allow_lds((const void*)k1, 160 * 1024, "wgrad_1x1s_kernel");
+        hipLaunchKernelGGL(k1, dim3(w1.splits, w1.tiles), dim3(256), lds, st, p, x0, dz, part);
+        CODEPS_CHECK_LAUNCH("wgrad_1x1s_kernel");
+        launch_wgrad_reduce(part, splits, d->out_c, d->c0, 1, out_c_real, in_c_real, dw_oihw, accumulate, st);
         CODEPS_CHECK_LAUNCH("wgrad_reduce_kernel");
         return CODEPS_OK;
     }

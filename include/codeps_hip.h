@@ -118,6 +118,9 @@ int codeps_conv2d_arith(const codeps_conv_desc* d, int mode, int source);
 /* Name of the kernel variant the last conv2d_{fwd,dgrad,wgrad} call of this PROCESS launched (diagnostics / tests; not
  * synchronised: meaningful when one thread at a time drives the library, e.g. forward, then backward, then the query). */
 const char* codeps_conv2d_last_kernel(void);
+/* Name of the finish pass of the last conv2d_{fwd,dgrad} launch that was cut into K slices: "splitk_finish_kernel", or
+ * "splitk_finish_ex_kernel" when the epilogue extras (codeps_conv_epilogue) ran there ("" before any such launch). */
+const char* codeps_conv2d_last_finish_kernel(void);
 /* Process-wide operand arithmetic of the conv engine: 3 (default; CODEPS_SPLIT) = fp32 operands as three exact bf16 pieces on
  * the bf16 MFMA, 0 = v_mfma_f32_32x32x2_f32, 2 = two pieces (experiments; outside the parity bar).  Returns the previous value;
  * any other argument only queries.  Weight packs made under one arithmetic stay valid under the others (they carry both forms). */

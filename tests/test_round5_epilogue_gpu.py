@@ -362,3 +362,111 @@ def test_stem_statistics_from_the_halo_kernel_epilogue(groups):
         zz = z.double().reshape(-1, 64)
         assert torch.allclose(mean[0].double(), zz.mean(0), rtol=1e-5, atol=1e-7)
         assert torch.allclose(var[0].double(), zz.var(0, unbiased=False), rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 512, 512, 3, True), (4, 32, 64, 1024, 256, 1, False), (4, 16, 32, 2048, 512, 1, True)])
+def test_extras_ride_in_the_split_k_finish(case):
+    """Small-M, deep-K layers (ResNet-50/101 layer3 / layer4 of the pre-training configurations, models/resnet_encoder.py:115-126) are cut
+    into K slices; their epilogue extras then run in the finish pass (splitk_finish_ex_kernel, 64-row tiles): forward statistics against
+    float64 statistics of the output, output bit-identical to the launch without extras; BatchNorm + ReLU gate of an exclusive
+    consumer's data gradient: the hand-off carries (sum g, sum g xhat) partials, gradients against the separate passes."""
+    import ctypes
+    from codeps_amd._lib import lib
+    F = _F()
+    b, h, w, ci, co, k, dgrad_sliced = case               # (case 1: the consumer's K = 256 is too short for K slices -- its own epilogue gates)
+    lib().codeps_conv2d_last_finish_kernel.restype = ctypes.c_char_p
+    g = torch.Generator().manual_seed(ci + co)
+    x = _nhwc(g, b, h, w, ci)
+    w0 = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(DEV).requires_grad_()
+    y0 = F.conv2d(x, w0, None, pad=k // 2)
+    y = F.conv2d(x, w0, None, pad=k // 2, bn_stats=True)
+    assert lib().codeps_conv2d_last_finish_kernel().decode() == "splitk_finish_ex_kernel"
+    st = y._codeps_stats
+    assert st is not None and st["rows"] == 64 and torch.equal(y, y0)
+    mean = torch.empty(1, co, device=DEV)
+    var, inv = torch.empty_like(mean), torch.empty_like(mean)
+    ngi, gb0, gb1 = F._img_groups([(0, b)])
+    F.check(lib().codeps_bn_finalize_tiles(F.ptr(st["part"]), st["tile0"], st["tpi"], st["rows"], ngi, gb0, gb1, co, 1e-5, F.ptr(mean), F.ptr(var),
+                                           F.ptr(inv), F.stream_ptr()), "finalize")
+    yy = y.detach().double().reshape(-1, co)
+    assert torch.allclose(mean[0].double(), yy.mean(0), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(var[0].double(), yy.var(0, unbiased=False), rtol=1e-5)
+    # BatchNorm + ReLU behind it, an exclusive consumer of the same depth: its data gradient is cut into K slices too
+    w1 = (torch.randn(co, co, k, k, generator=g) / (co * k * k) ** 0.5).to(DEV).requires_grad_()
+    res = {}
+    for mode in ("separate", "fused"):
+        F._EPI = mode == "fused"
+        try:
+            gamma, beta = torch.full((co,), 1.2, device=DEV).requires_grad_(), torch.full((co,), 0.1, device=DEV).requires_grad_()
+            rm, rv = torch.zeros(co, device=DEV), torch.ones(co, device=DEV)
+            xi = x.clone().requires_grad_()
+            z = F.batch_norm_train(F.conv2d(xi, w0, None, pad=k // 2, bn_stats=True), gamma, beta, rm, rv, act="relu")
+            o = F.conv2d(z, w1, None, pad=k // 2, exclusive=True)
+            gy = torch.randn(o.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+            seen = {}
+            orig = F._Gate.take
+
+            def spy(self, dy, _o=orig, _s=seen):
+                if self.kind == "bn":
+                    _s["parts"] = self.handoff is not None and self.handoff["part"] is not None
+                    _s["rows"] = self.handoff["segs"][0][2] if _s["parts"] else 0
+                    _s["finish"] = lib().codeps_conv2d_last_finish_kernel().decode()
+                return _o(self, dy)
+            F._Gate.take = spy
+            try:
+                res[mode] = torch.autograd.grad(o, [xi, w0, w1, gamma, beta], gy)
+            finally:
+                F._Gate.take = orig
+            if mode == "fused":
+                assert seen.get("parts") is True and seen.get("finish") == "splitk_finish_ex_kernel", seen
+                assert (seen["rows"] == 64) == dgrad_sliced or seen["rows"] == 64, seen
+        finally:
+            F._EPI = True
+    rel = lambda a, r: float((a.double() - r.double()).norm() / (r.double().norm() + 1e-30))      # noqa: E731
+    for i, (a, r) in enumerate(zip(res["fused"], res["separate"])):
+        assert rel(a, r) <= 5e-3, (i, rel(a, r))           # (statistics in another summation order: a ReLU at ~0 may flip)
+
+
+@pytest.mark.parametrize("case", [
+    # (batch, H, W, ci, co, stride): the bottleneck 1 x 1 convolutions of the pre-training configurations (models/resnet_encoder.py:115-126)
+    (4, 128, 256, 64, 256, 1), (4, 128, 256, 256, 64, 1), (4, 32, 64, 1024, 256, 1), (4, 16, 32, 512, 2048, 1),
+    (4, 64, 128, 256, 512, 2),              # a down-sampling shortcut (stride 2)
+    (3, 30, 44, 96, 80, 1), (2, 33, 47, 72, 200, 2), (2, 24, 40, 320, 136, 1),      # ragged: channels that fill no tile, pixel counts that fill no K-step
+])
+def test_weight_gradient_of_1x1_convolutions_on_the_split_arithmetic(case):
+    """`wgrad_1x1s_kernel` (3-piece bf16 operands, pixels as the GEMM's K) against float64: within 3 x torch's own fp32 error, bit-identical
+    from launch to launch, and the kernel is the one that ran."""
+    import ctypes
+    import torch.nn.functional as TF
+    from codeps_amd._lib import lib
+    F = _F()
+    b, h, w, ci, co, stride = case
+    g = torch.Generator().manual_seed(ci + co + h)
+    x = torch.relu(torch.randn(b, ci, h, w, generator=g))
+    wt = torch.randn(co, ci, 1, 1, generator=g) * (2.0 / ci) ** 0.5
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    gy = torch.randn(b, co, ho, wo, generator=g)
+
+    def ref(dtype):
+        ww = wt.to(dtype).requires_grad_(True)
+        TF.conv2d(x.to(dtype), ww, stride=stride).backward(gy.to(dtype))
+        return ww.grad
+
+    dw64, dw32 = ref(torch.float64), ref(torch.float32)
+    lib().codeps_conv2d_last_kernel.restype = ctypes.c_char_p
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    if xn.shape[-1] % 16:
+        xn = torch.nn.functional.pad(xn, (0, 16 - xn.shape[-1] % 16))
+    outs = []
+    for _ in range(3):
+        ww = wt.to(DEV).detach().requires_grad_(True)
+        y = F.conv2d(xn, ww, None, stride=stride)
+        gyn = torch.zeros_like(y)
+        gyn[..., :co] = gy.permute(0, 2, 3, 1).to(DEV)
+        y.backward(gyn)
+        assert lib().codeps_conv2d_last_kernel().decode() == "wgrad_1x1s_kernel"
+        outs.append(ww.grad.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
+    e, t = l2(outs[0], dw64), l2(dw32, dw64)
+    assert e <= 3 * t + 1e-9, f"{case}: {e:.3e} vs torch fp32 {t:.3e}"

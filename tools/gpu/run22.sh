@@ -1,16 +1,13 @@
 #!/bin/bash
+# round 5: epilogue extras in the split-K finish -- tests + A/B on the pre-training configuration and the headline step
 mkdir -p gpurun_out/r5
-python -m pytest tests -m gpu -q -x > gpurun_out/r5/t_all.log 2>&1
-echo "all tests rc=$?"; tail -4 gpurun_out/r5/t_all.log
-b() { python bench.py $2 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-secondary 2>/dev/null | grep '^{"metric"' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d.get('step_ms'))"; }
+python -m pytest tests/test_round5_epilogue_gpu.py tests/test_configs_gpu.py -x -q -m gpu > gpurun_out/r5/t22.log 2>&1
+echo "tests rc=$?"; tail -5 gpurun_out/r5/t22.log
 for i in 1 2; do
-  CODEPS_PARITY_MERGE=0 b "adapt merge0" ""
-  b "adapt merge1" ""
-  CODEPS_EPILOGUE=0 b "adapt epi0  " ""
+  for s in 1 0; do
+    CODEPS_EPI_FINISH=$s python bench.py --mode train --steps 12 --warmup 4 --no-secondary --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('pretrain fin=$s', d['value'], d['ms_per_step'])"
+  done
 done
-b "pretrain    " "--mode train"
-CODEPS_EPILOGUE=0 b "pretrain epi0" "--mode train"
-CODEPS_EPI_BN=0 b "pretrain bn0 " "--mode train"
-b "pretrain    " "--mode train"
-CODEPS_EPILOGUE=0 b "pretrain epi0" "--mode train"
-CODEPS_EPI_BN=0 b "pretrain bn0 " "--mode train"
+for s in 1 0; do
+  CODEPS_EPI_FINISH=$s python bench.py --steps 30 --warmup 8 --no-secondary --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('adapt fin=$s', d['value'], d['ms_per_step'])"
+done

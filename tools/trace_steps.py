@@ -25,7 +25,7 @@ def short(name):
 
 def main():
     d = sys.argv[1]
-    groups = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    groups = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 2
     rows = []
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
@@ -50,7 +50,18 @@ def main():
         out.append({"step": i, "launches": len(st), "kernel_busy_ms": round(busy / 1e6, 3), "span_ms": round(span / 1e6, 3),
                     "pack_weights_kernel": names.get("pack_weights_kernel", 0), "split_pack_kernel": names.get("split_pack_kernel", 0),
                     "library_launches": sum(foreign.values()), "library_busy_ms": round(foreign_ms, 3), "library_kernels": dict(sorted(foreign.items(), key=lambda kv: -kv[1])[:12])})
-    print(json.dumps({"steps": out}, indent=1))
+    res = {"steps": out}
+    if "--hist" in sys.argv and len(steps) > 2:
+        # every kernel of ONE steady step (the middle one): launches and busy time per kernel name
+        st = steps[len(steps) // 2]
+        hist = {}
+        for r in st:
+            e = hist.setdefault(short(r["Kernel_Name"]), [0, 0])
+            e[0] += 1
+            e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        res["kernels_of_step"] = {"step": len(steps) // 2, "by_kernel": {k: {"launches": v[0], "busy_us": round(v[1] / 1e3, 1)}
+                                                                          for k, v in sorted(hist.items(), key=lambda kv: -kv[1][1])}}
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
