@@ -400,7 +400,8 @@ extern "C" int codeps_panoptic_fusion_strided(const uint8_t* semantic, const flo
     hipLaunchKernelGGL(compact_kernel, dim3(nchunk, batch), dim3(256), 0, st, HW, nchunk, (const uint8_t*)flag, (const int*)counts, cand, CAND_CAP);
     hipLaunchKernelGGL(select_kernel, dim3(batch), dim3(1024), 0, st, p, nchunk, center, (const uint8_t*)flag, counts, state, centers, (const int*)cand,
                        CAND_CAP);
-    hipLaunchKernelGGL(group_kernel, dim3(std::min(gx, 256), batch), dim3(256), 0, st, p, semantic, offset, (const int*)state, (const int*)centers,
+    // (four blocks per CU -- what the 34 KB of LDS per block allow: the centre loop is a dependent compare chain, one wave per SIMD leaves it exposed)
+    hipLaunchKernelGGL(group_kernel, dim3(std::min(gx, 1024), batch), dim3(256), 0, st, p, semantic, offset, (const int*)state, (const int*)centers,
                        instance, hist);
     hipLaunchKernelGGL(assign_kernel, dim3(batch), dim3(MAXC), 0, st, p, (const int*)state, (const int*)hist, idmap);
     hipLaunchKernelGGL(paste_kernel, dim3(gx, batch), dim3(256), 0, st, p, semantic, (const uint8_t*)instance, (const int*)idmap, panoptic, instance_i64);

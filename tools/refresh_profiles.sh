@@ -12,7 +12,7 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | line > $OUT/${R}_b
 # 2. rocprofv3 kernel stats of the same command (shorter; no CPU baseline)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o r -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>&1
 cp $(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${R}_adapt_step_kernel_stats.csv
-python3 tools/trace_steps.py gpurun_out/prof_stats > $OUT/${R}_step_trace_graph.json 2>/dev/null
+python3 tools/trace_steps.py gpurun_out/prof_stats 2 --hist > $OUT/${R}_step_trace_graph.json 2>/dev/null
 rm -rf gpurun_out/prof_stats
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_eager -o r -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary --graph 0 > /dev/null 2>&1
 python3 tools/trace_steps.py gpurun_out/prof_eager > $OUT/${R}_step_trace_eager.json 2>/dev/null
