@@ -51,10 +51,12 @@ def test_counters_add():
 
 
 @pytest.mark.parametrize("shape", [(4, 32, 64, 64, 64, 3, 1), (2, 32, 64, 256, 256, 3, 1), (3, 32, 64, 64, 128, 3, 2), (3, 32, 64, 64, 128, 1, 2),
-                                   (2, 16, 32, 256, 64, 1, 1), (1, 32, 64, 32, 16, 3, 1)])
+                                   (2, 16, 32, 256, 64, 1, 1), (1, 32, 64, 32, 16, 3, 1),
+                                   (1, 16, 32, 512, 512, 3, 1), (2, 16, 32, 512, 2048, 1, 1)])      # cut into K slices: the finish pass adds
 def test_forked_conv_gradient_equals_autograd_sum(shape):
     """y, x' = conv2d(x, fork=True); the gradient arriving through x' is added inside the data-gradient kernel: same bits as autograd's
-    own sum of the two gradients (one fp32 add per element either way), for the halo, generic, stride-2 parity-class and 16-column kernels."""
+    own sum of the two gradients (one fp32 add per element either way), for the halo, generic, stride-2 parity-class and 16-column kernels
+    and for launches cut into K slices (the finish pass adds)."""
     F = _F()
     b, h, w, ci, co, k, st = shape
     g = torch.Generator().manual_seed(ci + co + k)
@@ -75,6 +77,11 @@ def test_forked_conv_gradient_equals_autograd_sum(shape):
         grads.append(xx.grad.clone())
     torch.cuda.synchronize()
     assert torch.equal(grads[0], grads[1]), f"max |diff| {(grads[0] - grads[1]).abs().max().item():.3e}"
+    if b * h * w <= 1024 and co >= 512:
+        import ctypes
+        from codeps_amd._lib import lib
+        lib().codeps_conv2d_last_finish_kernel.restype = ctypes.c_char_p
+        assert lib().codeps_conv2d_last_finish_kernel().decode().startswith("splitk_finish")
 
 
 def test_panoptic_fusion_reads_strided_maps_in_place():
