@@ -1749,6 +1749,191 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
     }
 }
 
+// ---------------------------------------------------------------------------------- 3x3 layers of 16 / 32 channels, split arithmetic
+// The full-resolution tail of the depth decoder (models/depth_head.py:60-71: 32 -> 16 and 16 -> 16 at 256 x 512 and 512 x 1024) ran on
+// the f32 MFMA in conv_igemm16_kernel / conv_igemm_kernel<f32>: 45-68 TFLOP/s of 157 and 0.8-2.1 TB/s -- neither roof.  With 16
+// channels a K-step of v_mfma_f32_16x16x32_bf16 is TWO TAPS x 16 channels (k group kg of a lane: tap 2 s + (kg >> 1), channels
+// 8 (kg & 1) ..): five steps for the nine taps, the tenth half-step against zero weights.  The A fragment of a lane is then 8
+// consecutive channels of ITS pixel shifted by ITS tap -- an aligned 16-byte read at a per-lane address of the halo tile, which is split
+// into the three bf16 pieces once for all nine taps ([pixel][piece][16 channels], 112-byte pitch).  The weights (<= 32 x 9 x 32
+// floats) never touch LDS: every lane builds its B fragments from the fp32 pack once per block (persistent over its tiles) and keeps
+// them in registers (60 per 16 x 16 channel block).  Block = 8 x 32 output pixels, wave = two rows = four 16-pixel row tiles; the next
+// tile's loads are in flight under the MFMAs; the epilogue goes through LDS so that stores are 16 bytes per lane and the epilogue extras
+// (gates 1 / 2, column sums) are the common code.  MODE_DGRAD: the same kernel on the [ci][tap][co] pack with mirrored tap geometry.
+template <int MODE, int NT, int KH, bool EX = false>
+__global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(ConvP p, int tiles_x, int tiles_y, int tiles_per_block, const float* __restrict__ x,
+                                                                const float* __restrict__ wq, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ residual,
+                                                                float* __restrict__ out) {
+    constexpr int TH = 8, TW = 32, XH = TH + 2, XW = TW + 2, PIT = 56, CI = 16 * KH, CO = 16 * NT;
+    constexpr int NTASK = XH * XW * (CI / 4), NRAW = (NTASK + 255) / 256;
+    constexpr int LDC = CO + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    unsigned short* Xs = lds16;                                   // [KH][XH * XW][PIT]
+    float* Cs = reinterpret_cast<float*>(lds16);                  // [256][LDC] (epilogue: aliases the activation tile)
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hm = (MODE == MODE_FWD) ? p.Ho : p.H, Wm = (MODE == MODE_FWD) ? p.Wo : p.W;      // (= the input's size: stride 1, pad 1)
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blockIdx.x * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    const size_t ximg = (size_t)Hm * Wm * CI;
+
+    // ---- B fragments from the fp32 pack (row n: [tap][CI]); lane = (column l16, k group kg): tap 2 s + (kg >> 1), channels 8 (kg & 1) ..
+    bf16x8 bfr[NT][KH][5][3];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int hf = 0; hf < KH; ++hf)
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+                const int tap = 2 * st + (kg >> 1);
+                f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+                if (tap < 9) {
+                    const float* wp = wq + ((size_t)(j * 16 + l16) * 9 + tap) * CI + hf * 16 + (kg & 1) * 8;
+                    w0 = *reinterpret_cast<const f32x4*>(wp);
+                    w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+                }
+                u16x4 p0[3], p1[3];
+                split_bf16<3>(w0, p0);
+                split_bf16<3>(w1, p1);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bfr[j][hf][st][q] = __builtin_bit_cast(bf16x8, pack8(p0[q], p1[q]));
+            }
+    // ---- A fragment offsets (halfwords) of this lane's tap per K-step: forward pixel + (ky, kx), data gradient pixel + (2 - ky, 2 - kx)
+    int aoff[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int tap = min(2 * st + (kg >> 1), 8);                // (the tenth half-step multiplies zero weights: any valid address)
+        const int ky = tap / 3, kx = tap % 3;
+        const int gy = (MODE == MODE_FWD) ? ky : 2 - ky, gx = (MODE == MODE_FWD) ? kx : 2 - kx;
+        aoff[st] = (gy * XW + gx) * PIT + (kg & 1) * 8;
+    }
+
+    // ---- staging tasks: (halo pixel pc, channel quad c4); thread tid owns tasks tid + 256 k
+    int t_off[NRAW], t_rc[NRAW], t_dst[NRAW];                       // t_rc: halo row << 8 | halo column (one register: this kernel is at its register limit)
+#pragma unroll
+    for (int k = 0; k < NRAW; ++k) {
+        const int t = tid + 256 * k, c4 = t % (CI / 4), pc = t / (CI / 4), c = pc % XW, r = pc / XW;
+        t_rc[k] = ((t < NTASK ? r : 1 << 20) << 8) | c;            // (a row no image has)
+        t_off[k] = ((r * Wm + c) * CI + c4 * 4) * 4;
+        t_dst[k] = (c4 / 4) * (XH * XW * PIT) + pc * PIT + (c4 % 4) * 4;
+    }
+    f32x4 raw[NRAW];
+    auto load_x = [&](int tile, bool valid) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);             // (scalar)
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(x + (size_t)b * ximg, ximg * 4);
+        const int iy0 = ty0 - 1, ix0 = tx0 - 1, org = (iy0 * Wm + ix0) * CI * 4;
+#pragma unroll
+        for (int k = 0; k < NRAW; ++k) {
+            const bool ok = valid && (unsigned)(iy0 + (t_rc[k] >> 8)) < (unsigned)Hm && (unsigned)(ix0 + (t_rc[k] & 255)) < (unsigned)Wm;
+            const unsigned vo = ok ? (unsigned)(org + t_off[k]) : GATHER_OOB;
+            raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int k = 0; k < NRAW; ++k) {
+            if (tid + 256 * k >= NTASK) continue;
+            u16x4 pc[3];
+            split_bf16<3>(raw[k], pc);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u16x4*>(Xs + t_dst[k] + q * 16) = pc[q];
+        }
+    };
+
+    // epilogue roles: thread = (column quad c4e, row r0e + RPASS k)
+    constexpr int V4 = CO / 4, RPASS = 256 / V4, NROW = 256 / RPASS;
+    const int c4e = tid % V4, r0e = tid / V4, n = c4e * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_FWD && n < p.N) {
+        if (scale) sc = *reinterpret_cast<const f32x4*>(scale + n);
+        if (shift) sh = *reinterpret_cast<const f32x4*>(shift + n);
+    }
+
+    if (t_beg < t_end) load_x(t_beg, true);
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        __syncthreads();                                            // the previous tile's epilogue has read Cs
+        store_x();
+        __syncthreads();
+        load_x(min(tile + 1, t_end - 1), tile + 1 < t_end);         // in flight under the MFMAs and the epilogue
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hf = 0; hf < KH; ++hf)
+#pragma unroll
+            for (int st = 0; st < 5; ++st)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int base = ((2 * wave + (m >> 1)) * XW + (m & 1) * 16 + l16) * PIT + hf * (XH * XW * PIT) + aoff[st];
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(Xs + base + q * 16);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                            for (int qa = 0; qa <= ord; ++qa)
+                                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa], bfr[j][hf][st][ord - qa], acc[m][j], 0, 0, 0);
+                }
+        __syncthreads();                                            // every wave is done with the activation tile: Cs may overwrite it
+        // C layout of a 16 x 16 tile: column = l16, row = 4 kg + reg; tile row index = pixel (yy * 32 + xx) of the 8 x 32 tile
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cs[((2 * wave + (m >> 1)) * TW + (m & 1) * 16 + 4 * kg + r) * LDC + j * 16 + l16] = acc[m][j][r];
+        __syncthreads();
+        f32x4 colsum = {0.f, 0.f, 0.f, 0.f};                        // (extras of this kernel: gates 1 / 2 and statistics 2 only -- written out here:
+        if (n < p.N) {                                              //  the common EpiCtx keeps 28 registers live that this kernel does not have)
+#pragma unroll
+            for (int k = 0; k < NROW; ++k) {
+                const int rr = r0e + k * RPASS;                     // pixel of the tile
+                const size_t idx = (((size_t)b * Hm + ty0 + rr / TW) * Wm + tx0 + rr % TW) * p.N + n;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4e * 4);
+                if (MODE == MODE_FWD) {
+                    v = v * sc + sh;
+                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + idx);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                } else if (residual) {                              // data gradient + the gradient that reached the same tensor by another path
+                    v += *reinterpret_cast<const f32x4*>(residual + idx);
+                }
+                if constexpr (EX) {
+                    if (p.ex_gate_act) {                            // = epi_apply's gates 1 / 2
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(p.ex_gate + idx);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= g[e] > 0.f ? 1.f : (p.ex_gate_act == 2 ? g[e] + 1.f : 0.f);
+                    }
+                    colsum += v;
+                }
+                *reinterpret_cast<f32x4*>(out + idx) = v;
+            }
+        }
+        if constexpr (EX) {
+            if (p.ex_stat == 2) {                                   // = epi_flush for statistics 2: the tile's column sums, fixed order
+                f32x4* red = reinterpret_cast<f32x4*>(Cs + 256 * LDC);      // (behind the C tile: the activation tile's space, free until the next store_x)
+                __syncthreads();
+                red[tid] = colsum;
+                __syncthreads();
+                if (tid < V4 && n < p.N) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    for (int k = 0; k < RPASS; ++k) a += red[k * V4 + tid];
+                    *reinterpret_cast<f32x4*>(p.ex_part + (size_t)(p.ex_tile0 + tile) * p.N + n) = a;
+                }
+            }
+        }
+    }
+}
+
 template <int MODE, int BK, bool EX = false>
 __global__ __launch_bounds__(256) void conv_igemm16_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                            const float* __restrict__ wq, const float* __restrict__ scale,
@@ -4425,11 +4610,46 @@ static int pick_tile(const ConvP& p, const TileOpt* opts, int n, int nsteps) {
     return best;
 }
 
+// 3 x 3 / stride 1 / zero padding layers with 16 or 32 channels on either side (not 32 x 32: the 32-column halo kernel) on whole 8 x 32
+// tiles: conv_halo3n16_kernel
+template <int MODE>
+static bool halo3n16_ok(const ConvP& p) {
+    static const int on = getenv("CODEPS_HALO_N16") ? atoi(getenv("CODEPS_HALO_N16")) : 1;                // A/B switch
+    const int kc = (MODE == MODE_FWD) ? p.Ct : p.Co, Hm = (MODE == MODE_FWD) ? p.Ho : p.H, Wm = (MODE == MODE_FWD) ? p.Wo : p.W;
+    return on && split_pieces() == 3 && halo3_shape_ok<MODE>(p) && !p.up0 && p.C1 == 0 && p.pitch0 == 0 && Hm % 8 == 0 && (kc == 16 || kc == 32) &&
+           (p.N == 16 || p.N == 32) && !(kc == 32 && p.N == 32) && (size_t)Hm * Wm * 32 * 4 < (size_t)GATHER_OOB;
+}
+template <int MODE>
+static void launch_halo3n16(ConvP p, const float* a0, const float* wq, const float* scale, const float* shift, const float* residual, float* out,
+                            hipStream_t st) {
+    const int kc = (MODE == MODE_FWD) ? p.Ct : p.Co, Hm = (MODE == MODE_FWD) ? p.Ho : p.H, Wm = (MODE == MODE_FWD) ? p.Wo : p.W;
+    const int tiles_x = Wm / 32, tiles_y = Hm / 8, total = p.B * tiles_x * tiles_y;
+    const int nt = p.N / 16, kh = kc / 16;
+    // persistent blocks: the weights are fetched and split once per block.  Two per CU; one for the 32-channel-input form, whose 120
+    // registers of weight fragments + 44 of prefetched pixels spill at 256 registers
+    const int tpb = std::max(1, cdiv(total, kh == 2 ? 256 : 512));
+    p.n_mt = total; p.n_nt = 1; p.ksplit = 1;
+    // extras of this kernel: the activation gates and the column sums (the decoder tail has no BatchNorm)
+    const bool ex = epi_plan(p, 256, p.ex_gate_act != 3 && (p.ex_stat == 0 || p.ex_stat == 2));
+    const size_t lds_x = (size_t)kh * 340 * 56 * 2, lds_c = (size_t)256 * (p.N + 4) * 4 + 2 * 256 * 16;
+    const size_t lds = std::max(lds_x, lds_c);
+    g_last_kernel = "conv_halo3n16_kernel";
+#define N16_LAUNCH(NT_, KH_)                                                                                                   \
+    do {                                                                                                                       \
+        auto k = ex ? conv_halo3n16_kernel<MODE, NT_, KH_, true> : conv_halo3n16_kernel<MODE, NT_, KH_, false>;                 \
+        codeps_allow_lds((const void*)k, 160 * 1024, "conv_halo3n16_kernel");                                                   \
+        hipLaunchKernelGGL(k, dim3(cdiv(total, tpb)), dim3(256), lds, st, p, tiles_x, tiles_y, tpb, a0, wq, scale, shift, residual, out); \
+    } while (0)
+    if (nt == 1 && kh == 1) N16_LAUNCH(1, 1); else if (nt == 1) N16_LAUNCH(1, 2); else N16_LAUNCH(2, 1);
+#undef N16_LAUNCH
+}
+
 template <int MODE>
 static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a1, const float* wq, const float* scale,
                            const float* shift, const float* residual, float* out, hipStream_t st) {
     static const int force_bk = getenv("CODEPS_FORCE_BK") ? atoi(getenv("CODEPS_FORCE_BK")) : 0;   // tuning experiments only
     const bool bk32 = (kc_gran % 32) == 0 && force_bk != 16;
+    if (halo3n16_ok<MODE>(p)) { launch_halo3n16<MODE>(p, a0, wq, scale, shift, residual, out, st); return; }
     if (p.N <= 16) {
         p.n_mt = cdiv(p.M, 256); p.n_nt = 1;
         p.ksplit = 1;
@@ -4628,6 +4848,14 @@ static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
     static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;
     if (split_np != 2 && split_np != 3) return 0;
     if (force_bk == 16 || (nbuf_env && nbuf_env != 1)) return 0;
+    if (mode != 2 && split_np == 3) {
+        // conv_halo3n16_kernel's shapes (halo3n16_ok on the descriptor; the same for the forward and the data gradient: stride 1, pad 1)
+        static const int n16_on = getenv("CODEPS_HALO_N16") ? atoi(getenv("CODEPS_HALO_N16")) : 1;
+        if (n16_on && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->stride_w == 1 && d->pad == 1 && d->pad_w == 1 && d->pad_mode == 0 && d->c1 == 0 &&
+            !d->up0 && d->pix_pitch == 0 && d->out_h == d->in_h && d->out_w == d->in_w && d->in_w % 32 == 0 && d->in_h % 8 == 0 &&
+            (d->c0 == 16 || d->c0 == 32) && (d->out_c == 16 || d->out_c == 32) && !(d->c0 == 32 && d->out_c == 32))
+            return 3;
+    }
     if (mode == 0) {
         const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
         if (d->out_c > 16 && gran == 16 && d->c1 == 0 && split_np == 3 && (d->kh * d->kw * 16) % 32 == 0) return 3;     // the stem

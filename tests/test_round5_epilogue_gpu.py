@@ -470,3 +470,55 @@ def test_weight_gradient_of_1x1_convolutions_on_the_split_arithmetic(case):
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
     e, t = l2(outs[0], dw64), l2(dw32, dw64)
     assert e <= 3 * t + 1e-9, f"{case}: {e:.3e} vs torch fp32 {t:.3e}"
+
+
+@pytest.mark.parametrize("case", [
+    # (batch, H, W, ci, co): the depth decoder's full-resolution tail (models/depth_head.py:60-71) and its data gradients
+    (2, 64, 128, 16, 16), (2, 64, 128, 32, 16), (1, 32, 64, 16, 32), (3, 8, 32, 32, 16), (1, 128, 256, 16, 16),
+])
+def test_16_channel_3x3_layers_on_the_split_arithmetic(case):
+    """`conv_halo3n16_kernel` (K-steps of two taps x 16 channels on v_mfma_f32_16x16x32_bf16, weights as register fragments): forward
+    with bias + ELU and the data gradient against float64 within 3 x torch's own fp32 error, bit-identical from launch to launch, the
+    kernel is the one that ran (forward AND data gradient), and 12 real output channels in a 16-channel tensor."""
+    import ctypes
+    import torch.nn.functional as TF
+    from codeps_amd._lib import lib
+    F = _F()
+    b, h, w, ci, co = case
+    co_real = co - 4 if co == 16 else co
+    g = torch.Generator().manual_seed(ci * 3 + co + h)
+    x = torch.randn(b, ci, h, w, generator=g)
+    wt = torch.randn(co_real, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5
+    bias = torch.randn(co_real, generator=g) * 0.1
+    gy = torch.randn(b, co_real, h, w, generator=g)
+
+    def ref(dtype):
+        xx = x.to(dtype).requires_grad_(True)
+        y = TF.elu(TF.conv2d(xx, wt.to(dtype), bias.to(dtype), padding=1))
+        y.backward(gy.to(dtype))
+        return y.detach(), xx.grad
+
+    (y64, dx64), (y32, dx32) = ref(torch.float64), ref(torch.float32)
+    lib().codeps_conv2d_last_kernel.restype = ctypes.c_char_p
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)       # noqa: E731
+    outs = []
+    for _ in range(2):
+        xn = nhwc(x).requires_grad_(True)
+        y = F.conv2d(xn, wt.to(DEV), bias.to(DEV), pad=1, act="elu")
+        assert lib().codeps_conv2d_last_kernel().decode() == "conv_halo3n16_kernel"
+        gyn = torch.zeros_like(y)
+        gyn[..., :co_real] = nhwc(gy)
+        dx, = torch.autograd.grad(y, xn, gyn)
+        outs.append((y[..., :co_real].detach().permute(0, 3, 1, 2).cpu(), dx.permute(0, 3, 1, 2).cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(y[..., co_real:].abs().max()) == 0.0 if co_real < co else True
+    l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
+    e, t = l2(outs[0][0], y64), l2(y32, y64)
+    assert e <= 3 * t + 1e-9, f"{case} forward: {e:.3e} vs torch fp32 {t:.3e}"
+    e, t = l2(outs[0][1], dx64), l2(dx32, dx64)
+    assert e <= 3 * t + 1e-9, f"{case} data gradient: {e:.3e} vs torch fp32 {t:.3e}"
+    # the data gradient alone (no weight gradient launch after it): its kernel
+    xn = nhwc(x).requires_grad_(True)
+    y = F.conv2d(xn, wt.to(DEV).requires_grad_(False), None, pad=1)
+    torch.autograd.grad(y, xn, torch.ones_like(y))
+    assert lib().codeps_conv2d_last_kernel().decode() == "conv_halo3n16_kernel"
