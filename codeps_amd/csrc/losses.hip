@@ -138,7 +138,12 @@ __device__ __forceinline__ float ce_of_probs_kept(const float* __restrict__ p, i
 
 __global__ __launch_bounds__(256) void sem_px_kernel(const float* __restrict__ probs, int C, int Cp, const uint8_t* __restrict__ target,
                                                      const uint8_t* __restrict__ pw, const float* __restrict__ cw, int ignore,
-                                                     unsigned long long drop, long long N, float* __restrict__ loss_px) {
+                                                     unsigned long long drop, long long N, float* __restrict__ loss_px,
+                                                     uint32_t* __restrict__ hist0) {
+    // hist0 != null: the first pass of the top-k radix select (the keys' high byte; no prefix yet) rides here -- one launch and one pass
+    // over the loss map less
+    __shared__ uint32_t h[256];
+    if (hist0) { h[threadIdx.x] = 0; __syncthreads(); }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const int t = target[i];
         float l = 0.f;
@@ -153,51 +158,86 @@ __global__ __launch_bounds__(256) void sem_px_kernel(const float* __restrict__ p
             if (pw) l *= (float)pw[i];
         }
         loss_px[i] = l;
+        if (hist0) atomicAdd(&h[(l > 0.f ? __float_as_uint(l) : 0u) >> 24], 1u);
+    }
+    if (hist0) {
+        __syncthreads();
+        if (h[threadIdx.x]) atomicAdd(&hist0[threadIdx.x], h[threadIdx.x]);
     }
 }
 
-// radix-select state: [0] prefix (key bits found so far), [1] k remaining, [2] n_gt (elements strictly above the final bin)
-// hist: 256 bins.  Keys = float bits of non-negative losses (monotone as uint32).
-__global__ __launch_bounds__(256) void radix_hist_kernel(const float* __restrict__ v, long long N, int shift, const uint32_t* __restrict__ state,
+// radix-select state: [0] prefix (key bits found so far), [1] k remaining, [2] n_gt (elements strictly above the final bin), [3] the
+// threshold's multiplicity.  Keys = float bits of non-negative losses (monotone as uint32); four passes of 8 bits, one 256-bin histogram
+// each (hist[pass][256], zeroed by radix_init_kernel).  Round 5: the single-block "pick" launches between the passes are gone -- EVERY
+// block of pass j + 1 (and of the top-k sum after the last pass) derives the state after pass j from hist[j] and the state before it
+// (a 256-thread suffix scan: ~1 us instead of a 12 us launch with a serial walk), block 0 records it for the pass after (and, at the
+// end, as the final state the backward reads).  Same integers, same threshold.
+struct RadixState { uint32_t prefix, k, n_gt, mult; };
+
+// all 256 threads of the block; `scan` = 256 words of LDS, `bin_s` = one word
+__device__ __forceinline__ RadixState radix_pick(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ prev, int shift, uint32_t* scan,
+                                                  int* bin_s) {
+    const int t = threadIdx.x;
+    const uint32_t mine = hist[t];
+    scan[t] = mine;
+    if (t == 0) *bin_s = 0;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                  // inclusive SUFFIX sums: scan[t] = sum_{i >= t} hist[i]
+        const uint32_t add = t + off < 256 ? scan[t + off] : 0u;
+        __syncthreads();
+        scan[t] += add;
+        __syncthreads();
+    }
+    RadixState st{prev[0], prev[1], prev[2], prev[3]};
+    // the reference walk: from bin 255 down, stop at the first bin whose suffix sum reaches k; bin 0 if none does
+    if (t >= 1 && scan[t] >= st.k) atomicMax(bin_s, t);
+    __syncthreads();
+    const int bin = *bin_s;
+    const uint32_t above = bin < 255 ? scan[bin + 1] : 0u;
+    const uint32_t cnt = scan[bin] - above;
+    __syncthreads();                                           // (scan / bin_s may be reused by the caller)
+    st.prefix |= ((uint32_t)bin) << shift;
+    st.k -= above;
+    st.n_gt += above;
+    if (shift == 0) st.mult = cnt;
+    return st;
+}
+
+// pass `pass` (1 .. 3; shift = 24 - 8 pass): state before it = pick(hist[pass - 1], states[pass - 1]); block 0 records it in states[pass]
+__global__ __launch_bounds__(256) void radix_hist_kernel(const float* __restrict__ v, long long N, int pass, uint32_t* __restrict__ states,
                                                          uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[256];
+    __shared__ int bin_s;
+    const int shift = 24 - 8 * pass;
+    const RadixState st = radix_pick(hist + (pass - 1) * 256, states + (pass - 1) * 4, shift + 8, h, &bin_s);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { uint32_t* o = states + pass * 4; o[0] = st.prefix; o[1] = st.k; o[2] = st.n_gt; o[3] = st.mult; }
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t prefix = state[0];
-    const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    const uint32_t himask = 0xFFFFFFFFu << (shift + 8);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const float vi = v[i];
         const uint32_t key = vi > 0.f ? __float_as_uint(vi) : 0u;
-        if ((key & himask) == (prefix & himask)) atomicAdd(&h[(key >> shift) & 0xFF], 1u);
+        if ((key & himask) == (st.prefix & himask)) atomicAdd(&h[(key >> shift) & 0xFF], 1u);
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void radix_pick_kernel(uint32_t* __restrict__ state, uint32_t* __restrict__ hist, int shift) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = hist[threadIdx.x];
-    hist[threadIdx.x] = 0;                       // ready for the next pass
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t k = state[1], above = 0;
-        int bin = 255;
-        for (; bin > 0; --bin) {
-            if (above + h[bin] >= k) break;
-            above += h[bin];
-        }
-        state[0] |= ((uint32_t)bin) << shift;
-        state[1] = k - above;                    // rank inside the chosen bin
-        state[2] += above;                       // strictly greater than everything in the chosen bin
-        if (shift == 0) state[3] = h[bin];       // multiplicity of the threshold value itself
-    }
+    if (h[threadIdx.x]) atomicAdd(&hist[pass * 256 + threadIdx.x], h[threadIdx.x]);
 }
 
 // sum of the top-k: sum_{v > tau} v + (k - n_gt) * tau     -> partials
-__global__ __launch_bounds__(256) void topk_sum_kernel(const float* __restrict__ v, long long N, const uint32_t* __restrict__ state,
+__global__ __launch_bounds__(256) void topk_sum_kernel(const float* __restrict__ v, long long N, uint32_t* __restrict__ state,
+                                                       const uint32_t* __restrict__ states, const uint32_t* __restrict__ hist,
                                                        float* __restrict__ part) {
     __shared__ float red[4];
-    const float tau = __uint_as_float(state[0]);
+    __shared__ uint32_t scan[256];
+    __shared__ int bin_s;
+    float tau;
+    if (hist) {                                                // top-k: the state after the last pass, from hist[3] (block 0 records it: `state`)
+        const RadixState st = radix_pick(hist + 3 * 256, states + 3 * 4, 0, scan, &bin_s);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { state[0] = st.prefix; state[1] = st.k; state[2] = st.n_gt; state[3] = st.mult; }
+        tau = __uint_as_float(st.prefix);
+    } else {
+        tau = __uint_as_float(state[0]);
+    }
     float a = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const float x = fmaxf(v[i], 0.f);
@@ -479,18 +519,11 @@ extern "C" int codeps_smoothness_bwd(const float* img, const float* disp, const 
     return CODEPS_OK;
 }
 
-static void radix_select(const float* v, long long N, uint32_t k, uint32_t* state, uint32_t* hist, hipStream_t st) {
-    // state/hist must be zero on entry except state[1] = k
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks_for(N)), dim3(256), 0, st, v, N, shift, (const uint32_t*)state, hist);
-        hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, st, state, hist, shift);
-    }
-}
-
+// state: [0..3] final state (what the backward reads), [4..19] states[pass][4] = the state BEFORE pass `pass`'s pick ... hist: [4][256]
 __global__ void radix_init_kernel(uint32_t* state, uint32_t* hist, uint32_t k) {
     const int i = threadIdx.x;
-    hist[i] = 0;
-    if (i < 4) state[i] = i == 1 ? k : 0;
+    for (int j = i; j < 4 * 256; j += 256) hist[j] = 0;
+    if (i < 20) state[i] = i == 5 ? k : 0;                     // states[0] = (prefix 0, k, n_gt 0, mult 0)
 }
 
 extern "C" int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, const uint8_t* target, const uint8_t* pixel_weights,
@@ -505,22 +538,29 @@ extern "C" int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, co
     float* lpx = (float*)workspace;
     float* part = (float*)((char*)workspace + align_up((size_t)pixels * 4, 256));
     uint32_t* state = (uint32_t*)(part + (size_t)RB * 32);
-    uint32_t* hist = state + 16;
-    hipLaunchKernelGGL(sem_px_kernel, dim3(blocks_for(pixels)), dim3(256), 0, st, probs, c, c_pad, target, pixel_weights, class_weights, ignore_index,
-                       drop, pixels, lpx);
-    CODEPS_CHECK_LAUNCH("sem_px_kernel");
+    uint32_t* hist = state + 32;
     const int nblk = blocks_for(pixels);
     if (top_k < 1.0) {
         const uint32_t k = (uint32_t)((double)top_k * (double)pixels);     // int(top_k * numel), algos/semantic_seg.py:62
         CODEPS_REQUIRE(k >= 1, CODEPS_ERR_ARG, "semantic_loss_fwd: top-k selects zero pixels");
+        // 7 launches (round 4: 12): init | per-pixel loss + pass 0 | passes 1-3, each picking the previous one's bin itself | sum (+ last pick) | finish
         hipLaunchKernelGGL(radix_init_kernel, dim3(1), dim3(256), 0, st, state, hist, k);
-        radix_select(lpx, pixels, k, state, hist, st);
-        hipLaunchKernelGGL(topk_sum_kernel, dim3(nblk), dim3(256), 0, st, (const float*)lpx, pixels, (const uint32_t*)state, part);
+        hipLaunchKernelGGL(sem_px_kernel, dim3(blocks_for(pixels)), dim3(256), 0, st, probs, c, c_pad, target, pixel_weights, class_weights,
+                           ignore_index, drop, pixels, lpx, hist);
+        CODEPS_CHECK_LAUNCH("sem_px_kernel");
+        for (int pass = 1; pass < 4; ++pass)
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks_for(pixels)), dim3(256), 0, st, (const float*)lpx, pixels, pass, state + 4, hist);
+        hipLaunchKernelGGL(topk_sum_kernel, dim3(nblk), dim3(256), 0, st, (const float*)lpx, pixels, state, (const uint32_t*)(state + 4),
+                           (const uint32_t*)hist, part);
         hipLaunchKernelGGL(topk_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, (const uint32_t*)state, k, loss);
     } else {
+        hipLaunchKernelGGL(sem_px_kernel, dim3(blocks_for(pixels)), dim3(256), 0, st, probs, c, c_pad, target, pixel_weights, class_weights,
+                           ignore_index, drop, pixels, lpx, (uint32_t*)nullptr);
+        CODEPS_CHECK_LAUNCH("sem_px_kernel");
         hipLaunchKernelGGL(radix_init_kernel, dim3(1), dim3(256), 0, st, state, hist, 0u);     // tau = 0, n_gt = 0: unused
         // plain mean over all pixels (tau = +0: every positive loss is summed)
-        hipLaunchKernelGGL(topk_sum_kernel, dim3(nblk), dim3(256), 0, st, (const float*)lpx, pixels, (const uint32_t*)state, part);
+        hipLaunchKernelGGL(topk_sum_kernel, dim3(nblk), dim3(256), 0, st, (const float*)lpx, pixels, state, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, part);
         hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, (float)(1.0 / (double)pixels), loss, 0);
     }
     CODEPS_CHECK_LAUNCH("semantic_loss_fwd kernels");
