@@ -97,6 +97,7 @@ SIGNATURES = {
     "codeps_chain1x1_expand_reduce": (c_int, [P, P, P, P, P, P, LL, I, P, P, P, c_size_t, P]),
     "codeps_nchw_to_nhwc": (c_int, [P, I, I, I, I, P, I, I, I, P]),
     "codeps_nchw_to_nhwc_xpad": (c_int, [P, I, I, I, I, P, I, I, I, I, I, P]),
+    "codeps_frames_to_nhwc": (c_int, [P, P, P, I, I, I, I, P, I, I, I, P]),
     "codeps_nhwc_to_nchw": (c_int, [P, I, I, I, I, I, P, P]),
     "codeps_colsum_workspace_bytes": (c_size_t, [LL, I, I]),
     "codeps_act_bwd": (c_int, [P, P, P, I, LL, I, P, P, I, I, P, c_size_t, P]),

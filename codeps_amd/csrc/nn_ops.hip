@@ -1423,9 +1423,71 @@ static int check_colsum_c(int C, const char* who) {
 }
 static inline int col_tiles(int C) { return cdiv(C / 4, 256); }
 
+// Several NCHW frame batches -> ONE NHWC tensor in one launch (round 5: the pose net's six frame pairs were twelve launches, the encoder's
+// four image keys four): slab s covers nb[s] consecutive batch items of the destination; its pixels take the c channels of frame a at
+// channel 0 and (b != null) of frame b at channel c, zeros elsewhere -- what nchw_to_nhwc_kernel wrote with (zero_rest = 1) for a and
+// (zero_rest = 0, c_off = c) for b.  One thread per (destination pixel, 4-channel group).
+struct FrameSlabs { const float* a[16]; const float* b[16]; int b0[17]; int n; };
+__global__ __launch_bounds__(256) void frames_to_nhwc_kernel(FrameSlabs fs, int C, int H, int W, float* __restrict__ y, int Cp, int pad_l, int Wp) {
+    const int groups = Cp / 4;
+    const long long total = (long long)fs.b0[16] * H * Wp * groups;            // (b0[n .. 16] = the batch total: constant index, no scratch)
+    const long long HW = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % groups);
+        long long r = i / groups;
+        const int xd = (int)(r % Wp); r /= Wp;
+        const int yy = (int)(r % H);
+        const int bb = (int)(r / H);
+        int s = 0;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += (k < fs.n && bb >= fs.b0[k]) ? 1 : 0;
+        const float* fa = fs.a[0];
+        const float* fb = fs.b[0];
+        int bs = fs.b0[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) if (k == s) { fa = fs.a[k]; fb = fs.b[k]; bs = fs.b0[k]; }        // (select chain: no indexed access into the by-value struct)
+        const int xs = xd - pad_l, bl = bb - bs;
+        const bool in = xs >= 0 && xs < W;
+        const long long hw = (long long)yy * W + xs;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = g * 4 + e;
+            float t = 0.f;
+            if (in && c < C) t = fa[((size_t)bl * C + c) * HW + hw];
+            else if (in && fb && c < 2 * C) t = fb[((size_t)bl * C + (c - C)) * HW + hw];
+            v[e] = t;
+        }
+        *reinterpret_cast<f32x4*>(y + (((size_t)bb * H + yy) * Wp + xd) * Cp + g * 4) = v;
+    }
+}
+
 }  // namespace
 
 // =============================================================================================== C ABI
+extern "C" int codeps_frames_to_nhwc(const float* const* frames_a, const float* const* frames_b, const int* slab_batch, int n_slabs, int c, int h,
+                                     int w, float* y, int c_pad, int pad_left, int pad_right, codeps_stream_t stream) {
+    CODEPS_REQUIRE(frames_a && slab_batch && y && n_slabs >= 1 && n_slabs <= 16 && c > 0 && h > 0 && w > 0 && (c_pad % 4) == 0 && pad_left >= 0 &&
+                   pad_right >= 0, CODEPS_ERR_ARG, "frames_to_nhwc: bad arguments (1..16 slabs)");
+    FrameSlabs fs;
+    memset(&fs, 0, sizeof(fs));
+    fs.n = n_slabs;
+    bool two = false;
+    for (int s = 0; s < n_slabs; ++s) {
+        CODEPS_REQUIRE(frames_a[s] && slab_batch[s] > 0, CODEPS_ERR_ARG, "frames_to_nhwc: null frame / empty slab %d", s);
+        fs.a[s] = frames_a[s]; fs.b[s] = frames_b ? frames_b[s] : nullptr;
+        two = two || fs.b[s];
+        fs.b0[s + 1] = fs.b0[s] + slab_batch[s];
+    }
+    for (int s = n_slabs + 1; s <= 16; ++s) fs.b0[s] = fs.b0[n_slabs];
+    CODEPS_REQUIRE((two ? 2 : 1) * c <= c_pad, CODEPS_ERR_ARG, "frames_to_nhwc: %d channels do not fit c_pad %d", (two ? 2 : 1) * c, c_pad);
+    const int wp = pad_left + w + pad_right;
+    const long long items = (long long)fs.b0[n_slabs] * h * wp * (c_pad / 4);
+    hipLaunchKernelGGL(frames_to_nhwc_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, fs, c, h, w, y, c_pad, pad_left, wp);
+    CODEPS_CHECK_LAUNCH("frames_to_nhwc_kernel");
+    return CODEPS_OK;
+}
+
 static int nchw_to_nhwc_impl(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off, int zero_rest, int pad_l,
                              int pad_r, codeps_stream_t stream, const char* who) {
     CODEPS_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0 && (c_pad % 4) == 0 && c_off >= 0 && c_off + c <= c_pad && pad_l >= 0 &&

@@ -189,6 +189,27 @@ def _to_nhwc_into(im, y, c_pad, c_off, zero_rest, xpad):
 STEM_XPAD = (4, 2)      # zero columns left / right of every row in the double-pixel stem layout (see stem_conv2d)
 
 
+def _frames_to_nhwc(slabs, y, c_pad, xpad):
+    """slabs = [(frame_a [B_i,C,H,W], frame_b or None), ...] -> y [sum B_i, H, W + xpad, c_pad] in ONE launch (C ABI codeps_frames_to_nhwc);
+    more than 16 slabs: the per-frame launches."""
+    _, c, h, w = slabs[0][0].shape
+    if len(slabs) > 16:
+        off = 0
+        for fa, fb in slabs:
+            b = fa.shape[0]
+            _to_nhwc_into(fa, y[off:off + b], c_pad, 0, 1, xpad)
+            if fb is not None:
+                _to_nhwc_into(fb, y[off:off + b], c_pad, c, 0, xpad)
+            off += b
+        return y
+    n = len(slabs)
+    pa = (ctypes.c_void_p * n)(*[fa.data_ptr() for fa, _ in slabs])
+    pb = (ctypes.c_void_p * n)(*[(fb.data_ptr() if fb is not None else None) for _, fb in slabs])
+    nb = (ctypes.c_int * n)(*[fa.shape[0] for fa, _ in slabs])
+    check(lib().codeps_frames_to_nhwc(pa, pb, nb, n, c, h, w, ptr(y), c_pad, xpad[0], xpad[1], stream_ptr()), "codeps_frames_to_nhwc")
+    return y
+
+
 def images_to_nhwc(images, c_pad=16, xpad=(0, 0)):
     """[B,3,H,W] NCHW image(s) -> one NHWC tensor with the images stacked along channels and zero
     padding up to c_pad (stem input; two frames for the pose net); xpad = extra zero columns (left, right)."""
@@ -196,6 +217,8 @@ def images_to_nhwc(images, c_pad=16, xpad=(0, 0)):
     require_cuda(*imgs)
     b, c, h, w = imgs[0].shape
     y = torch.empty(b, h, w + sum(xpad), c_pad, dtype=torch.float32, device=imgs[0].device)
+    if len(imgs) <= 2:
+        return _frames_to_nhwc([(imgs[0], imgs[1] if len(imgs) == 2 else None)], y, c_pad, xpad)
     for k, im in enumerate(imgs):
         _to_nhwc_into(im, y, c_pad, k * c, 1 if k == 0 else 0, xpad)
     return y
@@ -208,13 +231,7 @@ def frame_pairs_to_nhwc(pairs, c_pad=16, xpad=(0, 0)):
     _, c, h, w = pairs[0][0].shape
     total = sum(p[0].shape[0] for p in pairs)
     y = torch.empty(total, h, w + sum(xpad), c_pad, dtype=torch.float32, device=pairs[0][0].device)
-    off = 0
-    for fa, fb in pairs:
-        b = fa.shape[0]
-        for k, im in enumerate((_f32c(fa), _f32c(fb))):
-            _to_nhwc_into(im, y[off:off + b], c_pad, k * c, 1 if k == 0 else 0, xpad)
-        off += b
-    return y
+    return _frames_to_nhwc([(_f32c(fa), _f32c(fb)) for fa, fb in pairs], y, c_pad, xpad)
 
 
 def image_batches_to_nhwc(images, c_pad=16, xpad=(0, 0)):
@@ -224,12 +241,7 @@ def image_batches_to_nhwc(images, c_pad=16, xpad=(0, 0)):
     _, c, h, w = imgs[0].shape
     total = sum(i.shape[0] for i in imgs)
     y = torch.empty(total, h, w + sum(xpad), c_pad, dtype=torch.float32, device=imgs[0].device)
-    off = 0
-    for im in imgs:
-        b = im.shape[0]
-        _to_nhwc_into(im, y[off:off + b], c_pad, 0, 1, xpad)
-        off += b
-    return y
+    return _frames_to_nhwc([(im, None) for im in imgs], y, c_pad, xpad)
 
 
 _ws_cache = {}

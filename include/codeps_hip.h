@@ -218,6 +218,11 @@ int codeps_nchw_to_nhwc(const float* x, int batch, int c, int h, int w, float* y
  * whose K dimension is 7*4*16 = 448 instead of 7*7*16 = 784 (weights W'[o][p*8 + c][ky][j] = W[o][c][ky][2j + p - 1]). */
 int codeps_nchw_to_nhwc_xpad(const float* x, int batch, int c, int h, int w, float* y, int c_pad, int c_off,
                              int zero_rest, int pad_left, int pad_right, codeps_stream_t stream);
+/* Several NCHW frame batches into ONE such tensor in one launch: slab s = slab_batch[s] consecutive batch items of y whose pixels
+ * take the c channels of frames_a[s] at channel 0 and (frames_b && frames_b[s]) of frames_b[s] at channel c, zeros elsewhere -- the pose
+ * net's frame pairs concatenated along the batch (algos/depth.py:408-413) or the encoder's image keys (frames_b = NULL); 1..16 slabs. */
+int codeps_frames_to_nhwc(const float* const* frames_a, const float* const* frames_b, const int* slab_batch, int n_slabs, int c,
+                          int h, int w, float* y, int c_pad, int pad_left, int pad_right, codeps_stream_t stream);
 int codeps_nhwc_to_nchw(const float* x, int batch, int c, int h, int w, int c_pad, float* y,
                         codeps_stream_t stream);
 size_t codeps_colsum_workspace_bytes(long long rows, int c, int k);
