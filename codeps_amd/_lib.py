@@ -110,6 +110,7 @@ SIGNATURES = {
     "codeps_bn_sync_combine": (c_int, [P, I, I, P, P, I, I, c_float, c_float, P, P, P, P, P, P]),
     "codeps_bn_bwd_mg": (c_int, [P, P, P, I, P, P, I, I, P, P, P, P, P, I, P, P, P, I, P, P, I, I, P, c_size_t, P]),
     "codeps_colsum_finish": (c_int, [P, I, I, P, I, I, P]),
+    "codeps_colsum_finish_multi": (c_int, [P, P, P, P, P, I, P]),
     "codeps_bn_finalize_tiles": (c_int, [P, I, I, I, I, P, P, I, c_float, P, P, P, P]),
     "codeps_bn_bwd_tiles": (c_int, [P, I, P, P, P, I, P, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, P, I, P]),
     "codeps_bn_relu_pool_fwd": (c_int, [P, I, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, c_float, I, P]),

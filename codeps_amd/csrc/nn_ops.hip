@@ -155,6 +155,32 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     *o = accumulate ? *o + a : a;
 }
 
+// Several column-sum finishes in one launch (the bias gradients of a backward pass, accumulated into their slots of the flat gradient
+// buffer): item k owns blocks [blk0[k], blk0[k + 1]); per item exactly colsum_finish_kernel's arithmetic (K = 1, accumulate).
+struct ColsumItems { const float* part[32]; float* out[32]; int tiles[32], c[32], c_real[32], blk0[33]; int n; };
+__global__ __launch_bounds__(256) void colsum_finish_multi_kernel(ColsumItems it) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 32; ++j) k += (j < it.n && (int)blockIdx.x >= it.blk0[j]) ? 1 : 0;
+    const float* part = it.part[0];
+    float* out = it.out[0];
+    int nblk = it.tiles[0], C = it.c[0], c_real = it.c_real[0], b0 = it.blk0[0];
+#pragma unroll
+    for (int j = 1; j < 32; ++j)
+        if (j == k) { part = it.part[j]; out = it.out[j]; nblk = it.tiles[j]; C = it.c[j]; c_real = it.c_real[j]; b0 = it.blk0[j]; }     // (select chain: no indexed access)
+    const int i = ((int)blockIdx.x - b0) * 4 + threadIdx.x / 64, sub = threadIdx.x % 64;
+    const bool in = i < C;
+    float a = 0.f;
+    if (in) {
+#pragma unroll 4
+        for (int b = sub; b < nblk; b += 64) a += part[(size_t)b * C + i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (!in || sub != 0 || i >= c_real) return;
+    out[i] += a;
+}
+
 // ---------------------------------------------------------------------------------- BatchNorm (train)
 // forward statistics: partial (sum (x - s), sum (x - s)^2) per channel with the shift s = x[row 0][c]
 // ("shifted data" variance: no catastrophic cancellation when |mean| >> std)
@@ -1579,6 +1605,22 @@ extern "C" int codeps_colsum_finish(const float* part, int tiles, int c, float* 
     CODEPS_REQUIRE(part && out && tiles > 0 && c > 0 && c_real > 0 && c_real <= c, CODEPS_ERR_ARG, "colsum_finish: bad arguments");
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(c, 4)), dim3(256), 0, (hipStream_t)stream, part, tiles, 1, c, out, c_real, accumulate);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
+    return CODEPS_OK;
+}
+
+extern "C" int codeps_colsum_finish_multi(const float* const* parts, const int* tiles, const int* c, float* const* outs, const int* c_real, int n,
+                                          codeps_stream_t stream) {
+    CODEPS_REQUIRE(parts && tiles && c && outs && c_real && n >= 1 && n <= 32, CODEPS_ERR_ARG, "colsum_finish_multi: 1..32 items");
+    ColsumItems it;
+    memset(&it, 0, sizeof(it));
+    it.n = n;
+    for (int k = 0; k < n; ++k) {
+        CODEPS_REQUIRE(parts[k] && outs[k] && tiles[k] > 0 && c[k] > 0 && c_real[k] > 0 && c_real[k] <= c[k], CODEPS_ERR_ARG, "colsum_finish_multi: bad item %d", k);
+        it.part[k] = parts[k]; it.out[k] = outs[k]; it.tiles[k] = tiles[k]; it.c[k] = c[k]; it.c_real[k] = c_real[k];
+        it.blk0[k + 1] = it.blk0[k] + cdiv(c[k], 4);
+    }
+    hipLaunchKernelGGL(colsum_finish_multi_kernel, dim3(it.blk0[n]), dim3(256), 0, (hipStream_t)stream, it);
+    CODEPS_CHECK_LAUNCH("colsum_finish_multi_kernel");
     return CODEPS_OK;
 }
 

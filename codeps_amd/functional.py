@@ -433,6 +433,52 @@ ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
 # accumulate kernels, and the buffer is ready for a single RCCL all-reduce.
 _grad_sink = {}            # id(param) -> (weakref(param), view into the flat gradient buffer)
 
+# Bias gradients whose column-sum partials a data-gradient epilogue left and whose destination is a slot of the flat gradient buffer: their
+# finishes are collected per stream and run as ONE launch (codeps_colsum_finish_multi) when the step harness asks (StepRunner: after the
+# backward pass, and before a gradient segment is handed to the all-reduce) -- 25 launches of 6 us per adaptation step were one each.
+_DEFER_COLSUM = os.environ.get("CODEPS_DEFER_COLSUM", "1") != "0"
+_colsum_pending = {}       # stream handle -> (torch stream, [(partials tensor, tiles, c, sink view, c_real)])
+_colsum_armed = [False]    # only a harness that promises to flush arms the deferral
+
+
+def arm_colsum_deferral(on):
+    """StepRunner.forward_backward: True for the span of one backward pass (stale entries of an aborted pass are dropped)."""
+    _colsum_pending.clear()
+    _colsum_armed[0] = bool(on) and _DEFER_COLSUM
+
+
+def _colsum_finish(part, tiles, c, out, c_real, accumulate):
+    if accumulate and _colsum_armed[0]:
+        st = torch.cuda.current_stream()
+        items = _colsum_pending.setdefault(st.cuda_stream, (st, []))[1]
+        if any(t[3].data_ptr() == out.data_ptr() for t in items):      # a module applied twice: its two finishes must not share a launch
+            flush_colsums(current_only=True)
+            items = _colsum_pending.setdefault(st.cuda_stream, (st, []))[1]
+        items.append((part, tiles, c, out, c_real))
+        return
+    check(lib().codeps_colsum_finish(ptr(part), tiles, c, ptr(out), c_real, 1 if accumulate else 0, stream_ptr()), "codeps_colsum_finish")
+
+
+def flush_colsums(current_only=False):
+    """Run the pending bias-gradient finishes, each stream's on that stream (current_only: just the current stream's)."""
+    if not _colsum_pending:
+        return
+    cur = torch.cuda.current_stream().cuda_stream
+    for key in list(_colsum_pending.keys()):
+        if current_only and key != cur:
+            continue
+        st, items = _colsum_pending.pop(key)
+        with torch.cuda.stream(st):
+            for i in range(0, len(items), 32):
+                chunk = items[i:i + 32]
+                n = len(chunk)
+                parts = (ctypes.c_void_p * n)(*[t[0].data_ptr() for t in chunk])
+                outs = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in chunk])
+                tiles = (ctypes.c_int * n)(*[t[1] for t in chunk])
+                cs = (ctypes.c_int * n)(*[t[2] for t in chunk])
+                crs = (ctypes.c_int * n)(*[t[4] for t in chunk])
+                check(lib().codeps_colsum_finish_multi(parts, tiles, cs, outs, crs, n, st.cuda_stream), "codeps_colsum_finish_multi")
+
 
 def register_grad_sink(param, view):
     _grad_sink[id(param)] = (_weak(param, _grad_sink, id(param)), view)
@@ -658,8 +704,7 @@ class _Conv2d(torch.autograd.Function):
             if need_b:
                 if gated["part"] is not None:
                     tiles = sum(sg[3] for sg in gated["segs"])
-                    check(lib().codeps_colsum_finish(ptr(gated["part"]), tiles, cop, ptr(dbias), ctx.co, b_acc, stream_ptr()),
-                          "codeps_colsum_finish")
+                    _colsum_finish(gated["part"], tiles, cop, dbias, ctx.co, b_acc)
                 else:
                     wsb = lib().codeps_colsum_workspace_bytes(rows, cop, 1)
                     ws = _workspace(wsb, dy.device, "colsum")
@@ -1760,8 +1805,7 @@ class _UpConv16(torch.autograd.Function):
         if gated is not None:                   # dy arrived multiplied by act'(y), with its column sums per block
             if need_b:
                 if gated["part"] is not None:
-                    check(lib().codeps_colsum_finish(ptr(gated["part"]), gated["segs"][0][3], 16, ptr(dbias), 16, 1 if ctx.b_sink is not None else 0,
-                                                     stream_ptr()), "codeps_colsum_finish")
+                    _colsum_finish(gated["part"], gated["segs"][0][3], 16, dbias, 16, 1 if ctx.b_sink is not None else 0)
                 else:
                     ws = _workspace(lib().codeps_colsum_workspace_bytes(rows, 16, 1), dev, "colsum")
                     check(lib().codeps_act_bwd(ptr(dy), None, None, 0, rows, 16, None, ptr(dbias), 16, 1 if ctx.b_sink is not None else 0, ptr(ws),

@@ -274,7 +274,12 @@ class StepRunner:
                 self._seg = {"need": need, "events": [], "work": None}
         if self._one is None or self._one.device != total.device:
             self._one = torch.ones((), dtype=total.dtype, device=total.device)
-        total.backward(self._one)                # (the default seed is an ATen ones_like launch per step)
+        F.arm_colsum_deferral(True)              # bias-gradient finishes of this backward pass: one launch per stream (F.flush_colsums)
+        try:
+            total.backward(self._one)            # (the default seed is an ATen ones_like launch per step)
+            F.flush_colsums()                    # (each stream's on that stream: before the side streams are joined below)
+        finally:
+            F.arm_colsum_deferral(False)
         for side in (getattr(self.net, "pose_stream", None), getattr(self.net, "branch_stream", None)):
             if side is not None:      # the gradient sinks are written by kernels autograd does not track: join the side streams by hand
                 torch.cuda.current_stream().wait_stream(side)
@@ -314,6 +319,7 @@ class StepRunner:
         seg = self._seg
         if seg is None or seg["work"] is not None:
             return
+        F.flush_colsums(current_only=True)                   # the head's pending bias-gradient finishes belong in front of the event
         ev = torch.cuda.Event()
         ev.record()                                          # this node's stream: everything the head's backward issued precedes it
         seg["events"].append(ev)

@@ -235,6 +235,10 @@ int codeps_act_bwd(const float* dy, const float* y, const float* scale, int act,
  * (codeps_conv_epilogue stat_mode 2), fixed order.  With the gate of that launch it replaces codeps_act_bwd for a conv + activation
  * whose output feeds one convolution (models/depth_head.py:63-71). */
 int codeps_colsum_finish(const float* part, int tiles, int c, float* out, int c_real, int accumulate, codeps_stream_t stream);
+/* n (1..32) such finishes in ONE launch, each accumulating into its output (outs[k][0 .. c_real[k]) += column sums of parts[k]
+ * [tiles[k]][c[k]]): the bias gradients a backward pass leaves pending (codeps_amd.functional.flush_colsums). */
+int codeps_colsum_finish_multi(const float* const* parts, const int* tiles, const int* c, float* const* outs, const int* c_real,
+                               int n, codeps_stream_t stream);
 /* Train-mode BatchNorm (nn.BatchNorm2d / SyncBatchNorm, misc/train_utils.py:50-51): statistics leave
  * the library as raw sums so the caller can all-reduce them over ranks before normalising.
  *   bn_stats:       sums[0][c] = sum (x - s_c), sums[1][c] = sum (x - s_c)^2 with the shift s_c = x[0][c]
