@@ -189,11 +189,14 @@ def _to_nhwc_into(im, y, c_pad, c_off, zero_rest, xpad):
 STEM_XPAD = (4, 2)      # zero columns left / right of every row in the double-pixel stem layout (see stem_conv2d)
 
 
+_FRAMES_MULTI = os.environ.get("CODEPS_FRAMES_MULTI", "1") != "0"       # A/B switch: 0 = one launch per frame
+
+
 def _frames_to_nhwc(slabs, y, c_pad, xpad):
     """slabs = [(frame_a [B_i,C,H,W], frame_b or None), ...] -> y [sum B_i, H, W + xpad, c_pad] in ONE launch (C ABI codeps_frames_to_nhwc);
     more than 16 slabs: the per-frame launches."""
     _, c, h, w = slabs[0][0].shape
-    if len(slabs) > 16:
+    if len(slabs) > 16 or not _FRAMES_MULTI:
         off = 0
         for fa, fb in slabs:
             b = fa.shape[0]
