@@ -167,17 +167,34 @@ __device__ __forceinline__ void epi_begin(const ConvP& p, EpiCtx& ec, int img, i
     }
 }
 
+// What a gate reads from memory at out[idx] (the BatchNorm's input, the gate tensor).  The kernels fetch these for ALL rows of an
+// epilogue pass before the pass's first store: the stores go to `out`, which the compiler cannot prove distinct from the gate tensors, so
+// loads written inside the store loop are issued one row at a time, each behind the previous row's store -- a memory latency per row
+// (8 rows x 2 passes per block: most of the 35-40 us a BatchNorm-gate data gradient cost over the plain one).
+struct EpiPre { f32x4 x, g; };
+__device__ __forceinline__ EpiPre epi_prefetch(const ConvP& p, size_t idx, bool ok) {
+    EpiPre e{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (!ok) return e;
+    if (p.ex_gate_act == 3) {
+        e.x = *reinterpret_cast<const f32x4*>(p.ex_bn_x + idx);
+        if (p.ex_bn_relu && p.ex_gate) e.g = *reinterpret_cast<const f32x4*>(p.ex_gate + idx);
+    } else if (p.ex_gate_act) {
+        e.g = *reinterpret_cast<const f32x4*>(p.ex_gate + idx);
+    }
+    return e;
+}
+
 // v = the value about to be stored at out[idx]: gate it, account for it in the tile's statistics
-__device__ __forceinline__ f32x4 epi_apply(const ConvP& p, EpiCtx& ec, f32x4 v, size_t idx) {
+__device__ __forceinline__ f32x4 epi_apply(const ConvP& p, EpiCtx& ec, f32x4 v, const EpiPre& pre) {
     if (p.ex_gate_act == 1 || p.ex_gate_act == 2) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(p.ex_gate + idx);
+        const f32x4 g = pre.g;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= g[e] > 0.f ? 1.f : (p.ex_gate_act == 2 ? g[e] + 1.f : 0.f);      // = act_bwd_kernel's product
     }
     if (p.ex_gate_act == 3) {
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(p.ex_bn_x + idx) - ec.mu) * ec.is;
+        const f32x4 xh = (pre.x - ec.mu) * ec.is;
         if (p.ex_bn_relu) {
-            const f32x4 yy = p.ex_gate ? *reinterpret_cast<const f32x4*>(p.ex_gate + idx) : xh * ec.ga + ec.be;    // bn_bwd_reduce_mg_kernel's mask
+            const f32x4 yy = p.ex_gate ? pre.g : xh * ec.ga + ec.be;    // bn_bwd_reduce_mg_kernel's mask
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = yy[e] > 0.f ? v[e] : 0.f;
         }
@@ -213,9 +230,15 @@ __device__ __forceinline__ void epi_flush(const ConvP& p, const EpiCtx& ec, floa
 
 // The extras are compiled into the EX = true instantiation of a kernel only: with them in every instantiation the epilogue, not the
 // K loop, set the register count (conv_igemm_kernel 128 x 128: 166 -> 176 registers, 3 -> 2 waves per SIMD).
+__device__ __forceinline__ f32x4 epi_apply(const ConvP& p, EpiCtx& ec, f32x4 v, size_t idx) { return epi_apply(p, ec, v, epi_prefetch(p, idx, true)); }
 template <bool EX>
 __device__ __forceinline__ f32x4 epi_apply_t(const ConvP& p, EpiCtx& ec, f32x4 v, size_t idx) {
     if constexpr (EX) return epi_apply(p, ec, v, idx);
+    else return v;
+}
+template <bool EX>
+__device__ __forceinline__ f32x4 epi_apply_t(const ConvP& p, EpiCtx& ec, f32x4 v, const EpiPre& pre) {
+    if constexpr (EX) return epi_apply(p, ec, v, pre);
     else return v;
 }
 
@@ -556,13 +579,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         // 1x1 layers spend a fifth of a block's life in this epilogue)
         constexpr int NRES = (WM * 32 + RPASS - 1) / RPASS;
         f32x4 resv[NRES];
-        const bool use_res = MODE == MODE_FWD && residual != nullptr && p.ksplit <= 1 && n < p.N;
-        if (use_res) {
+        EpiPre pre[NRES];                                     // (the gates' tensors: all rows at once, see EpiPre)
+        const bool use_res = residual != nullptr && p.ksplit <= 1 && n < p.N;
+        auto row_of = [&](int u, int& rr) -> int {            // output row (pixel index) of this thread's u-th row of the pass, -1 = none
+            rr = r0 + u * RPASS;
+            int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
+            if (rr >= WM * 32 || m >= p.M) return -1;
+            if (MODE == MODE_DGRAD && p.par) {                // class row -> pixel of the full-resolution gradient
+                const int bb = m / (p.Hc * p.Wc), rem = m % (p.Hc * p.Wc);
+                m = (bb * p.H + 2 * (rem / p.Wc) + pc.py) * p.W + 2 * (rem % p.Wc) + pc.px;
+            }
+            return m;
+        };
+        if (use_res || EX) {
 #pragma unroll
             for (int u = 0; u < NRES; ++u) {
-                const int rr = r0 + u * RPASS;
-                const int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
-                resv[u] = (rr < WM * 32 && m < p.M) ? *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                int rr;
+                const int m = row_of(u, rr);
+                const bool live = m >= 0 && p.ksplit <= 1 && n < p.N;
+                resv[u] = (use_res && live) ? *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (EX) pre[u] = epi_prefetch(p, (size_t)(m < 0 ? 0 : m) * p.N + n, live);
             }
         }
         __syncthreads();
@@ -570,16 +606,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         if (n < p.N) {
 #pragma unroll
             for (int u = 0; u < NRES; ++u) {
-                const int rr = r0 + u * RPASS;
-                if (rr >= WM * 32) break;
-                int m = m0 + ((rr >> 5) * TM + i) * 32 + (rr & 31);
-                if (m >= p.M) continue;
-                if (MODE == MODE_DGRAD && p.par) {            // class row -> pixel of the full-resolution gradient
-                    const int bb = m / (p.Hc * p.Wc), rem = m % (p.Hc * p.Wc);
-                    m = (bb * p.H + 2 * (rem / p.Wc) + pc.py) * p.W + 2 * (rem % p.Wc) + pc.px;
-                }
+                int rr;
+                const int m = row_of(u, rr);
+                if (m < 0) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
                 if (p.ksplit > 1) {                           // raw partial sum of this K slice; splitk_finish_kernel does the rest
+                    // (K slices never meet the parity classes: the rows of `part` are the output's rows)
                     *reinterpret_cast<f32x4*>(p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
                     continue;
                 }
@@ -588,10 +620,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     if (use_res) v += resv[u];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-                } else if (residual) {                        // data gradient + the gradient that reached the same tensor by another path
-                    v += *reinterpret_cast<const f32x4*>(residual + (size_t)m * p.N + n);
+                } else if (use_res) {                         // data gradient + the gradient that reached the same tensor by another path
+                    v += resv[u];
                 }
-                *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = epi_apply_t<EX>(p, ec, v, (size_t)m * p.N + n);
+                *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = epi_apply_t<EX>(p, ec, v, pre[u]);
             }
         }
     }
@@ -980,23 +1012,35 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     Cs[(wm * 32 + ih * 16 + 4 * kg + r) * LDC + (wn * NB + j) * 16 + l16] = acc[2 * i + ih][j][r];
+        // what the rows of this pass read from memory (residual / second gradient, the gates' tensors): requested before the barrier,
+        // all rows at once (see EpiPre)
+        constexpr int NRW = WM * 32 / RPASS;
+        f32x4 resv[NRW];
+        EpiPre pre[NRW];
+#pragma unroll
+        for (int u = 0; u < NRW; ++u) {
+            const int rr = r0 + u * RPASS, pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
+            const size_t idx = (((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW) * p.N + n;
+            resv[u] = (residual && n < p.N) ? *reinterpret_cast<const f32x4*>(residual + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EX) pre[u] = epi_prefetch(p, idx, n < p.N);
+        }
         __syncthreads();
         if constexpr (EX) if (i == 0 && p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + c4 * 4) * sc + sh;     // the tile's first row = the statistics' shift
         if (n < p.N) {
-#pragma unroll 4
-            for (int rr = r0; rr < WM * 32; rr += RPASS) {
-                const int pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
+#pragma unroll
+            for (int u = 0; u < NRW; ++u) {
+                const int rr = r0 + u * RPASS, pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
                 const size_t m = ((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
                 if (MODE == MODE_FWD) {
                     v = v * sc + sh;
-                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
+                    if (residual) v += resv[u];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
                 } else if (residual) {
-                    v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
+                    v += resv[u];
                 }
-                *reinterpret_cast<f32x4*>(out + m * p.N + n) = epi_apply_t<EX>(p, ec, v, m * p.N + n);
+                *reinterpret_cast<f32x4*>(out + m * p.N + n) = epi_apply_t<EX>(p, ec, v, pre[u]);
             }
         }
     }
@@ -1270,12 +1314,25 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     Cs[(wm * 32 + ih * 16 + 4 * kg + r) * LDC + (wn * NB + j) * 16 + l16] = acc[2 * i + ih][j][r];
+        // what the rows of this pass read from memory (residual / second gradient, the gates' tensors): requested before the barrier,
+        // all rows at once (see EpiPre); K slices: nothing (the finish pass applies the epilogue)
+        constexpr int NRW = WM * 32 / RPASS;
+        f32x4 resv[NRW];
+        EpiPre pre[NRW];
+#pragma unroll
+        for (int u = 0; u < NRW; ++u) {
+            const int rr = r0 + u * RPASS, pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
+            const size_t idx = (((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW) * p.N + n;
+            const bool live = p.ksplit <= 1 && n < p.N;
+            resv[u] = (residual && live) ? *reinterpret_cast<const f32x4*>(residual + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EX) pre[u] = epi_prefetch(p, idx, live);
+        }
         __syncthreads();
         if constexpr (EX) if (i == 0 && p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + c4 * 4) * sc + sh;     // the tile's first row = the statistics' shift
         if (n < p.N) {
-#pragma unroll 4
-            for (int rr = r0; rr < WM * 32; rr += RPASS) {
-                const int pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
+#pragma unroll
+            for (int u = 0; u < NRW; ++u) {
+                const int rr = r0 + u * RPASS, pix = ((rr >> 5) * TM + i) * 32 + (rr & 31);
                 const size_t m = ((size_t)b * Hm + y0 + pix / TW) * Wm + x0 + pix % TW;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4 * 4);
                 if (p.ksplit > 1) {                           // raw partial sum of this K slice; splitk_finish_kernel does the rest
@@ -1284,13 +1341,13 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
                 }
                 if (MODE == MODE_FWD) {
                     v = v * sc + sh;
-                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
+                    if (residual) v += resv[u];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
                 } else if (residual) {
-                    v += *reinterpret_cast<const f32x4*>(residual + m * p.N + n);
+                    v += resv[u];
                 }
-                *reinterpret_cast<f32x4*>(out + m * p.N + n) = epi_apply_t<EX>(p, ec, v, m * p.N + n);
+                *reinterpret_cast<f32x4*>(out + m * p.N + n) = epi_apply_t<EX>(p, ec, v, pre[u]);
             }
         }
     }
@@ -4448,6 +4505,15 @@ __global__ __launch_bounds__(256) void splitk_finish_ex_kernel(ConvP p, const fl
         for (int z = 1; z < p.ksplit; ++z) f += *reinterpret_cast<const f32x4*>(p.part + (size_t)z * MN + i0);
         ec.sh = f * sc + sh;
     }
+    f32x4 resv[NR];
+    EpiPre pre[NR];                                            // (residual and the gates' tensors: all rows before the first store, see EpiPre)
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int m = m0 + k + u * RPASS;
+        const size_t i = (size_t)(m < p.M ? m : 0) * p.N + n;
+        resv[u] = (residual && m < p.M) ? *reinterpret_cast<const f32x4*>(residual + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pre[u] = epi_prefetch(p, i, m < p.M);
+    }
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
         const int m = m0 + k + u * RPASS;
@@ -4456,10 +4522,10 @@ __global__ __launch_bounds__(256) void splitk_finish_ex_kernel(ConvP p, const fl
         f32x4 r = v[u];
         if (scale) r = r * sc;
         if (shift) r += sh;
-        if (residual) r += *reinterpret_cast<const f32x4*>(residual + i);
+        if (residual) r += resv[u];
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = apply_act(r[e], act);
-        *reinterpret_cast<f32x4*>(out + i) = epi_apply(p, ec, r, i);
+        *reinterpret_cast<f32x4*>(out + i) = epi_apply(p, ec, r, pre[u]);
     }
     epi_flush(p, ec, red, tid, V4, RPASS, tile, n);
 }
