@@ -1951,28 +1951,43 @@ __global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(Con
         __syncthreads();
         f32x4 colsum = {0.f, 0.f, 0.f, 0.f};                        // (extras of this kernel: gates 1 / 2 and statistics 2 only -- written out here:
         if (n < p.N) {                                              //  the common EpiCtx keeps 28 registers live that this kernel does not have)
+            // residual / gate rows: requested before the stores (see EpiPre), four rows at a time (two in the 32-column form, which is at its register limit)
+            constexpr int CH = NT == 2 ? 2 : 4;
 #pragma unroll
-            for (int k = 0; k < NROW; ++k) {
+            for (int k0 = 0; k0 < NROW; k0 += CH) {
+            f32x4 resv[CH], gv[CH];
+#pragma unroll
+            for (int kk = 0; kk < CH; ++kk) {
+                const int k = k0 + kk;
+                const int rr = r0e + k * RPASS;
+                const size_t idx = (((size_t)b * Hm + ty0 + rr / TW) * Wm + tx0 + rr % TW) * p.N + n;
+                resv[kk] = residual ? *reinterpret_cast<const f32x4*>(residual + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (EX) gv[kk] = p.ex_gate_act ? *reinterpret_cast<const f32x4*>(p.ex_gate + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kk = 0; kk < CH; ++kk) {
+                const int k = k0 + kk;
                 const int rr = r0e + k * RPASS;                     // pixel of the tile
                 const size_t idx = (((size_t)b * Hm + ty0 + rr / TW) * Wm + tx0 + rr % TW) * p.N + n;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + c4e * 4);
                 if (MODE == MODE_FWD) {
                     v = v * sc + sh;
-                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + idx);
+                    if (residual) v += resv[kk];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
                 } else if (residual) {                              // data gradient + the gradient that reached the same tensor by another path
-                    v += *reinterpret_cast<const f32x4*>(residual + idx);
+                    v += resv[kk];
                 }
                 if constexpr (EX) {
                     if (p.ex_gate_act) {                            // = epi_apply's gates 1 / 2
-                        const f32x4 g = *reinterpret_cast<const f32x4*>(p.ex_gate + idx);
+                        const f32x4 g = gv[kk];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= g[e] > 0.f ? 1.f : (p.ex_gate_act == 2 ? g[e] + 1.f : 0.f);
                     }
                     colsum += v;
                 }
                 *reinterpret_cast<f32x4*>(out + idx) = v;
+            }
             }
         }
         if constexpr (EX) {
