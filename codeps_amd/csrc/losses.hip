@@ -10,6 +10,7 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int RB = 1024;                  // max partial blocks of the generic reductions
 
 static inline int blocks_for(long long n) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, RB)); }
@@ -260,7 +261,30 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const float* __restric
     }
 }
 
-// d probs: selected pixels get gout/k * w_t * pw * (softmax(p) - onehot); ties at tau share (k-n_gt)/n_eq
+// d probs: selected pixels get gout/k * w_t * pw * (softmax(p) - onehot); ties at tau share (k-n_gt)/n_eq.
+// One pixel's row: p -> d (may be the same memory: d[c] depends on p[c] and the row's constants only)
+__device__ __forceinline__ void sem_bwd_row(const float* p, float* d, int C, int Cp, int t, float l, float tau, float frac, float go,
+                                            const uint8_t* __restrict__ pw, const float* __restrict__ cw, int ignore, unsigned long long drop,
+                                            long long i) {
+    float sel = l > tau ? 1.f : (l == tau ? frac : 0.f);
+    if (t == ignore || t >= C || (drop && ((drop >> t) & 1ull))) sel = 0.f;
+    float lse;
+    int ct = t;
+    if (sel != 0.f) {
+        if (drop) ce_of_probs_kept(p, C, drop, t, lse, ct); else ce_of_probs(p, C, t, lse);
+        if (ct < 0) sel = 0.f;
+    }
+    if (sel == 0.f) {
+        for (int c = 0; c < Cp; ++c) d[c] = 0.f;
+        return;
+    }
+    float coef = go * sel;
+    if (cw) coef *= cw[t];
+    if (pw) coef *= (float)pw[i];
+    for (int c = 0; c < C; ++c) d[c] = ((drop >> c) & 1ull) ? 0.f : coef * (expf(p[c] - lse) - (c == ct ? 1.f : 0.f));
+    for (int c = C; c < Cp; ++c) d[c] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void sem_bwd_kernel(const float* __restrict__ probs, int C, int Cp, const uint8_t* __restrict__ target,
                                                       const uint8_t* __restrict__ pw, const float* __restrict__ cw, int ignore,
                                                       unsigned long long drop, long long N,
@@ -269,28 +293,44 @@ __global__ __launch_bounds__(256) void sem_bwd_kernel(const float* __restrict__ 
     const float tau = state ? __uint_as_float(state[0]) : -1.f;
     const float frac = state ? (float)(k - state[2]) / (float)max(state[3], 1u) : 1.f;
     const float go = gout[0] / (float)k;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
-        float* d = dprobs + (size_t)i * Cp;
-        const int t = target[i];
-        const float l = fmaxf(loss_px[i], 0.f);
-        float sel = l > tau ? 1.f : (l == tau ? frac : 0.f);
-        if (t == ignore || t >= C || (drop && ((drop >> t) & 1ull))) sel = 0.f;
-        const float* p = probs + (size_t)i * Cp;
-        float lse;
-        int ct = t;
-        if (sel != 0.f) {
-            if (drop) ce_of_probs_kept(p, C, drop, t, lse, ct); else ce_of_probs(p, C, t, lse);
-            if (ct < 0) sel = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
+        sem_bwd_row(probs + (size_t)i * Cp, dprobs + (size_t)i * Cp, C, Cp, target[i], fmaxf(loss_px[i], 0.f), tau, frac, go, pw, cw, ignore, drop, i);
+}
+
+// The same through LDS for Cp <= 32 (round 5): a thread per pixel walking its Cp floats reads and writes 4 bytes per lane at a stride of
+// Cp floats -- 64 lanes touch 40 cache lines per instruction (2.2 TB/s at Cp = 20).  Here a block moves its 256 pixels x Cp floats with
+// 16-byte accesses in memory order, each thread works on its row in LDS (odd pitch: conflict-free), in place.  Same arithmetic per row.
+__global__ __launch_bounds__(256) void sem_bwd_tile_kernel(const float* __restrict__ probs, int C, int Cp, const uint8_t* __restrict__ target,
+                                                           const uint8_t* __restrict__ pw, const float* __restrict__ cw, int ignore,
+                                                           unsigned long long drop, long long N,
+                                                           const float* __restrict__ loss_px, const uint32_t* __restrict__ state, uint32_t k,
+                                                           const float* __restrict__ gout, float* __restrict__ dprobs) {
+    __shared__ float tile[256 * 33];
+    const float tau = state ? __uint_as_float(state[0]) : -1.f;
+    const float frac = state ? (float)(k - state[2]) / (float)max(state[3], 1u) : 1.f;
+    const float go = gout[0] / (float)k;
+    const int pitch = Cp + 1, q4 = Cp / 4;
+    const long long chunks = (N + 255) / 256;
+    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const long long i0 = ch * 256;
+        const int npx = (int)min((long long)256, N - i0);
+        __syncthreads();                                       // the previous chunk's stores have read the tile
+        for (int e = threadIdx.x; e < npx * q4; e += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(probs + (size_t)i0 * Cp + (size_t)e * 4);
+            float* dst = tile + (e / q4) * pitch + (e % q4) * 4;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
         }
-        if (sel == 0.f) {
-            for (int c = 0; c < Cp; ++c) d[c] = 0.f;
-            continue;
+        __syncthreads();
+        if ((int)threadIdx.x < npx) {
+            const long long i = i0 + threadIdx.x;
+            float* row = tile + threadIdx.x * pitch;
+            sem_bwd_row(row, row, C, Cp, target[i], fmaxf(loss_px[i], 0.f), tau, frac, go, pw, cw, ignore, drop, i);
         }
-        float coef = go * sel;
-        if (cw) coef *= cw[t];
-        if (pw) coef *= (float)pw[i];
-        for (int c = 0; c < C; ++c) d[c] = ((drop >> c) & 1ull) ? 0.f : coef * (expf(p[c] - lse) - (c == ct ? 1.f : 0.f));
-        for (int c = C; c < Cp; ++c) d[c] = 0.f;
+        __syncthreads();
+        for (int e = threadIdx.x; e < npx * q4; e += 256) {
+            const float* src = tile + (e / q4) * pitch + (e % q4) * 4;
+            *reinterpret_cast<f32x4*>(dprobs + (size_t)i0 * Cp + (size_t)e * 4) = f32x4{src[0], src[1], src[2], src[3]};
+        }
     }
 }
 
@@ -431,7 +471,6 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__
 // dxp [B][H+2p][W+2p][C] (gradient w.r.t. the reflect-padded tensor) -> dx [B][H][W][C]
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dxp, int B, int H, int W, int C, int p,
                                                            float* __restrict__ dx) {
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int G = C / 4, Hp = H + 2 * p, Wp = W + 2 * p;
     const long long total = (long long)B * H * W * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -579,7 +618,9 @@ extern "C" int codeps_semantic_loss_bwd(const float* probs, int c, int c_pad, co
     const uint32_t* state = (const uint32_t*)(part + (size_t)RB * 32);
     const bool topk = top_k < 1.0;
     const uint32_t k = topk ? (uint32_t)((double)top_k * (double)pixels) : (uint32_t)pixels;
-    hipLaunchKernelGGL(sem_bwd_kernel, dim3(blocks_for(pixels)), dim3(256), 0, (hipStream_t)stream, probs, c, c_pad, target, pixel_weights,
+    static const int tile_on = getenv("CODEPS_SEM_TILE") ? atoi(getenv("CODEPS_SEM_TILE")) : 1;          // A/B switch
+    auto kb = (tile_on && c_pad <= 32 && (c_pad % 4) == 0) ? sem_bwd_tile_kernel : sem_bwd_kernel;
+    hipLaunchKernelGGL(kb, dim3(blocks_for(pixels)), dim3(256), 0, (hipStream_t)stream, probs, c, c_pad, target, pixel_weights,
                        class_weights, ignore_index, dropped_channels, pixels, lpx, topk ? state : (const uint32_t*)nullptr, k, grad_loss, grad_probs);
     CODEPS_CHECK_LAUNCH("sem_bwd_kernel");
     return CODEPS_OK;
