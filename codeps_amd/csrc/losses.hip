@@ -167,6 +167,49 @@ __global__ __launch_bounds__(256) void sem_px_kernel(const float* __restrict__ p
     }
 }
 
+// sem_px_kernel through an LDS tile for Cp <= 32 (see sem_bwd_tile_kernel): the block's 256 rows arrive by 16-byte loads in memory order
+__global__ __launch_bounds__(256) void sem_px_tile_kernel(const float* __restrict__ probs, int C, int Cp, const uint8_t* __restrict__ target,
+                                                          const uint8_t* __restrict__ pw, const float* __restrict__ cw, int ignore,
+                                                          unsigned long long drop, long long N, float* __restrict__ loss_px,
+                                                          uint32_t* __restrict__ hist0) {
+    __shared__ float tile[256 * 33];
+    __shared__ uint32_t h[256];
+    if (hist0) h[threadIdx.x] = 0;
+    const int pitch = Cp + 1, q4 = Cp / 4;
+    const long long chunks = (N + 255) / 256;
+    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const long long i0 = ch * 256;
+        const int npx = (int)min((long long)256, N - i0);
+        __syncthreads();                                       // the previous chunk's rows have been read (first trip: h is zero)
+        for (int e = threadIdx.x; e < npx * q4; e += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(probs + (size_t)i0 * Cp + (size_t)e * 4);
+            float* dst = tile + (e / q4) * pitch + (e % q4) * 4;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < npx) {
+            const long long i = i0 + threadIdx.x;
+            const float* row = tile + threadIdx.x * pitch;
+            const int t = target[i];
+            float l = 0.f;
+            if (t != ignore && t < C && !(drop && ((drop >> t) & 1ull))) {
+                float lse;
+                int ct = t;
+                if (drop) l = ce_of_probs_kept(row, C, drop, t, lse, ct);
+                else l = ce_of_probs(row, C, t, lse);
+                if (cw && ct >= 0) l *= cw[t];
+                if (pw) l *= (float)pw[i];
+            }
+            loss_px[i] = l;
+            if (hist0) atomicAdd(&h[(l > 0.f ? __float_as_uint(l) : 0u) >> 24], 1u);
+        }
+    }
+    if (hist0) {
+        __syncthreads();
+        if (h[threadIdx.x]) atomicAdd(&hist0[threadIdx.x], h[threadIdx.x]);
+    }
+}
+
 // radix-select state: [0] prefix (key bits found so far), [1] k remaining, [2] n_gt (elements strictly above the final bin), [3] the
 // threshold's multiplicity.  Keys = float bits of non-negative losses (monotone as uint32); four passes of 8 bits, one 256-bin histogram
 // each (hist[pass][256], zeroed by radix_init_kernel).  Round 5: the single-block "pick" launches between the passes are gone -- EVERY
@@ -579,12 +622,14 @@ extern "C" int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, co
     uint32_t* state = (uint32_t*)(part + (size_t)RB * 32);
     uint32_t* hist = state + 32;
     const int nblk = blocks_for(pixels);
+    static const int tile_on = getenv("CODEPS_SEM_TILE") ? atoi(getenv("CODEPS_SEM_TILE")) : 1;          // A/B switch
+    auto kpx = (tile_on && c_pad <= 32 && (c_pad % 4) == 0) ? sem_px_tile_kernel : sem_px_kernel;
     if (top_k < 1.0) {
         const uint32_t k = (uint32_t)((double)top_k * (double)pixels);     // int(top_k * numel), algos/semantic_seg.py:62
         CODEPS_REQUIRE(k >= 1, CODEPS_ERR_ARG, "semantic_loss_fwd: top-k selects zero pixels");
         // 7 launches (round 4: 12): init | per-pixel loss + pass 0 | passes 1-3, each picking the previous one's bin itself | sum (+ last pick) | finish
         hipLaunchKernelGGL(radix_init_kernel, dim3(1), dim3(256), 0, st, state, hist, k);
-        hipLaunchKernelGGL(sem_px_kernel, dim3(blocks_for(pixels)), dim3(256), 0, st, probs, c, c_pad, target, pixel_weights, class_weights,
+        hipLaunchKernelGGL(kpx, dim3(blocks_for(pixels)), dim3(256), 0, st, probs, c, c_pad, target, pixel_weights, class_weights,
                            ignore_index, drop, pixels, lpx, hist);
         CODEPS_CHECK_LAUNCH("sem_px_kernel");
         for (int pass = 1; pass < 4; ++pass)
@@ -593,7 +638,7 @@ extern "C" int codeps_semantic_loss_fwd(const float* probs, int c, int c_pad, co
                            (const uint32_t*)hist, part);
         hipLaunchKernelGGL(topk_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, (const uint32_t*)state, k, loss);
     } else {
-        hipLaunchKernelGGL(sem_px_kernel, dim3(blocks_for(pixels)), dim3(256), 0, st, probs, c, c_pad, target, pixel_weights, class_weights,
+        hipLaunchKernelGGL(kpx, dim3(blocks_for(pixels)), dim3(256), 0, st, probs, c, c_pad, target, pixel_weights, class_weights,
                            ignore_index, drop, pixels, lpx, (uint32_t*)nullptr);
         CODEPS_CHECK_LAUNCH("sem_px_kernel");
         hipLaunchKernelGGL(radix_init_kernel, dim3(1), dim3(256), 0, st, state, hist, 0u);     // tau = 0, n_gt = 0: unused
