@@ -1369,43 +1369,81 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 
 // Cp == 16 (every class head of the path): one thread per pixel row held in four float4 registers (64 contiguous bytes
 // per lane, whole cache lines per wave) instead of scalar loads through an indexed local array
+// Round 5: the rows travel through an LDS tile -- the block's 256 rows are read and written with 16-byte accesses in memory order (a wave
+// = 1 KB contiguous) and a thread picks its row out of LDS (68-byte pitch).  A thread reading its own 64 bytes straight from memory issued
+// four instructions of 16 bytes at a 64-byte lane stride: 3.3 TB/s.  Same arithmetic per row.
+constexpr int SM_PITCH = 17;
+__device__ __forceinline__ void rows16_in(const float* __restrict__ x, long long r0, int nrow, float* tile) {
+    for (int e = threadIdx.x; e < nrow * 4; e += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r0 * 16 + (size_t)e * 4);
+        float* d = tile + (e >> 2) * SM_PITCH + (e & 3) * 4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+}
+__device__ __forceinline__ void rows16_out(const float* tile, long long r0, int nrow, float* __restrict__ y) {
+    for (int e = threadIdx.x; e < nrow * 4; e += 256) {
+        const float* s = tile + (e >> 2) * SM_PITCH + (e & 3) * 4;
+        *reinterpret_cast<f32x4*>(y + (size_t)r0 * 16 + (size_t)e * 4) = f32x4{s[0], s[1], s[2], s[3]};
+    }
+}
+
 __global__ __launch_bounds__(256) void softmax16_fwd_kernel(const float* __restrict__ x, long long M, int C, float* __restrict__ y) {
-    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
-        f32x4 v[4];
+    __shared__ float tile[256 * SM_PITCH];
+    const long long chunks = (M + 255) / 256;
+    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const long long r0 = ch * 256;
+        const int nrow = (int)min((long long)256, M - r0);
+        __syncthreads();
+        rows16_in(x, r0, nrow, tile);
+        __syncthreads();
+        if ((int)threadIdx.x < nrow) {
+            float* row = tile + threadIdx.x * SM_PITCH;
+            float v[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(x + (size_t)r * 16 + k * 4);
-        float mx = -INFINITY;
+            for (int c = 0; c < 16; ++c) v[c] = row[c];
+            float mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) if (c < C) mx = fmaxf(mx, v[c >> 2][c & 3]);
-        float s = 0.f;
+            for (int c = 0; c < 16; ++c) if (c < C) mx = fmaxf(mx, v[c]);
+            float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float e = c < C ? expf(v[c >> 2][c & 3] - mx) : 0.f;
-            v[c >> 2][c & 3] = e; s += e;
+            for (int c = 0; c < 16; ++c) {
+                const float e = c < C ? expf(v[c] - mx) : 0.f;
+                v[c] = e; s += e;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) row[c] = v[c] / s;          // same rounding as the generic kernel (v / s)
         }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c >> 2][c & 3] = v[c >> 2][c & 3] / s;      // same rounding as the generic kernel (v / s)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(y + (size_t)r * 16 + k * 4) = v[k];
+        __syncthreads();
+        rows16_out(tile, r0, nrow, y);
     }
 }
 
 __global__ __launch_bounds__(256) void softmax16_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long M, int C,
                                                             float* __restrict__ dx) {
-    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
-        f32x4 d[4], p[4];
+    __shared__ float td[256 * SM_PITCH];
+    __shared__ float tp[256 * SM_PITCH];
+    const long long chunks = (M + 255) / 256;
+    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const long long r0 = ch * 256;
+        const int nrow = (int)min((long long)256, M - r0);
+        __syncthreads();
+        rows16_in(dy, r0, nrow, td);
+        rows16_in(y, r0, nrow, tp);
+        __syncthreads();
+        if ((int)threadIdx.x < nrow) {
+            float* d = td + threadIdx.x * SM_PITCH;
+            const float* p = tp + threadIdx.x * SM_PITCH;
+            float dv[16], pv[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            d[k] = *reinterpret_cast<const f32x4*>(dy + (size_t)r * 16 + k * 4);
-            p[k] = *reinterpret_cast<const f32x4*>(y + (size_t)r * 16 + k * 4);
+            for (int c = 0; c < 16; ++c) { dv[c] = d[c]; pv[c] = p[c]; }
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) if (c < C) dot += dv[c] * pv[c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) d[c] = c < C ? pv[c] * (dv[c] - dot) : 0.f;
         }
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) if (c < C) dot += d[c >> 2][c & 3] * p[c >> 2][c & 3];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) d[c >> 2][c & 3] = c < C ? p[c >> 2][c & 3] * (d[c >> 2][c & 3] - dot) : 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dx + (size_t)r * 16 + k * 4) = d[k];
+        __syncthreads();
+        rows16_out(td, r0, nrow, dx);
     }
 }
 
