@@ -407,6 +407,35 @@ __global__ __launch_bounds__(256) void inst_bwd_kernel(int kind, const float* __
                                                        const float* __restrict__ gout, float* __restrict__ dpred) {
     const long long N = (long long)B * HW;
     const float go = gout[0] * scale;
+    if (C <= 4 && (Cp % 4) == 0) {
+        // (round 5) the heads' 1 / 2 real channels sit in the first quad of a 16-channel row: one thread per (pixel, quad), 16-byte accesses
+        // in memory order -- quad 0 computes, the others write zeros (a thread per pixel issued Cp scalar stores at a Cp-float stride)
+        const int q4 = Cp / 4;
+        for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < N * q4; j += (long long)gridDim.x * 256) {
+            const long long i = j / q4;
+            f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+            if (j % q4 == 0) {
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(pred + (size_t)i * Cp);
+                const float pr[4] = {pv[0], pv[1], pv[2], pv[3]};
+                if (kind == 2) {
+                    const int t = tu[i];
+                    if (t != ignore && t < C) {
+                        float lse;
+                        ce_of_probs(pr, C, t, lse);
+                        for (int c = 0; c < C; ++c) dv[c] = go * (expf(pr[c] - lse) - (c == t ? 1.f : 0.f));
+                    }
+                } else {
+                    const int b = (int)(i / HW), hw = (int)(i % HW);
+                    for (int c = 0; c < C; ++c) {
+                        const float df = pr[c] - tf[((size_t)b * C + c) * HW + hw];
+                        dv[c] = kind == 0 ? go * 2.f * df : go * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4*>(dpred + j * 4) = dv;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
         const float* p = pred + (size_t)i * Cp;
         float* d = dpred + (size_t)i * Cp;
