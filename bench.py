@@ -566,9 +566,10 @@ def main():
             "step_ms": {"median": round(per_step[len(per_step) // 2], 3), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
                         "images_per_sec_at_median": round(n_images * world / (per_step[len(per_step) // 2] * 1e-3), 2)},
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": ("fp32 end to end; conv forward / data-gradient / halo-tile weight-gradient operands enter the matrix cores as "
+            "arithmetic": ("fp32 end to end; conv forward / data-gradient / halo-tile and 1x1 weight-gradient operands enter the matrix cores as "
                            "exact 3-way bf16 splits (six bf16 products per multiply, fp32 accumulate: product error ~6e-9 relative, below "
-                           "fp32 rounding); the other weight gradients and the 16-column kernels on the f32 MFMA") if os.environ.get("CODEPS_SPLIT", "3") == "3" else
+                           "fp32 rounding); the <= 32-channel weight gradients, the 1x1 16-column kernels, the last up-convolution and the "
+                           "1-channel disparity head on the f32 MFMA") if os.environ.get("CODEPS_SPLIT", "3") == "3" else
                           ("CODEPS_SPLIT=" + os.environ.get("CODEPS_SPLIT", "3") + " (non-default arithmetic, see codeps_amd/csrc/conv.hip)"),
             "config": {"workload": workload,
                        "global_batch": n_images * world, "parallelism": f"dp{world}", "launch": "hip-graph" if graph is not None else "eager",
