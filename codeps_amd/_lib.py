@@ -218,6 +218,7 @@ DIAG_SIGNATURES = {
     "codeps_diag_feed_rate": (c_int, [I, I, I, I, I, P, LL, P, P, P]),
     "codeps_diag_mfma_rate_clock": (c_int, [I, I, I, I, I, P, P, P, P]),
     "codeps_diag_mfma_valu_clock": (c_int, [I, I, I, I, I, P, P, P, P]),
+    "codeps_diag_mfma_once": (c_int, [I, P, P, P, P, P]),
     "codeps_split_pack_rows": (c_int, [P, LL, I, I, P, P]),
     "codeps_conv1x1_split_fwd": (c_int, [P, LL, I, I, P, P, P, P, I, P, P]),
 }

@@ -22,6 +22,7 @@
 // Variants: 16-column kernels (N <= 16, v_mfma_f32_16x16x4_f32, operands straight to registers), split-K for small-M
 // launches, per-tap / halo-tile / stem weight-gradient kernels.  DESIGN.md section 3 has the measurements behind each choice.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -73,6 +74,9 @@ struct ConvP {
     // weights of this launch pre-split into three bf16 pieces ([row][K group of 32][piece][32], written by the weight pack
     // behind its fp32 part); the 3-piece kernel stages its B operand from here with plain copies
     const void* w3;
+    // ... and as two fp16 pieces of w * 2^kb ([row][K group of 32][piece][32]); w2s[0] = 2^-kb (the pack's per-tensor scale, inverted)
+    const void* w2;
+    const float* w2s;
     // epilogue extras (codeps_conv_epilogue; all optional, applied to the value the epilogue is about to store, after the residual /
     // second-gradient add):  a GATE  v *= g'  and per-M-tile COLUMN STATISTICS of the gated v
     const float* ex_gate;       // gate 1 / 2: the activation's output [M][N];  gate 3: the block output when a residual fed the ReLU (else null)
@@ -114,6 +118,42 @@ __device__ __forceinline__ void split_bf16(const f32x4 v, u16x4 (&pc)[NP]) {
             pc[q][e] = h;
             r[e] -= __builtin_bit_cast(float, (unsigned)h << 16);
         }
+}
+
+// ---- Two-piece fp16 arithmetic (round 6; ARITH = 16 in the kernels that have it, CODEPS_SPLIT=16 / codeps_conv2d_set_arith(16)).
+// x s = hi + lo with hi = rn16(x s), lo = rn16(x s - hi): |x s - hi - lo| <= 2^-22 |x s| (two 11-bit significands and the sign of lo),
+// and the THREE products hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_f16 (fp16 x fp16 is exact in fp32, fp32 accumulation) drop a term
+// <= 2^-24: half the matrix instructions of the 3 x bf16 split and 4 instead of 6 bytes per element in LDS, at an operand error of the size
+// of fp32's own rounding.  fp16 has 5 exponent bits, so every operand carries a power-of-two scale s that puts its largest magnitude
+// just below 2^15: weights per tensor, found by the pack (pack_amax_kernel); activations / gradients per BLOCK and K chunk inside the
+// kernel (the running maximum exponent of the tiles staged so far; when it grows the accumulators are multiplied by the exact ratio),
+// so no tensor needs a side channel for its range.  Elements more than 2^17 below the block's maximum lose their lo piece gradually
+// (fp16 subnormals, honoured by the instruction: tools/f16_mfma_probe.py): absolute error <= 2^-40 of that maximum.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int F16_TARGET = 14;      // |x s| < 2^(F16_TARGET + 1)
+constexpr int F16_EMIN = 27;        // operands below 2^-100 count as 2^-100 when the scale is chosen
+
+__device__ __forceinline__ void split_f16(const f32x4 v, const float s, u16x4& hi, u16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h = (_Float16)(v[e] * s);
+        const _Float16 l = (_Float16)__builtin_fmaf(v[e], s, -(float)h);
+        hi[e] = __builtin_bit_cast(unsigned short, h);
+        lo[e] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+// biased exponent of the largest magnitude among the wave's values m (>= 0): every lane returns it
+__device__ __forceinline__ int wave_max_exponent(float m) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    return (int)(__builtin_bit_cast(unsigned, m) >> 23);
+}
+// scale 2^(F16_TARGET - (e - 127)) of a tile whose maximum exponent is e, its inverse, and the factor 2^(e_old - e_new) that re-bases sums
+__device__ __forceinline__ float f16_scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(254 + F16_TARGET - e) << 23); }
+__device__ __forceinline__ float f16_inv_scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(e - F16_TARGET) << 23); }
+__device__ __forceinline__ float f16_rebase(int e_old, int e_new) {
+    const int d = e_old - e_new;
+    return d < -126 ? 0.f : __builtin_bit_cast(float, (unsigned)(127 + d) << 23);
 }
 
 CODEPS_STAMP_DECL(conv)
@@ -1066,11 +1106,15 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 #define CODEPS_ABLATE_RING 0
 #endif
 
-template <int MODE, int TN, bool EX = false>
+// ARITH 3: three bf16 pieces, six products (rounds 2-5).  ARITH 16: two fp16 pieces, three products, block-local scales (round 6).
+template <int MODE, int TN, bool EX = false, int ARITH = 3>
 __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ residual, float* __restrict__ out) {
-    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = 3;
+    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = ARITH == 16 ? 2 : 3;
+    constexpr bool H16 = ARITH == 16;
+    constexpr int EB = NP * 2;                                // bytes per element of the pre-split weights
+    constexpr int NPROD = NP * (NP + 1) / 2;
     constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;
     constexpr int BN = 32 * WN * TN;
     constexpr int LDK = (NP * BK + 8) / 2;
@@ -1080,12 +1124,16 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     // cycles).  Activation tile: 224-byte pitch (14 slots per row: conflict-free for every alignment of the 16 consecutive halo
     // positions a fragment reads).  Weight tiles: the pitch stays 208 (LDS DMA image = pack rows + one pad segment) and the k groups
     // of rows 4 .. 11 (mod 16) are stored pairwise swapped -- the DMA picks the source segment per lane, the reader flips bit 0 of kg.
+    // Two pieces: weight rows 144 bytes (9 slots: odd, so the pairwise swap works as above), activation rows 160 bytes (10 slots == -6 mod 16:
+    // the 16 consecutive positions of a fragment at k group 0 cover the even slots, k group 1 the odd ones, for every alignment).
     constexpr int LDKA = CODEPS_HALO_SWZ ? LDK + 4 : LDK;
+    constexpr int SEG = LDK / 4;                              // 16-byte slots per weight row in LDS (the last one is padding)
     constexpr int APASS = (HPIX * 4 + 255) / 256, NALOAD = APASS * 2;
     constexpr int RING = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                  // [HPIX + 1][LDKA]  (row HPIX: staging tasks past the tile)
     float* Bs = smem + (HPIX + 1) * LDKA;              // [RING][BN][LDK]
+    int* amax_slot = reinterpret_cast<int*>(Bs + RING * BN * LDK);     // ARITH 16: the waves' maximum exponents of the activation tile in flight
     CODEPS_STAMP_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -1111,22 +1159,22 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     // weights: lane L of the tile's linear 16-byte segment index copies segment L % 13 of row L / 13 (13th = pad); every wave
     // issues BPW instructions per tile (the waves past the last partial group repeat their previous instruction)
     const size_t wrow = (size_t)9 * Kc;
-    constexpr int BINS = BN * 13 / 64, BPW = (BINS + 3) / 4;
-    static_assert((BN * 13) % 64 == 0 && LDK * 4 == 13 * 16 && BPW + NALOAD < 16, "linear DMA layout; vmcnt immediates");
+    constexpr int BINS = BN * SEG / 64, BPW = (BINS + 3) / 4;
+    static_assert((BN * SEG) % 64 == 0 && LDK * 4 == SEG * 16 && (SEG & 1) && BPW + NALOAD < 16, "linear DMA layout; vmcnt immediates");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     unsigned boff[BPW], bins[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
         const int ins = wave_u + 4 * i < BINS ? wave_u + 4 * i : wave_u + 4 * (i - 1);
-        const int L = ins * 64 + lane, row = L / 13, seg = L % 13;
+        const int L = ins * 64 + lane, row = L / SEG, seg = L % SEG;
         const int swz = CODEPS_HALO_SWZ ? (((row >> 2) ^ (row >> 3)) & 1) : 0;       // rows 4 .. 11 (mod 16): k groups swapped pairwise
         bins[i] = (unsigned)ins * 1024u;
-        boff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * 6 + (seg < 12 ? (seg ^ swz) : 0) * 16);
+        boff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * EB + (seg < SEG - 1 ? (seg ^ swz) : 0) * 16);
     }
     i32x4 rsBv;
     {
-        const unsigned long long a = reinterpret_cast<unsigned long long>(p.w3);
-        const size_t bytes = (size_t)p.N * wrow * 6;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(H16 ? p.w2 : p.w3);
+        const size_t bytes = (size_t)p.N * wrow * EB;
         rsBv[0] = (int)__builtin_amdgcn_readfirstlane((unsigned)a);
         rsBv[1] = (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xFFFFu);
         rsBv[2] = (int)__builtin_amdgcn_readfirstlane((unsigned)(bytes < (size_t)GATHER_OOB ? bytes : (size_t)GATHER_OOB));
@@ -1134,7 +1182,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     }
     const unsigned bs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(Bs);
     auto dma_b = [&](int tap, int chunk, int slot) {
-        const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((tap * Kc + (cbase + chunk) * BK) * 6);
+        const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((tap * Kc + (cbase + chunk) * BK) * EB);
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(bs_lds + slot * BN * LDK * 4 + bins[i]);
@@ -1166,6 +1214,19 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             }
         }
     };
+    // ARITH 16: the exponent of the largest magnitude in the tile `areg` holds -> amax_slot[wave] (read behind the next barrier)
+    auto publish_amax = [&]() {
+        if constexpr (H16) {
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < NALOAD; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(areg[i][e]));
+            const int ex = wave_max_exponent(m);
+            if (lane == 0) amax_slot[wave] = ex;
+        }
+    };
+    float a_scale = 1.f;
     auto store_a = [&]() {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
@@ -1178,8 +1239,13 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
                 hi[q] = u16x4{(unsigned short)__builtin_bit_cast(unsigned, areg[i * 2 + 1][q]), 1, 2, 3};
             }
 #else
-            split_bf16<NP>(areg[i * 2], lo);
-            split_bf16<NP>(areg[i * 2 + 1], hi);
+            if constexpr (H16) {
+                split_f16(areg[i * 2], a_scale, lo[0], lo[1]);
+                split_f16(areg[i * 2 + 1], a_scale, hi[0], hi[1]);
+            } else {
+                split_bf16<NP>(areg[i * 2], lo);
+                split_bf16<NP>(areg[i * 2 + 1], hi);
+            }
 #endif
             unsigned short* row = reinterpret_cast<unsigned short*>(As + pos * LDKA);
 #pragma unroll
@@ -1203,7 +1269,8 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     const int bswz = CODEPS_HALO_SWZ ? (((l16 >> 2) ^ (l16 >> 3)) & 1) : 0;
     const unsigned short* brow = reinterpret_cast<const unsigned short*>(Bs + (wn * TN * 32 + l16) * LDK) + (kg ^ bswz) * 8;
 
-    struct Frag { bf16x8 a[NA][NP], b[NB][NP]; };
+    typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
+    struct Frag { frag_t a[NA][NP], b[NB][NP]; };
     auto read_frags = [&](int tap, int slot, Frag& f) {             // tap: compile-time after unrolling; slot: wave-uniform
         const int ky = tap / 3, kx = tap % 3;
         const int toff = ((MODE == MODE_FWD) ? ky * HW + kx : (2 - ky) * HW + (2 - kx)) * LDKA * 2;     // halfwords
@@ -1211,11 +1278,11 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) f.a[i][q] = *reinterpret_cast<const bf16x8*>(arow[i] + toff + q * BK);
+            for (int q = 0; q < NP; ++q) f.a[i][q] = *reinterpret_cast<const frag_t*>(arow[i] + toff + q * BK);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) f.b[j][q] = *reinterpret_cast<const bf16x8*>(bp + j * 16 * LDK * 2 + q * BK);
+            for (int q = 0; q < NP; ++q) f.b[j][q] = *reinterpret_cast<const frag_t*>(bp + j * 16 * LDK * 2 + q * BK);
     };
     auto mfmas = [&](const Frag& f) {
 #pragma unroll
@@ -1226,7 +1293,8 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
                 for (int i = 0; i < NA; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i][qa], f.b[j][ord - qa], acc[i][j], 0, 0, 0);
+                        if constexpr (H16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[i][qa], f.b[j][ord - qa], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i][qa], f.b[j][ord - qa], acc[i][j], 0, 0, 0);
     };
     const int T = 9 * nchunks;
     load_a(0);
@@ -1235,10 +1303,25 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // the first activation tile and four weight tiles have landed
 #pragma unroll
     for (int i = 0; i < NALOAD; ++i) asm volatile("" : "+v"(areg[i]));
+    publish_amax();
+    int run_e = F16_EMIN;                                         // ARITH 16: the largest exponent among the activation tiles staged so far
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int g0 = chunk * 9;
         const bool more = chunk + 1 < nchunks;
         __syncthreads();                                          // the previous chunk's fragment reads are done
+        if constexpr (H16) {
+            const i32x4 pe = *reinterpret_cast<const i32x4*>(amax_slot);
+            const int e_new = __builtin_amdgcn_readfirstlane(max(max(max(pe[0], pe[1]), max(pe[2], pe[3])), run_e));
+            if (e_new != run_e) {                                 // the tile outgrew the scale of the sums so far: re-base them (exact)
+                const float rb = f16_rebase(run_e, e_new);
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] *= rb;
+                run_e = e_new;
+            }
+            a_scale = f16_scale_of(run_e);
+        }
         store_a();
         __syncthreads();
         Frag fr[2];
@@ -1261,7 +1344,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
 #pragma unroll
                 for (int k = 0; k < NA * NP + NB * NP; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, (NA * NB * 6) / (NA * NP + NB * NP), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, (NA * NB * NPROD) / (NA * NP + NB * NP), 0);
                 }
             }
             // End of tap g: tile g + 2 (issued after the barrier that ended tap g - 2) must have landed.  Younger operations
@@ -1282,6 +1365,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             if (tap == 2) {                                        // unconditional: the waitcnt pass is not path-sensitive
 #pragma unroll
                 for (int i = 0; i < NALOAD; ++i) asm volatile("" : "+v"(areg[i]));
+                if (more) publish_amax();                          // (the slot's previous values were read at this chunk's start, barriers ago)
             }
             __syncthreads();
             // every wave has read tile g's fragments (during tap g - 1, or at the chunk's start): its slot takes tile g + 4
@@ -1304,6 +1388,13 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     }
     EpiCtx ec;
     if constexpr (EX) epi_begin(p, ec, b, n);
+    if constexpr (H16) {                                          // sums of (x 2^ka)(w 2^kb): back to the operands' units (exact)
+        const float inv = f16_inv_scale_of(run_e) * p.w2s[0];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] *= inv;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         __syncthreads();
@@ -4032,10 +4123,13 @@ static int halo_ws_on() {
 }
 
 static int g_split_np = -1;
-static int split_pieces() {
+static int split_raw() {
     if (g_split_np < 0) g_split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
     return g_split_np;
 }
+// 16 = two fp16 pieces in the kernels that have that form (f16_pairs()); every other kernel runs the three-bf16-piece arithmetic under it
+static int split_pieces() { return split_raw() == 16 ? 3 : split_raw(); }
+static bool f16_pairs() { return split_raw() == 16; }
 
 static bool wgrad_split_on() {
     static const bool env_on = getenv("CODEPS_WGRAD_SPLIT") ? atoi(getenv("CODEPS_WGRAD_SPLIT")) != 0 : true;
@@ -4267,19 +4361,57 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 // A thread then emits 8 consecutive k of a pack row -- the fp32 pack (32 bytes) and, when the row takes the split-operand
 // kernel, its three bf16 pieces (3 x 16 bytes) -- exactly the bytes codeps_conv2d_pack_weights writes.
 constexpr int PACK_SLAB = 4608;          // floats of LDS per work group (512 columns x 9 taps)
+// Layout of a pack buffer in floats, `total` = rows x K extent (codeps_conv2d_packed_weight_floats):  [0, total) the fp32 pack;
+// [total, 2.5 total) three bf16 pieces (6 bytes per element);  [2.5 total, 3.5 total) two fp16 pieces of w 2^kb (4 bytes per element; written
+// when the arithmetic is 16);  [3.5 total, +4) the scale slot (2^-kb, 2^kb, 0, 0);  behind it one partial maximum per work group of the item.
+__host__ __device__ __forceinline__ long long pack_off_f16(long long total) { return total + (total * 6 + 3) / 4; }
+__host__ __device__ __forceinline__ long long pack_off_scale(long long total) { return pack_off_f16(total) + total; }
 struct PackItem {
     const float* w;              // OIHW parameter
     float* out;                  // fp32 pack [rows][taps * cols] (+ the split copy behind it when `split`)
     int co_real, ci_real, taps, rows, cols;      // rows x cols = padded (Co x Ci) for the forward pack, (Ci x Co) for the dgrad pack
-    int dgrad, split;
+    int dgrad, split;            // split: 0 fp32 only, 1 + the three bf16 pieces, 16 + the two fp16 pieces and their scale as well
     int cbw, rb;                 // slab shape: columns per slab (forward: <= 512; dgrad: 64), rows per slab (forward: 1)
     long long first_group, groups;               // work groups (slabs) of this item
 };
+
+// Per-tensor scale of the fp16 pieces, pass 1: work group u of an item takes the u-th share of the OIHW parameter and leaves the largest
+// magnitude it saw behind the scale slot; the pack's groups (pass 2, the next launch) each reduce the item's partials -- no atomics, no
+// zeroing, the same bits whatever the order of the groups.
+__device__ __forceinline__ void pack_amax_body(const PackItem& it, long long g, float* red) {
+    if (it.split != 16) return;
+    const long long total = (long long)it.rows * it.taps * it.cols;
+    const long long n = (long long)it.co_real * it.ci_real * it.taps;
+    const int u = (int)(g - it.first_group);
+    const long long per = (n + it.groups - 1) / it.groups;
+    const long long i0 = (long long)u * per, i1 = min(n, i0 + per);
+    float m = 0.f;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) m = fmaxf(m, fabsf(it.w[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) it.out[pack_off_scale(total) + 4 + u] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 
 __device__ __forceinline__ void pack_item_body(const PackItem& it, long long g, float* slab) {
     const long long wrow = (long long)it.taps * it.cols;                   // k extent of a pack row
     const long long total = (long long)it.rows * wrow;
     const int u = (int)(g - it.first_group);
+    float w_scale = 1.f;
+    if (it.split == 16) {                                                  // every group of the item derives the same scale from the partials
+        const float* part = it.out + pack_off_scale(total) + 4;
+        float m = 0.f;
+        for (long long i = threadIdx.x; i < it.groups; i += 256) m = fmaxf(m, part[i]);
+        m = wave_max(m);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) slab[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(slab[0], slab[1]), fmaxf(slab[2], slab[3]));
+        __syncthreads();
+        const int e = max((int)(__builtin_bit_cast(unsigned, m) >> 23), F16_EMIN);
+        w_scale = f16_scale_of(e);
+        if (u == 0 && threadIdx.x == 0) *reinterpret_cast<f32x4*>(it.out + pack_off_scale(total)) = f32x4{f16_inv_scale_of(e), w_scale, m, 0.f};
+    }
     const int ncb = (it.cols + it.cbw - 1) / it.cbw;
     const int r0 = (u / ncb) * it.rb, c0 = (u % ncb) * it.cbw;
     const int ncol = min(it.cbw, it.cols - c0), nrow = min(it.rb, it.rows - r0);
@@ -4321,7 +4453,32 @@ __device__ __forceinline__ void pack_item_body(const PackItem& it, long long g, 
 #pragma unroll
             for (int qq = 0; qq < 3; ++qq) *reinterpret_cast<i32x4*>(sp + qq * 32) = pack8(pl[qq], ph[qq]);
         }
+        if (it.split == 16) {
+            u16x4 pl[2], ph[2];
+            split_f16(a, w_scale, pl[0], pl[1]);
+            split_f16(b, w_scale, ph[0], ph[1]);
+            unsigned short* sp = reinterpret_cast<unsigned short*>(it.out + pack_off_f16(total)) + (chunk / 4) * 64 + (chunk % 4) * 8;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) *reinterpret_cast<i32x4*>(sp + qq * 32) = pack8(pl[qq], ph[qq]);
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void pack_amax_multi_kernel(const PackItem* __restrict__ items, int n_items) {
+    __shared__ float red[4];
+    int lo = 0, hi = n_items - 1;
+    const long long g = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_group <= g) lo = mid; else hi = mid - 1;
+    }
+    const PackItem it = items[lo];
+    pack_amax_body(it, g, red);
+}
+__global__ __launch_bounds__(256) void pack_amax_pair_kernel(PackItem a, PackItem b) {
+    __shared__ float red[4];
+    if ((long long)blockIdx.x < a.groups) pack_amax_body(a, blockIdx.x, red);
+    else pack_amax_body(b, blockIdx.x, red);
 }
 
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem* __restrict__ items, int n_items) {
@@ -4597,18 +4754,24 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                 if (halo_ring || hks >= 2) {
                     constexpr size_t lds_r = ((size_t)205 * (LDKp + (CODEPS_HALO_SWZ ? 4 : 0)) + (size_t)4 * BN * LDKp) * sizeof(float);
                     // CODEPS_HALO_WS=1: the producer / consumer form of the ring kernel (bit-identical results); default 0: the 256-thread form
-                    const int halo_ws = halo_ws_on();
-                    auto kr = halo_ws ? conv_halo3p_kernel<MODE, TN> : conv_halo3r_kernel<MODE, TN>;
+                    const bool h16 = f16_pairs();
+                    const int halo_ws = h16 ? 0 : halo_ws_on();
+                    auto kr = halo_ws ? conv_halo3p_kernel<MODE, TN> : (h16 ? conv_halo3r_kernel<MODE, TN, false, 16> : conv_halo3r_kernel<MODE, TN>);
                     codeps_allow_lds((const void*)kr, 160 * 1024, halo_ws ? "conv_halo3p_kernel" : "conv_halo3r_kernel");
                     p.ksplit = 1; p.ksteps = nchunks_;
                     // grids below one block per CU (the 1/16- and 1/32-resolution layers of the pose encoder and the decoders): cut the
                     // channel chunks into K slices so that the ring kernel (one block per CU) runs whole rounds of 256 blocks
                     if (hks >= 2) { p.ksteps = cdiv(nchunks_, hks); p.ksplit = cdiv(nchunks_, p.ksteps); }
                     const bool ex = epi_plan(p, 128, !halo_ws);
-                    if (ex) { kr = conv_halo3r_kernel<MODE, TN, true>; codeps_allow_lds((const void*)kr, 160 * 1024, "conv_halo3r_kernel<ex>"); }
+                    if (ex) {
+                        kr = h16 ? conv_halo3r_kernel<MODE, TN, true, 16> : conv_halo3r_kernel<MODE, TN, true>;
+                        codeps_allow_lds((const void*)kr, 160 * 1024, "conv_halo3r_kernel<ex>");
+                    }
                     g_last_kernel = halo_ws ? (p.ksplit > 1 ? "conv_halo3p_kernel<splitk>" : "conv_halo3p_kernel")
+                                            : h16 ? (p.ksplit > 1 ? "conv_halo3r_kernel<f16x2,splitk>" : "conv_halo3r_kernel<f16x2>")
                                             : (p.ksplit > 1 ? "conv_halo3r_kernel<splitk>" : "conv_halo3r_kernel");
-                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(halo_ws ? 384 : 256), lds_r, st, p, a0, a1, scale, shift, residual, out);
+                    constexpr size_t lds_r16 = ((size_t)205 * ((2 * BK + 8) / 2 + 4) + (size_t)4 * BN * ((2 * BK + 8) / 2)) * sizeof(float) + 16;
+                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(halo_ws ? 384 : 256), h16 ? lds_r16 : lds_r, st, p, a0, a1, scale, shift, residual, out);
                     if (p.ksplit > 1) launch_splitk_finish<MODE>(p, st, scale, shift, residual, out);
                     return;
                 }
@@ -4814,7 +4977,7 @@ static bool fill_pack_item(PackItem& it, const float* w_oihw, float* out, int ou
     if ((out_c_pad % 8) != 0 || (in_c_pad % 8) != 0 || kh * kw * 64 > PACK_SLAB) return false;
     it.w = w_oihw; it.out = out; it.co_real = out_c; it.ci_real = in_c; it.taps = kh * kw; it.dgrad = dgrad ? 1 : 0;
     it.rows = dgrad ? in_c_pad : out_c_pad; it.cols = dgrad ? out_c_pad : in_c_pad;
-    it.split = split_tail_ok(it.cols, it.taps) ? 1 : 0;
+    it.split = split_tail_ok(it.cols, it.taps) ? (f16_pairs() ? 16 : 1) : 0;
     it.first_group = first_group;
     if (!it.dgrad) {
         it.rb = 1;
@@ -4843,6 +5006,7 @@ extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, i
         if (w_fwd) { ok = ok && fill_pack_item(*slot, w_oihw, w_fwd, out_c, in_c, kh, kw, out_c_pad, in_c_pad, 0, groups); groups += slot->groups; slot = &b; }
         if (w_dgrad) { ok = ok && fill_pack_item(*slot, w_oihw, w_dgrad, out_c, in_c, kh, kw, out_c_pad, in_c_pad, 1, groups); groups += slot->groups; }
         if (ok && groups > 0 && groups < (1ll << 31)) {
+            if (a.split == 16 || b.split == 16) hipLaunchKernelGGL(pack_amax_pair_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a, b);
             hipLaunchKernelGGL(pack_weights_pair_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a, b);
             CODEPS_CHECK_LAUNCH("pack_weights_pair_kernel");
             return CODEPS_OK;
@@ -4884,6 +5048,9 @@ extern "C" long long codeps_pack_item_fill(void* item, const float* w_oihw, floa
 
 extern "C" int codeps_conv2d_pack_weights_multi(const void* items_device, int n_items, long long total_groups, codeps_stream_t stream) {
     CODEPS_REQUIRE(items_device && n_items > 0 && total_groups > 0 && total_groups < (1ll << 31), CODEPS_ERR_ARG, "pack_weights_multi: bad arguments");
+    // (the fp16 pieces need the tensors' largest magnitudes first; items filled under another arithmetic skip the pass)
+    if (f16_pairs())
+        hipLaunchKernelGGL(pack_amax_multi_kernel, dim3((unsigned)total_groups), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_device, n_items);
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_groups), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_device, n_items);
     CODEPS_CHECK_LAUNCH("pack_weights_multi_kernel");
     return CODEPS_OK;
@@ -4895,7 +5062,8 @@ extern "C" size_t codeps_conv2d_packed_weight_floats(int out_c_pad, int in_c_pad
     if (out_c_pad <= 0 || in_c_pad <= 0 || kh <= 0 || kw <= 0) return 0;
     const size_t total = (size_t)out_c_pad * in_c_pad * kh * kw;
     const int kext = dgrad ? out_c_pad : in_c_pad;
-    return total + (split_tail_ok(kext, kh * kw) ? (total * 6 + 3) / 4 : 0);
+    // (+ the two fp16 pieces, their scale slot and the partial maxima of the pack's work groups: see pack_off_f16 / pack_off_scale)
+    return total + (split_tail_ok(kext, kh * kw) ? 3 * total + 16 : 0);
 }
 
 // Which arithmetic a launch of this shape uses: 3 / 2 = fp32 operands as 3 / 2 bf16 pieces on v_mfma_f32_32x32x16_bf16 (main
@@ -5019,6 +5187,10 @@ extern "C" int codeps_conv2d_fwd_ex(const codeps_conv_desc* d, const float* x0, 
     p.ex_img_rows = d->out_h * d->out_w;
     if (workspace && codeps_conv2d_fwd_workspace_bytes(d) > 0) { p.part = (float*)workspace; p.part_bytes = workspace_bytes; }
     p.w3 = w_fwd + (size_t)d->out_c * d->kh * d->kw * (d->c0 + d->c1);         // behind the fp32 pack (codeps_conv2d_packed_weight_floats)
+    {
+        const long long total = (long long)d->out_c * d->kh * d->kw * (d->c0 + d->c1);
+        p.w2 = w_fwd + pack_off_f16(total); p.w2s = w_fwd + pack_off_scale(total);
+    }
     const int gran = (d->c1 == 0) ? d->c0 : ((d->c0 % 32 == 0 && d->c1 % 32 == 0) ? 32 : 16);
     static const int stem_halo = getenv("CODEPS_STEM_HALO") ? atoi(getenv("CODEPS_STEM_HALO")) : 1;                  // tuning experiments only
     if (stem_halo && d->kh == 7 && d->kw == 4 && d->stride == 2 && d->stride_w == 1 && d->pad == 3 && d->pad_w == 0 && d->c0 == 16 && d->c1 == 0 &&
@@ -5095,6 +5267,11 @@ extern "C" int codeps_conv2d_dgrad_ex(const codeps_conv_desc* d, int source, con
     // weights of this source: rows [c_off, c_off + Cs) of the [ci][tap][co] pack
     const float* wsrc = w_dgrad + (size_t)p.c_off * d->kh * d->kw * d->out_c;
     p.w3 = reinterpret_cast<const char*>(w_dgrad + (size_t)(d->c0 + d->c1) * d->kh * d->kw * d->out_c) + (size_t)p.c_off * d->kh * d->kw * d->out_c * 6;
+    {
+        const long long total = (long long)(d->c0 + d->c1) * d->kh * d->kw * d->out_c;
+        p.w2 = reinterpret_cast<const char*>(w_dgrad + pack_off_f16(total)) + (size_t)p.c_off * d->kh * d->kw * d->out_c * 4;
+        p.w2s = w_dgrad + pack_off_scale(total);
+    }
     if (d->stride == 2 && p.N > 16) {
         // one launch per input-parity class with only the taps that can reach it; classes without taps are zero
         bool need_zero = false;
@@ -5196,8 +5373,8 @@ extern "C" int codeps_conv2d_set_halo_ws(int on) {
 }
 
 extern "C" int codeps_conv2d_set_arith(int pieces) {
-    const int prev = split_pieces();
-    if (pieces == 0 || pieces == 2 || pieces == 3) g_split_np = pieces;
+    const int prev = split_raw();
+    if (pieces == 0 || pieces == 2 || pieces == 3 || pieces == 16) g_split_np = pieces;
     return prev;
 }
 

@@ -279,7 +279,37 @@ int timed(hipStream_t st, int reps, float* ms, F&& launch) {
     return CODEPS_OK;
 }
 
+// One matrix instruction on caller-supplied operands: what the f16 / bf16 MFMA does with subnormal inputs, how exactly it forms and sums
+// its 32 products (tools/f16_mfma_probe.py; the question behind the two-fp16-piece arithmetic of the conv engine).
+// mode 0: v_mfma_f32_16x16x32_f16, 1: v_mfma_f32_16x16x32_bf16.  a [16][32], b [16][32] raw 16-bit patterns (row = M / N index, k contiguous),
+// c, d [16][16] fp32 (d[m][n] = c[m][n] + sum_k a[m][k] b[n][k]).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int MODE>
+__global__ __launch_bounds__(64) void mfma_once_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                                                       const float* __restrict__ c, float* __restrict__ d) {
+    const int lane = threadIdx.x, l16 = lane & 15, kg = lane >> 4;
+    typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+    const u16x8_t av = *reinterpret_cast<const u16x8_t*>(a + l16 * 32 + kg * 8), bv = *reinterpret_cast<const u16x8_t*>(b + l16 * 32 + kg * 8);
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = c[(4 * kg + r) * 16 + l16];
+    if (MODE == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, av), __builtin_bit_cast(f16x8_t, bv), acc, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[(4 * kg + r) * 16 + l16] = acc[r];
+}
+
 }  // namespace
+
+extern "C" int codeps_diag_mfma_once(int mode, const void* a, const void* b, const float* c, float* d, codeps_stream_t stream) {
+    CODEPS_REQUIRE((mode == 0 || mode == 1) && a && b && c && d, CODEPS_ERR_ARG, "codeps_diag_mfma_once: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mode == 0) hipLaunchKernelGGL(mfma_once_kernel<0>, dim3(1), dim3(64), 0, st, (const unsigned short*)a, (const unsigned short*)b, c, d);
+    else hipLaunchKernelGGL(mfma_once_kernel<1>, dim3(1), dim3(64), 0, st, (const unsigned short*)a, (const unsigned short*)b, c, d);
+    CODEPS_CHECK_LAUNCH("mfma_once_kernel");
+    return CODEPS_OK;
+}
 
 extern "C" int codeps_diag_mfma_rate(int mode, int random_data, int blocks, int iters, int reps, float* scratch, double* flops_per_launch,
                                      float* ms_per_launch, codeps_stream_t stream) {

@@ -299,6 +299,12 @@ def invalidate_weight_cache(everything=False):
         _pack_cache.clear()
 
 
+def _arith():
+    """The conv engine's operand arithmetic (codeps_conv2d_set_arith; a pack made under 16 carries every form, one made under the
+    others lacks the fp16 pieces: the arithmetic is part of a pack's stamp)."""
+    return lib().codeps_conv2d_set_arith(-1)
+
+
 def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
     """OIHW parameter -> (w_fwd, w_dgrad) packs.  Frozen weights are packed once per (storage, tensor version).  Trainable
     ones (and frozen-looking ones whose storage is rewritten by raw-pointer kernels: an EMA teacher bound to the optimizer's
@@ -307,7 +313,7 @@ def pack_weights(weight, out_c_pad, in_c_pad, need_dgrad):
     volatile = weight.requires_grad or getattr(weight, "_codeps_volatile", False)
     cache = _pack_cache_train if volatile else _pack_cache
     key = (id(weight), out_c_pad, in_c_pad)
-    stamp = (weight._version, _weights_epoch[0] if volatile else 0)
+    stamp = (weight._version, _weights_epoch[0] if volatile else 0, _arith())
     ent = cache.get(key)          # [weakref to the parameter, storage, stamp, w_fwd, w_dgrad]: ids / addresses get reused
     same = ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr()
     if same and ent[2] == stamp and (ent[4] is not None or not need_dgrad):
@@ -361,7 +367,7 @@ def build_pack_table():
             groups += g
             i += 1
     dev = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(live[0][2].device)
-    _pack_table.update(dev=dev, n=n_items, groups=groups, epoch=-1,
+    _pack_table.update(dev=dev, n=n_items, groups=groups, epoch=-1, arith=_arith(),
                        entries=[(e, w.data_ptr(), weakref.ref(w), e[4] is not None) for _k, e, w in live])
     _pack_table["builds"] = _pack_table.get("builds", 0) + 1
     return n_items
@@ -371,6 +377,8 @@ def refresh_weight_packs():
     """Re-fill every pack of the table for the current weights epoch in ONE launch (no-op when they are current).  Falls back
     to the one-by-one path (drops the table) as soon as a parameter of the table died or moved."""
     t = _pack_table
+    if t["dev"] is not None and t.get("arith") != _arith():
+        t.update(dev=None, n=0, groups=0, entries=[], epoch=-1)          # the table's items were filled for another arithmetic
     if t["dev"] is None or t["epoch"] == _weights_epoch[0]:
         return
     for ent, dptr, ref, had_wd in t["entries"]:
@@ -382,7 +390,7 @@ def refresh_weight_packs():
     t["epoch"] = _weights_epoch[0]
     mark = _mark_written()
     for ent, _dptr, ref, _had in t["entries"]:
-        ent[2] = (ref()._version, _weights_epoch[0])
+        ent[2] = (ref()._version, _weights_epoch[0], t["arith"])
         ent[5] = mark
 
 

@@ -38,6 +38,10 @@ int codeps_diag_mfma_rate_clock(int mode, int random_data, int blocks, int iters
                                 float* ms_per_launch, codeps_stream_t stream);
 int codeps_diag_mfma_valu_clock(int valu_per_mfma, int other_wave, int blocks, int iters, int reps, float* scratch,
                                 unsigned long long* stamps, float* ms_per_launch, codeps_stream_t stream);
+/* codeps_diag_mfma_once: ONE matrix instruction on caller-supplied operands (mode 0 v_mfma_f32_16x16x32_f16, 1 v_mfma_f32_16x16x32_bf16):
+ *   a [16][32], b [16][32] raw 16-bit patterns (k contiguous), c / d [16][16] fp32, d[m][n] = c[m][n] + sum_k a[m][k] b[n][k].  Answers whether
+ *   subnormal inputs are honoured and how exactly the 32 products are formed and summed (tools/f16_mfma_probe.py). */
+int codeps_diag_mfma_once(int mode, const void* a, const void* b, const float* c, float* d, codeps_stream_t stream);
 /* Pre-split activations and their first consumer (csrc/conv1x1s.hip; DESIGN.md 8: the measurement behind "activations kept in the
  * matrix cores' operand form between the frozen encoder's layers").
  * codeps_split_pack_rows: x fp32 [rows][row_stride] (first `channels` of every row, channels % 32 == 0) ->
