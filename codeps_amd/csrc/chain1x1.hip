@@ -299,6 +299,245 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
     CODEPS_STAMP_END(chain);
 }
 
+// ---------------------------------------------------------------------------------- the same kernel on two fp16 pieces (round 6)
+// Arithmetic 16 of the conv engine (csrc/conv.hip, split_f16): x 2^k = hi + lo in fp16, three products hi hi + hi lo + lo hi on
+// v_mfma_f32_16x16x32_f16 -- 48 instead of 96 matrix instructions per phase, weight tiles of 256 x 144 bytes (128 data + 16 pad; ring 110 KB).
+// Scales: the weights' per-tensor 2^kb comes from the pack and its inverse is folded into the affines on the host (scale2, scale3);
+// the activations are scaled PER PIXEL: in the transposed GEMMs a pixel is a column of D, all accumulators of a lane belong to ONE pixel,
+// and the four lanes that share it agree on its largest exponent with two lane swaps (v_permlane16_swap / v_permlane32_swap) -- y1 once in
+// the prologue, the expand's output per stage (running maximum; when it grows the lane's 64 reduce sums are multiplied by the exact ratio).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int ROWH = 144;                 // bytes per LDS row: [piece][32 fp16] + 16 pad
+constexpr int TILE_H = 256 * ROWH;
+constexpr int W2ROWH = KMID * 4 + 16;     // bytes per expand-weight row in HBM: 8 groups x [2 pieces][32 fp16] + (scale 2^-kb, shift, 0, 0)
+constexpr int NDMAH = 9;                  // 4 loader waves x 9 x 64 lanes x 16 B = 256 x 144 B
+constexpr int H_TARGET = 14, H_EMIN = 27; // |x 2^k| < 2^15; magnitudes below 2^-100 count as 2^-100 (conv.hip: F16_TARGET, F16_EMIN)
+
+__device__ __forceinline__ float h_scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(254 + H_TARGET - e) << 23); }
+__device__ __forceinline__ float h_inv_scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(e - H_TARGET) << 23); }
+// biased exponent of the largest of the values m (>= 0) held by the four lanes l16 + 16 kg of one pixel, floored at H_EMIN
+__device__ __forceinline__ int pixel_exponent(float m) {
+    unsigned u = __builtin_bit_cast(unsigned, m);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    u = max(a[0], a[1]);                                       // (non-negative floats order like their bit patterns)
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    u = max(b[0], b[1]);
+    return max((int)(u >> 23), H_EMIN);
+}
+// eight fp32 values x s -> (hi, lo) fp16x8 fragments
+__device__ __forceinline__ void split8h(const f32x4 lo4, const f32x4 hi4, const float s, f16x8 (&f)[2]) {
+    _Float16 h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? lo4[e] : hi4[e - 4];
+        h[e] = (_Float16)(x * s);
+        l[e] = (_Float16)__builtin_fmaf(x, s, -(float)h[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f[0][e] = h[e]; f[1][e] = l[e]; }
+}
+
+__global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    CODEPS_STAMP_BEGIN();
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * BPIX;
+    const long long m = m0 + wave * 16 + l16;                  // this lane's pixel
+    const int NS = p.N2 / 32 / p.ksplit;                       // stages of this block (even), global stages [sbase, sbase + NS)
+    const int sbase = (int)blockIdx.y * NS;
+    auto rsrc_of = [](const void* base, size_t bytes) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+        i32x4 r;
+        r[0] = (int)__builtin_amdgcn_readfirstlane((unsigned)a);
+        r[1] = (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xFFFFu);
+        r[2] = (int)__builtin_amdgcn_readfirstlane((unsigned)(bytes < 0xFFFF0000ull ? bytes : 0xFFFF0000ull));
+        r[3] = 0x00020000;
+        return r;
+    };
+    const i32x4 rsW2 = rsrc_of(p.w2, (size_t)p.N2 * W2ROWH);
+    const i32x4 rsW3 = rsrc_of(p.w3, (size_t)KMID * p.N2 * 4);
+    const i32x4 rsRes = rsrc_of(p.res + (size_t)m0 * p.N2, (size_t)BPIX * p.N2 * 4);
+    const i32x4 rsOut = rsrc_of(p.out + (size_t)m0 * p.N2, (size_t)BPIX * p.N2 * 4);
+    const unsigned row_off = (unsigned)((wave * 16 + l16) * p.N2 + 4 * kg) * 4u;
+
+    // DMA roles as in chain_expand_reduce_kernel; a tile row is 9 segments of 16 bytes (8 data + pad)
+    unsigned offE[NDMAH], offR[NDMAH], ldsdst[NDMAH];
+#pragma unroll
+    for (int i = 0; i < NDMAH; ++i) {
+        const int ins = (wave & 3) + 4 * i, L = ins * 64 + lane, prow = L / 9, seg = L % 9;
+        ldsdst[i] = (unsigned)ins * 1024u;
+        const int ks = prow >> 5, r = prow & 31;
+        const int swz = ((prow >> 2) ^ (prow >> 3)) & 1;       // odd slot pitch: k groups of rows 4 .. 11 (mod 16) swapped pairwise
+        offE[i] = (unsigned)(r * W2ROWH + (seg < 8 ? ks * 128 + (seg ^ swz) * 16 : KMID * 4));
+        offR[i] = (unsigned)((size_t)prow * p.N2 * 4 + (seg < 8 ? (seg ^ swz) : 0) * 16);
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const bool loader = wave >= 4;
+    auto dma_tile = [&](int t) {
+        if (!loader) return;
+        const int s = sbase + (t >> 1);
+        const unsigned slot = lds_base + (unsigned)(t % 3) * TILE_H;
+        if (t & 1) {
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 128);
+#pragma unroll
+            for (int i = 0; i < NDMAH; ++i) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + ldsdst[i]);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(offR[i]), "s"(rsW3), "s"(soff) : "memory");
+            }
+        } else {
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 32 * W2ROWH);
+#pragma unroll
+            for (int i = 0; i < NDMAH; ++i) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + ldsdst[i]);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(offE[i]), "s"(rsW2), "s"(soff) : "memory");
+            }
+        }
+    };
+    auto res_load = [&](int sl, f32x4 (&r)[2]) {
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((sbase + sl) * 128);
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[0]) : "v"(row_off), "s"(rsRes), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:64" : "=v"(r[1]) : "v"(row_off), "s"(rsRes), "s"(soff) : "memory");
+    };
+    auto out_store = [&](int sl, const f32x4 (&v)[2]) {
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((sbase + sl) * 128);
+        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v[0]), "v"(row_off), "s"(rsOut), "s"(soff) : "memory");
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:64\n\ts_nop 1" :: "v"(v[1]), "v"(row_off), "s"(rsOut), "s"(soff) : "memory");
+    };
+
+    f32x4 rA[2], rB[2];
+    res_load(0, rA);
+    dma_tile(0);
+    dma_tile(1);
+    if (NS > 1) dma_tile(2);
+    f16x8 yf[8][2];
+    float inv_y;
+    {
+        const float* yrow = p.y1 + (size_t)m * KMID + kg * 8;
+        f32x4 ylo[8], yhi[8];
+        float ym = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            ylo[ks] = *reinterpret_cast<const f32x4*>(yrow + ks * 32); yhi[ks] = *reinterpret_cast<const f32x4*>(yrow + ks * 32 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ym = fmaxf(ym, fmaxf(fabsf(ylo[ks][e]), fabsf(yhi[ks][e])));
+        }
+        const int ey = pixel_exponent(ym);                     // the pixel's 256 channels lie in its four lanes
+        const float sy = h_scale_of(ey);
+        inv_y = h_inv_scale_of(ey);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) split8h(ylo[ks], yhi[ks], sy, yf[ks]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rA[0]), "+v"(rA[1]) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc3[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int e_run = H_EMIN;                                        // largest exponent of this pixel's expand outputs so far
+
+    const char* arow = lds + l16 * ROWH + (kg ^ (((l16 >> 2) ^ (l16 >> 3)) & 1)) * 16;
+
+    auto stage = [&](const int s, f32x4 (&rcur)[2], f32x4 (&rnext)[2]) {
+        const bool last = s + 1 == NS;
+        // vector-memory queue as in chain_expand_reduce_kernel with 9 DMA instructions per tile: 9 + 2 younger operations here ...
+        if (s > 0) { if (loader) CHAIN_WAIT(11); else CHAIN_WAIT(2); }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(rcur[0]), "+v"(rcur[1]));
+        res_load(s + 1, rnext);
+        if (s > 0 && 2 * s + 2 < 2 * NS) dma_tile(2 * s + 2);
+        const char* et = arow + ((2 * s) % 3) * TILE_H;
+        CODEPS_STAMP_PHASE_START();
+        f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const char* a = et + (ks * 32 + nt * 16) * ROWH;
+                f16x8 wf[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) wf[q] = *reinterpret_cast<const f16x8*>(a + q * 64);
+                acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], yf[ks][1], acc2[nt], 0, 0, 0);
+                acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], yf[ks][0], acc2[nt], 0, 0, 0);
+                acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], yf[ks][0], acc2[nt], 0, 0, 0);
+            }
+        CODEPS_STAMP_PHASE_A();
+        f32x4 v[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* aff = reinterpret_cast<const float*>(lds + ((2 * s) % 3) * TILE_H + (nt * 16 + 4 * kg + r) * ROWH + 128);
+                v[nt][r] = acc2[nt][r] * (aff[0] * inv_y) + aff[1];          // aff[0] = scale2 2^-kb (host), inv_y = the pixel's 2^-ky
+            }
+        float vm = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = v[nt][r] + rcur[nt][r];
+                v[nt][r] = t > 0.f ? t : 0.f;
+                vm = fmaxf(vm, v[nt][r]);
+            }
+        out_store(s, v);
+        // the pixel's running scale: when this stage's outputs outgrow it, the lane's reduce sums move to the new scale (exact)
+        const int e_new = max(e_run, pixel_exponent(vm));
+        if (__builtin_amdgcn_ballot_w64(e_new != e_run)) {
+            const int d = e_run - e_new;
+            const float rb = d < -126 ? 0.f : __builtin_bit_cast(float, (unsigned)(127 + d) << 23);
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) acc3[jt] *= rb;
+            e_run = e_new;
+        }
+        f16x8 of[2];                                           // B fragment of reduce k-step s: element j = channel 16 (j >> 2) + 4 kg + (j & 3)
+        split8h(v[0], v[1], h_scale_of(e_run), of);
+        // ... and 2 + 9 + 2 here
+        if (loader) { if (last) CHAIN_WAIT(0); else CHAIN_WAIT(13); }
+        __syncthreads();
+        if (2 * s + 3 < 2 * NS) dma_tile(2 * s + 3);
+        const char* rt = arow + ((2 * s + 1) % 3) * TILE_H;
+        CODEPS_STAMP_PHASE_START();
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) {
+            const char* a = rt + jt * 16 * ROWH;
+            f16x8 wf[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wf[q] = *reinterpret_cast<const f16x8*>(a + q * 64);
+            acc3[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], of[1], acc3[jt], 0, 0, 0);
+            acc3[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], of[0], acc3[jt], 0, 0, 0);
+            acc3[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], of[0], acc3[jt], 0, 0, 0);
+        }
+        CODEPS_STAMP_PHASE_B();
+    };
+    for (int s = 0; s < NS; s += 2) {
+        stage(s, rA, rB);
+        stage(s + 1, rB, rA);
+    }
+    CHAIN_WAIT(0);
+
+    const float inv_o = h_inv_scale_of(e_run);                 // (scale3 carries the reduce weights' 2^-kb: host)
+    if (p.ksplit > 1) {
+        float* po = p.part + ((size_t)blockIdx.y * p.M + m) * KMID + 4 * kg;
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) *reinterpret_cast<f32x4*>(po + jt * 16) = acc3[jt] * inv_o;
+        CODEPS_STAMP_END(chain);
+        return;
+    }
+    float* yo = p.y0n + (size_t)m * KMID + 4 * kg;
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale3 + jt * 16 + 4 * kg), sh = *reinterpret_cast<const f32x4*>(p.shift3 + jt * 16 + 4 * kg);
+        f32x4 o = (acc3[jt] * inv_o) * sc + sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
+        *reinterpret_cast<f32x4*>(yo + jt * 16) = o;
+    }
+    CODEPS_STAMP_END(chain);
+}
+
 // y0n = relu((sum_z part[z]) * scale3 + shift3), slices added in fixed order
 __global__ __launch_bounds__(256) void chain_finish_kernel(const float* __restrict__ part, int ksplit, long long MN, const float* __restrict__ scale3,
                                                            const float* __restrict__ shift3, float* __restrict__ y0n) {
@@ -334,9 +573,9 @@ extern "C" size_t codeps_chain1x1_workspace_bytes(long long rows, int n2) {
     return ks > 1 ? (size_t)ks * rows * KMID * sizeof(float) : 0;
 }
 
-extern "C" int codeps_chain1x1_expand_reduce(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
-                                             const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
-                                             void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+static int chain_launch(bool h16, const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
+                        const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
+                        void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     CODEPS_REQUIRE(y1 && residual && w2_rows && w3_split && scale3 && shift3 && out && y0_next, CODEPS_ERR_ARG, "chain1x1: null pointer argument");
     CODEPS_REQUIRE(rows > 0 && rows % BPIX == 0 && rows / BPIX < (1ll << 31), CODEPS_ERR_ARG, "chain1x1: rows (%lld) must be a positive multiple of %d", rows, BPIX);
     CODEPS_REQUIRE(n2 >= 64 && n2 % 64 == 0 && n2 <= 4096, CODEPS_ERR_ARG, "chain1x1: expand channels (%d) must be a multiple of 64 in [64, 4096]", n2);
@@ -351,8 +590,13 @@ extern "C" int codeps_chain1x1_expand_reduce(const float* y1, const float* resid
         p.part = static_cast<float*>(workspace);
     }
     hipStream_t st = (hipStream_t)stream;
-    codeps_allow_lds((const void*)chain_expand_reduce_kernel, 160 * 1024, "chain_expand_reduce_kernel");
-    hipLaunchKernelGGL(chain_expand_reduce_kernel, dim3((unsigned)(rows / BPIX), p.ksplit), dim3(64 * NWAVE), 3 * TILE_B, st, p);
+    if (h16) {
+        codeps_allow_lds((const void*)chain_expand_reduce_h_kernel, 160 * 1024, "chain_expand_reduce_h_kernel");
+        hipLaunchKernelGGL(chain_expand_reduce_h_kernel, dim3((unsigned)(rows / BPIX), p.ksplit), dim3(64 * NWAVE), 3 * TILE_H, st, p);
+    } else {
+        codeps_allow_lds((const void*)chain_expand_reduce_kernel, 160 * 1024, "chain_expand_reduce_kernel");
+        hipLaunchKernelGGL(chain_expand_reduce_kernel, dim3((unsigned)(rows / BPIX), p.ksplit), dim3(64 * NWAVE), 3 * TILE_B, st, p);
+    }
     if (p.ksplit > 1) {
         const long long MN = rows * KMID;
         hipLaunchKernelGGL(chain_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, (const float*)p.part, p.ksplit, MN,
@@ -360,4 +604,18 @@ extern "C" int codeps_chain1x1_expand_reduce(const float* y1, const float* resid
     }
     CODEPS_CHECK_LAUNCH("chain_expand_reduce_kernel");
     return CODEPS_OK;
+}
+
+extern "C" int codeps_chain1x1_expand_reduce(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
+                                             const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
+                                             void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    return chain_launch(false, y1, residual, w2_rows, w3_split, scale3, shift3, rows, n2, out, y0_next, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t codeps_chain1x1_w2_row_bytes_h(void) { return W2ROWH; }
+
+extern "C" int codeps_chain1x1_expand_reduce_h(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
+                                               const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
+                                               void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    return chain_launch(true, y1, residual, w2_rows, w3_split, scale3, shift3, rows, n2, out, y0_next, workspace, workspace_bytes, stream);
 }

@@ -380,7 +380,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     // = 10-13 % of these kernels' CU cycles (PMC, round 4).  At a 192-byte pitch two consecutive rows fill all eight slots, and the
     // swizzle spreads the fragment reads (lane = row, 16 rows per ds_read_b128 lane group, 12 r mod 16 takes four values only) over
     // all sixteen -- both conflict-free under the documented lane groups (MI355X_MICROARCH.md, LDS); 8 % less LDS per block.
-    constexpr bool SWZ = CODEPS_IGEMM_SWZ && NP > 0 && BK == 32;
+    // NP = 2 (round 6): TWO fp16 pieces of x 2^k (split_f16; block-local running scale for the gathered operand, the pack's per-tensor scale for
+    // the weights), rows of 128 bytes = [piece][4 k groups]: besides the k-group swizzle the two pieces swap places in rows 2, 3 (mod 4), so that
+    // the 16 lanes of a staging store (4 rows x 4 chunks) and the 16 rows of a fragment-read lane group each cover all sixteen 16-byte slots.
+    constexpr bool H16 = NP == 2;
+    constexpr int EB = NP * 2;                        // bytes per element of the pre-split weights
+    constexpr bool SWZ = (CODEPS_IGEMM_SWZ || H16) && NP > 0 && BK == 32;
     constexpr int LDK = NP == 0 ? BK + 4 : (SWZ ? NP * BK / 2 : (NP * BK + 8) / 2);
     constexpr int KPT = NP > 0 ? 8 : 4;               // consecutive k values staged per thread and row (split kernel: 8, so that each bf16
                                                       // piece goes to LDS as one 16-B write)
@@ -427,14 +432,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     const size_t wrow = (MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct : (size_t)p.KH * p.KW * p.Co;     // floats per packed weight row
     // 3-piece arithmetic: the weights arrive pre-split (6 bytes per element, laid out like an LDS row), so the B operand is
     // staged with copies only -- every weight element would otherwise be converted again by each of the M / BM row tiles
-    constexpr bool BPRE = NP == 3;
+    constexpr bool BPRE = NP >= 2;
     constexpr int BREGS = BPRE ? NP : SUB;            // 16-byte registers per staged B row chunk
-    const __amdgpu_buffer_rsrc_t rsB = BPRE ? make_rsrc(static_cast<const float*>(p.w3), (size_t)p.N * wrow * 6) : make_rsrc(wq, (size_t)p.N * wrow * 4);
+    const __amdgpu_buffer_rsrc_t rsB = BPRE ? make_rsrc(static_cast<const float*>(H16 ? p.w2 : p.w3), (size_t)p.N * wrow * EB) : make_rsrc(wq, (size_t)p.N * wrow * 4);
     unsigned boff[BPASS];
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
         const size_t row = (size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow;
-        boff[i] = BPRE ? (unsigned)(row * 6 + chunk * 16) : (unsigned)((row + chunk * KPT) * 4);
+        boff[i] = BPRE ? (unsigned)(row * EB + chunk * 16) : (unsigned)((row + chunk * KPT) * 4);
     }
 
     f32x4 areg[APASS * SUB], breg[BPASS * BREGS];
@@ -464,8 +469,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #pragma unroll
             for (int u = 0; u < BREGS; ++u)
                 breg[i * BREGS + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rsB, BPRE ? boff[i] + (unsigned)(koff >> 5) * 192u + (unsigned)(koff & 31) * 2u + 64 * u : boff[i] + (unsigned)koff * 4u + 16 * u, 0, 0));
+                    rsB, BPRE ? boff[i] + (unsigned)(koff >> 5) * (unsigned)(32 * EB) + (unsigned)(koff & 31) * 2u + 64 * u : boff[i] + (unsigned)koff * 4u + 16 * u, 0, 0));
     };
+    // NP = 2: the exponent of the largest magnitude of the gathered tile in `areg` -> amax_slot[wave] (read behind the next barrier)
+    int* amax_slot = reinterpret_cast<int*>(tab + ((MODE == MODE_FWD && p.C1 > 0) ? 2 : 1) * ntap * BM);
+    auto publish_amax = [&]() {
+        if constexpr (H16) {
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < APASS * SUB; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(areg[i][e]));
+            const int ex = wave_max_exponent(m);
+            if (lane == 0) amax_slot[wave] = ex;
+        }
+    };
+    float a_scale = 1.f;
+    const int psw = H16 ? (rbase >> 1) & 1 : 0;        // NP = 2: rows 2, 3 (mod 4) keep their pieces in swapped places (RPP % 4 == 0)
     auto store_step = [&](int buf) {
         float* Ab = As + buf * BM * LDK;
         float* Bb = Bs + buf * BN * LDK;
@@ -476,12 +496,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     *reinterpret_cast<f32x4*>(Ab + (rbase + RPP * i) * LDK + chunk * 4) = areg[i];
                 } else {                                     // row = [piece][32 bf16]; this thread's 8 k values of every piece: one b128 each
                     u16x4 lo[NP > 0 ? NP : 1], hi[NP > 0 ? NP : 1];
-                    split_bf16<(NP > 0 ? NP : 1)>(areg[i * SUB], lo);
-                    split_bf16<(NP > 0 ? NP : 1)>(areg[i * SUB + SUB - 1], hi);
+                    if constexpr (H16) {
+                        split_f16(areg[i * SUB], a_scale, lo[0], lo[1]);
+                        split_f16(areg[i * SUB + SUB - 1], a_scale, hi[0], hi[1]);
+                    } else {
+                        split_bf16<(NP > 0 ? NP : 1)>(areg[i * SUB], lo);
+                        split_bf16<(NP > 0 ? NP : 1)>(areg[i * SUB + SUB - 1], hi);
+                    }
                     unsigned short* row = reinterpret_cast<unsigned short*>(Ab + (rbase + RPP * i) * LDK);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        *reinterpret_cast<i32x4*>(row + q * BK + wchunk * 8) = pack8(lo[q], hi[q]);
+                        *reinterpret_cast<i32x4*>(row + (q ^ psw) * BK + wchunk * 8) = pack8(lo[q], hi[q]);
                 }
             }
 #pragma unroll
@@ -493,7 +518,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                     unsigned short* row = reinterpret_cast<unsigned short*>(Bb + (rbase + RPP * i) * LDK);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        *reinterpret_cast<i32x4*>(row + q * BK + wchunk * 8) = __builtin_bit_cast(i32x4, breg[i * BREGS + q]);
+                        *reinterpret_cast<i32x4*>(row + (q ^ psw) * BK + wchunk * 8) = __builtin_bit_cast(i32x4, breg[i * BREGS + q]);
                 } else {
                     u16x4 lo[NP > 0 ? NP : 1], hi[NP > 0 ? NP : 1];
                     split_bf16<(NP > 0 ? NP : 1)>(breg[i * SUB], lo);
@@ -516,7 +541,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 
     const int s_begin = p.ksplit > 1 ? (int)blockIdx.y * p.ksteps : 0;
     const int s_end = p.ksplit > 1 ? min(nsteps, s_begin + p.ksteps) : nsteps;
+    // NP = 2: the running maximum exponent of the gathered tiles -> the scale of the next tile's split; when it grows the sums so far are
+    // multiplied by the exact ratio.  Called between the barrier that publishes the waves' maxima and the tile's LDS stores.
+    int run_e = F16_EMIN;
+    auto rescale = [&]() {
+        if constexpr (H16) {
+            const i32x4 pe = *reinterpret_cast<const i32x4*>(amax_slot);
+            const int e_new = __builtin_amdgcn_readfirstlane(max(max(max(pe[0], pe[1]), max(pe[2], pe[3])), run_e));
+            if (e_new != run_e) {
+                const float rb = f16_rebase(run_e, e_new);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] *= rb;
+                run_e = e_new;
+            }
+            a_scale = f16_scale_of(run_e);
+        }
+    };
     load_step(s_begin);
+    if constexpr (H16) { publish_amax(); __syncthreads(); rescale(); }
     store_step(0);
     __syncthreads();
 
@@ -551,19 +595,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
             // 16-deep chunk; per chunk the products p_a * p_b with a + b < NP, smallest terms first
 #pragma unroll
             for (int kc = 0; kc < BK / 16; ++kc) {
-                bf16x8 af[TM][NP > 0 ? NP : 1], bf[TN][NP > 0 ? NP : 1];
+                typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
+                frag_t af[TM][NP > 0 ? NP : 1], bf[TN][NP > 0 ? NP : 1];
+                const int pr = H16 ? (lrow >> 1) & 1 : 0;
                 // halfword offset of this lane's k group inside a piece (swizzled layout: group (2 kc + half) ^ ((row >> 2) & 3))
                 const int ho = SWZ ? (((kc * 2 + lhalf) ^ ((lrow >> 2) & 3)) * 8) : kc * 16 + lhalf * 8;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        af[i][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Ab + i * 32 * LDK) + q * BK + ho);
+                        af[i][q] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const unsigned short*>(Ab + i * 32 * LDK) + (q ^ pr) * BK + ho);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        bf[j][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Bb + j * 32 * LDK) + q * BK + ho);
+                        bf[j][q] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const unsigned short*>(Bb + j * 32 * LDK) + (q ^ pr) * BK + ho);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ord = NP - 1; ord >= 0; --ord)
@@ -573,7 +619,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+                                if constexpr (H16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+                                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
             }
         }
@@ -582,8 +629,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #endif
         CODEPS_STAMP_PHASE_A();                               // A: loads issued + fragment reads + MFMAs of this wave
         CODEPS_STAMP_PHASE_START();
+        if (H16 && step + 1 < s_end) publish_amax();          // (the next tile's loads have had the MFMAs to land)
         if (NBUF == 1) __syncthreads();                       // every wave is done reading the single buffer
-        if (step + 1 < s_end) store_step(NBUF == 2 ? (buf ^ 1) : 0);
+        if (step + 1 < s_end) { rescale(); store_step(NBUF == 2 ? (buf ^ 1) : 0); }
         __syncthreads();
         CODEPS_STAMP_PHASE_B();                               // B: barrier + (wait for the loads) split + LDS stores + barrier
     }
@@ -605,6 +653,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     }
     EpiCtx ec;
     if constexpr (EX) epi_begin(p, ec, p.ex_img_rows ? m0 / p.ex_img_rows : 0, n);
+    if constexpr (H16) {                                      // sums of (x 2^ka)(w 2^kb): back to the operands' units (exact)
+        const float inv = f16_inv_scale_of(run_e) * p.w2s[0];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] *= inv;
+    }
     // one pass per row-tile index i: staging holds WM*32 rows (keeps the LDS footprint at <= 34 KB so that the
     // K-loop buffers, not the epilogue, decide how many blocks fit on a CU)
 #pragma unroll
@@ -877,11 +932,13 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
 // MODE_DGRAD (stride 1): input pixel p sums dZ(p + (1 - ky, 1 - kx)) x W[ci][tap][co]: the same kernel with mirrored taps.
 // WM x WN waves: 2 x 2 = 4 x 32 output pixels x (64 TN) columns (two blocks per CU at TN = 1); 4 x 1 (round 4) = 8 x 32 pixels x 32
 // columns for the layers with <= 32 output channels (the decoders' half-resolution stage), which the generic kernel ran at 84-119 TFLOP/s.
-template <int MODE, int TN, int WM = 2, int WN = 2, bool EX = false>
+template <int MODE, int TN, int WM = 2, int WN = 2, bool EX = false, int ARITH = 3>
 __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ residual, float* __restrict__ out) {
-    constexpr int TM = 2, BK = 32, NP = 3;
+    constexpr int TM = 2, BK = 32, NP = ARITH == 16 ? 2 : 3;       // ARITH 16: two fp16 pieces, block-local scales (see split_f16)
+    constexpr bool H16 = ARITH == 16;
+    constexpr int EB = NP * 2, SEGD = NP * 4;                      // bytes per pre-split weight element; 16-byte segments per (row, K group)
     constexpr int TH = 2 * WM, TW = 32, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;  // WM = 2: 128 outputs, 204 halo pixels; WM = 4: 256 / 340
     constexpr int BN = 32 * WN * TN;
     constexpr int LDK = (NP * BK + 8) / 2;                                        // floats per LDS row
@@ -890,6 +947,7 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                  // [HPIX][LDKA]
     float* Bs = smem + HPIX * LDKA;                    // [2][BN][LDK]
+    int* amax_slot = reinterpret_cast<int*>(Bs + 2 * BN * LDK);        // ARITH 16: the waves' maximum exponents of the activation tile in flight
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int logical = xcd_remap(blockIdx.x, p.n_mt * p.n_nt);
@@ -913,14 +971,14 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
     // B staging roles: a (tap, chunk) row of the pre-split pack is 192 contiguous bytes = 12 16-byte segments, and so is its LDS
     // row ([piece][32]): task t = tid + 256 i copies segment t % 12 of row t / 12 -- twelve neighbouring lanes move one row, so
     // both the global read and the LDS write are contiguous (the 4-lanes-per-row mapping left the writes on a 2-way bank conflict)
-    constexpr int BTASK = (BN * 12 + 255) / 256;                                   // (BN = 32: 384 segments, the second pass half empty)
+    constexpr int BTASK = (BN * SEGD + 255) / 256;                                   // (BN = 32: 384 segments, the second pass half empty)
     const size_t wrow = (size_t)9 * Kc;
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const float*>(p.w3), (size_t)p.N * wrow * 6);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const float*>(H16 ? p.w2 : p.w3), (size_t)p.N * wrow * EB);
     unsigned boff[BTASK], bdst[BTASK];
 #pragma unroll
     for (int i = 0; i < BTASK; ++i) {
-        const int t = min(tid + 256 * i, BN * 12 - 1), row = t / 12, seg = t % 12;        // (surplus lanes repeat the last segment: same data, same slot)
-        boff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * 6 + seg * 16);
+        const int t = min(tid + 256 * i, BN * SEGD - 1), row = t / SEGD, seg = t % SEGD;        // (surplus lanes repeat the last segment: same data, same slot)
+        boff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * EB + seg * 16);
         bdst[i] = (unsigned)(row * LDK * 4 + (seg ^ (CODEPS_HALO_SWZ ? (((row >> 2) ^ (row >> 3)) & 1) : 0)) * 16);    // k groups of rows 4 .. 11 swapped pairwise
     }
 
@@ -940,21 +998,38 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
             areg[i * 2 + 1] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    auto publish_amax = [&]() {                                   // ARITH 16 (as in conv_halo3r_kernel)
+        if constexpr (H16) {
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < APASS * 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(areg[i][e]));
+            const int ex = wave_max_exponent(m);
+            if (lane == 0) amax_slot[wave] = ex;
+        }
+    };
+    float a_scale = 1.f;
     auto store_a = [&]() {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int pos = (tid >> 2) + 64 * i;
             if (pos >= HPIX) continue;
             u16x4 lo[NP], hi[NP];
-            split_bf16<NP>(areg[i * 2], lo);
-            split_bf16<NP>(areg[i * 2 + 1], hi);
+            if constexpr (H16) {
+                split_f16(areg[i * 2], a_scale, lo[0], lo[1]);
+                split_f16(areg[i * 2 + 1], a_scale, hi[0], hi[1]);
+            } else {
+                split_bf16<NP>(areg[i * 2], lo);
+                split_bf16<NP>(areg[i * 2 + 1], hi);
+            }
             unsigned short* row = reinterpret_cast<unsigned short*>(As + pos * LDKA);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + achunk * 8) = pack8(lo[q], hi[q]);
         }
     };
     auto load_b = [&](int tap, int chunk) {
-        const unsigned koff = (unsigned)(tap * Kc + chunk * BK) * 6u;
+        const unsigned koff = (unsigned)(tap * Kc + chunk * BK) * (unsigned)EB;
 #pragma unroll
         for (int i = 0; i < BTASK; ++i)
             breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + koff, 0, 0));
@@ -986,9 +1061,24 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 
     load_a(0);
     load_b(0, 0);
+    publish_amax();
+    int run_e = F16_EMIN;
     int bbuf = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();                                          // the previous chunk's fragment reads are done
+        if constexpr (H16) {
+            const i32x4 pe = *reinterpret_cast<const i32x4*>(amax_slot);
+            const int e_new = __builtin_amdgcn_readfirstlane(max(max(max(pe[0], pe[1]), max(pe[2], pe[3])), run_e));
+            if (e_new != run_e) {                                 // re-base the sums so far to the larger tile's scale (exact)
+                const float rb = f16_rebase(run_e, e_new);
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] *= rb;
+                run_e = e_new;
+            }
+            a_scale = f16_scale_of(run_e);
+        }
         store_a();
         if (chunk == 0) store_b(0);
         __syncthreads();
@@ -1000,18 +1090,20 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
             const int ky = tap / 3, kx = tap % 3;
             const int toff = (MODE == MODE_FWD) ? ky * HW + kx : (2 - ky) * HW + (2 - kx);
             const float* Bb = Bs + bbuf * BN * LDK + (wn * TN * 32 + l16) * LDK;
+            if (H16 && tap == 4 && chunk + 1 < nchunks) publish_amax();      // the next tile has landed by now; read behind the chunk's last barrier
             {
-                bf16x8 af[NA][NP], bf[NB][NP];
+                typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
+                frag_t af[NA][NP], bf[NB][NP];
 #pragma unroll
                 for (int i = 0; i < NA; ++i)
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        af[i][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(As + (apos[i] + toff) * LDKA) + q * BK + kg * 8);
+                        af[i][q] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const unsigned short*>(As + (apos[i] + toff) * LDKA) + q * BK + kg * 8);
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        bf[j][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Bb + j * 16 * LDK) + q * BK + kgb * 8);
+                        bf[j][q] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const unsigned short*>(Bb + j * 16 * LDK) + q * BK + kgb * 8);
 #pragma unroll
                 for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
@@ -1020,7 +1112,8 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
                         for (int i = 0; i < NA; ++i)
 #pragma unroll
                             for (int j = 0; j < NB; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+                                if constexpr (H16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+                                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
             }
             if (!last) store_b(bbuf ^ 1);                         // the other buffer: nobody reads it during this tap
             bbuf ^= 1;
@@ -1041,6 +1134,13 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
     }
     EpiCtx ec;
     if constexpr (EX) epi_begin(p, ec, b, n);
+    if constexpr (H16) {                                          // sums of (x 2^ka)(w 2^kb): back to the operands' units (exact)
+        const float inv = f16_inv_scale_of(run_e) * p.w2s[0];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] *= inv;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if (i > 0) __syncthreads();
@@ -3389,7 +3489,389 @@ __device__ __forceinline__ void wgrad_halo64d_body(const WgradP& p, int ci_chunk
 #endif
 }
 
+// wgrad_halo64d_body on TWO fp16 pieces (round 6, arithmetic 16; split_f16 has the arithmetic): three products per tap instead of six, 86 KB
+// of LDS instead of 127.  Both operands are activations, so both carry a running block-local scale: a wave publishes the largest exponent
+// of its share of sub-tile t (dZ: wave 0; X: waves 1-3) two phases before the sub-tile's MFMAs, every wave derives the same two scales from
+// the four words, and when a scale grows the nine accumulator tiles are multiplied by the exact ratio at the phase boundary.  A sub-tile
+// is loaded three phases ahead (three register sets) -- a phase is 54 MFMAs now, shorter than a load's latency under traffic.
 template <bool CO32>
+__device__ __forceinline__ void wgrad_halo64h_body(const WgradP& p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
+                                                   const float* __restrict__ x0, const float* __restrict__ x1,
+                                                   const float* __restrict__ dz, float* __restrict__ part, unsigned short* lds16) {
+    constexpr int TH = 2, TW = 16, XH = TH + 2, PIX = TH * TW, XROW = 32;
+    constexpr int NP = 2, NPROD = 3;
+    constexpr int ZP = NP * PIX + 8;                   // halfwords per dZ channel (72: 36 dwords = 9 slots of 16 bytes, odd: conflict-free fragment reads)
+    constexpr int XQ = XH * XROW, XP = NP * XQ + 8;    // halfwords per X piece / per X channel (264: 132 dwords = 33 slots)
+    constexpr int XS0 = 64 * ZP;                       // X rows start behind the dZ rows
+    constexpr int BUF = 64 * (ZP + XP);               // halfwords per buffer: [64][ZP] dZ, [64][XP] X
+    int* slots = reinterpret_cast<int*>(lds16 + 2 * BUF);               // [sub-tile parity][wave]: the largest exponent a wave found in its share
+    CODEPS_STAMP_BEGIN();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int wco = CO32 ? 0 : (wave & 1), wci = wave >> 1;
+    const int role = __builtin_amdgcn_readfirstlane(wave);            // 0: dZ, 1 / 2: X interior, 3: halo pixels
+    const int co_base = blockIdx.y * 64;
+    const int chunk = blockIdx.x % ci_chunks, blk = blockIdx.x / ci_chunks;
+    const int c_base = chunk * 64;
+    const int total_tiles = p.B * tiles_y * tiles_x;
+    const int t_beg = blk * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
+    const int NJ = 2 * (t_end - t_beg);                               // sub-tiles of this block (even)
+    // X source of a half of the chunk (block-uniform)
+    struct XSrc { const float* ptr; int cs, c0; bool up; size_t img; };
+    auto xsrc_of = [&](int half) {
+        const int ch = c_base + 32 * half;
+        const bool s1 = ch >= p.C0;
+        XSrc o;
+        o.ptr = s1 ? x1 : x0; o.cs = s1 ? p.C1 : p.C0; o.c0 = s1 ? ch - p.C0 : ch; o.up = p.up0 && !s1;
+        o.img = o.up ? (size_t)(p.H / 2) * (p.W / 2) * o.cs : (size_t)p.H * p.W * o.cs;
+        return o;
+    };
+    const XSrc xs[2] = {xsrc_of(0), xsrc_of(1)};
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-thread constants.  Big task (quad's low two bits over four consecutive lanes, then the pixel group, then the quad's high
+    // bits: see wgrad_halo64s_body): global byte offset from the sub-tile origin, the X row it reads, LDS halfword of its first store
+    int b_off = 0, b_row = 0, b_dst = 0;
+    bool b_ok = false;
+    if (role == 0) {
+        const int c4 = (lane & 3) | ((lane >> 4) << 2), grp = (lane >> 2) & 3;
+        b_off = (((grp >> 1) * p.Wo + (grp & 1) * 8) * p.Co + co_base + c4 * 4) * 4;
+        b_ok = co_base + c4 * 4 < p.Co;
+        b_dst = (c4 * 4) * ZP + grp * 8;
+    } else if (role < 3) {
+        const XSrc& sx = xs[role - 1];
+        const int t = tid - 64, c4 = (t & 3) | ((t >> 5) << 2), c4l = c4 & 7, grp = (t >> 2) & 7;      // wave 1: quads 0-7, wave 2: 8-15
+        b_row = (grp >> 1) - 1;
+        b_off = sx.up ? (((b_row >> 1) * (p.W / 2) + (grp & 1) * 4) * sx.cs + sx.c0 + c4l * 4) * 4
+                      : ((b_row * p.W + (grp & 1) * 8) * sx.cs + sx.c0 + c4l * 4) * 4;
+        b_ok = sx.c0 + c4l * 4 < sx.cs;
+        b_dst = XS0 + (c4 * 4) * XP + (grp >> 1) * XROW + 8 + (grp & 1) * 8;
+    }
+    int s_off[2] = {0, 0}, s_row = 0, s_dstk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    unsigned s_selk[4] = {0, 0, 0, 0};
+    bool s_ok[2] = {false, false}, s_side = false;
+    if (role == 3) {
+        const int c4l = lane & 7, rs = lane >> 3;                    // task u: quad c4l + 8 u, (row, side) rs
+        s_side = rs & 1;
+        s_row = (rs >> 1) - 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const XSrc& sx = xs[u];
+            s_off[u] = sx.up ? (((s_row >> 1) * (p.W / 2) + (s_side ? TW / 2 : -1)) * sx.cs + sx.c0 + c4l * 4) * 4
+                             : ((s_row * p.W + (s_side ? TW : -1)) * sx.cs + sx.c0 + c4l * 4) * 4;
+            s_ok[u] = sx.c0 + c4l * 4 < sx.cs;
+            const int dst = XS0 + ((c4l + 8 * u) * 4) * XP + (rs >> 1) * XROW + (s_side ? 24 : 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_dstk[u][k] = dst + ((k + (c4l >> 1)) & 3) * XP;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (k + (c4l >> 1)) & 3;
+            s_selk[k] = 0x0c0c0000u | (e == 0 ? 0x0504u : e == 1 ? 0x0706u : e == 2 ? 0x0100u : 0x0302u);
+        }
+    }
+    const size_t zimg = (size_t)p.Ho * p.Wo * p.Co;
+    // cfg of a wave's code copy: bits 0-1 role (0: dZ, 1: X interior, 3: halo pixels), bit 2: the wave's source (role 1) / the source of
+    // half 0 (role 3) is up-sampled, bit 3: role 3, the source of half 1 is up-sampled, bit 4: CO32, the wave's output row
+    // the loads of sub-tile j (role 0, 1: eight 16-byte loads, four from an up-sampled source; 3: two halo pixels); all lanes read
+    // zeros when !valid (the sub-tile behind the last one), so the tile loop has no branch around its loads
+    auto issue_loads = [&](auto cfg_c, int j, bool valid, f32x4 (&raw)[8], unsigned tok = 0) {
+        constexpr int CFG = decltype(cfg_c)::value, ROLE = CFG & 3;
+        constexpr bool UPA = (CFG >> 2) & 1, UPB = (CFG >> 3) & 1;
+        const int tile = t_beg + (j >> 1);                                                     // (all scalar)
+        const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
+        const int ty0 = (tr / tiles_x) * 4 + (j & 1) * TH, tx0 = (tr % tiles_x) * TW;
+        if (ROLE == 0) {
+            const __amdgpu_buffer_rsrc_t rsz = make_rsrc(dz + (size_t)b * zimg, zimg * 4);
+            const int zorg = (ty0 * p.Wo + tx0) * p.Co * 4, zpix = p.Co * 4;
+            const unsigned vo = (valid && b_ok) ? (unsigned)(zorg + b_off) : GATHER_OOB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsz, vo, i * zpix, 0));
+        } else if (ROLE == 1) {
+            const XSrc& sx = xs[role - 1];
+            const __amdgpu_buffer_rsrc_t rsx = make_rsrc(sx.ptr + (size_t)b * sx.img, sx.img * 4);
+            const int xorg = UPA ? ((ty0 / 2) * (p.W / 2) + tx0 / 2) * sx.cs * 4 : (ty0 * p.W + tx0) * sx.cs * 4, xpix = sx.cs * 4;
+            const unsigned vo = (valid && b_ok && (unsigned)(ty0 + b_row) < (unsigned)p.H) ? (unsigned)(xorg + b_off) : GATHER_OOB;
+#pragma unroll
+            for (int i = 0; i < (UPA ? 4 : 8); ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, i * xpix, 0));
+        } else {
+            const bool okp = valid && (unsigned)(ty0 + s_row) < (unsigned)p.H && (s_side ? tx0 + TW < p.W : tx0 > 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const XSrc& sx = xs[u];
+                const bool up = u == 0 ? UPA : UPB;
+                const __amdgpu_buffer_rsrc_t rsx = make_rsrc(sx.ptr + (size_t)b * sx.img, sx.img * 4);
+                const int xorg = up ? ((ty0 / 2) * (p.W / 2) + tx0 / 2) * sx.cs * 4 : (ty0 * p.W + tx0) * sx.cs * 4;
+                raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, ((okp && s_ok[u]) ? (unsigned)(xorg + s_off[u]) : GATHER_OOB) + tok, 0, 0));
+            }
+        }
+    };
+    // channel e of the big task: 8 pixels -> three 16-byte rows (one per piece)
+    auto store_big = [&](auto cfg_c, const f32x4 (&raw)[8], int e, unsigned short* buf, float sc) {
+        constexpr int CFG = decltype(cfg_c)::value, ROLE = CFG & 3;
+        constexpr bool UPA = (CFG >> 2) & 1;
+        constexpr int cs = ROLE == 0 ? ZP : XP, qs = ROLE == 0 ? PIX : XQ;
+        if (UPA && ROLE == 1) {                                     // four source pixels, each twice
+            const f32x4 v4 = {raw[0][e], raw[1][e], raw[2][e], raw[3][e]};
+            u16x4 pc[NP];
+            split_f16(v4, sc, pc[0], pc[1]);
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                *reinterpret_cast<i32x4*>(buf + b_dst + e * cs + q * qs) =
+                    pack8(u16x4{pc[q][0], pc[q][0], pc[q][1], pc[q][1]}, u16x4{pc[q][2], pc[q][2], pc[q][3], pc[q][3]});
+            return;
+        }
+        const f32x4 lo4 = {raw[0][e], raw[1][e], raw[2][e], raw[3][e]};
+        const f32x4 hi4 = {raw[4][e], raw[5][e], raw[6][e], raw[7][e]};
+        u16x4 lo[NP], hi[NP];
+        split_f16(lo4, sc, lo[0], lo[1]);
+        split_f16(hi4, sc, hi[0], hi[1]);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(buf + b_dst + e * cs + q * qs) = pack8(lo[q], hi[q]);
+    };
+    // a halo pixel's 2-byte stores: a channel's row starts 196 dwords behind its neighbour's (= 4 mod 32: what the 16-byte fragment reads
+    // want), so the halo slots of all rows and channels fall on 16 of the 32 write banks -- 4-way at best.  With all lanes storing the
+    // SAME channel of their quad the 64 addresses would fall on four to eight banks; so lane's k-th store takes channel
+    // (k + (quad >> 1)) & 3 of its quad: 4 lanes per bank.
+    struct SmallPc { unsigned lo[NP], hi[NP]; };                    // a halo pixel's 4 channels x 2 pieces, two halfwords per dword
+    auto split_small = [&](const f32x4 v, float sc) {
+        u16x4 pc[NP];
+        split_f16(v, sc, pc[0], pc[1]);
+        SmallPc o;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            o.lo[q] = (unsigned)pc[q][0] | ((unsigned)pc[q][1] << 16);
+            o.hi[q] = (unsigned)pc[q][2] | ((unsigned)pc[q][3] << 16);
+        }
+        return o;
+    };
+    auto store_small = [&](const SmallPc& pc, int u, unsigned short* buf) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)                              // v_perm_b32: bytes 0-3 = hi, 4-7 = lo (selector = byte numbers of the wanted halfword)
+                buf[s_dstk[u][k] + q * XQ] = (unsigned short)__builtin_amdgcn_perm(pc.lo[q], pc.hi[q], s_selk[k]);
+    };
+    auto store_all = [&](auto cfg_c, const f32x4 (&raw)[8], unsigned short* buf, float sc) {
+        constexpr int ROLE = decltype(cfg_c)::value & 3;
+        if (ROLE == 3) { store_small(split_small(raw[0], sc), 0, buf); store_small(split_small(raw[1], sc), 1, buf); }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_big(cfg_c, raw, e, buf, sc);
+        }
+    };
+    // the largest exponent in a wave's share of a sub-tile (the registers of its loads) -> slots[parity][wave]
+    auto publish = [&](auto cfg_c, const f32x4 (&raw)[8], int parity) {
+        constexpr int CFG = decltype(cfg_c)::value, ROLE = CFG & 3;
+        constexpr bool UPA = (CFG >> 2) & 1;
+        constexpr int NR = ROLE == 3 ? 2 : ((ROLE == 1 && UPA) ? 4 : 8);
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(raw[i][e]));
+        const int ex = wave_max_exponent(m);
+        if (lane == 0) slots[parity * 4 + wave] = ex;
+    };
+    // running exponents of the two operands (block-uniform: every wave derives them from the same slots)
+    int ez_run = F16_EMIN, ex_run = F16_EMIN;
+    auto next_exponents = [&](int parity, int& ez_n, int& ex_n) {
+        const i32x4 pe = *reinterpret_cast<const i32x4*>(slots + parity * 4);
+        ez_n = __builtin_amdgcn_readfirstlane(max(ez_run, pe[0]));
+        ex_n = __builtin_amdgcn_readfirstlane(max(ex_run, max(pe[1], max(pe[2], pe[3]))));
+    };
+
+    const int zoff = (wco * 32 + l32) * ZP + h * 8, xoff = XS0 + (wci * 32 + l32) * XP + h * 8;
+    // fragments a phase starts with: the dZ rows and X row 0 of its buffer.  They are read by the PREVIOUS phase, right behind the
+    // barrier that phase places in front of its last row's MFMAs (row 3: registers only) -- the LDS latency at the start of a sub-tile
+    // disappears under those MFMAs
+    struct Frag { f16x8 zf[TH][NP]; i32x4 x0[NP][3]; };
+    auto prefetch = [&](const unsigned short* buf, Frag& f) {
+        const unsigned short* zrow = buf + zoff;
+        const unsigned short* xrow = buf + xoff;
+#pragma unroll
+        for (int py = 0; py < TH; ++py)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) f.zf[py][q] = *reinterpret_cast<const f16x8*>(zrow + q * PIX + py * TW);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const unsigned short* g0 = xrow + q * XQ;
+            f.x0[q][0] = *reinterpret_cast<const i32x4*>(g0);
+            f.x0[q][1] = *reinterpret_cast<const i32x4*>(g0 + 8);
+            f.x0[q][2] = *reinterpret_cast<const i32x4*>(g0 + 16);
+        }
+    };
+    // one sub-tile: its MFMAs out of `cur`, the staging of the next one (registers rs, loaded a phase ago) into `nxt`, the loads of the
+    // one after that into rl.  One copy of this code per cfg: a wave runs ITS staging instructions between the MFMAs and nothing else,
+    // in one basic block
+    // rs: sub-tile j + 1 (stored now), rp: sub-tile j + 2 (landed; its maximum is published in front of this phase's barrier, so the next
+    // phase knows the scale of its stores), rl: sub-tile j + 3 (loads issued now): three register sets, because a phase is half as long as
+    // with three pieces and a load needs more than one of them to land
+    auto phase = [&](auto cfg_c, int j, const f32x4 (&rs)[8], const f32x4 (&rp)[8], f32x4 (&rl)[8], Frag& fr) {
+        constexpr int CFG = decltype(cfg_c)::value, ROLE = CFG & 3, PH = (CFG >> 4) & 1;
+        const unsigned short* cur = lds16 + (j & 1) * BUF;
+        unsigned short* nxt = lds16 + ((j + 1) & 1) * BUF;
+        int ez_n, ex_n;
+        next_exponents((j + 1) & 1, ez_n, ex_n);
+        const float sc = f16_scale_of(ROLE == 0 ? ez_n : ex_n);
+        // (halo role: split BEFORE the next loads are issued -- with the two old and the two new loads in flight together the compiler's
+        //  wait in front of the split, vmcnt(1), also waited for the first NEW load: a memory latency per sub-tile, stamped per wave)
+        SmallPc pc0 = {}, pc1 = {};
+        unsigned tok = 0;                                           // (zero; makes the loads' offsets depend on the split's results: program order alone did not hold)
+        if (ROLE == 3) {
+            pc0 = split_small(rs[0], sc);
+            pc1 = split_small(rs[1], sc);
+            asm volatile("" : "+v"(tok) : "v"(pc0.lo[0]), "v"(pc0.lo[1]), "v"(pc0.hi[0]), "v"(pc0.hi[1]),
+                                          "v"(pc1.lo[0]), "v"(pc1.lo[1]), "v"(pc1.hi[0]), "v"(pc1.hi[1]));
+        }
+        issue_loads(cfg_c, min(j + 3, NJ - 1), j + 3 < NJ, rl, tok);
+        const unsigned short* xrow = cur + xoff;
+        f16x8 zf[TH][NP];
+        i32x4 xraw[2][NP][3];                                       // [row parity][piece][prev | cur | next]
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+#pragma unroll
+            for (int py = 0; py < TH; ++py) zf[py][q] = fr.zf[py][q];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xraw[0][q][i] = fr.x0[q][i];
+        }
+        auto read_row = [&](int r) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const unsigned short* g0 = xrow + q * XQ + r * XROW;
+                xraw[r & 1][q][0] = *reinterpret_cast<const i32x4*>(g0);
+                xraw[r & 1][q][1] = *reinterpret_cast<const i32x4*>(g0 + 8);
+                xraw[r & 1][q][2] = *reinterpret_cast<const i32x4*>(g0 + 16);
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < XH; ++r) {
+            if (r + 1 < XH) read_row(r + 1);
+            else {
+                if (j + 2 < NJ) publish(cfg_c, rp, j & 1);          // sub-tile j + 2 (parity j: last read at this phase's start, by every wave before its stores)
+                __syncthreads();                                    // every wave has read `cur` (row 3 is in registers) and written its part of `nxt`
+                prefetch(nxt, fr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // staging of the next sub-tile under the MFMAs of the two middle rows
+            if (ROLE == 3) {
+                if (r == 1) store_small(pc0, 0, nxt);
+                if (r == 2) store_small(pc1, 1, nxt);
+            } else {
+                if (r == 1) { store_big(cfg_c, rs, 0, nxt, sc); store_big(cfg_c, rs, 1, nxt, sc); }
+                if (r == 2) { store_big(cfg_c, rs, 2, nxt, sc); store_big(cfg_c, rs, 3, nxt, sc); }
+            }
+            f16x8 xf[3][NP];                                         // [kx][piece]
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const i32x4 prev = xraw[r & 1][q][0], curv = xraw[r & 1][q][1], next = xraw[r & 1][q][2];
+                i32x4 left, right;
+                left[0] = (int)__builtin_amdgcn_alignbit((unsigned)curv[0], (unsigned)prev[3], 16);
+                right[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)curv[3], 16);
+#pragma unroll
+                for (int i = 1; i < 4; ++i) left[i] = (int)__builtin_amdgcn_alignbit((unsigned)curv[i], (unsigned)curv[i - 1], 16);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) right[i] = (int)__builtin_amdgcn_alignbit((unsigned)curv[i + 1], (unsigned)curv[i], 16);
+                xf[0][q] = __builtin_bit_cast(f16x8, left);
+                xf[1][q] = __builtin_bit_cast(f16x8, curv);
+                xf[2][q] = __builtin_bit_cast(f16x8, right);
+            }
+            int n_mfma = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int py = r - ky;
+                if (py < 0 || py >= TH) continue;
+                if (CO32 && py != PH) continue;
+                n_mfma += 3 * NPROD;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+                        for (int qa = 0; qa <= ord; ++qa)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zf[py][qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
+            }
+            // one MFMA, then up to WG_FILL of the staging's vector / LDS-store instructions in the cycles it leaves free
+#pragma unroll
+            for (int i = 0; i < n_mfma; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x202, CO32 ? 2 * WG_FILL + 2 : 2 * WG_FILL, 0);      // (half the MFMAs for the same staging)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next sub-tile was staged at (ez_n, ex_n): when that differs from this one's scale, re-base the sums (exact)
+        if (ez_n + ex_n != ez_run + ex_run) {
+            const float rb = f16_rebase(ez_run + ex_run, ez_n + ex_n);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] *= rb;
+        }
+        ez_run = ez_n; ex_run = ex_n;
+    };
+    auto run = [&](auto cfg_c) {
+        constexpr int ROLE = decltype(cfg_c)::value & 3;
+        f32x4 r0[8], r1[8], r2[8];                                  // sub-tile t lives in set t % 3
+        issue_loads(cfg_c, 0, true, r0);
+        issue_loads(cfg_c, 1, true, r1);                            // (NJ >= 2)
+        issue_loads(cfg_c, min(2, NJ - 1), 2 < NJ, r2);
+        publish(cfg_c, r0, 0);
+        publish(cfg_c, r1, 1);
+        __syncthreads();
+        {
+            int ez_n, ex_n;
+            next_exponents(0, ez_n, ex_n);
+            ez_run = ez_n; ex_run = ex_n;
+            store_all(cfg_c, r0, lds16, f16_scale_of(ROLE == 0 ? ez_n : ex_n));
+        }
+        __syncthreads();
+        Frag fr;
+        prefetch(lds16, fr);
+        for (int j = 0; j < NJ; j += 3) {
+            phase(cfg_c, j, r1, r2, r0, fr);
+            if (j + 1 < NJ) phase(cfg_c, j + 1, r2, r0, r1, fr);
+            if (j + 2 < NJ) phase(cfg_c, j + 2, r0, r1, r2, fr);
+        }
+    };
+    if (NJ > 0) {
+        // the wave's code copy.  CO32: output row ph = wave & 1
+#define WG_RUN(CFG) run(std::integral_constant<int, (CFG)>{})
+        constexpr int P1 = CO32 ? 16 : 0;                           // cfg bit 4 of the odd waves
+        if (role == 0) WG_RUN(0);
+        else if (role == 1) { if (xs[0].up) WG_RUN(1 | 4 | P1); else WG_RUN(1 | P1); }
+        else if (role == 2) { if (xs[1].up) WG_RUN(1 | 4); else WG_RUN(1); }
+        else if (xs[1].up) WG_RUN(3 | 4 | 8 | P1);
+        else if (xs[0].up) WG_RUN(3 | 4 | P1);
+        else WG_RUN(3 | P1);
+#undef WG_RUN
+    }
+    {                                                               // sums of (dZ 2^kz)(X 2^kx): back to the operands' units (exact)
+        const float inv = f16_inv_scale_of(ez_run) * f16_inv_scale_of(ex_run);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] *= inv;
+    }
+    // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 31, row (co) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* dst = part + (size_t)(CO32 ? blk * 2 + (wave & 1) : blk) * p.Co * 9 * p.Ct;
+    const int ci = c_base + wci * 32 + l32;
+    if (ci < p.Ct) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Co) dst[((size_t)co * 9 + t) * p.Ct + ci] = acc[t][r];
+            }
+    }
+#ifdef CODEPS_WG_STAMP_WAVES
+    CODEPS_STAMP_END_WAVES(conv);
+#else
+    CODEPS_STAMP_END(conv);
+#endif
+}
+
+template <bool CO32, int ARITH = 3>
 __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                             const float* __restrict__ x0, const float* __restrict__ x1,
                                                             const float* __restrict__ dz, float* __restrict__ part) {
@@ -3397,8 +3879,11 @@ __global__ __launch_bounds__(256) void wgrad_halo64s_kernel(WgradP p, int ci_chu
     const int c_base = (blockIdx.x % ci_chunks) * 64;
     const bool one_src = c_base >= p.C0 || p.C1 == 0 || c_base + 64 <= p.C0;
     // p.fast: the layer-wide conditions (host); per block: each 32-channel half of the chunk in one source -> the double-buffered body
-    if (p.fast && (one_src || c_base + 32 == p.C0)) wgrad_halo64d_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
-    else wgrad_halo64s_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+    // (ARITH 16: on two fp16 pieces; the generic body keeps the three bf16 pieces under either arithmetic)
+    if (p.fast && (one_src || c_base + 32 == p.C0)) {
+        if constexpr (ARITH == 16) wgrad_halo64h_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+        else wgrad_halo64d_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
+    } else wgrad_halo64s_body<CO32>(p, ci_chunks, tiles_x, tiles_y, tiles_per_block, x0, x1, dz, part, lds16);
 }
 
 // Weight gradient of the double-pixel stem (7 x 4 taps of 16 channels, stride (2, 1), 64 output channels) on the bf16 matrix
@@ -4768,7 +5253,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                         codeps_allow_lds((const void*)kr, 160 * 1024, "conv_halo3r_kernel<ex>");
                     }
                     g_last_kernel = halo_ws ? (p.ksplit > 1 ? "conv_halo3p_kernel<splitk>" : "conv_halo3p_kernel")
-                                            : h16 ? (p.ksplit > 1 ? "conv_halo3r_kernel<f16x2,splitk>" : "conv_halo3r_kernel<f16x2>")
+                                            : h16 ? (p.ksplit > 1 ? "conv_halo3r_kernel<splitk,f16x2>" : "conv_halo3r_kernel<f16x2>")
                                             : (p.ksplit > 1 ? "conv_halo3r_kernel<splitk>" : "conv_halo3r_kernel");
                     constexpr size_t lds_r16 = ((size_t)205 * ((2 * BK + 8) / 2 + 4) + (size_t)4 * BN * ((2 * BK + 8) / 2)) * sizeof(float) + 16;
                     hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(halo_ws ? 384 : 256), h16 ? lds_r16 : lds_r, st, p, a0, a1, scale, shift, residual, out);
@@ -4777,10 +5262,14 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                 }
             }
             p.ksplit = 1;
-            auto kh = epi_plan(p, 128) ? conv_halo3_kernel<MODE, TN, 2, 2, true> : conv_halo3_kernel<MODE, TN>;
+            const bool h16 = f16_pairs();
+            const bool ex = epi_plan(p, 128);
+            auto kh = h16 ? (ex ? conv_halo3_kernel<MODE, TN, 2, 2, true, 16> : conv_halo3_kernel<MODE, TN, 2, 2, false, 16>)
+                          : (ex ? conv_halo3_kernel<MODE, TN, 2, 2, true> : conv_halo3_kernel<MODE, TN>);
             codeps_allow_lds((const void*)kh, 160 * 1024, "kh");
-            g_last_kernel = "conv_halo3_kernel";
-            hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
+            g_last_kernel = h16 ? "conv_halo3_kernel<f16x2>" : "conv_halo3_kernel";
+            constexpr size_t lds_h16 = std::max(((size_t)204 * 40 + (size_t)2 * BN * 36) * sizeof(float) + 16, (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), h16 ? lds_h16 : lds_h, st, p, a0, a1, scale, shift, residual, out);
             return;
         }
         static const int ws_min = getenv("CODEPS_WS_MIN") ? atoi(getenv("CODEPS_WS_MIN")) : 32;      // K-steps from which the wave-specialised kernel runs
@@ -4812,10 +5301,14 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             constexpr size_t lds_h = std::max(((size_t)340 * (LDKp + (CODEPS_HALO_SWZ ? 4 : 0)) + (size_t)2 * BN * LDKp) * sizeof(float),
                                               (size_t)WM * 32 * (BN + 4) * sizeof(float));
             p.ksplit = 1;
-            auto kh = epi_plan(p, 256) ? conv_halo3_kernel<MODE, 1, 4, 1, true> : conv_halo3_kernel<MODE, 1, 4, 1>;
+            const bool h16 = f16_pairs();
+            const bool ex = epi_plan(p, 256);
+            auto kh = h16 ? (ex ? conv_halo3_kernel<MODE, 1, 4, 1, true, 16> : conv_halo3_kernel<MODE, 1, 4, 1, false, 16>)
+                          : (ex ? conv_halo3_kernel<MODE, 1, 4, 1, true> : conv_halo3_kernel<MODE, 1, 4, 1>);
             codeps_allow_lds((const void*)kh, 160 * 1024, "conv_halo3_kernel<4x1>");
-            g_last_kernel = "conv_halo3_kernel<32 columns>";
-            hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), lds_h, st, p, a0, a1, scale, shift, residual, out);
+            g_last_kernel = h16 ? "conv_halo3_kernel<32 columns,f16x2>" : "conv_halo3_kernel<32 columns>";
+            constexpr size_t lds_h16 = std::max(((size_t)340 * 40 + (size_t)2 * BN * 36) * sizeof(float) + 16, (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            hipLaunchKernelGGL(kh, dim3(p.n_mt * p.n_nt), dim3(256), h16 ? lds_h16 : lds_h, st, p, a0, a1, scale, shift, residual, out);
             return;
         }
     }
@@ -4830,11 +5323,22 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     }
     // (the extras exist in the default arithmetic's instantiations -- three bf16 pieces at 32-channel K steps -- and the f32 form the <= 64-column tiles fall back to)
     constexpr bool EXOK = (NP == 3 && BK == 32 && NBUF == 1) || (NP == 0 && BK == 16 && NBUF == 2);
-    if constexpr (EXOK) { if (epi_plan(p, BM)) k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, NP, true>; }
-    else epi_plan(p, BM, false);
+    bool h16 = false;
+    size_t lds_k = lds;
+    if constexpr (NP == 3 && BK == 32 && NBUF == 1) {
+        if (f16_pairs()) {                                   // two fp16 pieces (conv_igemm_kernel<.., NP = 2>): 128-byte LDS rows + the maxima slot
+            h16 = true;
+            k = epi_plan(p, BM) ? conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, 2, true> : conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, 2>;
+            lds_k = std::max(((size_t)(BM + BN) * 32 + (size_t)nsrc * ntap * BM) * sizeof(float) + 16, (size_t)WM * 32 * (BN + 4) * sizeof(float));
+        }
+    }
+    if (!h16) {
+        if constexpr (EXOK) { if (epi_plan(p, BM)) k = conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, NP, true>; }
+        else epi_plan(p, BM, false);
+    }
     codeps_allow_lds((const void*)k, 160 * 1024, "k");
-    g_last_kernel = NP == 3 ? (BK == 16 ? "conv_igemm_kernel<split3,bk16>" : "conv_igemm_kernel<split3>") : (NP == 2 ? "conv_igemm_kernel<split2>" : "conv_igemm_kernel<f32>");
-    hipLaunchKernelGGL(k, dim3(blocks, p.ksplit, p.par == 2 ? 4 : 1), dim3(256), lds, st, p, a0, a1, wq, scale, shift, residual, out);
+    g_last_kernel = h16 ? "conv_igemm_kernel<f16x2>" : NP == 3 ? (BK == 16 ? "conv_igemm_kernel<split3,bk16>" : "conv_igemm_kernel<split3>") : "conv_igemm_kernel<f32>";
+    hipLaunchKernelGGL(k, dim3(blocks, p.ksplit, p.par == 2 ? 4 : 1), dim3(256), lds_k, st, p, a0, a1, wq, scale, shift, residual, out);
     if (p.ksplit > 1) launch_splitk_finish<MODE>(p, st, scale, shift, residual, out);
 }
 
@@ -4929,7 +5433,6 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         /* form on the whole adapt step (63.3 vs 66.2 ms of conv time), so it is the default                          */ \
         const int nbuf = nbuf_env ? nbuf_env : 1;                                                    \
         if (bk32 && nbuf == 1 && split_np == 3) launch_igemm<MODE, WM, WN, TM, TN, 32, 1, 3>(p, a0, a1, wq, scale, shift, residual, out, st); \
-        else if (bk32 && nbuf == 1 && split_np == 2) launch_igemm<MODE, WM, WN, TM, TN, 32, 1, 2>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (bk32 && nbuf == 1) launch_igemm<MODE, WM, WN, TM, TN, 32, 1>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (MODE == MODE_FWD && split_np == 3 && nbuf == 1 && p.Ct == 16 && p.C1 == 0 && (p.KH * p.KW * 16) % 32 == 0)   /* stem */ \
@@ -5095,7 +5598,7 @@ static int conv_arith(const codeps_conv_desc* d, int mode, int source) {
     const int split_np = split_pieces();
     static const int force_bk = getenv("CODEPS_FORCE_BK") ? atoi(getenv("CODEPS_FORCE_BK")) : 0;
     static const int nbuf_env = getenv("CODEPS_NBUF") ? atoi(getenv("CODEPS_NBUF")) : 0;
-    if (split_np != 2 && split_np != 3) return 0;
+    if (split_np != 3) return 0;
     if (force_bk == 16 || (nbuf_env && nbuf_env != 1)) return 0;
     if (mode != 2 && split_np == 3) {
         // conv_halo3n16_kernel's shapes (halo3n16_ok on the descriptor; the same for the forward and the data gradient: stride 1, pad 1)
@@ -5374,7 +5877,7 @@ extern "C" int codeps_conv2d_set_halo_ws(int on) {
 
 extern "C" int codeps_conv2d_set_arith(int pieces) {
     const int prev = split_raw();
-    if (pieces == 0 || pieces == 2 || pieces == 3 || pieces == 16) g_split_np = pieces;
+    if (pieces == 0 || pieces == 3 || pieces == 16) g_split_np = pieces;
     return prev;
 }
 
@@ -5432,17 +5935,13 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
             if (wgrad_split_on()) {
                 // 4 x 16 tiles: dZs + Xs (halfwords); the double-buffered body: two 2 x 16 sub-tiles
                 constexpr size_t lds_s = (size_t)64 * ((3 * 64 + 8) + (3 * 6 * 32 + 8)) * 2, lds_d = (size_t)2 * (64 * ((3 * 32 + 8) + (3 * 4 * 32 + 8))) * 2;
-                const size_t lds = std::max(lds_s, lds_d);
-                if (sp.co32) {
-                    g_last_kernel = "wgrad_halo64s_kernel<co32>";
-                    codeps_allow_lds((const void*)wgrad_halo64s_kernel<true>, 160 * 1024, "wgrad_halo64s_kernel<co32>");
-                    hipLaunchKernelGGL(wgrad_halo64s_kernel<true>, dim3(g, sp.co_groups), dim3(256), lds, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
-                                       sp.tiles_per_block, x0, x1, dz, part);
-                } else {
-                    codeps_allow_lds((const void*)wgrad_halo64s_kernel<false>, 160 * 1024, "wgrad_halo64s_kernel");
-                    hipLaunchKernelGGL(wgrad_halo64s_kernel<false>, dim3(g, sp.co_groups), dim3(256), lds, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
-                                       sp.tiles_per_block, x0, x1, dz, part);
-                }
+                constexpr size_t lds_h = (size_t)2 * (64 * ((2 * 32 + 8) + (2 * 4 * 32 + 8))) * 2 + 32;       // two fp16 pieces + the exponent slots
+                const bool h16 = f16_pairs();
+                const size_t lds = h16 ? std::max(lds_s, lds_h) : std::max(lds_s, lds_d);
+                auto kw = sp.co32 ? (h16 ? wgrad_halo64s_kernel<true, 16> : wgrad_halo64s_kernel<true>) : (h16 ? wgrad_halo64s_kernel<false, 16> : wgrad_halo64s_kernel<false>);
+                g_last_kernel = sp.co32 ? (h16 ? "wgrad_halo64s_kernel<co32,f16x2>" : "wgrad_halo64s_kernel<co32>") : (h16 ? "wgrad_halo64s_kernel<f16x2>" : "wgrad_halo64s_kernel");
+                codeps_allow_lds((const void*)kw, 160 * 1024, "wgrad_halo64s_kernel");
+                hipLaunchKernelGGL(kw, dim3(g, sp.co_groups), dim3(256), lds, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, x1, dz, part);
             } else
             hipLaunchKernelGGL(wgrad_halo64_kernel, dim3(g, sp.co_groups), dim3(256), 0, st, p, sp.ci_chunks, sp.tiles_x, sp.tiles_y,
                                sp.tiles_per_block, x0, x1, dz, part);

@@ -26,6 +26,9 @@ TIMED = {               # name: (B, H, W, C0, C1, Cout, k, up0)
     "l1_3x3": (8, 128, 256, 64, 0, 64, 3, False),
     "l4_3x3": (8, 16, 32, 512, 0, 512, 3, False),
     "pose_l2": (12, 64, 128, 128, 0, 128, 3, False),
+    "pose_l1": (12, 128, 256, 64, 0, 64, 3, False),
+    "dec_64": (6, 128, 256, 64, 256, 64, 3, True),
+    "dec_32col": (6, 256, 512, 32, 64, 32, 3, True),
     "l1_expand": (8, 128, 256, 64, 0, 256, 1, False),
     "l2_expand": (8, 64, 128, 128, 0, 512, 1, False),
     "l3_reduce": (8, 32, 64, 1024, 0, 256, 1, False),
@@ -109,6 +112,10 @@ ACC = {                 # name: (B, H, W, Cin, Cout, k)
     "halo3r_dgrad": (2, 64, 128, 256, 256, 3),
     "halo3r_splitk": (4, 32, 64, 512, 256, 3),
     "deep_k": (2, 32, 64, 2048, 256, 3),
+    "halo3_64": (4, 64, 128, 64, 64, 3),
+    "igemm_1x1": (8, 32, 64, 256, 1024, 1),
+    "igemm_1x1_b": (8, 32, 64, 512, 2048, 1),
+    "igemm_odd": (3, 40, 72, 96, 160, 3),
 }
 
 
