@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
 LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 9
+ABI_VERSION = 10
 DIAG_LIB_PATH = os.path.join(_HERE, "libcodeps_diag.so")
 
 _lib = None
@@ -95,6 +95,8 @@ SIGNATURES = {
     "codeps_chain1x1_w2_row_bytes": (c_size_t, []),
     "codeps_chain1x1_workspace_bytes": (c_size_t, [LL, I]),
     "codeps_chain1x1_expand_reduce": (c_int, [P, P, P, P, P, P, LL, I, P, P, P, c_size_t, P]),
+    "codeps_chain1x1_w2_row_bytes_h": (c_size_t, []),
+    "codeps_chain1x1_expand_reduce_h": (c_int, [P, P, P, P, P, P, LL, I, P, P, P, c_size_t, P]),
     "codeps_nchw_to_nhwc": (c_int, [P, I, I, I, I, P, I, I, I, P]),
     "codeps_nchw_to_nhwc_xpad": (c_int, [P, I, I, I, I, P, I, I, I, I, I, P]),
     "codeps_frames_to_nhwc": (c_int, [P, P, P, I, I, I, I, P, I, I, I, P]),

@@ -975,20 +975,29 @@ def _chain_perm(n2, device):
     return (torch.arange(0, n2, 32, device=device).view(-1, 1) + inner.view(1, -1)).reshape(-1)
 
 
-def chain_weights(w_expand, scale2, shift2, w_reduce):
+def _pack_regions(wf, total):
+    """Byte views of a pack buffer (csrc/conv.hip, pack_off_*): the three-bf16-piece copy, the two-fp16-piece copy, the scale slot."""
+    b = wf.view(torch.uint8)
+    off16 = (total + (total * 6 + 3) // 4) * 4
+    return b[total * 4:][:total * 6], b[off16:][:total * 4], wf[(off16 // 4) + total:][:4]
+
+
+def chain_weights(w_expand, scale2, shift2, w_reduce, scale3=None):
     """Weight blobs of codeps_chain1x1_expand_reduce for FROZEN 1x1 weights (cached per parameter pair / version):
     w2 rows = the pre-split expand pack row (8 x [3 pieces][32 bf16]) + 16 bytes (scale, shift, 0, 0); w3 = the pre-split pack
-    of the reduce weights with the permuted k order."""
-    key = (id(w_expand), id(w_reduce))
+    of the reduce weights with the permuted k order.  Under arithmetic 16 (two fp16 pieces, codeps_chain1x1_expand_reduce_h) the rows
+    hold 8 x [2 pieces][32 fp16], the affine's scale carries the pack's 2^-kb, and a third result is scale3 x the reduce pack's 2^-kb."""
+    h16 = _arith() == 16
+    key = (id(w_expand), id(w_reduce), h16)
     # trainable (or teacher-view) weights are rewritten through raw pointers by the fused optimizer: their entry lives for one
     # weights epoch.  The folded BatchNorm is identified by OBJECT (the entry keeps scale2 / shift2 alive, so their addresses
     # cannot be handed to a newer fold while the entry exists)
     volatile = _is_volatile(w_expand) or _is_volatile(w_reduce) or _is_volatile(scale2) or _is_volatile(shift2)
     stamp = (w_expand._version, w_reduce._version, scale2._version, shift2._version, w_expand.data_ptr(), w_reduce.data_ptr(),
-             _weights_epoch[0] if volatile else 0)
+             _weights_epoch[0] if volatile else 0, None if scale3 is None else (scale3.data_ptr(), scale3._version))
     hit = _chain_cache.get(key)
     if hit is not None and hit[0] == stamp and hit[3]() is w_expand and hit[4]() is w_reduce and hit[5] is scale2 and hit[6] is shift2:
-        return hit[1], hit[2]
+        return (hit[1], hit[2], hit[7]) if h16 else (hit[1], hit[2])
     n2, kmid = w_expand.shape[:2]
     c3 = w_reduce.shape[0]
     if kmid != 256 or c3 != 256 or w_reduce.shape[1] != n2 or n2 % 64 or tuple(w_expand.shape[2:]) != (1, 1) or tuple(w_reduce.shape[2:]) != (1, 1):
@@ -996,17 +1005,22 @@ def chain_weights(w_expand, scale2, shift2, w_reduce):
     dev = w_expand.device
     with torch.no_grad():
         wf, _ = pack_weights(w_expand, n2, kmid, False)
-        split = wf.view(torch.uint8)[n2 * kmid * 4:][:n2 * kmid * 6].view(n2, kmid * 6)
+        s3, s2h, slot2 = _pack_regions(wf, n2 * kmid)
         aff = torch.zeros(n2, 4, dtype=torch.float32, device=dev)
         aff[:, 0], aff[:, 1] = _f32c(scale2.detach()), _f32c(shift2.detach())
-        rowb = lib().codeps_chain1x1_w2_row_bytes()
+        if h16:
+            aff[:, 0] *= slot2[0]                                 # 2^-kb of the expand pack (a device scalar: no sync)
+        rowb = lib().codeps_chain1x1_w2_row_bytes_h() if h16 else lib().codeps_chain1x1_w2_row_bytes()
+        split = s2h.view(n2, kmid * 4) if h16 else s3.view(n2, kmid * 6)
         w2 = torch.cat([split, aff.view(torch.uint8).view(n2, 16)], 1).contiguous()
         assert w2.shape[1] == rowb
         w3p = _f32c(w_reduce.detach())[:, _chain_perm(n2, dev)].contiguous()
         wf3, _ = pack_weights(w3p, c3, n2, False)
-        w3 = wf3.view(torch.uint8)[c3 * n2 * 4:][:c3 * n2 * 6].clone()
-    _chain_cache[key] = (stamp, w2, w3, _weak(w_expand, _chain_cache, key), weakref.ref(w_reduce), scale2, shift2)
-    return w2, w3
+        r3, r2h, slot3 = _pack_regions(wf3, c3 * n2)
+        w3 = (r2h if h16 else r3).clone()
+        sc3 = (_f32c(scale3.detach()) * slot3[0]).contiguous() if (h16 and scale3 is not None) else None
+    _chain_cache[key] = (stamp, w2, w3, _weak(w_expand, _chain_cache, key), weakref.ref(w_reduce), scale2, shift2, sc3)
+    return (w2, w3, sc3) if h16 else (w2, w3)
 
 
 def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3, shift3):
@@ -1020,7 +1034,12 @@ def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3
     b, h, w_, kmid = y1.shape
     n2 = w_expand.shape[0]
     rows = b * h * w_
-    w2, w3 = chain_weights(w_expand, scale2, shift2, w_reduce)
+    h16 = _arith() == 16
+    if h16:
+        w2, w3, sc3 = chain_weights(w_expand, scale2, shift2, w_reduce, scale3)
+    else:
+        w2, w3 = chain_weights(w_expand, scale2, shift2, w_reduce)
+        sc3 = _f32c(scale3)
     y1, residual = y1.contiguous(), residual.contiguous()
     out = torch.empty(b, h, w_, n2, dtype=torch.float32, device=y1.device)
     y0 = torch.empty(b, h, w_, 256, dtype=torch.float32, device=y1.device)
@@ -1028,10 +1047,12 @@ def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3
     t0 = _prof_begin()
     wsb = lib().codeps_chain1x1_workspace_bytes(rows, n2)
     ws = _workspace(wsb, y1.device, "chain1x1") if wsb else None
-    check(lib().codeps_chain1x1_expand_reduce(ptr(y1), ptr(residual), ptr(w2), ptr(w3), ptr(_f32c(scale3)), ptr(_f32c(shift3)), rows, n2,
-                                              ptr(out), ptr(y0), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()),
+    fn = lib().codeps_chain1x1_expand_reduce_h if h16 else lib().codeps_chain1x1_expand_reduce
+    check(fn(ptr(y1), ptr(residual), ptr(w2), ptr(w3), ptr(sc3), ptr(_f32c(shift3)), rows, n2,
+             ptr(out), ptr(y0), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()),
           "codeps_chain1x1_expand_reduce")
-    _prof_end(t0, "conv_fwd_split", flops, tag=f"B{b} {h}x{w_} 256->{n2}->256 k1 chain", kernel="chain_expand_reduce_kernel")
+    _prof_end(t0, "conv_fwd_split", flops, tag=f"B{b} {h}x{w_} 256->{n2}->256 k1 chain",
+              kernel="chain_expand_reduce_h_kernel" if h16 else "chain_expand_reduce_kernel")
     return out, y0
 
 

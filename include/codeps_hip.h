@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* codeps_stream_t;
 
-int codeps_version(void);                 /* ABI version (9), bumped on any signature / buffer-contract change */
+int codeps_version(void);                 /* ABI version (10), bumped on any signature / buffer-contract change */
 const char* codeps_last_error(void);      /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------------------------------------
@@ -194,6 +194,14 @@ size_t codeps_chain1x1_w2_row_bytes(void);
  * reduce's partial sums pass through `workspace` (codeps_chain1x1_workspace_bytes, 0 = not needed) and a fixed-order finish pass. */
 size_t codeps_chain1x1_workspace_bytes(long long rows, int n2);
 int codeps_chain1x1_expand_reduce(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
+                                  const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
+                                  void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* The same launch on the two-fp16-piece arithmetic (codeps_conv2d_set_arith(16)): w2_rows = n2 rows of codeps_chain1x1_w2_row_bytes_h() bytes =
+ * the fp16-pair pack row of W2 (256 x 4 bytes) + (scale2 * 2^-kb, shift2, 0, 0) with 2^-kb the pack's inverted per-tensor scale; w3_split = the
+ * fp16-pair pack of the k-permuted reduce weights; scale3 must carry THAT pack's 2^-kb as well (codeps_amd.functional.chain_weights builds all
+ * three).  Activations are scaled per pixel inside the kernel. */
+size_t codeps_chain1x1_w2_row_bytes_h(void);
+int codeps_chain1x1_expand_reduce_h(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
                                   const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
                                   void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d);
