@@ -275,18 +275,25 @@ def conv_roofline(runner, data, steps=2, default_workload=False):
     flops = sum(v[0] for v in by.values())
     secs = sum(v[1] for v in by.values())
     n = sum(v[2] for v in by.values())
-    split_pieces = int(os.environ.get("CODEPS_SPLIT", "3"))
-    products = {3: 6, 2: 3}.get(split_pieces, 6)
-    peak_of = lambda k: PEAK_BF16_MFMA_TFLOPS / products if k.endswith("_split") else PEAK_F32_MFMA_TFLOPS
+    # kinds: *_f16x2 = two fp16 pieces, three products per multiply on the f16 MFMA (same rate as bf16): peak = dense 16-bit MFMA / 3;
+    #        *_split = three bf16 pieces, six products: / 6;  the rest: f32 MFMA
+    peak_of = lambda k: (PEAK_BF16_MFMA_TFLOPS / 3 if k.endswith("_f16x2") else PEAK_BF16_MFMA_TFLOPS / 6 if k.endswith("_split")
+                         else PEAK_F32_MFMA_TFLOPS)
     detail = {k: {"launches_per_step": v[2] // steps, "tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3),
                   "peak": round(peak_of(k), 1), "frac": round(v[0] / v[1] / 1e12 / peak_of(k), 4)} for k, v in by.items()}
     # dominant kernel: the split-operand implicit GEMM (forward + data gradient) when it runs, else everything on the f32 MFMA
-    dom = [k for k in by if k.endswith("_split")]
+    groups = {sfx: [k for k in by if k.endswith(sfx)] for sfx in ("_f16x2", "_split")}
+    sfx = max(groups, key=lambda g: sum(by[k][1] for k in groups[g]))      # the arithmetic most of the conv time runs on
+    dom = groups[sfx]
+    products = 3 if sfx == "_f16x2" else 6
     if dom:
         dflops, dsecs, dn = (sum(by[k][i] for k in dom) for i in range(3))
         peak = PEAK_BF16_MFMA_TFLOPS / products
-        name = (f"conv_igemm_kernel fwd + dgrad, wgrad_halo64s_kernel: fp32 operands as {split_pieces} bf16 pieces, {products} products on "
-                f"v_mfma_f32_32x32x16_bf16, fp32 accumulate (peak = dense bf16 MFMA {PEAK_BF16_MFMA_TFLOPS:.0f} / {products})")
+        name = ("conv_halo3 / conv_halo3r / conv_igemm / chain_expand_reduce_h fwd + dgrad, wgrad_halo64s: fp32 operands as two fp16 pieces of x 2^k "
+                "(block-local power-of-two scales), three products on v_mfma_f32_16x16x32_f16 / 32x32x16_f16, fp32 accumulate (peak = dense 16-bit MFMA "
+                f"{PEAK_BF16_MFMA_TFLOPS:.0f} / 3)") if sfx == "_f16x2" else (
+                "conv_igemm_kernel fwd + dgrad, wgrad_halo64s_kernel: fp32 operands as 3 bf16 pieces, 6 products on "
+                f"v_mfma_f32_32x32x16_bf16, fp32 accumulate (peak = dense bf16 MFMA {PEAK_BF16_MFMA_TFLOPS:.0f} / 6)")
     else:
         dflops, dsecs, dn, peak = flops, secs, n, PEAK_F32_MFMA_TFLOPS
         name = "conv_igemm_kernel + conv_wgrad_kernel (f32 MFMA 32x32x2)"
@@ -566,11 +573,21 @@ def main():
             "step_ms": {"median": round(per_step[len(per_step) // 2], 3), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
                         "images_per_sec_at_median": round(n_images * world / (per_step[len(per_step) // 2] * 1e-3), 2)},
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": ("fp32 end to end; conv forward / data-gradient / halo-tile and 1x1 weight-gradient operands enter the matrix cores as "
-                           "exact 3-way bf16 splits (six bf16 products per multiply, fp32 accumulate: product error ~6e-9 relative, below "
-                           "fp32 rounding); the <= 32-channel weight gradients, the 1x1 16-column kernels, the last up-convolution and the "
-                           "1-channel disparity head on the f32 MFMA") if os.environ.get("CODEPS_SPLIT", "3") == "3" else
-                          ("CODEPS_SPLIT=" + os.environ.get("CODEPS_SPLIT", "3") + " (non-default arithmetic, see codeps_amd/csrc/conv.hip)"),
+            "arithmetic": {
+                "16": ("fp32 tensors end to end.  Default since round 6 (CODEPS_SPLIT=16): the 3x3 / 1x1 forward, data-gradient and 3x3 weight-gradient "
+                       "kernels feed the matrix cores every fp32 operand as TWO fp16 pieces of x 2^k (hi = rn16(x 2^k), lo = rn16(x 2^k - hi): "
+                       "|x 2^k - hi - lo| <= 2^-22 |x 2^k|) and sum the THREE products hi hi + hi lo + lo hi on v_mfma_f32_*_f16 with fp32 "
+                       "accumulation; 2^k is a power of two chosen per weight tensor by the pack and per block (chain kernel: per pixel) for "
+                       "activations / gradients, so scaling is exact and no tensor overflows fp16.  Error against float64 measured per kernel at or "
+                       "below the three-bf16-piece kernels' and within 3x of torch's own fp32 convolution (profiles/r06_f16_stage_*.json, "
+                       "tests/test_precision_gpu.py).  Kernels without an fp16 form yet (wave-specialised deep-K GEMM, stems, stride-2 / 1x1 weight "
+                       "gradients, 16-channel tail) keep the exact 3-way bf16 split (six products); <= 32-channel weight gradients, 16-column 1x1 "
+                       "kernels, the last up-convolution and the disparity head run on the f32 MFMA"),
+                "3": ("fp32 end to end; conv forward / data-gradient / halo-tile and 1x1 weight-gradient operands enter the matrix cores as "
+                      "exact 3-way bf16 splits (six bf16 products per multiply, fp32 accumulate: product error ~6e-9 relative, below "
+                      "fp32 rounding); the <= 32-channel weight gradients, the 1x1 16-column kernels, the last up-convolution and the "
+                      "1-channel disparity head on the f32 MFMA"),
+            }.get(os.environ.get("CODEPS_SPLIT", "16"), "CODEPS_SPLIT=" + os.environ.get("CODEPS_SPLIT", "16") + " (non-default arithmetic, see codeps_amd/csrc/conv.hip)"),
             "config": {"workload": workload,
                        "global_batch": n_images * world, "parallelism": f"dp{world}", "launch": "hip-graph" if graph is not None else "eager",
                        "grad_allreduce_mb": round(runner.grad_bytes / 1e6, 1),

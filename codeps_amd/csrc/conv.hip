@@ -4609,7 +4609,7 @@ static int halo_ws_on() {
 
 static int g_split_np = -1;
 static int split_raw() {
-    if (g_split_np < 0) g_split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 3;
+    if (g_split_np < 0) g_split_np = getenv("CODEPS_SPLIT") ? atoi(getenv("CODEPS_SPLIT")) : 16;
     return g_split_np;
 }
 // 16 = two fp16 pieces in the kernels that have that form (f16_pairs()); every other kernel runs the three-bf16-piece arithmetic under it

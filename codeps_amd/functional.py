@@ -530,8 +530,10 @@ def _prof_end(start, kind, flops, desc=None, source=0, tag=None, kernel=None):
     if desc is not None:
         tag = (f"B{desc.batch} {desc.in_h}x{desc.in_w} {desc.c0}+{desc.c1}->{desc.out_c} k{desc.kh} s{desc.stride}"
                f"{' up' if desc.up0 else ''}")
-        # arithmetic of the launch: bf16-split operands on the bf16 MFMA (fwd / dgrad main kernel) or the f32 MFMA
-        if kind == "conv_fwd" and lib().codeps_conv2d_arith(ctypes.byref(desc), 0, 0) > 0:
+        # arithmetic of the launch: two fp16 pieces (the kernel that ran says so in its name), three bf16 pieces, or the f32 MFMA
+        if kind in ("conv_fwd", "conv_dgrad", "conv_wgrad") and "f16x2" in lib().codeps_conv2d_last_kernel().decode():
+            kind += "_f16x2"
+        elif kind == "conv_fwd" and lib().codeps_conv2d_arith(ctypes.byref(desc), 0, 0) > 0:
             kind = "conv_fwd_split"
         elif kind == "conv_dgrad" and lib().codeps_conv2d_arith(ctypes.byref(desc), 1, source) > 0:
             kind = "conv_dgrad_split"
@@ -1051,7 +1053,7 @@ def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3
     check(fn(ptr(y1), ptr(residual), ptr(w2), ptr(w3), ptr(sc3), ptr(_f32c(shift3)), rows, n2,
              ptr(out), ptr(y0), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()),
           "codeps_chain1x1_expand_reduce")
-    _prof_end(t0, "conv_fwd_split", flops, tag=f"B{b} {h}x{w_} 256->{n2}->256 k1 chain",
+    _prof_end(t0, "conv_fwd_f16x2" if h16 else "conv_fwd_split", flops, tag=f"B{b} {h}x{w_} 256->{n2}->256 k1 chain",
               kernel="chain_expand_reduce_h_kernel" if h16 else "chain_expand_reduce_kernel")
     return out, y0
 

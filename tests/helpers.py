@@ -152,3 +152,11 @@ def logit_bar(test, name, log, golden, result_check):
 def depth_of_logit(logit, min_depth=0.1, max_depth=100.0):
     s = torch.sigmoid(logit.double())
     return 1.0 / (1.0 / max_depth + (1.0 / min_depth - 1.0 / max_depth) * s)
+
+
+def kernel_family(name):
+    """A launch's name (codeps_conv2d_last_kernel) without its arithmetic tag: 'conv_halo3r_kernel<splitk,f16x2>' ->
+    'conv_halo3r_kernel<splitk>'; the generic kernel's two split-operand forms ('<split3>' on three bf16 pieces, '<f16x2>' on two fp16
+    pieces) are one family.  The tests name the kernel a shape is meant to select; which arithmetic it ran is asserted separately."""
+    n = name.replace(",f16x2", "").replace("<f16x2>", "")
+    return "conv_igemm_kernel<split3>" if n == "conv_igemm_kernel" else n

@@ -54,28 +54,41 @@ def _set_ws(on):
     return _lib.lib().codeps_conv2d_set_halo_ws(on)
 
 
+def _set_arith(a):
+    from codeps_amd import _lib
+    return _lib.lib().codeps_conv2d_set_arith(a)
+
+
+def _family(name):
+    from helpers import kernel_family
+    return kernel_family(name)
+
+
 @pytest.mark.parametrize("ws", [1, 0])
 @pytest.mark.parametrize("name", list(SHAPES))
 def test_ring_kernel_is_repeatable(name, ws):
-    prev = _set_ws(ws)
+    # the producer / consumer form exists on the three-bf16-piece arithmetic only; the 256-thread form runs the default (two fp16 pieces)
+    prev, prev_a = _set_ws(ws), _set_arith(3 if ws else -1)
     try:
         first, outs, kernel = run_case(name, 300)
     finally:
         _set_ws(prev)
-    assert kernel.replace("<splitk>", "") == ("conv_halo3p_kernel" if ws else "conv_halo3r_kernel"), kernel
+        _set_arith(prev_a)
+    assert _family(kernel).replace("<splitk>", "") == ("conv_halo3p_kernel" if ws else "conv_halo3r_kernel"), kernel
     bad = [i for i, o in enumerate(outs) if not torch.equal(o, first)]
     assert not bad, f"{name}: launches {bad[:5]} differ from launch 0"
 
 
 @pytest.mark.parametrize("name", list(SHAPES))
 def test_producer_consumer_form_equals_the_256_thread_form_bit_for_bit(name):
-    prev = _set_ws(1)
+    prev, prev_a = _set_ws(1), _set_arith(3)
     try:
         a, _, ka = run_case(name, 1)
         _set_ws(0)
         b, _, kb = run_case(name, 1)
     finally:
         _set_ws(prev)
+        _set_arith(prev_a)
     assert "halo3p" in ka and "halo3r" in kb, (ka, kb)
     assert torch.equal(a, b), f"{name}: max |diff| {(a - b).abs().max().item():.3e}"
 
@@ -93,7 +106,7 @@ def test_producer_consumer_data_gradient_equals_the_256_thread_form_bit_for_bit(
         gy = torch.randn(b, h, w, co, generator=g).to(DEV)
         got = {}
         for ws in (1, 0):
-            prev = _set_ws(ws)
+            prev, prev_a = _set_ws(ws), _set_arith(3)
             try:
                 xx = x.clone().requires_grad_(True)
                 F.conv2d(xx, wt, pad=1).backward(gy)
@@ -101,6 +114,7 @@ def test_producer_consumer_data_gradient_equals_the_256_thread_form_bit_for_bit(
                 got[ws] = (xx.grad.clone(), lib.codeps_conv2d_last_kernel().decode())
             finally:
                 _set_ws(prev)
+                _set_arith(prev_a)
         assert "halo3p" in got[1][1] and "halo3r" in got[0][1], (got[1][1], got[0][1])
         assert torch.equal(got[1][0], got[0][0]), f"B{b} {ci}->{co}: data gradients differ"
 
@@ -113,5 +127,5 @@ def test_ring_kernel_equals_the_register_staged_kernel_bit_for_bit(tmp_path):
     ref = torch.load(out)
     for name in SHAPES:
         got, _, kernel = run_case(name, 1)
-        assert kernel.replace("<splitk>", "") in ("conv_halo3p_kernel", "conv_halo3r_kernel"), kernel
+        assert _family(kernel).replace("<splitk>", "") in ("conv_halo3p_kernel", "conv_halo3r_kernel"), kernel
         assert torch.equal(got.cpu(), ref[name]), f"{name}: max |diff| {(got.cpu() - ref[name]).abs().max().item():.3e}"

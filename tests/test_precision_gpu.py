@@ -21,9 +21,15 @@ def _F():
     return F
 
 
-def _last():
+def _last_raw():
     from codeps_amd._lib import lib
     return lib().codeps_conv2d_last_kernel().decode()
+
+
+def _last():
+    """the kernel family of the last launch (without the arithmetic tag: helpers.kernel_family)"""
+    from helpers import kernel_family
+    return kernel_family(_last_raw())
 
 
 def nhwc(x):
@@ -52,6 +58,14 @@ class _arith:
     def __exit__(self, *exc):
         from codeps_amd._lib import lib
         lib().codeps_conv2d_set_arith(self.prev)
+
+
+@pytest.fixture(autouse=True, params=[16, 3], ids=["f16x2", "bf16x3"])
+def split_arith(request):
+    """Every test of this module runs under both split-operand arithmetics: 16 = two fp16 pieces, three products, block-local scales (the
+    default since round 6), 3 = three bf16 pieces, six products (CODEPS_SPLIT=3).  Kernels without an fp16 form run the bf16 one under 16."""
+    with _arith(request.param):
+        yield request.param
 
 
 def _bound(err_torch, err_f32mfma, factor, chain=1.5):

@@ -5,6 +5,12 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+def _kfam(name):
+    from helpers import kernel_family
+    return kernel_family(name)
+
 DEV = "cuda:0"
 
 
@@ -145,7 +151,7 @@ def test_weight_gradient_fast_bodies_against_float64(case):
         ww = wt.to(DEV).detach().requires_grad_(True)
         y = F.conv2d(nhwc(x0), ww, x1=nhwc(x1) if c1 else None, pad=1, up0=up0)
         y.backward(nhwc(gy) if y.shape[-1] == co else torch.nn.functional.pad(nhwc(gy), (0, y.shape[-1] - co)))
-        assert lib().codeps_conv2d_last_kernel().decode().startswith("wgrad_halo64s_kernel")
+        assert _kfam(lib().codeps_conv2d_last_kernel().decode()).startswith("wgrad_halo64s_kernel")
         outs.append(ww.grad.cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
@@ -219,7 +225,7 @@ def test_stride2_weight_gradient_against_float64(case):
         ww = wt.to(DEV).detach().requires_grad_(True)
         y = F.conv2d(nhwc(x), ww, stride=2, pad=1)
         y.backward(nhwc(gy))
-        assert lib().codeps_conv2d_last_kernel().decode() == "wgrad_s2_halo_kernel"
+        assert _kfam(lib().codeps_conv2d_last_kernel().decode()) == "wgrad_s2_halo_kernel"
         outs.append(ww.grad.cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
@@ -291,7 +297,7 @@ def test_halo_kernel_with_32_output_columns_against_float64(case):
     outs = []
     for _ in range(2):
         y = F.conv2d(nhwc(x0), wt.to(DEV), bias.to(DEV), x1=nhwc(x1) if c1 else None, pad=1, up0=up0, act="elu")
-        assert lib().codeps_conv2d_last_kernel().decode() == "conv_halo3_kernel<32 columns>"
+        assert _kfam(lib().codeps_conv2d_last_kernel().decode()) == "conv_halo3_kernel<32 columns>"
         outs.append(y[..., :co].permute(0, 3, 1, 2).cpu())
     assert torch.equal(outs[0], outs[1])
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
@@ -340,13 +346,13 @@ def test_full_size_weight_gradients_agree_with_the_f32_mfma_kernels(case):
             return y.detach(), ww.grad
         expect = "wgrad_s2_halo_kernel" if kind == "s2" else "wgrad_halo64s_kernel"
     y3, dw3 = run(wt, gy)
-    assert lib().codeps_conv2d_last_kernel().decode() == expect
+    assert _kfam(lib().codeps_conv2d_last_kernel().decode()) == expect
     _y, dw3b = run(wt, 0.5 * gy)
     assert torch.equal(dw3b, 0.5 * dw3)                               # scaling by a power of two is exact in every product and sum
     prev = lib().codeps_conv2d_set_arith(0)
     try:
         y0, dw0 = run(wt, gy)
-        assert "split" not in lib().codeps_conv2d_last_kernel().decode() and lib().codeps_conv2d_last_kernel().decode() != expect
+        assert "split" not in _kfam(lib().codeps_conv2d_last_kernel().decode()) and _kfam(lib().codeps_conv2d_last_kernel().decode()) != expect
     finally:
         lib().codeps_conv2d_set_arith(prev)
     l2 = lambda a, r: float((a.double() - r.double()).norm() / r.double().norm())       # noqa: E731

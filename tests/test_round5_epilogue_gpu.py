@@ -6,6 +6,12 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+def _kfam(name):
+    from helpers import kernel_family
+    return kernel_family(name)
+
 DEV = "cuda:0"
 
 
@@ -322,7 +328,7 @@ def test_stem_statistics_from_the_halo_kernel_epilogue(groups):
 
     def spy(*a, **k):
         z = orig(*a, **k)
-        seen["kernel"] = lib().codeps_conv2d_last_kernel().decode()
+        seen["kernel"] = _kfam(lib().codeps_conv2d_last_kernel().decode())
         seen["stats"] = getattr(z, "_codeps_stats", None)
         return z
     keep = F._EPI_PARTS["stats"]
@@ -464,7 +470,7 @@ def test_weight_gradient_of_1x1_convolutions_on_the_split_arithmetic(case):
         gyn = torch.zeros_like(y)
         gyn[..., :co] = gy.permute(0, 2, 3, 1).to(DEV)
         y.backward(gyn)
-        assert lib().codeps_conv2d_last_kernel().decode() == "wgrad_1x1s_kernel"
+        assert _kfam(lib().codeps_conv2d_last_kernel().decode()) == "wgrad_1x1s_kernel"
         outs.append(ww.grad.cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     l2 = lambda a, r: float((a.double() - r).norm() / r.norm())       # noqa: E731
@@ -505,7 +511,7 @@ def test_16_channel_3x3_layers_on_the_split_arithmetic(case):
     for _ in range(2):
         xn = nhwc(x).requires_grad_(True)
         y = F.conv2d(xn, wt.to(DEV), bias.to(DEV), pad=1, act="elu")
-        assert lib().codeps_conv2d_last_kernel().decode() == "conv_halo3n16_kernel"
+        assert _kfam(lib().codeps_conv2d_last_kernel().decode()) == "conv_halo3n16_kernel"
         gyn = torch.zeros_like(y)
         gyn[..., :co_real] = nhwc(gy)
         dx, = torch.autograd.grad(y, xn, gyn)
@@ -521,4 +527,4 @@ def test_16_channel_3x3_layers_on_the_split_arithmetic(case):
     xn = nhwc(x).requires_grad_(True)
     y = F.conv2d(xn, wt.to(DEV).requires_grad_(False), None, pad=1)
     torch.autograd.grad(y, xn, torch.ones_like(y))
-    assert lib().codeps_conv2d_last_kernel().decode() == "conv_halo3n16_kernel"
+    assert _kfam(lib().codeps_conv2d_last_kernel().decode()) == "conv_halo3n16_kernel"
