@@ -21,32 +21,31 @@ def _free_port():
 
 
 def _run_worker(out_file, world, extra=(), tile_stats=False):
-    """tile_stats=False (the exactness tests): BatchNorm's batch statistics come from the pass over the tensor on BOTH sides.  The
-    round-5 default takes them from per-tile partials of the producing convolution where the launch plan allows; which layers that is
-    depends on the per-process batch, so single-process and sharded runs would differ in the last bits of a few statistics -- enough to
-    put one ReLU with a ~1e-7 pre-activation on the other side of zero at 64 x 128 and move a flat gradient by 1e-3 of its norm, which
-    says nothing about the SyncBatchNorm algebra these tests pin to 1e-5.  test_sharded_step_with_tile_statistics runs the default."""
+    """tile_stats=False (the exactness tests): two switches take both sides back to arithmetic whose bits do not depend on how the batch
+    is cut -- CODEPS_EPI_STATS=0: BatchNorm's batch statistics come from the pass over the tensor (the round-5 default takes them from
+    per-tile partials of the producing convolution where the launch plan allows, and which layers that is depends on the per-process
+    batch); CODEPS_SPLIT=3: the three-bf16-piece split, exact per product (the round-6 default scales fp16 pieces per block, and a weight
+    gradient's running scale sees the tiles of the images ITS process holds).  Either default moves a few results in their last bits between
+    a single-process and a sharded run -- enough to put one ReLU with a ~1e-7 pre-activation on the other side of zero at 64 x 128 and move
+    a flat gradient by 1e-4 .. 1e-3 of its norm, which says nothing about the SyncBatchNorm / all-reduce algebra these tests pin to 1e-5.
+    test_sharded_step_with_tile_statistics runs both defaults.  The switches travel in the children's environment only."""
     worker = os.path.join(ROOT, "tests", "dist_equiv_worker.py")
-    if not tile_stats:
-        os.environ["CODEPS_EPI_STATS"] = "0"
-    else:
-        os.environ.pop("CODEPS_EPI_STATS", None)
-    try:
-        return _run_worker_env(worker, out_file, world, extra)
-    finally:
-        os.environ.pop("CODEPS_EPI_STATS", None)
+    over = {} if tile_stats else {"CODEPS_EPI_STATS": "0", "CODEPS_SPLIT": "3"}
+    return _run_worker_env(worker, out_file, world, extra, over)
 
 
-def _run_worker_env(worker, out_file, world, extra):
+def _run_worker_env(worker, out_file, world, extra, over):
+    base = {k: v for k, v in os.environ.items() if k not in ("CODEPS_EPI_STATS", "CODEPS_SPLIT") or not over}
+    base.update(over)
     if world == 1:
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env = {k: v for k, v in base.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
         out = subprocess.run([sys.executable, worker, out_file, *extra], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-3000:]
         return
     port = str(_free_port())
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+        env = dict(base, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, worker, out_file.replace(".pt", f"_r{r}.pt"), *extra], cwd=ROOT, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -140,8 +139,8 @@ def test_sharded_step_equals_single_process_step(tmp_path, asym):
 
 
 def test_sharded_step_with_tile_statistics(tmp_path):
-    """The unequal two-rank layout with the round-5 defaults (BatchNorm statistics from the convolutions' epilogues where the plan
-    allows, on both sides): ranks bit-identical, SyncBN running statistics to 1e-5, flat gradients to 5e-3 of their norm -- the bound
+    """The unequal two-rank layout with the shipped defaults (BatchNorm statistics from the convolutions' epilogues where the plan
+    allows, the two-fp16-piece arithmetic with its block-local scales, on both sides): ranks bit-identical, SyncBN running statistics to 1e-5, flat gradients to 5e-3 of their norm -- the bound
     that survives a ReLU flipped by last-bit differences of a statistic (see _run_worker)."""
     single = str(tmp_path / "single.pt")
     _run_worker(single, 1, ("--asym",), tile_stats=True)

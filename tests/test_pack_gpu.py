@@ -40,8 +40,11 @@ def test_multi_pack_equals_single_packs():
         F._pack_cache_train.pop((id(p), F.pad16(co), F.pad16(ci)))
         ref_f, ref_d = F.pack_weights(p, F.pad16(co), F.pad16(ci), True)
         torch.cuda.synchronize()
-        assert torch.equal(got_f.view(torch.int32), ref_f.view(torch.int32)), f"forward pack of {tuple(p.shape)} differs"
-        assert torch.equal(got_d.view(torch.int32), ref_d.view(torch.int32)), f"data-gradient pack of {tuple(p.shape)} differs"
+        # the defined part of a pack: fp32, three bf16 pieces, two fp16 pieces, the scale slot (behind it: scratch of the pack's work groups)
+        total = F.pad16(co) * F.pad16(ci) * p.shape[2] * p.shape[3]
+        used = total + (total * 6 + 3) // 4 + total + 4 if got_f.numel() > total else total
+        assert torch.equal(got_f[:used].view(torch.int32), ref_f[:used].view(torch.int32)), f"forward pack of {tuple(p.shape)} differs"
+        assert torch.equal(got_d[:used].view(torch.int32), ref_d[:used].view(torch.int32)), f"data-gradient pack of {tuple(p.shape)} differs"
         assert not torch.equal(got_f, wf0), "the refresh did not see the new weights"
     F._pack_cache_train.clear()
     F._pack_table.update(dev=None, n=0, groups=0, entries=[], epoch=-1)
@@ -82,4 +85,16 @@ def test_single_pack_matches_the_layout_written_out_in_torch(shape):
         if pieces is not None:
             have = got[n:].view(torch.int16)[:pieces.numel()]
             assert torch.equal(have, pieces), f"split copy (dgrad={dgrad}) of {shape}"
+            # the two fp16 pieces of w 2^kb ([group of 32][hi | lo][32]) and the scale slot (2^-kb, 2^kb, max |w|, 0): csrc/conv.hip, split_f16
+            off = n + (n * 6 + 3) // 4
+            inv, sc, amax = (float(v) for v in got[off + n:off + n + 3])
+            assert amax == float(ref.abs().max()) and inv * sc == 1.0 and 2.0 ** 14 <= amax * sc < 2.0 ** 15, (amax, sc)
+            h = got[off:off + n].view(torch.float16).view(-1, 2, 32).float()
+            hi, lo = h[:, 0].reshape(-1), h[:, 1].reshape(-1)
+            want_hi = (ref * sc).to(torch.float16)
+            assert torch.equal(hi, want_hi.float()), f"fp16 hi pieces (dgrad={dgrad}) of {shape}"
+            assert torch.equal(lo, (ref * sc - want_hi.float()).to(torch.float16).float()), f"fp16 lo pieces (dgrad={dgrad}) of {shape}"
+            err = ((hi.double() + lo.double()) * inv - ref.double()).abs()
+            ok = (err <= 2.0 ** -21 * ref.double().abs()) | (err <= 2.0 ** -24 * inv)       # (lo in fp16's subnormal range: absolute 2^-25 of the scaled value)
+            assert bool(ok.all()), "hi + lo reproduces w to 2^-22 (2^-25 / 2^kb absolute for elements 2^17 below the largest)"
     F._pack_cache_train.clear()
