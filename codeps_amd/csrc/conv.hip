@@ -5812,6 +5812,9 @@ extern "C" int codeps_conv2d_dgrad_ex(const codeps_conv_desc* d, int source, con
             epi_store(epilogue);
             return CODEPS_OK;
         }
+        // one launch per class (the A/B switch, odd sizes, classes without taps): the classes differ in K (1 to 4 taps) and may get different
+        // tile / K-slice plans, so the extras' all-or-nothing rule could not be kept across them -- they are dropped (the caller runs the passes)
+        p.ex_gate = nullptr; p.ex_gate_act = 0; p.ex_stat = 0;
         int tile0 = 0;
         for (int c = 0; c < 4; ++c) {
             ConvP q = p;

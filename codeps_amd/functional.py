@@ -687,6 +687,9 @@ class _Conv2d(torch.autograd.Function):
         ctx.b_sink = grad_sink(bias) if (bias is not None and bias.requires_grad) else None
         ctx.c0_real = min(ci, x0.shape[3])
         ctx.weight_ref = weakref.ref(weight)
+        expect = getattr(weight, "_codeps_grad_expect", None)
+        if expect is not None and any(ctx.needs_input_grad):      # codeps_amd.step: one backward node of this marked layer will fire per such call
+            expect()
         ctx.has_res = residual is not None
         ctx.save_for_backward(x0, x1, y if act else None, wd, sc)
         ctx.fork = bool(fork)
@@ -1177,7 +1180,7 @@ class _BatchNormTrain(torch.autograd.Function):
         ctx.plan = plan
         # BatchNorm + ReLU: what an exclusive consumer needs to run the mask and the backward sums in its data-gradient epilogue
         ctx.out_gate = None
-        if opts is not None and _EPI and act == 1 and ctx.needs_input_grad[0]:
+        if opts is not None and _EPI and act == 1 and ctx.needs_input_grad[0] and len(groups) <= 8:     # (codeps_conv_epilogue carries 8 statistic groups)
             gt = _Gate("bn", 3)
             gt.has_res = residual is not None
             gt.x, gt.mean, gt.invstd, gt.gamma, gt.beta, gt.groups = x, mean, invstd, g, b_, groups

@@ -178,12 +178,17 @@ class StepRunner:
         # front), launched on its own stream from inside the backward pass as soon as the last kernel that writes it has been issued
         # (the data-gradient / weight-gradient node of every head's FIRST convolution is that head's last backward node: it calls
         # _segment_ready through functional's `_codeps_grad_done` hook); segment B = the encoders, after the backward pass.  The
-        # collectives stay SUMs of the same buffer: results are those of the single all-reduce.  CODEPS_AR_OVERLAP=0: one collective.
+        # collectives stay SUMs of the same buffer: results are those of the single all-reduce.  OPT-IN (CODEPS_AR_OVERLAP=1) since round 6:
+        # the default is the ONE collective north_star describes until a box with >= 2 GPUs has shown that the overlap wins.
+        # A marked layer's backward node fires once per forward call that takes part in the graph -- a head runs once per resolution (the
+        # shipped adaptation yamls: source 512 x 1024, target 384 x 1408), twice for the pose pairs, once per key with a trainable backbone --
+        # so the forward pass COUNTS those calls (`_segment_expect`) and the front collective starts when as many nodes have fired.
         import os
         self._seg, self._seg_marks, self._early_end, self.comm_stream = None, [], 0, None
         self.ar_overlap_steps = 0
+        self._seg_expected = 0
         n_front = sum(p.numel() for p in ema_params) + n_heads
-        if world_size > 1 and os.environ.get("CODEPS_AR_OVERLAP", "1") != "0" and 0 < n_front < total and self.grad_all.is_cuda:
+        if world_size > 1 and os.environ.get("CODEPS_AR_OVERLAP", "0") == "1" and 0 < n_front < total and self.grad_all.is_cuda:
             for attr in ("depth_head", "semantic_head", "pose_head"):
                 mod = getattr(net, attr, None)
                 if mod is None or attr in self.frozen:
@@ -199,6 +204,7 @@ class StepRunner:
                 self.comm_stream = torch.cuda.Stream()
                 for w in self._seg_marks:
                     w._codeps_grad_done = self._segment_ready
+                    w._codeps_grad_expect = self._segment_expect
         # device step counter mixed into the photometric tie-break noise (bumped on the stream at the start of every step, so a
         # replayed HIP graph draws new noise) + this runner's host seed base for the calls within one step
         self.noise_counter = torch.zeros(1, dtype=torch.int64, device=self.groups[0].flat.device)
@@ -254,6 +260,7 @@ class StepRunner:
         F.step_counter_add(self.noise_counter, 1)
         F.refresh_weight_packs()                 # every trainable weight's packs in one launch (after the first step built the table)
         self.grad_all.zero_()
+        self._seg_expected = 0
         if self.mode == "adapt":
             losses, result, _, _ = self.net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
         else:
@@ -269,7 +276,9 @@ class StepRunner:
         self._touched = self._reached(tuple(k for k, v in losses.items() if any(v is t for t in terms)), total)
         self._seg = None
         if self._early_end and not torch.cuda.is_current_stream_capturing():
-            need = sum(1 for w in self._seg_marks if id(w) in self._found_ids)
+            # backward nodes of the marked layers that will fire: one per forward call counted above (a marked head the losses do not
+            # reach leaves its count short: the front collective then never starts early and allreduce_gradients sends the whole buffer)
+            need = self._seg_expected if all(id(w) in self._found_ids for w in self._seg_marks) else 0
             if need:
                 self._seg = {"need": need, "events": [], "work": None}
         if self._one is None or self._one.device != total.device:
@@ -311,6 +320,10 @@ class StepRunner:
             hit = self._reach_cache[active] = (None if all(all(m) for m in masks) else masks, frozenset(found))
         self._found_ids = hit[1]
         return hit[0]
+
+    def _segment_expect(self):
+        """Called from the forward of a marked layer for every call whose backward node will exist."""
+        self._seg_expected += 1
 
     def _segment_ready(self):
         """Called (on autograd's thread) right after the last backward kernels of one head have been issued.  When every head the

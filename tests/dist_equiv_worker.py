@@ -67,17 +67,21 @@ def main():
     cfg = get_cfg_shipped(adapt=True)
     cfg.model.po_depth_net.params.nof_layers = 18
     cfg.dataset.feed_img_size = [H, W]
-    cfg.adapt.source_dataset.feed_img_size = [H, W]
+    # --mixed-res: source items at another resolution than the target's, as in the shipped yamls (512 x 1024 vs 384 x 1408): every head runs
+    # once per resolution, so a marked layer's backward node fires twice per step (codeps_amd.step, segmented all-reduce)
+    HS, WS = (H, W + 32) if "--mixed-res" in sys.argv else (H, W)
+    cfg.adapt.source_dataset.feed_img_size = [HS, WS]
     cfg.semantics.top_k = 1.0
     net = gen_models(cfg, dev, list(range(9)), [9, 10, 11, 12, 13], [], adaptation_mode=True)
     gen = torch.Generator(device=dev).manual_seed(7)
     full = {"target": synthetic.triplet_item(ITEMS["target"], H, W, gen, dev),
             "target_replay": synthetic.triplet_item(ITEMS["target_replay"], H, W, gen, dev),
-            "source": synthetic.triplet_item(ITEMS["source"], H, W, gen, dev, labels=True)}
+            "source": synthetic.triplet_item(ITEMS["source"], HS, WS, gen, dev, labels=True)}
     mix = synthetic.triplet_item(ITEMS["cut_mixup"], H, W, gen, dev, labels=True)
     full["cut_mixup"] = {"rgb": {0: mix["rgb"][0]}, "semantic": mix["semantic"]}
     torch.manual_seed(1)
-    noise = {k: [torch.randn(ITEMS[k], 2, H >> s, W >> s) * 1e-5 for s in range(5)] for k in ("source", "target", "target_replay")}
+    noise = {k: [torch.randn(ITEMS[k], 2, (HS if k == "source" else H) >> s, (WS if k == "source" else W) >> s) * 1e-5 for s in range(5)]
+             for k in ("source", "target", "target_replay")}
 
     split = (lambda r: split_configs3(r, world)) if c3 else (lambda r: split_of(r, world, asym))
     sl = split(rank)
@@ -108,7 +112,7 @@ def main():
         F.adam_ema_step(g.flat, g.grad, g.m, g.v, 1, lr=runner.lr, grad_scale=1.0 / world, ema_params=g.ema, ema_alpha=runner.ema_alpha)
     torch.cuda.synchronize()
     bufs = {n: b.cpu() for n, b in net.backbone_pose_sflow.named_buffers()}
-    torch.save({"grads": grads, "bufs": bufs, "losses": {k: (None if v is None else float(v)) for k, v in losses.items()},
+    torch.save({"grads": grads, "bufs": bufs, "overlapped": runner.ar_overlap_steps, "expected_firings": runner._seg_expected, "losses": {k: (None if v is None else float(v)) for k, v in losses.items()},
                 "params": [g.flat.cpu() for g in runner.groups], "names": [[tuple(p.shape) for p in g.params] for g in runner.groups]},
                out_file)
     if world > 1:

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_worker(out_file, world, extra=(), tile_stats=False):
+def _run_worker(out_file, world, extra=(), tile_stats=False, env=None):
     """tile_stats=False (the exactness tests): two switches take both sides back to arithmetic whose bits do not depend on how the batch
     is cut -- CODEPS_EPI_STATS=0: BatchNorm's batch statistics come from the pass over the tensor (the round-5 default takes them from
     per-tile partials of the producing convolution where the launch plan allows, and which layers that is depends on the per-process
@@ -31,6 +31,7 @@ def _run_worker(out_file, world, extra=(), tile_stats=False):
     test_sharded_step_with_tile_statistics runs both defaults.  The switches travel in the children's environment only."""
     worker = os.path.join(ROOT, "tests", "dist_equiv_worker.py")
     over = {} if tile_stats else {"CODEPS_EPI_STATS": "0", "CODEPS_SPLIT": "3"}
+    over.update(env or {})
     return _run_worker_env(worker, out_file, world, extra, over)
 
 
@@ -138,6 +139,23 @@ def test_sharded_step_equals_single_process_step(tmp_path, asym):
         assert float(((p - pr).abs() > 1e-7).float().mean()) < 0.05, "more than 5 % of the weights stepped differently"
 
 
+@pytest.mark.parametrize("mixed", [False, True])
+def test_segmented_allreduce_waits_for_every_firing_of_a_marked_layer(tmp_path, mixed):
+    """CODEPS_AR_OVERLAP=1 (opt-in): the heads' front of the flat buffer is all-reduced from inside the backward pass.  With the source items
+    at another resolution than the target's (the shipped yamls: 512 x 1024 vs 384 x 1408) every head runs twice per step and its marked
+    layer's backward node fires twice: the collective must wait for the LAST firing (round 5 counted heads, not firings, and sent a front
+    that the second firing was still accumulating into -- ADVICE r05).  Same exactness bars as the single-collective tests."""
+    extra = ("--mixed-res",) if mixed else ()
+    single = str(tmp_path / "single.pt")
+    _run_worker(single, 1, extra)
+    _run_worker(str(tmp_path / "shard.pt"), 2, extra, env={"CODEPS_AR_OVERLAP": "1"})
+    shards = [torch.load(str(tmp_path / f"shard_r{r}.pt")) for r in range(2)]
+    assert all(sh["overlapped"] == 1 for sh in shards), "the front segment did not go out from inside the backward pass"
+    # three marked heads (depth, semantic, pose); the pose head runs once per frame pair, depth / semantic once per resolution
+    assert shards[0]["expected_firings"] > 3
+    _compare(torch.load(single), shards)
+
+
 def test_sharded_step_with_tile_statistics(tmp_path):
     """The unequal two-rank layout with the shipped defaults (BatchNorm statistics from the convolutions' epilogues where the plan
     allows, the two-fp16-piece arithmetic with its block-local scales, on both sides): ranks bit-identical, SyncBN running statistics to 1e-5, flat gradients to 5e-3 of their norm -- the bound
@@ -183,7 +201,7 @@ def test_bench_over_rccl_reports_the_collectives():
 
 
 def test_two_ranks_on_one_gpu_complete_with_default_flags():
-    env = dict(os.environ, CODEPS_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, CODEPS_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CODEPS_AR_OVERLAP="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
            "--encoder", "18", "--height", "128", "--width", "256", "--no-cpu-baseline"]
@@ -200,8 +218,8 @@ def test_two_ranks_on_one_gpu_complete_with_default_flags():
     assert c["backend"] == "gloo" and c["ranks_seen"] == 2 and c["grad_allreduce_ms"] > 0
     assert c["syncbn_allgathers_per_step"] == 20 and c["syncbn_allreduces_per_step"] == 20
     assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
-    # the gradient collective ran in two segments in every timed step (round 5): the heads' front of the flat buffer from inside the
-    # backward pass, the pose encoder's back after it
+    # CODEPS_AR_OVERLAP=1 (opt-in; the default is ONE collective): the gradient collective ran in two segments in every timed step -- the
+    # heads' front of the flat buffer from inside the backward pass, the pose encoder's back after it
     sg = c["grad_allreduce_segments"]
     assert sg["front_mb"] > 0 and sg["back_mb"] > 0 and abs(sg["front_mb"] + sg["back_mb"] - c["grad_allreduce_mb"]) < 0.2
     assert sg["steps_with_the_front_overlapped"] >= d["steps"]
