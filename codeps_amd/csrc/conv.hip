@@ -733,11 +733,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 // buffered, ONE barrier per K-step.  In the 256-thread kernel every wave runs load -> convert -> write -> barrier -> read ->
 // MFMA -> barrier in sequence and the matrix pipe idles ~63 % of the time (PMC); here a SIMD's producer wave
 // converts and writes K-step s + 1 while its consumer wave multiplies K-step s.
-template <int MODE, int TN, bool EX = false>
+// ARITH 16 (round 6): two fp16 pieces.  A producer wave stages one whole 32-row MFMA tile of the gathered operand (rows 32 w ..), so the
+// scale is per ROW TILE: the wave that stages a tile finds its largest exponent alone (no exchange), leaves the running exponent beside the
+// tile, and the consumer that multiplies the tile re-bases that row tile's sums when it grew.
+template <int MODE, int TN, bool EX = false, int ARITH = 3>
 __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ residual, float* __restrict__ out) {
-    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = 3;
+    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = ARITH == 16 ? 2 : 3;
+    constexpr bool H16 = ARITH == 16;
+    constexpr int EB = NP * 2;
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int LDK = (NP * BK + 8) / 2;            // floats per LDS row: [piece][32 bf16] + pad
     constexpr int CPR = BK / 8, RPP = 256 / CPR;      // producer threads: 8 consecutive k per thread and row, 64 rows per pass
@@ -761,6 +766,8 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
     const int nsteps = ntap * steps_per_tap;
     __amdgpu_buffer_rsrc_t rs0, rs1;
     build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1, pc);
+    int* slots = reinterpret_cast<int*>(tab + ((MODE == MODE_FWD && p.C1 > 0) ? 2 : 1) * ntap * BM);      // ARITH 16: [buffer][row tile] running exponents
+    int run_e[TM] = {F16_EMIN, F16_EMIN};             // consumer: of its two row tiles; producer: [0] = of the row tile it stages
 
     const int s_begin = p.ksplit > 1 ? (int)blockIdx.y * p.ksteps : 0;
     const int s_end = p.ksplit > 1 ? min(nsteps, s_begin + p.ksteps) : nsteps;
@@ -776,11 +783,15 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
 
     if (producer) {
         const int ptid = tid - 256, chunk = ptid % CPR, rbase = ptid / CPR;
+        const int pw = wave - 4;
+        // rows of the gathered operand this thread stages: passes of 64 rows over the block (three pieces), or the producer wave's own row tile
+        const int abase = H16 ? pw * 32 + (lane >> 2) : rbase;
+        constexpr int ASTEP = H16 ? 16 : RPP;
         const size_t wrow = (MODE == MODE_FWD) ? (size_t)p.KH * p.KW * p.Ct : (size_t)p.KH * p.KW * p.Co;
-        const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const float*>(p.w3), (size_t)p.N * wrow * 6);
+        const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const float*>(H16 ? p.w2 : p.w3), (size_t)p.N * wrow * EB);
         unsigned boff[BPASS];
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)((size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow * 6 + chunk * 16);
+        for (int i = 0; i < BPASS; ++i) boff[i] = (unsigned)((size_t)min(n0 + rbase + RPP * i, p.N - 1) * wrow * EB + chunk * 16);
         f32x4 areg[APASS * 2], breg[BPASS * NP];
         auto load_step = [&](int step) {
             const int tap = step / steps_per_tap;
@@ -788,10 +799,10 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
             const bool s1 = MODE == MODE_FWD && cstep >= p.C0;
             const __amdgpu_buffer_rsrc_t rs = s1 ? rs1 : rs0;
             const unsigned coff = (unsigned)((s1 ? cstep - p.C0 : cstep) + chunk * 8) * 4u;
-            const unsigned* t = tab + ((s1 ? ntap : 0) + tap) * BM + rbase;
+            const unsigned* t = tab + ((s1 ? ntap : 0) + tap) * BM + abase;
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
-                const unsigned off = t[RPP * i];
+                const unsigned off = t[ASTEP * i];
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     areg[i * 2 + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + coff + 16 * u, 0, 0));
@@ -804,17 +815,33 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
             for (int i = 0; i < BPASS; ++i)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    breg[i * NP + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + (unsigned)koff * 6u + 64 * q, 0, 0));
+                    breg[i * NP + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i] + (unsigned)koff * (unsigned)EB + 64 * q, 0, 0));
         };
         auto store_step = [&](int buf) {
             float* Ab = As + buf * BM * LDK;
             float* Bb = Bs + buf * BN * LDK;
+            float a_scale = 1.f;
+            if constexpr (H16) {                                  // this wave's row tile: largest exponent so far -> scale, left beside the tile
+                float m = 0.f;
+#pragma unroll
+                for (int i = 0; i < APASS * 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(areg[i][e]));
+                run_e[0] = max(run_e[0], wave_max_exponent(m));
+                a_scale = f16_scale_of(run_e[0]);
+                if (lane == 0) slots[buf * 4 + pw] = run_e[0];
+            }
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
                 u16x4 lo[NP], hi[NP];
-                split_bf16<NP>(areg[i * 2], lo);
-                split_bf16<NP>(areg[i * 2 + 1], hi);
-                unsigned short* row = reinterpret_cast<unsigned short*>(Ab + (rbase + RPP * i) * LDK);
+                if constexpr (H16) {
+                    split_f16(areg[i * 2], a_scale, lo[0], lo[1]);
+                    split_f16(areg[i * 2 + 1], a_scale, hi[0], hi[1]);
+                } else {
+                    split_bf16<NP>(areg[i * 2], lo);
+                    split_bf16<NP>(areg[i * 2 + 1], hi);
+                }
+                unsigned short* row = reinterpret_cast<unsigned short*>(Ab + (abase + ASTEP * i) * LDK);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + chunk * 8) = pack8(lo[q], hi[q]);
             }
@@ -841,20 +868,33 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
             const int buf = (step - s_begin) & 1;
             const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK;
             const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK;
+            if constexpr (H16) {                                  // the row tiles' scales of this K-step: re-base a tile's sums when its scale grew (exact)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int e_new = __builtin_amdgcn_readfirstlane(slots[buf * 4 + wm * TM + i]);
+                    if (e_new != run_e[i]) {
+                        const float rb = f16_rebase(run_e[i], e_new);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] *= rb;
+                        run_e[i] = e_new;
+                    }
+                }
+            }
 #pragma unroll
             for (int kc = 0; kc < BK / 16; ++kc) {
-                bf16x8 af[TM][NP], bf[TN][NP];
+                typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
+                frag_t af[TM][NP], bf[TN][NP];
                 const int ho = kc * 16 + lhalf * 8;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        af[i][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Ab + i * 32 * LDK) + q * BK + ho);
+                        af[i][q] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const unsigned short*>(Ab + i * 32 * LDK) + q * BK + ho);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        bf[j][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(Bb + j * 32 * LDK) + q * BK + ho);
+                        bf[j][q] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const unsigned short*>(Bb + j * 32 * LDK) + q * BK + ho);
 #pragma unroll
                 for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
@@ -863,7 +903,8 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+                                if constexpr (H16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
+                                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][qa], bf[j][ord - qa], acc[i][j], 0, 0, 0);
             }
             __syncthreads();
         }
@@ -886,11 +927,12 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(ConvP p, const float
     for (int i = 0; i < TM; ++i) {
         if (i > 0) __syncthreads();
         if (!producer) {
+            const float inv = H16 ? f16_inv_scale_of(run_e[i]) * p.w2s[0] : 1.f;      // back to the operands' units (exact)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+                    Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + (wn * TN + j) * 32 + lrow] = H16 ? acc[i][j][r] * inv : acc[i][j][r];
         }
         __syncthreads();
         if constexpr (EX) if (i == 0 && p.ex_stat == 1) ec.sh = *reinterpret_cast<const f32x4*>(Cs + c4 * 4) * sc + sh;
@@ -2008,12 +2050,18 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
 // them in registers (60 per 16 x 16 channel block).  Block = 8 x 32 output pixels, wave = two rows = four 16-pixel row tiles; the next
 // tile's loads are in flight under the MFMAs; the epilogue goes through LDS so that stores are 16 bytes per lane and the epilogue extras
 // (gates 1 / 2, column sums) are the common code.  MODE_DGRAD: the same kernel on the [ci][tap][co] pack with mirrored tap geometry.
-template <int MODE, int NT, int KH, bool EX = false>
+// ARITH 16 (round 6): two fp16 pieces.  The weights' scale is found by the block itself (<= 9216 floats, once per persistent block: these
+// packs are too small to carry the pack's slot), the activation tile's per tile (the sums start at zero with every tile).
+template <int MODE, int NT, int KH, bool EX = false, int ARITH = 3>
 __global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(ConvP p, int tiles_x, int tiles_y, int tiles_per_block, const float* __restrict__ x,
                                                                 const float* __restrict__ wq, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ residual,
                                                                 float* __restrict__ out) {
-    constexpr int TH = 8, TW = 32, XH = TH + 2, XW = TW + 2, PIT = 56, CI = 16 * KH, CO = 16 * NT;
+    constexpr int NP = ARITH == 16 ? 2 : 3;
+    constexpr bool H16 = ARITH == 16;
+    constexpr int TH = 8, TW = 32, XH = TH + 2, XW = TW + 2, PIT = NP * 16 + 8, CI = 16 * KH, CO = 16 * NT;
+    __shared__ float n16_red[4];                                  // ARITH 16: the waves' largest magnitudes (weights once, then every tile)
+    typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
     constexpr int NTASK = XH * XW * (CI / 4), NRAW = (NTASK + 255) / 256;
     constexpr int LDC = CO + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
@@ -2027,7 +2075,22 @@ __global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(Con
     const size_t ximg = (size_t)Hm * Wm * CI;
 
     // ---- B fragments from the fp32 pack (row n: [tap][CI]); lane = (column l16, k group kg): tap 2 s + (kg >> 1), channels 8 (kg & 1) ..
-    bf16x8 bfr[NT][KH][5][3];
+    float w_scale = 1.f, w_inv = 1.f;
+    if constexpr (H16) {
+        float m = 0.f;
+        for (int i = tid; i < CO * 9 * CI / 4; i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wq + (size_t)i * 4);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        m = wave_max(m);
+        if (lane == 0) n16_red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(n16_red[0], n16_red[1]), fmaxf(n16_red[2], n16_red[3]));
+        __syncthreads();
+        const int e = max((int)(__builtin_bit_cast(unsigned, m) >> 23), F16_EMIN);
+        w_scale = f16_scale_of(e); w_inv = f16_inv_scale_of(e);
+    }
+    frag_t bfr[NT][KH][5][NP];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -2041,11 +2104,11 @@ __global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(Con
                     w0 = *reinterpret_cast<const f32x4*>(wp);
                     w1 = *reinterpret_cast<const f32x4*>(wp + 4);
                 }
-                u16x4 p0[3], p1[3];
-                split_bf16<3>(w0, p0);
-                split_bf16<3>(w1, p1);
+                u16x4 p0[NP], p1[NP];
+                if constexpr (H16) { split_f16(w0, w_scale, p0[0], p0[1]); split_f16(w1, w_scale, p1[0], p1[1]); }
+                else { split_bf16<NP>(w0, p0); split_bf16<NP>(w1, p1); }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) bfr[j][hf][st][q] = __builtin_bit_cast(bf16x8, pack8(p0[q], p1[q]));
+                for (int q = 0; q < NP; ++q) bfr[j][hf][st][q] = __builtin_bit_cast(frag_t, pack8(p0[q], p1[q]));
             }
     // ---- A fragment offsets (halfwords) of this lane's tap per K-step: forward pixel + (ky, kx), data gradient pixel + (2 - ky, 2 - kx)
     int aoff[5];
@@ -2079,14 +2142,16 @@ __global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(Con
             raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
         }
     };
+    float a_scale = 1.f;
     auto store_x = [&]() {
 #pragma unroll
         for (int k = 0; k < NRAW; ++k) {
             if (tid + 256 * k >= NTASK) continue;
-            u16x4 pc[3];
-            split_bf16<3>(raw[k], pc);
+            u16x4 pc[NP];
+            if constexpr (H16) split_f16(raw[k], a_scale, pc[0], pc[1]);
+            else split_bf16<NP>(raw[k], pc);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<u16x4*>(Xs + t_dst[k] + q * 16) = pc[q];
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x4*>(Xs + t_dst[k] + q * 16) = pc[q];
         }
     };
 
@@ -2103,7 +2168,22 @@ __global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(Con
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        int e_tile = F16_EMIN;
+        if constexpr (H16) {                                        // this tile's largest magnitude (its loads have had the previous tile to land)
+            float m = 0.f;
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(raw[k][e]));
+            m = wave_max(m);
+            if (lane == 0) n16_red[wave] = m;
+        }
         __syncthreads();                                            // the previous tile's epilogue has read Cs
+        if constexpr (H16) {
+            const float m = fmaxf(fmaxf(n16_red[0], n16_red[1]), fmaxf(n16_red[2], n16_red[3]));
+            e_tile = max((int)(__builtin_bit_cast(unsigned, m) >> 23), F16_EMIN);
+            a_scale = f16_scale_of(e_tile);
+        }
         store_x();
         __syncthreads();
         load_x(min(tile + 1, t_end - 1), tile + 1 < t_end);         // in flight under the MFMAs and the epilogue
@@ -2119,16 +2199,18 @@ __global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(Con
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int base = ((2 * wave + (m >> 1)) * XW + (m & 1) * 16 + l16) * PIT + hf * (XH * XW * PIT) + aoff[st];
-                    bf16x8 a[3];
+                    frag_t a[NP];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(Xs + base + q * 16);
+                    for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const frag_t*>(Xs + base + q * 16);
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
 #pragma unroll
-                        for (int ord = 2; ord >= 0; --ord)
+                        for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
-                            for (int qa = 0; qa <= ord; ++qa)
-                                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa], bfr[j][hf][st][ord - qa], acc[m][j], 0, 0, 0);
+                            for (int qa = 0; qa <= ord; ++qa) {
+                                if constexpr (H16) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[qa], bfr[j][hf][st][ord - qa], acc[m][j], 0, 0, 0);
+                                else acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa], bfr[j][hf][st][ord - qa], acc[m][j], 0, 0, 0);
+                            }
                 }
         __syncthreads();                                            // every wave is done with the activation tile: Cs may overwrite it
         // C layout of a 16 x 16 tile: column = l16, row = 4 kg + reg; tile row index = pixel (yy * 32 + xx) of the 8 x 32 tile
@@ -2138,7 +2220,8 @@ __global__ __launch_bounds__(256, KH == 2 ? 1 : 2) void conv_halo3n16_kernel(Con
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    Cs[((2 * wave + (m >> 1)) * TW + (m & 1) * 16 + 4 * kg + r) * LDC + j * 16 + l16] = acc[m][j][r];
+                    Cs[((2 * wave + (m >> 1)) * TW + (m & 1) * 16 + 4 * kg + r) * LDC + j * 16 + l16] =
+                        H16 ? acc[m][j][r] * (f16_inv_scale_of(e_tile) * w_inv) : acc[m][j][r];
         __syncthreads();
         f32x4 colsum = {0.f, 0.f, 0.f, 0.f};                        // (extras of this kernel: gates 1 / 2 and statistics 2 only -- written out here:
         if (n < p.N) {                                              //  the common EpiCtx keeps 28 registers live that this kernel does not have)
@@ -5285,10 +5368,13 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
             p.ksplit = 1; p.ksteps = nsteps_;
             const int ks_ = splitk_slices(p, blocks_, nsteps_);
             if (ks_ >= 2) { p.ksteps = cdiv(nsteps_, ks_); p.ksplit = cdiv(nsteps_, p.ksteps); }
-            auto kw = epi_plan(p, BM) ? conv_igemm_ws_kernel<MODE, TN, true> : conv_igemm_ws_kernel<MODE, TN>;
+            const bool h16 = f16_pairs(), ex = epi_plan(p, BM);
+            auto kw = h16 ? (ex ? conv_igemm_ws_kernel<MODE, TN, true, 16> : conv_igemm_ws_kernel<MODE, TN, false, 16>)
+                          : (ex ? conv_igemm_ws_kernel<MODE, TN, true> : conv_igemm_ws_kernel<MODE, TN>);
             codeps_allow_lds((const void*)kw, 160 * 1024, "kw");
-            g_last_kernel = "conv_igemm_ws_kernel";
-            hipLaunchKernelGGL(kw, dim3(blocks_, p.ksplit, p.par == 2 ? 4 : 1), dim3(512), lds_ws, st, p, a0, a1, scale, shift, residual, out);
+            g_last_kernel = h16 ? "conv_igemm_ws_kernel<f16x2>" : "conv_igemm_ws_kernel";
+            const size_t lds_ws16 = std::max(((size_t)2 * (BM + BN) * 36 + (size_t)nsrc_ * ntap_ * BM) * sizeof(float) + 32, (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            hipLaunchKernelGGL(kw, dim3(blocks_, p.ksplit, p.par == 2 ? 4 : 1), dim3(512), h16 ? lds_ws16 : lds_ws, st, p, a0, a1, scale, shift, residual, out);
             if (p.ksplit > 1) launch_splitk_finish<MODE>(p, st, scale, shift, residual, out);
             return;
         }
@@ -5375,17 +5461,19 @@ static void launch_halo3n16(ConvP p, const float* a0, const float* wq, const flo
     const int nt = p.N / 16, kh = kc / 16;
     // persistent blocks: the weights are fetched and split once per block.  Two per CU; one for the 32-channel-input form, whose 120
     // registers of weight fragments + 44 of prefetched pixels spill at 256 registers
+    const bool h16 = f16_pairs();                  // (two fp16 pieces, 32 input channels: 80 registers of weight fragments, and the form with the extras still spills at 256)
     const int tpb = std::max(1, cdiv(total, kh == 2 ? 256 : 512));
     p.n_mt = total; p.n_nt = 1; p.ksplit = 1;
     // extras of this kernel: the activation gates and the column sums (the decoder tail has no BatchNorm)
     const bool ex = epi_plan(p, 256, p.ex_gate_act != 3 && (p.ex_stat == 0 || p.ex_stat == 2));
-    const size_t lds_x = (size_t)kh * 340 * 56 * 2, lds_c = (size_t)256 * (p.N + 4) * 4 + 2 * 256 * 16;
+    const size_t lds_x = (size_t)kh * 340 * (h16 ? 40 : 56) * 2, lds_c = (size_t)256 * (p.N + 4) * 4 + 2 * 256 * 16;
     const size_t lds = std::max(lds_x, lds_c);
-    g_last_kernel = "conv_halo3n16_kernel";
+    g_last_kernel = h16 ? "conv_halo3n16_kernel<f16x2>" : "conv_halo3n16_kernel";
 #define N16_LAUNCH(NT_, KH_)                                                                                                   \
     do {                                                                                                                       \
-        auto k = ex ? conv_halo3n16_kernel<MODE, NT_, KH_, true> : conv_halo3n16_kernel<MODE, NT_, KH_, false>;                 \
-        codeps_allow_lds((const void*)k, 160 * 1024, "conv_halo3n16_kernel");                                                   \
+        auto k = h16 ? (ex ? conv_halo3n16_kernel<MODE, NT_, KH_, true, 16> : conv_halo3n16_kernel<MODE, NT_, KH_, false, 16>)   \
+                     : (ex ? conv_halo3n16_kernel<MODE, NT_, KH_, true> : conv_halo3n16_kernel<MODE, NT_, KH_, false>);         \
+        codeps_allow_lds((const void*)k, 96 * 1024, "conv_halo3n16_kernel");      /* (+ 16 bytes of static LDS) */                \
         hipLaunchKernelGGL(k, dim3(cdiv(total, tpb)), dim3(256), lds, st, p, tiles_x, tiles_y, tpb, a0, wq, scale, shift, residual, out); \
     } while (0)
     if (nt == 1 && kh == 1) N16_LAUNCH(1, 1); else if (nt == 1) N16_LAUNCH(1, 2); else N16_LAUNCH(2, 1);

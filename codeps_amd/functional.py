@@ -687,9 +687,6 @@ class _Conv2d(torch.autograd.Function):
         ctx.b_sink = grad_sink(bias) if (bias is not None and bias.requires_grad) else None
         ctx.c0_real = min(ci, x0.shape[3])
         ctx.weight_ref = weakref.ref(weight)
-        expect = getattr(weight, "_codeps_grad_expect", None)
-        if expect is not None and any(ctx.needs_input_grad):      # codeps_amd.step: one backward node of this marked layer will fire per such call
-            expect()
         ctx.has_res = residual is not None
         ctx.save_for_backward(x0, x1, y if act else None, wd, sc)
         ctx.fork = bool(fork)

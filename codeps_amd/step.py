@@ -182,7 +182,8 @@ class StepRunner:
         # the default is the ONE collective north_star describes until a box with >= 2 GPUs has shown that the overlap wins.
         # A marked layer's backward node fires once per forward call that takes part in the graph -- a head runs once per resolution (the
         # shipped adaptation yamls: source 512 x 1024, target 384 x 1408), twice for the pose pairs, once per key with a trainable backbone --
-        # so the forward pass COUNTS those calls (`_segment_expect`) and the front collective starts when as many nodes have fired.
+        # so the walk over the step's autograd graph (`_reached`) COUNTS the marked layers' backward nodes that the losses reach, and the front
+        # collective starts when as many have fired.
         import os
         self._seg, self._seg_marks, self._early_end, self.comm_stream = None, [], 0, None
         self.ar_overlap_steps = 0
@@ -204,7 +205,6 @@ class StepRunner:
                 self.comm_stream = torch.cuda.Stream()
                 for w in self._seg_marks:
                     w._codeps_grad_done = self._segment_ready
-                    w._codeps_grad_expect = self._segment_expect
         # device step counter mixed into the photometric tie-break noise (bumped on the stream at the start of every step, so a
         # replayed HIP graph draws new noise) + this runner's host seed base for the calls within one step
         self.noise_counter = torch.zeros(1, dtype=torch.int64, device=self.groups[0].flat.device)
@@ -260,7 +260,6 @@ class StepRunner:
         F.step_counter_add(self.noise_counter, 1)
         F.refresh_weight_packs()                 # every trainable weight's packs in one launch (after the first step built the table)
         self.grad_all.zero_()
-        self._seg_expected = 0
         if self.mode == "adapt":
             losses, result, _, _ = self.net(data, "adapt", [0, -1, 1], do_panoptic_fusion=True)
         else:
@@ -276,8 +275,8 @@ class StepRunner:
         self._touched = self._reached(tuple(k for k, v in losses.items() if any(v is t for t in terms)), total)
         self._seg = None
         if self._early_end and not torch.cuda.is_current_stream_capturing():
-            # backward nodes of the marked layers that will fire: one per forward call counted above (a marked head the losses do not
-            # reach leaves its count short: the front collective then never starts early and allreduce_gradients sends the whole buffer)
+            # backward nodes of the marked layers that will fire (counted on the graph by _reached; a marked head the losses do not reach, or
+            # unequal shards -- no walk -- leave it at 0: allreduce_gradients then sends the whole buffer in one collective)
             need = self._seg_expected if all(id(w) in self._found_ids for w in self._seg_marks) else 0
             if need:
                 self._seg = {"need": need, "events": [], "work": None}
@@ -303,10 +302,12 @@ class StepRunner:
         Functions that launch them, so they appear as leaves of the graph like any other parameter.  Batch-sharded steps whose
         ranks hold different keys (set_key_counts) would need the union over ranks: they treat every parameter as reached."""
         if self.world > 1 and self._unequal_shards:
+            self._seg_expected = 0
             return None
         hit = self._reach_cache.get(active)
         if hit is None:
             seen, found, stack = set(), set(), [total.grad_fn]
+            marks, marked_nodes = {id(w) for w in self._seg_marks}, 0
             while stack:
                 fn = stack.pop()
                 if fn is None or fn in seen:
@@ -315,15 +316,15 @@ class StepRunner:
                 var = getattr(fn, "variable", None)
                 if var is not None:
                     found.add(id(var))
+                wref = getattr(fn, "weight_ref", None)          # a convolution's backward node (functional._Conv2d: the node IS its ctx)
+                if marks and wref is not None and id(wref()) in marks:
+                    marked_nodes += 1                            # ... of a marked layer: it will fire once (a head runs once per resolution / pair / key)
                 stack.extend(nf for nf, _ in fn.next_functions)
             masks = [[id(p) in found for p in g.params] for g in self.groups]
-            hit = self._reach_cache[active] = (None if all(all(m) for m in masks) else masks, frozenset(found))
+            hit = self._reach_cache[active] = (None if all(all(m) for m in masks) else masks, frozenset(found), marked_nodes)
         self._found_ids = hit[1]
+        self._seg_expected = hit[2]
         return hit[0]
-
-    def _segment_expect(self):
-        """Called from the forward of a marked layer for every call whose backward node will exist."""
-        self._seg_expected += 1
 
     def _segment_ready(self):
         """Called (on autograd's thread) right after the last backward kernels of one head have been issued.  When every head the
