@@ -1891,11 +1891,19 @@ __global__ __launch_bounds__(384) void conv_halo3p_kernel(ConvP p, const float* 
 // wave w owns output row w of the tile (one 32-pixel MFMA row tile x two 32-channel column tiles): 48 MFMAs per tap row against
 // 12 + 24 fragment reads.  Blocks walk `tiles_per_block` tiles; the next tile's loads are issued under the last tap rows of the
 // current one.
+// ARITH 16 (round 6): two fp16 pieces; the input tile's scale per tile (block-wide maximum in front of the tile's first barrier), the weights'
+// from the pack.
+template <int ARITH = 3>
 __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x, int tiles_y, int tiles_per_block, const float* __restrict__ x,
                                                            const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ y) {
-    constexpr int TH = 8, TW = 32, KH = 7, KW = 4, XH = 2 * TH + KH - 2, XW = TW + KW - 1, PIT = 56;      // PIT: halfwords per double pixel
-    constexpr int WROW = 200;                          // halfwords per output channel and tap row: [2 groups][3 pieces][32] + pad (100 dwords)
-    constexpr int NT = 512, NTASK = XH * XW * 4, NRAW = (NTASK + NT - 1) / NT, NWSEG = 64 * 24 / NT;
+    constexpr int NP = ARITH == 16 ? 2 : 3, EB = NP * 2;
+    constexpr bool H16 = ARITH == 16;
+    typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
+    __shared__ float stem_red[8];                      // ARITH 16: the waves' largest magnitudes of the input tile in flight
+    constexpr int TH = 8, TW = 32, KH = 7, KW = 4, XH = 2 * TH + KH - 2, XW = TW + KW - 1, PIT = NP * 16 + 8;      // PIT: halfwords per double pixel
+    constexpr int WROW = 2 * NP * 32 + 8;              // halfwords per output channel and tap row: [2 groups][NP pieces][32] + pad (100 / 68 dwords)
+    constexpr int WSEG = 2 * NP * 4;                   // 16-byte segments of such a row
+    constexpr int NT = 512, NTASK = XH * XW * 4, NRAW = (NTASK + NT - 1) / NT, NWSEG = 64 * WSEG / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
     unsigned short* Xs = lds16;                        // [XH][XW][PIT]
     unsigned short* Ws = lds16 + XH * XW * PIT;        // [2][64][WROW]
@@ -1904,7 +1912,7 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
     const int total_tiles = p.B * tiles_y * tiles_x;
     const int t_beg = blockIdx.x * tiles_per_block, t_end = min(t_beg + tiles_per_block, total_tiles);
     const size_t ximg = (size_t)p.H * p.W * 16;
-    const char* w3 = static_cast<const char*>(p.w3);
+    const char* w3 = static_cast<const char*>(H16 ? p.w2 : p.w3);
 
     // input tasks: (row r, double pixel c, channel quad c4); thread tid owns tasks tid + 512 k
     int t_off[NRAW], t_row[NRAW], t_dst[NRAW];
@@ -1927,14 +1935,16 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
             raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
         }
     };
+    float a_scale = 1.f;
     auto store_x = [&]() {
 #pragma unroll
         for (int k = 0; k < NRAW; ++k) {
             if (tid + NT * k >= NTASK) continue;
-            u16x4 pc[3];
-            split_bf16<3>(raw[k], pc);
+            u16x4 pc[NP];
+            if constexpr (H16) split_f16(raw[k], a_scale, pc[0], pc[1]);
+            else split_bf16<NP>(raw[k], pc);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<u16x4*>(Xs + t_dst[k] + q * 16) = pc[q];
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x4*>(Xs + t_dst[k] + q * 16) = pc[q];
         }
     };
     // weights of tap row ky: per output channel 384 contiguous bytes of the pre-split pack ([co][14 groups][3 pieces][32 bf16], groups 2 ky, 2 ky + 1)
@@ -1942,14 +1952,14 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
     auto load_w = [&](int ky) {
 #pragma unroll
         for (int i = 0; i < NWSEG; ++i) {
-            const int seg = tid + NT * i, co = seg / 24, s16 = seg % 24;
-            wreg[i] = *reinterpret_cast<const i32x4*>(w3 + ((size_t)co * 14 + 2 * ky) * 192 + s16 * 16);
+            const int seg = tid + NT * i, co = seg / WSEG, s16 = seg % WSEG;
+            wreg[i] = *reinterpret_cast<const i32x4*>(w3 + ((size_t)co * 14 + 2 * ky) * (32 * EB) + s16 * 16);
         }
     };
     auto store_w = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < NWSEG; ++i) {
-            const int seg = tid + NT * i, co = seg / 24, s16 = seg % 24;
+            const int seg = tid + NT * i, co = seg / WSEG, s16 = seg % WSEG;
             *reinterpret_cast<i32x4*>(Ws + (slot * 64 + co) * WROW + s16 * 8) = wreg[i];
         }
     };
@@ -1959,7 +1969,24 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
         load_w(0);
+        int e_tile = F16_EMIN;
+        if constexpr (H16) {
+            float m = 0.f;
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(raw[k][e]));
+            m = wave_max(m);
+            if (lane == 0) stem_red[wave] = m;
+        }
         __syncthreads();                                            // the previous tile's fragment reads are done
+        if constexpr (H16) {
+            float m = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) m = fmaxf(m, stem_red[w8]);
+            e_tile = max((int)(__builtin_bit_cast(unsigned, m) >> 23), F16_EMIN);
+            a_scale = f16_scale_of(e_tile);
+        }
         store_x();
         store_w(0);
         __syncthreads();
@@ -1975,28 +2002,34 @@ __global__ __launch_bounds__(512) void conv_stem74f_kernel(ConvP p, int tiles_x,
             const unsigned short* W = Ws + (ky & 1) * 64 * WROW;
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
-                bf16x8 bw[2][3];
+                frag_t bw[2][NP];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        bw[nt][q] = *reinterpret_cast<const bf16x8*>(W + (nt * 32 + l32) * WROW + ((kx >> 1) * 3 + q) * 32 + (kx & 1) * 16 + h * 8);
+                    for (int q = 0; q < NP; ++q)
+                        bw[nt][q] = *reinterpret_cast<const frag_t*>(W + (nt * 32 + l32) * WROW + ((kx >> 1) * NP + q) * 32 + (kx & 1) * 16 + h * 8);
                 const int row = 2 * wave + ky;
-                bf16x8 a[3];
+                frag_t a[NP];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(Xs + (row * XW + l32 + kx) * PIT + q * 16 + h * 8);
+                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const frag_t*>(Xs + (row * XW + l32 + kx) * PIT + q * 16 + h * 8);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int ord = 2; ord >= 0; --ord)
+                    for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
-                        for (int qa = 0; qa <= ord; ++qa)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[qa], bw[nt][ord - qa], acc[nt], 0, 0, 0);
+                        for (int qa = 0; qa <= ord; ++qa) {
+                            if constexpr (H16) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[qa], bw[nt][ord - qa], acc[nt], 0, 0, 0);
+                            else acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[qa], bw[nt][ord - qa], acc[nt], 0, 0, 0);
+                        }
             }
             if (ky + 1 < KH) {
                 store_w((ky + 1) & 1);                              // the slot tap row ky - 1 was read from: every wave is past the barrier behind it
                 __syncthreads();
             }
+        }
+        if constexpr (H16) {                                        // back to the operands' units (exact)
+            const float inv = f16_inv_scale_of(e_tile) * p.w2s[0];
+            acc[0] *= inv; acc[1] *= inv;
         }
         // epilogue: C layout of the 32 x 32 tile: column (channel) = lane & 31, row (pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -2741,10 +2774,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p, const float* 
 // block streams its A and B rows over ALL its pixels: a 128 x 64 tile (the first form of this kernel) moved ~200 MB per layer through
 // the memory system whatever the layer and ran at the f32 kernel's speed (60-70 us, ~3.3 TB/s).  The next K-step's loads are in flight
 // under the MFMAs.  SWAP: A = X, B = dZ (Ci > Co).  One partial slab [co][ci] per block, summed in a fixed order by wgrad_reduce_kernel.
-template <bool SWAP, int TB>
+// ARITH 16 (round 6): two fp16 pieces; both operands are activations, each with a running block-local scale: the waves publish the largest
+// exponent of the K-step they hold in registers in front of the barrier that precedes its LDS stores.
+template <bool SWAP, int TB, int ARITH = 3>
 __global__ __launch_bounds__(256, TB == 1 ? 2 : 1) void wgrad_1x1s_kernel(WgradP p, const float* __restrict__ x, const float* __restrict__ dz,
                                                                           float* __restrict__ part) {
-    constexpr int KP = 32, ZP = 3 * KP + 8;                  // pixels per K-step; halfwords per channel row (pad: conflict-free fragment reads)
+    constexpr int NP = ARITH == 16 ? 2 : 3;
+    constexpr bool H16 = ARITH == 16;
+    typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
+    __shared__ int w1_slots[8];                              // ARITH 16: [operand][wave] largest exponents of the K-step in flight
+    constexpr int KP = 32, ZP = NP * KP + 8;                  // pixels per K-step; halfwords per channel row (pad: conflict-free fragment reads)
     constexpr int TA = 4, BA = 2 * TA * 32, BB = 2 * TB * 32;
     constexpr int NBT = BB / 4 * (KP / 8);                   // B tasks per K-step (A: 256)
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
@@ -2789,14 +2828,17 @@ __global__ __launch_bounds__(256, TB == 1 ? 2 : 1) void wgrad_1x1s_kernel(WgradP
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, vb, 0, 0));     // (threads without a B task: out of range, no traffic)
         }
     };
-    auto store_task = [&](const f32x4 (&r)[8], unsigned short* dst) {      // dst = row of the quad's first channel, at this pixel group
-        u16x4 pc[8][3];
+    auto store_task = [&](const f32x4 (&r)[8], unsigned short* dst, float sc) {      // dst = row of the quad's first channel, at this pixel group
+        u16x4 pc[8][NP];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) split_bf16<3>(r[i], pc[i]);
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (H16) split_f16(r[i], sc, pc[i][0], pc[i][1]);
+            else split_bf16<NP>(r[i], pc[i]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NP; ++q) {
                 const u16x4 lo = {pc[0][q][e], pc[1][q][e], pc[2][q][e], pc[3][q][e]}, hi = {pc[4][q][e], pc[5][q][e], pc[6][q][e], pc[7][q][e]};
                 *reinterpret_cast<i32x4*>(dst + e * ZP + q * KP) = pack8(lo, hi);
             }
@@ -2812,39 +2854,70 @@ __global__ __launch_bounds__(256, TB == 1 ? 2 : 1) void wgrad_1x1s_kernel(WgradP
 
     const int nsteps = (pend - pbeg + KP - 1) / KP;
     if (nsteps > 0) load_step(pbeg);
+    int ea_run = F16_EMIN, eb_run = F16_EMIN;
     for (int step = 0; step < nsteps; ++step) {
+        float sa = 1.f, sb = 1.f;
+        if constexpr (H16) {
+            float ma = 0.f, mb = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ma = fmaxf(ma, fabsf(ra[i][e])); mb = fmaxf(mb, fabsf(rb[i][e])); }
+            const int xa = wave_max_exponent(ma), xb = wave_max_exponent(mb);
+            if (lane == 0) { w1_slots[wave] = xa; w1_slots[4 + wave] = xb; }
+        }
         __syncthreads();                                     // the previous K-step's fragment reads are done
-        store_task(ra, As + (t_c4 * 4) * ZP + t_g * 8);
-        if (b_on) store_task(rb, Bs + (t_c4 * 4) * ZP + t_g * 8);
+        if constexpr (H16) {
+            const i32x4 pa = *reinterpret_cast<const i32x4*>(w1_slots), pb = *reinterpret_cast<const i32x4*>(w1_slots + 4);
+            const int ea = __builtin_amdgcn_readfirstlane(max(max(max(pa[0], pa[1]), max(pa[2], pa[3])), ea_run));
+            const int eb = __builtin_amdgcn_readfirstlane(max(max(max(pb[0], pb[1]), max(pb[2], pb[3])), eb_run));
+            if (ea + eb != ea_run + eb_run) {                // re-base the sums to the larger tiles' scales (exact)
+                const float rbs = f16_rebase(ea_run + eb_run, ea + eb);
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) acc[i][j] *= rbs;
+            }
+            ea_run = ea; eb_run = eb;
+            sa = f16_scale_of(ea); sb = f16_scale_of(eb);
+        }
+        store_task(ra, As + (t_c4 * 4) * ZP + t_g * 8, sa);
+        if (b_on) store_task(rb, Bs + (t_c4 * 4) * ZP + t_g * 8, sb);
         __syncthreads();
         if (step + 1 < nsteps) load_step(pbeg + (step + 1) * KP);
 #pragma unroll
         for (int ks = 0; ks < KP / 16; ++ks) {
-            bf16x8 fb[TB][3];
+            frag_t fb[TB][NP];
 #pragma unroll
             for (int j = 0; j < TB; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    fb[j][q] = *reinterpret_cast<const bf16x8*>(Bs + ((wb * TB + j) * 32 + l32) * ZP + q * KP + ks * 16 + h * 8);
+                for (int q = 0; q < NP; ++q)
+                    fb[j][q] = *reinterpret_cast<const frag_t*>(Bs + ((wb * TB + j) * 32 + l32) * ZP + q * KP + ks * 16 + h * 8);
 #pragma unroll
             for (int i = 0; i < TA; ++i) {
-                bf16x8 fa[3];
+                frag_t fa[NP];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bf16x8*>(As + ((wa * TA + i) * 32 + l32) * ZP + q * KP + ks * 16 + h * 8);
+                for (int q = 0; q < NP; ++q) fa[q] = *reinterpret_cast<const frag_t*>(As + ((wa * TA + i) * 32 + l32) * ZP + q * KP + ks * 16 + h * 8);
 #pragma unroll
                 for (int j = 0; j < TB; ++j)
 #pragma unroll
-                    for (int ord = 2; ord >= 0; --ord)
+                    for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
-                        for (int qa = 0; qa <= ord; ++qa)
+                        for (int qa = 0; qa <= ord; ++qa) {
                             // (the lanes of the result run along the SECOND operand: always the input channels, the slab's fast axis)
-                            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ord - qa], fa[qa], acc[i][j], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa], fb[j][ord - qa], acc[i][j], 0, 0, 0);
+                            if constexpr (H16)
+                                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][ord - qa], fa[qa], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[qa], fb[j][ord - qa], acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ord - qa], fa[qa], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa], fb[j][ord - qa], acc[i][j], 0, 0, 0);
+                        }
             }
         }
     }
     // partial slab [split][co][ci]; C layout: column = lane & 31 (ci), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (co)
     float* dst = part + (size_t)split * p.Co * p.Ct;
+    const float inv = H16 ? f16_inv_scale_of(ea_run) * f16_inv_scale_of(eb_run) : 1.f;
 #pragma unroll
     for (int j = 0; j < TB; ++j)
 #pragma unroll
@@ -2855,7 +2928,7 @@ __global__ __launch_bounds__(256, TB == 1 ? 2 : 1) void wgrad_1x1s_kernel(WgradP
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (SWAP ? tb : ta) + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < p.Co) dst[(size_t)co * p.Ct + ci] = acc[i][j][r];
+                if (co < p.Co) dst[(size_t)co * p.Ct + ci] = H16 ? acc[i][j][r] * inv : acc[i][j][r];
             }
         }
 }
@@ -5790,14 +5863,16 @@ extern "C" int codeps_conv2d_fwd_ex(const codeps_conv_desc* d, const float* x0, 
         // the double-pixel stem (functional.stem_conv2d) on whole 8 x 32 tiles: the halo-tile kernel
         const int tiles_x = d->out_w / 32, tiles_y = d->out_h / 8, total = d->batch * tiles_x * tiles_y;
         const int tpb = std::max(1, cdiv(total, 256 * std::max(1, total / (256 * 12))));     // one block per CU and round, <= ~12 tiles each
-        constexpr size_t lds = ((size_t)21 * 35 * 56 + 2 * 64 * 200) * 2 + (64 + 8 * 2 * 64) * sizeof(float);
-        g_last_kernel = "conv_stem74f_kernel";
-        codeps_allow_lds((const void*)conv_stem74f_kernel, 160 * 1024, "conv_stem74f_kernel");
+        const bool h16 = f16_pairs();
+        const size_t lds = ((size_t)21 * 35 * (h16 ? 40 : 56) + 2 * 64 * (h16 ? 136 : 200)) * 2 + (64 + 8 * 2 * 64) * sizeof(float);
+        g_last_kernel = h16 ? "conv_stem74f_kernel<f16x2>" : "conv_stem74f_kernel";
+        auto ks = h16 ? conv_stem74f_kernel<16> : conv_stem74f_kernel<3>;
+        codeps_allow_lds((const void*)ks, 128 * 1024, "conv_stem74f_kernel");         // (+ 32 bytes of static LDS)
         // epilogue extras of this kernel: the forward statistics only (its 8 x 32 tiles lie inside one image by construction)
         const bool stem_stats = p.ex_stat == 1 && !p.ex_gate_act && !scale && !shift && d->act == 0;
         p.ex_gate = nullptr; p.ex_gate_act = 0;
         if (!stem_stats) p.ex_stat = 0;
-        hipLaunchKernelGGL(conv_stem74f_kernel, dim3(cdiv(total, tpb)), dim3(512), lds, (hipStream_t)stream, p, tiles_x, tiles_y, tpb, x0, scale, shift, y);
+        hipLaunchKernelGGL(ks, dim3(cdiv(total, tpb)), dim3(512), lds, (hipStream_t)stream, p, tiles_x, tiles_y, tpb, x0, scale, shift, y);
         CODEPS_CHECK_LAUNCH("conv_stem74f_kernel");
         if (stem_stats) {
             g_epi.applied = 2; g_epi.n_seg = 1;
@@ -6068,11 +6143,14 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
         return CODEPS_OK;
     }
     if (w1.ok) {
-        const size_t lds = (size_t)(256 + 64 * w1.tb) * (3 * 32 + 8) * 2;
-        g_last_kernel = "wgrad_1x1s_kernel";
-        auto k1 = w1.tb == 2 ? (w1.swap ? wgrad_1x1s_kernel<true, 2> : wgrad_1x1s_kernel<false, 2>)
-                             : (w1.swap ? wgrad_1x1s_kernel<true, 1> : wgrad_1x1s_kernel<false, 1>);
-        codeps_allow_lds((const void*)k1, 160 * 1024, "wgrad_1x1s_kernel");
+        const bool h16 = f16_pairs();
+        const size_t lds = (size_t)(256 + 64 * w1.tb) * ((h16 ? 2 : 3) * 32 + 8) * 2;
+        g_last_kernel = h16 ? "wgrad_1x1s_kernel<f16x2>" : "wgrad_1x1s_kernel";
+        auto k1 = h16 ? (w1.tb == 2 ? (w1.swap ? wgrad_1x1s_kernel<true, 2, 16> : wgrad_1x1s_kernel<false, 2, 16>)
+                                    : (w1.swap ? wgrad_1x1s_kernel<true, 1, 16> : wgrad_1x1s_kernel<false, 1, 16>))
+                      : (w1.tb == 2 ? (w1.swap ? wgrad_1x1s_kernel<true, 2> : wgrad_1x1s_kernel<false, 2>)
+                                    : (w1.swap ? wgrad_1x1s_kernel<true, 1> : wgrad_1x1s_kernel<false, 1>));
+        codeps_allow_lds((const void*)k1, 128 * 1024, "wgrad_1x1s_kernel");       // (+ 32 bytes of static LDS)
         hipLaunchKernelGGL(k1, dim3(w1.splits, w1.tiles), dim3(256), lds, st, p, x0, dz, part);
         CODEPS_CHECK_LAUNCH("wgrad_1x1s_kernel");
         launch_wgrad_reduce(part, splits, d->out_c, d->c0, 1, out_c_real, in_c_real, dw_oihw, accumulate, st);
