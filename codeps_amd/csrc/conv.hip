@@ -1247,6 +1247,9 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 #ifndef CODEPS_ABLATE_RING
 #define CODEPS_ABLATE_RING 0
 #endif
+#ifndef CODEPS_RING_BREG
+#define CODEPS_RING_BREG 0       // A/B builds only: 1 = the fp16-pair ring kernel fills its weight ring through registers (measured 61.2 vs 58.6 us on ResNet-101 layer3: not kept)
+#endif
 
 // ARITH 3: three bf16 pieces, six products (rounds 2-5).  ARITH 16: two fp16 pieces, three products, block-local scales (round 6).
 template <int MODE, int TN, bool EX = false, int ARITH = 3>
@@ -1331,6 +1334,35 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                          :: "s"(dst), "v"(boff[i]), "s"(rsBv), "s"(koff) : "memory");
         }
+    };
+
+    // CODEPS_RING_BREG=1 (A/B builds; NOT the default): the weight tiles of the fp16 form travel global -> registers -> LDS instead of by LDS
+    // DMA.  With half the matrix instructions per tap the five DMA instructions every wave issues per tap are the largest item next to the
+    // MFMAs (the kernel without them: 58.9 -> 52.2 us on ResNet-101 layer3, -DCODEPS_ABLATE_RING=1), but four 16-byte loads + four
+    // ds_write_b128 per thread and tap (and 25 more registers) cost as much: 61.2 us.  The loads of tile g + 4 are issued behind the barrier
+    // that ends tap g and written in front of the next one; plain builtins, the compiler counts vmcnt itself.
+    constexpr bool BREG = H16 && CODEPS_RING_BREG;
+    constexpr int BTASK = BN * (SEG - 1) / 256;               // 16-byte segments per thread and tile (the pad segment is not copied)
+    static_assert(!BREG || (BN * (SEG - 1)) % 256 == 0, "weight tile: whole segments per thread");
+    const __amdgpu_buffer_rsrc_t rsBr = make_rsrc(static_cast<const float*>(H16 ? p.w2 : p.w3), (size_t)p.N * wrow * EB);
+    unsigned rboff[BTASK], rbdst[BTASK];
+#pragma unroll
+    for (int i = 0; i < BTASK; ++i) {
+        const int t = tid + 256 * i, row = t / (SEG - 1), seg = t % (SEG - 1);
+        const int swz = CODEPS_HALO_SWZ ? (((row >> 2) ^ (row >> 3)) & 1) : 0;
+        rboff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * EB + seg * 16);
+        rbdst[i] = (unsigned)(row * LDK * 4 + (seg ^ swz) * 16);
+    }
+    f32x4 breg[BTASK];
+    auto load_b = [&](int tap, int chunk, f32x4 (&r)[BTASK]) {
+        const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((tap * Kc + (cbase + chunk) * BK) * EB);
+#pragma unroll
+        for (int i = 0; i < BTASK; ++i) r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsBr, rboff[i], koff, 0));
+    };
+    auto store_b = [&](int slot, const f32x4 (&r)[BTASK]) {
+        char* Bb = reinterpret_cast<char*>(Bs + slot * BN * LDK);
+#pragma unroll
+        for (int i = 0; i < BTASK; ++i) *reinterpret_cast<f32x4*>(Bb + rbdst[i]) = r[i];
     };
 
     const __amdgpu_buffer_rsrc_t rsA0 = make_rsrc(img0, (size_t)H0 * W0 * cs0 * 4);
@@ -1440,11 +1472,18 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     };
     const int T = 9 * nchunks;
     load_a(0);
+    if constexpr (BREG) {                                         // tiles 0 .. 2 into the ring, tile 3 into the registers (written at the end of tap 0)
+        f32x4 b1[BTASK], b2[BTASK];
+        load_b(0, 0, breg); load_b(1, 0, b1); load_b(2, 0, b2);
+        store_b(0, breg); store_b(1, b1); store_b(2, b2);
+        load_b(3, 0, breg);
+    } else {
 #pragma unroll
-    for (int g = 0; g < RING; ++g) dma_b(g, 0, g);                // nchunks >= 1: taps 0 .. 3 exist
-    __builtin_amdgcn_s_waitcnt(0x0F70);                           // the first activation tile and four weight tiles have landed
+        for (int g = 0; g < RING; ++g) dma_b(g, 0, g);            // nchunks >= 1: taps 0 .. 3 exist
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // the first activation tile and four weight tiles have landed
 #pragma unroll
-    for (int i = 0; i < NALOAD; ++i) asm volatile("" : "+v"(areg[i]));
+        for (int i = 0; i < NALOAD; ++i) asm volatile("" : "+v"(areg[i]));
+    }
     publish_amax();
     int run_e = F16_EMIN;                                         // ARITH 16: the largest exponent among the activation tiles staged so far
     for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -1497,6 +1536,16 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             const bool t3 = g + 3 < T;
             CODEPS_STAMP_PHASE_A();                                // A: fragment reads of tap + 1 issued, 96 MFMAs of tap issued
             CODEPS_STAMP_PHASE_START();
+            if constexpr (BREG) {
+                // tile g + 3 (loaded during this tap) -> its slot, which held tile g - 1 (last read during tap g - 2); behind the barrier the
+                // loads of tile g + 4.  sched_barriers: the stores stay behind the tap's MFMAs, the loads behind the barrier
+                __builtin_amdgcn_sched_barrier(0);
+                if (t3) store_b((g + 3) & 3, breg);
+                if (tap == 2 && more) publish_amax();
+                __syncthreads();
+                if (g + 4 < T) load_b((tap + 4) % 9, chunk + (tap + 4) / 9, breg);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
             if (tap < 2 && more) {
                 if (t3) __builtin_amdgcn_s_waitcnt(0x0F70 | (BPW + NALOAD));
                 else __builtin_amdgcn_s_waitcnt(0x0F70 | NALOAD);
@@ -1512,10 +1561,11 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
             __syncthreads();
             // every wave has read tile g's fragments (during tap g - 1, or at the chunk's start): its slot takes tile g + 4
             if (g + 4 < T && !(CODEPS_ABLATE_RING & 1)) dma_b((tap + 4) % 9, chunk + (tap + 4) / 9, g & 3);
+            }
             CODEPS_STAMP_PHASE_B();                                // B: wait for tile g + 2, barrier, DMA of tile g + 4 issued
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if constexpr (!BREG) __builtin_amdgcn_s_waitcnt(0x0F70);
 
     // ---- epilogue (as in conv_halo3_kernel)
     constexpr int LDC = BN + 4;
@@ -5002,6 +5052,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 // A thread then emits 8 consecutive k of a pack row -- the fp32 pack (32 bytes) and, when the row takes the split-operand
 // kernel, its three bf16 pieces (3 x 16 bytes) -- exactly the bytes codeps_conv2d_pack_weights writes.
 constexpr int PACK_SLAB = 4608;          // floats of LDS per work group (512 columns x 9 taps)
+constexpr long long PACK_AMAX_INLINE = 32768;      // parameters up to this many elements: every pack group takes the maximum itself (128 loads per thread)
 // Layout of a pack buffer in floats, `total` = rows x K extent (codeps_conv2d_packed_weight_floats):  [0, total) the fp32 pack;
 // [total, 2.5 total) three bf16 pieces (6 bytes per element);  [2.5 total, 3.5 total) two fp16 pieces of w 2^kb (4 bytes per element; written
 // when the arithmetic is 16);  [3.5 total, +4) the scale slot (2^-kb, 2^kb, 0, 0);  behind it one partial maximum per work group of the item.
@@ -5020,7 +5071,7 @@ struct PackItem {
 // magnitude it saw behind the scale slot; the pack's groups (pass 2, the next launch) each reduce the item's partials -- no atomics, no
 // zeroing, the same bits whatever the order of the groups.
 __device__ __forceinline__ void pack_amax_body(const PackItem& it, long long g, float* red) {
-    if (it.split != 16) return;
+    if (it.split != 16 || (long long)it.co_real * it.ci_real * it.taps <= PACK_AMAX_INLINE) return;
     const long long total = (long long)it.rows * it.taps * it.cols;
     const long long n = (long long)it.co_real * it.ci_real * it.taps;
     const int u = (int)(g - it.first_group);
@@ -5039,9 +5090,13 @@ __device__ __forceinline__ void pack_item_body(const PackItem& it, long long g, 
     const long long total = (long long)it.rows * wrow;
     const int u = (int)(g - it.first_group);
     float w_scale = 1.f;
-    if (it.split == 16) {                                                  // every group of the item derives the same scale from the partials
+    if (it.split == 16) {                                                  // every group of the item derives the same scale ...
         const float* part = it.out + pack_off_scale(total) + 4;
+        const long long n_w = (long long)it.co_real * it.ci_real * it.taps;
         float m = 0.f;
+        if (n_w <= PACK_AMAX_INLINE) {                                     // ... small tensors (re-laid-out stem / GUDA tap weights, packed one by one every step): from the parameter itself, no first pass
+            for (long long i = threadIdx.x; i < n_w; i += 256) m = fmaxf(m, fabsf(it.w[i]));
+        } else                                                             // ... from the partials of pack_amax_*_kernel
         for (long long i = threadIdx.x; i < it.groups; i += 256) m = fmaxf(m, part[i]);
         m = wave_max(m);
         __syncthreads();
@@ -5609,7 +5664,8 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         const TileOpt o[3] = {{128, 128, 1.0f}, {128, 64, nsteps32 <= shortk ? pens : pen1}, {64, 64, pen2}};
         // 3x3 layers whose 128 x 128 grid is below one block per CU: the halo ring kernel (215 TFLOP/s class) on >= 128 CUs, or
         // with its channel chunks cut into K slices that make whole rounds of 256 blocks, instead of the gather kernels (140-160)
-        const bool halo_sk = bk32 && split_np == 3 && p.N % 128 == 0 && halo3_shape_ok<MODE>(p) &&
+        static const int halo_sk_on = getenv("CODEPS_HALO_SK") ? atoi(getenv("CODEPS_HALO_SK")) : 1;     // tuning experiments only
+        const bool halo_sk = halo_sk_on && bk32 && split_np == 3 && p.N % 128 == 0 && halo3_shape_ok<MODE>(p) &&
                              halo_splitk_slices(p, cdiv(p.M, 128) * cdiv(p.N, 128), ((MODE == MODE_FWD) ? p.Ct : p.Co) / 32) >= 1;
         switch (halo_sk ? 0 : pick_tile(p, o, 3, nsteps32)) {
             case 0: IG(2, 2, 2, 2); break;
@@ -5670,7 +5726,9 @@ extern "C" int codeps_conv2d_pack_weights(int out_c, int in_c, int kh, int kw, i
         if (w_fwd) { ok = ok && fill_pack_item(*slot, w_oihw, w_fwd, out_c, in_c, kh, kw, out_c_pad, in_c_pad, 0, groups); groups += slot->groups; slot = &b; }
         if (w_dgrad) { ok = ok && fill_pack_item(*slot, w_oihw, w_dgrad, out_c, in_c, kh, kw, out_c_pad, in_c_pad, 1, groups); groups += slot->groups; }
         if (ok && groups > 0 && groups < (1ll << 31)) {
-            if (a.split == 16 || b.split == 16) hipLaunchKernelGGL(pack_amax_pair_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a, b);
+            const bool big_a = a.split == 16 && (long long)a.co_real * a.ci_real * a.taps > PACK_AMAX_INLINE;
+            const bool big_b = b.split == 16 && (long long)b.co_real * b.ci_real * b.taps > PACK_AMAX_INLINE;
+            if (big_a || big_b) hipLaunchKernelGGL(pack_amax_pair_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a, b);
             hipLaunchKernelGGL(pack_weights_pair_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a, b);
             CODEPS_CHECK_LAUNCH("pack_weights_pair_kernel");
             return CODEPS_OK;
