@@ -1247,16 +1247,23 @@ __global__ __launch_bounds__(256) void conv_halo3_kernel(ConvP p, const float* _
 #ifndef CODEPS_ABLATE_RING
 #define CODEPS_ABLATE_RING 0
 #endif
+#ifndef CODEPS_RING_ADB
+#define CODEPS_RING_ADB 0        // A/B builds only: 1 = the fp16-pair ring kernel with TWO activation tiles, the next one staged under taps 3 .. (measured: 56.8 vs 56.1 us with eight waves, 67.8 vs 59.0 with four -- not kept)
+#endif
 #ifndef CODEPS_RING_BREG
 #define CODEPS_RING_BREG 0       // A/B builds only: 1 = the fp16-pair ring kernel fills its weight ring through registers (measured 61.2 vs 58.6 us on ResNet-101 layer3: not kept)
 #endif
 
 // ARITH 3: three bf16 pieces, six products (rounds 2-5).  ARITH 16: two fp16 pieces, three products, block-local scales (round 6).
-template <int MODE, int TN, bool EX = false, int ARITH = 3>
-__global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
+// NW = 8 (round 6, fp16 form): EIGHT waves, two per SIMD, on the same 4 x 32 pixel x 128 column tile (wave = 64 pixels x 32 columns).  With half
+// the matrix instructions per tap a wave's own DMA issue, waits and barrier idle its SIMD's matrix pipe for as long as its MFMAs take; a
+// second wave per SIMD multiplies meanwhile.  Same LDS image, ring and arithmetic (bit-identical results).
+template <int MODE, int TN, bool EX = false, int ARITH = 3, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_halo3r_kernel(ConvP p, const float* __restrict__ a0, const float* __restrict__ a1,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ residual, float* __restrict__ out) {
-    constexpr int WM = 2, WN = 2, TM = 2, BK = 32, NP = ARITH == 16 ? 2 : 3;
+    constexpr int WM = 2, WN = NW / 2, TM = 2, BK = 32, NP = ARITH == 16 ? 2 : 3;
+    constexpr int NT = 64 * NW;                               // threads of the block
     constexpr bool H16 = ARITH == 16;
     constexpr int EB = NP * 2;                                // bytes per element of the pre-split weights
     constexpr int NPROD = NP * (NP + 1) / 2;
@@ -1273,11 +1280,18 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     // the 16 consecutive positions of a fragment at k group 0 cover the even slots, k group 1 the odd ones, for every alignment).
     constexpr int LDKA = CODEPS_HALO_SWZ ? LDK + 4 : LDK;
     constexpr int SEG = LDK / 4;                              // 16-byte slots per weight row in LDS (the last one is padding)
-    constexpr int APASS = (HPIX * 4 + 255) / 256, NALOAD = APASS * 2;
+    constexpr int APASS = (HPIX * 4 + NT - 1) / NT, NALOAD = APASS * 2;
     constexpr int RING = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                  // [HPIX + 1][LDKA]  (row HPIX: staging tasks past the tile)
-    float* Bs = smem + (HPIX + 1) * LDKA;              // [RING][BN][LDK]
+    // CODEPS_RING_ADB=1 (A/B builds; NOT the default): TWO activation tiles in the fp16 form (2 x 33 KB + 74 KB of weight ring).  The next
+    // chunk's tile is split and stored between the MFMAs of taps 3 .. of the current chunk and the taps run on across the chunk boundary
+    // instead of barrier -> split + store -> barrier -> first fragment reads (in-kernel stamps put a quarter of a chunk's time there).
+    // Bit-identical; measured no faster with eight waves and 15 % slower with four (256 registers): the staging's instructions among the
+    // MFMAs cost what the boundary cost.
+    constexpr bool ADB = H16 && CODEPS_RING_ADB;
+    constexpr int ATILE = (HPIX + 1) * LDKA;           // floats per activation tile
+    float* As = smem;                                  // [ADB ? 2 : 1][HPIX + 1][LDKA]  (row HPIX: staging tasks past the tile)
+    float* Bs = smem + (ADB ? 2 : 1) * ATILE;          // [RING][BN][LDK]
     int* amax_slot = reinterpret_cast<int*>(Bs + RING * BN * LDK);     // ARITH 16: the waves' maximum exponents of the activation tile in flight
     CODEPS_STAMP_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1304,13 +1318,13 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     // weights: lane L of the tile's linear 16-byte segment index copies segment L % 13 of row L / 13 (13th = pad); every wave
     // issues BPW instructions per tile (the waves past the last partial group repeat their previous instruction)
     const size_t wrow = (size_t)9 * Kc;
-    constexpr int BINS = BN * SEG / 64, BPW = (BINS + 3) / 4;
+    constexpr int BINS = BN * SEG / 64, BPW = (BINS + NW - 1) / NW;
     static_assert((BN * SEG) % 64 == 0 && LDK * 4 == SEG * 16 && (SEG & 1) && BPW + NALOAD < 16, "linear DMA layout; vmcnt immediates");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     unsigned boff[BPW], bins[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
-        const int ins = wave_u + 4 * i < BINS ? wave_u + 4 * i : wave_u + 4 * (i - 1);
+        const int ins = wave_u + NW * i < BINS ? wave_u + NW * i : wave_u + NW * (i - 1);
         const int L = ins * 64 + lane, row = L / SEG, seg = L % SEG;
         const int swz = CODEPS_HALO_SWZ ? (((row >> 2) ^ (row >> 3)) & 1) : 0;       // rows 4 .. 11 (mod 16): k groups swapped pairwise
         bins[i] = (unsigned)ins * 1024u;
@@ -1342,13 +1356,13 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     // ds_write_b128 per thread and tap (and 25 more registers) cost as much: 61.2 us.  The loads of tile g + 4 are issued behind the barrier
     // that ends tap g and written in front of the next one; plain builtins, the compiler counts vmcnt itself.
     constexpr bool BREG = H16 && CODEPS_RING_BREG;
-    constexpr int BTASK = BN * (SEG - 1) / 256;               // 16-byte segments per thread and tile (the pad segment is not copied)
-    static_assert(!BREG || (BN * (SEG - 1)) % 256 == 0, "weight tile: whole segments per thread");
+    constexpr int BTASK = BN * (SEG - 1) / NT;                // 16-byte segments per thread and tile (the pad segment is not copied)
+    static_assert(!BREG || (BN * (SEG - 1)) % NT == 0, "weight tile: whole segments per thread");
     const __amdgpu_buffer_rsrc_t rsBr = make_rsrc(static_cast<const float*>(H16 ? p.w2 : p.w3), (size_t)p.N * wrow * EB);
     unsigned rboff[BTASK], rbdst[BTASK];
 #pragma unroll
     for (int i = 0; i < BTASK; ++i) {
-        const int t = tid + 256 * i, row = t / (SEG - 1), seg = t % (SEG - 1);
+        const int t = tid + NT * i, row = t / (SEG - 1), seg = t % (SEG - 1);
         const int swz = CODEPS_HALO_SWZ ? (((row >> 2) ^ (row >> 3)) & 1) : 0;
         rboff[i] = (unsigned)((size_t)min(n0 + row, p.N - 1) * wrow * EB + seg * 16);
         rbdst[i] = (unsigned)(row * LDK * 4 + (seg ^ swz) * 16);
@@ -1375,7 +1389,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
         const unsigned cbyte = (unsigned)((s1 ? cstep - p.C0 : cstep) + achunk * 8) * 4u;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-            const int pos = (tid >> 2) + 64 * i;
+            const int pos = (tid >> 2) + (NT / 4) * i;
             const int iy = y0 + pos / HW - 1, ix = x0 + pos % HW - 1;
             const bool ok = pos < HPIX && iy >= 0 && iy < Hm && ix >= 0 && ix < Wm;
             const unsigned off = ok ? (unsigned)(((iy >> sh) * ws + (ix >> sh)) * cs) * 4u + cbyte : GATHER_OOB;
@@ -1401,10 +1415,24 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
         }
     };
     float a_scale = 1.f;
+    auto store_a_pos = [&](int i, float* Adst, float sc) {           // ADB: staging task i of this thread -> tile Adst
+        const int pos = min((tid >> 2) + (NT / 4) * i, HPIX);
+        u16x4 lo[NP], hi[NP];
+        if constexpr (H16) {
+            split_f16(areg[i * 2], sc, lo[0], lo[1]);
+            split_f16(areg[i * 2 + 1], sc, hi[0], hi[1]);
+        } else {
+            split_bf16<NP>(areg[i * 2], lo);
+            split_bf16<NP>(areg[i * 2 + 1], hi);
+        }
+        unsigned short* row = reinterpret_cast<unsigned short*>(Adst + pos * LDKA);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(row + q * BK + achunk * 8) = pack8(lo[q], hi[q]);
+    };
     auto store_a = [&]() {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-            const int pos = min((tid >> 2) + 64 * i, HPIX);
+            const int pos = min((tid >> 2) + (NT / 4) * i, HPIX);
             u16x4 lo[NP], hi[NP];
 #if CODEPS_ABLATE_RING & 2
 #pragma unroll
@@ -1445,14 +1473,14 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
 
     typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
     struct Frag { frag_t a[NA][NP], b[NB][NP]; };
-    auto read_frags = [&](int tap, int slot, Frag& f) {             // tap: compile-time after unrolling; slot: wave-uniform
+    auto read_frags = [&](int tap, int slot, Frag& f, int abuf = 0) {   // tap: compile-time after unrolling; slot, abuf (activation tile): wave-uniform
         const int ky = tap / 3, kx = tap % 3;
         const int toff = ((MODE == MODE_FWD) ? ky * HW + kx : (2 - ky) * HW + (2 - kx)) * LDKA * 2;     // halfwords
         const unsigned short* bp = brow + slot * (BN * LDK * 2);
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) f.a[i][q] = *reinterpret_cast<const frag_t*>(arow[i] + toff + q * BK);
+            for (int q = 0; q < NP; ++q) f.a[i][q] = *reinterpret_cast<const frag_t*>(arow[i] + abuf * (ATILE * 2) + toff + q * BK);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -1486,12 +1514,97 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     }
     publish_amax();
     int run_e = F16_EMIN;                                         // ARITH 16: the largest exponent among the activation tiles staged so far
+    auto block_exponent = [&](int floor_e) {                      // the waves' published exponents and `floor_e`: every thread the same value
+        i32x4 pe = *reinterpret_cast<const i32x4*>(amax_slot);
+        if constexpr (NW == 8) {
+            const i32x4 pe2 = *reinterpret_cast<const i32x4*>(amax_slot + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pe[e] = max(pe[e], pe2[e]);
+        }
+        return __builtin_amdgcn_readfirstlane(max(max(max(pe[0], pe[1]), max(pe[2], pe[3])), floor_e));
+    };
+    if constexpr (ADB) {
+        __syncthreads();                                          // the exponents of tile 0
+        run_e = block_exponent(run_e);
+        a_scale = f16_scale_of(run_e);
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) store_a_pos(i, As, a_scale);
+        __syncthreads();
+        Frag fr[2];
+        read_frags(0, 0, fr[0], 0);
+        int e_next = run_e;
+        float s_next = a_scale;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int g0 = chunk * 9, par = chunk & 1;
+            const bool more = chunk + 1 < nchunks;
+            float* Anext = As + (par ^ 1) * ATILE;
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) load_a(chunk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int g = g0 + tap;
+                CODEPS_STAMP_PHASE_START();
+                const bool pre = tap < 8 || more;                   // the next tap exists (tap 8: tap 0 of the next chunk, from the other tile)
+                if (tap < 8) read_frags(tap + 1, (g + 1) & 3, fr[(tap + 1) & 1], par);
+                else if (more) read_frags(0, (g + 1) & 3, fr[1], par ^ 1);
+                const bool stage = more && tap >= 3 && tap < 3 + APASS;      // this tap carries a staging task of the next tile
+                if (stage) {
+                    if (tap == 3) { e_next = block_exponent(run_e); s_next = f16_scale_of(e_next); }      // published in front of tap 2's barrier
+                    store_a_pos(tap - 3, Anext, s_next);
+                }
+                mfmas(fr[tap & 1]);
+                if (pre) {                                          // one fragment read, its share of the MFMAs, then room for the staging's instructions
+#pragma unroll
+                    for (int k = 0; k < NA * NP + NB * NP; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, (NA * NB * NPROD) / (NA * NP + NB * NP), 0);
+                        if (stage) __builtin_amdgcn_sched_group_barrier(0x202, 6, 0);
+                    }
+                }
+                const bool t3 = g + 3 < T;
+                CODEPS_STAMP_PHASE_A();
+                CODEPS_STAMP_PHASE_START();
+                if (tap < 2 && more) {
+                    if (t3) __builtin_amdgcn_s_waitcnt(0x0F70 | (BPW + NALOAD));
+                    else __builtin_amdgcn_s_waitcnt(0x0F70 | NALOAD);
+                } else {
+                    if (t3) __builtin_amdgcn_s_waitcnt(0x0F70 | BPW);
+                    else __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+                if (tap == 2) {
+#pragma unroll
+                    for (int i = 0; i < NALOAD; ++i) asm volatile("" : "+v"(areg[i]));
+                    if (more) publish_amax();
+                }
+                __syncthreads();
+                if (g + 4 < T) dma_b((tap + 4) % 9, chunk + (tap + 4) / 9, g & 3);
+                CODEPS_STAMP_PHASE_B();
+            }
+            if (more) {
+                if (e_next != run_e) {                            // the next tile was staged at a larger scale: re-base the sums (exact)
+                    const float rb = f16_rebase(run_e, e_next);
+#pragma unroll
+                    for (int i = 0; i < NA; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) acc[i][j] *= rb;
+                    run_e = e_next;
+                }
+                fr[0] = fr[1];                                    // (tap 8 runs from fr[0] and fetched the next chunk's tap 0 into fr[1])
+            }
+        }
+    } else
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int g0 = chunk * 9;
         const bool more = chunk + 1 < nchunks;
         __syncthreads();                                          // the previous chunk's fragment reads are done
         if constexpr (H16) {
-            const i32x4 pe = *reinterpret_cast<const i32x4*>(amax_slot);
+            i32x4 pe = *reinterpret_cast<const i32x4*>(amax_slot);
+            if constexpr (NW == 8) {
+                const i32x4 pe2 = *reinterpret_cast<const i32x4*>(amax_slot + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pe[e] = max(pe[e], pe2[e]);
+            }
             const int e_new = __builtin_amdgcn_readfirstlane(max(max(max(pe[0], pe[1]), max(pe[2], pe[3])), run_e));
             if (e_new != run_e) {                                 // the tile outgrew the scale of the sums so far: re-base them (exact)
                 const float rb = f16_rebase(run_e, e_new);
@@ -1570,7 +1683,7 @@ __global__ __launch_bounds__(256) void conv_halo3r_kernel(ConvP p, const float* 
     // ---- epilogue (as in conv_halo3_kernel)
     constexpr int LDC = BN + 4;
     float* Cs = smem;
-    constexpr int V4 = BN / 4, RPASS = 256 / V4;
+    constexpr int V4 = BN / 4, RPASS = NT / V4;
     const int c4 = tid % V4, r0 = tid / V4;
     const int n = n0 + c4 * 4;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -5463,11 +5576,18 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
                         kr = h16 ? conv_halo3r_kernel<MODE, TN, true, 16> : conv_halo3r_kernel<MODE, TN, true>;
                         codeps_allow_lds((const void*)kr, 160 * 1024, "conv_halo3r_kernel<ex>");
                     }
+                    // fp16 form: eight waves on the tile (two per SIMD) -- CODEPS_RING8=0: the four-wave form
+                    static const int ring8 = getenv("CODEPS_RING8") ? atoi(getenv("CODEPS_RING8")) : 1;
+                    const bool w8 = h16 && ring8;
+                    if (w8) {
+                        kr = ex ? conv_halo3r_kernel<MODE, 1, true, 16, 8> : conv_halo3r_kernel<MODE, 1, false, 16, 8>;
+                        codeps_allow_lds((const void*)kr, 160 * 1024, "conv_halo3r_kernel<8 waves>");
+                    }
                     g_last_kernel = halo_ws ? (p.ksplit > 1 ? "conv_halo3p_kernel<splitk>" : "conv_halo3p_kernel")
                                             : h16 ? (p.ksplit > 1 ? "conv_halo3r_kernel<splitk,f16x2>" : "conv_halo3r_kernel<f16x2>")
                                             : (p.ksplit > 1 ? "conv_halo3r_kernel<splitk>" : "conv_halo3r_kernel");
-                    constexpr size_t lds_r16 = ((size_t)205 * ((2 * BK + 8) / 2 + 4) + (size_t)4 * BN * ((2 * BK + 8) / 2)) * sizeof(float) + 16;
-                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(halo_ws ? 384 : 256), h16 ? lds_r16 : lds_r, st, p, a0, a1, scale, shift, residual, out);
+                    constexpr size_t lds_r16 = ((size_t)(CODEPS_RING_ADB ? 2 : 1) * 205 * ((2 * BK + 8) / 2 + 4) + (size_t)4 * BN * ((2 * BK + 8) / 2)) * sizeof(float) + 16;
+                    hipLaunchKernelGGL(kr, dim3(p.n_mt * p.n_nt, p.ksplit), dim3(halo_ws ? 384 : (w8 ? 512 : 256)), h16 ? lds_r16 + 16 : lds_r, st, p, a0, a1, scale, shift, residual, out);
                     if (p.ksplit > 1) launch_splitk_finish<MODE>(p, st, scale, shift, residual, out);
                     return;
                 }
