@@ -53,7 +53,7 @@ def test_no_kernel_spills_and_tuned_occupancies_hold():
             bad.append(f"{nice[n][:120]}: {r['scratch']} bytes of scratch per lane ({r['file']})")
     assert not bad, "kernels that spill:\n" + "\n".join(bad)
     # the occupancies the hot kernels were tuned at (waves per SIMD by registers; LDS decides the rest): plain instantiations only
-    want = {"conv_halo3r_kernel<0, 2, false, 3>": 1, "conv_halo3r_kernel<0, 2, false, 16>": 1,
+    want = {"conv_halo3r_kernel<0, 2, false, 3, 4>": 1, "conv_halo3r_kernel<0, 1, false, 16, 8>": 2,
             "conv_halo3_kernel<0, 1, 2, 2, false, 3>": 3, "conv_halo3_kernel<0, 1, 2, 2, false, 16>": 3,
             "conv_igemm_kernel<0, 2, 2, 2, 2, 32, 1, 3, false>": 3,
             "conv_igemm_kernel<0, 2, 2, 2, 1, 32, 1, 3, false>": 4, "conv_igemm_kernel<1, 2, 2, 2, 1, 32, 1, 3, false>": 4,
