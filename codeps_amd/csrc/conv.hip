@@ -5167,8 +5167,9 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 constexpr int PACK_SLAB = 4608;          // floats of LDS per work group (512 columns x 9 taps)
 constexpr long long PACK_AMAX_INLINE = 32768;      // parameters up to this many elements: every pack group takes the maximum itself (128 loads per thread)
 // Layout of a pack buffer in floats, `total` = rows x K extent (codeps_conv2d_packed_weight_floats):  [0, total) the fp32 pack;
-// [total, 2.5 total) three bf16 pieces (6 bytes per element);  [2.5 total, 3.5 total) two fp16 pieces of w 2^kb (4 bytes per element; written
-// when the arithmetic is 16);  [3.5 total, +4) the scale slot (2^-kb, 2^kb, 0, 0);  behind it one partial maximum per work group of the item.
+// [total, 2.5 total) three bf16 pieces (6 bytes per element; written under arithmetic 3);  [2.5 total, 3.5 total) two fp16 pieces of w 2^kb
+// (4 bytes per element; written under arithmetic 16);  [3.5 total, +4) the scale slot (2^-kb, 2^kb, max |w|, 0);  behind it one partial
+// maximum per work group of the item.  A pack carries the pieces of the arithmetic it was made under (codeps_conv2d_set_arith: re-pack after a switch).
 __host__ __device__ __forceinline__ long long pack_off_f16(long long total) { return total + (total * 6 + 3) / 4; }
 __host__ __device__ __forceinline__ long long pack_off_scale(long long total) { return pack_off_f16(total) + total; }
 struct PackItem {
@@ -5254,7 +5255,7 @@ __device__ __forceinline__ void pack_item_body(const PackItem& it, long long g, 
         float* dst = it.out + k;
         *reinterpret_cast<f32x4*>(dst) = a;
         *reinterpret_cast<f32x4*>(dst + 4) = b;
-        if (it.split) {
+        if (it.split == 1) {                                               // (arithmetic 16 reads the fp16 pieces only: the pack skips the bf16 ones)
             u16x4 pl[3], ph[3];
             split_bf16<3>(a, pl);
             split_bf16<3>(b, ph);
@@ -5771,7 +5772,7 @@ static void dispatch_igemm(ConvP p, int kc_gran, const float* a0, const float* a
         if (bk32 && nbuf == 1 && split_np == 3) launch_igemm<MODE, WM, WN, TM, TN, 32, 1, 3>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (bk32 && nbuf == 1) launch_igemm<MODE, WM, WN, TM, TN, 32, 1>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else if (bk32) launch_igemm<MODE, WM, WN, TM, TN, 32>(p, a0, a1, wq, scale, shift, residual, out, st); \
-        else if (MODE == MODE_FWD && split_np == 3 && nbuf == 1 && p.Ct == 16 && p.C1 == 0 && (p.KH * p.KW * 16) % 32 == 0)   /* stem */ \
+        else if (MODE == MODE_FWD && split_np == 3 && !f16_pairs() && nbuf == 1 && p.Ct == 16 && p.C1 == 0 && (p.KH * p.KW * 16) % 32 == 0)   /* stem */ \
             launch_igemm<MODE, WM, WN, TM, TN, 16, 1, 3>(p, a0, a1, wq, scale, shift, residual, out, st); \
         else      launch_igemm<MODE, WM, WN, TM, TN, 16>(p, a0, a1, wq, scale, shift, residual, out, st); \
     } while (0)

@@ -121,9 +121,11 @@ const char* codeps_conv2d_last_kernel(void);
 /* Name of the finish pass of the last conv2d_{fwd,dgrad} launch that was cut into K slices: "splitk_finish_kernel", or
  * "splitk_finish_ex_kernel" when the epilogue extras (codeps_conv_epilogue) ran there ("" before any such launch). */
 const char* codeps_conv2d_last_finish_kernel(void);
-/* Process-wide operand arithmetic of the conv engine: 3 (default; CODEPS_SPLIT) = fp32 operands as three exact bf16 pieces on
- * the bf16 MFMA, 0 = v_mfma_f32_32x32x2_f32, 2 = two pieces (experiments; outside the parity bar).  Returns the previous value;
- * any other argument only queries.  Weight packs made under one arithmetic stay valid under the others (they carry both forms). */
+/* Process-wide operand arithmetic of the conv engine (CODEPS_SPLIT): 16 (default since ABI 10) = fp32 operands as TWO fp16 pieces of x 2^k
+ * (power-of-two scales: per weight tensor from the pack, per block / row tile / pixel for activations and gradients inside the kernels), three
+ * products per multiply on the f16 MFMA; kernels without that form run the next one.  3 = three exact bf16 pieces, six products on the bf16
+ * MFMA.  0 = v_mfma_f32_32x32x2_f32.  Returns the previous value; any other argument only queries.  A weight pack carries the pre-split pieces
+ * of the arithmetic it was made under: re-pack after a switch (codeps_amd.functional stamps its packs with the arithmetic). */
 int codeps_conv2d_set_arith(int pieces);
 /* Process-wide form of the 3x3 / stride-1 halo-tile ring kernel: 0 (default) = the 256-thread kernel in which every wave stages and
  * multiplies, 1 (CODEPS_HALO_WS=1) = 384 threads, four consumer waves (fragment reads + MFMAs) + two producer waves (weight tiles by

@@ -33,7 +33,12 @@ def test_split_pack_rows_is_exact_and_laid_out_like_the_weight_pack():
     assert torch.equal(s2, s[:, :2])
     # same bytes as the weight pack's pre-split part for a 1x1 weight (rows = output channels)
     w = x[:64].contiguous().view(64, 96, 1, 1)
-    wf, _ = F.pack_weights(w, 64, 96, False)
+    from codeps_amd._lib import lib as _l
+    prev = _l().codeps_conv2d_set_arith(3)                     # (the bf16 pieces are the pack's content under arithmetic 3)
+    try:
+        wf, _ = F.pack_weights(w, 64, 96, False)
+    finally:
+        _l().codeps_conv2d_set_arith(prev)
     assert torch.equal(wf.view(-1)[64 * 96:].view(torch.int16)[: 64 * 96 * 3], _split(x[:64].contiguous()))
 
 
@@ -48,7 +53,12 @@ def test_conv1x1_split_fwd_matches_engine_and_float64(rows, ci, co, act):
     ref = pre if act == 0 else (pre.clamp_min(0) if act == 1 else torch.where(pre > 0, pre, torch.expm1(pre)))
     xd, wd = x.to(DEV), w.to(DEV).view(co, ci, 1, 1)
     sc_d, sh_d, res_d = scale.to(DEV), shift.to(DEV), res.to(DEV)       # (held: raw pointers go to the library)
-    wf, _ = F.pack_weights(wd, co, ci, False)
+    prev0 = _lib.lib().codeps_conv2d_set_arith(3)            # the prototype reads the three-bf16-piece pack
+    try:
+        wf, _ = F.pack_weights(wd, co, ci, False)
+        wf = wf.clone()
+    finally:
+        _lib.lib().codeps_conv2d_set_arith(prev0)
     xs, w_split = _split(xd), wf.view(-1)[co * ci:]
     y = torch.empty(rows, co, device=DEV)
     _lib.check_diag(_lib.diag_lib().codeps_conv1x1_split_fwd(_lib.ptr(xs), rows, ci, co, _lib.ptr(w_split), _lib.ptr(sc_d), _lib.ptr(sh_d), _lib.ptr(res_d), act,

@@ -42,9 +42,11 @@ def test_multi_pack_equals_single_packs():
         torch.cuda.synchronize()
         # the defined part of a pack: fp32, three bf16 pieces, two fp16 pieces, the scale slot (behind it: scratch of the pack's work groups)
         total = F.pad16(co) * F.pad16(ci) * p.shape[2] * p.shape[3]
-        used = total + (total * 6 + 3) // 4 + total + 4 if got_f.numel() > total else total
-        assert torch.equal(got_f[:used].view(torch.int32), ref_f[:used].view(torch.int32)), f"forward pack of {tuple(p.shape)} differs"
-        assert torch.equal(got_d[:used].view(torch.int32), ref_d[:used].view(torch.int32)), f"data-gradient pack of {tuple(p.shape)} differs"
+        off16 = total + (total * 6 + 3) // 4
+        parts = [(0, total)] + ([(off16, off16 + total + 4)] if got_f.numel() > total else [])      # fp32; the fp16 pieces + the scale slot (default arithmetic)
+        for lo, hi in parts:
+            assert torch.equal(got_f[lo:hi].view(torch.int32), ref_f[lo:hi].view(torch.int32)), f"forward pack of {tuple(p.shape)} differs"
+            assert torch.equal(got_d[lo:hi].view(torch.int32), ref_d[lo:hi].view(torch.int32)), f"data-gradient pack of {tuple(p.shape)} differs"
         assert not torch.equal(got_f, wf0), "the refresh did not see the new weights"
     F._pack_cache_train.clear()
     F._pack_table.update(dev=None, n=0, groups=0, entries=[], epoch=-1)
@@ -76,14 +78,21 @@ def test_single_pack_matches_the_layout_written_out_in_torch(shape):
     co, ci = shape[:2]
     p = torch.nn.Parameter(torch.randn(*shape, device=DEV) * torch.exp2(torch.randint(-8, 9, shape, device=DEV).float()))
     cop, cip = F.pad16(co), F.pad16(ci)
-    wf, wd = F.pack_weights(p, cop, cip, True)
+    from codeps_amd._lib import lib
+    prev = lib().codeps_conv2d_set_arith(3)                    # the three bf16 pieces are written under arithmetic 3 ...
+    try:
+        wf3, wd3 = (t.clone() for t in F.pack_weights(p, cop, cip, True))
+    finally:
+        lib().codeps_conv2d_set_arith(prev)
+    wf, wd = F.pack_weights(p, cop, cip, True)                 # ... the two fp16 pieces under the default (the stamp of a pack carries the arithmetic)
     torch.cuda.synchronize()
-    for got, dgrad, rows, cols in ((wf, False, cop, cip), (wd, True, cip, cop)):
+    for got, got3, dgrad, rows, cols in ((wf, wf3, False, cop, cip), (wd, wd3, True, cip, cop)):
         ref, pieces = _reference_pack(p.detach(), rows, cols, dgrad)
         n = ref.numel()
         assert torch.equal(got[:n].view(torch.int32), ref.view(torch.int32)), f"fp32 pack (dgrad={dgrad}) of {shape}"
+        assert torch.equal(got3[:n].view(torch.int32), ref.view(torch.int32)), f"fp32 pack under arithmetic 3 (dgrad={dgrad}) of {shape}"
         if pieces is not None:
-            have = got[n:].view(torch.int16)[:pieces.numel()]
+            have = got3[n:].view(torch.int16)[:pieces.numel()]
             assert torch.equal(have, pieces), f"split copy (dgrad={dgrad}) of {shape}"
             # the two fp16 pieces of w 2^kb ([group of 32][hi | lo][32]) and the scale slot (2^-kb, 2^kb, max |w|, 0): csrc/conv.hip, split_f16
             off = n + (n * 6 + 3) // 4
