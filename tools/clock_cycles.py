@@ -129,8 +129,11 @@ def kernels(warm_s):
         row = {"layer": name, "kernel": kname, "blocks_stamped": int(len(s)), "us_per_launch_stamped_build": round(us, 1), "in_kernel_ghz": round(ghz, 3),
                "ghz_p10_p90": [round(float(np.percentile(s[:, 0] / s[:, 1], 10) * 0.1), 3), round(float(np.percentile(s[:, 0] / s[:, 1], 90) * 0.1), 3)],
                "block_lifetime_cycles_median": round(life), "algorithmic_tflops_stamped_build": round(flops / us / 1e6, 1),
-               # fraction of the matrix pipe's cycles that six bf16 products per fp32 multiply need, AT THE CLOCK THE KERNEL RAN AT
-               "mfma_cycles_needed_over_cycles_elapsed": round(6.0 * flops / PEAK_FLOP_PER_CYCLE_SIMD / N_SIMD / (us * 1e-6 * ghz * 1e9), 3)}
+               # fraction of the matrix pipe's cycles that the piece products per fp32 multiply need (three on the fp16 form -- the kernel's
+               # name says so --, six on the bf16 one), AT THE CLOCK THE KERNEL RAN AT
+               "products_per_multiply": 3 if ("f16x2" in kname or "_h_kernel" in kname) else 6,
+               "mfma_cycles_needed_over_cycles_elapsed": round((3.0 if ("f16x2" in kname or "_h_kernel" in kname) else 6.0) * flops / PEAK_FLOP_PER_CYCLE_SIMD / N_SIMD /
+                                                               (us * 1e-6 * ghz * 1e9), 3)}
         if s[:, 2].sum() > 0:
             row["phase_mfma_share_of_lifetime"] = round(float(np.median(s[:, 2] / s[:, 0])), 3)
             row["phase_staging_share_of_lifetime"] = round(float(np.median(s[:, 3] / s[:, 0])), 3)
