@@ -100,6 +100,12 @@ def kernels(warm_s):
     g = torch.Generator(device="cpu").manual_seed(1)
     rows = []
 
+    arith16 = _lib.lib().codeps_conv2d_set_arith(-1) == 16
+
+    def h16(kname):
+        """the launch ran the two-fp16-piece arithmetic: its name says so, or (weight gradient / chain rows, named by this tool) the engine's default does"""
+        return "f16x2" in kname or "_h_kernel" in kname or (arith16 and ("wgrad_halo64s" in kname or "chain_expand" in kname))
+
     def measure(name, fn, stamped_part, flops, note=""):
         """fn(): enqueue the launches; stamped_part(): the sub-sequence whose stamps are read (run once after the warm-up)."""
         fn()
@@ -131,9 +137,8 @@ def kernels(warm_s):
                "block_lifetime_cycles_median": round(life), "algorithmic_tflops_stamped_build": round(flops / us / 1e6, 1),
                # fraction of the matrix pipe's cycles that the piece products per fp32 multiply need (three on the fp16 form -- the kernel's
                # name says so --, six on the bf16 one), AT THE CLOCK THE KERNEL RAN AT
-               "products_per_multiply": 3 if ("f16x2" in kname or "_h_kernel" in kname) else 6,
-               "mfma_cycles_needed_over_cycles_elapsed": round((3.0 if ("f16x2" in kname or "_h_kernel" in kname) else 6.0) * flops / PEAK_FLOP_PER_CYCLE_SIMD / N_SIMD /
-                                                               (us * 1e-6 * ghz * 1e9), 3)}
+               "products_per_multiply": 3 if h16(kname) else 6,
+               "mfma_cycles_needed_over_cycles_elapsed": round((3.0 if h16(kname) else 6.0) * flops / PEAK_FLOP_PER_CYCLE_SIMD / N_SIMD / (us * 1e-6 * ghz * 1e9), 3)}
         if s[:, 2].sum() > 0:
             row["phase_mfma_share_of_lifetime"] = round(float(np.median(s[:, 2] / s[:, 0])), 3)
             row["phase_staging_share_of_lifetime"] = round(float(np.median(s[:, 3] / s[:, 0])), 3)
@@ -198,7 +203,7 @@ def kernels(warm_s):
     def chain_part(st):
         st.zero_()
         chain()
-        return "chain_expand_reduce_kernel"
+        return "chain_expand_reduce_h_kernel" if arith16 else "chain_expand_reduce_kernel"
     measure("layer3 chained 1x1 pair (B8 32x64 256->1024->256)", chain, chain_part, 2.0 * b * h * w * (n2 * 256 + 256 * n2))
     return {"what": "diagnostic build with in-kernel clock stamps (-DCODEPS_CLOCK_STAMPS): wave 0 of every block stamps its lifetime; run times of "
                     "this build are NOT benchmarks", "rows": rows}
