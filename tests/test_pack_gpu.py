@@ -43,7 +43,9 @@ def test_multi_pack_equals_single_packs():
         # the defined part of a pack: fp32, three bf16 pieces, two fp16 pieces, the scale slot (behind it: scratch of the pack's work groups)
         total = F.pad16(co) * F.pad16(ci) * p.shape[2] * p.shape[3]
         off16 = total + (total * 6 + 3) // 4
-        parts = [(0, total)] + ([(off16, off16 + total + 4)] if got_f.numel() > total else [])      # fp32; the fp16 pieces + the scale slot (default arithmetic)
+        from codeps_amd._lib import lib
+        pieces = (off16, off16 + total + 4) if lib().codeps_conv2d_set_arith(-1) == 16 else (total, off16)    # the fp16 pieces + scale slot, or the bf16 pieces
+        parts = [(0, total)] + ([pieces] if got_f.numel() > total else [])
         for lo, hi in parts:
             assert torch.equal(got_f[lo:hi].view(torch.int32), ref_f[lo:hi].view(torch.int32)), f"forward pack of {tuple(p.shape)} differs"
             assert torch.equal(got_d[lo:hi].view(torch.int32), ref_d[lo:hi].view(torch.int32)), f"data-gradient pack of {tuple(p.shape)} differs"
@@ -84,7 +86,11 @@ def test_single_pack_matches_the_layout_written_out_in_torch(shape):
         wf3, wd3 = (t.clone() for t in F.pack_weights(p, cop, cip, True))
     finally:
         lib().codeps_conv2d_set_arith(prev)
-    wf, wd = F.pack_weights(p, cop, cip, True)                 # ... the two fp16 pieces under the default (the stamp of a pack carries the arithmetic)
+    prev = lib().codeps_conv2d_set_arith(16)                   # ... the two fp16 pieces under 16 (the stamp of a pack carries the arithmetic)
+    try:
+        wf, wd = (t.clone() for t in F.pack_weights(p, cop, cip, True))
+    finally:
+        lib().codeps_conv2d_set_arith(prev)
     torch.cuda.synchronize()
     for got, got3, dgrad, rows, cols in ((wf, wf3, False, cop, cip), (wd, wd3, True, cip, cop)):
         ref, pieces = _reference_pack(p.detach(), rows, cols, dgrad)
