@@ -216,6 +216,7 @@ DIAG_SIGNATURES = {
     "codeps_diag_last_error": (c_char_p, []),
     "codeps_diag_mfma_rate": (c_int, [I, I, I, I, I, P, P, P, P]),
     "codeps_diag_stream_triad": (c_int, [P, P, P, LL, I, P, P]),
+    "codeps_diag_stream_copy": (c_int, [P, P, LL, I, P, P]),
     "codeps_diag_mfma_valu": (c_int, [I, I, I, I, I, P, P, P]),
     "codeps_diag_feed_rate": (c_int, [I, I, I, I, I, P, LL, P, P, P]),
     "codeps_diag_mfma_rate_clock": (c_int, [I, I, I, I, I, P, P, P, P]),

@@ -152,6 +152,19 @@ __global__ __launch_bounds__(256) void triad_kernel(const f32x4* __restrict__ b,
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) a[i] = b[i] + s * c[i];
 }
 
+// HBM copy, the form MI355X_MICROARCH.md quotes its measured roof on (float4 copy: 6.29 TB/s = 79 % of 8): every thread moves four 16-byte
+// vectors per trip, all four loads issued before the first store (loads behind stores queue on vmcnt), consecutive lanes consecutive vectors.
+__global__ __launch_bounds__(256) void copy_kernel(const f32x4* __restrict__ src, long long n4, f32x4* __restrict__ dst) {
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i + 256 * k < n4 ? __builtin_nontemporal_load(src + i + 256 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + 256 * k < n4) __builtin_nontemporal_store(v[k], dst + i + 256 * k);
+    }
+}
+
 // How many bytes per clock can a CU take in NEXT TO a full-rate MFMA stream?  One block of four waves per CU; per iteration
 // every wave issues 96 v_mfma_f32_16x16x32_bf16 on register operands (a 128 x 128 x 32 six-product K-step) and the block
 // brings `kb` KiB from an L2-resident window into LDS:
@@ -388,6 +401,16 @@ extern "C" int codeps_diag_stream_triad(float* a, const float* b, const float* c
                            n / 4, reinterpret_cast<f32x4*>(a));
     });
     CODEPS_CHECK_LAUNCH("triad_kernel");
+    return rc;
+}
+
+extern "C" int codeps_diag_stream_copy(float* dst, const float* src, long long n, int reps, float* ms_per_launch, codeps_stream_t stream) {
+    CODEPS_REQUIRE(dst && src && n > 0 && n % 4 == 0 && reps > 0 && ms_per_launch, CODEPS_ERR_ARG, "codeps_diag_stream_copy: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = timed(st, reps, ms_per_launch, [&]() {
+        hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src), n / 4, reinterpret_cast<f32x4*>(dst));
+    });
+    CODEPS_CHECK_LAUNCH("copy_kernel");
     return rc;
 }
 

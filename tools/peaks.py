@@ -47,6 +47,9 @@ def measure(sustain_ms=200.0):
                "codeps_diag_stream_triad")
     assert float(a[12345]) == 4.0
     out["hbm_triad_gbs"] = round(12.0 * n / (ms.value * 1e-3) / 1e9, 1)
+    _lib.check_diag(lib.codeps_diag_stream_copy(_lib.ptr(a), _lib.ptr(b), n, 20, ctypes.byref(ms), _lib.stream_ptr()), "codeps_diag_stream_copy")
+    assert float(a[12345]) == 1.0
+    out["hbm_copy_gbs"] = round(8.0 * n / (ms.value * 1e-3) / 1e9, 1)       # the roof MI355X_MICROARCH.md measures (float4 copy: 6.29 TB/s)
     return out
 
 
