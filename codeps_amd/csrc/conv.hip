@@ -4579,14 +4579,20 @@ __global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_
 // 52 KB) and its four waves are (co tile) x (output row of the sub-tile): 54 MFMAs per wave and sub-tile.  Staging roles: wave 0 dZ (64
 // tasks of 8 pixels x 4 channels), waves 1-3 the 160 X tasks (8 input pixels x 4 channels: four even + four odd, two 8-byte stores per
 // channel and piece), wave 3 also the 40 halo pixels (column -1).  Until this kernel these layers ran on the f32 MFMA at 84 TFLOP/s.
+// ARITH 16 (round 6): two fp16 pieces, both operands with running block-local scales, three register sets -- as wgrad_halo64h_body.
+template <int ARITH = 3>
 __global__ __launch_bounds__(256) void wgrad_s2_halo_kernel(WgradP p, int ci_chunks, int tiles_x, int tiles_y, int tiles_per_block,
                                                             const float* __restrict__ x0, const float* __restrict__ dz, float* __restrict__ part) {
     constexpr int TH = 2, TW = 16, XR = 5, PIX = TH * TW, XROW = 40;
-    constexpr int ZP = 3 * PIX + 8;                    // halfwords per dZ channel (104)
-    constexpr int XQ = XR * XROW, XP = 3 * XQ + 16;    // halfwords per X piece / per X channel (616: 308 dwords = 4 x 77, conflict-free 16-byte reads)
+    constexpr int NP = ARITH == 16 ? 2 : 3, NPROD = NP * (NP + 1) / 2;
+    constexpr bool H16 = ARITH == 16;
+    typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
+    constexpr int ZP = NP * PIX + 8;                   // halfwords per dZ channel (104 / 72)
+    constexpr int XQ = XR * XROW, XP = NP * XQ + (H16 ? 24 : 16);    // halfwords per X piece / per X channel (616 / 424: 77 / 53 slots of 16 bytes, odd: conflict-free reads)
     constexpr int XS0 = 64 * ZP, BUF = XS0 + 32 * XP;  // halfwords per buffer: [64][ZP] dZ, [32][XP] X
     constexpr int OOFF = 16;                           // the O plane of a row starts here: slot OOFF + 7 = column -1, OOFF + 8 + i = column 2 i + 1
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    int* slots = reinterpret_cast<int*>(lds16 + 2 * BUF);         // ARITH 16: [sub-tile parity][wave] largest exponents
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave & 1, ph = wave >> 1;          // this wave's 32-row co tile and output row of a sub-tile
@@ -4654,45 +4660,66 @@ __global__ __launch_bounds__(256) void wgrad_s2_halo_kernel(WgradP p, int ci_chu
         }
     };
     // channel e of the big task.  dZ: 8 pixels -> one 16-byte row per piece.  X: pixels 0, 2, 4, 6 -> E, 1, 3, 5, 7 -> O, 8 bytes each
-    auto store_big = [&](auto role_c, const f32x4 (&raw)[9], int e, unsigned short* buf) {
+    auto split_np = [&](const f32x4 v, float sc, u16x4 (&pc)[NP]) {
+        if constexpr (H16) split_f16(v, sc, pc[0], pc[1]);
+        else split_bf16<NP>(v, pc);
+    };
+    auto store_big = [&](auto role_c, const f32x4 (&raw)[9], int e, unsigned short* buf, float sc) {
         constexpr int ROLE = decltype(role_c)::value;
-        u16x4 lo[3], hi[3];
+        u16x4 lo[NP], hi[NP];
         if (ROLE == 0) {
-            split_bf16<3>(f32x4{raw[0][e], raw[1][e], raw[2][e], raw[3][e]}, lo);
-            split_bf16<3>(f32x4{raw[4][e], raw[5][e], raw[6][e], raw[7][e]}, hi);
+            split_np(f32x4{raw[0][e], raw[1][e], raw[2][e], raw[3][e]}, sc, lo);
+            split_np(f32x4{raw[4][e], raw[5][e], raw[6][e], raw[7][e]}, sc, hi);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(buf + b_dst + e * ZP + q * PIX) = pack8(lo[q], hi[q]);
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(buf + b_dst + e * ZP + q * PIX) = pack8(lo[q], hi[q]);
         } else {
-            split_bf16<3>(f32x4{raw[0][e], raw[2][e], raw[4][e], raw[6][e]}, lo);      // even columns
-            split_bf16<3>(f32x4{raw[1][e], raw[3][e], raw[5][e], raw[7][e]}, hi);      // odd columns
+            split_np(f32x4{raw[0][e], raw[2][e], raw[4][e], raw[6][e]}, sc, lo);      // even columns
+            split_np(f32x4{raw[1][e], raw[3][e], raw[5][e], raw[7][e]}, sc, hi);      // odd columns
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NP; ++q) {
                 *reinterpret_cast<u16x4*>(buf + b_dst + e * XP + q * XQ) = lo[q];
                 *reinterpret_cast<u16x4*>(buf + b_dst + e * XP + q * XQ + OOFF + 8) = hi[q];
             }
         }
     };
-    auto store_small = [&](const f32x4 v, unsigned short* buf) {
-        u16x4 pc[3];
-        split_bf16<3>(v, pc);
+    auto store_small = [&](const f32x4 v, unsigned short* buf, float sc) {
+        u16x4 pc[NP];
+        split_np(v, sc, pc);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) buf[s_dst + e * XP + q * XQ] = pc[q][e];
+            for (int q = 0; q < NP; ++q) buf[s_dst + e * XP + q * XQ] = pc[q][e];
     };
-    auto store_all = [&](auto role_c, const f32x4 (&raw)[9], unsigned short* buf) {
+    auto store_all = [&](auto role_c, const f32x4 (&raw)[9], unsigned short* buf, float sc) {
         constexpr int ROLE = decltype(role_c)::value;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) store_big(role_c, raw, e, buf);
-        if (ROLE == 3) store_small(raw[8], buf);
+        for (int e = 0; e < 4; ++e) store_big(role_c, raw, e, buf, sc);
+        if (ROLE == 3) store_small(raw[8], buf, sc);
+    };
+    // ARITH 16: the largest exponent in a wave's share of a sub-tile -> slots[parity][wave]; every wave derives the same running exponents
+    auto publish = [&](auto role_c, const f32x4 (&raw)[9], int parity) {
+        constexpr int ROLE = decltype(role_c)::value;
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < (ROLE == 3 ? 9 : 8); ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(raw[i][e]));
+        const int ex = wave_max_exponent(m);
+        if (lane == 0) slots[parity * 4 + wave] = ex;
+    };
+    int ez_run = F16_EMIN, ex_run = F16_EMIN;
+    auto next_exponents = [&](int parity, int& ez_n, int& ex_n) {
+        const i32x4 pe = *reinterpret_cast<const i32x4*>(slots + parity * 4);
+        ez_n = __builtin_amdgcn_readfirstlane(max(ez_run, pe[0]));
+        ex_n = __builtin_amdgcn_readfirstlane(max(ex_run, max(pe[1], max(pe[2], pe[3]))));
     };
 
     const int zoff = (wco * 32 + l32) * ZP + ph * TW + h * 8, xoff = XS0 + l32 * XP + (2 * ph) * XROW + h * 8;
     // fragments a phase starts with (read by the previous phase behind its barrier): this wave's dZ row and its first X row
-    struct Frag { bf16x8 zf[3]; i32x4 x0[3][3]; };                  // x0[piece][E | O | O's preceding group]
-    auto read_row = [&](const unsigned short* xrow, int ky, i32x4 (&dst)[3][3]) {
+    struct Frag { frag_t zf[NP]; i32x4 x0[NP][3]; };                // x0[piece][E | O | O's preceding group]
+    auto read_row = [&](const unsigned short* xrow, int ky, i32x4 (&dst)[NP][3]) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
             const unsigned short* g0 = xrow + q * XQ + ky * XROW;
             dst[q][0] = *reinterpret_cast<const i32x4*>(g0);
             dst[q][1] = *reinterpret_cast<const i32x4*>(g0 + OOFF + 8);
@@ -4701,17 +4728,28 @@ __global__ __launch_bounds__(256) void wgrad_s2_halo_kernel(WgradP p, int ci_chu
     };
     auto prefetch = [&](const unsigned short* buf, Frag& f) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) f.zf[q] = *reinterpret_cast<const bf16x8*>(buf + zoff + q * PIX);
+        for (int q = 0; q < NP; ++q) f.zf[q] = *reinterpret_cast<const frag_t*>(buf + zoff + q * PIX);
         read_row(buf + xoff, 0, f.x0);
     };
-    auto phase = [&](auto role_c, int j, const f32x4 (&rs)[9], f32x4 (&rl)[9], const unsigned short* cur, unsigned short* nxt, Frag& fr) {
+    // rs: sub-tile j + 1 (stored now); rp (ARITH 16): sub-tile j + 2, landed, its exponent published in front of this phase's barrier;
+    // rl: the sub-tile whose loads are issued now (j + 2, or j + 3 with three register sets)
+    auto phase = [&](auto role_c, int j, const f32x4 (&rs)[9], const f32x4 (&rp)[9], f32x4 (&rl)[9], Frag& fr) {
         constexpr int ROLE = decltype(role_c)::value;
-        issue_loads(role_c, min(j + 2, NJ - 1), j + 2 < NJ, rl);
+        const unsigned short* cur = lds16 + (j & 1) * BUF;
+        unsigned short* nxt = lds16 + ((j + 1) & 1) * BUF;
+        int ez_n = ez_run, ex_n = ex_run;
+        float sc = 1.f;
+        if constexpr (H16) {
+            next_exponents((j + 1) & 1, ez_n, ex_n);
+            sc = f16_scale_of(ROLE == 0 ? ez_n : ex_n);
+        }
+        constexpr int AHEAD = H16 ? 3 : 2;
+        issue_loads(role_c, min(j + AHEAD, NJ - 1), j + AHEAD < NJ, rl);
         const unsigned short* xrow = cur + xoff;
-        bf16x8 zf[3];
-        i32x4 xraw[2][3][3];
+        frag_t zf[NP];
+        i32x4 xraw[2][NP][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
             zf[q] = fr.zf[q];
 #pragma unroll
             for (int i = 0; i < 3; ++i) xraw[0][q][i] = fr.x0[q][i];
@@ -4720,58 +4758,96 @@ __global__ __launch_bounds__(256) void wgrad_s2_halo_kernel(WgradP p, int ci_chu
         for (int ky = 0; ky < 3; ++ky) {
             if (ky + 1 < 3) read_row(xrow, ky + 1, xraw[(ky + 1) & 1]);
             else {
+                if constexpr (H16) { if (j + 2 < NJ) publish(role_c, rp, j & 1); }
                 __syncthreads();                                    // every wave has read `cur` (its last row is in registers) and written its part of `nxt`
                 prefetch(nxt, fr);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (ky == 0) { store_big(role_c, rs, 0, nxt); store_big(role_c, rs, 1, nxt); }
-            if (ky == 1) { store_big(role_c, rs, 2, nxt); store_big(role_c, rs, 3, nxt); if (ROLE == 3) store_small(rs[8], nxt); }
-            bf16x8 xf[3][3];                                         // [kx][piece]
+            if (ky == 0) { store_big(role_c, rs, 0, nxt, sc); store_big(role_c, rs, 1, nxt, sc); }
+            if (ky == 1) { store_big(role_c, rs, 2, nxt, sc); store_big(role_c, rs, 3, nxt, sc); if (ROLE == 3) store_small(rs[8], nxt, sc); }
+            frag_t xf[3][NP];                                        // [kx][piece]
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NP; ++q) {
                 const i32x4 ev = xraw[ky & 1][q][0], od = xraw[ky & 1][q][1], pv = xraw[ky & 1][q][2];
                 i32x4 left;
                 left[0] = (int)__builtin_amdgcn_alignbit((unsigned)od[0], (unsigned)pv[3], 16);
 #pragma unroll
                 for (int i = 1; i < 4; ++i) left[i] = (int)__builtin_amdgcn_alignbit((unsigned)od[i], (unsigned)od[i - 1], 16);
-                xf[0][q] = __builtin_bit_cast(bf16x8, left);
-                xf[1][q] = __builtin_bit_cast(bf16x8, ev);
-                xf[2][q] = __builtin_bit_cast(bf16x8, od);
+                xf[0][q] = __builtin_bit_cast(frag_t, left);
+                xf[1][q] = __builtin_bit_cast(frag_t, ev);
+                xf[2][q] = __builtin_bit_cast(frag_t, od);
             }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int ord = 2; ord >= 0; --ord)
+                for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
-                    for (int qa = 0; qa <= ord; ++qa)
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
+                    for (int qa = 0; qa <= ord; ++qa) {
+                        if constexpr (H16) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zf[qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
+                        else acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[qa], xf[kx][ord - qa], acc[ky * 3 + kx], 0, 0, 0);
+                    }
 #pragma unroll
-            for (int i = 0; i < 18; ++i) {
+            for (int i = 0; i < 3 * NPROD; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x202, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x202, H16 ? 12 : 6, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (H16) {                                        // the next sub-tile was staged at (ez_n, ex_n): re-base the sums when that grew (exact)
+            if (ez_n + ex_n != ez_run + ex_run) {
+                const float rb = f16_rebase(ez_run + ex_run, ez_n + ex_n);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] *= rb;
+            }
+            ez_run = ez_n; ex_run = ex_n;
+        }
     };
     auto run = [&](auto role_c) {
-        f32x4 ra[9], rb[9];
-        unsigned short* buf0 = lds16;
-        unsigned short* buf1 = lds16 + BUF;
-        issue_loads(role_c, 0, true, ra);
-        issue_loads(role_c, 1, true, rb);
-        store_all(role_c, ra, buf0);
-        __syncthreads();
+        constexpr int ROLE = decltype(role_c)::value;
         Frag fr;
-        prefetch(buf0, fr);
-        for (int j = 0; j < NJ; j += 2) {
-            phase(role_c, j, rb, ra, buf0, buf1, fr);
-            phase(role_c, j + 1, ra, rb, buf1, buf0, fr);
+        if constexpr (H16) {
+            f32x4 r0[9], r1[9], r2[9];                              // sub-tile t lives in set t % 3
+            issue_loads(role_c, 0, true, r0);
+            issue_loads(role_c, 1, true, r1);                       // (NJ >= 2)
+            issue_loads(role_c, min(2, NJ - 1), 2 < NJ, r2);
+            publish(role_c, r0, 0);
+            publish(role_c, r1, 1);
+            __syncthreads();
+            {
+                int ez_n, ex_n;
+                next_exponents(0, ez_n, ex_n);
+                ez_run = ez_n; ex_run = ex_n;
+                store_all(role_c, r0, lds16, f16_scale_of(ROLE == 0 ? ez_n : ex_n));
+            }
+            __syncthreads();
+            prefetch(lds16, fr);
+            for (int j = 0; j < NJ; j += 3) {
+                phase(role_c, j, r1, r2, r0, fr);
+                if (j + 1 < NJ) phase(role_c, j + 1, r2, r0, r1, fr);
+                if (j + 2 < NJ) phase(role_c, j + 2, r0, r1, r2, fr);
+            }
+        } else {
+            f32x4 ra[9], rb[9];
+            issue_loads(role_c, 0, true, ra);
+            issue_loads(role_c, 1, true, rb);
+            store_all(role_c, ra, lds16, 1.f);
+            __syncthreads();
+            prefetch(lds16, fr);
+            for (int j = 0; j < NJ; j += 2) {
+                phase(role_c, j, rb, rb, ra, fr);
+                phase(role_c, j + 1, ra, ra, rb, fr);
+            }
         }
     };
     if (NJ > 0) {
         if (wave == 0) run(std::integral_constant<int, 0>{});
         else if (wave == 3) run(std::integral_constant<int, 3>{});
         else run(std::integral_constant<int, 1>{});
+    }
+    if constexpr (H16) {                                            // back to the operands' units (exact)
+        const float inv = f16_inv_scale_of(ez_run) * f16_inv_scale_of(ex_run);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] *= inv;
     }
     // one partial slab per (block, output row of the sub-tiles): [2 blk + ph][co][tap][ci]
     float* dst = part + (size_t)(blk * 2 + ph) * p.Co * 9 * p.Ct;
@@ -6260,10 +6336,12 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
     if (s2.ok) {
-        constexpr size_t lds = (size_t)2 * (64 * (3 * 32 + 8) + 32 * (3 * 5 * 40 + 16)) * 2;
-        g_last_kernel = "wgrad_s2_halo_kernel";
-        codeps_allow_lds((const void*)wgrad_s2_halo_kernel, 160 * 1024, "wgrad_s2_halo_kernel");
-        hipLaunchKernelGGL(wgrad_s2_halo_kernel, dim3(s2.nblk * s2.ci_chunks, s2.co_groups), dim3(256), lds, st, p, s2.ci_chunks, s2.tiles_x, s2.tiles_y,
+        const bool h16 = f16_pairs();
+        const size_t lds = h16 ? (size_t)2 * (64 * (2 * 32 + 8) + 32 * (2 * 5 * 40 + 24)) * 2 + 32 : (size_t)2 * (64 * (3 * 32 + 8) + 32 * (3 * 5 * 40 + 16)) * 2;
+        g_last_kernel = h16 ? "wgrad_s2_halo_kernel<f16x2>" : "wgrad_s2_halo_kernel";
+        auto k2 = h16 ? wgrad_s2_halo_kernel<16> : wgrad_s2_halo_kernel<3>;
+        codeps_allow_lds((const void*)k2, 160 * 1024, "wgrad_s2_halo_kernel");
+        hipLaunchKernelGGL(k2, dim3(s2.nblk * s2.ci_chunks, s2.co_groups), dim3(256), lds, st, p, s2.ci_chunks, s2.tiles_x, s2.tiles_y,
                            s2.tiles_per_block, x0, dz, part);
         CODEPS_CHECK_LAUNCH("wgrad_s2_halo_kernel");
         launch_wgrad_reduce(part, splits, d->out_c, d->c0, 9, out_c_real, in_c_real, dw_oihw, accumulate, st);
