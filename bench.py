@@ -580,7 +580,7 @@ def main():
                        "accumulation; 2^k is a power of two chosen per weight tensor by the pack and per block (chain kernel: per pixel) for "
                        "activations / gradients, so scaling is exact and no tensor overflows fp16.  Error against float64 measured per kernel at or "
                        "below the three-bf16-piece kernels' and within 3x of torch's own fp32 convolution (profiles/r06_f16_stage_*.json, "
-                       "tests/test_precision_gpu.py).  Kernels without an fp16 form (the stem's weight gradient) keep the exact 3-way bf16 split (six products); <= 32-channel weight gradients, 16-column 1x1 "
+                       "tests/test_precision_gpu.py).  <= 32-channel weight gradients, 16-column 1x1 "
                        "kernels, the last up-convolution and the disparity head run on the f32 MFMA"),
                 "3": ("fp32 end to end; conv forward / data-gradient / halo-tile and 1x1 weight-gradient operands enter the matrix cores as "
                       "exact 3-way bf16 splits (six bf16 products per multiply, fp32 accumulate: product error ~6e-9 relative, below "

@@ -4361,13 +4361,20 @@ __global__ __launch_bounds__(256) void wgrad_stem74s_kernel(WgradP p, int tiles_
 // t + 1 between them and then issues the loads of tile t + 2; addresses are (scalar tile origin) + (per-thread constant), row padding
 // is the range check of the buffer resource.  Roles: waves 0, 1 stage dZ (128 tasks of 8 pixels x 4 channels), wave 2 the first 64 of
 // the 156 X tasks; wave 3 -- tap row 6 only, half the MFMAs -- the other 92 (two per lane).  One code copy per role.
+// ARITH 16 (round 6): two fp16 pieces, running block-local scales for dZ (waves 0, 1) and X (waves 2, 3), three register sets per task: a tile is
+// loaded three phases ahead, its exponent published two ahead, stored one ahead -- as in wgrad_halo64h_body.
+template <int ARITH = 3>
 __global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_x, int tiles_y, int tiles_per_block,
                                                             const float* __restrict__ x0, const float* __restrict__ dz, float* __restrict__ part) {
     constexpr int TH = 4, TW = 16, KH = 7, KW = 4, XH = (TH - 1) * 2 + KH, PIX = TH * TW, XROW = 24;
-    constexpr int ZP = 3 * PIX + 8;                    // halfwords per dZ channel
-    constexpr int XQ = XH * XROW, XP = 3 * XQ;         // halfwords per X piece / channel (468 dwords: odd multiple of 4 -> conflict-free)
+    constexpr int NP = ARITH == 16 ? 2 : 3;
+    constexpr bool H16 = ARITH == 16;
+    typedef typename std::conditional<H16, f16x8, bf16x8>::type frag_t;
+    constexpr int ZP = NP * PIX + 8;                   // halfwords per dZ channel
+    constexpr int XQ = XH * XROW, XP = NP * XQ + (H16 ? 8 : 0);      // halfwords per X piece / channel (468 / 316 dwords: odd multiples of 4 -> conflict-free)
     constexpr int XS0 = 64 * ZP, BUF = XS0 + 16 * XP;  // halfwords per buffer
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    int* slots = reinterpret_cast<int*>(lds16 + 2 * BUF);           // ARITH 16: [tile parity][wave] largest exponents
     const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = blockIdx.x;
@@ -4424,31 +4431,59 @@ __global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_
             for (int i = 0; i < 8; ++i) raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, i * 64, 0));
         }
     };
-    auto store_big = [&](auto role_c, int u, const f32x4 (&raw)[8], int e, unsigned short* buf) {
+    auto store_big = [&](auto role_c, int u, const f32x4 (&raw)[8], int e, unsigned short* buf, float sc = 1.f) {
         constexpr int ROLE = decltype(role_c)::value;
         constexpr int cs = ROLE == 0 ? ZP : XP, qs = ROLE == 0 ? PIX : XQ;
         const f32x4 lo4 = {raw[0][e], raw[1][e], raw[2][e], raw[3][e]};
         const f32x4 hi4 = {raw[4][e], raw[5][e], raw[6][e], raw[7][e]};
-        u16x4 lo[3], hi[3];
-        split_bf16<3>(lo4, lo);
-        split_bf16<3>(hi4, hi);
+        u16x4 lo[NP], hi[NP];
+        if constexpr (H16) { split_f16(lo4, sc, lo[0], lo[1]); split_f16(hi4, sc, hi[0], hi[1]); }
+        else { split_bf16<NP>(lo4, lo); split_bf16<NP>(hi4, hi); }
         // (lanes 28-63 of wave 3's second task have no task: they hold zeros and store them where the first task of the same lane
         //  stores -- before it, in program order -- so the slot ends with the real data)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<i32x4*>(buf + k_dst[u] + e * cs + q * qs) = pack8(lo[q], hi[q]);
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<i32x4*>(buf + k_dst[u] + e * cs + q * qs) = pack8(lo[q], hi[q]);
     };
     const int ky0 = wave * 2;
     // one tile: its MFMAs out of `cur`; between them the staging of the next tile (registers r0 / r1, loaded a phase ago) into `nxt`,
     // then the loads of the tile after that
-    auto phase = [&](auto role_c, int t, f32x4 (&r0)[8], f32x4 (&r1)[8], const unsigned short* cur, unsigned short* nxt) {
+    // ARITH 16: exponents of the two operands (block-uniform: every wave derives them from the same slots)
+    int ez_run = F16_EMIN, ex_run = F16_EMIN;
+    auto publish = [&](auto role_c, const f32x4 (&a0)[8], const f32x4 (&a1)[8], int parity) {
+        constexpr int ROLE = decltype(role_c)::value;
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { m = fmaxf(m, fabsf(a0[i][e])); if (ROLE == 2) m = fmaxf(m, fabsf(a1[i][e])); }
+        const int ex = wave_max_exponent(m);
+        if (lane == 0) slots[parity * 4 + wave] = ex;
+    };
+    auto next_exponents = [&](int parity, int& ez_n, int& ex_n) {
+        const i32x4 pe = *reinterpret_cast<const i32x4*>(slots + parity * 4);
+        ez_n = __builtin_amdgcn_readfirstlane(max(ez_run, max(pe[0], pe[1])));
+        ex_n = __builtin_amdgcn_readfirstlane(max(ex_run, max(pe[2], pe[3])));
+    };
+    // ARITH 3: r0 / r1 hold tile t + 1 (stored in regions 0 / 1) and are re-loaded with tile t + 2 behind their stores (rp*, rl* unused).
+    // ARITH 16: r0 / r1 = tile t + 1 (stored), rp0 / rp1 = tile t + 2 (published in front of the barrier), rl0 / rl1 = tile t + 3 (loads issued first).
+    auto phase = [&](auto role_c, int t, f32x4 (&r0)[8], f32x4 (&r1)[8], const f32x4 (&rp0)[8], const f32x4 (&rp1)[8], f32x4 (&rl0)[8], f32x4 (&rl1)[8],
+                     const unsigned short* cur, unsigned short* nxt) {
         constexpr int ROLE = decltype(role_c)::value, NKYL = ROLE == 2 ? 1 : 2;
+        int ez_n = ez_run, ex_n = ex_run;
+        float sc = 1.f;
+        if constexpr (H16) {
+            next_exponents((t + 1) & 1, ez_n, ex_n);
+            sc = f16_scale_of(ROLE == 0 ? ez_n : ex_n);
+            issue_loads(role_c, 0, min(t + 3, NT - 1), t + 3 < NT, rl0);
+            if (ROLE == 2) issue_loads(role_c, 1, min(t + 3, NT - 1), t + 3 < NT, rl1);
+        }
         const unsigned short* dZs = cur;
         const unsigned short* Xs = cur + XS0;
-        i32x4 xraw[2][3][2];                                        // [region parity][piece][cur | next]
+        i32x4 xraw[2][NP][2];                                       // [region parity][piece][cur | next]
         auto read_x = [&](int ks, int kyl, int par) {
             const int r = 2 * (2 * ks + (kg >> 1)) + ky0 + kyl;     // input row of this lane's 8 pixels through tap row ky
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NP; ++q) {
                 const unsigned short* g0 = Xs + l16 * XP + q * XQ + r * XROW + (kg & 1) * 8;
                 xraw[par][q][0] = *reinterpret_cast<const i32x4*>(g0);
                 xraw[par][q][1] = *reinterpret_cast<const i32x4*>(g0 + 8);
@@ -4458,12 +4493,12 @@ __global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_
         int region = 0;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {                           // K-step = 32 output pixels = tile rows 2 ks, 2 ks + 1
-            bf16x8 zf[4][3];
+            frag_t zf[4][NP];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    zf[a][q] = *reinterpret_cast<const bf16x8*>(dZs + (a * 16 + l16) * ZP + q * PIX + ks * 32 + kg * 8);
+                for (int q = 0; q < NP; ++q)
+                    zf[a][q] = *reinterpret_cast<const frag_t*>(dZs + (a * 16 + l16) * ZP + q * PIX + ks * 32 + kg * 8);
 #pragma unroll
             for (int kyl = 0; kyl < NKYL; ++kyl, ++region) {
                 const int par = region & 1;
@@ -4475,20 +4510,20 @@ __global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_
                 if (ROLE == 2) {
                     if (region == 0) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) store_big(role_c, 1, r1, e, nxt);      // (second task first: see store_big)
+                        for (int e = 0; e < 4; ++e) store_big(role_c, 1, r1, e, nxt, sc);      // (second task first: see store_big)
                     } else {
-                        issue_loads(role_c, 1, min(t + 2, NT - 1), t + 2 < NT, r1);
+                        if constexpr (!H16) issue_loads(role_c, 1, min(t + 2, NT - 1), t + 2 < NT, r1);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) store_big(role_c, 0, r0, e, nxt);
+                        for (int e = 0; e < 4; ++e) store_big(role_c, 0, r0, e, nxt, sc);
                     }
                 } else {
-                    if (region == 0) { store_big(role_c, 0, r0, 0, nxt); store_big(role_c, 0, r0, 1, nxt); }
-                    if (region == 1) { store_big(role_c, 0, r0, 2, nxt); store_big(role_c, 0, r0, 3, nxt); }
-                    if (region == 2) issue_loads(role_c, 0, min(t + 2, NT - 1), t + 2 < NT, r0);
+                    if (region == 0) { store_big(role_c, 0, r0, 0, nxt, sc); store_big(role_c, 0, r0, 1, nxt, sc); }
+                    if (region == 1) { store_big(role_c, 0, r0, 2, nxt, sc); store_big(role_c, 0, r0, 3, nxt, sc); }
+                    if constexpr (!H16) { if (region == 2) issue_loads(role_c, 0, min(t + 2, NT - 1), t + 2 < NT, r0); }
                 }
-                bf16x8 xf[KW][3];
+                frag_t xf[KW][NP];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NP; ++q) {
                     const i32x4 cur4 = xraw[par][q][0], next = xraw[par][q][1];
                     i32x4 s1, s2, s3;
                     s2[0] = cur4[1]; s2[1] = cur4[2]; s2[2] = cur4[3]; s2[3] = next[0];
@@ -4499,31 +4534,78 @@ __global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_
                     s3[1] = (int)__builtin_amdgcn_alignbit((unsigned)cur4[3], (unsigned)cur4[2], 16);
                     s3[2] = (int)__builtin_amdgcn_alignbit((unsigned)next[0], (unsigned)cur4[3], 16);
                     s3[3] = (int)__builtin_amdgcn_alignbit((unsigned)next[1], (unsigned)next[0], 16);
-                    xf[0][q] = __builtin_bit_cast(bf16x8, cur4);
-                    xf[1][q] = __builtin_bit_cast(bf16x8, s1);
-                    xf[2][q] = __builtin_bit_cast(bf16x8, s2);
-                    xf[3][q] = __builtin_bit_cast(bf16x8, s3);
+                    xf[0][q] = __builtin_bit_cast(frag_t, cur4);
+                    xf[1][q] = __builtin_bit_cast(frag_t, s1);
+                    xf[2][q] = __builtin_bit_cast(frag_t, s2);
+                    xf[3][q] = __builtin_bit_cast(frag_t, s3);
                 }
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
-                    for (int ord = 2; ord >= 0; --ord)
+                    for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
                         for (int qa = 0; qa <= ord; ++qa)
 #pragma unroll
-                            for (int a = 0; a < 4; ++a)
-                                acc[a][kyl][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[a][qa], xf[kx][ord - qa], acc[a][kyl][kx], 0, 0, 0);
-                // 96 MFMAs of 16 cycles: two of them, then up to three of the staging's vector / LDS-store instructions
+                            for (int a = 0; a < 4; ++a) {
+                                if constexpr (H16) acc[a][kyl][kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zf[a][qa], xf[kx][ord - qa], acc[a][kyl][kx], 0, 0, 0);
+                                else acc[a][kyl][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[a][qa], xf[kx][ord - qa], acc[a][kyl][kx], 0, 0, 0);
+                            }
+                // 96 (48) MFMAs of 16 cycles: two of them, then up to three (six) of the staging's vector / LDS-store instructions
 #pragma unroll
-                for (int i = 0; i < 48; ++i) {
+                for (int i = 0; i < (H16 ? 24 : 48); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x202, ROLE == 2 ? 5 : 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x202, (ROLE == 2 ? 5 : 3) * (H16 ? 2 : 1), 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (ROLE == 2) issue_loads(role_c, 0, min(t + 2, NT - 1), t + 2 < NT, r0);
+        if constexpr (!H16) { if (ROLE == 2) issue_loads(role_c, 0, min(t + 2, NT - 1), t + 2 < NT, r0); }
+        if constexpr (H16) {
+            if (t + 2 < NT) publish(role_c, rp0, rp1, t & 1);      // tile t + 2 (parity t: read at this phase's start by every wave)
+            if (ez_n + ex_n != ez_run + ex_run) {                   // the next tile was staged at a larger scale: re-base the sums (exact)
+                const float rb = f16_rebase(ez_run + ex_run, ez_n + ex_n);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                        for (int x = 0; x < KW; ++x) acc[a][b2][x] *= rb;
+            }
+            ez_run = ez_n; ex_run = ex_n;
+        }
         __syncthreads();                                            // `cur` is read, `nxt` is written
+    };
+    auto run_h = [&](auto role_c) {                                 // ARITH 16: tile t lives in register sets (a[t % 3], b[t % 3])
+        constexpr int ROLE = decltype(role_c)::value;
+        f32x4 a0[8], a1[8], a2[8], b0[8], b1[8], b2[8];
+        auto buf_of = [&](int par) { return lds16 + (par & 1) * BUF; };
+        issue_loads(role_c, 0, 0, true, a0);
+        if (ROLE == 2) issue_loads(role_c, 1, 0, true, b0);
+        issue_loads(role_c, 0, min(1, NT - 1), 1 < NT, a1);
+        if (ROLE == 2) issue_loads(role_c, 1, min(1, NT - 1), 1 < NT, b1);
+        issue_loads(role_c, 0, min(2, NT - 1), 2 < NT, a2);
+        if (ROLE == 2) issue_loads(role_c, 1, min(2, NT - 1), 2 < NT, b2);
+        publish(role_c, a0, b0, 0);
+        publish(role_c, a1, b1, 1);
+        __syncthreads();
+        {
+            int ez_n, ex_n;
+            next_exponents(0, ez_n, ex_n);
+            ez_run = ez_n; ex_run = ex_n;
+            const float sc = f16_scale_of(ROLE == 0 ? ez_n : ex_n);
+            if (ROLE == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) store_big(role_c, 1, b0, e, lds16, sc);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_big(role_c, 0, a0, e, lds16, sc);
+        }
+        __syncthreads();
+        for (int t = 0; t < NT; t += 3) {
+            phase(role_c, t, a1, b1, a2, b2, a0, b0, buf_of(t), buf_of(t + 1));
+            if (t + 1 < NT) phase(role_c, t + 1, a2, b2, a0, b0, a1, b1, buf_of(t + 1), buf_of(t));
+            if (t + 2 < NT) phase(role_c, t + 2, a0, b0, a1, b1, a2, b2, buf_of(t), buf_of(t + 1));
+        }
     };
     auto run = [&](auto role_c) {
         constexpr int ROLE = decltype(role_c)::value;
@@ -4542,14 +4624,29 @@ __global__ __launch_bounds__(256) void wgrad_stem74d_kernel(WgradP p, int tiles_
         if (ROLE == 2) issue_loads(role_c, 1, min(1, NT - 1), 1 < NT, r1);
         __syncthreads();
         for (int t = 0; t < NT; t += 2) {
-            phase(role_c, t, r0, r1, buf0, buf1);
-            if (t + 1 < NT) phase(role_c, t + 1, r0, r1, buf1, buf0);
+            phase(role_c, t, r0, r1, r0, r1, r0, r1, buf0, buf1);
+            if (t + 1 < NT) phase(role_c, t + 1, r0, r1, r0, r1, r0, r1, buf1, buf0);
         }
     };
     if (NT > 0) {
-        if (wave < 2) run(std::integral_constant<int, 0>{});
-        else if (wave == 2) run(std::integral_constant<int, 1>{});
-        else run(std::integral_constant<int, 2>{});
+        if constexpr (H16) {
+            if (wave < 2) run_h(std::integral_constant<int, 0>{});
+            else if (wave == 2) run_h(std::integral_constant<int, 1>{});
+            else run_h(std::integral_constant<int, 2>{});
+        } else {
+            if (wave < 2) run(std::integral_constant<int, 0>{});
+            else if (wave == 2) run(std::integral_constant<int, 1>{});
+            else run(std::integral_constant<int, 2>{});
+        }
+    }
+    if constexpr (H16) {                                            // back to the operands' units (exact)
+        const float inv = f16_inv_scale_of(ez_run) * f16_inv_scale_of(ex_run);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int x = 0; x < KW; ++x) acc[a][b2][x] *= inv;
     }
     // partial slab [blk][co][tap][ci]; C layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + reg
     float* dst = part + (size_t)blk * p.Co * (KH * KW) * p.Ct;
@@ -6376,9 +6473,12 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
                 g_last_kernel = "wgrad_stem74s_kernel";
                 static const int stem_dbuf = getenv("CODEPS_STEM_DBUF") ? atoi(getenv("CODEPS_STEM_DBUF")) : 1;        // tuning experiments only
                 if (stem_dbuf && p.fast && d->pad_w == 0 && d->in_h == 2 * d->out_h) {          // whole tiles, rows padded by the range check
-                    constexpr size_t lds = (size_t)2 * (64 * (3 * 64 + 8) + 16 * 3 * 13 * 24) * 2;
-                    codeps_allow_lds((const void*)wgrad_stem74d_kernel, 160 * 1024, "wgrad_stem74d_kernel");
-                    hipLaunchKernelGGL(wgrad_stem74d_kernel, dim3(g), dim3(256), lds, st, p, sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, dz, part);
+                    const bool h16 = f16_pairs();
+                    const size_t lds = h16 ? (size_t)2 * (64 * (2 * 64 + 8) + 16 * (2 * 13 * 24 + 8)) * 2 + 32 : (size_t)2 * (64 * (3 * 64 + 8) + 16 * 3 * 13 * 24) * 2;
+                    auto kst = h16 ? wgrad_stem74d_kernel<16> : wgrad_stem74d_kernel<3>;
+                    if (h16) g_last_kernel = "wgrad_stem74s_kernel<f16x2>";
+                    codeps_allow_lds((const void*)kst, 160 * 1024, "wgrad_stem74d_kernel");
+                    hipLaunchKernelGGL(kst, dim3(g), dim3(256), lds, st, p, sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, dz, part);
                 } else
                 hipLaunchKernelGGL(wgrad_stem74s_kernel, dim3(g), dim3(256), 0, st, p, sp.tiles_x, sp.tiles_y, sp.tiles_per_block, x0, dz, part);
             } else                                       // double-pixel stem: 7 x 4 taps of 16 (2 pixels x 8 channels), stride (2, 1)
