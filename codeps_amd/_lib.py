@@ -97,6 +97,8 @@ SIGNATURES = {
     "codeps_chain1x1_expand_reduce": (c_int, [P, P, P, P, P, P, LL, I, P, P, P, c_size_t, P]),
     "codeps_chain1x1_w2_row_bytes_h": (c_size_t, []),
     "codeps_chain1x1_expand_reduce_h": (c_int, [P, P, P, P, P, P, LL, I, P, P, P, c_size_t, P]),
+    "codeps_chain1x1_workspace_bytes_k": (c_size_t, [LL, I, I]),
+    "codeps_chain1x1_expand_reduce_hk": (c_int, [P, P, P, P, P, P, LL, I, I, P, P, P, c_size_t, P]),
     "codeps_nchw_to_nhwc": (c_int, [P, I, I, I, I, P, I, I, I, P]),
     "codeps_nchw_to_nhwc_xpad": (c_int, [P, I, I, I, I, P, I, I, I, I, I, P]),
     "codeps_frames_to_nhwc": (c_int, [P, P, P, I, I, I, I, P, I, I, I, P]),

@@ -308,9 +308,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_kernel(ChainP p) {
 // the prologue, the expand's output per stage (running maximum; when it grows the lane's 64 reduce sums are multiplied by the exact ratio).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int ROWH = 144;                 // bytes per LDS row: [piece][32 fp16] + 16 pad
-constexpr int TILE_H = 256 * ROWH;
-constexpr int W2ROWH = KMID * 4 + 16;     // bytes per expand-weight row in HBM: 8 groups x [2 pieces][32 fp16] + (scale 2^-kb, shift, 0, 0)
-constexpr int NDMAH = 9;                  // 4 loader waves x 9 x 64 lanes x 16 B = 256 x 144 B
+constexpr int W2ROWH = KMID * 4 + 16;     // bytes per expand-weight row in HBM at mid width 256: 8 groups x [2 pieces][32 fp16] + (scale 2^-kb, shift, 0, 0)
 constexpr int H_TARGET = 14, H_EMIN = 27; // |x 2^k| < 2^15; magnitudes below 2^-100 count as 2^-100 (conv.hip: F16_TARGET, F16_EMIN)
 
 __device__ __forceinline__ float h_scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(254 + H_TARGET - e) << 23); }
@@ -337,7 +335,14 @@ __device__ __forceinline__ void split8h(const f32x4 lo4, const f32x4 hi4, const 
     for (int e = 0; e < 8; ++e) { f[0][e] = h[e]; f[1][e] = l[e]; }
 }
 
-__global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
+// KM = the bottleneck's mid width: 256 (layer3), 128 (layer2), 64 (layer1) -- the tile image is KM rows x 144 bytes for both GEMMs (expand: KM / 32
+// k-steps x 32 rows; reduce: KM output rows x 32 k), a pixel's y1 row is KM / 32 fragment pairs, the reduce keeps KM / 16 accumulator tiles.
+template <int KM>
+__global__ __launch_bounds__(512, KM == 256 ? 2 : 4) void chain_expand_reduce_h_kernel(ChainP p) {
+    constexpr int KS = KM / 32, JT = KM / 16;
+    constexpr int TILE = KM * ROWH, W2R = KM * 4 + 16;
+    constexpr int BINS = KM * 9 / 64, ND = (BINS + 3) / 4;       // DMA instructions per tile / per loader wave (waves past the last one repeat their previous instruction)
+    static_assert((KM * 9) % 64 == 0 && KM % 32 == 0, "tile image: whole 1 KiB DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     CODEPS_STAMP_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
@@ -355,44 +360,54 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
         r[3] = 0x00020000;
         return r;
     };
-    const i32x4 rsW2 = rsrc_of(p.w2, (size_t)p.N2 * W2ROWH);
-    const i32x4 rsW3 = rsrc_of(p.w3, (size_t)KMID * p.N2 * 4);
+    const i32x4 rsW2 = rsrc_of(p.w2, (size_t)p.N2 * W2R);
+    const i32x4 rsW3 = rsrc_of(p.w3, (size_t)KM * p.N2 * 4);
     const i32x4 rsRes = rsrc_of(p.res + (size_t)m0 * p.N2, (size_t)BPIX * p.N2 * 4);
     const i32x4 rsOut = rsrc_of(p.out + (size_t)m0 * p.N2, (size_t)BPIX * p.N2 * 4);
     const unsigned row_off = (unsigned)((wave * 16 + l16) * p.N2 + 4 * kg) * 4u;
 
-    // DMA roles as in chain_expand_reduce_kernel; a tile row is 9 segments of 16 bytes (8 data + pad)
-    unsigned offE[NDMAH], offR[NDMAH], ldsdst[NDMAH];
-#pragma unroll
-    for (int i = 0; i < NDMAH; ++i) {
-        const int ins = (wave & 3) + 4 * i, L = ins * 64 + lane, prow = L / 9, seg = L % 9;
-        ldsdst[i] = (unsigned)ins * 1024u;
+    // DMA roles as in chain_expand_reduce_kernel; a tile row is 9 segments of 16 bytes (8 data + pad).  At mid width 256 the per-lane source
+    // offsets live in registers; the narrower forms (two blocks per CU: 128 registers) recompute them per tile -- a dozen integer operations
+    // beside a tile's worth of matrix work.
+    constexpr bool KEEP = KM == 256;
+    auto off_of = [&](const int i, const int ln, const bool reduce) {
+        const int ins = (wave & 3) + 4 * i < BINS ? (wave & 3) + 4 * i : (wave & 3) + 4 * (i - 1), L = ins * 64 + ln, prow = L / 9, seg = L % 9;
         const int ks = prow >> 5, r = prow & 31;
         const int swz = ((prow >> 2) ^ (prow >> 3)) & 1;       // odd slot pitch: k groups of rows 4 .. 11 (mod 16) swapped pairwise
-        offE[i] = (unsigned)(r * W2ROWH + (seg < 8 ? ks * 128 + (seg ^ swz) * 16 : KMID * 4));
-        offR[i] = (unsigned)((size_t)prow * p.N2 * 4 + (seg < 8 ? (seg ^ swz) : 0) * 16);
+        return reduce ? (unsigned)((size_t)prow * p.N2 * 4 + (seg < 8 ? (seg ^ swz) : 0) * 16)
+                      : (unsigned)(r * W2R + (seg < 8 ? ks * 128 + (seg ^ swz) * 16 : KM * 4));
+    };
+    auto dst_of = [&](const int i) { return (unsigned)((wave & 3) + 4 * i < BINS ? (wave & 3) + 4 * i : (wave & 3) + 4 * (i - 1)) * 1024u; };
+    unsigned offE[KEEP ? ND : 1], offR[KEEP ? ND : 1];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { offE[i] = off_of(i, lane, false); offR[i] = off_of(i, lane, true); }
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const bool loader = wave >= 4;
     auto dma_tile = [&](int t) {
         if (!loader) return;
         const int s = sbase + (t >> 1);
-        const unsigned slot = lds_base + (unsigned)(t % 3) * TILE_H;
+        const unsigned slot = lds_base + (unsigned)(t % 3) * TILE;
+        int ln = lane;
+        if constexpr (!KEEP) asm volatile("" : "+v"(ln));      // (keeps the offsets out of the loop-invariant set)
         if (t & 1) {
             const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 128);
 #pragma unroll
-            for (int i = 0; i < NDMAH; ++i) {
-                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + ldsdst[i]);
+            for (int i = 0; i < ND; ++i) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + dst_of(i));
+                const unsigned off = KEEP ? offR[KEEP ? i : 0] : off_of(i, ln, true);
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(offR[i]), "s"(rsW3), "s"(soff) : "memory");
+                             :: "s"(dst), "v"(off), "s"(rsW3), "s"(soff) : "memory");
             }
         } else {
-            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 32 * W2ROWH);
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s * 32 * W2R);
 #pragma unroll
-            for (int i = 0; i < NDMAH; ++i) {
-                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + ldsdst[i]);
+            for (int i = 0; i < ND; ++i) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(slot + dst_of(i));
+                const unsigned off = KEEP ? offE[KEEP ? i : 0] : off_of(i, ln, false);
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(offE[i]), "s"(rsW2), "s"(soff) : "memory");
+                             :: "s"(dst), "v"(off), "s"(rsW2), "s"(soff) : "memory");
             }
         }
     };
@@ -412,14 +427,14 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
     dma_tile(0);
     dma_tile(1);
     if (NS > 1) dma_tile(2);
-    f16x8 yf[8][2];
+    f16x8 yf[KS][2];
     float inv_y;
     {
-        const float* yrow = p.y1 + (size_t)m * KMID + kg * 8;
-        f32x4 ylo[8], yhi[8];
+        const float* yrow = p.y1 + (size_t)m * KM + kg * 8;
+        f32x4 ylo[KS], yhi[KS];
         float ym = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             ylo[ks] = *reinterpret_cast<const f32x4*>(yrow + ks * 32); yhi[ks] = *reinterpret_cast<const f32x4*>(yrow + ks * 32 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) ym = fmaxf(ym, fmaxf(fabsf(ylo[ks][e]), fabsf(yhi[ks][e])));
@@ -428,14 +443,14 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
         const float sy = h_scale_of(ey);
         inv_y = h_inv_scale_of(ey);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) split8h(ylo[ks], yhi[ks], sy, yf[ks]);
+        for (int ks = 0; ks < KS; ++ks) split8h(ylo[ks], yhi[ks], sy, yf[ks]);
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rA[0]), "+v"(rA[1]) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
-    f32x4 acc3[16];
+    f32x4 acc3[JT];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JT; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int e_run = H_EMIN;                                        // largest exponent of this pixel's expand outputs so far
 
     const char* arow = lds + l16 * ROWH + (kg ^ (((l16 >> 2) ^ (l16 >> 3)) & 1)) * 16;
@@ -443,17 +458,17 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
     auto stage = [&](const int s, f32x4 (&rcur)[2], f32x4 (&rnext)[2]) {
         const bool last = s + 1 == NS;
         // vector-memory queue as in chain_expand_reduce_kernel with 9 DMA instructions per tile: 9 + 2 younger operations here ...
-        if (s > 0) { if (loader) CHAIN_WAIT(11); else CHAIN_WAIT(2); }
+        if (s > 0) { if (loader) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND + 2) : "memory"); else CHAIN_WAIT(2); }
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+v"(rcur[0]), "+v"(rcur[1]));
         res_load(s + 1, rnext);
         if (s > 0 && 2 * s + 2 < 2 * NS) dma_tile(2 * s + 2);
-        const char* et = arow + ((2 * s) % 3) * TILE_H;
+        const char* et = arow + ((2 * s) % 3) * TILE;
         CODEPS_STAMP_PHASE_START();
         f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const char* a = et + (ks * 32 + nt * 16) * ROWH;
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float* aff = reinterpret_cast<const float*>(lds + ((2 * s) % 3) * TILE_H + (nt * 16 + 4 * kg + r) * ROWH + 128);
+                const float* aff = reinterpret_cast<const float*>(lds + ((2 * s) % 3) * TILE + (nt * 16 + 4 * kg + r) * ROWH + 128);
                 v[nt][r] = acc2[nt][r] * (aff[0] * inv_y) + aff[1];          // aff[0] = scale2 2^-kb (host), inv_y = the pixel's 2^-ky
             }
         float vm = 0.f;
@@ -489,19 +504,19 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
             const int d = e_run - e_new;
             const float rb = d < -126 ? 0.f : __builtin_bit_cast(float, (unsigned)(127 + d) << 23);
 #pragma unroll
-            for (int jt = 0; jt < 16; ++jt) acc3[jt] *= rb;
+            for (int jt = 0; jt < JT; ++jt) acc3[jt] *= rb;
             e_run = e_new;
         }
         f16x8 of[2];                                           // B fragment of reduce k-step s: element j = channel 16 (j >> 2) + 4 kg + (j & 3)
         split8h(v[0], v[1], h_scale_of(e_run), of);
         // ... and 2 + 9 + 2 here
-        if (loader) { if (last) CHAIN_WAIT(0); else CHAIN_WAIT(13); }
+        if (loader) { if (last) CHAIN_WAIT(0); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND + 4) : "memory"); }
         __syncthreads();
         if (2 * s + 3 < 2 * NS) dma_tile(2 * s + 3);
-        const char* rt = arow + ((2 * s + 1) % 3) * TILE_H;
+        const char* rt = arow + ((2 * s + 1) % 3) * TILE;
         CODEPS_STAMP_PHASE_START();
 #pragma unroll
-        for (int jt = 0; jt < 16; ++jt) {
+        for (int jt = 0; jt < JT; ++jt) {
             const char* a = rt + jt * 16 * ROWH;
             f16x8 wf[2];
 #pragma unroll
@@ -520,15 +535,15 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
 
     const float inv_o = h_inv_scale_of(e_run);                 // (scale3 carries the reduce weights' 2^-kb: host)
     if (p.ksplit > 1) {
-        float* po = p.part + ((size_t)blockIdx.y * p.M + m) * KMID + 4 * kg;
+        float* po = p.part + ((size_t)blockIdx.y * p.M + m) * KM + 4 * kg;
 #pragma unroll
-        for (int jt = 0; jt < 16; ++jt) *reinterpret_cast<f32x4*>(po + jt * 16) = acc3[jt] * inv_o;
+        for (int jt = 0; jt < JT; ++jt) *reinterpret_cast<f32x4*>(po + jt * 16) = acc3[jt] * inv_o;
         CODEPS_STAMP_END(chain);
         return;
     }
-    float* yo = p.y0n + (size_t)m * KMID + 4 * kg;
+    float* yo = p.y0n + (size_t)m * KM + 4 * kg;
 #pragma unroll
-    for (int jt = 0; jt < 16; ++jt) {
+    for (int jt = 0; jt < JT; ++jt) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale3 + jt * 16 + 4 * kg), sh = *reinterpret_cast<const f32x4*>(p.shift3 + jt * 16 + 4 * kg);
         f32x4 o = (acc3[jt] * inv_o) * sc + sh;
 #pragma unroll
@@ -539,12 +554,12 @@ __global__ __launch_bounds__(512) void chain_expand_reduce_h_kernel(ChainP p) {
 }
 
 // y0n = relu((sum_z part[z]) * scale3 + shift3), slices added in fixed order
-__global__ __launch_bounds__(256) void chain_finish_kernel(const float* __restrict__ part, int ksplit, long long MN, const float* __restrict__ scale3,
+__global__ __launch_bounds__(256) void chain_finish_kernel(const float* __restrict__ part, int ksplit, long long MN, int kmid, const float* __restrict__ scale3,
                                                            const float* __restrict__ shift3, float* __restrict__ y0n) {
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (long long)gridDim.x * 1024) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
         for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + (size_t)z * MN + i);
-        const int c = (int)(i % KMID);
+        const int c = (int)(i % kmid);
         v = v * *reinterpret_cast<const f32x4*>(scale3 + c) + *reinterpret_cast<const f32x4*>(shift3 + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
@@ -573,33 +588,35 @@ extern "C" size_t codeps_chain1x1_workspace_bytes(long long rows, int n2) {
     return ks > 1 ? (size_t)ks * rows * KMID * sizeof(float) : 0;
 }
 
-static int chain_launch(bool h16, const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
+static int chain_launch(bool h16, int kmid, const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
                         const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
                         void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     CODEPS_REQUIRE(y1 && residual && w2_rows && w3_split && scale3 && shift3 && out && y0_next, CODEPS_ERR_ARG, "chain1x1: null pointer argument");
     CODEPS_REQUIRE(rows > 0 && rows % BPIX == 0 && rows / BPIX < (1ll << 31), CODEPS_ERR_ARG, "chain1x1: rows (%lld) must be a positive multiple of %d", rows, BPIX);
     CODEPS_REQUIRE(n2 >= 64 && n2 % 64 == 0 && n2 <= 4096, CODEPS_ERR_ARG, "chain1x1: expand channels (%d) must be a multiple of 64 in [64, 4096]", n2);
+    CODEPS_REQUIRE(kmid == 256 || (h16 && (kmid == 128 || kmid == 64)), CODEPS_ERR_ARG, "chain1x1: mid width %d (256; 128 and 64 on the fp16-pair form only)", kmid);
     ChainP p;
     p.M = rows; p.N2 = n2; p.y1 = y1; p.res = residual; p.w2 = w2_rows; p.w3 = w3_split; p.scale3 = scale3; p.shift3 = shift3;
     p.out = out; p.y0n = y0_next;
     p.ksplit = chain_slices(rows, n2);
     p.part = nullptr;
     if (p.ksplit > 1) {
-        CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)p.ksplit * rows * KMID * sizeof(float), CODEPS_ERR_WORKSPACE,
+        CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)p.ksplit * rows * kmid * sizeof(float), CODEPS_ERR_WORKSPACE,
                        "chain1x1: workspace too small (codeps_chain1x1_workspace_bytes)");
         p.part = static_cast<float*>(workspace);
     }
     hipStream_t st = (hipStream_t)stream;
     if (h16) {
-        codeps_allow_lds((const void*)chain_expand_reduce_h_kernel, 160 * 1024, "chain_expand_reduce_h_kernel");
-        hipLaunchKernelGGL(chain_expand_reduce_h_kernel, dim3((unsigned)(rows / BPIX), p.ksplit), dim3(64 * NWAVE), 3 * TILE_H, st, p);
+        auto kh = kmid == 256 ? chain_expand_reduce_h_kernel<256> : (kmid == 128 ? chain_expand_reduce_h_kernel<128> : chain_expand_reduce_h_kernel<64>);
+        codeps_allow_lds((const void*)kh, 160 * 1024, "chain_expand_reduce_h_kernel");
+        hipLaunchKernelGGL(kh, dim3((unsigned)(rows / BPIX), p.ksplit), dim3(64 * NWAVE), (size_t)3 * kmid * ROWH, st, p);
     } else {
         codeps_allow_lds((const void*)chain_expand_reduce_kernel, 160 * 1024, "chain_expand_reduce_kernel");
         hipLaunchKernelGGL(chain_expand_reduce_kernel, dim3((unsigned)(rows / BPIX), p.ksplit), dim3(64 * NWAVE), 3 * TILE_B, st, p);
     }
     if (p.ksplit > 1) {
-        const long long MN = rows * KMID;
-        hipLaunchKernelGGL(chain_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, (const float*)p.part, p.ksplit, MN,
+        const long long MN = rows * kmid;
+        hipLaunchKernelGGL(chain_finish_kernel, dim3((int)std::min<long long>((MN / 4 + 255) / 256, 2048)), dim3(256), 0, st, (const float*)p.part, p.ksplit, MN, kmid,
                            scale3, shift3, y0_next);
     }
     CODEPS_CHECK_LAUNCH("chain_expand_reduce_kernel");
@@ -609,7 +626,7 @@ static int chain_launch(bool h16, const float* y1, const float* residual, const 
 extern "C" int codeps_chain1x1_expand_reduce(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
                                              const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
                                              void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
-    return chain_launch(false, y1, residual, w2_rows, w3_split, scale3, shift3, rows, n2, out, y0_next, workspace, workspace_bytes, stream);
+    return chain_launch(false, KMID, y1, residual, w2_rows, w3_split, scale3, shift3, rows, n2, out, y0_next, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t codeps_chain1x1_w2_row_bytes_h(void) { return W2ROWH; }
@@ -617,5 +634,18 @@ extern "C" size_t codeps_chain1x1_w2_row_bytes_h(void) { return W2ROWH; }
 extern "C" int codeps_chain1x1_expand_reduce_h(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
                                                const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
                                                void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
-    return chain_launch(true, y1, residual, w2_rows, w3_split, scale3, shift3, rows, n2, out, y0_next, workspace, workspace_bytes, stream);
+    return chain_launch(true, KMID, y1, residual, w2_rows, w3_split, scale3, shift3, rows, n2, out, y0_next, workspace, workspace_bytes, stream);
+}
+
+// ... at the mid widths of the other stages (fp16-pair form only): kmid = 256 (layer3), 128 (layer2), 64 (layer1).  y1 [rows][kmid], w2 rows of
+// kmid * 4 + 16 bytes, w3 [kmid][n2 / 32][2][32] fp16, scale3 / shift3 [kmid], y0_next [rows][kmid]; workspace: codeps_chain1x1_workspace_bytes_k.
+extern "C" size_t codeps_chain1x1_workspace_bytes_k(long long rows, int n2, int kmid) {
+    if (rows <= 0 || rows % BPIX || n2 < 64 || n2 % 64 || (kmid != 256 && kmid != 128 && kmid != 64)) return 0;
+    const int ks = chain_slices(rows, n2);
+    return ks > 1 ? (size_t)ks * rows * kmid * sizeof(float) : 0;
+}
+extern "C" int codeps_chain1x1_expand_reduce_hk(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
+                                                const float* scale3, const float* shift3, long long rows, int n2, int kmid, float* out, float* y0_next,
+                                                void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
+    return chain_launch(true, kmid, y1, residual, w2_rows, w3_split, scale3, shift3, rows, n2, out, y0_next, workspace, workspace_bytes, stream);
 }

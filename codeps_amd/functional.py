@@ -1002,8 +1002,10 @@ def chain_weights(w_expand, scale2, shift2, w_reduce, scale3=None):
         return (hit[1], hit[2], hit[7]) if h16 else (hit[1], hit[2])
     n2, kmid = w_expand.shape[:2]
     c3 = w_reduce.shape[0]
-    if kmid != 256 or c3 != 256 or w_reduce.shape[1] != n2 or n2 % 64 or tuple(w_expand.shape[2:]) != (1, 1) or tuple(w_reduce.shape[2:]) != (1, 1):
-        raise CodepsHipError("chain_weights: expects 1x1 weights [N2, 256, 1, 1] and [256, N2, 1, 1] with N2 % 64 == 0")
+    if (kmid not in ((256, 128, 64) if h16 else (256,)) or c3 != kmid or w_reduce.shape[1] != n2 or n2 % 64 or tuple(w_expand.shape[2:]) != (1, 1)
+            or tuple(w_reduce.shape[2:]) != (1, 1)):
+        raise CodepsHipError("chain_weights: expects 1x1 weights [N2, K, 1, 1] and [K, N2, 1, 1] with N2 % 64 == 0 and K = 256 "
+                             "(128 and 64 as well on the fp16-pair arithmetic)")
     dev = w_expand.device
     with torch.no_grad():
         wf, _ = pack_weights(w_expand, n2, kmid, False)
@@ -1012,7 +1014,7 @@ def chain_weights(w_expand, scale2, shift2, w_reduce, scale3=None):
         aff[:, 0], aff[:, 1] = _f32c(scale2.detach()), _f32c(shift2.detach())
         if h16:
             aff[:, 0] *= slot2[0]                                 # 2^-kb of the expand pack (a device scalar: no sync)
-        rowb = lib().codeps_chain1x1_w2_row_bytes_h() if h16 else lib().codeps_chain1x1_w2_row_bytes()
+        rowb = kmid * 4 + 16 if h16 else lib().codeps_chain1x1_w2_row_bytes()
         split = s2h.view(n2, kmid * 4) if h16 else s3.view(n2, kmid * 6)
         w2 = torch.cat([split, aff.view(torch.uint8).view(n2, 16)], 1).contiguous()
         assert w2.shape[1] == rowb
@@ -1028,8 +1030,8 @@ def chain_weights(w_expand, scale2, shift2, w_reduce, scale3=None):
 def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3, shift3):
     """Inference-only fusion of two frozen 1x1 layers of consecutive ResNet bottlenecks (models/resnet_encoder.py:115-126):
         out = relu(bn3(conv3(y1)) + residual)            [B,H,W,N2]
-        y0  = relu(bn1'(conv1'(out)))                    [B,H,W,256]    (the next bottleneck's first layer)
-    in ONE launch (C ABI: codeps_chain1x1_expand_reduce); the BatchNorms arrive folded as (scale, shift)."""
+        y0  = relu(bn1'(conv1'(out)))                    [B,H,W,K]      (the next bottleneck's first layer; K = y1's width)
+    in ONE launch (C ABI: codeps_chain1x1_expand_reduce / _hk); the BatchNorms arrive folded as (scale, shift)."""
     require_cuda(y1, residual, w_expand, w_reduce)
     if torch.is_grad_enabled() and (y1.requires_grad or residual.requires_grad or w_expand.requires_grad or w_reduce.requires_grad):
         raise CodepsHipError("chain_expand_reduce is an inference kernel (frozen encoder): no autograd support")
@@ -1044,23 +1046,31 @@ def chain_expand_reduce(y1, residual, w_expand, scale2, shift2, w_reduce, scale3
         sc3 = _f32c(scale3)
     y1, residual = y1.contiguous(), residual.contiguous()
     out = torch.empty(b, h, w_, n2, dtype=torch.float32, device=y1.device)
-    y0 = torch.empty(b, h, w_, 256, dtype=torch.float32, device=y1.device)
-    flops = 2.0 * rows * (n2 * kmid + 256 * n2)
+    y0 = torch.empty(b, h, w_, kmid, dtype=torch.float32, device=y1.device)
+    flops = 2.0 * rows * (n2 * kmid + kmid * n2)
     t0 = _prof_begin()
-    wsb = lib().codeps_chain1x1_workspace_bytes(rows, n2)
+    wsb = lib().codeps_chain1x1_workspace_bytes_k(rows, n2, kmid)
     ws = _workspace(wsb, y1.device, "chain1x1") if wsb else None
-    fn = lib().codeps_chain1x1_expand_reduce_h if h16 else lib().codeps_chain1x1_expand_reduce
-    check(fn(ptr(y1), ptr(residual), ptr(w2), ptr(w3), ptr(sc3), ptr(_f32c(shift3)), rows, n2,
-             ptr(out), ptr(y0), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()),
-          "codeps_chain1x1_expand_reduce")
-    _prof_end(t0, "conv_fwd_f16x2" if h16 else "conv_fwd_split", flops, tag=f"B{b} {h}x{w_} 256->{n2}->256 k1 chain",
-              kernel="chain_expand_reduce_h_kernel" if h16 else "chain_expand_reduce_kernel")
+    tail = (ptr(out), ptr(y0), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
+    head = (ptr(y1), ptr(residual), ptr(w2), ptr(w3), ptr(sc3), ptr(_f32c(shift3)), rows, n2)
+    if h16:
+        check(lib().codeps_chain1x1_expand_reduce_hk(*head, kmid, *tail), "codeps_chain1x1_expand_reduce_hk")
+    else:
+        check(lib().codeps_chain1x1_expand_reduce(*head, *tail), "codeps_chain1x1_expand_reduce")
+    _prof_end(t0, "conv_fwd_f16x2" if h16 else "conv_fwd_split", flops, tag=f"B{b} {h}x{w_} {kmid}->{n2}->{kmid} k1 chain",
+              kernel=f"chain_expand_reduce_h_kernel<{kmid}>" if h16 else "chain_expand_reduce_kernel")
     return out, y0
 
 
+_CHAIN_NARROW = os.environ.get("CODEPS_CHAIN_NARROW", "1") != "0"    # A/B switch: 0 = mid widths 128 / 64 as separate launches
+
+
 def chain_ok(y1, n2):
-    """Shapes the chained kernel takes: 256 mid channels, N2 % 64 == 0, pixel count a multiple of 128."""
-    return _CHAIN and y1.shape[-1] == 256 and n2 % 64 == 0 and (y1.numel() // 256) % 128 == 0
+    """Shapes the chained kernel takes: 256 mid channels (128 and 64 too on the fp16-pair arithmetic), N2 % 64 == 0, pixel count a
+    multiple of 128."""
+    k = y1.shape[-1]
+    return (_CHAIN and (k == 256 or (k in (128, 64) and _CHAIN_NARROW and _arith() == 16)) and n2 % 64 == 0
+            and (y1.numel() // k) % 128 == 0)
 
 
 # ---------------------------------------------------------------------------------------- BatchNorm

@@ -65,7 +65,7 @@ def _frozen_eval(*mods):
 
 def _run_layer(layer, x, sync, groups, own_input=False):
     """One ResNet stage.  Frozen bottlenecks in eval mode whose mid width is 256 (ResNet-50 / 101 layer3: 22 of the 101's 33
-    bottlenecks) hand their last layer to the NEXT bottleneck's first one inside one launch (F.chain_expand_reduce: conv3 + bn3
+    bottlenecks; 128 and 64 -- layer2, layer1 -- as well on the fp16-pair arithmetic) hand their last layer to the NEXT bottleneck's first one inside one launch (F.chain_expand_reduce: conv3 + bn3
     + residual + ReLU, then conv1' + bn1' + ReLU, the 1024-channel tensor passing from one product to the other in
     registers); every other block runs layer by layer.
     own_input: the stage is the only reader of x (the caller keeps no other use of the previous stage's map); between the blocks of a
@@ -84,7 +84,7 @@ def _run_layer(layer, x, sync, groups, own_input=False):
         identity = xa if blk.downsample is None else conv_bn(xa, blk.downsample[0], blk.downsample[1], sync=sync, groups=groups)
         y1 = conv_bn(y0, blk.conv2, blk.bn2, "relu", sync=sync, groups=groups, exclusive=True)
         y0 = None
-        if (nxt is not None and nxt.downsample is None and nxt.conv1.out_channels == 256 and blk.conv3.in_channels == 256
+        if (nxt is not None and nxt.downsample is None and nxt.conv1.out_channels == blk.conv3.in_channels
                 and F.chain_ok(y1, blk.conv3.out_channels) and _frozen_eval(blk.bn3, blk.conv3, nxt.bn1, nxt.conv1)
                 and not (torch.is_grad_enabled() and (y1.requires_grad or identity.requires_grad))):
             s2, t2 = folded_bn(blk.bn3)

@@ -206,6 +206,14 @@ size_t codeps_chain1x1_w2_row_bytes_h(void);
 int codeps_chain1x1_expand_reduce_h(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
                                   const float* scale3, const float* shift3, long long rows, int n2, float* out, float* y0_next,
                                   void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+/* ... at the mid widths of the other bottleneck stages (fp16-pair arithmetic only): kmid = 256 (ResNet-50/101 layer3), 128 (layer2), 64 (layer1).
+ * y1 / y0_next [rows][kmid]; w2_rows: n2 rows of kmid * 4 + 16 bytes; w3_split: fp16-pair pack of W3 [kmid][n2] (k-permuted as above);
+ * scale3 / shift3 [kmid].  codeps_chain1x1_workspace_bytes_k returns 0 for an unsupported shape as well as for "not needed": the launch
+ * validates the shape itself. */
+size_t codeps_chain1x1_workspace_bytes_k(long long rows, int n2, int kmid);
+int codeps_chain1x1_expand_reduce_hk(const float* y1, const float* residual, const void* w2_rows, const void* w3_split,
+                                     const float* scale3, const float* shift3, long long rows, int n2, int kmid, float* out, float* y0_next,
+                                     void* workspace, size_t workspace_bytes, codeps_stream_t stream);
 size_t codeps_conv2d_wgrad_workspace_bytes(const codeps_conv_desc* d);
 /* dw_oihw [out_c_real][in_c_real][kh][kw] (= or += when accumulate); split-K slabs + fixed-order reduce. */
 int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float* x1, const float* dz,

@@ -14,20 +14,20 @@ def _l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
 
 
-def _case(rows, n2, seed, kind="normal"):
+def _case(rows, n2, seed, kind="normal", k=256):
     g = torch.Generator().manual_seed(seed)
     if kind == "normal":
-        y1 = torch.relu(torch.randn(rows, 256, generator=g))
+        y1 = torch.relu(torch.randn(rows, k, generator=g))
         res = torch.relu(torch.randn(rows, n2, generator=g))
-        w2 = torch.randn(n2, 256, generator=g) * (2.0 / 256) ** 0.5
-        w3 = torch.randn(256, n2, generator=g) * (2.0 / n2) ** 0.5
+        w2 = torch.randn(n2, k, generator=g) * (2.0 / k) ** 0.5
+        w3 = torch.randn(k, n2, generator=g) * (2.0 / n2) ** 0.5
     else:                       # wide dynamic range
-        y1 = torch.randn(rows, 256, generator=g) * torch.exp2(torch.randint(-10, 11, (rows, 256), generator=g).float())
+        y1 = torch.randn(rows, k, generator=g) * torch.exp2(torch.randint(-10, 11, (rows, k), generator=g).float())
         res = torch.randn(rows, n2, generator=g) * torch.exp2(torch.randint(-6, 7, (rows, n2), generator=g).float())
-        w2 = torch.randn(n2, 256, generator=g) * torch.exp2(torch.randint(-6, 7, (n2, 256), generator=g).float()) / 16
-        w3 = torch.randn(256, n2, generator=g) * torch.exp2(torch.randint(-6, 7, (256, n2), generator=g).float()) / 32
+        w2 = torch.randn(n2, k, generator=g) * torch.exp2(torch.randint(-6, 7, (n2, k), generator=g).float()) / 16
+        w3 = torch.randn(k, n2, generator=g) * torch.exp2(torch.randint(-6, 7, (k, n2), generator=g).float()) / 32
     s2, t2 = 0.5 + torch.rand(n2, generator=g), 0.2 * torch.randn(n2, generator=g)
-    s3, t3 = 0.5 + torch.rand(256, generator=g), 0.2 * torch.randn(256, generator=g)
+    s3, t3 = 0.5 + torch.rand(k, generator=g), 0.2 * torch.randn(k, generator=g)
     return y1, res, w2, w3, s2, t2, s3, t3
 
 
@@ -38,23 +38,27 @@ def _ref(y1, res, w2, w3, s2, t2, s3, t3, dt):
 
 
 @pytest.mark.parametrize("kind", ["normal", "wide"])
-@pytest.mark.parametrize("rows,n2", [(128, 64), (256, 1024), (16384, 1024), (4096, 512), (8192, 1024), (1024, 256)])
-def test_chain_matches_float64_and_the_unfused_layers(rows, n2, kind):
+@pytest.mark.parametrize("rows,n2,k", [(128, 64, 256), (256, 1024, 256), (16384, 1024, 256), (4096, 512, 256), (8192, 1024, 256), (1024, 256, 256),
+                                       (128, 64, 64), (32768, 256, 64), (1024, 128, 64), (128, 64, 128), (16384, 512, 128), (4096, 1024, 128)])
+def test_chain_matches_float64_and_the_unfused_layers(rows, n2, k, kind):
+    """k = the mid width: 256 (layer3) on both arithmetics; 128 / 64 (layer2 / layer1) exist on the fp16-pair arithmetic only."""
     from codeps_amd import functional as F
-    y1, res, w2, w3, s2, t2, s3, t3 = _case(rows, n2, 11 + rows % 97 + n2, kind)
+    if k != 256 and F._arith() != 16:
+        pytest.skip("the narrow forms exist on the fp16-pair arithmetic only")
+    y1, res, w2, w3, s2, t2, s3, t3 = _case(rows, n2, 11 + rows % 97 + n2 + k, kind, k)
     o64, z64 = _ref(y1, res, w2, w3, s2, t2, s3, t3, torch.float64)
     o32, z32 = _ref(y1, res, w2, w3, s2, t2, s3, t3, torch.float32)
     d = lambda v: v.to(DEV)      # noqa: E731
     h = 8 if rows % 8 == 0 else 1
-    y1d, resd = d(y1).view(1, h, rows // h, 256), d(res).view(1, h, rows // h, n2)
-    w2d, w3d = d(w2).view(n2, 256, 1, 1), d(w3).view(256, n2, 1, 1)
+    y1d, resd = d(y1).view(1, h, rows // h, k), d(res).view(1, h, rows // h, n2)
+    w2d, w3d = d(w2).view(n2, k, 1, 1), d(w3).view(k, n2, 1, 1)
     with torch.no_grad():
         out, z = F.chain_expand_reduce(y1d, resd, w2d, d(s2), d(t2), w3d, d(s3), d(t3))
         # the same two layers, one launch each, on the conv engine
         uo = F.conv2d(y1d, w2d, scale=d(s2), shift=d(t2), residual=resd, act="relu")
         uz = F.conv2d(uo, w3d, scale=d(s3), shift=d(t3), act="relu")
     torch.cuda.synchronize()
-    out, z, uo, uz = out.view(rows, n2).cpu(), z.view(rows, 256).cpu(), uo.view(rows, n2).cpu(), uz.view(rows, 256).cpu()
+    out, z, uo, uz = out.view(rows, n2).cpu(), z.view(rows, k).cpu(), uo.view(rows, n2).cpu(), uz[..., :k].reshape(rows, k).cpu()
     e_o, e_z = _l2(out, o64), _l2(z, z64)
     t_o, t_z = _l2(o32, o64), _l2(z32, z64)
     u_o, u_z = _l2(uo, o64), _l2(uz, z64)
@@ -67,12 +71,15 @@ def test_chain_matches_float64_and_the_unfused_layers(rows, n2, kind):
     assert float((z.double() - z64).abs().max()) <= 5e-5 * float(z64.abs().max())
 
 
-def test_chain_is_repeatable_launch_to_launch():
+@pytest.mark.parametrize("k,n2", [(256, 1024), (128, 512), (64, 256)])
+def test_chain_is_repeatable_launch_to_launch(k, n2):
     from codeps_amd import functional as F
-    y1, res, w2, w3, s2, t2, s3, t3 = _case(16384, 1024, 5)
+    if k != 256 and F._arith() != 16:
+        pytest.skip("the narrow forms exist on the fp16-pair arithmetic only")
+    y1, res, w2, w3, s2, t2, s3, t3 = _case(16384, n2, 5, "normal", k)
     d = lambda v: v.to(DEV)      # noqa: E731
-    y1d, resd = d(y1).view(8, 32, 64, 256), d(res).view(8, 32, 64, 1024)
-    w2d, w3d = d(w2).view(1024, 256, 1, 1), d(w3).view(256, 1024, 1, 1)
+    y1d, resd = d(y1).view(8, 32, 64, k), d(res).view(8, 32, 64, n2)
+    w2d, w3d = d(w2).view(n2, k, 1, 1), d(w3).view(k, n2, 1, 1)
     args = (y1d, resd, w2d, d(s2), d(t2), w3d, d(s3), d(t3))
     with torch.no_grad():
         o0, z0 = F.chain_expand_reduce(*args)
@@ -128,6 +135,8 @@ def test_trunk_features_with_and_without_the_chain(layers):
         assert fa.shape == fb.shape
         assert _l2(fa, fb) < 5e-6, f"feature {i}: {_l2(fa, fb):.2e}"
     assert not torch.equal(a[3], b[3]), "the chained path did not run (layer3 features are bit-identical)"
+    if F._arith() == 16:
+        assert not torch.equal(a[1], b[1]) and not torch.equal(a[2], b[2]), "the narrow chained forms (layer1 / layer2) did not run"
 
 
 @pytest.mark.parametrize("b,h,w", [(2, 64, 128), (1, 96, 160), (3, 32, 64)])

@@ -58,7 +58,7 @@ def test_no_kernel_spills_and_tuned_occupancies_hold():
             "conv_igemm_kernel<0, 2, 2, 2, 2, 32, 1, 3, false>": 3,
             "conv_igemm_kernel<0, 2, 2, 2, 1, 32, 1, 3, false>": 4, "conv_igemm_kernel<1, 2, 2, 2, 1, 32, 1, 3, false>": 4,
             "conv_igemm_kernel<0, 2, 2, 2, 1, 32, 1, 2, false>": 4, "conv_igemm_kernel<1, 2, 2, 2, 1, 32, 1, 2, false>": 4,
-            "chain_expand_reduce_kernel": 1, "chain_expand_reduce_h_kernel": 2}
+            "chain_expand_reduce_kernel": 1, "chain_expand_reduce_h_kernel<256>": 2, "chain_expand_reduce_h_kernel<128>": 4, "chain_expand_reduce_h_kernel<64>": 4}
     for frag, occ in want.items():
         hits = [r for n, r in ks.items() if frag in nice[n].replace("(anonymous namespace)::", "")]
         assert hits, f"kernel {frag} not found in the resource remarks"
