@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CODEPS_HIP_LIB: developer override to A/B two builds of the library in one session (never set in production)
 LIB_PATH = os.environ.get("CODEPS_HIP_LIB") or os.path.join(_HERE, "libcodeps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 10
+ABI_VERSION = 11
 DIAG_LIB_PATH = os.path.join(_HERE, "libcodeps_diag.so")
 
 _lib = None
@@ -90,6 +90,9 @@ SIGNATURES = {
     "codeps_conv2d_epilogue_part_bytes": (c_size_t, [LL, I, I]),
     "codeps_conv2d_fwd_ex": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, POINTER(ConvEpilogue), P]),
     "codeps_conv2d_dgrad_ex": (c_int, [POINTER(ConvDesc), I, P, P, P, P, P, c_size_t, POINTER(ConvEpilogue), P]),
+    "codeps_conv2d_in_affine_ok": (c_int, [POINTER(ConvDesc), I]),
+    "codeps_conv2d_fwd_in": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, POINTER(ConvEpilogue), P]),
+    "codeps_conv2d_wgrad_in": (c_int, [POINTER(ConvDesc), P, P, P, P, I, I, I, P, c_size_t, P]),
     "codeps_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "codeps_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, I, I, I, P, c_size_t, P]),
     "codeps_chain1x1_w2_row_bytes": (c_size_t, []),
@@ -111,6 +114,9 @@ SIGNATURES = {
     "codeps_bn_bwd_apply": (c_int, [P, P, P, P, P, P, P, c_float, I, LL, I, P, P, P]),
     "codeps_bn_mg_workspace_bytes": (c_size_t, [I, I]),
     "codeps_bn_fwd_mg": (c_int, [P, I, P, P, I, I, P, P, P, I, c_float, c_float, P, P, P, P, P, P, I, I, P, c_size_t, P]),
+    "codeps_bn_in_affine": (c_int, [P, P, P, P, P, I, P, P, I, I, I, I, c_float, P, P, P, P]),
+    "codeps_in_affine_apply": (c_int, [P, P, I, I, I, P, P]),
+    "codeps_bn_finalize_tiles_table": (c_int, [P, I, I, I, I, P, P, I, I, c_float, c_float, P, P, P, P, P, P, P, P, P]),
     "codeps_bn_sync_combine": (c_int, [P, I, I, P, P, I, I, c_float, c_float, P, P, P, P, P, P]),
     "codeps_bn_bwd_mg": (c_int, [P, P, P, I, P, P, I, I, P, P, P, P, P, I, P, P, P, I, P, P, I, I, P, c_size_t, P]),
     "codeps_colsum_finish": (c_int, [P, I, I, P, I, I, P]),

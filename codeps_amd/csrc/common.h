@@ -40,6 +40,18 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 #ifdef __HIPCC__
+// relu((v - mean) invstd gamma + beta): the ONE expression of the train-mode BatchNorm apply (bn_apply_mg_kernel) and of the kernels that
+// normalise on their operand load instead (conv_igemm_kernel / wgrad_1x1s_kernel with in_aff) -- the same operations in the same order, so
+// a product over the normalised-on-load operand equals the product over the materialised tensor bit for bit
+typedef float codeps_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ codeps_f32x4 bn_norm_relu(const codeps_f32x4 v, const codeps_f32x4 mu, const codeps_f32x4 is, const codeps_f32x4 ga,
+                                                     const codeps_f32x4 be) {
+    codeps_f32x4 r = (v - mu) * is * ga + be;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : 0.f;
+    return r;
+}
+
 // ---- in-kernel clock stamps: ONLY in the diagnostic variant build (tools/build_variant.sh stamps -DCODEPS_CLOCK_STAMPS; in the
 // product library the macros are empty and no stamp executes).  MI355X_MICROARCH.md "DVFS give-back" item 6: s_memtime counts shader
 // cycles, s_memrealtime a constant 100 MHz; wave 0 of every block writes (cycles, 100 MHz ticks, phase A cycles, phase B cycles) of its

@@ -90,6 +90,9 @@ struct ConvP {
     const float* ex_bn_mean; const float* ex_bn_invstd; const float* ex_bn_gamma; const float* ex_bn_beta;
     int ex_bn_relu, ex_bn_ng;
     int ex_bn_b0[8];            // first image of every statistic group
+    // forward, source 0 arrives as the INPUT of a train-mode BatchNorm + ReLU (codeps_conv2d_fwd_in): [image][mean | invstd | gamma | beta][Ct];
+    // the kernel normalises on its operand load -- the normalised tensor is never written
+    const float* in_aff;
 };
 
 
@@ -422,6 +425,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     //      the loop the MFMA pipe idled 20-45 % of the time behind VALU work).
     unsigned* tab = reinterpret_cast<unsigned*>(smem + NBUF * (BM + BN) * LDK);
     __amdgpu_buffer_rsrc_t rs0, rs1;
+    // in_aff (forward only; tiles lie inside one image): the image's [mean | invstd | gamma | beta][Ct] behind the table and the maxima slot
+    float* aff = reinterpret_cast<float*>(tab + ((MODE == MODE_FWD && p.C1 > 0) ? 2 : 1) * ntap * BM + 4);
+    if (MODE == MODE_FWD && p.in_aff) {
+        const float* src = p.in_aff + (size_t)(m0 / (p.Ho * p.Wo)) * 4 * p.Ct;
+        for (int e = tid; e < p.Ct; e += 256) *reinterpret_cast<f32x4*>(aff + e * 4) = *reinterpret_cast<const f32x4*>(src + e * 4);
+    }
     build_gather<MODE, BM>(p, m0, ntap, tab, a0, a1, rs0, rs1, pc);
 
     // ---- per-thread staging roles: 16-B chunk `chunk` of rows rbase + RPP * i
@@ -443,10 +452,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
     }
 
     f32x4 areg[APASS * SUB], breg[BPASS * BREGS];
+    int areg_c = 0;                                           // channel offset of the tile `areg` holds (in_aff)
 
     auto load_step = [&](int step) {
         const int tap = step / steps_per_tap;
         const int cstep = (step - tap * steps_per_tap) * BK;   // channel offset within the tap
+        areg_c = cstep;
         // ---- A operand
         const bool s1 = MODE == MODE_FWD && cstep >= p.C0;        // which source this chunk belongs to
         const __amdgpu_buffer_rsrc_t rs = s1 ? rs1 : rs0;
@@ -470,6 +481,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
             for (int u = 0; u < BREGS; ++u)
                 breg[i * BREGS + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     rsB, BPRE ? boff[i] + (unsigned)(koff >> 5) * (unsigned)(32 * EB) + (unsigned)(koff & 31) * 2u + 64 * u : boff[i] + (unsigned)koff * 4u + 16 * u, 0, 0));
+    };
+    // in_aff: the tile in `areg` is BatchNorm's INPUT -- normalise + ReLU in registers (bn_norm_relu: the expression of bn_apply_mg_kernel, so
+    // the product equals the one over the materialised tensor bit for bit).  1x1 / no padding only: every gathered element is a real pixel.
+    auto transform_a = [&]() {
+        if (MODE == MODE_FWD && p.in_aff) {
+            const float* a = aff + areg_c + chunk * KPT;
+#pragma unroll
+            for (int u = 0; u < SUB; ++u) {
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(a + 4 * u), is = *reinterpret_cast<const f32x4*>(a + p.Ct + 4 * u);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(a + 2 * p.Ct + 4 * u), be = *reinterpret_cast<const f32x4*>(a + 3 * p.Ct + 4 * u);
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) areg[i * SUB + u] = bn_norm_relu(areg[i * SUB + u], mu, is, ga, be);
+            }
+        }
     };
     // NP = 2: the exponent of the largest magnitude of the gathered tile in `areg` -> amax_slot[wave] (read behind the next barrier)
     int* amax_slot = reinterpret_cast<int*>(tab + ((MODE == MODE_FWD && p.C1 > 0) ? 2 : 1) * ntap * BM);
@@ -560,6 +585,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
         }
     };
     load_step(s_begin);
+    transform_a();
     if constexpr (H16) { publish_amax(); __syncthreads(); rescale(); }
     store_step(0);
     __syncthreads();
@@ -629,6 +655,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, const float* _
 #endif
         CODEPS_STAMP_PHASE_A();                               // A: loads issued + fragment reads + MFMAs of this wave
         CODEPS_STAMP_PHASE_START();
+        if (step + 1 < s_end) transform_a();
         if (H16 && step + 1 < s_end) publish_amax();          // (the next tile's loads have had the MFMAs to land)
         if (NBUF == 1) __syncthreads();                       // every wave is done reading the single buffer
         if (step + 1 < s_end) { rescale(); store_step(NBUF == 2 ? (buf ^ 1) : 0); }
@@ -2727,6 +2754,7 @@ struct WgradP {
     int B, H, W, C0, C1, Ct, up0, Co, Ho, Wo, KH, KW, stride, pad, pad_mode, stride_w, pad_w;
     int n_mt, n_nt, splits, pix_per_split, P;     // P = B*Ho*Wo output pixels
     int fast;                                     // wgrad_halo64s_kernel: the layer-wide conditions of its FAST address path hold
+    const float* in_aff;                          // wgrad_1x1s_kernel: x is the INPUT of a train-mode BatchNorm + ReLU, [image][mean | invstd | gamma | beta][Ct]
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -2979,6 +3007,11 @@ __global__ __launch_bounds__(256, TB == 1 ? 2 : 1) void wgrad_1x1s_kernel(WgradP
         return (unsigned)(((b * p.H + (rem / p.Wo) * p.stride) * p.W + (rem % p.Wo) * p.stride_w)) * (unsigned)p.Ct;
     };
     f32x4 ra[8], rb[8];
+    // in_aff: x = BatchNorm's input; this thread's channel quad of the K-step's image (K-steps lie inside one image: codeps_conv2d_in_affine_ok)
+    f32x4 nmu, nis, nga, nbe;
+    int q_cur = pbeg;
+    const int cx = SWAP ? ca : cb;
+    const bool x_ok = SWAP ? a_ok : b_ok;
     auto load_step = [&](int q0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -2989,6 +3022,19 @@ __global__ __launch_bounds__(256, TB == 1 ? 2 : 1) void wgrad_1x1s_kernel(WgradP
             const unsigned vb = (ok && b_ok) ? ((SWAP ? oz : ox) + cb) * 4u : GATHER_OOB;
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, va, 0, 0));
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, vb, 0, 0));     // (threads without a B task: out of range, no traffic)
+        }
+        if (p.in_aff) {
+            const float* t = p.in_aff + (size_t)(q0 / (p.Ho * p.Wo)) * 4 * p.Ct + (x_ok ? cx : 0);
+            nmu = *reinterpret_cast<const f32x4*>(t); nis = *reinterpret_cast<const f32x4*>(t + p.Ct);
+            nga = *reinterpret_cast<const f32x4*>(t + 2 * p.Ct); nbe = *reinterpret_cast<const f32x4*>(t + 3 * p.Ct);
+            q_cur = q0;
+        }
+    };
+    auto normalise = [&](f32x4 (&r)[8]) {                       // relu(BatchNorm(x)) in registers; pixels behind the slab's end stay zero
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 v = bn_norm_relu(r[i], nmu, nis, nga, nbe);
+            r[i] = (x_ok && q_cur + t_g * 8 + i < pend) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_task = [&](const f32x4 (&r)[8], unsigned short* dst, float sc) {      // dst = row of the quad's first channel, at this pixel group
@@ -3020,6 +3066,7 @@ __global__ __launch_bounds__(256, TB == 1 ? 2 : 1) void wgrad_1x1s_kernel(WgradP
     int ea_run = F16_EMIN, eb_run = F16_EMIN;
     for (int step = 0; step < nsteps; ++step) {
         float sa = 1.f, sb = 1.f;
+        if (p.in_aff) { if constexpr (SWAP) normalise(ra); else normalise(rb); }
         if constexpr (H16) {
             float ma = 0.f, mb = 0.f;
 #pragma unroll
@@ -3136,9 +3183,22 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // in_aff (1x1 only): x is the INPUT of a train-mode BatchNorm + ReLU; a thread's channel quad is the same for all its loads (NT * 4 divides
+    // 256), its four BatchNorm vectors are reloaded when the tile's image changes
+    f32x4 nmu = {0.f, 0.f, 0.f, 0.f}, nis = nmu, nga = nmu, nbe = nmu;
+    int n_img = -1;
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+        if constexpr (TAPS == 1 && 256 % (NT * 4) == 0) {
+            if (p.in_aff && b != n_img) {
+                const int cq = c_src + (tid % (NT * 4)) * 4;
+                const float* t = p.in_aff + (size_t)b * 4 * p.Ct + (cq < cs ? cq : 0);
+                nmu = *reinterpret_cast<const f32x4*>(t); nis = *reinterpret_cast<const f32x4*>(t + p.Ct);
+                nga = *reinterpret_cast<const f32x4*>(t + 2 * p.Ct); nbe = *reinterpret_cast<const f32x4*>(t + 3 * p.Ct);
+                n_img = b;
+            }
+        }
         // all global loads of the tile are issued into registers first, then written to LDS (one latency, not one per
         // element: a load -> ds_write pair per loop iteration would wait for every load separately)
         constexpr int NZ = PIX * MT * 4 / 256, NX = (XH * XW * NT * 4 + 255) / 256;
@@ -3164,6 +3224,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradP p, int ci_chunk
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c_src + c4 * 4 < cs) {
                     if (up) { iy >>= 1; ix >>= 1; }
                     v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + iy) * Ws + ix) * cs + c_src + c4 * 4);
+                    if constexpr (TAPS == 1 && 256 % (NT * 4) == 0) { if (p.in_aff) v = bn_norm_relu(v, nmu, nis, nga, nbe); }
                 }
             }
             xr_[u] = v;
@@ -5721,7 +5782,8 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
     const int nsrc = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
     constexpr int LDKp = NP == 0 ? BK + 4 : (NP * BK + 8) / 2;   // LDS row in floats of the padded layouts (halo / ring / wave-specialised kernels)
     constexpr int LDKf = (CODEPS_IGEMM_SWZ && NP > 0 && BK == 32) ? NP * BK / 2 : LDKp;      // ... of conv_igemm_kernel (unpadded + swizzled at BK = 32)
-    const size_t lds = std::max(((size_t)NBUF * (BM + BN) * LDKf + (size_t)nsrc * ntap * BM) * sizeof(float),
+    const size_t aff_b = (MODE == MODE_FWD && p.in_aff) ? 16 + (size_t)16 * p.Ct : 0;     // in_aff: the image's four BatchNorm vectors behind the gather table
+    const size_t lds = std::max(((size_t)NBUF * (BM + BN) * LDKf + (size_t)nsrc * ntap * BM) * sizeof(float) + aff_b,
                                 (size_t)WM * 32 * (BN + 4) * sizeof(float));
     if constexpr (NP == 3 && WM == 2 && WN == 2 && TM == 2 && BK == 32) {
         // 3x3 / stride 1 / zero padding, one source at full resolution: halo-tile kernel (activations staged once per channel chunk)
@@ -5783,7 +5845,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         // ... and whose grid is a single round of one block per CU: the block owns the CU (111 KB of LDS), so a second round
         // would run without the co-resident blocks that hide the 256-thread kernel's prologue / epilogue
         static const int ws_blocks = getenv("CODEPS_WS_BLOCKS") ? atoi(getenv("CODEPS_WS_BLOCKS")) : 256;
-        if (ws_min > 0 && nsteps_ >= ws_min && p.n_mt * p.n_nt * std::max(p.grid_mult, 1) <= ws_blocks) {
+        if (ws_min > 0 && nsteps_ >= ws_min && p.n_mt * p.n_nt * std::max(p.grid_mult, 1) <= ws_blocks && !(MODE == MODE_FWD && p.in_aff)) {
             const int nsrc_ = (MODE == MODE_FWD && p.C1 > 0) ? 2 : 1;
             const size_t lds_ws = std::max(((size_t)2 * (BM + BN) * LDKp + (size_t)nsrc_ * ntap_ * BM) * sizeof(float), (size_t)WM * 32 * (BN + 4) * sizeof(float));
             const int blocks_ = p.n_mt * p.n_nt;
@@ -5837,7 +5899,7 @@ static void launch_igemm(ConvP p, const float* a0, const float* a1, const float*
         if (f16_pairs()) {                                   // two fp16 pieces (conv_igemm_kernel<.., NP = 2>): 128-byte LDS rows + the maxima slot
             h16 = true;
             k = epi_plan(p, BM) ? conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, 2, true> : conv_igemm_kernel<MODE, WM, WN, TM, TN, BK, NBUF, 2>;
-            lds_k = std::max(((size_t)(BM + BN) * 32 + (size_t)nsrc * ntap * BM) * sizeof(float) + 16, (size_t)WM * 32 * (BN + 4) * sizeof(float));
+            lds_k = std::max(((size_t)(BM + BN) * 32 + (size_t)nsrc * ntap * BM) * sizeof(float) + 16 + aff_b, (size_t)WM * 32 * (BN + 4) * sizeof(float));
         }
     }
     if (!h16) {
@@ -6190,13 +6252,48 @@ extern "C" int codeps_conv2d_fwd(const codeps_conv_desc* d, const float* x0, con
     return codeps_conv2d_fwd_ex(d, x0, x1, w_fwd, scale, shift, residual, y, workspace, workspace_bytes, nullptr, stream);
 }
 
+// Shapes whose forward (which = 0) / weight gradient (which = 1) can take source 0 as the INPUT of a train-mode BatchNorm + ReLU and
+// normalise it on the operand load: 1x1 / stride 1 / no padding, one dense source, > 16 output columns, M tiles inside one image.
+extern "C" int codeps_conv2d_in_affine_ok(const codeps_conv_desc* d, int which) {
+    if (check_conv(d, "conv2d_in_affine_ok") != CODEPS_OK) return 0;
+    const int hw = d->out_h * d->out_w;
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->stride_w != 1 || d->pad != 0 || d->pad_w != 0 || d->c1 != 0 || d->up0 || d->pix_pitch != 0 ||
+        d->pad_mode != 0 || d->c0 % 16 != 0 || d->c0 > 2048)
+        return 0;
+    if (which == 0) return d->out_c > 16 && hw % 256 == 0;
+    const SmallPlan sp = wgrad_small_plan(d);
+    if (sp.ok) return !sp.stem && !sp.halo64;                     // wgrad_small_kernel's 1x1 form (<= 32 output channels)
+    const W1Plan w1 = wgrad_1x1_plan(d);
+    return !wgrad_s2_plan(d).ok && w1.ok && hw % 32 == 0 && w1.pps % 32 == 0;
+}
+
+static int conv_fwd_impl(const codeps_conv_desc* d, const float* x0, const float* x1, const float* in_aff, const float* w_fwd,
+                         const float* scale, const float* shift, const float* residual, float* y, void* workspace,
+                         size_t workspace_bytes, codeps_conv_epilogue* epilogue, codeps_stream_t stream);
+
 extern "C" int codeps_conv2d_fwd_ex(const codeps_conv_desc* d, const float* x0, const float* x1, const float* w_fwd,
                                     const float* scale, const float* shift, const float* residual, float* y, void* workspace,
                                     size_t workspace_bytes, codeps_conv_epilogue* epilogue, codeps_stream_t stream) {
+    return conv_fwd_impl(d, x0, x1, nullptr, w_fwd, scale, shift, residual, y, workspace, workspace_bytes, epilogue, stream);
+}
+
+// codeps_conv2d_fwd_ex over relu(BatchNorm(x0)) without that tensor: x0 = the BatchNorm's input, in_affine [batch][mean | invstd | gamma |
+// beta][c0] (codeps_bn_in_affine) -- shapes of codeps_conv2d_in_affine_ok(d, 0) only
+extern "C" int codeps_conv2d_fwd_in(const codeps_conv_desc* d, const float* x0, const float* in_affine, const float* w_fwd,
+                                    const float* scale, const float* shift, const float* residual, float* y, void* workspace,
+                                    size_t workspace_bytes, codeps_conv_epilogue* epilogue, codeps_stream_t stream) {
+    CODEPS_REQUIRE(in_affine && codeps_conv2d_in_affine_ok(d, 0), CODEPS_ERR_ARG, "conv2d_fwd_in: shape not served (codeps_conv2d_in_affine_ok)");
+    return conv_fwd_impl(d, x0, nullptr, in_affine, w_fwd, scale, shift, residual, y, workspace, workspace_bytes, epilogue, stream);
+}
+
+static int conv_fwd_impl(const codeps_conv_desc* d, const float* x0, const float* x1, const float* in_aff, const float* w_fwd,
+                         const float* scale, const float* shift, const float* residual, float* y, void* workspace,
+                         size_t workspace_bytes, codeps_conv_epilogue* epilogue, codeps_stream_t stream) {
     int rc = check_conv(d, "conv2d_fwd");
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(x0 && w_fwd && y && (d->c1 == 0 || x1), CODEPS_ERR_ARG, "conv2d_fwd: null pointer");
     ConvP p = make_convp(d);
+    p.in_aff = in_aff;
     p.M = d->batch * d->out_h * d->out_w; p.N = d->out_c;
     rc = epi_load(p, epilogue, p.M, "conv2d_fwd");
     if (rc != CODEPS_OK) return rc;
@@ -6399,9 +6496,25 @@ extern "C" int codeps_conv2d_set_arith(int pieces) {
     return prev;
 }
 
+static int conv_wgrad_impl(const codeps_conv_desc* d, const float* x0, const float* x1, const float* in_aff, const float* dz, float* dw_oihw,
+                           int out_c_real, int in_c_real, int accumulate, void* workspace, size_t workspace_bytes, codeps_stream_t stream);
+
 extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, const float* x1, const float* dz, float* dw_oihw,
                                    int out_c_real, int in_c_real, int accumulate, void* workspace, size_t workspace_bytes,
                                    codeps_stream_t stream) {
+    return conv_wgrad_impl(d, x0, x1, nullptr, dz, dw_oihw, out_c_real, in_c_real, accumulate, workspace, workspace_bytes, stream);
+}
+
+// codeps_conv2d_wgrad over relu(BatchNorm(x0)) without that tensor (see codeps_conv2d_fwd_in) -- shapes of codeps_conv2d_in_affine_ok(d, 1) only
+extern "C" int codeps_conv2d_wgrad_in(const codeps_conv_desc* d, const float* x0, const float* in_affine, const float* dz, float* dw_oihw,
+                                      int out_c_real, int in_c_real, int accumulate, void* workspace, size_t workspace_bytes,
+                                      codeps_stream_t stream) {
+    CODEPS_REQUIRE(in_affine && codeps_conv2d_in_affine_ok(d, 1), CODEPS_ERR_ARG, "conv2d_wgrad_in: shape not served (codeps_conv2d_in_affine_ok)");
+    return conv_wgrad_impl(d, x0, nullptr, in_affine, dz, dw_oihw, out_c_real, in_c_real, accumulate, workspace, workspace_bytes, stream);
+}
+
+static int conv_wgrad_impl(const codeps_conv_desc* d, const float* x0, const float* x1, const float* in_aff, const float* dz, float* dw_oihw,
+                           int out_c_real, int in_c_real, int accumulate, void* workspace, size_t workspace_bytes, codeps_stream_t stream) {
     int rc = check_conv(d, "conv2d_wgrad");
     if (rc != CODEPS_OK) return rc;
     CODEPS_REQUIRE(x0 && dz && dw_oihw && workspace && (d->c1 == 0 || x1), CODEPS_ERR_ARG, "conv2d_wgrad: null pointer");
@@ -6426,6 +6539,7 @@ extern "C" int codeps_conv2d_wgrad(const codeps_conv_desc* d, const float* x0, c
     p.stride_w = d->stride_w; p.pad_w = d->pad_w;
     p.pad_mode = d->pad_mode; p.n_mt = n_mt; p.n_nt = n_nt; p.splits = splits; p.pix_per_split = pps;
     p.P = d->batch * d->out_h * d->out_w;
+    p.in_aff = in_aff;
     static const int wg_fast = getenv("CODEPS_WGRAD_FAST") ? atoi(getenv("CODEPS_WGRAD_FAST")) : 1;                 // tuning experiments only
     p.fast = wg_fast && d->pad_mode == 0 && d->out_h % 4 == 0 && d->out_w % 16 == 0 && (d->c0 % 4) == 0 && (d->c1 % 4) == 0 &&
              (size_t)d->in_h * d->in_w * std::max(std::max(d->c0, d->c1), d->out_c) * 4 < ((size_t)1 << 31);

@@ -21,7 +21,7 @@ void codeps_set_error(const char* fmt, ...) {
 extern "C" int codeps_diag_version(void) { return 1; }
 extern "C" const char* codeps_diag_last_error(void) { return g_err; }
 #else
-extern "C" int codeps_version(void) { return 10; }
+extern "C" int codeps_version(void) { return 11; }
 extern "C" const char* codeps_last_error(void) { return g_err; }
 #endif
 

@@ -444,8 +444,12 @@ struct ImgGroups { int n; int b0[8]; int b1[8]; };
 // one anyway.)
 // forward: part[tile][3][C] = (shift, sum (z - shift), sum (z - shift)^2) -> mean / biased var / invstd of group blockIdx.y
 // (bn_finalize_mg_kernel's arithmetic on sums re-based to the group's first tile's shift)
+// tab (codeps_bn_finalize_tiles_table): the [image][mean | invstd | gamma | beta][C] table of a BatchNorm whose apply pass is left to its consumer's
+// operand load, written for the group's images, + the running-statistics updates of a ONE-group launch (bn_apply_mg_kernel's expressions)
+struct BnTableOut { float* table; const float* gamma; const float* beta; float* run_mean; float* run_var; float momentum; int c_real; };
 __global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(const float* __restrict__ part, TileSegs sg, ImgGroups ig, int C, float eps,
-                                                                 float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd) {
+                                                                 float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
+                                                                 BnTableOut tab) {
     const int g = blockIdx.y;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     const bool cin = c < C;
@@ -473,6 +477,17 @@ __global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(const float* __
         const float d = a / n;
         const float v = fmaxf(b / n - d * d, 0.f);
         mean[g * C + c] = sh0 + d; var[g * C + c] = v; invstd[g * C + c] = rsqrtf(v + eps);
+        if (tab.table) {
+            const float ga = tab.gamma[c], be = tab.beta[c];
+            for (int b = ig.b0[g]; b < ig.b1[g]; ++b) {
+                float* t = tab.table + (size_t)b * 4 * C + c;
+                t[0] = sh0 + d; t[C] = rsqrtf(v + eps); t[2 * C] = ga; t[3 * C] = be;
+            }
+            if (tab.run_mean && c < tab.c_real) {
+                tab.run_mean[c] = tab.run_mean[c] * (1.f - tab.momentum) + tab.momentum * (sh0 + d);
+                tab.run_var[c] = tab.run_var[c] * (1.f - tab.momentum) + tab.momentum * (v * (n / fmaxf(n - 1.f, 1.f)));
+            }
+        }
     }
 }
 
@@ -1766,7 +1781,26 @@ extern "C" int codeps_bn_finalize_tiles(const float* part, int tile0, int tiles_
     int rc = make_tile_args(1, &tile0, &tiles_per_image, &tile_rows, n_groups, group_b0, group_b1, sg, ig, "bn_finalize_tiles");
     if (rc) return rc;
     CODEPS_REQUIRE(part && mean && var && invstd && c > 0, CODEPS_ERR_ARG, "bn_finalize_tiles: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(c, 64), n_groups), dim3(1024), 0, (hipStream_t)stream, part, sg, ig, c, eps, mean, var, invstd);
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(c, 64), n_groups), dim3(1024), 0, (hipStream_t)stream, part, sg, ig, c, eps, mean, var, invstd,
+                       BnTableOut{});
+    CODEPS_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+    return CODEPS_OK;
+}
+
+// codeps_bn_finalize_tiles + codeps_bn_in_affine in one launch: statistics from the producing convolution's per-tile partials AND the table of a
+// BatchNorm whose apply pass is left to its consumer (gamma / beta [c]; table [batch][4][c]).  running_mean / running_var: one statistic group
+// only (the updates of several groups are ordered: codeps_bn_in_affine).
+extern "C" int codeps_bn_finalize_tiles_table(const float* part, int tile0, int tiles_per_image, int tile_rows, int n_groups, const int* group_b0,
+                                              const int* group_b1, int c, int c_real, float eps, float momentum, const float* gamma, const float* beta,
+                                              float* mean, float* var, float* invstd, float* running_mean, float* running_var, float* table,
+                                              codeps_stream_t stream) {
+    TileSegs sg; ImgGroups ig;
+    int rc = make_tile_args(1, &tile0, &tiles_per_image, &tile_rows, n_groups, group_b0, group_b1, sg, ig, "bn_finalize_tiles_table");
+    if (rc) return rc;
+    CODEPS_REQUIRE(part && mean && var && invstd && gamma && beta && table && c > 0 && c_real <= c && (!running_mean || (running_var && n_groups == 1)),
+                   CODEPS_ERR_ARG, "bn_finalize_tiles_table: bad arguments (running statistics: one group only)");
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cdiv(c, 64), n_groups), dim3(1024), 0, (hipStream_t)stream, part, sg, ig, c, eps, mean, var, invstd,
+                       BnTableOut{table, gamma, beta, running_mean, running_var, momentum, c_real});
     CODEPS_CHECK_LAUNCH("bn_finalize_tiles_kernel");
     return CODEPS_OK;
 }
@@ -1798,6 +1832,74 @@ extern "C" int codeps_bn_bwd_tiles(const float* part, int n_seg, const int* seg_
                            BnAffineGrad{dgamma, dbeta, local_sums, accumulate, c_real});
         CODEPS_CHECK_LAUNCH("bn_bwd_apply_mg_kernel");
     }
+    return CODEPS_OK;
+}
+
+// ---- train-mode BatchNorm + ReLU applied on the CONSUMER's operand load (round 6): the per-image table the consumer reads
+// (codeps_conv2d_fwd_in / codeps_conv2d_wgrad_in) + the running-statistics update that otherwise rides in the apply pass
+namespace {
+__global__ __launch_bounds__(256) void bn_in_affine_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, ImgGroups ig, int batch, int C, float* __restrict__ table,
+                                                           BnRunning run, int rows_per_image) {
+    if (run.mean && blockIdx.x == 0)                             // (bn_apply_mg_kernel's expressions, group after group)
+        for (int c = threadIdx.x; c < run.c_real; c += 256) {
+            float rm = run.mean[c], rv = run.var[c];
+            for (int g = 0; g < ig.n; ++g) {
+                const float n = (float)((long long)(ig.b1[g] - ig.b0[g]) * rows_per_image);
+                rm = rm * (1.f - run.momentum) + run.momentum * mean[g * C + c];
+                rv = rv * (1.f - run.momentum) + run.momentum * (run.batch_var[g * C + c] * (n / fmaxf(n - 1.f, 1.f)));
+            }
+            run.mean[c] = rm; run.var[c] = rv;
+        }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < batch * C; i += gridDim.x * 256) {
+        const int b = i / C, c = i % C;
+        int g = 0;
+        for (int k = 1; k < ig.n; ++k) g += b >= ig.b0[k] ? 1 : 0;
+        float* t = table + (size_t)b * 4 * C + c;
+        t[0] = mean[g * C + c]; t[C] = invstd[g * C + c]; t[2 * C] = gamma[c]; t[3 * C] = beta[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void in_affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ table, long long total4, int rows_per_image,
+                                                              int C, float* __restrict__ y) {
+    const int G = C / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int g4 = (int)(i % G);
+        const long long row = i / G;
+        const float* t = table + (size_t)(row / rows_per_image) * 4 * C + g4 * 4;
+        *reinterpret_cast<f32x4*>(y + i * 4) = bn_norm_relu(*reinterpret_cast<const f32x4*>(x + i * 4), *reinterpret_cast<const f32x4*>(t),
+                                                            *reinterpret_cast<const f32x4*>(t + C), *reinterpret_cast<const f32x4*>(t + 2 * C),
+                                                            *reinterpret_cast<const f32x4*>(t + 3 * C));
+    }
+}
+}  // namespace
+
+extern "C" int codeps_bn_in_affine(const float* mean, const float* var, const float* invstd, const float* gamma, const float* beta, int n_groups,
+                                   const int* group_b0, const int* group_b1, int batch, int rows_per_image, int c, int c_real, float momentum,
+                                   float* running_mean, float* running_var, float* table, codeps_stream_t stream) {
+    CODEPS_REQUIRE(mean && invstd && gamma && beta && table && n_groups >= 1 && n_groups <= 8 && group_b0 && group_b1 && batch > 0 && rows_per_image > 0 &&
+                   c > 0 && (c % 4) == 0 && c_real <= c && (!running_mean || (running_var && var)), CODEPS_ERR_ARG, "bn_in_affine: bad arguments");
+    ImgGroups ig;
+    memset(&ig, 0, sizeof(ig));
+    ig.n = n_groups;
+    for (int g = 0; g < n_groups; ++g) {
+        CODEPS_REQUIRE(group_b1[g] > group_b0[g] && group_b0[g] >= 0 && group_b1[g] <= batch, CODEPS_ERR_ARG, "bn_in_affine: bad statistic group %d", g);
+        ig.b0[g] = group_b0[g]; ig.b1[g] = group_b1[g];
+    }
+    BnRunning run{running_mean, running_var, var, momentum, c_real};
+    hipLaunchKernelGGL(bn_in_affine_kernel, dim3(std::max(1, std::min(64, cdiv(batch * c, 256)))), dim3(256), 0, (hipStream_t)stream, mean, invstd, gamma, beta, ig,
+                       batch, c, table, run, rows_per_image);
+    CODEPS_CHECK_LAUNCH("bn_in_affine_kernel");
+    return CODEPS_OK;
+}
+
+// y = relu(BatchNorm(x)) from the table of codeps_bn_in_affine: the pass the consumers of codeps_conv2d_in_affine_ok shapes do without
+// (for a consumer that cannot normalise on its load)
+extern "C" int codeps_in_affine_apply(const float* x, const float* table, int batch, int rows_per_image, int c, float* y, codeps_stream_t stream) {
+    CODEPS_REQUIRE(x && table && y && batch > 0 && rows_per_image > 0 && c > 0 && (c % 4) == 0, CODEPS_ERR_ARG, "in_affine_apply: bad arguments");
+    const long long total4 = (long long)batch * rows_per_image * (c / 4);
+    hipLaunchKernelGGL(in_affine_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, table, total4, rows_per_image, c, y);
+    CODEPS_CHECK_LAUNCH("in_affine_apply_kernel");
     return CODEPS_OK;
 }
 

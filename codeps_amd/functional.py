@@ -582,10 +582,10 @@ class _ConvOpts:
     """Non-tensor options / results of one conv2d call: in -- in_gate (the gate of x0, consumed exclusively), bn_stats (the output feeds a
     train-mode BatchNorm: leave its batch statistics as per-tile partials); out -- gate (of the output, when it has an activation),
     stats (the partials record, None when the launch plan could not produce them)."""
-    __slots__ = ("in_gate", "bn_stats", "gate", "stats")
+    __slots__ = ("in_gate", "bn_stats", "gate", "stats", "in_defer")
 
-    def __init__(self, in_gate=None, bn_stats=False):
-        self.in_gate, self.bn_stats, self.gate, self.stats = in_gate, bn_stats, None, None
+    def __init__(self, in_gate=None, bn_stats=False, in_defer=None):
+        self.in_gate, self.bn_stats, self.gate, self.stats, self.in_defer = in_gate, bn_stats, None, None, in_defer
 
 
 def _epilogue_for(gate, x0, rows, cols, device):
@@ -633,6 +633,19 @@ def _act_gate_of(x, exclusive):
     return g if (g is not None and g.kind == "act" and _EPI and _EPI_PARTS["act"]) else None
 
 
+_DEFER = os.environ.get("CODEPS_BN_DEFER", "1") != "0"     # A/B switch: 0 = every train-mode BatchNorm writes its normalised tensor
+
+
+def in_affine_apply(x, table):
+    """relu(BatchNorm(x)) from a codeps_bn_in_affine table [B][4][C]: the apply pass a deferred BatchNorm skipped, for a consumer that
+    cannot normalise on its operand load."""
+    x = x.contiguous()
+    b, c = x.shape[0], x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().codeps_in_affine_apply(ptr(x), ptr(table), b, x.numel() // c // b, c, ptr(y), stream_ptr()), "codeps_in_affine_apply")
+    return y
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv(cat(up(x0), x1), W) * scale + shift + residual) on NHWC tensors (C ABI conv2d)."""
 
@@ -656,6 +669,16 @@ class _Conv2d(torch.autograd.Function):
         t0 = _prof_begin()
         wsb = lib().codeps_conv2d_fwd_workspace_bytes(ctypes.byref(desc))          # split-K scratch (small-M, deep-K shapes only)
         ws = _workspace(wsb, x0.device, "splitk") if wsb else None
+        # x0 = the INPUT of a train-mode BatchNorm + ReLU whose apply pass was left to this consumer (batch_norm_train(defer=True)): the kernel
+        # normalises on its operand load where the shape allows (codeps_conv2d_in_affine_ok), else the tensor is made here after all
+        table = opts.in_defer if opts is not None else None
+        fused_in = False
+        if table is not None:
+            if x1 is None and not up0 and lib().codeps_conv2d_in_affine_ok(ctypes.byref(desc), 0):
+                fused_in = True
+            else:
+                x0 = in_affine_apply(x0, table)
+                table = None
         epi = spart = None
         if opts is not None and opts.bn_stats and _EPI and _EPI_PARTS["stats"] and not act and sc is None and sh is None and residual is None:
             # the output feeds a train-mode BatchNorm: (shift, sum, sum of squares) per M tile from the epilogue instead of a pass over y
@@ -664,9 +687,14 @@ class _Conv2d(torch.autograd.Function):
             nbytes = lib().codeps_conv2d_epilogue_part_bytes(desc.batch * desc.out_h * desc.out_w, cop, 1)
             spart = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
             epi.stat_part, epi.stat_part_bytes = spart.data_ptr(), nbytes
-        check(lib().codeps_conv2d_fwd_ex(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
-                                         ptr(ws), ws.numel() if ws is not None else 0, ctypes.byref(epi) if epi is not None else None,
-                                         stream_ptr()), "codeps_conv2d_fwd")
+        if fused_in:
+            check(lib().codeps_conv2d_fwd_in(ctypes.byref(desc), ptr(x0), ptr(table), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
+                                             ptr(ws), ws.numel() if ws is not None else 0, ctypes.byref(epi) if epi is not None else None,
+                                             stream_ptr()), "codeps_conv2d_fwd_in")
+        else:
+            check(lib().codeps_conv2d_fwd_ex(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(wf), ptr(sc), ptr(sh), ptr(residual), ptr(y),
+                                             ptr(ws), ws.numel() if ws is not None else 0, ctypes.byref(epi) if epi is not None else None,
+                                             stream_ptr()), "codeps_conv2d_fwd")
         _prof_end(t0, "conv_fwd", flops, desc)
         if epi is not None and (epi.applied & 2):
             opts.stats = {"part": spart, "tile0": epi.seg_tile0[0], "tpi": epi.seg_tiles_per_image[0], "rows": epi.seg_tile_rows[0]}
@@ -688,7 +716,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.c0_real = min(ci, x0.shape[3])
         ctx.weight_ref = weakref.ref(weight)
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x0, x1, y if act else None, wd, sc)
+        ctx.save_for_backward(x0, x1, y if act else None, wd, sc, table)         # (table: x0 is still BatchNorm's input -- the weight gradient normalises too)
         ctx.fork = bool(fork)
         if fork:
             # second output = x0 itself (an alias): whatever else consumes the tensor (a residual connection, a down-sampling
@@ -699,7 +727,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, g_fork=None):
-        x0, x1, y, wd, sc = ctx.saved_tensors
+        x0, x1, y, wd, sc, in_table = ctx.saved_tensors
         desc = ctx.desc
         add = g_fork.contiguous() if (ctx.fork and g_fork is not None) else None
         gated = ctx.out_gate.take(dy) if ctx.out_gate is not None else None
@@ -808,8 +836,13 @@ class _Conv2d(torch.autograd.Function):
             wsb = lib().codeps_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
             ws = _workspace(wsb, dy.device, "wgrad")
             t0 = _prof_begin()
-            check(lib().codeps_conv2d_wgrad(ctypes.byref(desc), ptr(x0), ptr(x1), ptr(dz), ptr(dw), ctx.co, ctx.ci,
-                                            1 if sink is not None else 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_conv2d_wgrad")
+            if in_table is not None and lib().codeps_conv2d_in_affine_ok(ctypes.byref(desc), 1):
+                check(lib().codeps_conv2d_wgrad_in(ctypes.byref(desc), ptr(x0), ptr(in_table), ptr(dz), ptr(dw), ctx.co, ctx.ci,
+                                                   1 if sink is not None else 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_conv2d_wgrad_in")
+            else:
+                xw = in_affine_apply(x0, in_table) if in_table is not None else x0         # (a weight-gradient kernel without the normalise-on-load)
+                check(lib().codeps_conv2d_wgrad(ctypes.byref(desc), ptr(xw), ptr(x1), ptr(dz), ptr(dw), ctx.co, ctx.ci,
+                                                1 if sink is not None else 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_conv2d_wgrad")
             _prof_end(t0, "conv_wgrad", ctx.flops, desc)
             if sink is not None:
                 dw = None               # accumulated in place into the flat gradient buffer
@@ -836,8 +869,12 @@ def conv2d(x0, weight, bias=None, *, x1=None, scale=None, shift=None, residual=N
     exclusive=True: this call (and the taker of its fork alias) is the ONLY consumer of x0 -- when x0 came out of a conv + activation or
     a train-mode BatchNorm + ReLU of this library, that producer's activation backward (and its bias / BatchNorm sums) then happens in
     this convolution's data-gradient epilogue (`_Gate`).  bn_stats=True: the result feeds a train-mode BatchNorm; `y._codeps_stats`
-    then carries its batch statistics as per-tile partials (None when the launch plan cannot produce them)."""
-    opts = _ConvOpts(getattr(x0, "_codeps_gate", None) if exclusive else None, bn_stats)
+    then carries its batch statistics as per-tile partials (None when the launch plan cannot produce them).
+    x0 with `._codeps_defer` (batch_norm_train(defer=True)) holds the INPUT of a train-mode BatchNorm + ReLU: the forward and weight-gradient
+    kernels normalise on their operand load (1x1 shapes, codeps_conv2d_in_affine_ok) or the tensor is materialised here."""
+    if fork and getattr(x0, "_codeps_defer", None) is not None:
+        raise _lib.CodepsHipError("conv2d: a deferred BatchNorm output (batch_norm_train(defer=True)) has ONE reader; fork=True hands the tensor on")
+    opts = _ConvOpts(getattr(x0, "_codeps_gate", None) if exclusive else None, bn_stats, getattr(x0, "_codeps_defer", None))
     out = _Conv2d.apply(x0, x1, weight, bias, scale, shift, residual, _pair(stride), _pair(pad),
                         1 if pad_mode == "reflect" else 0, ACT[act], bool(up0), macs_per_out, bool(fork), opts)
     y = out[0] if fork else out
@@ -1123,6 +1160,21 @@ class _BatchNormTrain(torch.autograd.Function):
         counts = [float((b1 - b0) * per_item) for b0, b1 in groups]
         rm = running_mean if (running_mean is not None and running_mean.numel() == c) else None
         tiles = opts.stats if (opts is not None and _EPI) else None       # statistics partials the producing convolution's epilogue left
+        # defer: the apply pass is left to the consumer (a 1x1 convolution that normalises on its operand load): no y, a [B][4][C] table
+        defer = bool(opts is not None and opts.want_defer and _DEFER and act == 1 and residual is None and len(groups) <= 8)
+        table = torch.empty(bsz, 4, cp, dtype=torch.float32, device=dev) if defer else None
+        if defer:
+            y = None
+
+        def apply_pass(mean_, var_, invstd_, run_m, run_v):
+            if defer:
+                ngi, gb0, gb1 = _img_groups(groups)
+                check(lib().codeps_bn_in_affine(ptr(mean_), ptr(var_), ptr(invstd_), ptr(g), ptr(b_), ngi, gb0, gb1, bsz, per_item, cp, c, momentum,
+                                                ptr(run_m), ptr(run_v) if run_m is not None else None, ptr(table), stream_ptr()), "codeps_bn_in_affine")
+            else:
+                check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, ptr(run_m),
+                                             ptr(run_v) if run_m is not None else None, ptr(mean_), ptr(var_), ptr(invstd_), ptr(y), 0, 1,
+                                             ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
 
         def local_stats(mean_o, var_o, invstd_o):
             """per-group (mean, biased var, invstd) of THIS rank's rows"""
@@ -1134,12 +1186,20 @@ class _BatchNormTrain(torch.autograd.Function):
                 check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, None, None, ptr(mean_o),
                                              ptr(var_o), ptr(invstd_o), None, 1, 0, ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
 
-        if reduce_fn is None and tiles is not None:
+        if reduce_fn is None and tiles is not None and defer and (ng == 1 or rm is None):
+            ngi, gb0, gb1 = _img_groups(groups)      # statistics finish + table (+ the running statistics of a one-group layer) in ONE launch
+            check(lib().codeps_bn_finalize_tiles_table(ptr(tiles["part"]), tiles["tile0"], tiles["tpi"], tiles["rows"], ngi, gb0, gb1, cp, c, eps, momentum,
+                                                       ptr(g), ptr(b_), ptr(mean), ptr(var), ptr(invstd), ptr(rm), ptr(running_var) if rm is not None else None,
+                                                       ptr(table), stream_ptr()), "codeps_bn_finalize_tiles_table")
+        elif reduce_fn is None and tiles is not None:
             local_stats(mean, var, invstd)
             # (apply_only with the running statistics: their momentum updates ride in the apply pass)
-            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, ptr(rm),
-                                         ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1,
-                                         ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")
+            apply_pass(mean, var, invstd, rm, running_var)
+        elif reduce_fn is None and defer:
+            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, None, None, None, act, eps, momentum, ptr(rm),
+                                         ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), None, 1, 0,
+                                         ptr(ws), ws.numel(), stream_ptr()), "codeps_bn_fwd_mg")        # (statistics pass: the momentum updates ride in its finish)
+            apply_pass(mean, var, invstd, None, None)
         elif reduce_fn is None:
             check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, ptr(rm),
                                          ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 0,
@@ -1164,9 +1224,7 @@ class _BatchNormTrain(torch.autograd.Function):
                                                ptr(var_g), ptr(invstd_g), stream_ptr()), "codeps_bn_sync_combine")
             mean, var, invstd = mean_g.index_select(0, l2g), var_g.index_select(0, l2g), invstd_g.index_select(0, l2g)
             counts = [gcounts[g] for g in plan["local_to_global"]]
-            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, None, None,
-                                         ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1, ptr(ws), ws.numel(), stream_ptr()),
-                  "codeps_bn_fwd_mg")
+            apply_pass(mean, var, invstd, None, None)
         else:       # SyncBN: local statistics -> all-gather -> one combine kernel (merge + running stats + invstd) -> apply
             pk = torch.empty(2, ng, cp, dtype=torch.float32, device=dev)        # [mean | var] = the all-gather packet, no packing pass
             local_stats(pk[0], pk[1], invstd)
@@ -1177,9 +1235,7 @@ class _BatchNormTrain(torch.autograd.Function):
             check(lib().codeps_bn_sync_combine(ptr(gathered), world, ng, gc, None, cp, c, eps, momentum, ptr(rm),
                                                ptr(running_var) if rm is not None else None, ptr(mean), ptr(var), ptr(invstd),
                                                stream_ptr()), "codeps_bn_sync_combine")
-            check(lib().codeps_bn_fwd_mg(ptr(x), ng, row0, rows, cp, c, ptr(g), ptr(b_), ptr(residual), act, eps, momentum, None, None,
-                                         ptr(mean), ptr(var), ptr(invstd), ptr(y), 0, 1, ptr(ws), ws.numel(), stream_ptr()),
-                  "codeps_bn_fwd_mg")
+            apply_pass(mean, var, invstd, None, None)
         ctx.inv_count = [1.0 / n for n in counts]
         # ReLU without a residual: the backward recomputes the mask from x (y is neither kept nor re-read)
         ctx.save_for_backward(x, y if (act and residual is not None) else None, g, b_, mean, invstd)
@@ -1195,6 +1251,9 @@ class _BatchNormTrain(torch.autograd.Function):
         # flat-gradient sinks of the affine parameters (codeps_amd.step): the backward accumulates dgamma / dbeta in place
         gs, bs = grad_sink(gamma), grad_sink(beta)
         ctx.sinks = (gs, bs) if (gs is not None and bs is not None and gamma.requires_grad and beta.requires_grad) else None
+        if defer:
+            opts.defer = table
+            return x                        # (an alias: BatchNorm's input, raw -- batch_norm_train marks it with the table)
         return y
 
     @staticmethod
@@ -1313,21 +1372,26 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, residua
 
 
 class _BnOpts:
-    __slots__ = ("stats", "gate")
+    __slots__ = ("stats", "gate", "want_defer", "defer")
 
-    def __init__(self, stats=None):
-        self.stats, self.gate = stats, None
+    def __init__(self, stats=None, want_defer=False):
+        self.stats, self.gate, self.want_defer, self.defer = stats, None, want_defer, None
 
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None, act=None,
-                     reduce_fn=None, groups=None):
+                     reduce_fn=None, groups=None, defer=False):
     """x may carry `._codeps_stats` (conv2d(..., bn_stats=True)): the statistics pass then is a finish over per-tile partials.  A ReLU
-    output carries `._codeps_gate` for a convolution that consumes it exclusively (conv2d(..., exclusive=True))."""
-    opts = _BnOpts(getattr(x, "_codeps_stats", None))
+    output carries `._codeps_gate` for a convolution that consumes it exclusively (conv2d(..., exclusive=True)).
+    defer=True (BatchNorm + ReLU without a residual whose ONLY reader is the next F.conv2d call): the apply pass is not run; the result is
+    BatchNorm's INPUT marked with `._codeps_defer` (a [B][4][C] table of mean / invstd / gamma / beta per image) and conv2d normalises
+    on its operand load, or materialises the tensor itself when its kernels cannot.  Nothing but F.conv2d may read such a tensor."""
+    opts = _BnOpts(getattr(x, "_codeps_stats", None), defer)
     y = _BatchNormTrain.apply(x, gamma, beta, residual, running_mean, running_var, float(momentum), float(eps), ACT[act],
                               reduce_fn, groups, opts)
     if opts.gate is not None:
         y._codeps_gate = opts.gate
+    if opts.defer is not None:
+        y._codeps_defer = opts.defer
     return y
 
 

@@ -53,7 +53,7 @@ def folded_bn(bn: nn.BatchNorm2d):
 
 
 def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, sync=None, groups=None, stem=False, fork=False,
-            exclusive=False):
+            exclusive=False, defer=False):
     """act(BN(conv(x)) + residual).  Eval-mode BN is folded into the conv epilogue (one kernel);
     train-mode BN uses batch statistics (`sync` = cross-rank sum reducer for SyncBatchNorm).
     stem=True: x is in the double-pixel stem layout and conv is ResNet's conv1 (F.stem_conv2d).
@@ -61,12 +61,14 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
     convolution's data-gradient kernel then adds the gradient that comes back through x' in its epilogue (F.conv2d(fork=True)).
     exclusive=True: this call (with the taker of its fork alias) is x's only consumer, so the backward of the activation that produced
     x may run in this convolution's data-gradient epilogue (F.conv2d(exclusive=True)).  Train-mode BatchNorm takes its batch statistics
-    from the convolution's epilogue (F.conv2d(bn_stats=True)) where the launch plan allows."""
+    from the convolution's epilogue (F.conv2d(bn_stats=True)) where the launch plan allows.
+    defer=True: the result's ONLY reader is the next conv_bn / F.conv2d call -- a train-mode BatchNorm + ReLU then leaves its apply pass to
+    that convolution's operand load (F.batch_norm_train(defer=True)); the tensor returned holds BatchNorm's input and must go nowhere else."""
     if fork:
         if not (_FORK and torch.is_grad_enabled() and x.requires_grad) or stem:
             # (without the fork the alias is x itself: a second consumer autograd sums separately -> not exclusive)
-            return conv_bn(x, conv, bn, act, residual, sync, groups, stem), x
-        return _conv_bn_fork(x, conv, bn, act, residual, sync, groups, exclusive)
+            return conv_bn(x, conv, bn, act, residual, sync, groups, stem, defer=defer), x
+        return _conv_bn_fork(x, conv, bn, act, residual, sync, groups, exclusive, defer)
     stride, pad = conv.stride[0], conv.padding[0]
     if stem == "s3":                   # frozen 3-channel stem (eval BN folded, no gradients): F.stem3_conv2d, K = 224
         scale, shift = folded_bn(bn)
@@ -85,7 +87,7 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
     if bn.training:
         y = F.conv2d(x, conv.weight, stride=stride, pad=pad, exclusive=exclusive, bn_stats=True)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                 residual=residual, act=act, reduce_fn=sync, groups=groups)
+                                 residual=residual, act=act, reduce_fn=sync, groups=groups, defer=defer)
         _count_batch(bn, len(groups) if groups else 1)
         return out
     if torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad):
@@ -96,14 +98,14 @@ def conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, act=None, residual=None, syn
     return F.conv2d(x, conv.weight, scale=scale, shift=shift, residual=residual, stride=stride, pad=pad, act=act, exclusive=exclusive)
 
 
-def _conv_bn_fork(x, conv, bn, act, residual, sync, groups, exclusive=False):
+def _conv_bn_fork(x, conv, bn, act, residual, sync, groups, exclusive=False, defer=False):
     """conv_bn for an input that needs a gradient and has a second consumer (BN kept as its own op: x needs a gradient, so either BN is
     in train mode or, with eval statistics, its output still has to carry the graph)."""
     stride, pad = conv.stride[0], conv.padding[0]
     if bn.training:
         y, xa = F.conv2d(x, conv.weight, stride=stride, pad=pad, fork=True, exclusive=exclusive, bn_stats=True)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                 residual=residual, act=act, reduce_fn=sync, groups=groups)
+                                 residual=residual, act=act, reduce_fn=sync, groups=groups, defer=defer)
         _count_batch(bn, len(groups) if groups else 1)
         return out, xa
     if bn.weight.requires_grad or bn.bias.requires_grad:
@@ -114,12 +116,12 @@ def _conv_bn_fork(x, conv, bn, act, residual, sync, groups, exclusive=False):
                     exclusive=exclusive)
 
 
-def dwconv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, sync=None):
-    """5x5 depthwise + BN + ReLU (models/instance_head.py:38-46)."""
+def dwconv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, sync=None, defer=False):
+    """5x5 depthwise + BN + ReLU (models/instance_head.py:38-46).  defer: see conv_bn."""
     if bn.training:
         y = F.dwconv5x5(x, conv.weight)
         out = F.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act="relu",
-                                 reduce_fn=sync)
+                                 reduce_fn=sync, defer=defer)
         _count_batch(bn, 1)
         return out
     if torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad):

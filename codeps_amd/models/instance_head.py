@@ -18,7 +18,7 @@ def _dwsep(cin, cout):
 
 
 def _run_dwsep(x, seq, sync):
-    x = dwconv_bn_relu(x, seq[0], seq[1], sync)
+    x = dwconv_bn_relu(x, seq[0], seq[1], sync, defer=True)          # (... and its apply pass in that convolution's operand load)
     # (the 1 x 1 convolution is the only consumer of the depthwise stage's output: BatchNorm's ReLU mask and backward sums of that stage
     # ride in its data-gradient epilogue)
     return conv_bn(x, seq[3], seq[4], "relu", sync=sync, exclusive=True)

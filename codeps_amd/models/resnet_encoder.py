@@ -52,7 +52,8 @@ class _Bottleneck(nn.Module):
     def forward_nhwc(self, x, sync, groups=None, own_input=False):
         out, xa = conv_bn(x, self.conv1, self.bn1, "relu", sync=sync, groups=groups, fork=True, exclusive=own_input)
         identity = xa if self.downsample is None else conv_bn(xa, self.downsample[0], self.downsample[1], sync=sync, groups=groups)
-        out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync, groups=groups, exclusive=True)
+        # (bn2's normalise + ReLU happens on conv3's operand load when bn2 is in train mode: conv3, a 1x1, is `out`'s only reader)
+        out = conv_bn(out, self.conv2, self.bn2, "relu", sync=sync, groups=groups, exclusive=True, defer=True)
         return conv_bn(out, self.conv3, self.bn3, "relu", residual=identity, sync=sync, groups=groups, exclusive=True)
 
 
@@ -82,10 +83,11 @@ def _run_layer(layer, x, sync, groups, own_input=False):
         if y0 is None:
             y0, xa = conv_bn(x, blk.conv1, blk.bn1, "relu", sync=sync, groups=groups, fork=True, exclusive=own)
         identity = xa if blk.downsample is None else conv_bn(xa, blk.downsample[0], blk.downsample[1], sync=sync, groups=groups)
-        y1 = conv_bn(y0, blk.conv2, blk.bn2, "relu", sync=sync, groups=groups, exclusive=True)
+        y1 = conv_bn(y0, blk.conv2, blk.bn2, "relu", sync=sync, groups=groups, exclusive=True, defer=True)
         y0 = None
         if (nxt is not None and nxt.downsample is None and nxt.conv1.out_channels == blk.conv3.in_channels
                 and F.chain_ok(y1, blk.conv3.out_channels) and _frozen_eval(blk.bn3, blk.conv3, nxt.bn1, nxt.conv1)
+                and getattr(y1, "_codeps_defer", None) is None          # (a train-mode bn2 left its apply pass to F.conv2d)
                 and not (torch.is_grad_enabled() and (y1.requires_grad or identity.requires_grad))):
             s2, t2 = folded_bn(blk.bn3)
             s3, t3 = folded_bn(nxt.bn1)

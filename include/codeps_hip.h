@@ -183,6 +183,21 @@ int codeps_conv2d_fwd_ex(const codeps_conv_desc* d, const float* x0, const float
 int codeps_conv2d_dgrad_ex(const codeps_conv_desc* d, int source, const float* dz, const float* w_dgrad, const float* add,
                            float* dx, void* workspace, size_t workspace_bytes, codeps_conv_epilogue* epilogue,
                            codeps_stream_t stream);
+/* Train-mode BatchNorm + ReLU applied on the CONSUMER's operand load (round 6; models/resnet_encoder.py:115-126 via torchvision's Bottleneck:
+ * conv -> bn -> relu -> 1x1 conv; models/instance_head.py:38-46: depthwise 5x5 -> bn -> relu -> 1x1 conv).  x0 is the BatchNorm's INPUT,
+ * in_affine [batch][mean | invstd | gamma | beta][c0] (codeps_bn_in_affine): the kernels compute relu((x - mean) invstd gamma + beta) in
+ * registers where they stage their operand -- bit for bit what codeps_bn_fwd_mg's apply pass writes -- and the normalised tensor never
+ * exists.  Served shapes (codeps_conv2d_in_affine_ok; which = 0 forward, 1 weight gradient): 1x1 / stride 1 / no padding, one dense source;
+ * forward: > 16 output columns and out_h * out_w % 256 == 0; weight gradient: the shapes of the split-operand 1x1 kernel (>= 48 channels on
+ * both sides) and of the <= 32-output-channel kernel.  The data
+ * gradient needs nothing new: it never reads x0 (the BatchNorm gate of codeps_conv_epilogue recomputes the ReLU mask from bn_x). */
+int codeps_conv2d_in_affine_ok(const codeps_conv_desc* d, int which);
+int codeps_conv2d_fwd_in(const codeps_conv_desc* d, const float* x0, const float* in_affine, const float* w_fwd,
+                         const float* scale, const float* shift, const float* residual, float* y,
+                         void* workspace, size_t workspace_bytes, codeps_conv_epilogue* epilogue, codeps_stream_t stream);
+int codeps_conv2d_wgrad_in(const codeps_conv_desc* d, const float* x0, const float* in_affine, const float* dz,
+                           float* dw_oihw, int out_c_real, int in_c_real, int accumulate, void* workspace,
+                           size_t workspace_bytes, codeps_stream_t stream);
 /* Two FROZEN 1x1 layers of consecutive ResNet bottlenecks in one launch (inference only; csrc/chain1x1.hip; replaces
  * conv3 + bn3 + residual + ReLU of bottleneck i and conv1 + bn1 + ReLU of bottleneck i + 1, models/resnet_encoder.py:115-126):
  *     out[m][n2]  = relu(scale2 * (y1[m][:] . W2[n2][:]) + shift2 + residual[m][n2])     y1 [rows][256], out / residual [rows][n2]
@@ -288,6 +303,19 @@ int codeps_bn_fwd_mg(const float* x, int n_groups, const long long* row0, const 
                      float momentum, float* running_mean, float* running_var, float* mean, float* var,
                      float* invstd, float* y, int stats_only, int apply_only, void* workspace,
                      size_t workspace_bytes, codeps_stream_t stream);
+/* The table the kernels above read, from per-group batch statistics (mean / var / invstd [n_groups][c]; group g = images group_b0[g] ..
+ * group_b1[g] - 1), + the running-statistics momentum updates that otherwise ride in the apply pass (running_mean may be NULL: SyncBN's
+ * combine kernel already did them).  codeps_in_affine_apply: y = relu(BatchNorm(x)) from the table, for a consumer that cannot normalise
+ * on its load. */
+int codeps_bn_in_affine(const float* mean, const float* var, const float* invstd, const float* gamma, const float* beta, int n_groups,
+                        const int* group_b0, const int* group_b1, int batch, int rows_per_image, int c, int c_real, float momentum,
+                        float* running_mean, float* running_var, float* table, codeps_stream_t stream);
+int codeps_in_affine_apply(const float* x, const float* table, int batch, int rows_per_image, int c, float* y, codeps_stream_t stream);
+/* codeps_bn_finalize_tiles + codeps_bn_in_affine in one launch (running statistics: n_groups == 1 only, else NULL + codeps_bn_in_affine). */
+int codeps_bn_finalize_tiles_table(const float* part, int tile0, int tiles_per_image, int tile_rows, int n_groups, const int* group_b0,
+                                   const int* group_b1, int c, int c_real, float eps, float momentum, const float* gamma, const float* beta,
+                                   float* mean, float* var, float* invstd, float* running_mean, float* running_var, float* table,
+                                   codeps_stream_t stream);
 /* SyncBatchNorm (misc/train_utils.py:50-51, torch.nn.SyncBatchNorm): after the all-gather of every rank's per-group
  * (mean, biased var) -- gathered [world][2][n_groups][c] -- merge them (parallel-variance formula), compute invstd and
  * apply the running-stat momentum updates group by group with the global counts (host array [n_groups]).

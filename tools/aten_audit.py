@@ -16,14 +16,19 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--encoder", type=int, default=101)
+    ap.add_argument("--encoder", type=int, default=None)
+    ap.add_argument("--mode", default="adapt", choices=["adapt", "train"])
+    ap.add_argument("--batch", type=int, default=None)
     args = ap.parse_args()
+    mode = args.mode
+    enc = args.encoder or (101 if mode == "adapt" else 50)
+    batch = args.batch or (8 if mode == "adapt" else 4)
     import bench
     from codeps_amd.step import StepRunner
     dev = torch.device("cuda:0")
-    net, cfg = bench.build(dev, args.encoder, 512, 1024, "adapt")
-    data, _ = bench.make_data("adapt", 512, 1024, dev, 0, 8)
-    runner = StepRunner(net, cfg, "adapt", 1)
+    net, cfg = bench.build(dev, enc, 512, 1024, mode)
+    data, _ = bench.make_data(mode, 512, 1024, dev, 0, batch)
+    runner = StepRunner(net, cfg, mode, 1)
     for _ in range(3):
         runner.step(data)
     torch.cuda.synchronize()
