@@ -1039,6 +1039,192 @@ __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------- depthwise 5x5 on LDS tiles (round 6)
+// dwconv5_kernel gathers every thread's (RS + 4) x (CS + 4) patch from global memory: 6 loads per output quad (11 in the weight gradient), and
+// a block's footprint (82 KB at 128 channels) does not stay in the 32 KB L1 -- the loads are served by the L2 and the kernel moves 2.4 TB/s of
+// algorithmic bytes (tools/dwconv_rate.py).  Here a block stages ONE halo tile of 20 x 20 pixels x 32 channels in LDS (every input element
+// fetched once per block: 1.56x with the halo, 128-byte segments) and the threads -- (channel quad, column pair, 4-row strip) of a 16 x 16
+// output tile -- run dwconv5_kernel's register loops on LDS reads.  Same products, same summation order per output: bit-identical results.
+constexpr int DWT = 16, DWH = DWT + 4, DWCG = 32, DWPITCH = DWCG + 4;        // tile, halo tile, channels per block, floats per staged pixel
+// blocks with equal blockIdx.x % 8 share an XCD (its L2): they take CONSECUTIVE tiles, so that the halos neighbouring tiles share are fetched from
+// HBM once (conv.hip: xcd_remap)
+__device__ __forceinline__ int dw_xcd_remap(int bid, int nblk) {
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8, i = bid / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+constexpr int DWLOADS = (DWH * DWH * (DWCG / 4) + 255) / 256;
+
+template <int U0, int U1>
+__device__ __forceinline__ void dw_stage(const float* __restrict__ x, int b, int ty0, int tx0, int c0, int H, int W, int C, f32x4 (&r)[U1 - U0]) {
+#pragma unroll
+    for (int u = U0; u < U1; ++u) {
+        const int i = threadIdx.x + 256 * u, pos = min(i, DWH * DWH * (DWCG / 4) - 1) / (DWCG / 4), q = i % (DWCG / 4);
+        const int iy = ty0 - 2 + pos / DWH, ix = tx0 - 2 + pos % DWH, c = c0 + q * 4;
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c < C;
+        // branch-free: a clamped address is loaded and zeroed afterwards, so the loads of a part are issued back to back
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * C + min(c, C - 4));
+        r[u - U0] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <int U0, int U1>
+__device__ __forceinline__ void dw_store(float* xs, const f32x4 (&r)[U1 - U0]) {
+#pragma unroll
+    for (int u = U0; u < U1; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < DWH * DWH * (DWCG / 4)) *reinterpret_cast<f32x4*>(xs + (i / (DWCG / 4)) * DWPITCH + (i % (DWCG / 4)) * 4) = r[u - U0];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void dwconv5_tile_kernel(const float* __restrict__ x, const float* __restrict__ w25c, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act, int B, int H, int W, int C, int flip,
+                                                           float* __restrict__ y, int tiles_x, int tiles_y) {
+    constexpr int RS = 4, CS = 2;
+    __shared__ __attribute__((aligned(16))) float xs[DWH * DWH * DWPITCH];
+    const int tile = dw_xcd_remap(blockIdx.x, gridDim.x), c0 = blockIdx.y * DWCG;
+    const int b = tile / (tiles_x * tiles_y), ty0 = ((tile / tiles_x) % tiles_y) * DWT, tx0 = (tile % tiles_x) * DWT;
+    {
+        f32x4 r[DWLOADS];
+        dw_stage<0, DWLOADS>(x, b, ty0, tx0, c0, H, W, C, r);
+        dw_store<0, DWLOADS>(xs, r);
+    }
+    __syncthreads();
+    const int q = threadIdx.x % 8, cp = (threadIdx.x / 8) % 8, rs = threadIdx.x / 64;
+    const int c = c0 + q * 4;
+    if (c >= C) return;
+    const int oy0 = ty0 + rs * RS, ox0 = tx0 + cp * CS;
+    f32x4 a[RS][CS];
+#pragma unroll
+    for (int o = 0; o < RS; ++o)
+#pragma unroll
+        for (int k = 0; k < CS; ++k) a[o][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wprev[5];
+#pragma unroll
+    for (int jx = 0; jx < CS + 4; ++jx) {                       // (dwconv5_kernel's loops: the zero padding is in the staged tile)
+        f32x4 wk[5];
+        if (jx < 5) {
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky)
+                wk[ky] = *reinterpret_cast<const f32x4*>(w25c + (size_t)(flip ? (4 - ky) * 5 + (4 - jx) : ky * 5 + jx) * C + c);
+        }
+        f32x4 v[RS + 4];
+#pragma unroll
+        for (int ry = 0; ry < RS + 4; ++ry) v[ry] = *reinterpret_cast<const f32x4*>(xs + ((rs * RS + ry) * DWH + cp * CS + jx) * DWPITCH + q * 4);
+#pragma unroll
+        for (int ry = 0; ry < RS + 4; ++ry) {
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int o = ry - ky;
+                if (o < 0 || o >= RS) continue;
+                if (jx < 5) a[o][0] += v[ry] * wk[ky];
+                if (jx >= 1) a[o][1] += v[ry] * wprev[ky];
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) wprev[ky] = wk[ky];
+        // one patch column in registers at a time: the sums pass through an empty asm, so the products of this column are placed here (the
+        // instruction selector would otherwise put all 48 LDS reads in front of all the arithmetic: 60 spilled registers)
+#pragma unroll
+        for (int o = 0; o < RS; ++o) asm volatile("" : "+v"(a[o][0]), "+v"(a[o][1]));
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + c);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + c);
+#pragma unroll
+    for (int o = 0; o < RS; ++o)
+#pragma unroll
+        for (int k = 0; k < CS; ++k) {
+            if (oy0 + o >= H || ox0 + k >= W) continue;
+            f32x4 v = a[o][k] * sc + sh;
+            if (act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(y + (((size_t)b * H + oy0 + o) * W + ox0 + k) * C + c) = v;
+        }
+}
+
+// ... and the weight gradient: a block walks `tiles_per_blk` tiles of one 32-channel group with the 25 tap sums of every thread in registers,
+// then the 32 threads of a channel quad meet in LDS in a fixed order: part[blk][25][C] (summed over blocks by colsum_finish_kernel)
+__global__ __launch_bounds__(256, 2) void dwconv5_wgrad_tile_kernel(const float* __restrict__ x, const float* __restrict__ dz, int B, int H, int W, int C,
+                                                                 float* __restrict__ part, int tiles_total, int tiles_per_blk, int tiles_x, int tiles_y) {
+    constexpr int RS = 4, CS = 2;
+    __shared__ __attribute__((aligned(16))) float xs[DWH * DWH * DWPITCH];
+    const int c0 = blockIdx.y * DWCG;
+    const int q = threadIdx.x % 8, cp = (threadIdx.x / 8) % 8, rs = threadIdx.x / 64;
+    const int c = c0 + q * 4;
+    const bool cok = c < C;
+    f32x4 acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int t_beg = dw_xcd_remap(blockIdx.x, gridDim.x) * tiles_per_blk, t_end = min(t_beg + tiles_per_blk, tiles_total);
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int b = tile / (tiles_x * tiles_y), ty0 = ((tile / tiles_x) % tiles_y) * DWT, tx0 = (tile % tiles_x) * DWT;
+        constexpr int T1 = (DWLOADS + 2) / 3, T2 = 2 * T1 < DWLOADS ? 2 * T1 : DWLOADS;     // the tile in three parts: a part's registers are the previous part's
+        const int oy0 = ty0 + rs * RS, ox0 = tx0 + cp * CS;
+        f32x4 g[RS][CS];
+        {
+            f32x4 r[T1];
+            dw_stage<0, T1>(x, b, ty0, tx0, c0, H, W, C, r);
+            __syncthreads();                                    // the previous tile's reads are done
+            dw_store<0, T1>(xs, r);
+        }
+        {
+            f32x4 r[T2 - T1];
+            dw_stage<T1, T2>(x, b, ty0, tx0, c0, H, W, C, r);
+            dw_store<T1, T2>(xs, r);
+        }
+        {
+            f32x4 r[DWLOADS - T2];
+            dw_stage<T2, DWLOADS>(x, b, ty0, tx0, c0, H, W, C, r);
+#pragma unroll
+            for (int o = 0; o < RS; ++o)
+#pragma unroll
+                for (int k = 0; k < CS; ++k)
+                    g[o][k] = (cok && oy0 + o < H && ox0 + k < W) ? *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + oy0 + o) * W + ox0 + k) * C + c)
+                                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            dw_store<T2, DWLOADS>(xs, r);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jx = 0; jx < CS + 4; ++jx) {
+            asm volatile("" ::: "memory");                      // (this column's LDS reads stay behind the previous column's products)
+            f32x4 v[RS + 4];
+#pragma unroll
+            for (int ry = 0; ry < RS + 4; ++ry) v[ry] = *reinterpret_cast<const f32x4*>(xs + ((rs * RS + ry) * DWH + cp * CS + jx) * DWPITCH + q * 4);
+#pragma unroll
+            for (int ry = 0; ry < RS + 4; ++ry)
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int o = ry - ky;
+                    if (o < 0 || o >= RS) continue;
+                    if (jx < 5) acc[ky * 5 + jx] += g[o][0] * v[ry];
+                    if (jx >= 1) acc[ky * 5 + jx - 1] += g[o][1] * v[ry];
+                }
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {                    // (as in dwconv5_tile_kernel: this column's products stay with this column's reads)
+                if (jx < 5) asm volatile("" : "+v"(acc[ky * 5 + (jx < 5 ? jx : 0)]));
+                if (jx >= 1) asm volatile("" : "+v"(acc[ky * 5 + (jx >= 1 ? jx - 1 : 0)]));
+            }
+        }
+    }
+    // the 32 threads of a channel quad meet in LDS, five taps (one kernel row) per round: [tap][thread] quads, thread 8 t + q sums tap t of quad q
+    f32x4* red = reinterpret_cast<f32x4*>(xs);                  // [5][256] quads = 20 KB of the 57 KB tile
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        __syncthreads();
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) red[kx * 256 + threadIdx.x] = acc[ky * 5 + kx];
+        __syncthreads();
+        if (threadIdx.x < 40) {
+            const int kx = threadIdx.x / 8, qq = threadIdx.x % 8, cc = c0 + qq * 4;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) t += red[kx * 256 + k * 8 + qq];
+            if (cc < C) *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 25 + ky * 5 + kx) * C + cc) = t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- bilinear resize (NHWC)
 __device__ __forceinline__ void bil_src(int align, float ratio, int dst, int in_size, int out_size, int& i0, int& i1, float& l0,
                                         float& l1) {
@@ -2043,6 +2229,14 @@ extern "C" int codeps_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, i
 extern "C" int codeps_dwconv5x5(const float* x, const float* w25c, const float* scale, const float* shift, int act, int batch, int h,
                                 int w, int c, int flip, float* y, codeps_stream_t stream) {
     CODEPS_REQUIRE(x && w25c && y && batch > 0 && h > 0 && w > 0 && (c % 4) == 0, CODEPS_ERR_ARG, "dwconv5x5: bad arguments");
+    static const int dw_tile = getenv("CODEPS_DW_TILE") ? atoi(getenv("CODEPS_DW_TILE")) : 1;       // A/B switch: 0 = the gather kernels
+    const int tiles_x = cdiv(w, DWT), tiles_y = cdiv(h, DWT);
+    if (dw_tile && (long long)batch * tiles_x * tiles_y < (1ll << 31)) {
+        hipLaunchKernelGGL(dwconv5_tile_kernel, dim3(batch * tiles_x * tiles_y, cdiv(c, DWCG)), dim3(256), 0, (hipStream_t)stream, x, w25c, scale, shift, act,
+                           batch, h, w, c, flip, y, tiles_x, tiles_y);
+        CODEPS_CHECK_LAUNCH("dwconv5_tile_kernel");
+        return CODEPS_OK;
+    }
     hipLaunchKernelGGL(dwconv5_kernel, dim3(grid_for((long long)batch * ((h + 3) / 4) * ((w + 1) / 2) * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, w25c, scale,
                        shift, act, batch, h, w, c, flip, y);
     CODEPS_CHECK_LAUNCH("dwconv5_kernel");
@@ -2058,10 +2252,23 @@ extern "C" int codeps_dwconv5x5_wgrad(const float* x, const float* dz, int batch
     (void)rows_per_block((long long)batch * h * w, nblk);        // block count (= workspace slabs) as codeps_colsum_workspace_bytes sizes it
     CODEPS_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * 25 * c * 4, CODEPS_ERR_WORKSPACE, "dwconv5x5_wgrad: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const long long items = (long long)batch * ((h + 3) / 4) * w;  // (image, 4-row strip, column)
-    const int ipb = (int)((items + nblk - 1) / nblk);
-    hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, dz, batch, h, w, c, (float*)workspace, ipb);
-    CODEPS_CHECK_LAUNCH("dwconv5_wgrad_kernel");
+    static const int dw_tile = getenv("CODEPS_DW_TILE") ? atoi(getenv("CODEPS_DW_TILE")) : 1;       // A/B switch: 0 = the gather kernel
+    const int tiles_x = cdiv(w, DWT), tiles_y = cdiv(h, DWT);
+    const long long tiles = (long long)batch * tiles_x * tiles_y;
+    if (dw_tile && tiles < (1ll << 31)) {
+        // <= nblk slabs (the workspace's size); ~2 blocks per CU and channel group in flight, whole tiles per block
+        const int groups = cdiv(c, DWCG);
+        const int want = std::max(1, std::min<int>(nblk, std::max(1, 1024 / groups)));
+        const int tpb = (int)((tiles + want - 1) / want);
+        nblk = (int)((tiles + tpb - 1) / tpb);
+        hipLaunchKernelGGL(dwconv5_wgrad_tile_kernel, dim3(nblk, groups), dim3(256), 0, st, x, dz, batch, h, w, c, (float*)workspace, (int)tiles, tpb, tiles_x, tiles_y);
+        CODEPS_CHECK_LAUNCH("dwconv5_wgrad_tile_kernel");
+    } else {
+        const long long items = (long long)batch * ((h + 3) / 4) * w;  // (image, 4-row strip, column)
+        const int ipb = (int)((items + nblk - 1) / nblk);
+        hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(nblk, col_tiles(c)), dim3(256), 0, st, x, dz, batch, h, w, c, (float*)workspace, ipb);
+        CODEPS_CHECK_LAUNCH("dwconv5_wgrad_kernel");
+    }
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(25 * c, 4)), dim3(256), 0, st, (const float*)workspace, nblk, 25, c, dw25c, c, 0);
     CODEPS_CHECK_LAUNCH("colsum_finish_kernel");
     return CODEPS_OK;

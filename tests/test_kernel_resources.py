@@ -14,6 +14,7 @@ BUILD = os.path.join(ROOT, "codeps_amd", "csrc", "build")
 # kernels allowed to carry scratch: (name fragment, bytes per lane)
 SCRATCH_OK = {"photo_fwd_kernel": 64,          # 36 bytes at 3 waves per SIMD, measured faster than 2 waves without (photometric.hip)
               "wgrad_halo64s_kernel": 96,      # 80 bytes since round 4: the generic single-buffered body's spills (the double-buffered body the step runs has none)
+              "dwconv5_wgrad_tile_kernel": 8,  # one loop-invariant staging offset at the 256-register budget of two blocks per CU (25 tap sums x 4 channels = 100 registers)
               "match_lut_kernel": 8192}        # one thread per channel builds a 256-entry CDF + LUT in private memory (preprocess.hip, not on the step's path)
 
 
