@@ -1412,39 +1412,32 @@ __global__ __launch_bounds__(256) void guda_gather_fwd_tiled_kernel(GudaP p, int
         bil_src(0, br.rw, min(tx0 + GT_TW, p.W - 1), br.w, p.W, dummy, c_hi, fd0, fd1);
         const int ncols = c_hi - c_lo + 1;                          // <= GT_COLS (checked by the launcher)
         __syncthreads();                                            // the previous branch's reads of R are done
-        // one thread per (low-res column, channel quad of the 48): it walks the tile's 8 rows and keeps, per ky, the two Y rows of
-        // the previous output row -- consecutive output rows mostly blend the same pair (ratio <= 1/2), so a Y value is loaded once
-        for (int e = tid; e < ncols * 12; e += 256) {
-            const int k4 = e % 12, col = e / 12;
+        // one item per (output row, low-res column, channel quad of the 48): its six Y values (3 ky x 2 rows) are loaded TOGETHER and blended.
+        // (Until round 6 a thread walked the tile's 8 rows keeping the row pair of the previous output row: a sixth of the loads, but every load
+        // waited for the one before it -- 9-12 memory latencies in a row per branch, 25 us per tile and block, 2.0 TB/s of algorithmic bytes.
+        // Neighbouring rows' items read the same Y rows: the repeats hit in the L1.)
+        const int nitems = GT_TH * ncols * 12;
+#pragma unroll 2
+        for (int e = tid; e < nitems; e += 256) {
+            const int k4 = e % 12, col = (e / 12) % ncols, ty = e / (12 * ncols);
             const float* src = yb + (size_t)(c_lo + col) * 144 + k4 * 4;
-            int r0[3] = {-1, -1, -1}, r1[3] = {-1, -1, -1};
+            const int y = ty0 + ty;
             f32x4 v0[3], v1[3];
+            float l0[3], l1[3];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) v0[ky] = v1[ky] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ty = 0; ty < GT_TH; ++ty) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                const int y = ty0 + ty;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int qy = y + ky - 1;
-                    if (y >= p.H || qy < 0 || qy >= p.H) continue;               // (uniform: depends on the row only)
-                    int y0, y1; float ly0, ly1;
-                    bil_src(0, br.rh, qy, br.h, p.H, y0, y1, ly0, ly1);
-                    if (y0 != r0[ky]) {
-                        if (y0 == r1[ky]) v0[ky] = v1[ky];
-                        else v0[ky] = *reinterpret_cast<const f32x4*>(src + (size_t)y0 * br.w * 144 + ky * 48);
-                        r0[ky] = y0;
-                    }
-                    if (y1 != r1[ky]) {
-                        if (y1 == y0) v1[ky] = v0[ky];
-                        else v1[ky] = *reinterpret_cast<const f32x4*>(src + (size_t)y1 * br.w * 144 + ky * 48);
-                        r1[ky] = y1;
-                    }
-                    v += ly0 * v0[ky] + ly1 * v1[ky];
-                }
-                *reinterpret_cast<f32x4*>(R + (ty * GT_COLS + col) * GT_PITCH + k4 * 4) = v;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int qy = y + ky - 1;
+                const bool ok = y < p.H && qy >= 0 && qy < p.H;
+                int y0, y1;
+                bil_src(0, br.rh, min(max(qy, 0), p.H - 1), br.h, p.H, y0, y1, l0[ky], l1[ky]);
+                if (!ok) l0[ky] = l1[ky] = 0.f;
+                v0[ky] = *reinterpret_cast<const f32x4*>(src + (size_t)y0 * br.w * 144 + ky * 48);
+                v1[ky] = *reinterpret_cast<const f32x4*>(src + (size_t)y1 * br.w * 144 + ky * 48);
             }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) v += l0[ky] * v0[ky] + l1[ky] * v1[ky];
+            *reinterpret_cast<f32x4*>(R + (ty * GT_COLS + col) * GT_PITCH + k4 * 4) = v;
         }
         __syncthreads();
         if (oy < p.H) {
