@@ -1686,37 +1686,37 @@ static inline int col_tiles(int C) { return cdiv(C / 4, 256); }
 // channel 0 and (b != null) of frame b at channel c, zeros elsewhere -- what nchw_to_nhwc_kernel wrote with (zero_rest = 1) for a and
 // (zero_rest = 0, c_off = c) for b.  One thread per (destination pixel, 4-channel group).
 struct FrameSlabs { const float* a[16]; const float* b[16]; int b0[17]; int n; };
+// Block = (destination row bb * H + yy, a run of 256 (column, channel group) items of that row): the slab lookup and the row's addresses are
+// block-uniform scalars, a thread's own arithmetic is one small division.  (Until round 6 every thread split a 64-bit linear index with three
+// 64-bit divisions and two 15-step select chains -- ~400 instructions per 16-byte store: 122 us for the adaptation step's 8-frame batch, 2.0 TB/s.)
 __global__ __launch_bounds__(256) void frames_to_nhwc_kernel(FrameSlabs fs, int C, int H, int W, float* __restrict__ y, int Cp, int pad_l, int Wp) {
     const int groups = Cp / 4;
-    const long long total = (long long)fs.b0[16] * H * Wp * groups;            // (b0[n .. 16] = the batch total: constant index, no scratch)
-    const long long HW = (long long)H * W;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i % groups);
-        long long r = i / groups;
-        const int xd = (int)(r % Wp); r /= Wp;
-        const int yy = (int)(r % H);
-        const int bb = (int)(r / H);
-        int s = 0;
+    const int row = blockIdx.x, bb = row / H, yy = row % H;
+    int s = 0;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) s += (k < fs.n && bb >= fs.b0[k]) ? 1 : 0;
-        const float* fa = fs.a[0];
-        const float* fb = fs.b[0];
-        int bs = fs.b0[0];
+    for (int k = 1; k < 16; ++k) s += (k < fs.n && bb >= fs.b0[k]) ? 1 : 0;
+    const float* fa = fs.a[0];
+    const float* fb = fs.b[0];
+    int bs = fs.b0[0];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) if (k == s) { fa = fs.a[k]; fb = fs.b[k]; bs = fs.b0[k]; }        // (select chain: no indexed access into the by-value struct)
-        const int xs = xd - pad_l, bl = bb - bs;
+    for (int k = 1; k < 16; ++k) if (k == s) { fa = fs.a[k]; fb = fs.b[k]; bs = fs.b0[k]; }        // (select chain: no indexed access into the by-value struct)
+    const size_t HW = (size_t)H * W;
+    const size_t src_row = (size_t)(bb - bs) * C * HW + (size_t)yy * W;
+    float* dst_row = y + (size_t)row * Wp * Cp;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < Wp * groups; i += gridDim.y * 256) {
+        const int xd = i / groups, g = i - xd * groups;
+        const int xs = xd - pad_l;
         const bool in = xs >= 0 && xs < W;
-        const long long hw = (long long)yy * W + xs;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = g * 4 + e;
             float t = 0.f;
-            if (in && c < C) t = fa[((size_t)bl * C + c) * HW + hw];
-            else if (in && fb && c < 2 * C) t = fb[((size_t)bl * C + (c - C)) * HW + hw];
+            if (in && c < C) t = fa[src_row + (size_t)c * HW + xs];
+            else if (in && fb && c < 2 * C) t = fb[src_row + (size_t)(c - C) * HW + xs];
             v[e] = t;
         }
-        *reinterpret_cast<f32x4*>(y + (((size_t)bb * H + yy) * Wp + xd) * Cp + g * 4) = v;
+        *reinterpret_cast<f32x4*>(dst_row + (size_t)i * 4) = v;
     }
 }
 
@@ -1740,8 +1740,10 @@ extern "C" int codeps_frames_to_nhwc(const float* const* frames_a, const float* 
     for (int s = n_slabs + 1; s <= 16; ++s) fs.b0[s] = fs.b0[n_slabs];
     CODEPS_REQUIRE((two ? 2 : 1) * c <= c_pad, CODEPS_ERR_ARG, "frames_to_nhwc: %d channels do not fit c_pad %d", (two ? 2 : 1) * c, c_pad);
     const int wp = pad_left + w + pad_right;
-    const long long items = (long long)fs.b0[n_slabs] * h * wp * (c_pad / 4);
-    hipLaunchKernelGGL(frames_to_nhwc_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, fs, c, h, w, y, c_pad, pad_left, wp);
+    const long long rows = (long long)fs.b0[n_slabs] * h;
+    CODEPS_REQUIRE(rows < (1ll << 31), CODEPS_ERR_ARG, "frames_to_nhwc: too many rows");
+    hipLaunchKernelGGL(frames_to_nhwc_kernel, dim3((unsigned)rows, std::min(cdiv(wp * (c_pad / 4), 256), 64)), dim3(256), 0, (hipStream_t)stream, fs, c, h, w,
+                       y, c_pad, pad_left, wp);
     CODEPS_CHECK_LAUNCH("frames_to_nhwc_kernel");
     return CODEPS_OK;
 }
