@@ -1241,44 +1241,43 @@ __device__ __forceinline__ void bil_src(int align, float ratio, int dst, int in_
     l0 = 1.f - l1;
 }
 
+// Block = (output row b * Ho + oy, a run of 256 (column, channel quad) items): the row's two source rows and their weights are block-uniform
+// (until round 6 every thread split a 64-bit linear index with three 64-bit divisions: 20 launches, 0.34 ms of the adaptation step).
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho, int Wo,
                                                            int align, float rh, float rw, float* __restrict__ y, int Cy, int c_off) {
     const int G = C / 4;
-    const long long total = (long long)B * Ho * Wo * G;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i % G);
-        long long pix = i / G;
-        const int ox = (int)(pix % Wo); pix /= Wo;
-        const int oy = (int)(pix % Ho);
-        const int b = (int)(pix / Ho);
-        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
-        bil_src(align, rh, oy, H, Ho, y0, y1, ly0, ly1);
+    const int row = blockIdx.x, b = row / Ho, oy = row % Ho;
+    int y0, y1; float ly0, ly1;
+    bil_src(align, rh, oy, H, Ho, y0, y1, ly0, ly1);
+    const float* r0 = x + ((size_t)b * H + y0) * W * C;
+    const float* r1 = x + ((size_t)b * H + y1) * W * C;
+    float* dst = y + (size_t)row * Wo * Cy + c_off;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < Wo * G; i += gridDim.y * 256) {
+        const int ox = i / G, g = i - ox * G;
+        int x0, x1; float lx0, lx1;
         bil_src(align, rw, ox, W, Wo, x0, x1, lx0, lx1);
-        const float* base = x + (size_t)b * H * W * C + g * 4;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * C);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * C);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * C);
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + (size_t)x0 * C + g * 4);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + (size_t)x1 * C + g * 4);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + (size_t)x0 * C + g * 4);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + (size_t)x1 * C + g * 4);
         const f32x4 r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-        *reinterpret_cast<f32x4*>(y + (((size_t)b * Ho + oy) * Wo + ox) * Cy + c_off + g * 4) = r;
+        *reinterpret_cast<f32x4*>(dst + (size_t)ox * Cy + g * 4) = r;
     }
 }
 
 // transposed resize as a gather over INPUT pixels (deterministic): dx[i] = sum_o w(o,i) dy[o]
+// Block = (input row b * H + iy, a run of 256 (column, channel quad) items): the output rows that touch the row and their weights are
+// block-uniform; same sums in the same order as before round 6 (when every thread split a 64-bit linear index with three 64-bit divisions).
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, int Ho, int Wo,
                                                            int align, float rh, float rw, int Cy, int c_off,
                                                            float* __restrict__ dx) {
     const int G = C / 4;
-    const long long total = (long long)B * H * W * G;
     const float inv_rh = rh > 0.f ? 1.f / rh : (float)Ho, inv_rw = rw > 0.f ? 1.f / rw : (float)Wo;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i % G);
-        long long pix = i / G;
-        const int ix = (int)(pix % W); pix /= W;
-        const int iy = (int)(pix % H);
-        const int b = (int)(pix / H);
-        // output rows that can touch input row iy: src(o) in (iy-1, iy+1)  =>  o in ((iy-1.5)/r, (iy+1.5)/r) (+-1 slack)
-        const int oy_lo = max(0, (int)floorf(((float)iy - 1.5f) * inv_rh) - 1), oy_hi = min(Ho - 1, (int)ceilf(((float)iy + 1.5f) * inv_rh) + 1);
+    const int row = blockIdx.x, b = row / H, iy = row % H;
+    // output rows that can touch input row iy: src(o) in (iy-1, iy+1)  =>  o in ((iy-1.5)/r, (iy+1.5)/r) (+-1 slack)
+    const int oy_lo = max(0, (int)floorf(((float)iy - 1.5f) * inv_rh) - 1), oy_hi = min(Ho - 1, (int)ceilf(((float)iy + 1.5f) * inv_rh) + 1);
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < W * G; i += gridDim.y * 256) {
+        const int ix = i / G, g = i - ix * G;
         const int ox_lo = max(0, (int)floorf(((float)ix - 1.5f) * inv_rw) - 1), ox_hi = min(Wo - 1, (int)ceilf(((float)ix + 1.5f) * inv_rw) + 1);
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
@@ -1286,15 +1285,16 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
             bil_src(align, rh, oy, H, Ho, y0, y1, ly0, ly1);
             const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
             if (wy == 0.f) continue;
+            const float* drow = dy + ((size_t)b * Ho + oy) * Wo * Cy + c_off + g * 4;
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
                 int x0, x1; float lx0, lx1;
                 bil_src(align, rw, ox, W, Wo, x0, x1, lx0, lx1);
                 const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
                 if (wx == 0.f) continue;
-                a += (wy * wx) * *reinterpret_cast<const f32x4*>(dy + (((size_t)b * Ho + oy) * Wo + ox) * Cy + c_off + g * 4);
+                a += (wy * wx) * *reinterpret_cast<const f32x4*>(drow + (size_t)ox * Cy);
             }
         }
-        *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + iy) * W + ix) * C + g * 4) = a;
+        *reinterpret_cast<f32x4*>(dx + ((size_t)row * W + ix) * C + g * 4) = a;
     }
 }
 
@@ -1489,44 +1489,41 @@ __device__ __forceinline__ float guda_weight(int o, int q, float r, int n_low) {
     return fmaxf(0.f, 1.f - fabsf(s - (float)q));
 }
 
+// (Both passes: block = one row of the result, a run of 256 items of that row -- until round 6 every thread split a 64-bit linear index with
+// three or four 64-bit divisions in front of a 4 ... 18-term sum.)
 __global__ __launch_bounds__(256) void guda_gather_bwd_x_kernel(int B, int H, int W, int w, float rw, const float* __restrict__ dout,
                                                                 float* __restrict__ tmp) {
-    const long long total = (long long)B * H * w * 12;
     const float inv_rw = 1.f / rw;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i & 3);
-        long long r = i >> 2;
-        const int kx = (int)(r % 3); r /= 3;
-        const int qx = (int)(r % w); r /= w;                     // r = b * H + py
+    const size_t r = blockIdx.x;                                  // b * H + py
+    const float* drow = dout + ((r * W) << 4);
+    float* trow = tmp + r * (size_t)w * 48;                        // tmp[b][py][qx][kx][16]
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < w * 12; i += gridDim.y * 256) {
+        const int g = i & 3, q3 = i >> 2, qx = q3 / 3, kx = q3 - qx * 3;
         int lo, hi;
         guda_range(qx, inv_rw, W, lo, hi);
-        const float* row = dout + (((size_t)r * W) << 4) + g * 4;
+        const float* row = drow + g * 4;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         for (int ox = max(lo, kx - 1); ox <= min(hi, W - 2 + kx); ++ox)          // px = ox - (kx - 1) in [0, W)
             a += guda_weight(ox, qx, rw, w) * *reinterpret_cast<const f32x4*>(row + ((size_t)(ox - kx + 1) << 4));
-        *reinterpret_cast<f32x4*>(tmp + (i << 2)) = a;           // tmp[b][py][qx][kx][16] in the enumeration order
+        *reinterpret_cast<f32x4*>(trow + ((size_t)i << 2)) = a;
     }
 }
 
 __global__ __launch_bounds__(256) void guda_gather_bwd_y_kernel(int B, int H, int h, int w, float rh, const float* __restrict__ tmp,
                                                                 float* __restrict__ dy) {
-    const long long total = (long long)B * h * w * 36;
     const float inv_rh = 1.f / rh;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i & 3);
-        long long r = i >> 2;
-        const int tap = (int)(r % 9); r /= 9;
-        const int qx = (int)(r % w); r /= w;
-        const int qy = (int)(r % h);
-        const int b = (int)(r / h);
-        const int ky = tap / 3, kx = tap % 3;
-        int lo, hi;
-        guda_range(qy, inv_rh, H, lo, hi);
+    const int rowi = blockIdx.x, b = rowi / h, qy = rowi % h;
+    int lo, hi;
+    guda_range(qy, inv_rh, H, lo, hi);
+    float* yrow = dy + (size_t)rowi * w * 144;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < w * 36; i += gridDim.y * 256) {
+        const int g = i & 3, q9 = i >> 2, qx = q9 / 9, tap = q9 - qx * 9;
+        const int ky = tap / 3, kx = tap - ky * 3;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         for (int oy = max(lo, ky - 1); oy <= min(hi, H - 2 + ky); ++oy)
             a += guda_weight(oy, qy, rh, h) *
                  *reinterpret_cast<const f32x4*>(tmp + (((((size_t)b * H + (oy - ky + 1)) * w + qx) * 3 + kx) << 4) + g * 4);
-        *reinterpret_cast<f32x4*>(dy + ((((size_t)b * h + qy) * w + qx) * 9 + tap) * 16 + g * 4) = a;
+        *reinterpret_cast<f32x4*>(yrow + ((size_t)i << 2)) = a;
     }
 }
 
@@ -2286,7 +2283,8 @@ extern "C" int codeps_bilinear_fwd(const float* x, int batch, int h, int w, int 
                    CODEPS_ERR_ARG, "bilinear_fwd: bad arguments");
     float rh, rw;
     resize_ratios(align_corners, h, w, out_h, out_w, rh, rw);
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for((long long)batch * out_h * out_w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x,
+    CODEPS_REQUIRE((long long)batch * out_h < (1ll << 31), CODEPS_ERR_ARG, "bilinear_fwd: too many rows");
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3((unsigned)(batch * out_h), std::min(cdiv(out_w * (c / 4), 256), 64)), dim3(256), 0, (hipStream_t)stream, x,
                        batch, h, w, c, out_h, out_w, align_corners, rh, rw, y, y_c, y_c_off);
     CODEPS_CHECK_LAUNCH("bilinear_fwd_kernel");
     return CODEPS_OK;
@@ -2299,7 +2297,8 @@ extern "C" int codeps_bilinear_bwd(const float* dy, int batch, int h, int w, int
                    CODEPS_ERR_ARG, "bilinear_bwd: bad arguments (only up-sampling is differentiated)");
     float rh, rw;
     resize_ratios(align_corners, h, w, out_h, out_w, rh, rw);
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long long)batch * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, dy, batch, h,
+    CODEPS_REQUIRE((long long)batch * h < (1ll << 31), CODEPS_ERR_ARG, "bilinear_bwd: too many rows");
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)(batch * h), std::min(cdiv(w * (c / 4), 256), 64)), dim3(256), 0, (hipStream_t)stream, dy, batch, h,
                        w, c, out_h, out_w, align_corners, rh, rw, y_c, y_c_off, dx);
     CODEPS_CHECK_LAUNCH("bilinear_bwd_kernel");
     return CODEPS_OK;
@@ -2341,9 +2340,9 @@ extern "C" int codeps_guda_gather_bwd(const float* grad_out, int batch, int h, i
     CODEPS_REQUIRE(workspace && workspace_bytes >= codeps_guda_gather_bwd_workspace_bytes(batch, h, bw), CODEPS_ERR_WORKSPACE,
                    "guda_gather_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(guda_gather_bwd_x_kernel, dim3(grid_for((long long)batch * h * bw * 12)), dim3(256), 0, st, batch, h, w, bw,
+    hipLaunchKernelGGL(guda_gather_bwd_x_kernel, dim3((unsigned)(batch * h), std::min(cdiv(bw * 12, 256), 64)), dim3(256), 0, st, batch, h, w, bw,
                        (float)bw / (float)w, grad_out, (float*)workspace);
-    hipLaunchKernelGGL(guda_gather_bwd_y_kernel, dim3(grid_for((long long)batch * bh * bw * 36)), dim3(256), 0, st, batch, h, bh, bw,
+    hipLaunchKernelGGL(guda_gather_bwd_y_kernel, dim3((unsigned)(batch * bh), std::min(cdiv(bw * 36, 256), 64)), dim3(256), 0, st, batch, h, bh, bw,
                        (float)bh / (float)h, (const float*)workspace, grad_y);
     CODEPS_CHECK_LAUNCH("guda_gather_bwd kernels");
     return CODEPS_OK;
