@@ -42,6 +42,18 @@ fi
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_k -o r -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --graph 0 > /dev/null 2>&1
 python3 tools/pmc_kernels.py gpurun_out/pmc_k photo_ pyramid wgrad_halo64s conv_halo3 conv_igemm chain_ bn_ > $OUT/${R}_pmc_kernels.json 2>/dev/null
 rm -rf gpurun_out/pmc_k
+# 7. the non-convolution kernels against the bytes they move, the chained 1x1 pair per stage, where the step does not fill the chip
+python3 tools/chain_widths.py --json $OUT/${R}_chain_widths.json > /dev/null 2>&1
+python3 tools/bn_apply_rate.py --json $OUT/${R}_bn_apply_rate.json > /dev/null 2>&1
+python3 tools/dwconv_rate.py --json $OUT/${R}_dwconv_rate.json > /dev/null 2>&1
+python3 tools/guda_rate.py --json $OUT/${R}_guda_rate.json > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_cp -o r -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>&1
+python3 tools/critical_path.py gpurun_out/trace_cp > $OUT/${R}_critical_path.json 2>/dev/null
+rm -rf gpurun_out/trace_cp
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c1 -o r -- python3 bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>&1
+cp $(find gpurun_out/prof_c1 -name "*kernel_stats.csv" | head -1) $OUT/${R}_configs1_kernel_stats.csv
+rm -rf gpurun_out/prof_c1
+python3 tools/aten_audit.py --mode train > $OUT/${R}_aten_audit_train.txt 2>/dev/null
 python3 tools/aten_audit.py > $OUT/${R}_aten_audit.txt 2>/dev/null
 python3 tools/conv_layers.py --json $OUT/${R}_conv_layers.json > $OUT/${R}_conv_layers.txt 2>/dev/null
 ls -la $OUT
