@@ -1387,7 +1387,10 @@ __global__ __launch_bounds__(256) void guda_gather_fwd_kernel(GudaP p, const flo
 // blends HORIZONTALLY: out += sum_kx (wx0 R[ty][x0][kx] + wx1 R[ty][x1][kx]) at position x + kx - 1 (outside the image: nothing).
 // 6 Y loads per R element instead of 36 per output pixel and channel quad; column pitch 52 floats keeps the 16-byte LDS reads of
 // neighbouring pixels on different banks.  Rounding differs from the direct form in the order of the blends only.
-constexpr int GT_TH = 8, GT_TW = 64, GT_COLS = 36, GT_PITCH = 52;
+#ifndef CODEPS_GUDA_TW
+#define CODEPS_GUDA_TW 32            // A/B builds: 64 = the 8 x 64 tile of rounds 2-5 (60 KB of LDS, two blocks per CU)
+#endif
+constexpr int GT_TH = 8, GT_TW = CODEPS_GUDA_TW, GT_PXT = GT_TW / 32, GT_COLS = GT_TW / 2 + 4, GT_PITCH = 52;    // 8 x 32: 33 KB, four blocks per CU
 __global__ __launch_bounds__(256) void guda_gather_fwd_tiled_kernel(GudaP p, int tiles_x, int tiles_y, const float* __restrict__ base,
                                                                     float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float R[GT_TH * GT_COLS * GT_PITCH];
@@ -1395,11 +1398,11 @@ __global__ __launch_bounds__(256) void guda_gather_fwd_tiled_kernel(GudaP p, int
     const int tile = blockIdx.x;
     const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
     const int ty0 = (tr / tiles_x) * GT_TH, tx0 = (tr % tiles_x) * GT_TW;
-    const int prow = tid >> 5, px0 = (tid & 31) * 2;               // this thread's two pixels: row ty0 + prow, columns tx0 + px0, + 1
+    const int prow = tid >> 5, px0 = (tid & 31) * GT_PXT;          // this thread's pixel(s): row ty0 + prow, columns tx0 + px0 (+ 1)
     const int oy = ty0 + prow;
-    f32x4 acc[2][4];
+    f32x4 acc[GT_PXT][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < GT_PXT; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < p.nb; ++k) {
@@ -1442,7 +1445,7 @@ __global__ __launch_bounds__(256) void guda_gather_fwd_tiled_kernel(GudaP p, int
         __syncthreads();
         if (oy < p.H) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < GT_PXT; ++j) {
                 const int ox = tx0 + px0 + j;
                 if (ox >= p.W) continue;
 #pragma unroll
@@ -1462,7 +1465,7 @@ __global__ __launch_bounds__(256) void guda_gather_fwd_tiled_kernel(GudaP p, int
     }
     if (oy < p.H) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < GT_PXT; ++j) {
             const int ox = tx0 + px0 + j;
             if (ox >= p.W) continue;
             const size_t o = (((size_t)b * p.H + oy) * p.W + ox) << 4;

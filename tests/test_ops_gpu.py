@@ -259,11 +259,13 @@ def test_guda_fusion_matches_concat_conv(h, w, b):
     assert rel_err(db.grad.cpu(), rb.grad) < 1e-5
 
 
-def test_dwconv5x5():
+@pytest.mark.parametrize("b,c,h,w", [(2, 144, 13, 17), (2, 128, 40, 70), (1, 320, 33, 16), (3, 32, 16, 16), (1, 36, 48, 50), (5, 64, 5, 37)])
+def test_dwconv5x5(b, c, h, w):
+    """Depthwise 5x5 (models/instance_head.py:38-46) on the LDS-tile kernels: one tile, several tiles with ragged edges, channel counts that
+    end inside a 32-channel block, more tiles than one block of the weight gradient takes."""
     F = _F()
-    g = torch.Generator().manual_seed(9)
-    c = 144
-    x = torch.randn(2, c, 13, 17, generator=g)
+    g = torch.Generator().manual_seed(9 + c + h)
+    x = torch.randn(b, c, h, w, generator=g)
     wt = torch.randn(c, 1, 5, 5, generator=g) * 0.2
     sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
     rx, rw = x.double().requires_grad_(True), wt.double().requires_grad_(True)
