@@ -106,6 +106,44 @@ def test_in_affine_apply_equals_the_apply_pass():
     assert torch.equal(rm2, rm3) and torch.equal(rv2, rv3)
 
 
+class _OneRank:
+    """SyncBatchNormReducer's interface on a 'world' of one rank: the cross-rank branch of F.batch_norm_train (all-gather packet ->
+    codeps_bn_sync_combine -> apply), without a process group."""
+
+    def gather(self, packet):
+        return packet.contiguous().unsqueeze(0).clone()
+
+    def sum(self, sums):
+        return sums
+
+
+@pytest.mark.parametrize("groups", [None, [(0, 1), (1, 3)]])
+def test_deferred_apply_under_sync_batchnorm(groups):
+    """SyncBatchNorm (misc/train_utils.py:50-51): the statistics are combined across ranks, the running statistics are updated by the combine
+    kernel, and the apply pass -- deferred or not -- sees the combined (mean, invstd): same bits either way, forward and backward."""
+    from codeps_amd import functional as F
+    g = torch.Generator().manual_seed(12)
+    b, h, w, c, co = 3, 32, 64, 128, 64
+    res = []
+    for defer in (False, True):
+        x = torch.randn(b, h, w, 32, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+        w1 = (torch.randn(c, 32, 1, 1, generator=torch.Generator().manual_seed(2)) * 0.2).to(DEV).requires_grad_(True)
+        w2 = (torch.randn(co, c, 1, 1, generator=torch.Generator().manual_seed(3)) * 0.1).to(DEV).requires_grad_(True)
+        gamma = torch.full((c,), 1.3, device=DEV, requires_grad=True)
+        beta = torch.full((c,), -0.1, device=DEV, requires_grad=True)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        z = F.conv2d(x, w1, bn_stats=True)
+        y = F.batch_norm_train(z, gamma, beta, rm, rv, 0.1, 1e-5, act="relu", reduce_fn=_OneRank(), groups=groups, defer=defer)
+        assert (getattr(y, "_codeps_defer", None) is not None) == defer
+        out = F.conv2d(y, w2, exclusive=True)
+        out.backward(torch.randn(out.shape, generator=torch.Generator().manual_seed(4)).to(DEV))
+        torch.cuda.synchronize()
+        res.append((out.detach(), rm, rv, x.grad, w1.grad, w2.grad, gamma.grad, beta.grad))
+    for a, bb in zip(*res):
+        assert torch.equal(a, bb), float((a - bb).abs().max())
+    del g
+
+
 def test_a_deferred_tensor_refuses_a_fork():
     from codeps_amd import functional as F
     from codeps_amd._lib import CodepsHipError
