@@ -31,11 +31,22 @@ __device__ __forceinline__ int reflect1(int i, int n) {
 }
 
 // x [B][H][W][16] halo tile of (y0 - 1 .., x0 - 1 ..) into LDS, reflected at the image border
+// (all loads of a thread are issued into registers before the first LDS store: as a load -> store loop every element waited for its own
+// memory latency, six in a row per tile -- disp_head_dw_kernel spent 129 us on 214 MB)
 __device__ __forceinline__ void load_halo(const float* __restrict__ x, int b, int H, int W, int y0, int x0, f32x4* xs) {
-    for (int i = threadIdx.x; i < HPIX * C4; i += 256) {
+    constexpr int NL = (HPIX * C4 + 255) / 256;
+    f32x4 r[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int i = min((int)threadIdx.x + 256 * u, HPIX * C4 - 1);
         const int px = i / C4, q = i % C4;
         const int iy = reflect1(y0 - 1 + px / HW, H), ix = reflect1(x0 - 1 + px % HW, W);
-        xs[px * PITCH4 + q] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + q * 4);
+        r[u] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + q * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < HPIX * C4) xs[(i / C4) * PITCH4 + i % C4] = r[u];
     }
 }
 

@@ -44,13 +44,24 @@ __global__ __launch_bounds__(256) void upconv16_collapse_kernel(const float* __r
 }
 
 // source halo tile (rows sy0 - 1 .., columns sx0 - 1 ..), zero outside the image
+// (round 6: every staging loop of this file issues ALL its loads -- from clamped addresses, zeroed afterwards -- into registers before the first
+// LDS store.  As `if (inside) v = load; store` loops each element waited for its own memory latency: 12 in a row per tile in the data
+// gradient, 8 + 3 in the weight gradient -- 140 / 104 us per launch for 300 / 250 MB.)
 __device__ __forceinline__ void load_src_halo(const float* __restrict__ x, int b, int Hs, int Ws, int sy0, int sx0, f32x4* xs) {
-    for (int i = threadIdx.x; i < XPIX * 4; i += 256) {
+    constexpr int NL = (XPIX * 4 + 255) / 256;
+    f32x4 r[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int i = min((int)threadIdx.x + 256 * u, XPIX * 4 - 1);
         const int px = i >> 2, q = i & 3;
         const int iy = sy0 - 1 + px / XW, ix = sx0 - 1 + px % XW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < Hs && ix >= 0 && ix < Ws) v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * Hs + iy) * Ws + ix) * C + q * 4);
-        xs[px * P4 + q] = v;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * Hs + min(max(iy, 0), Hs - 1)) * Ws + min(max(ix, 0), Ws - 1)) * C + q * 4);
+        r[u] = (iy >= 0 && iy < Hs && ix >= 0 && ix < Ws) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < XPIX * 4) xs[(i >> 2) * P4 + (i & 3)] = r[u];
     }
 }
 
@@ -125,12 +136,22 @@ __global__ __launch_bounds__(256) void upconv16_dgrad_kernel(const float* __rest
     float* os = smem + ZPIX * P4 * 4;                  // [SH x SW source pixels][P4 * 4] output staging
     const int b = blockIdx.y, sy0 = (blockIdx.x / tiles_x) * SH, sx0 = (blockIdx.x % tiles_x) * SW;
     const int H = 2 * Hs, W = 2 * Ws;
-    for (int idx = threadIdx.x; idx < ZPIX * 4; idx += 256) {
-        const int p = idx >> 2, q = idx & 3;
-        const int oy = 2 * (sy0 - 1) + p / ZW, ox = 2 * (sx0 - 1) + p % ZW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (oy >= 0 && oy < H && ox >= 0 && ox < W) v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + oy) * W + ox) * C + q * 4);
-        zs[p * P4 + q] = v;
+    {
+        constexpr int NL = (ZPIX * 4 + 255) / 256;
+        f32x4 r[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = min((int)threadIdx.x + 256 * u, ZPIX * 4 - 1);
+            const int p = idx >> 2, q = idx & 3;
+            const int oy = 2 * (sy0 - 1) + p / ZW, ox = 2 * (sx0 - 1) + p % ZW;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + min(max(oy, 0), H - 1)) * W + min(max(ox, 0), W - 1)) * C + q * 4);
+            r[u] = (oy >= 0 && oy < H && ox >= 0 && ox < W) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            if (idx < ZPIX * 4) zs[(idx >> 2) * P4 + (idx & 3)] = r[u];
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, i = lane >> 4;
     f32x4 bf[16];                                       // B[k = co = 4 i + j][n = ci = m] = Wc[class][tap][ci][co]: one 16-byte load per (class, tap)
@@ -208,14 +229,25 @@ __global__ __launch_bounds__(256) void upconv16_wgrad_kernel(const float* __rest
         const int b = tile / (tiles_y * tiles_x), tr = tile % (tiles_y * tiles_x);
         const int sy0 = (tr / tiles_x) * SH, sx0 = (tr % tiles_x) * SW;
         __syncthreads();
-        load_src_halo(x, b, Hs, Ws, sy0, sx0, xs);
-        for (int idx = threadIdx.x; idx < OPIX * 4; idx += 256) {
-            const int p = idx >> 2, q = idx & 3;
-            const int oy = 2 * sy0 + p / OW, ox = 2 * sx0 + p % OW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < H && ox < W) v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + oy) * W + ox) * C + q * 4);
-            float* d = zs + p * 17 + q * 4;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        {
+            static_assert((OPIX * 4) % 256 == 0, "whole passes");
+            constexpr int NL = OPIX * 4 / 256;
+            f32x4 r[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int idx = threadIdx.x + 256 * u;
+                const int p = idx >> 2, q = idx & 3;
+                const int oy = 2 * sy0 + p / OW, ox = 2 * sx0 + p % OW;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(dz + (((size_t)b * H + min(oy, H - 1)) * W + min(ox, W - 1)) * C + q * 4);
+                r[u] = (oy < H && ox < W) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            load_src_halo(x, b, Hs, Ws, sy0, sx0, xs);
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int idx = threadIdx.x + 256 * u;
+                float* d = zs + (idx >> 2) * 17 + (idx & 3) * 4;
+                d[0] = r[u][0]; d[1] = r[u][1]; d[2] = r[u][2]; d[3] = r[u][3];
+            }
         }
         __syncthreads();
 #pragma unroll 2
