@@ -1506,8 +1506,16 @@ __global__ __launch_bounds__(256) void guda_gather_bwd_x_kernel(int B, int H, in
         guda_range(qx, inv_rw, W, lo, hi);
         const float* row = drow + g * 4;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int ox = max(lo, kx - 1); ox <= min(hi, W - 2 + kx); ++ox)          // px = ox - (kx - 1) in [0, W)
-            a += guda_weight(ox, qx, rw, w) * *reinterpret_cast<const f32x4*>(row + ((size_t)(ox - kx + 1) << 4));
+        // four terms' loads in flight at a time (a `for (ox ...) a += w * load` loop waits for every load in turn: 4 ... 18 memory latencies
+        // per item); the terms are added in the same order
+        const int o0 = max(lo, kx - 1), o1 = min(hi, W - 2 + kx);               // px = ox - (kx - 1) in [0, W)
+        for (int ob = o0; ob <= o1; ob += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(row + ((size_t)(min(ob + u, o1) - kx + 1) << 4));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (ob + u <= o1) a += guda_weight(ob + u, qx, rw, w) * v[u];
+        }
         *reinterpret_cast<f32x4*>(trow + ((size_t)i << 2)) = a;
     }
 }
@@ -1523,9 +1531,15 @@ __global__ __launch_bounds__(256) void guda_gather_bwd_y_kernel(int B, int H, in
         const int g = i & 3, q9 = i >> 2, qx = q9 / 9, tap = q9 - qx * 9;
         const int ky = tap / 3, kx = tap - ky * 3;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int oy = max(lo, ky - 1); oy <= min(hi, H - 2 + ky); ++oy)
-            a += guda_weight(oy, qy, rh, h) *
-                 *reinterpret_cast<const f32x4*>(tmp + (((((size_t)b * H + (oy - ky + 1)) * w + qx) * 3 + kx) << 4) + g * 4);
+        const int o0 = max(lo, ky - 1), o1 = min(hi, H - 2 + ky);
+        for (int ob = o0; ob <= o1; ob += 4) {                  // (four loads in flight, as in the x pass)
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[u] = *reinterpret_cast<const f32x4*>(tmp + (((((size_t)b * H + (min(ob + u, o1) - ky + 1)) * w + qx) * 3 + kx) << 4) + g * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (ob + u <= o1) a += guda_weight(ob + u, qy, rh, h) * v[u];
+        }
         *reinterpret_cast<f32x4*>(yrow + ((size_t)i << 2)) = a;
     }
 }
