@@ -35,17 +35,28 @@ __global__ __launch_bounds__(256) void item_sum_kernel(const float* __restrict__
     const float* px = x + (size_t)b * HW;
     const float* py = y ? y + (size_t)b * HW : nullptr;
     float a = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += nblk * 256) a += py ? px[i] * py[i] : px[i];
+    if ((HW & 3) == 0) {                                        // 16-byte loads (the planes start at multiples of HW floats)
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(px);
+        const f32x4* q4 = reinterpret_cast<const f32x4*>(py);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += nblk * 256) {
+            const f32x4 v = q4 ? p4[i] * q4[i] : p4[i];
+            a += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += nblk * 256) a += py ? px[i] * py[i] : px[i];
+    }
     const float t = block_sum<256>(a, red);
     if (threadIdx.x == 0) part[b * nblk + blockIdx.x] = t;
 }
 
-__global__ void item_finish_kernel(const float* __restrict__ part, int nblk, float scale, float* __restrict__ out) {
-    // one thread per item (tiny)
+__global__ __launch_bounds__(64) void item_finish_kernel(const float* __restrict__ part, int nblk, float scale, float* __restrict__ out) {
+    // one wave per item: lane l adds partials l, l + 64, ... in order, the lanes meet in a fixed-order xor tree
     const int b = blockIdx.x;
     float a = 0.f;
-    for (int i = 0; i < nblk; ++i) a += part[b * nblk + i];
-    out[b] = a * scale;
+    for (int i = threadIdx.x; i < nblk; i += 64) a += part[b * nblk + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (threadIdx.x == 0) out[b] = a * scale;
 }
 
 __device__ __forceinline__ float img_grad_w(const float* __restrict__ img, int HW, int i, int j) {
@@ -596,9 +607,9 @@ extern "C" int codeps_smoothness_fwd(const float* img, const float* disp, int ba
     CODEPS_REQUIRE(workspace_bytes >= codeps_loss_workspace_bytes((long long)batch * h * w), CODEPS_ERR_WORKSPACE, "smoothness_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
-    const int HW = h * w, nb = std::min(64, cdiv(HW, 256));
+    const int HW = h * w, nb = std::min(256, cdiv(HW, 1024));
     hipLaunchKernelGGL(item_sum_kernel, dim3(nb, batch), dim3(256), 0, st, disp, (const float*)nullptr, HW, nb, part);
-    hipLaunchKernelGGL(item_finish_kernel, dim3(batch), dim3(1), 0, st, (const float*)part, nb, 1.f / (float)HW, mean_disp);
+    hipLaunchKernelGGL(item_finish_kernel, dim3(batch), dim3(64), 0, st, (const float*)part, nb, 1.f / (float)HW, mean_disp);
     CODEPS_CHECK_LAUNCH("item_sum_kernel");
     const int nblk = blocks_for((long long)batch * HW);
     float* part2 = part + (size_t)RB * 32;
@@ -619,11 +630,11 @@ extern "C" int codeps_smoothness_bwd(const float* img, const float* disp, const 
     float* g = (float*)workspace;
     float* part = (float*)((char*)workspace + align_up((size_t)N * 4, 256));
     float* gdot = part + (size_t)RB * 32;
-    const int HW = h * w, nb = std::min(64, cdiv(HW, 256));
+    const int HW = h * w, nb = std::min(256, cdiv(HW, 1024));
     const float wx = (float)(1.0 / ((double)batch * h * (w - 1))), wy = (float)(1.0 / ((double)batch * (h - 1) * w));
     hipLaunchKernelGGL(smooth_bwd_g_kernel, dim3(blocks_for(N)), dim3(256), 0, st, img, disp, mean_disp, batch, h, w, wx, wy, g);
     hipLaunchKernelGGL(item_sum_kernel, dim3(nb, batch), dim3(256), 0, st, (const float*)g, disp, HW, nb, part);
-    hipLaunchKernelGGL(item_finish_kernel, dim3(batch), dim3(1), 0, st, (const float*)part, nb, 1.f, gdot);
+    hipLaunchKernelGGL(item_finish_kernel, dim3(batch), dim3(64), 0, st, (const float*)part, nb, 1.f, gdot);
     hipLaunchKernelGGL(smooth_bwd_apply_kernel, dim3(blocks_for(N)), dim3(256), 0, st, (const float*)g, mean_disp, (const float*)gdot, grad_loss,
                        batch, HW, grad_disp);
     CODEPS_CHECK_LAUNCH("smooth_bwd kernels");
