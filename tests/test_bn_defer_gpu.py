@@ -144,6 +144,28 @@ def test_deferred_apply_under_sync_batchnorm(groups):
     del g
 
 
+def test_c_abi_refuses_shapes_it_does_not_serve():
+    """codeps_conv2d_fwd_in / _wgrad_in on a shape codeps_conv2d_in_affine_ok rejects: an error code and a message, no launch."""
+    from codeps_amd import _lib
+    lib = _lib.lib()
+    b, h, w, c, co = 1, 16, 16, 64, 64
+    x = torch.zeros(b, h, w, c, device=DEV)
+    y = torch.zeros(b, h, w, co, device=DEV)
+    tab = torch.zeros(b, 4, c, device=DEV)
+    wf = torch.zeros(lib.codeps_conv2d_packed_weight_floats(co, c, 3, 3, 0), device=DEV)
+    d3 = _lib.ConvDesc(b, h, w, c, 0, 0, co, h, w, 3, 3, 1, 1, 0, 0, 1, 1, 0, 0)
+    rc = lib.codeps_conv2d_fwd_in(ctypes.byref(d3), _lib.ptr(x), _lib.ptr(tab), _lib.ptr(wf), None, None, None, _lib.ptr(y), None, 0, None, _lib.stream_ptr())
+    assert rc != 0 and b"in_affine_ok" in lib.codeps_last_error()
+    dw = torch.zeros(co, c, 3, 3, device=DEV)
+    ws = torch.zeros(1 << 20, device=DEV)
+    rc = lib.codeps_conv2d_wgrad_in(ctypes.byref(d3), _lib.ptr(x), _lib.ptr(tab), _lib.ptr(y), _lib.ptr(dw), co, c, 0, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    assert rc != 0 and b"in_affine_ok" in lib.codeps_last_error()
+    d1 = _lib.ConvDesc(b, h, w, c, 0, 0, co, h, w, 1, 1, 1, 0, 0, 0, 1, 0, 0, 0)          # 256 pixels per image: served
+    assert lib.codeps_conv2d_in_affine_ok(ctypes.byref(d1), 0) == 1
+    d1s = _lib.ConvDesc(b, 2 * h, 2 * w, c, 0, 0, co, h, w, 1, 1, 2, 0, 0, 0, 2, 0, 0, 0)  # stride 2 (a down-sampling shortcut): not served
+    assert lib.codeps_conv2d_in_affine_ok(ctypes.byref(d1s), 0) == 0 and lib.codeps_conv2d_in_affine_ok(ctypes.byref(d1s), 1) == 0
+
+
 def test_a_deferred_tensor_refuses_a_fork():
     from codeps_amd import functional as F
     from codeps_amd._lib import CodepsHipError
