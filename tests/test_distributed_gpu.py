@@ -224,3 +224,25 @@ def test_two_ranks_on_one_gpu_complete_with_default_flags():
     sg = c["grad_allreduce_segments"]
     assert sg["front_mb"] > 0 and sg["back_mb"] > 0 and abs(sg["front_mb"] + sg["back_mb"] - c["grad_allreduce_mb"]) < 0.2
     assert sg["steps_with_the_front_overlapped"] >= d["steps"]
+
+
+def test_two_ranks_pretraining_step_with_sync_batchnorm_and_deferred_apply():
+    """`--mode train` (BASELINE configs[1] / configs[4]: every BatchNorm in train mode, SyncBatchNorm across the ranks,
+    misc/train_utils.py:50-51) on two gloo ranks: the bottlenecks' bn2 and the instance head's depthwise stages leave their apply pass to
+    the 1x1 consumer (F.batch_norm_train(defer=True)) while their statistics cross the ranks -- the step completes with finite losses on
+    both settings of CODEPS_BN_DEFER and reports the same collectives."""
+    res = {}
+    for defer in ("1", "0"):
+        env = dict(os.environ, CODEPS_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CODEPS_BN_DEFER=defer)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "2", "--warmup", "1",
+               "--dist-backend", "gloo", "--encoder", "50", "--height", "128", "--width", "256", "--per-gpu-batch", "2", "--no-cpu-baseline",
+               "--no-roofline", "--no-secondary"]
+        out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["value"] > 0 and d["value"] == d["value"]
+        res[defer] = d["comm"]
+    assert res["1"]["syncbn_allgathers_per_step"] == res["0"]["syncbn_allgathers_per_step"] > 50       # ResNet-50's 53 layers + the heads'
+    assert res["1"]["syncbn_allreduces_per_step"] == res["0"]["syncbn_allreduces_per_step"]
+
