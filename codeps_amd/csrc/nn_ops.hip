@@ -1544,6 +1544,58 @@ __global__ __launch_bounds__(256) void guda_gather_bwd_y_kernel(int B, int H, in
     }
 }
 
+// Both passes in ONE launch (round 6): a block owns TQ x TX low-resolution outputs (all nine taps), runs the x pass for the <= (TQ + 1) s + 6
+// full-resolution rows they touch into LDS (T[row][qx][kx][16]) and the y pass from there -- the [B][H][w][3][16] intermediate (151 MB at
+// 1/2 resolution and B = 3) is neither written nor read back; the rows two vertically neighbouring blocks share are computed twice (x 1.4 ...
+// 2 of the x pass, whose reads hit the L2).  Same terms in the same order as the two-pass form: bit-identical.
+template <int TX>
+__global__ __launch_bounds__(256) void guda_gather_bwd_fused_kernel(int B, int H, int W, int h, int w, float rh, float rw, int TQ, int tiles_x, int tiles_y,
+                                                                    const float* __restrict__ dout, float* __restrict__ dy) {
+    extern __shared__ __attribute__((aligned(16))) float T[];       // [rows][TX][3][16]
+    const float inv_rh = 1.f / rh, inv_rw = 1.f / rw;
+    const int tile = blockIdx.x;
+    const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
+    const int qy0 = (tr / tiles_x) * TQ, qx0 = (tr % tiles_x) * TX;
+    int lo0, hi0, lo1, hi1;
+    guda_range(qy0, inv_rh, H, lo0, hi0);
+    guda_range(min(qy0 + TQ, h) - 1, inv_rh, H, lo1, hi1);
+    const int py_lo = max(lo0 - 1, 0), py_hi = min(hi1 + 1, H - 1), nrows = py_hi - py_lo + 1;
+    // x pass: T[r][qxl][kx] = sum_ox wx(ox; qx) dout[py_lo + r][ox - kx + 1]
+    for (int e = threadIdx.x; e < nrows * TX * 12; e += 256) {
+        const int g = e & 3, q3 = e >> 2, kx = q3 % 3, t = q3 / 3, qxl = t % TX, r = t / TX;
+        const int qx = qx0 + qxl;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (qx < w) {
+            int lo, hi;
+            guda_range(qx, inv_rw, W, lo, hi);
+            const float* row = dout + ((((size_t)b * H + py_lo + r) * W) << 4) + g * 4;
+            const int o0 = max(lo, kx - 1), o1 = min(hi, W - 2 + kx);
+            for (int ob = o0; ob <= o1; ob += 4) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(row + ((size_t)(min(ob + u, o1) - kx + 1) << 4));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (ob + u <= o1) a += guda_weight(ob + u, qx, rw, w) * v[u];
+            }
+        }
+        *reinterpret_cast<f32x4*>(T + ((size_t)e << 2)) = a;         // (e enumerates [r][qxl][kx][g] in T's order)
+    }
+    __syncthreads();
+    // y pass: dy[qy][qx][ky][kx] = sum_oy wy(oy; qy) T[oy - ky + 1 - py_lo][qxl][kx]
+    for (int e = threadIdx.x; e < TQ * TX * 36; e += 256) {
+        const int g = e & 3, q9 = e >> 2, tap = q9 % 9, t = q9 / 9, qxl = t % TX, qyl = t / TX;
+        const int qy = qy0 + qyl, qx = qx0 + qxl;
+        if (qy >= h || qx >= w) continue;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        int lo, hi;
+        guda_range(qy, inv_rh, H, lo, hi);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = max(lo, ky - 1); oy <= min(hi, H - 2 + ky); ++oy)
+            a += guda_weight(oy, qy, rh, h) * *reinterpret_cast<const f32x4*>(T + ((((oy - ky + 1 - py_lo) * TX + qxl) * 3 + kx) << 4) + g * 4);
+        *reinterpret_cast<f32x4*>(dy + ((((size_t)b * h + qy) * w + qx) * 9 + tap) * 16 + g * 4) = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------- channel softmax / sigmoid-depth
 // x, y: [M][Cp] with C real channels (padding channels of y are written as 0)
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, long long M, int C, int Cp,
@@ -2357,6 +2409,23 @@ extern "C" int codeps_guda_gather_bwd(const float* grad_out, int batch, int h, i
     CODEPS_REQUIRE(workspace && workspace_bytes >= codeps_guda_gather_bwd_workspace_bytes(batch, h, bw), CODEPS_ERR_WORKSPACE,
                    "guda_gather_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    {
+        // the fused form: TQ low-resolution rows per block so that (TQ + 1) s + 6 full-resolution rows x 8 columns x 192 bytes fit 48 KB of LDS
+        static const int fused = getenv("CODEPS_GUDA_BWD_FUSED") ? atoi(getenv("CODEPS_GUDA_BWD_FUSED")) : 1;       // A/B switch: 0 = two passes
+        constexpr int TX = 8;
+        const int sy = cdiv(h, bh);
+        const int TQ = std::max(1, std::min(8, 16 / sy));
+        const int max_rows = (TQ + 1) * sy + 6;
+        const size_t lds = (size_t)max_rows * TX * 48 * sizeof(float);
+        const long long tiles = (long long)batch * cdiv(bh, TQ) * cdiv(bw, TX);
+        // (measured at B = 3, 512 x 1024: 1/2 resolution 206 -> 140 us; 1/4: 76 -> 77; 1/8: 49 -> 80 -- the shared rows are 2.1 x the x pass there)
+        if (fused && sy <= 2 && lds <= 48 * 1024 && tiles < (1ll << 31)) {
+            hipLaunchKernelGGL(guda_gather_bwd_fused_kernel<TX>, dim3((unsigned)tiles), dim3(256), lds, st, batch, h, w, bh, bw, (float)bh / (float)h,
+                               (float)bw / (float)w, TQ, cdiv(bw, TX), cdiv(bh, TQ), grad_out, grad_y);
+            CODEPS_CHECK_LAUNCH("guda_gather_bwd_fused_kernel");
+            return CODEPS_OK;
+        }
+    }
     hipLaunchKernelGGL(guda_gather_bwd_x_kernel, dim3((unsigned)(batch * h), std::min(cdiv(bw * 12, 256), 64)), dim3(256), 0, st, batch, h, w, bw,
                        (float)bw / (float)w, grad_out, (float*)workspace);
     hipLaunchKernelGGL(guda_gather_bwd_y_kernel, dim3((unsigned)(batch * bh), std::min(cdiv(bw * 36, 256), 64)), dim3(256), 0, st, batch, h, bh, bw,
